@@ -1,0 +1,218 @@
+/*
+ * merlin_hip.h -- C ABI of libmerlin_hip.so: the MI355X (gfx950) hot path behind the
+ * Merlin Models `mm` Python surface.
+ *
+ * The reference (NVIDIA-Merlin/models) is pure Python over TensorFlow and has NO FFI of its
+ * own: every entry point below replaces the TensorFlow op(s) a reference call site dispatches
+ * to.  Each declaration cites that call site (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - return int32 status: MH_OK (0) or a negative MH_ERR_*; mh_last_error() returns a
+ *     thread-local human-readable message for the last failing call on this thread.
+ *   - every data pointer is a DEVICE pointer owned by the caller (row-major, contiguous unless a
+ *     leading dimension is given); arguments documented as "HOST array" are small host arrays
+ *     (of device pointers / sizes) that are consumed before the call returns.
+ *   - the library allocates no persistent device memory; workspaces are caller-provided and
+ *     sized by the matching mh_*_workspace_bytes() query.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and ordered with respect to that stream only.
+ *   - no exceptions cross the ABI, no torch / C++ types appear in signatures.
+ *   - all floating point data is IEEE fp32; ids are int32 or int64 (MH_I32 / MH_I64).
+ */
+#ifndef MERLIN_HIP_H
+#define MERLIN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_ERR_INVALID_ARGUMENT (-1)
+#define MH_ERR_UNSUPPORTED (-2)
+#define MH_ERR_LAUNCH (-3)
+#define MH_ERR_WORKSPACE (-4)
+
+/* id dtypes */
+#define MH_I32 0
+#define MH_I64 1
+
+/* activations, keras names: linear / relu / sigmoid (blocks/mlp.py:35-139) */
+#define MH_ACT_NONE 0
+#define MH_ACT_RELU 1
+#define MH_ACT_SIGMOID 2
+
+/* sequence combiners (inputs/embedding.py:432-441, 1545-1587) */
+#define MH_COMBINER_SUM 0
+#define MH_COMBINER_MEAN 1
+#define MH_COMBINER_SQRTN 2
+
+/* sparse optimizers for the embedding backward (models/base.py:1121-1174; blocks/optimizer.py) */
+#define MH_OPT_SGD 0
+#define MH_OPT_ADAGRAD 1
+
+/* max features per gather call (pointer tables travel as kernel arguments) */
+#define MH_MAX_FEATURES 64
+
+typedef void* mh_stream_t;
+
+/* ---- library --------------------------------------------------------------------------- */
+int32_t mh_version(void);
+const char* mh_last_error(void);
+/* number of compute units / XCDs of the current device, for grid sizing by callers */
+int32_t mh_device_info(int32_t* cu_count, int64_t* hbm_bytes);
+
+/* ---- a1/a3: categorical embedding lookup ------------------------------------------------
+ * Replaces keras Embedding / tf.gather in EmbeddingTable._call_table
+ * (merlin/models/tf/inputs/embedding.py:424-471, one-hot branch :458-461) and
+ * EmbeddingFeatures.lookup_feature (:1126-1156), for ALL features of a batch in ONE launch.
+ * Feature f reads ids[f][b] (b < B) from table tables[f] ([table_rows[f], D] fp32) and writes
+ *   out[b * out_row_stride + out_slot[f] * D + d]   (d < D)
+ * i.e. directly into the stacked [B, F_total, D] layout StackFeatures would produce
+ * (core/aggregation.py:101-108) when out_row_stride = F_total*D and out_slot = sorted-name rank.
+ * Ids outside [0, table_rows[f]) produce a zero row (TF-GPU gather semantics).
+ * D must be a multiple of 4 and <= 1024; F <= MH_MAX_FEATURES. */
+int32_t mh_embedding_gather_fwd(const float* const* tables /*HOST [F]*/,
+                                const int64_t* table_rows /*HOST [F]*/,
+                                const void* const* ids /*HOST [F] of device ptrs*/,
+                                int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
+                                float* out, int64_t out_row_stride,
+                                const int32_t* out_slot /*HOST [F]*/, mh_stream_t stream);
+
+/* Multi-hot / ragged lookup with a string combiner: replaces
+ * tf.nn.safe_embedding_lookup_sparse(W, sp_ids, None, combiner)
+ * (inputs/embedding.py:432-441, :1131-1139).  CSR input: values[nnz], offsets[B+1] (int32 or
+ * int64, same dtype as values).  Empty bags -> zero row; ids < 0 are pruned (safe_* semantics);
+ * ids >= rows contribute zero but are counted (TF-GPU gather).  mean divides by the number of
+ * kept ids, sqrtn by its sqrt.  nnz = number of entries of values (host-known shape).
+ * out[b * out_row_stride + d]. */
+int32_t mh_embedding_bag_fwd(const float* table, int64_t rows, const void* values, int64_t nnz,
+                             const void* offsets, int32_t ids_dtype, int64_t B, int32_t D,
+                             int32_t combiner, float* out, int64_t out_row_stride,
+                             mh_stream_t stream);
+
+/* Dense fixed-length list [B, L] with a string combiner over axis 1 (mean / sum):
+ * process_str_sequence_combiner (inputs/embedding.py:1556-1587): every position counts
+ * (id 0 is NOT padding-aware). */
+int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void* ids /*[B,L]*/,
+                                    int32_t ids_dtype, int64_t B, int32_t L, int32_t D,
+                                    int32_t combiner, float* out, int64_t out_row_stride,
+                                    mh_stream_t stream);
+
+/* Backward of the one-hot lookup fused with the sparse optimizer step (the IndexedSlices
+ * apply of BaseModel.train_step, models/base.py:1121-1174).  grad[b * grad_row_stride +
+ * grad_slot[f]*D + d] is dL/d out.  Duplicate ids in a batch are summed BEFORE the update
+ * (Keras _deduplicate_indexed_slices semantics).
+ *   SGD:     W[r] -= lr * g[r]
+ *   ADAGRAD: acc[r] += g[r]^2 ; W[r] -= lr * g[r] / (sqrt(acc[r]) + eps)   (keras Adagrad)
+ * state[f] (Adagrad accumulator, same shape as the table) may be NULL for SGD.
+ * workspace: mh_embedding_bwd_workspace_bytes(B, F, D) bytes. */
+int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
+int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
+                                const int64_t* table_rows /*HOST [F]*/,
+                                const void* const* ids /*HOST [F]*/, int32_t ids_dtype,
+                                int64_t B, int32_t F, int32_t D, const float* grad,
+                                int64_t grad_row_stride, const int32_t* grad_slot /*HOST [F]*/,
+                                int32_t optimizer, float lr, float eps, void* workspace,
+                                int64_t workspace_bytes, mh_stream_t stream);
+
+/* ---- a6: Dense layer  y = act(x W + b) -------------------------------------------------
+ * Replaces keras Dense inside _Dense.call (blocks/mlp.py:275-280).  x[M, K] (leading dim ldx),
+ * W[K, N] row-major (the Keras kernel layout), b[N] or NULL, y[M, N] (leading dim ldy).
+ * fp32 in / fp32 accumulate on the f32 MFMA pipe; for N > 4 each output is one k-ascending fmaf
+ * chain (N <= 4 heads use 16 interleaved partial chains + a shuffle tree). */
+int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, const float* b,
+                               int64_t M, int32_t K, int32_t N, int32_t act, float* y,
+                               int64_t ldy, mh_stream_t stream);
+
+/* Backward: given dy (leading dim lddy) and the forward OUTPUT y (for the activation
+ * derivative), computes dz = dy * act'(y) in place of dy (unless act == NONE), then
+ *   dx[M,K] = dz W^T (skipped if dx == NULL), dW[K,N] = x^T dz, db[N] = colsum(dz) (if db).
+ * workspace: mh_linear_bwd_workspace_bytes(M, K, N). */
+int64_t mh_linear_bwd_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, const float* y,
+                               int64_t ldy, float* dy, int64_t lddy, int64_t M, int32_t K,
+                               int32_t N, int32_t act, float* dx, int64_t lddx, float* dW,
+                               float* db, void* workspace, int64_t workspace_bytes,
+                               mh_stream_t stream);
+
+/* ---- a7: DLRM pairwise dot interaction --------------------------------------------------
+ * Replaces tf.matmul(x, x, transpose_b=True) + strict-upper-triangle boolean_mask in
+ * DotProductInteraction.call (blocks/interaction.py:86-116): x[B, F, D] ->
+ * out[b, p(i,j)] = <x[b,i,:], x[b,j,:]> for i < j in row-major order, p = i(2F-i-1)/2 + j-i-1.
+ * When tail != NULL, tail[b, 0:T] is appended after the F(F-1)/2 interaction columns
+ * (the "concat" of the shortcut branch, core/combinators.py:669-693 + aggregation.py:54-66).
+ * out has leading dimension ldo >= F(F-1)/2 + T.   F <= 32, D % 4 == 0, D <= 256. */
+int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D,
+                               const float* tail, int64_t ld_tail, int32_t T, float* out,
+                               int64_t ldo, mh_stream_t stream);
+/* Backward: dx[B,F,D] = (G + G^T) x with G the upper-triangular matrix scattered from
+ * dout[:, :P]; dtail[B,T] = dout[:, P:P+T] (skipped if dtail == NULL). */
+int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, int64_t B,
+                               int32_t F, int32_t D, float* dx, float* dtail, int64_t ld_dtail,
+                               int32_t T, mh_stream_t stream);
+
+/* ---- a9: DCN-v2 cross layer  out = x0 * (x W + b) + x ----------------------------------
+ * Replaces Cross.call (blocks/cross.py:188-202) with a full-rank kernel W[d, d]
+ * (DenseMaybeLowRank, blocks/mlp.py:304-396, low_rank_dim=None). x0, x, out: [M, d]. */
+int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, const float* b,
+                           int64_t M, int32_t d, float* out, mh_stream_t stream);
+
+/* ---- a10: L2 row normalisation (transforms/regularization.py:26-80) --------------------
+ * y = x / max(||x||_2, eps) per row  == tf.linalg.l2_normalize(x, axis=-1, epsilon=eps^2). */
+int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y,
+                       mh_stream_t stream);
+
+/* ---- a11-a13: in-batch sampled-softmax scorer ------------------------------------------
+ * Replaces ItemRetrievalScorer.call_outputs (blocks/retrieval/base.py:283-429) /
+ * ContrastiveOutput.outputs (outputs/contrastive.py:276-344) + rescore_false_negatives
+ * (utils/tf_utils.py:126-154) + LogitsTemperatureScaler (transforms/bias.py:65-68) +
+ * CategoricalCrossEntropy(from_logits=True) (losses/listwise.py:38-52).
+ *   pos[b]    = <q[b], item[b]>
+ *   neg[b, j] = <q[b], neg_item[j]>, replaced by false_neg_score where pos_ids[b]==neg_ids[j]
+ *               (skipped when pos_ids == NULL: downscore_false_negatives=False)
+ *   logits[b] = [pos[b], neg[b, 0..Nn)] / temperature                     (fp32, [B, 1+Nn])
+ *   loss[b]   = logsumexp(logits[b]) - logits[b, 0];  lse[b] = logsumexp(logits[b])
+ * logits may be NULL (fused mode: nothing of size B*Nn is written); loss / lse may be NULL.
+ * q, item: [B, E]; neg_item: [Nn, E] (pass item and Nn = B for in-batch negatives).
+ * ids int32 or int64.  E % 4 == 0, E <= 512. */
+int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* neg_item,
+                               const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
+                               int64_t B, int64_t Nn, int32_t E, float temperature,
+                               float false_neg_score, float* logits, int64_t ld_logits,
+                               float* loss, float* lse, mh_stream_t stream);
+
+/* Backward of mean_b(loss[b]) * grad_scale w.r.t. q, item (positive role) and neg_item:
+ * recomputes the logits tile by tile from (q, neg_item, lse) -- nothing of size B*Nn is read
+ * or written.  dneg_item accumulates (caller zero-fills, may alias ditem for in-batch). */
+int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* neg_item,
+                               const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
+                               int64_t B, int64_t Nn, int32_t E, float temperature,
+                               float false_neg_score, const float* lse, float grad_scale,
+                               float* dq, float* ditem, float* dneg_item, mh_stream_t stream);
+
+/* ---- a14: brute-force top-k retrieval ----------------------------------------------------
+ * Replaces BruteForce.call (outputs/topk.py:182-237): scores = q C^T (:113-115),
+ * tf.math.top_k(scores, k) (values descending, ties -> lower candidate index first),
+ * tf.gather(ids, idx).  q[Bq, E], cand[N, E] fp32, cand_ids[N] int32 (NULL -> index itself).
+ * Each score is a k-ascending fp32 fmaf chain (bit-reproducible by oracle/oracle_c.c).
+ * out_scores[Bq, k] fp32, out_ids[Bq, k] int32, out_idx[Bq, k] int32 (may be NULL).
+ * k <= 1024, k <= N.  workspace: mh_topk_workspace_bytes(Bq, N, k). */
+int64_t mh_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k);
+int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, int64_t Bq,
+                    int64_t N, int32_t E, int32_t k, float* out_scores, int32_t* out_ids,
+                    int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                    mh_stream_t stream);
+
+/* ---- BinaryOutput head loss (outputs/classification.py:72-123): BCE on probabilities ----
+ * p[M] = sigmoid output of the head, label[M] in {0,1}: loss[m] = keras binary_crossentropy
+ * (clip p to [1e-7, 1-1e-7]); dlogit[m] = (p - label) * grad_scale (gradient w.r.t. the
+ * pre-sigmoid logit).  Either output may be NULL. */
+int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale,
+                       float* loss, float* dlogit, mh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERLIN_HIP_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libmerlin_hip.so -- the C ABI declared in include/merlin_hip.h.
+
+There is NO CPU fallback: if the shared object is missing and cannot be built, importing the
+ops raises.  PyTorch tensors are only buffer carriers (``tensor.data_ptr()``), the stream is
+``torch.cuda.current_stream().cuda_stream``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import shutil
+from pathlib import Path
+
+from . import build as _build
+
+MH_OK = 0
+MH_I32, MH_I64 = 0, 1
+ACT = {"linear": 0, None: 0, "none": 0, "relu": 1, "sigmoid": 2}
+COMBINER = {"sum": 0, "mean": 1, "sqrtn": 2}
+OPT = {"sgd": 0, "adagrad": 1}
+MAX_FEATURES = 64
+
+_p = C.c_void_p
+_i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/merlin_hip.h
+SIGNATURES = {
+    "mh_version": (_i32, []),
+    "mh_last_error": (C.c_char_p, []),
+    "mh_device_info": (_i32, [C.POINTER(_i32), C.POINTER(_i64)]),
+    "mh_embedding_gather_fwd": (_i32, [_p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _p]),
+    "mh_embedding_bag_fwd": (_i32, [_p, _i64, _p, _i64, _p, _i32, _i64, _i32, _i32, _p, _i64, _p]),
+    "mh_embedding_dense_list_fwd": (_i32, [_p, _i64, _p, _i32, _i64, _i32, _i32, _i32, _p, _i64, _p]),
+    "mh_embedding_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "mh_embedding_gather_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _i64, _p]),
+    "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
+    "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "mh_linear_bias_act_bwd": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
+    "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _i64, _i32, _p]),
+    "mh_cross_layer_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "mh_l2norm_rows": (_i32, [_p, _i64, _i32, _f32, _p, _p]),
+    "mh_inbatch_softmax_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _i64, _p, _p, _p]),
+    "mh_inbatch_softmax_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _f32, _p, _p, _p, _p]),
+    "mh_topk_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "mh_topk_dot": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
+    "mh_bce_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p]),
+}
+
+_LIB = None
+
+
+class MerlinHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _build.LIB
+
+
+def load() -> C.CDLL:
+    """Load (building first if the in-tree .so is absent or stale and hipcc is available)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if _build.needs_build():
+        if shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists():
+            _build.build()
+        elif not path.exists():
+            raise MerlinHipError(
+                f"{path} is missing and hipcc is not available: the HIP hot path cannot run "
+                "(there is no CPU fallback). Run `python -m models_amd.build` on a ROCm box."
+            )
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != MH_OK:
+        msg = load().mh_last_error().decode("utf-8", "replace")
+        raise MerlinHipError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,77 @@
+"""Build libmerlin_hip.so (gfx950) with hipcc, in-tree.
+
+The shared object lands next to the sources (``models_amd/csrc/libmerlin_hip.so``): it is
+git-ignored but travels to the GPU box with the repository snapshot.  hipcc cross-compiles
+without a GPU, so this runs in the authoring container as the "does it build" check.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libmerlin_hip.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: cannot build libmerlin_hip.so")
+    return exe
+
+
+def sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _deps() -> list[Path]:
+    return sources() + sorted(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "merlin_hip.h"]
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in _deps())
+
+
+def _compile(src: Path, verbose: bool) -> Path:
+    obj = src.with_suffix(".o")
+    hdr_t = max(p.stat().st_mtime for p in _deps() if p.suffix == ".h")
+    if obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
+        return obj
+    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every ``csrc/*.hip`` for gfx950 and link ``libmerlin_hip.so``."""
+    if not force and not needs_build():
+        return LIB
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,39 @@
+// Internal helpers shared by the HIP translation units of libmerlin_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/merlin_hip.h"
+
+#define MH_WAVE 64
+
+void mh_set_error(const char* fmt, ...);
+
+#define MH_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            mh_set_error(__VA_ARGS__);        \
+            return MH_ERR_INVALID_ARGUMENT;   \
+        }                                     \
+    } while (0)
+
+#define MH_CHECK_LAUNCH(name)                                                       \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            mh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));     \
+            return MH_ERR_LAUNCH;                                                   \
+        }                                                                           \
+    } while (0)
+
+static inline hipStream_t mh_stream(mh_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t mh_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Number of workgroups that fill the chip a few times over for grid-stride kernels.
+int mh_num_cus();

@@ -1,0 +1,255 @@
+// Categorical embedding lookup kernels for gfx950 (HBM-bound).
+//
+// Reference semantics: EmbeddingTable._call_table (merlin/models/tf/inputs/embedding.py:424-471),
+// EmbeddingFeatures.lookup_feature (:1126-1156), process_str_sequence_combiner (:1556-1587).
+//
+// Data layout: a table is [rows, D] fp32 row-major; one embedding row is D*4 bytes, moved as
+// D/4 16-byte lanes ("LPR" = lanes per row).  A 64-wide wavefront therefore moves 64/LPR whole
+// rows per vector-memory instruction (4 rows of 256 B at D=64), each row a contiguous,
+// 16-B-aligned segment -- the widest coalescing a random-row gather admits.  Every thread keeps
+// R independent row loads in flight before the first store so that a CU has
+// 256 threads x R x 16 B = 32 KiB outstanding per workgroup, enough to cover HBM latency.
+//
+// Algorithmic bytes: per looked-up row  D*4 read + D*4 write + id bytes.
+#include "mh_common.h"
+
+namespace {
+
+struct GatherArgs {
+    const float* table[MH_MAX_FEATURES];
+    const void* ids[MH_MAX_FEATURES];
+    int64_t rows[MH_MAX_FEATURES];
+    int32_t slot[MH_MAX_FEATURES];
+};
+
+// grid.x = sample tiles, grid.y = feature.  block = 256 threads = (256/LPR) rows x LPR lanes.
+template <typename IdT, int R>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const GatherArgs args, int64_t B, int LPR,
+                                                        float* __restrict__ out,
+                                                        int64_t out_row_stride) {
+    const int f = blockIdx.y;
+    const float* __restrict__ table = args.table[f];
+    const IdT* __restrict__ ids = static_cast<const IdT*>(args.ids[f]);
+    const int64_t rows = args.rows[f];
+    const int rows_per_pass = 256 / LPR;
+    const int t = threadIdx.x;
+    const int r_in = t / LPR;
+    const int c = t - r_in * LPR;
+    if (r_in >= rows_per_pass) return;
+    const int64_t b0 = (int64_t)blockIdx.x * (rows_per_pass * R) + r_in;
+    float* __restrict__ obase = out + (int64_t)args.slot[f] * (LPR * 4) + c * 4;
+
+    int64_t id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t b = b0 + (int64_t)r * rows_per_pass;
+        id[r] = (b < B) ? (int64_t)ids[b] : -1;
+    }
+    f32x4 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool ok = (id[r] >= 0) && (id[r] < rows);
+        v[r] = ok ? *reinterpret_cast<const f32x4*>(table + id[r] * (int64_t)(LPR * 4) + c * 4)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t b = b0 + (int64_t)r * rows_per_pass;
+        if (b < B) *reinterpret_cast<f32x4*>(obase + b * out_row_stride) = v[r];
+    }
+}
+
+// Bag (multi-hot) lookup.  COOP=false: one LPR-lane group per bag, sequential accumulate
+// (4 independent row loads in flight).  COOP=true (LPR power of two <= 32): the 64/LPR groups
+// of a wavefront split one bag round-robin and combine with wavefront shuffles -- the
+// segmented reduce of the north star; no LDS round trip is needed because a row never spans
+// more than one wavefront.
+//   offsets == nullptr  -> dense list of fixed length L (bag b = [b*L, (b+1)*L)), negatives
+//                          are not pruned (tf.gather semantics, zero row, still counted).
+template <typename IdT, bool COOP>
+__global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ table, int64_t rows,
+                                                     const IdT* __restrict__ values,
+                                                     const IdT* __restrict__ offsets, int64_t L,
+                                                     int64_t B, int LPR, int combiner,
+                                                     float* __restrict__ out,
+                                                     int64_t out_row_stride) {
+    const int t = threadIdx.x;
+    const bool prune_neg = (offsets != nullptr);
+    int64_t bag;
+    int c, g, G;
+    if (COOP) {
+        const int wave = t >> 6, lane = t & 63;
+        G = 64 / LPR;
+        g = lane / LPR;
+        c = lane - g * LPR;
+        bag = (int64_t)blockIdx.x * 4 + wave;
+    } else {
+        const int groups = 256 / LPR;
+        const int r_in = t / LPR;
+        c = t - r_in * LPR;
+        g = 0;
+        G = 1;
+        bag = (r_in < groups) ? (int64_t)blockIdx.x * groups + r_in : B;
+    }
+    if (bag >= B) {
+        if (!COOP) return;
+        // COOP: whole wave shares the bag, so the whole wave exits together.
+        return;
+    }
+    const int64_t beg = offsets ? (int64_t)offsets[bag] : bag * L;
+    const int64_t end = offsets ? (int64_t)offsets[bag + 1] : beg + L;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    const int64_t stride = (int64_t)LPR * 4;
+    int64_t p = beg + g;
+    // 4 independent loads per trip
+    for (; p + 3 * G < end; p += 4 * G) {
+        int64_t i0 = values[p], i1 = values[p + G], i2 = values[p + 2 * G], i3 = values[p + 3 * G];
+        const bool k0 = !(prune_neg && i0 < 0), k1 = !(prune_neg && i1 < 0),
+                   k2 = !(prune_neg && i2 < 0), k3 = !(prune_neg && i3 < 0);
+        const bool o0 = i0 >= 0 && i0 < rows, o1 = i1 >= 0 && i1 < rows, o2 = i2 >= 0 && i2 < rows,
+                   o3 = i3 >= 0 && i3 < rows;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v0 = o0 ? *reinterpret_cast<const f32x4*>(table + i0 * stride + c * 4) : z;
+        f32x4 v1 = o1 ? *reinterpret_cast<const f32x4*>(table + i1 * stride + c * 4) : z;
+        f32x4 v2 = o2 ? *reinterpret_cast<const f32x4*>(table + i2 * stride + c * 4) : z;
+        f32x4 v3 = o3 ? *reinterpret_cast<const f32x4*>(table + i3 * stride + c * 4) : z;
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+        cnt += (int)k0 + (int)k1 + (int)k2 + (int)k3;
+    }
+    for (; p < end; p += G) {
+        int64_t i0 = values[p];
+        const bool k0 = !(prune_neg && i0 < 0);
+        const bool o0 = i0 >= 0 && i0 < rows;
+        if (o0) acc += *reinterpret_cast<const f32x4*>(table + i0 * stride + c * 4);
+        cnt += (int)k0;
+    }
+    if (COOP) {
+        for (int off = LPR; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off);
+            acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off);
+            acc.w += __shfl_xor(acc.w, off);
+            cnt += __shfl_xor(cnt, off);
+        }
+        if (g != 0) return;
+    }
+    if (cnt > 0) {
+        if (combiner == MH_COMBINER_MEAN) {
+            const float n = (float)cnt;
+            acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n;
+        } else if (combiner == MH_COMBINER_SQRTN) {
+            const float n = sqrtf((float)cnt);
+            acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n;
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + bag * out_row_stride + c * 4) = acc;
+}
+
+template <typename IdT>
+int launch_bag(const float* table, int64_t rows, const void* values, const void* offsets,
+               int64_t L, int64_t nnz_hint, int64_t B, int D, int combiner, float* out,
+               int64_t out_row_stride, hipStream_t s) {
+    const int LPR = D / 4;
+    const bool pow2 = (LPR & (LPR - 1)) == 0;
+    const bool coop = pow2 && LPR <= 32 && nnz_hint >= 8 * B;
+    if (coop) {
+        dim3 grid((unsigned)mh_ceil_div(B, 4));
+        hipLaunchKernelGGL((bag_fwd_kernel<IdT, true>), grid, dim3(256), 0, s, table, rows,
+                           (const IdT*)values, (const IdT*)offsets, L, B, LPR, combiner, out,
+                           out_row_stride);
+    } else {
+        const int groups = 256 / LPR;
+        dim3 grid((unsigned)mh_ceil_div(B, groups));
+        hipLaunchKernelGGL((bag_fwd_kernel<IdT, false>), grid, dim3(256), 0, s, table, rows,
+                           (const IdT*)values, (const IdT*)offsets, L, B, LPR, combiner, out,
+                           out_row_stride);
+    }
+    return MH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mh_embedding_gather_fwd(const float* const* tables, const int64_t* table_rows,
+                                const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F,
+                                int32_t D, float* out, int64_t out_row_stride,
+                                const int32_t* out_slot, mh_stream_t stream) {
+    MH_REQUIRE(tables && table_rows && ids && out && out_slot, "mh_embedding_gather_fwd: null argument");
+    MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_embedding_gather_fwd: F=%d outside [1,%d]", F,
+               MH_MAX_FEATURES);
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_fwd: D=%d must be a multiple of 4 in [4,1024]", D);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_gather_fwd: bad ids_dtype %d", ids_dtype);
+    MH_REQUIRE(B >= 0, "mh_embedding_gather_fwd: negative batch");
+    MH_REQUIRE(out_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               "mh_embedding_gather_fwd: out must be 16-byte aligned with out_row_stride %% 4 == 0");
+    if (B == 0) return MH_OK;
+    GatherArgs a;
+    for (int f = 0; f < F; ++f) {
+        MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_fwd: null table/ids for feature %d", f);
+        MH_REQUIRE((reinterpret_cast<uintptr_t>(tables[f]) & 15) == 0, "mh_embedding_gather_fwd: table %d not 16-byte aligned", f);
+        MH_REQUIRE((int64_t)(out_slot[f] + 1) * D <= out_row_stride, "mh_embedding_gather_fwd: slot %d of feature %d exceeds out_row_stride", out_slot[f], f);
+        a.table[f] = tables[f];
+        a.ids[f] = ids[f];
+        a.rows[f] = table_rows[f];
+        a.slot[f] = out_slot[f];
+    }
+    const int LPR = D / 4;
+    constexpr int R = 8;
+    const int rows_per_block = (256 / LPR) * R;
+    dim3 grid((unsigned)mh_ceil_div(B, rows_per_block), (unsigned)F);
+    hipStream_t s = mh_stream(stream);
+    if (ids_dtype == MH_I32)
+        hipLaunchKernelGGL((gather_fwd_kernel<int32_t, R>), grid, dim3(256), 0, s, a, B, LPR, out, out_row_stride);
+    else
+        hipLaunchKernelGGL((gather_fwd_kernel<int64_t, R>), grid, dim3(256), 0, s, a, B, LPR, out, out_row_stride);
+    MH_CHECK_LAUNCH("mh_embedding_gather_fwd");
+    return MH_OK;
+}
+
+int32_t mh_embedding_bag_fwd(const float* table, int64_t rows, const void* values, int64_t nnz,
+                             const void* offsets, int32_t ids_dtype, int64_t B, int32_t D,
+                             int32_t combiner, float* out, int64_t out_row_stride,
+                             mh_stream_t stream) {
+    MH_REQUIRE(table && offsets && out, "mh_embedding_bag_fwd: null argument");
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_bag_fwd: D=%d must be a multiple of 4 in [4,1024]", D);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_bag_fwd: bad ids_dtype %d", ids_dtype);
+    MH_REQUIRE(combiner >= MH_COMBINER_SUM && combiner <= MH_COMBINER_SQRTN, "mh_embedding_bag_fwd: bad combiner %d", combiner);
+    MH_REQUIRE(out_row_stride % 4 == 0 && out_row_stride >= D, "mh_embedding_bag_fwd: bad out_row_stride");
+    if (B <= 0) return MH_OK;
+    hipStream_t s = mh_stream(stream);
+    MH_REQUIRE(nnz == 0 || values, "mh_embedding_bag_fwd: null values");
+    const int64_t nnz_hint = nnz;  // long bags (>= 8 ids on average) take the wave-cooperative kernel
+    if (ids_dtype == MH_I32)
+        launch_bag<int32_t>(table, rows, values, offsets, 0, nnz_hint, B, D, combiner, out, out_row_stride, s);
+    else
+        launch_bag<int64_t>(table, rows, values, offsets, 0, nnz_hint, B, D, combiner, out, out_row_stride, s);
+    MH_CHECK_LAUNCH("mh_embedding_bag_fwd");
+    return MH_OK;
+}
+
+int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void* ids,
+                                    int32_t ids_dtype, int64_t B, int32_t L, int32_t D,
+                                    int32_t combiner, float* out, int64_t out_row_stride,
+                                    mh_stream_t stream) {
+    MH_REQUIRE(table && ids && out, "mh_embedding_dense_list_fwd: null argument");
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_dense_list_fwd: D=%d must be a multiple of 4 in [4,1024]", D);
+    MH_REQUIRE(L >= 1, "mh_embedding_dense_list_fwd: L must be >= 1");
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_dense_list_fwd: bad ids_dtype %d", ids_dtype);
+    MH_REQUIRE(combiner == MH_COMBINER_SUM || combiner == MH_COMBINER_MEAN, "mh_embedding_dense_list_fwd: combiner must be sum or mean");
+    MH_REQUIRE(out_row_stride % 4 == 0 && out_row_stride >= D, "mh_embedding_dense_list_fwd: bad out_row_stride");
+    if (B <= 0) return MH_OK;
+    hipStream_t s = mh_stream(stream);
+    if (ids_dtype == MH_I32)
+        launch_bag<int32_t>(table, rows, ids, nullptr, L, (int64_t)L * B, B, D, combiner, out, out_row_stride, s);
+    else
+        launch_bag<int64_t>(table, rows, ids, nullptr, L, (int64_t)L * B, B, D, combiner, out, out_row_stride, s);
+    MH_CHECK_LAUNCH("mh_embedding_dense_list_fwd");
+    return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// DLRM pairwise dot interaction for gfx950.
+// Reference: DotProductInteraction.call (merlin/models/tf/blocks/interaction.py:86-116):
+//   Z = X X^T per sample, keep the strict upper triangle in row-major (i<j) order, then the
+//   "concat" aggregation with the shortcut branch (core/combinators.py:669-693,
+//   core/aggregation.py:54-66) -> out = [interactions | bottom_mlp_out].
+//
+// One wavefront owns one sample at a time.  X[F<=32, D] is staged in LDS ([32][D+4] fp32, rows
+// >= F zero) and Z is formed on the matrix pipe with v_mfma_f32_16x16x4_f32: only the three
+// 16x16 tiles that intersect the upper triangle are computed -- (0,0), (0,1), (1,1) -- and A == B
+// for X X^T, so one LDS fragment feeds both operands.  The four k-slots of the instruction take
+// the four contiguous quarter-rows [q*D/4, (q+1)*D/4) (the contraction order is
+// s, D/4+s, D/2+s, 3D/4+s for s = 0..D/4-1; documented so the oracle can restate it).
+// HBM-bound: algorithmic bytes/sample = F*D*4 + (F(F-1)/2 + T)*4 (+ T*4 tail read).
+#include "mh_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int IMAXF = 32;
+
+__device__ __forceinline__ void store_tile(const f32x4& acc, int ti, int tj, int lane, int F,
+                                           float* __restrict__ orow) {
+    const int j = 16 * tj + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + (lane >> 4) * 4 + r;
+        if (i < j && j < F) orow[i * (2 * F - i - 1) / 2 + (j - i - 1)] = acc[r];
+    }
+}
+
+// block = 256 threads = 4 wavefronts, each with a private [32][LD] LDS slab.
+__global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* __restrict__ x, int64_t B,
+                                                                 int F, int D,
+                                                                 const float* __restrict__ tail,
+                                                                 int64_t ld_tail, int T,
+                                                                 float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = D + 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Xs = smem + wave * IMAXF * LD;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int P = F * (F - 1) / 2;
+    const int vpr = D / 4;            // float4 per row
+    const int nvec = F * vpr;         // float4 per sample
+    const int qoff = q * (D / 4);
+    const int steps = D / 4;          // MFMA steps (each consumes 4 k)
+
+    // zero the padding rows once (rows F..31 are never rewritten)
+    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+
+    const int64_t nblk_samples = (B + 3) / 4;
+    for (int64_t it = blockIdx.x; it < nblk_samples; it += gridDim.x) {
+        const int64_t b = it * 4 + wave;
+        const bool live = b < B;
+        __syncthreads();  // previous iteration's fragment reads are done
+        if (live) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + b * (int64_t)F * D);
+            for (int idx = lane; idx < nvec; idx += 64) {
+                const int r = idx / vpr, c4 = idx - r * vpr;
+                *reinterpret_cast<f32x4*>(Xs + r * LD + c4 * 4) = src[idx];
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
+        f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
+        const float* r0 = Xs + i16 * LD + qoff;
+        const float* r1 = Xs + (16 + i16) * LD + qoff;
+        const bool two = F > 16;
+        int s = 0;
+        for (; s + 3 < steps; s += 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0 + s);
+            if (two) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(r1 + s);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc00 = mfma16(a0[j], a0[j], acc00);
+                    acc01 = mfma16(a0[j], a1[j], acc01);
+                    acc11 = mfma16(a1[j], a1[j], acc11);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc00 = mfma16(a0[j], a0[j], acc00);
+            }
+        }
+        for (; s < steps; ++s) {
+            const float a0 = r0[s];
+            acc00 = mfma16(a0, a0, acc00);
+            if (two) {
+                const float a1 = r1[s];
+                acc01 = mfma16(a0, a1, acc01);
+                acc11 = mfma16(a1, a1, acc11);
+            }
+        }
+        float* orow = out + b * ldo;
+        store_tile(acc00, 0, 0, lane, F, orow);
+        if (two) {
+            store_tile(acc01, 0, 1, lane, F, orow);
+            store_tile(acc11, 1, 1, lane, F, orow);
+        }
+        if (tail) {
+            const float* trow = tail + b * ld_tail;
+            for (int t = lane; t < T; t += 64) orow[P + t] = trow[t];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, const float* tail,
+                               int64_t ld_tail, int32_t T, float* out, int64_t ldo,
+                               mh_stream_t stream) {
+    MH_REQUIRE(x && out, "mh_dot_interaction_fwd: null argument");
+    MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dot_interaction_fwd: F=%d outside [2,%d]", F, IMAXF);
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 256, "mh_dot_interaction_fwd: D=%d must be a multiple of 4 in [4,256]", D);
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "mh_dot_interaction_fwd: x must be 16-byte aligned");
+    const int P = F * (F - 1) / 2;
+    if (!tail) T = 0;
+    MH_REQUIRE(T >= 0 && ldo >= P + T, "mh_dot_interaction_fwd: ldo=%lld < %d", (long long)ldo, P + T);
+    MH_REQUIRE(!tail || ld_tail >= T, "mh_dot_interaction_fwd: ld_tail < T");
+    if (B <= 0) return MH_OK;
+    const size_t lds = (size_t)4 * IMAXF * (D + 4) * sizeof(float);
+    const int64_t want = mh_ceil_div(B, 4);
+    const int64_t cap = (int64_t)mh_num_cus() * 8;
+    dim3 grid((unsigned)(want < cap ? want : cap));
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dot_interaction_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            mh_set_error("mh_dot_interaction_fwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return MH_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
+                       tail, ld_tail, T, out, ldo);
+    MH_CHECK_LAUNCH("mh_dot_interaction_fwd");
+    return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// Dense layer y = act(x W + b) on the fp32 MFMA pipe (gfx950).
+// Reference: _Dense.call -> keras Dense (merlin/models/tf/blocks/mlp.py:275-280), MLPBlock (:35-139).
+//
+// Shapes on this path are tall-and-skinny (M = batch = 64 K rows, N <= 512, K <= 3341): the
+// workgroup tile is 128 rows x {128,64,32} columns, W streams through LDS k-tile by k-tile
+// (it is L2-resident: <= 212 KB on the DLRM config), x is read exactly once, y written once.
+// Roofline: bytes = 4(MK + KN + MN), flops = 2MKN; layers with K,N >= 128 sit above the fp32
+// ridge (157 TF / 8 TB/s ~ 20 flop/B), K = 13 / N <= 64 layers are HBM-bound.
+#include "mh_gemm_core.h"
+
+using namespace mhgemm;
+
+namespace {
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == MH_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MH_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ W,
+                                                        const float* __restrict__ bias, int64_t M,
+                                                        int K, int N, int act, float* __restrict__ y,
+                                                        int64_t ldy, int vec_x, int vec_w) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BK * BN];
+    float* As0 = smem;
+    float* As1 = smem + BM * LDK;
+    float* Bs0 = smem + 2 * BM * LDK;
+    float* Bs1 = Bs0 + BK * BN;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    KMajorTile<BM> ta;
+    NMajorTile<BN> tb;
+    f32x16 acc[TM][TN];
+    zero_acc<TM, TN>(acc);
+
+    const int nk = (K + BK - 1) / BK;
+    ta.load(x, ldx, row0, M, 0, K, vec_x);
+    tb.load(W, N, 0, K, n0, N, vec_w);
+    ta.store(As0);
+    tb.store(Bs0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        float* Ac = (kt & 1) ? As1 : As0;
+        float* Bc = (kt & 1) ? Bs1 : Bs0;
+        float* An = (kt & 1) ? As0 : As1;
+        float* Bn = (kt & 1) ? Bs0 : Bs1;
+        if (more) {
+            ta.load(x, ldx, row0, M, (kt + 1) * BK, K, vec_x);
+            tb.load(W, N, (kt + 1) * BK, K, n0, N, vec_w);
+        }
+        mma_ktile<TM, TN, false>(Ac, wm * TM * 32, Bc, wn * TN * 32, BN, acc);
+        if (more) {
+            ta.store(An);
+            tb.store(Bn);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + acc_col(lane);
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
+                if (row < M) y[row * ldy + col] = apply_act(acc[tm][tn][r] + bv, act);
+            }
+        }
+    }
+}
+
+// N <= 4 heads (e.g. BinaryOutput's Dense(1, sigmoid), outputs/classification.py:114):
+// HBM-bound GEMV, 16 lanes per row, k-ascending per-lane partial chains + shuffle tree.
+template <int NMAX>
+__global__ __launch_bounds__(256) void linear_small_n_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int64_t M,
+                                                            int K, int N, int act, float* __restrict__ y,
+                                                            int64_t ldy) {
+    const int t = threadIdx.x;
+    const int sub = t & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (t >> 4);
+    float acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+    if (row < M) {
+        const float* xr = x + row * ldx;
+        for (int k = sub; k < K; k += 16) {
+            const float xv = xr[k];
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n)
+                if (n < N) acc[n] = fmaf(xv, W[(int64_t)k * N + n], acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) acc[n] += __shfl_xor(acc[n], off);
+    }
+    if (row < M && sub == 0) {
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n)
+            if (n < N) y[row * ldy + n] = apply_act(acc[n] + (bias ? bias[n] : 0.f), act);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, const float* b,
+                               int64_t M, int32_t K, int32_t N, int32_t act, float* y,
+                               int64_t ldy, mh_stream_t stream) {
+    MH_REQUIRE(x && W && y, "mh_linear_bias_act_fwd: null argument");
+    MH_REQUIRE(M >= 0 && K >= 1 && N >= 1, "mh_linear_bias_act_fwd: bad shape M=%lld K=%d N=%d", (long long)M, K, N);
+    MH_REQUIRE(ldx >= K && ldy >= N, "mh_linear_bias_act_fwd: leading dimension smaller than row");
+    MH_REQUIRE(act >= MH_ACT_NONE && act <= MH_ACT_SIGMOID, "mh_linear_bias_act_fwd: bad activation %d", act);
+    if (M == 0) return MH_OK;
+    hipStream_t s = mh_stream(stream);
+    if (N <= 4) {
+        dim3 grid((unsigned)mh_ceil_div(M, 16));
+        hipLaunchKernelGGL((linear_small_n_kernel<4>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy);
+        MH_CHECK_LAUNCH("mh_linear_bias_act_fwd");
+        return MH_OK;
+    }
+    const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
+    const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
+    if (N > 64) {
+        dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(N, 128));
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w);
+    } else if (N > 32) {
+        dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w);
+    } else {
+        dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w);
+    }
+    MH_CHECK_LAUNCH("mh_linear_bias_act_fwd");
+    return MH_OK;
+}
+
+}  // extern "C"

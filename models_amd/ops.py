@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the C ABI (include/merlin_hip.h).
+
+Every function takes PyTorch-ROCm device tensors purely as buffer carriers, validates shape /
+dtype / contiguity, and launches the HIP kernel on the current torch stream.  CPU tensors are
+rejected: the product path has no CPU fallback (the CPU restatement lives in ``oracle/`` and is
+test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT, COMBINER, MH_I32, MH_I64, check
+
+__all__ = [
+    "embedding_gather",
+    "embedding_bag",
+    "embedding_dense_list",
+    "linear",
+    "dot_interaction",
+]
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise _lib.MerlinHipError(
+            f"{name} is a CPU tensor: models_amd ops only run on a HIP device (no CPU fallback)"
+        )
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _ids_dtype(t: torch.Tensor, name: str) -> int:
+    if t.dtype == torch.int32:
+        return MH_I32
+    if t.dtype == torch.int64:
+        return MH_I64
+    raise TypeError(f"{name} must be int32 or int64, got {t.dtype}")
+
+
+def _host_ptr_array(vals: Sequence[int]):
+    arr = (C.c_void_p * len(vals))(*vals)
+    return arr
+
+
+# --------------------------------------------------------------------------------------------
+# embeddings
+# --------------------------------------------------------------------------------------------
+def embedding_gather(
+    tables: Sequence[torch.Tensor],
+    ids: Sequence[torch.Tensor],
+    out: Optional[torch.Tensor] = None,
+    out_slot: Optional[Sequence[int]] = None,
+    n_slots: Optional[int] = None,
+) -> torch.Tensor:
+    """One-hot lookup of F features in one launch -> stacked ``[B, n_slots, D]``.
+
+    ``tables[f]`` is ``[V_f, D]`` fp32, ``ids[f]`` is ``[B]`` or ``[B, 1]`` int32/int64.  Feature f
+    lands in slot ``out_slot[f]`` (default f) of the stacked output -- the layout
+    ``StackFeatures`` produces in the reference (core/aggregation.py:101-108).
+    """
+    lib = _lib.load()
+    F = len(tables)
+    if F == 0 or F != len(ids):
+        raise ValueError("embedding_gather: need one ids tensor per table")
+    D = tables[0].shape[1]
+    B = ids[0].shape[0]
+    idt = _ids_dtype(ids[0], "ids[0]")
+    flat_ids = []
+    for f, (w, i) in enumerate(zip(tables, ids)):
+        _dev(w, f"tables[{f}]", torch.float32)
+        _dev(i, f"ids[{f}]")
+        if w.dim() != 2 or w.shape[1] != D or not w.is_contiguous():
+            raise ValueError(f"tables[{f}] must be contiguous [V, {D}]")
+        if _ids_dtype(i, f"ids[{f}]") != idt:
+            raise TypeError("embedding_gather: all ids must share one dtype")
+        i = i.reshape(-1)
+        if i.shape[0] != B or not i.is_contiguous():
+            raise ValueError(f"ids[{f}] must be contiguous with {B} entries")
+        flat_ids.append(i)
+    slots = list(range(F)) if out_slot is None else [int(s) for s in out_slot]
+    if n_slots is None:
+        n_slots = (max(slots) + 1) if out is None else out.shape[1]
+    if out is None:
+        out = torch.empty((B, n_slots, D), dtype=torch.float32, device=tables[0].device)
+    else:
+        _dev(out, "out", torch.float32)
+        if out.dim() != 3 or out.shape[0] != B or out.shape[2] != D or not out.is_contiguous():
+            raise ValueError("out must be contiguous [B, n_slots, D]")
+    row_stride = out.shape[1] * D
+    for start in range(0, F, _lib.MAX_FEATURES):
+        sl = slice(start, min(F, start + _lib.MAX_FEATURES))
+        n = sl.stop - sl.start
+        tab = _host_ptr_array([w.data_ptr() for w in tables[sl]])
+        idp = _host_ptr_array([i.data_ptr() for i in flat_ids[sl]])
+        rows = (C.c_int64 * n)(*[w.shape[0] for w in tables[sl]])
+        slot = (C.c_int32 * n)(*slots[sl])
+        check(
+            lib.mh_embedding_gather_fwd(tab, rows, idp, idt, B, n, D, _ptr(out), row_stride, slot, _stream()),
+            "mh_embedding_gather_fwd",
+        )
+    return out
+
+
+def embedding_bag(
+    table: torch.Tensor, values: torch.Tensor, offsets: torch.Tensor, combiner: str = "mean",
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Ragged multi-hot lookup (CSR ``values``/``offsets``) with a sum/mean/sqrtn combiner."""
+    lib = _lib.load()
+    _dev(table, "table", torch.float32)
+    _dev(values, "values")
+    _dev(offsets, "offsets")
+    idt = _ids_dtype(values, "values")
+    if offsets.dtype != values.dtype:
+        raise TypeError("offsets and values must share one integer dtype")
+    if combiner not in COMBINER:
+        raise ValueError(f"combiner must be one of {sorted(COMBINER)}, got {combiner!r}")
+    B = offsets.shape[0] - 1
+    D = table.shape[1]
+    values = values.reshape(-1).contiguous()
+    offsets = offsets.reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty((B, D), dtype=torch.float32, device=table.device)
+    check(
+        lib.mh_embedding_bag_fwd(_ptr(table), table.shape[0], _ptr(values), values.shape[0], _ptr(offsets),
+                                 idt, B, D, COMBINER[combiner], _ptr(out), out.stride(0), _stream()),
+        "mh_embedding_bag_fwd",
+    )
+    return out
+
+
+def embedding_dense_list(
+    table: torch.Tensor, ids: torch.Tensor, combiner: str = "mean", out: Optional[torch.Tensor] = None
+) -> torch.Tensor:
+    """Fixed-length list ``[B, L]`` lookup reduced over axis 1 (mean / sum)."""
+    lib = _lib.load()
+    _dev(table, "table", torch.float32)
+    _dev(ids, "ids")
+    idt = _ids_dtype(ids, "ids")
+    if combiner not in ("mean", "sum"):
+        raise ValueError("Only 'mean' and 'sum' str combiners are implemented on the HIP path")
+    if ids.dim() == 3 and ids.shape[-1] == 1:
+        ids = ids.squeeze(-1)
+    if ids.dim() != 2:
+        raise ValueError("ids must be [B, L]")
+    ids = ids.contiguous()
+    B, L = ids.shape
+    D = table.shape[1]
+    if out is None:
+        out = torch.empty((B, D), dtype=torch.float32, device=table.device)
+    check(
+        lib.mh_embedding_dense_list_fwd(_ptr(table), table.shape[0], _ptr(ids), idt, B, L, D,
+                                        COMBINER[combiner], _ptr(out), out.stride(0), _stream()),
+        "mh_embedding_dense_list_fwd",
+    )
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# dense layers
+# --------------------------------------------------------------------------------------------
+def _rowmajor_2d(t: torch.Tensor, name: str) -> torch.Tensor:
+    _dev(t, name, torch.float32)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name} must be 2-D with unit inner stride")
+    return t
+
+
+def linear(
+    x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor] = None, activation: Optional[str] = None,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """``act(x @ W + b)`` with ``W`` in the Keras kernel layout ``[K, N]``."""
+    lib = _lib.load()
+    _rowmajor_2d(x, "x")
+    _dev(W, "W", torch.float32)
+    if activation not in ACT:
+        raise ValueError(f"unsupported activation {activation!r}")
+    M, K = x.shape
+    if W.dim() != 2 or W.shape[0] != K or not W.is_contiguous():
+        raise ValueError(f"W must be contiguous [{K}, N]")
+    N = W.shape[1]
+    if b is not None:
+        _dev(b, "b", torch.float32)
+        if b.numel() != N:
+            raise ValueError("bias must have N entries")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    else:
+        _rowmajor_2d(out, "out")
+    check(
+        lib.mh_linear_bias_act_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation],
+                                   _ptr(out), out.stride(0), _stream()),
+        "mh_linear_bias_act_fwd",
+    )
+    return out
+
+
+def dot_interaction(
+    x: torch.Tensor, tail: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
+) -> torch.Tensor:
+    """Strict-upper-triangle pairwise dots of ``x[B, F, D]`` (row-major pair order), optionally
+    followed by ``tail[B, T]`` in the same output row."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    if x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("x must be contiguous [B, F, D]")
+    B, F, D = x.shape
+    P = F * (F - 1) // 2
+    T = 0
+    if tail is not None:
+        _rowmajor_2d(tail, "tail")
+        T = tail.shape[1]
+    if out is None:
+        out = torch.empty((B, P + T), dtype=torch.float32, device=x.device)
+    else:
+        _rowmajor_2d(out, "out")
+    check(
+        lib.mh_dot_interaction_fwd(_ptr(x), B, F, D, _ptr(tail), 0 if tail is None else tail.stride(0), T,
+                                   _ptr(out), out.stride(0), _stream()),
+        "mh_dot_interaction_fwd",
+    )
+    return out

@@ -1,0 +1,29 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` tests must not silently skip on a GPU box; without a GPU they are deselected by -m.
+    pass
+
+
+@pytest.fixture(scope="session")
+def device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test running without a HIP device")
+    return torch.device("cuda:0")

@@ -1,0 +1,89 @@
+"""HIP dense / interaction kernels vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from models_amd import ops
+from oracle import cbind, oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# fp32 logits tolerance of the north star / reference (tf/utils/testing_utils.py:113-119)
+ATOL = 1e-4
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+@pytest.mark.parametrize("M,K,N", [(257, 13, 128), (1000, 128, 64), (300, 415, 128), (129, 64, 32),
+                                   (64, 100, 200), (77, 33, 7), (515, 64, 1), (5, 3341, 96)])
+@pytest.mark.parametrize("act", [None, "relu", "sigmoid"])
+def test_linear_matches_oracle(device, M, K, N, act):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    W = O.glorot_uniform(rng, K, N)
+    b = rng.normal(size=N).astype(np.float32) * 0.1
+    y = ops.linear(_t(x, device), _t(W, device), _t(b, device), act).cpu().numpy()
+    ref = O.dense(x, W, b, act)
+    np.testing.assert_allclose(y, ref, atol=ATOL, rtol=1e-5)
+
+
+def test_linear_is_k_ascending_fmaf_chain(device):
+    """Bit-exact against the C oracle's sequential fmaf chain (documented accumulation order)."""
+    rng = np.random.default_rng(0)
+    M, K, N = 200, 415, 128
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    W = rng.normal(size=(K, N)).astype(np.float32)
+    y = ops.linear(_t(x, device), _t(W, device), None, None).cpu().numpy()
+    np.testing.assert_array_equal(y, cbind.gemm_nn_fmaf(x, W))
+
+
+def test_linear_transpose_detecting(device):
+    """A = I-like input with an asymmetric W catches row/col swaps in the C/D layout."""
+    K = N = 64
+    x = np.eye(K, dtype=np.float32)
+    W = (np.arange(K * N, dtype=np.float32).reshape(K, N)) / 100.0
+    y = ops.linear(_t(x, device), _t(W, device)).cpu().numpy()
+    np.testing.assert_array_equal(y, W)
+
+
+def test_linear_strided_input_and_output(device):
+    rng = np.random.default_rng(1)
+    M, K, N = 130, 64, 32
+    big = rng.normal(size=(M, 100)).astype(np.float32)
+    W = O.glorot_uniform(rng, K, N)
+    xb = _t(big, device)
+    outb = torch.zeros(M, 50, device=device)
+    ops.linear(xb[:, 4:4 + K], _t(W, device), None, "relu", out=outb[:, 8:8 + N])
+    ref = O.dense(big[:, 4:4 + K], W, None, "relu")
+    np.testing.assert_allclose(outb[:, 8:8 + N].cpu().numpy(), ref, atol=ATOL)
+    assert torch.all(outb[:, :8] == 0) and torch.all(outb[:, 8 + N:] == 0)
+
+
+@pytest.mark.parametrize("F,D", [(27, 64), (5, 8), (16, 32), (17, 128), (32, 16), (3, 40), (27, 256)])
+@pytest.mark.parametrize("with_tail", [False, True])
+def test_dot_interaction_matches_oracle(device, F, D, with_tail):
+    rng = np.random.default_rng(F * D)
+    B = 203
+    X = rng.normal(size=(B, F, D)).astype(np.float32)
+    tail = X[:, -1].copy() if with_tail else None
+    out = ops.dot_interaction(_t(X, device), None if tail is None else _t(tail, device)).cpu().numpy()
+    ref = O.dlrm_interaction_concat(X, tail)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, atol=ATOL * max(1.0, D / 64), rtol=1e-5)
+
+
+def test_dot_interaction_asymmetric_order(device):
+    """Distinct one-hot rows: pair (i,j) output is 1 iff rows i and j share a hot column."""
+    F, D, B = 6, 8, 2
+    X = np.zeros((B, F, D), np.float32)
+    X[0, 0, 1] = X[0, 3, 1] = 1.0  # only pair (0,3)
+    X[1, 2, 5] = 2.0
+    X[1, 5, 5] = 3.0  # only pair (2,5) -> 6
+    out = ops.dot_interaction(_t(X, device)).cpu().numpy()
+    pairs = [(i, j) for i in range(F) for j in range(i + 1, F)]
+    exp = np.zeros((B, len(pairs)), np.float32)
+    exp[0, pairs.index((0, 3))] = 1.0
+    exp[1, pairs.index((2, 5))] = 6.0
+    np.testing.assert_array_equal(out, exp)
