@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- samples/sec of the DLRM hot path (BASELINE.json config 2) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic batch of 65 536 samples that is already
+resident in HBM: 26 categorical lookups (Criteo cardinalities capped at 1 M rows, D = 64) + 13
+dense features -> bottom MLP [128, 64] -> pairwise dot interaction -> top MLP [128, 64, 32] ->
+sigmoid head (``--mode fwd``), plus loss, backward and the optimizer update (``--mode train``).
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+``roofline`` (dominant kernel: the multi-table embedding gather, HBM-bound) and ``cpu_baseline``
+(the numpy oracle timed on the host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def build_model(device, emb_dim=64, seed=0):
+    import models_amd as mm
+    from models_amd import schema as S
+    from models_amd.synthetic import CRITEO_CARDINALITIES, CRITEO_CAT_NAMES, CRITEO_CONT_NAMES
+
+    cols = [S.categorical(n, v) for n, v in zip(CRITEO_CAT_NAMES, CRITEO_CARDINALITIES)]
+    cols += [S.continuous(n) for n in CRITEO_CONT_NAMES]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+    model = mm.DLRMModel(schema, embedding_dim=emb_dim, bottom_block=mm.MLPBlock([128, emb_dim], device=device),
+                         top_block=mm.MLPBlock([128, 64, 32], device=device), device=device)
+    return model, schema
+
+
+def make_batch(device, B, rank, dist="uniform"):
+    from models_amd.synthetic import CRITEO_CARDINALITIES, CRITEO_CAT_NAMES, CRITEO_CONT_NAMES, lognormal_ids
+
+    rng = np.random.default_rng(1234 + rank)
+    batch = {}
+    for n, v in zip(CRITEO_CAT_NAMES, CRITEO_CARDINALITIES):
+        ids = rng.integers(0, v, size=B) if dist == "uniform" else lognormal_ids(rng, B, v - 1)
+        batch[n] = torch.from_numpy(ids.astype(np.int32)).to(device)
+    dense = rng.random(size=(B, len(CRITEO_CONT_NAMES)), dtype=np.float32)
+    for i, n in enumerate(CRITEO_CONT_NAMES):
+        batch[n] = torch.from_numpy(np.ascontiguousarray(dense[:, i:i + 1])).to(device)
+    label = torch.from_numpy(rng.integers(0, 2, size=(B, 1)).astype(np.float32)).to(device)
+    return batch, label
+
+
+def cpu_baseline(model, batch, B_cpu, budget_s=20.0):
+    """numpy oracle ("port") of the same forward on the host cores, bounded sample."""
+    from oracle import oracle as O
+
+    body = model.body
+    tables = {n: body.embeddings.feature_table[n].table.data.cpu().numpy() for n in body.cat_names}
+    cat = {n: batch[n][:B_cpu].cpu().numpy() for n in body.cat_names}
+    cont = {n: batch[n][:B_cpu].cpu().numpy() for n in body.continuous.features}
+    lay = lambda blk: [(l.kernel.numpy(), l.bias.numpy(), l.activation) for l in blk.layers]
+    head = model.output.to_call
+    args = (cat, cont, tables, lay(body.bottom_block), lay(body.top_block), (head.kernel.numpy(), head.bias.numpy()))
+    O.dlrm_forward(*args)  # first step discarded (tf/logging/callbacks.py:174-189)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        out = O.dlrm_forward(*args)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": B_cpu * n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"numpy oracle dlrm_forward, {n} steps x {B_cpu} samples (same tables/ids as the GPU batch)"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--ids", choices=["uniform", "lognormal"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16384)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from models_amd import ops
+
+    model, schema = build_model(device)
+    batch, label = make_batch(device, args.batch, rank, args.ids)
+
+    def step():
+        if args.mode == "fwd":
+            return model(batch)
+        return model.train_step(batch, label)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ops.TIMER.enable()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ops.TIMER.summary()
+    ops.TIMER.disable()
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        return
+    F, D, B = len(model.body.cat_names), model.body.dim, args.batch
+    gather_bytes = B * (F * (D * 4 + D * 4) + F * 4)  # 13 416 B/sample at F=26, D=64, int32 ids
+    g_ms = kernel_ms.get("embedding_gather", {}).get("avg_ms")
+    roofline = None
+    if g_ms:
+        ach = gather_bytes / (g_ms * 1e-3) / 1e9
+        roofline = {"kernel": "gather_fwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms}
+    res = {
+        "metric": "samples/sec at batch 64K (DLRM)", "value": world * B * args.steps / dt, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: DLRM 26 cat (Criteo cardinalities capped 1M) + 13 dense, "
+                               f"emb_dim=64, bottom [128,64], top [128,64,32], {args.mode}, ids={args.ids}",
+                   "global_batch": world * B, "per_gpu_batch": B, "mode": args.mode,
+                   "parallelism": f"dp{world}"},
+        "roofline": roofline,
+        "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
+    }
+    if not args.no_cpu_baseline:
+        base, ref = cpu_baseline(model, batch, min(args.cpu_batch, B))
+        res["cpu_baseline"] = base
+        got = model(batch)[: ref["prob"].shape[0]].cpu().numpy()
+        res["max_abs_err_vs_oracle"] = float(np.abs(got - ref["prob"]).max())
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+"""models_amd -- the MI355X-native hot path behind the Merlin Models ``mm`` surface.
+
+``import models_amd as mm`` gives the names the reference exports at
+merlin/models/tf/__init__.py:21-132 for the retrieval / ranking hot path.
+"""
+from .schema import ColumnSchema, Schema, Tags  # noqa: F401
+from .core import (  # noqa: F401
+    Block, ConcatFeatures, Filter, ParallelBlock, Parameter, SequentialBlock, StackFeatures, TabularBlock,
+)
+from .inputs import (  # noqa: F401
+    Continuous, ContinuousFeatures, EmbeddingTable, Embeddings, EmbeddingsBlock, InputBlockV2, Ragged,
+    infer_embedding_dim,
+)
+from .blocks import (  # noqa: F401
+    Cross, CrossBlock, DLRMBlock, DotProductInteraction, DotProductInteractionBlock, MLPBlock, TwoTowerBlock,
+)
+from .outputs import (  # noqa: F401
+    MIN_FLOAT, BinaryOutput, BruteForce, ContrastiveOutput, DotProduct, Prediction, TopKOutput, TopKPrediction,
+)
+from .models import (  # noqa: F401
+    DCNModel, DLRMModel, Model, RankingModel, RetrievalModel, TopKEncoder, TwoTowerModel, TwoTowerModelV2,
+)
+
+__version__ = "0.1.0"

@@ -62,6 +62,11 @@ def load() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be resident BEFORE
+    # libmerlin_hip.so is dlopen'ed so that both share ONE HIP runtime (streams, allocations);
+    # loading ours first would pull in /opt/rocm's copy and torch would then load a second one.
+    import torch  # noqa: F401  (buffer carrier + the process-wide HIP runtime)
+
     path = lib_path()
     if _build.needs_build():
         if shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists():

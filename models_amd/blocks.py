@@ -1,0 +1,360 @@
+"""Hot-path blocks of the kept ``mm`` surface (reference layer L3, merlin/models/tf/blocks/).
+
+MLPBlock / _Dense (mlp.py:35-139, 210-300), DotProductInteraction (interaction.py:35-124),
+DLRMBlock (dlrm.py:32-170), CrossBlock / Cross (cross.py:29-202), TwoTowerBlock
+(retrieval/two_tower.py:32-118).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .core import Block, ConcatFeatures, Filter, ParallelBlock, Parameter, SequentialBlock, TabularData
+from .inputs import ContinuousFeatures, Embeddings, EmbeddingsBlock, default_device
+from .schema import Schema, Tags
+
+_SUPPORTED_ACT = ("relu", "sigmoid", "linear", None)
+
+
+def _glorot_uniform(fan_in: int, fan_out: int, seed: int) -> torch.Tensor:
+    """keras glorot_uniform, the Dense default (mlp.py:39)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return (torch.rand((fan_in, fan_out), generator=g) * 2.0 - 1.0) * lim
+
+
+def _truncated_normal(shape, std: float, seed: int) -> torch.Tensor:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    t = torch.empty(shape)
+    torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=g)
+    return t
+
+
+_seed_counter = [1000]
+
+
+def _next_seed() -> int:
+    _seed_counter[0] += 1
+    return _seed_counter[0]
+
+
+class _Dense(Block):
+    """A Dense layer that concat-aggregates dict inputs before projecting (mlp.py:210-300).
+    ``kernel`` is [in, out] (Keras layout); built lazily on the first call."""
+
+    def __init__(self, units: int, activation: Optional[str] = None, use_bias: bool = True,
+                 kernel_initializer="glorot_uniform", bias_initializer="zeros", pre_aggregation="concat",
+                 name: Optional[str] = None, device=None, seed: Optional[int] = None):
+        super().__init__(name)
+        if activation not in _SUPPORTED_ACT:
+            raise NotImplementedError(f"activation {activation!r} is not on the HIP hot path (relu/sigmoid/linear)")
+        self.units = int(units)
+        self.activation = None if activation == "linear" else activation
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.pre_aggregation = ConcatFeatures() if pre_aggregation == "concat" else None
+        self.device = torch.device(device) if device is not None else default_device()
+        self.seed = _next_seed() if seed is None else seed
+        self.kernel: Optional[Parameter] = None
+        self.bias: Optional[Parameter] = None
+
+    def build(self, in_dim: int) -> None:
+        init = self.kernel_initializer
+        if init == "glorot_uniform":
+            w = _glorot_uniform(in_dim, self.units, self.seed)
+        elif init == "truncated_normal":
+            w = _truncated_normal((in_dim, self.units), 0.05, self.seed)
+        elif callable(init):
+            w = torch.as_tensor(np.asarray(init((in_dim, self.units))), dtype=torch.float32)
+        else:
+            w = torch.as_tensor(np.asarray(init), dtype=torch.float32)
+        if tuple(w.shape) != (in_dim, self.units):
+            raise ValueError(f"kernel initializer gave {tuple(w.shape)}, expected {(in_dim, self.units)}")
+        self.kernel = Parameter(w.contiguous().to(self.device), name=f"{self.name}/kernel")
+        if self.use_bias:
+            if self.bias_initializer == "zeros":
+                b = torch.zeros(self.units)
+            else:
+                b = torch.as_tensor(np.asarray(self.bias_initializer), dtype=torch.float32).reshape(self.units)
+            self.bias = Parameter(b.to(self.device), name=f"{self.name}/bias")
+
+    def own_parameters(self):
+        return [p for p in (self.kernel, self.bias) if p is not None]
+
+    def forward(self, inputs, out: Optional[torch.Tensor] = None):
+        if isinstance(inputs, dict):
+            inputs = self.pre_aggregation(inputs)
+        if self.kernel is None:
+            self.build(inputs.shape[-1])
+        self._x = inputs
+        self._y = ops.linear(inputs, self.kernel.data, None if self.bias is None else self.bias.data,
+                             self.activation, out=out)
+        return self._y
+
+    def backward(self, grad, need_dx: bool = True):
+        dx, dW, db = ops.linear_backward(self._x, self.kernel.data, self._y, grad, self.activation,
+                                         need_dx=need_dx, need_db=self.bias is not None)
+        self.kernel.grad = dW
+        if self.bias is not None:
+            self.bias.grad = db
+        return dx
+
+
+def MLPBlock(dimensions: Sequence[int], activation: Union[str, List[str]] = "relu", use_bias: bool = True,
+             kernel_initializer="glorot_uniform", bias_initializer="zeros", dropout: Optional[float] = None,
+             normalization=None, filter=None, no_activation_last_layer: bool = False,
+             block_name: str = "MLPBlock", device=None, seed: Optional[int] = None, **kwargs) -> SequentialBlock:
+    """mlp.py:35-139.  Dropout / BatchNorm are Keras machinery outside the hot path."""
+    if isinstance(activation, list) and len(activation) != len(dimensions):
+        raise ValueError(
+            f"Activation and Dimensions length mismatch. "
+            f"Activation length: {len(activation)}, Dimensions length: {len(dimensions)}"
+        )
+    if dropout or normalization:
+        raise NotImplementedError("dropout / normalization layers are outside the HIP hot path")
+    layers = []
+    for idx, dim in enumerate(dimensions):
+        act = (activation or "linear") if not isinstance(activation, list) else activation[idx]
+        if no_activation_last_layer and idx == len(dimensions) - 1:
+            act = "linear"
+        layers.append(_Dense(dim, activation=act, use_bias=use_bias, kernel_initializer=kernel_initializer,
+                             bias_initializer=bias_initializer, device=device,
+                             seed=None if seed is None else seed + idx))
+    return SequentialBlock(layers, name=block_name, filter=filter)
+
+
+class DotProductInteraction(Block):
+    """interaction.py:35-124 with interaction_type=None, self_interaction=False."""
+
+    def __init__(self, interaction_type=None, self_interaction: bool = False, name: Optional[str] = None):
+        super().__init__(name)
+        if interaction_type is not None or self_interaction:
+            raise NotImplementedError("only the DLRM default (plain dot, no self interaction) is on the hot path")
+
+    def forward(self, inputs: torch.Tensor, tail: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        self._x, self._has_tail = inputs, tail is not None
+        return ops.dot_interaction(inputs, tail, out=out)
+
+    def backward(self, grad, tail_width: int = 0):
+        return ops.dot_interaction_backward(self._x, grad, tail_width)
+
+    def compute_output_shape(self, input_shape):
+        return input_shape[0], input_shape[1] * (input_shape[1] - 1) // 2
+
+
+def DotProductInteractionBlock() -> SequentialBlock:
+    """dlrm.py:169-170."""
+    from .core import StackFeatures
+
+    return SequentialBlock([StackFeatures(axis=1), DotProductInteraction()])
+
+
+def _last_dense_units(block: Block) -> int:
+    dense = [l for l in getattr(block, "layers", [block]) if isinstance(l, _Dense)]
+    if not dense:
+        raise ValueError("bottom_block must contain a Dense layer")
+    return dense[-1].units
+
+
+class DLRMBlock(Block):
+    """dlrm.py:32-133, executed as a fused pipeline:
+
+        continuous -> bottom MLP --(last layer writes slot "bottom_block")--+
+        categorical ids -> ONE multi-table gather -> slots (sorted names) --+-> stacked [B, F, D]
+        stacked -> dot interaction (+ bottom output appended)  -> [B, F(F-1)/2 + D] -> top MLP
+
+    The stack order is ``sorted(feature names + ["bottom_block"])`` (core/aggregation.py:101-108)
+    and the concat order is [interactions | bottom output] ("sequential_block..." < "shortcut",
+    core/combinators.py:669-693).
+    """
+
+    def __init__(self, schema: Schema, *, embedding_dim: Optional[int] = None, embeddings: Optional[EmbeddingsBlock] = None,
+                 bottom_block: Optional[Block] = None, top_block: Optional[Block] = None, device=None,
+                 name: Optional[str] = None):
+        super().__init__(name)
+        if schema is None:
+            raise ValueError("The schema is required by DLRM")
+        con_schema = schema.select_by_tag(Tags.CONTINUOUS).excluding_by_tag(Tags.TARGET)
+        cat_schema = schema.select_by_tag(Tags.CATEGORICAL).excluding_by_tag(Tags.TARGET)
+        if not len(cat_schema) > 0:
+            raise ValueError("DLRM requires categorical features")
+        if embeddings is None:
+            if embedding_dim is None:
+                raise ValueError("The embedding_dim is required")
+            if bottom_block is not None and embedding_dim != _last_dense_units(bottom_block):
+                raise ValueError(
+                    f"The embedding_dim ({embedding_dim}) needs to match the "
+                    f"last layer of bottom MLP ({_last_dense_units(bottom_block)}) "
+                )
+            embeddings = Embeddings(cat_schema, dim=embedding_dim, sequence_combiner="mean", device=device)
+        if len(con_schema) > 0:
+            if bottom_block is None:
+                raise ValueError(
+                    "The bottom_block is required by DLRM when "
+                    "continuous features are available in the schema"
+                )
+            self.continuous = ContinuousFeatures.from_schema(con_schema, aggregation="concat")
+        else:
+            self.continuous = None
+            bottom_block = None
+        self.schema = schema
+        self.embeddings = embeddings
+        self.bottom_block = bottom_block
+        self.top_block = top_block
+        self.interaction = DotProductInteraction()
+        self.cat_names = [c.name for c in cat_schema]
+        dims = {embeddings.feature_table[n].dim for n in self.cat_names}
+        if len(dims) != 1:
+            raise ValueError("DLRM needs one embedding dim for all categorical features")
+        self.dim = dims.pop()
+        keys = self.cat_names + (["bottom_block"] if self.bottom_block is not None else [])
+        self.stack_order = sorted(keys)
+        self.slots = {k: i for i, k in enumerate(self.stack_order)}
+
+    def children(self):
+        return [b for b in (self.embeddings, self.bottom_block, self.top_block) if b is not None]
+
+    @property
+    def num_features(self) -> int:
+        return len(self.stack_order)
+
+    def forward(self, inputs: TabularData):
+        first = inputs[self.cat_names[0]]
+        B = first.shape[0] if isinstance(first, torch.Tensor) else first.offsets.shape[0] - 1
+        dev = self.embeddings.feature_table[self.cat_names[0]].table.data.device
+        F, D = self.num_features, self.dim
+        stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        tail = None
+        if self.bottom_block is not None:
+            x = self.continuous(inputs)
+            layers = self.bottom_block.layers if isinstance(self.bottom_block, SequentialBlock) else [self.bottom_block]
+            for layer in layers[:-1]:
+                x = layer(x)
+            tail = stacked[:, self.slots["bottom_block"]]
+            layers[-1].forward(x, out=tail)  # last bottom layer writes its slot of the stack
+        self.embeddings.gather_into(inputs, stacked, self.slots)
+        self._stacked = stacked
+        P = F * (F - 1) // 2
+        if self.top_block is None:
+            return self.interaction.forward(stacked)  # dlrm.py:120-121: interactions only
+        width = P + (D if tail is not None else 0)
+        ld = (width + 3) // 4 * 4  # keep rows 16-byte aligned for the next layer's vector loads
+        buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        if ld != width:
+            buf[:, width:].zero_()
+        top_in = buf[:, :width]
+        self.interaction.forward(stacked, tail, out=top_in)
+        self._top_in = top_in
+        return self.top_block(top_in)
+
+    def backward(self, grad):
+        D = self.dim
+        if self.top_block is not None:
+            grad = self.top_block.backward(grad)
+        has_tail = self.bottom_block is not None and self.top_block is not None
+        dstack, dtail = self.interaction.backward(grad, D if has_tail else 0)
+        if self.bottom_block is not None:
+            slot = self.slots["bottom_block"]
+            g = dstack[:, slot]
+            if dtail is not None:
+                g = g + dtail
+            self.bottom_block.backward(g.contiguous())
+        self._dstacked = dstack
+        return dstack
+
+
+class Cross(Block):
+    """One DCN-v2 cross layer x0 * (x W + b) + x (cross.py:113-202), full-rank kernel."""
+
+    def __init__(self, name: Optional[str] = None, device=None, seed: Optional[int] = None):
+        super().__init__(name)
+        self.device = torch.device(device) if device is not None else default_device()
+        self.seed = _next_seed() if seed is None else seed
+        self.kernel: Optional[Parameter] = None
+        self.bias: Optional[Parameter] = None
+
+    def build(self, d: int):
+        # CrossBlock default kernel_initializer="truncated_normal", bias "zeros" (cross.py:34-35)
+        self.kernel = Parameter(_truncated_normal((d, d), 0.05, self.seed).to(self.device), name=f"{self.name}/kernel")
+        self.bias = Parameter(torch.zeros(d, device=self.device), name=f"{self.name}/bias")
+
+    def own_parameters(self):
+        return [p for p in (self.kernel, self.bias) if p is not None]
+
+    def forward(self, inputs):
+        x0, x = inputs if isinstance(inputs, tuple) else (inputs, inputs)
+        if x0.shape != x.shape:
+            raise ValueError(f"`x0` ({tuple(x0.shape)}) and `x` ({tuple(x.shape)}) shapes mismatch!")
+        if self.kernel is None:
+            self.build(x.shape[-1])
+        return ops.cross_layer(x0, x, self.kernel.data, self.bias.data)
+
+
+class CrossBlock(Block):
+    """cross.py:29-109: ``depth`` stacked Cross layers, x_{l+1} = x0 * (W_l x_l + b_l) + x_l."""
+
+    def __init__(self, depth: int = 1, low_rank_dim: Optional[int] = None, name: Optional[str] = None, device=None):
+        super().__init__(name)
+        if low_rank_dim is not None:
+            raise NotImplementedError("low-rank cross kernels are not on the HIP hot path yet")
+        self.layers = [Cross(device=device) for _ in range(depth)]
+        self.pre_aggregation = ConcatFeatures()
+
+    def children(self):
+        return self.layers
+
+    def forward(self, inputs):
+        if isinstance(inputs, dict):
+            inputs = self.pre_aggregation(inputs)
+        x0 = x = inputs.contiguous()
+        for layer in self.layers:
+            x = layer((x0, x))
+        return x
+
+
+class TwoTowerBlock(ParallelBlock):
+    """retrieval/two_tower.py:32-118: two independent towers -> {"query": [B,E], "item": [B,E]};
+    the item tower defaults to a structural copy of the query tower (:98)."""
+
+    def __init__(self, schema: Schema, query_tower: Block, item_tower: Optional[Block] = None,
+                 query_tower_tag=Tags.USER, item_tower_tag=Tags.ITEM, embedding_dim: Optional[int] = None,
+                 l2_normalization: bool = False, device=None, name: Optional[str] = None):
+        from .inputs import InputBlockV2
+
+        q_schema = schema.select_by_tag(query_tower_tag)
+        i_schema = schema.select_by_tag(item_tower_tag)
+        if not len(q_schema) or not len(i_schema):
+            raise ValueError("The schema should contain features with the tags `user` and `item`")
+        if item_tower is None:
+            item_tower = _copy_mlp(query_tower, device)
+        q_in = InputBlockV2(q_schema, dim=embedding_dim, device=device)
+        i_in = InputBlockV2(i_schema, dim=embedding_dim, device=device)
+        towers = {"query": SequentialBlock([q_in, query_tower], name="query_tower"),
+                  "item": SequentialBlock([i_in, item_tower], name="item_tower")}
+        super().__init__(towers, name=name or "two_tower")
+        self.l2_normalization = l2_normalization
+        self.schema = schema
+
+    def forward(self, inputs: TabularData):
+        out = super().forward(inputs)
+        if self.l2_normalization:
+            out = {k: ops.l2norm(v) for k, v in out.items()}
+        return out
+
+
+def _copy_mlp(block: Block, device=None) -> Block:
+    """Structural copy (fresh weights) of an MLP tower -- ``query_tower.copy()`` in the reference."""
+    if isinstance(block, SequentialBlock):
+        return SequentialBlock([_copy_mlp(l, device) for l in block.layers], name=None)
+    if isinstance(block, _Dense):
+        return _Dense(block.units, activation=block.activation or "linear", use_bias=block.use_bias,
+                      kernel_initializer=block.kernel_initializer, bias_initializer=block.bias_initializer,
+                      device=device or block.device)
+    raise NotImplementedError(f"cannot copy tower layer {type(block).__name__}")

@@ -1,0 +1,279 @@
+"""Input blocks of the kept ``mm`` surface (reference layer L2, merlin/models/tf/inputs/).
+
+``EmbeddingTable`` (embedding.py:153-471), ``Embeddings`` (:585-683), ``ContinuousFeatures``
+(continuous.py:73-138) and ``InputBlockV2`` (base.py:216-341).  The per-table Keras
+``Embedding`` layers of the reference become ONE multi-table HIP gather launch per batch
+(``mh_embedding_gather_fwd``) that writes straight into a stacked ``[B, F, D]`` buffer.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, NamedTuple, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .core import Block, ParallelBlock, Parameter, TabularData, parse_aggregation
+from .schema import ColumnSchema, Schema, Tags, infer_embedding_dim as _infer_dim_from_cardinality
+
+
+class Ragged(NamedTuple):
+    """CSR list feature: ``values[nnz]`` + ``offsets[B+1]`` -- what PrepareFeatures builds from
+    ``name__values`` / ``name__offsets`` (tf/transforms/features.py:324-379)."""
+
+    values: torch.Tensor
+    offsets: torch.Tensor
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def infer_embedding_dim(col_schema: ColumnSchema, multiplier: float = 2.0, ensure_multiple_of_8: bool = True) -> int:
+    """utils/schema_utils.py:198-207."""
+    return _infer_dim_from_cardinality(int(col_schema.int_domain.max) + 1, multiplier, ensure_multiple_of_8)
+
+
+def _init_table(initializer, rows: int, dim: int, device, seed: Optional[int]) -> torch.Tensor:
+    """keras Embedding default "uniform" = U(-0.05, 0.05) (embedding.py:205); V1 EmbeddingFeatures
+    default TruncatedNormal(0, 0.05) (:1051) is available as "truncated_normal"."""
+    if initializer is None or initializer == "uniform":
+        g = torch.Generator(device="cpu")
+        g.manual_seed(0 if seed is None else seed)
+        if rows * dim > (1 << 24) and device.type == "cuda":
+            gd = torch.Generator(device=device)
+            gd.manual_seed(0 if seed is None else seed)
+            return (torch.rand((rows, dim), generator=gd, device=device) - 0.5) * 0.1
+        return ((torch.rand((rows, dim), generator=g) - 0.5) * 0.1).to(device)
+    if initializer == "truncated_normal":
+        g = torch.Generator(device="cpu")
+        g.manual_seed(0 if seed is None else seed)
+        t = torch.empty((rows, dim))
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=0.05, a=-0.1, b=0.1, generator=g)
+        return t.to(device)
+    if callable(initializer):
+        initializer = initializer((rows, dim))
+    w = torch.as_tensor(np.asarray(initializer.cpu() if isinstance(initializer, torch.Tensor) else initializer),
+                        dtype=torch.float32)
+    if tuple(w.shape) != (rows, dim):
+        raise ValueError(f"initializer gave shape {tuple(w.shape)}, expected {(rows, dim)}")
+    return w.contiguous().to(device)
+
+
+class EmbeddingTable(Block):
+    """One embedding table shared by one or more categorical columns (embedding.py:153).
+
+    ``input_dim = int_domain.max + 1`` (:91-93, :244-249).  Accepted inputs per feature:
+    ``[B]`` / ``[B,1]`` ids (one-hot), ``[B,L]`` dense list (reduced by ``sequence_combiner``),
+    or :class:`Ragged` CSR (``safe_embedding_lookup_sparse`` semantics, :432-441).
+    """
+
+    def __init__(self, dim: int, *col_schemas: ColumnSchema, sequence_combiner: Optional[str] = None,
+                 embeddings_initializer="uniform", trainable: bool = True, name: Optional[str] = None,
+                 device=None, seed: Optional[int] = None):
+        if not col_schemas:
+            raise ValueError("EmbeddingTable needs at least one ColumnSchema")
+        first = col_schemas[0]
+        super().__init__(name or (first.int_domain.name if first.int_domain and first.int_domain.name else first.name))
+        self.dim = int(dim)
+        if self.dim % 4 != 0:
+            raise ValueError(f"embedding dim must be a multiple of 4 on the HIP path, got {dim}")
+        self.features: Dict[str, ColumnSchema] = {}
+        self.input_dim = None
+        for col in col_schemas:
+            self.add_feature(col)
+        if sequence_combiner is not None and sequence_combiner not in ("mean", "sum", "sqrtn"):
+            raise ValueError("sequence_combiner must be 'mean', 'sum' or 'sqrtn'")
+        self.sequence_combiner = sequence_combiner
+        self.device = torch.device(device) if device is not None else default_device()
+        w = _init_table(embeddings_initializer, self.input_dim, self.dim, self.device, seed)
+        self.table = Parameter(w, name=f"{self.name}/embeddings", trainable=trainable, sparse=True)
+
+    # embedding.py:111-128
+    def add_feature(self, col: ColumnSchema) -> None:
+        if col.int_domain is None or col.int_domain.max is None:
+            raise ValueError(f"`col_schema` {col.name!r} needs to have an int-domain")
+        card = int(col.int_domain.max) + 1
+        if self.input_dim is not None and card != self.input_dim:
+            raise ValueError(
+                f"`col_schema` {col.name!r} does not share the table domain ({card} != {self.input_dim})"
+            )
+        self.input_dim = card
+        self.features[col.name] = col
+
+    @classmethod
+    def from_pretrained(cls, data, col_schema: Optional[ColumnSchema] = None, trainable: bool = True,
+                        name: Optional[str] = None, **kwargs) -> "EmbeddingTable":
+        """embedding.py:253-311: table initialised from a [rows, dim] array."""
+        arr = np.asarray(data.cpu() if isinstance(data, torch.Tensor) else data, dtype=np.float32)
+        rows, dim = arr.shape
+        if col_schema is None:
+            from .schema import categorical
+
+            col_schema = categorical(name or "pretrained", rows)
+        return cls(dim, col_schema, embeddings_initializer=arr, trainable=trainable, name=name, **kwargs)
+
+    @property
+    def schema(self) -> Schema:
+        return Schema(self.features.values())
+
+    def own_parameters(self):
+        return [self.table]
+
+    def _lookup(self, x, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        w = self.table.data
+        if isinstance(x, Ragged):
+            if not self.sequence_combiner:
+                raise ValueError("Ragged inputs need a str sequence_combiner on the HIP path")
+            return ops.embedding_bag(w, x.values, x.offsets, self.sequence_combiner, out=out)
+        if x.dim() == 3 and x.shape[-1] == 1:
+            x = x.squeeze(-1)
+        if x.dim() == 2 and x.shape[1] > 1:
+            if not self.sequence_combiner:
+                raise ValueError("dense list inputs need a sequence_combiner ('mean' or 'sum')")
+            return ops.embedding_dense_list(w, x, self.sequence_combiner, out=out)
+        res = ops.embedding_gather([w], [x], out=None if out is None else out.unsqueeze(1))
+        return res[:, 0]
+
+    def forward(self, inputs):
+        if isinstance(inputs, dict):
+            self._last = {n: inputs[n] for n in self.features if n in inputs}
+            return {n: self._lookup(v) for n, v in self._last.items()}
+        self._last = inputs
+        return self._lookup(inputs)
+
+
+class EmbeddingsBlock(ParallelBlock):
+    """ParallelBlock{table_name: EmbeddingTable} whose one-hot features are fetched by ONE
+    multi-table gather launch (what ``Embeddings(...)`` returns, embedding.py:585-683)."""
+
+    def __init__(self, tables: Dict[str, EmbeddingTable], schema: Schema, aggregation=None, name="embeddings"):
+        super().__init__(tables, aggregation=None, name=name, schema=schema)
+        self.agg = parse_aggregation(aggregation)
+        self.feature_table: Dict[str, EmbeddingTable] = {}
+        for t in tables.values():
+            for fname in t.features:
+                self.feature_table[fname] = t
+
+    @property
+    def feature_names(self) -> List[str]:
+        return [c.name for c in self.schema]
+
+    def _is_onehot(self, v) -> bool:
+        return isinstance(v, torch.Tensor) and (v.dim() == 1 or v.shape[-1] == 1 and v.dim() == 2)
+
+    def gather_into(self, inputs: TabularData, out: torch.Tensor, slots: Dict[str, int]) -> None:
+        """Write feature ``n`` into ``out[:, slots[n], :]`` for every categorical feature."""
+        names = [n for n in self.feature_names if n in inputs]
+        onehot = [n for n in names if self._is_onehot(inputs[n])]
+        if onehot:
+            ops.embedding_gather([self.feature_table[n].table.data for n in onehot],
+                                 [inputs[n] for n in onehot], out=out, out_slot=[slots[n] for n in onehot])
+        for n in names:
+            if n not in onehot:
+                self.feature_table[n]._lookup(inputs[n], out=out[:, slots[n]])
+        self._last = {n: inputs[n] for n in names}
+
+    def forward(self, inputs: TabularData):
+        names = [n for n in self.feature_names if n in inputs]
+        if not names:
+            raise ValueError("no categorical feature of the schema found in the inputs")
+        dims = {self.feature_table[n].dim for n in names}
+        outputs: Dict[str, torch.Tensor] = {}
+        for d in sorted(dims):
+            group = [n for n in names if self.feature_table[n].dim == d]
+            B = (inputs[group[0]].offsets.shape[0] - 1) if isinstance(inputs[group[0]], Ragged) else inputs[group[0]].shape[0]
+            buf = torch.empty((B, len(group), d), dtype=torch.float32, device=self.feature_table[group[0]].table.data.device)
+            self.gather_into({n: inputs[n] for n in group}, buf, {n: i for i, n in enumerate(group)})
+            for i, n in enumerate(group):
+                outputs[n] = buf[:, i]
+        self._last = {n: inputs[n] for n in names}
+        if self.agg is not None:
+            return self.agg(outputs)
+        return outputs
+
+    def tables(self) -> Dict[str, EmbeddingTable]:
+        return self.parallel_layers  # type: ignore[return-value]
+
+
+def Embeddings(schema: Schema, dim: Optional[Union[Dict[str, int], int]] = None,
+               infer_dim_fn: Callable[[ColumnSchema], int] = infer_embedding_dim,
+               sequence_combiner: Optional[Union[str, Dict[str, str]]] = "mean",
+               embeddings_initializer=None, trainable: Optional[Union[bool, Dict[str, bool]]] = None,
+               aggregation=None, block_name: str = "embeddings", device=None, seed: int = 0) -> EmbeddingsBlock:
+    """embedding.py:585-683: one EmbeddingTable per categorical column; columns whose
+    ``int_domain.name`` coincide share one table; ``dim=None`` -> ``infer_dim_fn(col)``."""
+    schema = schema.select_by_tag(Tags.CATEGORICAL) if any(Tags.CATEGORICAL in c.tags for c in schema) else schema
+    tables: Dict[str, EmbeddingTable] = {}
+
+    def pick(opt, col):
+        if isinstance(opt, dict):
+            return opt.get(col.name)
+        return opt
+
+    for i, col in enumerate(schema):
+        if col.int_domain is None:
+            raise ValueError(f"categorical column {col.name!r} needs an int_domain")
+        tname = col.int_domain.name or col.name
+        if tname in tables:
+            tables[tname].add_feature(col)
+            continue
+        d = pick(dim, col) or infer_dim_fn(col)
+        kw = {}
+        tr = pick(trainable, col)
+        if tr is not None:
+            kw["trainable"] = tr
+        init = pick(embeddings_initializer, col)
+        tables[tname] = EmbeddingTable(d, col, sequence_combiner=pick(sequence_combiner, col),
+                                       embeddings_initializer=init if init is not None else "uniform",
+                                       name=tname, device=device, seed=seed + i, **kw)
+    return EmbeddingsBlock(tables, schema, aggregation=aggregation, name=block_name)
+
+
+class ContinuousFeatures(Block):
+    """continuous.py:73-138: select the continuous columns, expand 1-D -> [B, 1]."""
+
+    def __init__(self, features: Sequence[str], aggregation=None, name: Optional[str] = None):
+        super().__init__(name)
+        self.features = list(features)
+        self.aggregation = parse_aggregation(aggregation)
+
+    @classmethod
+    def from_schema(cls, schema: Schema, aggregation=None, **kwargs) -> "ContinuousFeatures":
+        return cls(schema.select_by_tag(Tags.CONTINUOUS).column_names, aggregation=aggregation, **kwargs)
+
+    def forward(self, inputs: TabularData):
+        out = {}
+        for n in self.features:
+            if n in inputs:
+                v = inputs[n]
+                out[n] = v.unsqueeze(-1) if v.dim() == 1 else v
+        if self.aggregation is not None:
+            return self.aggregation(out)
+        return out
+
+    def backward(self, grad):
+        return None
+
+
+Continuous = ContinuousFeatures
+
+
+def InputBlockV2(schema: Schema, categorical: Optional[Block] = None, continuous: Optional[Block] = None,
+                 aggregation="concat", dim=None, device=None, **kwargs) -> ParallelBlock:
+    """base.py:216-341: ParallelBlock{"categorical": Embeddings, "continuous": Continuous} with a
+    "concat" aggregation over the merged (sorted) feature dict."""
+    branches: Dict[str, Block] = {}
+    cat_schema = schema.select_by_tag(Tags.CATEGORICAL).excluding_by_tag(Tags.TARGET)
+    con_schema = schema.select_by_tag(Tags.CONTINUOUS).excluding_by_tag(Tags.TARGET)
+    if categorical is None and len(cat_schema):
+        categorical = Embeddings(cat_schema, dim=dim, device=device, **kwargs)
+    if categorical is not None:
+        branches["categorical"] = categorical
+    if continuous is None and len(con_schema):
+        continuous = ContinuousFeatures.from_schema(con_schema)
+    if continuous is not None:
+        branches["continuous"] = continuous
+    if not branches:
+        raise ValueError("InputBlockV2: the schema has neither categorical nor continuous features")
+    return ParallelBlock(branches, aggregation=aggregation, name="input_block", schema=schema)

@@ -1,0 +1,217 @@
+"""Model factories of the kept ``mm`` surface (reference layer L5, merlin/models/tf/models/).
+
+``Model`` (base.py:311-1854) is reduced to what the hot path needs: ``model(batch)`` forward,
+``compile(optimizer=...)`` + ``train_step`` (base.py:1121-1174 without Keras machinery),
+``fit`` over an iterable of batches, ``evaluate``.  Factories: DLRMModel / DCNModel
+(ranking.py:23-168), TwoTowerModel / TwoTowerModelV2 (retrieval.py:106-486).
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import ops, optim
+from .blocks import CrossBlock, DLRMBlock, MLPBlock, TwoTowerBlock, _Dense
+from .core import Block, ConcatFeatures, ParallelBlock, SequentialBlock, TabularData, call_layer
+from .inputs import InputBlockV2, Ragged
+from .outputs import BinaryOutput, BruteForce, ContrastiveOutput, Prediction, TopKOutput
+from .schema import ColumnSchema, Schema, Tags
+
+
+def prepare_features(inputs: TabularData) -> TabularData:
+    """The part of PrepareFeatures the hot path relies on (tf/transforms/features.py:324-379):
+    ``name__values`` + ``name__offsets`` -> one ragged feature ``name``; 1-D scalars -> [B, 1]."""
+    out: TabularData = {}
+    for k, v in inputs.items():
+        if k.endswith("__values"):
+            name = k[: -len("__values")]
+            out[name] = Ragged(v, inputs[name + "__offsets"])
+        elif k.endswith("__offsets"):
+            continue
+        elif isinstance(v, torch.Tensor) and v.dim() == 1:
+            out[k] = v.unsqueeze(-1)
+        else:
+            out[k] = v
+    return out
+
+
+class Model(Block):
+    """Sequence of blocks ending in an output head (models/base.py:1805-1854 ``Model.call``)."""
+
+    def __init__(self, *blocks: Block, schema: Optional[Schema] = None, name: Optional[str] = None):
+        super().__init__(name)
+        self.blocks: List[Block] = list(blocks)
+        self.schema = schema
+        self.optimizer: Optional[optim.Optimizer] = None
+
+    def children(self):
+        return self.blocks
+
+    @property
+    def output_block(self) -> Block:
+        return self.blocks[-1]
+
+    def forward(self, inputs: TabularData, targets=None, training: bool = False, testing: bool = False):
+        x = prepare_features(inputs)
+        feats = x
+        for block in self.blocks:
+            x = call_layer(block, x, features=feats, targets=targets, training=training, testing=testing)
+        return x
+
+    def __call__(self, inputs, targets=None, training: bool = False, testing: bool = False):
+        return self.forward(inputs, targets=targets, training=training, testing=testing)
+
+    # --- training (models/base.py:311-508, 1121-1174) ---
+    def compile(self, optimizer: Union[str, "optim.Optimizer"] = "adagrad", **kwargs) -> "Model":
+        self.optimizer = optim.get(optimizer, **kwargs)
+        return self
+
+    def train_step(self, inputs: TabularData, targets: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def fit(self, batches: Iterable[Tuple[TabularData, torch.Tensor]], epochs: int = 1, steps_per_epoch: Optional[int] = None):
+        """Minimal fit loop; samples/sec follows ExamplesPerSecondCallback
+        (tf/logging/callbacks.py:174-189): batch_size * steps / elapsed, first step discarded."""
+        if self.optimizer is None:
+            self.compile()
+        history = {"loss": [], "examples_per_sec": []}
+        for _ in range(epochs):
+            t0, n, steps, last = None, 0, 0, None
+            for step, (x, y) in enumerate(batches):
+                if steps_per_epoch is not None and step >= steps_per_epoch:
+                    break
+                last = self.train_step(x, y)
+                if step == 0:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                else:
+                    n += y.shape[0]
+                    steps += 1
+            torch.cuda.synchronize()
+            if last is not None:
+                history["loss"].append(float(last))
+            if t0 is not None and steps:
+                history["examples_per_sec"].append(n / (time.perf_counter() - t0))
+        return history
+
+
+class RankingModel(Model):
+    """input/body block -> BinaryOutput; train_step = fwd, BCE, explicit bwd, fused updates."""
+
+    def __init__(self, body: Block, output: BinaryOutput, schema: Schema, name: Optional[str] = None):
+        super().__init__(body, output, schema=schema, name=name)
+        self.body, self.output = body, output
+
+    def train_step(self, inputs: TabularData, targets: torch.Tensor) -> torch.Tensor:
+        if self.optimizer is None:
+            self.compile()
+        x = prepare_features(inputs)
+        h = self.body(x)
+        p = self.output(h)
+        loss, dlogit = self.output.loss_and_grad(p, targets)
+        dh = self.output.backward(dlogit)
+        self.body.backward(dh)
+        self.optimizer.apply(self)
+        return loss
+
+
+def _target_column(schema: Schema) -> Optional[ColumnSchema]:
+    t = schema.select_by_tag(Tags.TARGET)
+    return t.first if len(t) else None
+
+
+def DLRMModel(schema: Schema, *, embedding_dim: Optional[int] = None, embeddings=None,
+              bottom_block: Optional[Block] = None, top_block: Optional[Block] = None,
+              prediction_tasks: Optional[BinaryOutput] = None, device=None) -> RankingModel:
+    """ranking.py:23-92."""
+    body = DLRMBlock(schema, embedding_dim=embedding_dim, embeddings=embeddings, bottom_block=bottom_block,
+                     top_block=top_block, device=device)
+    head = prediction_tasks or BinaryOutput(_target_column(schema), device=device)
+    return RankingModel(body, head, schema, name="dlrm_model")
+
+
+class DCNBody(Block):
+    """ranking.py:159-168: InputBlockV2 (concat) -> CrossBlock -> deep MLP (stacked) or
+    concat(cross, deep) (parallel)."""
+
+    def __init__(self, schema: Schema, depth: int, deep_block: Block, stacked: bool = True, input_block=None,
+                 embedding_dim: Optional[int] = None, device=None):
+        super().__init__("dcn_body")
+        self.input_block = input_block or InputBlockV2(schema, dim=embedding_dim, device=device)
+        self.cross = CrossBlock(depth, device=device)
+        self.deep = deep_block
+        self.stacked = stacked
+
+    def children(self):
+        return [self.input_block, self.cross, self.deep]
+
+    def forward(self, inputs: TabularData):
+        x = self.input_block(inputs)
+        if self.stacked:
+            return self.deep(self.cross(x))
+        return torch.cat([self.cross(x), self.deep(x)], dim=-1)
+
+
+def DCNModel(schema: Schema, depth: int, deep_block: Optional[Block] = None, stacked: bool = True,
+             input_block=None, embedding_dim: Optional[int] = None, prediction_tasks=None, device=None) -> RankingModel:
+    """ranking.py:95-168 (deep_block default MLPBlock([512, 256]), :98)."""
+    deep_block = deep_block or MLPBlock([512, 256], device=device)
+    body = DCNBody(schema, depth, deep_block, stacked, input_block, embedding_dim, device)
+    head = prediction_tasks or BinaryOutput(_target_column(schema), device=device)
+    return RankingModel(body, head, schema, name="dcn_model")
+
+
+class RetrievalModel(Model):
+    """TwoTower body -> ContrastiveOutput (retrieval.py:409-486; base.py:2491-2663)."""
+
+    def __init__(self, body: TwoTowerBlock, output: ContrastiveOutput, schema: Schema, name=None):
+        super().__init__(body, output, schema=schema, name=name)
+        self.body, self.output = body, output
+
+    def forward(self, inputs: TabularData, targets=None, training: bool = False, testing: bool = False):
+        x = prepare_features(inputs)
+        emb = self.body(x)
+        return self.output.forward({"query": emb["query"], "candidate": emb["item"]}, features=x,
+                                   training=training, testing=testing)
+
+    def query_embeddings(self, inputs: TabularData) -> torch.Tensor:
+        return self.body.parallel_layers["query"](prepare_features(inputs))
+
+    def candidate_embeddings(self, inputs: TabularData) -> torch.Tensor:
+        return self.body.parallel_layers["item"](prepare_features(inputs))
+
+    def to_top_k_encoder(self, candidates: torch.Tensor, identifiers: Optional[torch.Tensor] = None, k: int = 10):
+        """base.py:2632-2663: query tower + TopKOutput(BruteForce.index(candidates, ids))."""
+        return TopKEncoder(self.body.parallel_layers["query"], TopKOutput(candidates=candidates, identifiers=identifiers, k=k))
+
+
+class TopKEncoder(Block):
+    """core/encoder.py:427-482."""
+
+    def __init__(self, query_encoder: Block, topk_layer: TopKOutput, name=None):
+        super().__init__(name)
+        self.query_encoder, self.topk_layer = query_encoder, topk_layer
+
+    def forward(self, inputs: TabularData, **kwargs):
+        return self.topk_layer(self.query_encoder(prepare_features(inputs)), **kwargs)
+
+
+def TwoTowerModel(schema: Schema, query_tower: Block, item_tower: Optional[Block] = None,
+                  query_tower_tag=Tags.USER, item_tower_tag=Tags.ITEM, embedding_dim: Optional[int] = None,
+                  samplers: Sequence[str] = (), logits_temperature: float = 1.0, l2_normalization: bool = False,
+                  downscore_false_negatives: bool = True, device=None) -> RetrievalModel:
+    """retrieval.py:106-203 (V1 route; same scorer math, item branch key "item")."""
+    if samplers and list(samplers) != ["in-batch"]:
+        raise NotImplementedError("only the in-batch sampler is on the HIP hot path")
+    body = TwoTowerBlock(schema, query_tower, item_tower, query_tower_tag, item_tower_tag, embedding_dim,
+                         l2_normalization, device)
+    item_id = schema.select_by_tag(Tags.ITEM_ID)
+    out = ContrastiveOutput(item_id.first if len(item_id) else None, "in-batch",
+                            downscore_false_negatives=downscore_false_negatives and len(item_id) > 0,
+                            logits_temperature=logits_temperature)
+    return RetrievalModel(body, out, schema, name="two_tower_model")
+
+
+TwoTowerModelV2 = TwoTowerModel

@@ -24,6 +24,50 @@ __all__ = [
 ]
 
 
+class _KernelTimer:
+    """Optional per-op HIP-event timing (bench.py): events are recorded on the stream the kernels
+    are launched on (torch's current stream), one (start, end) pair around each C-ABI call."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def enable(self):
+        self.enabled, self.events = True, {}
+
+    def disable(self):
+        self.enabled = False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"avg_ms": sum(ms) / len(ms), "launches": len(ms)}
+        return out
+
+
+TIMER = _KernelTimer()
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMER.enabled:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMER.enabled:
+            self.b.record()
+            TIMER.events.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -102,6 +146,8 @@ def embedding_gather(
         if out.dim() != 3 or out.shape[0] != B or out.shape[2] != D or not out.is_contiguous():
             raise ValueError("out must be contiguous [B, n_slots, D]")
     row_stride = out.shape[1] * D
+    if B == 0:
+        return out
     for start in range(0, F, _lib.MAX_FEATURES):
         sl = slice(start, min(F, start + _lib.MAX_FEATURES))
         n = sl.stop - sl.start
@@ -109,10 +155,11 @@ def embedding_gather(
         idp = _host_ptr_array([i.data_ptr() for i in flat_ids[sl]])
         rows = (C.c_int64 * n)(*[w.shape[0] for w in tables[sl]])
         slot = (C.c_int32 * n)(*slots[sl])
-        check(
-            lib.mh_embedding_gather_fwd(tab, rows, idp, idt, B, n, D, _ptr(out), row_stride, slot, _stream()),
-            "mh_embedding_gather_fwd",
-        )
+        with _timed("embedding_gather"):
+            check(
+                lib.mh_embedding_gather_fwd(tab, rows, idp, idt, B, n, D, _ptr(out), row_stride, slot, _stream()),
+                "mh_embedding_gather_fwd",
+            )
     return out
 
 
@@ -203,11 +250,12 @@ def linear(
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     else:
         _rowmajor_2d(out, "out")
-    check(
-        lib.mh_linear_bias_act_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation],
-                                   _ptr(out), out.stride(0), _stream()),
-        "mh_linear_bias_act_fwd",
-    )
+    with _timed(f"linear_{K}x{N}"):
+        check(
+            lib.mh_linear_bias_act_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation],
+                                       _ptr(out), out.stride(0), _stream()),
+            "mh_linear_bias_act_fwd",
+        )
     return out
 
 
@@ -230,9 +278,10 @@ def dot_interaction(
         out = torch.empty((B, P + T), dtype=torch.float32, device=x.device)
     else:
         _rowmajor_2d(out, "out")
-    check(
-        lib.mh_dot_interaction_fwd(_ptr(x), B, F, D, _ptr(tail), 0 if tail is None else tail.stride(0), T,
-                                   _ptr(out), out.stride(0), _stream()),
-        "mh_dot_interaction_fwd",
-    )
+    with _timed("dot_interaction"):
+        check(
+            lib.mh_dot_interaction_fwd(_ptr(x), B, F, D, _ptr(tail), 0 if tail is None else tail.stride(0), T,
+                                       _ptr(out), out.stride(0), _stream()),
+            "mh_dot_interaction_fwd",
+        )
     return out

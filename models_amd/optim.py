@@ -1,0 +1,51 @@
+"""Optimizers of the explicit train step (models/base.py:476-508, 1121-1174).
+
+Dense parameters (MLP / cross / head weights) are updated by a HIP elementwise kernel; sparse
+parameters (embedding tables) are updated row-wise inside the fused embedding backward
+(``mh_embedding_gather_bwd``) and never see a dense gradient.
+"""
+from __future__ import annotations
+
+from typing import Union
+
+import torch
+
+
+class Optimizer:
+    name = "sgd"
+
+    def __init__(self, learning_rate: float = 0.01, epsilon: float = 1e-7, initial_accumulator_value: float = 0.1):
+        self.learning_rate = float(learning_rate)
+        self.epsilon = float(epsilon)
+        self.initial_accumulator_value = float(initial_accumulator_value)
+
+    def apply(self, model) -> None:
+        from . import ops
+
+        for p in model.parameters():
+            if p.sparse or not p.trainable or p.grad is None:
+                continue
+            ops.dense_optimizer_step(self, p)
+            p.grad = None
+
+
+class SGD(Optimizer):
+    name = "sgd"
+
+
+class Adagrad(Optimizer):
+    """keras Adagrad: acc += g^2; w -= lr * g / (sqrt(acc) + eps); acc0 = 0.1, eps = 1e-7."""
+
+    name = "adagrad"
+
+    def __init__(self, learning_rate: float = 0.001, **kw):
+        super().__init__(learning_rate, **kw)
+
+
+def get(opt: Union[str, Optimizer], **kwargs) -> Optimizer:
+    if isinstance(opt, Optimizer):
+        return opt
+    table = {"sgd": SGD, "adagrad": Adagrad}
+    if opt not in table:
+        raise ValueError(f"unknown optimizer {opt!r}; on the HIP path: {sorted(table)}")
+    return table[opt](**kwargs)
