@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
     ap.add_argument("--ids", choices=["uniform", "lognormal"], default="uniform")
+    ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16384)
     args = ap.parse_args()
@@ -118,10 +119,22 @@ def main():
     model, schema = build_model(device)
     batch, label = make_batch(device, args.batch, rank, args.ids)
 
-    def step():
+    from models_amd.graph import GraphedStep
+
+    static = dict(batch)
+    static["__label__"] = label
+
+    def eager(inp):
+        feats = {k: v for k, v in inp.items() if k != "__label__"}
         if args.mode == "fwd":
-            return model(batch)
-        return model.train_step(batch, label)
+            return model(feats)
+        return model.train_step(feats, inp["__label__"])
+
+    if args.eager:
+        step = lambda: eager(static)
+    else:
+        graphed = GraphedStep(eager, static)  # whole step captured once into a hipGraph
+        step = graphed.replay
 
     for _ in range(args.warmup):
         step()
@@ -133,13 +146,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.TIMER.enable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel durations: the same launches issued eagerly with a hipEvent pair around each
+    # C-ABI call on the launch stream (events cannot be read back from inside a replayed graph)
+    ops.TIMER.enable()
+    for _ in range(min(args.steps, 20)):
+        eager(static)
     kernel_ms = ops.TIMER.summary()
     ops.TIMER.disable()
     if world > 1:
@@ -167,7 +184,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: DLRM 26 cat (Criteo cardinalities capped 1M) + 13 dense, "
                                f"emb_dim=64, bottom [128,64], top [128,64,32], {args.mode}, ids={args.ids}",
                    "global_batch": world * B, "per_gpu_batch": B, "mode": args.mode,
-                   "parallelism": f"dp{world}"},
+                   "launch": "eager" if args.eager else "hipGraph replay", "parallelism": f"dp{world}"},
         "roofline": roofline,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
     }
