@@ -68,9 +68,10 @@ int32_t mh_device_info(int32_t* cu_count, int64_t* hbm_bytes);
  * (merlin/models/tf/inputs/embedding.py:424-471, one-hot branch :458-461) and
  * EmbeddingFeatures.lookup_feature (:1126-1156), for ALL features of a batch in ONE launch.
  * Feature f reads ids[f][b] (b < B) from table tables[f] ([table_rows[f], D] fp32) and writes
- *   out[b * out_row_stride + out_slot[f] * D + d]   (d < D)
+ *   out[b * out_row_stride + out_offset[f] + d]   (d < D; offsets in floats, multiples of 4)
  * i.e. directly into the stacked [B, F_total, D] layout StackFeatures would produce
- * (core/aggregation.py:101-108) when out_row_stride = F_total*D and out_slot = sorted-name rank.
+ * (core/aggregation.py:101-108) when out_row_stride = F_total*D and out_offset = rank*D of the
+ * sorted feature name -- or into the ConcatFeatures layout (aggregation.py:54-66).
  * Ids outside [0, table_rows[f]) produce a zero row (TF-GPU gather semantics).
  * D must be a multiple of 4 and <= 1024; F <= MH_MAX_FEATURES. */
 int32_t mh_embedding_gather_fwd(const float* const* tables /*HOST [F]*/,
@@ -78,7 +79,7 @@ int32_t mh_embedding_gather_fwd(const float* const* tables /*HOST [F]*/,
                                 const void* const* ids /*HOST [F] of device ptrs*/,
                                 int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
                                 float* out, int64_t out_row_stride,
-                                const int32_t* out_slot /*HOST [F]*/, mh_stream_t stream);
+                                const int64_t* out_offset /*HOST [F]*/, mh_stream_t stream);
 
 /* Multi-hot / ragged lookup with a string combiner: replaces
  * tf.nn.safe_embedding_lookup_sparse(W, sp_ids, None, combiner)
@@ -102,7 +103,8 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
 
 /* Backward of the one-hot lookup fused with the sparse optimizer step (the IndexedSlices
  * apply of BaseModel.train_step, models/base.py:1121-1174).  grad[b * grad_row_stride +
- * grad_slot[f]*D + d] is dL/d out.  Duplicate ids in a batch are summed BEFORE the update
+ * grad_offset[f] + d] is dL/d out (same layout as the forward).  Features whose table pointers
+ * coincide share one table (shared embeddings): their gradients are summed before the update.  Duplicate ids in a batch are summed BEFORE the update
  * (Keras _deduplicate_indexed_slices semantics).
  *   SGD:     W[r] -= lr * g[r]
  *   ADAGRAD: acc[r] += g[r]^2 ; W[r] -= lr * g[r] / (sqrt(acc[r]) + eps)   (keras Adagrad)
@@ -113,7 +115,7 @@ int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const*
                                 const int64_t* table_rows /*HOST [F]*/,
                                 const void* const* ids /*HOST [F]*/, int32_t ids_dtype,
                                 int64_t B, int32_t F, int32_t D, const float* grad,
-                                int64_t grad_row_stride, const int32_t* grad_slot /*HOST [F]*/,
+                                int64_t grad_row_stride, const int64_t* grad_offset /*HOST [F]*/,
                                 int32_t optimizer, float lr, float eps, void* workspace,
                                 int64_t workspace_bytes, mh_stream_t stream);
 
@@ -147,11 +149,12 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
 int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D,
                                const float* tail, int64_t ld_tail, int32_t T, float* out,
                                int64_t ldo, mh_stream_t stream);
-/* Backward: dx[B,F,D] = (G + G^T) x with G the upper-triangular matrix scattered from
- * dout[:, :P]; dtail[B,T] = dout[:, P:P+T] (skipped if dtail == NULL). */
+/* Backward: dx[B,F,D] = (G + G^T) x with G the strict-upper-triangular matrix scattered from
+ * dout[:, :P].  If tail_slot >= 0, the gradient of the appended shortcut copy dout[:, P:P+T]
+ * (T <= D) is added to dx[:, tail_slot, :T] in the same pass. */
 int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, int64_t B,
-                               int32_t F, int32_t D, float* dx, float* dtail, int64_t ld_dtail,
-                               int32_t T, mh_stream_t stream);
+                               int32_t F, int32_t D, float* dx, int32_t tail_slot, int32_t T,
+                               mh_stream_t stream);
 
 /* ---- a9: DCN-v2 cross layer  out = x0 * (x W + b) + x ----------------------------------
  * Replaces Cross.call (blocks/cross.py:188-202) with a full-rank kernel W[d, d]
@@ -163,6 +166,11 @@ int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, cons
  * y = x / max(||x||_2, eps) per row  == tf.linalg.l2_normalize(x, axis=-1, epsilon=eps^2). */
 int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y,
                        mh_stream_t stream);
+
+/* DotProduct.call (outputs/base.py:307-310): out[m] = sum_n a[m,n] * b[m,n]  (positive scores;
+ * the inference branch of ContrastiveOutput, outputs/contrastive.py:221). */
+int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M,
+                       int32_t N, float* out, mh_stream_t stream);
 
 /* ---- a11-a13: in-batch sampled-softmax scorer ------------------------------------------
  * Replaces ItemRetrievalScorer.call_outputs (blocks/retrieval/base.py:283-429) /
@@ -211,6 +219,11 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
  * pre-sigmoid logit).  Either output may be NULL. */
 int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale,
                        float* loss, float* dlogit, mh_stream_t stream);
+
+/* ---- dense optimizer step for MLP / cross / head weights (models/base.py:1161) -----------
+ * SGD: w -= lr*g.  ADAGRAD (keras): state += g^2; w -= lr * g / (sqrt(state) + eps). */
+int32_t mh_dense_optimizer_step(float* w, const float* grad, float* state, int64_t n,
+                                int32_t optimizer, float lr, float eps, mh_stream_t stream);
 
 #ifdef __cplusplus
 }

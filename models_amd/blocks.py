@@ -259,15 +259,15 @@ class DLRMBlock(Block):
         if self.top_block is not None:
             grad = self.top_block.backward(grad)
         has_tail = self.bottom_block is not None and self.top_block is not None
-        dstack, dtail = self.interaction.backward(grad, D if has_tail else 0)
+        slot = self.slots["bottom_block"] if self.bottom_block is not None else -1
+        dstack = ops.dot_interaction_backward(self._stacked, grad, slot if has_tail else -1, D if has_tail else 0)
         if self.bottom_block is not None:
-            slot = self.slots["bottom_block"]
-            g = dstack[:, slot]
-            if dtail is not None:
-                g = g + dtail
-            self.bottom_block.backward(g.contiguous())
-        self._dstacked = dstack
-        return dstack
+            layers = self.bottom_block.layers if isinstance(self.bottom_block, SequentialBlock) else [self.bottom_block]
+            g = dstack[:, slot]  # strided [B, D] view; overwritten in place by the activation gradient
+            for i in range(len(layers) - 1, -1, -1):
+                g = layers[i].backward(g, need_dx=i > 0)
+        self.embeddings.set_pending_grad(dstack, {n: self.slots[n] * D for n in self.cat_names})
+        return None
 
 
 class Cross(Block):

@@ -19,7 +19,7 @@ struct GatherArgs {
     const float* table[MH_MAX_FEATURES];
     const void* ids[MH_MAX_FEATURES];
     int64_t rows[MH_MAX_FEATURES];
-    int32_t slot[MH_MAX_FEATURES];
+    int64_t offset[MH_MAX_FEATURES];  // float offset of the feature inside an output row
 };
 
 // grid.x = sample tiles, grid.y = feature.  block = 256 threads = (256/LPR) rows x LPR lanes.
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const GatherArgs args, 
     const int c = t - r_in * LPR;
     if (r_in >= rows_per_pass) return;
     const int64_t b0 = (int64_t)blockIdx.x * (rows_per_pass * R) + r_in;
-    float* __restrict__ obase = out + (int64_t)args.slot[f] * (LPR * 4) + c * 4;
+    float* __restrict__ obase = out + args.offset[f] + c * 4;
 
     int64_t id[R];
 #pragma unroll
@@ -178,8 +178,8 @@ extern "C" {
 int32_t mh_embedding_gather_fwd(const float* const* tables, const int64_t* table_rows,
                                 const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F,
                                 int32_t D, float* out, int64_t out_row_stride,
-                                const int32_t* out_slot, mh_stream_t stream) {
-    MH_REQUIRE(tables && table_rows && ids && out && out_slot, "mh_embedding_gather_fwd: null argument");
+                                const int64_t* out_offset, mh_stream_t stream) {
+    MH_REQUIRE(tables && table_rows && ids && out && out_offset, "mh_embedding_gather_fwd: null argument");
     MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_embedding_gather_fwd: F=%d outside [1,%d]", F,
                MH_MAX_FEATURES);
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_fwd: D=%d must be a multiple of 4 in [4,1024]", D);
@@ -192,11 +192,12 @@ int32_t mh_embedding_gather_fwd(const float* const* tables, const int64_t* table
     for (int f = 0; f < F; ++f) {
         MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_fwd: null table/ids for feature %d", f);
         MH_REQUIRE((reinterpret_cast<uintptr_t>(tables[f]) & 15) == 0, "mh_embedding_gather_fwd: table %d not 16-byte aligned", f);
-        MH_REQUIRE((int64_t)(out_slot[f] + 1) * D <= out_row_stride, "mh_embedding_gather_fwd: slot %d of feature %d exceeds out_row_stride", out_slot[f], f);
+        MH_REQUIRE(out_offset[f] >= 0 && out_offset[f] % 4 == 0 && out_offset[f] + D <= out_row_stride,
+                   "mh_embedding_gather_fwd: offset %lld of feature %d is misaligned or exceeds out_row_stride", (long long)out_offset[f], f);
         a.table[f] = tables[f];
         a.ids[f] = ids[f];
         a.rows[f] = table_rows[f];
-        a.slot[f] = out_slot[f];
+        a.offset[f] = out_offset[f];
     }
     const int LPR = D / 4;
     constexpr int R = 8;

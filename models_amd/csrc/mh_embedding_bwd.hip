@@ -1,0 +1,263 @@
+// Backward of the one-hot embedding lookup fused with the sparse optimizer step (gfx950).
+// Reference: the IndexedSlices branch of BaseModel.train_step (merlin/models/tf/models/base.py:
+// 1121-1174): Keras sums duplicate indices first (_deduplicate_indexed_slices) and then applies
+// the optimizer row-wise, so the update must see the SUM of a row's gradients exactly once.
+//
+// Pipeline (all on one stream, no host sync):
+//   1. build 64-bit keys (table << 40 | id) + packed (feature, sample) for every (feature, sample)
+//      -- features sharing one table share its key space, so shared rows are updated once;
+//      out-of-range ids get the all-ones sentinel and sort to the end;
+//   2. rocPRIM radix sort of the (key, sample) pairs (46 key bits) -- library plumbing;
+//   3. segmented reduce over fixed chunks of 16 sorted entries: one D/4-lane group per chunk sums
+//      the gradient rows of each run in registers; a run wholly inside the chunk is applied to
+//      the table row directly (exclusive owner, no atomics); a run crossing a chunk boundary adds
+//      its piece to carry[home chunk] (home = chunk holding the run's first entry, found by a
+//      binary search for continuing runs) -- long runs of hot ids are pre-summed 16:1;
+//   4. each chunk that is home to a crossing run applies the carried sum.
+// HBM traffic: grad rows read once (random), table (+state) rows read+written once per UNIQUE id.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "mh_common.h"
+
+namespace {
+
+constexpr int CHUNK = 16;
+constexpr uint64_t SENTINEL = ~0ull;
+constexpr int KEY_BITS = 46;
+constexpr uint64_t ID_MASK = (1ull << 40) - 1;
+
+struct BwdArgs {
+    float* table[MH_MAX_FEATURES];
+    float* state[MH_MAX_FEATURES];
+    const void* ids[MH_MAX_FEATURES];
+    int64_t rows[MH_MAX_FEATURES];
+    int64_t offset[MH_MAX_FEATURES];  // float offset of the feature inside a grad row
+    int32_t tid[MH_MAX_FEATURES];  // first feature sharing the same table (shared embeddings)
+};
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void build_keys_kernel(const BwdArgs a, int64_t B, int F,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * F) return;
+    const int f = (int)(idx / B);
+    const int64_t b = idx - (int64_t)f * B;
+    const int64_t id = (int64_t) static_cast<const IdT*>(a.ids[f])[b];
+    const bool ok = id >= 0 && id < a.rows[f];
+    keys[idx] = ok ? (((uint64_t)a.tid[f] << 40) | (uint64_t)id) : SENTINEL;
+    vals[idx] = ((uint32_t)f << 26) | (uint32_t)b;
+}
+
+__device__ __forceinline__ void apply_update(const BwdArgs& a, uint64_t key, f32x4 g, int D, int c4, int opt,
+                                             float lr, float eps) {
+    const int f = (int)(key >> 40);
+    const int64_t id = (int64_t)(key & ID_MASK);
+    float* w = a.table[f] + id * D + c4 * 4;
+    f32x4 wv = *reinterpret_cast<f32x4*>(w);
+    if (opt == MH_OPT_ADAGRAD) {
+        float* st = a.state[f] + id * D + c4 * 4;
+        f32x4 sv = *reinterpret_cast<f32x4*>(st);
+        sv += g * g;
+        *reinterpret_cast<f32x4*>(st) = sv;
+        wv.x -= lr * g.x / (sqrtf(sv.x) + eps);
+        wv.y -= lr * g.y / (sqrtf(sv.y) + eps);
+        wv.z -= lr * g.z / (sqrtf(sv.z) + eps);
+        wv.w -= lr * g.w / (sqrtf(sv.w) + eps);
+    } else {
+        wv -= g * lr;
+    }
+    *reinterpret_cast<f32x4*>(w) = wv;
+}
+
+__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ keys, int64_t n, uint64_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
+                                                                  const uint32_t* __restrict__ vals, int64_t n,
+                                                                  int D, int LPR, const float* __restrict__ grad,
+                                                                  int64_t grad_row_stride, float* __restrict__ carry,
+                                                                  int opt, float lr, float eps) {
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    if (gi >= groups) return;
+    const int64_t chunk = (int64_t)blockIdx.x * groups + gi;
+    const int64_t c0 = chunk * CHUNK;
+    if (c0 >= n) return;
+    const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
+
+    uint64_t cur = keys[c0];
+    if (cur == SENTINEL) return;
+    int64_t run_start = c0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+    auto flush = [&](uint64_t key, int64_t s, int64_t e) {
+        const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
+        const bool ends_here = (e < c1) || (e == n) || (keys[e] != key);
+        if (starts_here && ends_here) {
+            apply_update(a, key, acc, D, c4, opt, lr, eps);
+        } else {
+            const int64_t home = starts_here ? chunk : lower_bound_u64(keys, c0, key) / CHUNK;
+            float* cr = carry + home * D + c4 * 4;
+            atomicAdd(cr + 0, acc.x);
+            atomicAdd(cr + 1, acc.y);
+            atomicAdd(cr + 2, acc.z);
+            atomicAdd(cr + 3, acc.w);
+        }
+    };
+
+    int64_t i = c0;
+    for (; i < c1; ++i) {
+        const uint64_t k = keys[i];
+        if (k == SENTINEL) break;
+        if (k != cur) {
+            flush(cur, run_start, i);
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            cur = k;
+            run_start = i;
+        }
+        const uint32_t v = vals[i];
+        const int f = (int)(v >> 26);
+        const float* g = grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + a.offset[f] + c4 * 4;
+        acc += *reinterpret_cast<const f32x4*>(g);
+    }
+    flush(cur, run_start, i);
+}
+
+__global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
+                                                         int64_t n, int D, int LPR, const float* __restrict__ carry,
+                                                         int opt, float lr, float eps) {
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    if (gi >= groups) return;
+    const int64_t chunk = (int64_t)blockIdx.x * groups + gi;
+    const int64_t c0 = chunk * CHUNK;
+    if (c0 >= n) return;
+    const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
+    if (c1 == n) return;  // the last chunk cannot be crossed
+    const uint64_t key = keys[c1 - 1];
+    if (key == SENTINEL || keys[c1] != key) return;  // last run ends here
+    int64_t s = c1 - 1;
+    while (s > c0 && keys[s - 1] == key) --s;
+    const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
+    if (!starts_here) return;  // an earlier chunk is this run's home
+    const f32x4 g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
+    apply_update(a, key, g, D, c4, opt, lr, eps);
+}
+
+struct WsLayout {
+    int64_t n, nchunks;
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_tmp, tmp_bytes, total;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
+    L->n = B * F;
+    L->nchunks = mh_ceil_div(L->n, CHUNK);
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, KEY_BITS);
+    if (e != hipSuccess) return false;
+    size_t o = 0;
+    L->off_keys_a = o; o = align_up(o + (size_t)L->n * 8, 256);
+    L->off_keys_b = o; o = align_up(o + (size_t)L->n * 8, 256);
+    L->off_vals_a = o; o = align_up(o + (size_t)L->n * 4, 256);
+    L->off_vals_b = o; o = align_up(o + (size_t)L->n * 4, 256);
+    L->off_carry = o; o = align_up(o + (size_t)L->nchunks * D * 4, 256);
+    L->off_tmp = o; L->tmp_bytes = tmp; o = align_up(o + tmp, 256);
+    L->total = o;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D) {
+    if (B <= 0 || F <= 0 || D <= 0) return 0;
+    WsLayout L;
+    if (!ws_layout(B, F, D, &L)) return -1;
+    return (int64_t)L.total;
+}
+
+int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const int64_t* table_rows,
+                                const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
+                                const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
+                                int32_t optimizer, float lr, float eps, void* workspace, int64_t workspace_bytes,
+                                mh_stream_t stream) {
+    MH_REQUIRE(tables && table_rows && ids && grad && grad_offset, "mh_embedding_gather_bwd: null argument");
+    MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_embedding_gather_bwd: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_bwd: D=%d must be a multiple of 4 in [4,1024]", D);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_gather_bwd: bad ids_dtype");
+    MH_REQUIRE(optimizer == MH_OPT_SGD || optimizer == MH_OPT_ADAGRAD, "mh_embedding_gather_bwd: bad optimizer %d", optimizer);
+    MH_REQUIRE(optimizer == MH_OPT_SGD || state, "mh_embedding_gather_bwd: Adagrad needs state tables");
+    MH_REQUIRE(grad_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0,
+               "mh_embedding_gather_bwd: grad must be 16-byte aligned with grad_row_stride %% 4 == 0");
+    if (B <= 0) return MH_OK;
+    MH_REQUIRE(B < (1ll << 26), "mh_embedding_gather_bwd: B must be < 2^26");
+    WsLayout L;
+    MH_REQUIRE(ws_layout(B, F, D, &L), "mh_embedding_gather_bwd: rocprim size query failed");
+    if (!workspace || workspace_bytes < (int64_t)L.total) {
+        mh_set_error("mh_embedding_gather_bwd: workspace too small (%lld < %zu)", (long long)workspace_bytes, L.total);
+        return MH_ERR_WORKSPACE;
+    }
+    BwdArgs a;
+    for (int f = 0; f < F; ++f) {
+        MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_bwd: null table/ids for feature %d", f);
+        MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_gather_bwd: null Adagrad state for feature %d", f);
+        a.table[f] = tables[f];
+        a.state[f] = state ? state[f] : nullptr;
+        a.ids[f] = ids[f];
+        a.rows[f] = table_rows[f];
+        MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && grad_offset[f] + D <= grad_row_stride,
+                   "mh_embedding_gather_bwd: grad offset of feature %d misaligned or out of row", f);
+        a.offset[f] = grad_offset[f];
+        a.tid[f] = f;
+        for (int g = 0; g < f; ++g)
+            if (tables[g] == tables[f]) {
+                a.tid[f] = g;
+                break;
+            }
+    }
+    char* ws = static_cast<char*>(workspace);
+    uint64_t* keys_a = reinterpret_cast<uint64_t*>(ws + L.off_keys_a);
+    uint64_t* keys_b = reinterpret_cast<uint64_t*>(ws + L.off_keys_b);
+    uint32_t* vals_a = reinterpret_cast<uint32_t*>(ws + L.off_vals_a);
+    uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + L.off_vals_b);
+    float* carry = reinterpret_cast<float*>(ws + L.off_carry);
+    hipStream_t s = mh_stream(stream);
+
+    dim3 gk((unsigned)mh_ceil_div(L.n, 256));
+    if (ids_dtype == MH_I32)
+        hipLaunchKernelGGL((build_keys_kernel<int32_t>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a);
+    else
+        hipLaunchKernelGGL((build_keys_kernel<int64_t>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a);
+    size_t tmp_bytes = L.tmp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)L.n, 0,
+                                             KEY_BITS, s);
+    if (e != hipSuccess) {
+        mh_set_error("mh_embedding_gather_bwd: radix sort failed: %s", hipGetErrorString(e));
+        return MH_ERR_LAUNCH;
+    }
+    (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
+    const int LPR = D / 4;
+    const int groups = 256 / LPR;
+    dim3 gs((unsigned)mh_ceil_div(L.nchunks, groups));
+    hipLaunchKernelGGL(segment_reduce_apply_kernel, gs, dim3(256), 0, s, a, keys_b, vals_b, L.n, D, LPR, grad,
+                       grad_row_stride, carry, optimizer, lr, eps);
+    hipLaunchKernelGGL(carry_apply_kernel, gs, dim3(256), 0, s, a, keys_b, L.n, D, LPR, carry, optimizer, lr, eps);
+    MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
+    return MH_OK;
+}
+
+}  // extern "C"

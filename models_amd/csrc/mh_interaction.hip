@@ -107,6 +107,111 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
     }
 }
 
+
+// ---- backward -----------------------------------------------------------------------------------
+// dX = (G + G^T) X with G the strict-upper-triangular matrix scattered from dout[:, :P].
+// One wavefront per sample: S = G + G^T ([32][34] fp32 in LDS, zero diagonal / padding) is the
+// MFMA A operand, X ([32][D+16]) the B operand; 2 x D/16 output tiles of 16x16, contraction over
+// the 32 (padded) features in 8 steps of 4.  If tail_slot >= 0 the gradient of the appended
+// shortcut copy, dout[:, P:P+T], is added to dX[:, tail_slot, :T] in the same pass.
+constexpr int LDS_S = 34;
+
+__global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dout, int64_t ldo,
+                                                                 int64_t B, int F, int D, float* __restrict__ dx,
+                                                                 int tail_slot, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = D + 16;
+    const int P = F * (F - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);        // [512]
+    unsigned char* pair_j = pair_i + 512;                                  // [512]
+    float* base = smem + 256;                                              // 1024 B of pair tables
+    float* Xs = base + wave * (IMAXF * LD + IMAXF * LDS_S);
+    float* Ss = Xs + IMAXF * LD;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int vpr = D / 4, nvec = F * vpr;
+
+    for (int p = threadIdx.x; p < P; p += 256) {
+        // invert p = i(2F-i-1)/2 + (j-i-1) by scanning rows (P <= 496)
+        int i = 0, start = 0;
+        while (start + (F - 1 - i) <= p) {
+            start += F - 1 - i;
+            ++i;
+        }
+        pair_i[p] = (unsigned char)i;
+        pair_j[p] = (unsigned char)(i + 1 + (p - start));
+    }
+    for (int idx = lane; idx < IMAXF * LDS_S; idx += 64) Ss[idx] = 0.f;
+    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+    __syncthreads();
+
+    const int64_t nblk = (B + 3) / 4;
+    for (int64_t it = blockIdx.x; it < nblk; it += gridDim.x) {
+        const int64_t b = it * 4 + wave;
+        const bool live = b < B;
+        __syncthreads();
+        if (live) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + b * (int64_t)F * D);
+            for (int idx = lane; idx < nvec; idx += 64) {
+                const int r = idx / vpr, c4 = idx - r * vpr;
+                *reinterpret_cast<f32x4*>(Xs + r * LD + c4 * 4) = src[idx];
+            }
+            const float* g = dout + b * ldo;
+            for (int p = lane; p < P; p += 64) {
+                const float v = g[p];
+                const int i = pair_i[p], j = pair_j[p];
+                Ss[i * LDS_S + j] = v;
+                Ss[j * LDS_S + i] = v;
+            }
+        }
+        __syncthreads();
+        if (!live) continue;
+        float* drow = dx + b * (int64_t)F * D;
+        const float* g = dout + b * ldo;
+        const int nti = F > 16 ? 2 : 1;
+        for (int tn = 0; tn < D / 16; ++tn) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int kk = 4 * st + q;
+                const float bv = Xs[kk * LD + 16 * tn + i16];
+                const float a0 = Ss[i16 * LDS_S + kk];
+                acc0 = mfma16(a0, bv, acc0);
+                if (nti == 2) {
+                    const float a1 = Ss[(16 + i16) * LDS_S + kk];
+                    acc1 = mfma16(a1, bv, acc1);
+                }
+            }
+            const int d = 16 * tn + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f0 = q * 4 + r;
+                if (f0 < F) {
+                    float v = acc0[r];
+                    if (f0 == tail_slot && d < T) v += g[P + d];
+                    drow[f0 * D + d] = v;
+                }
+                const int f1 = 16 + f0;
+                if (nti == 2 && f1 < F) {
+                    float v = acc1[r];
+                    if (f1 == tail_slot && d < T) v += g[P + d];
+                    drow[f1 * D + d] = v;
+                }
+            }
+        }
+        // tail columns beyond the last multiple of 16 of D (D % 16 != 0)
+        for (int d = (D / 16) * 16 + i16; d < D; d += 16) {
+            for (int f = q; f < F; f += 4) {
+                float v = 0.f;
+                for (int kk = 0; kk < F; ++kk) v = fmaf(Ss[f * LDS_S + kk], Xs[kk * LD + d], v);
+                if (f == tail_slot && d < T) v += g[P + d];
+                drow[f * D + d] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -138,6 +243,34 @@ int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, 
     hipLaunchKernelGGL(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
                        tail, ld_tail, T, out, ldo);
     MH_CHECK_LAUNCH("mh_dot_interaction_fwd");
+    return MH_OK;
+}
+
+int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, int64_t B, int32_t F,
+                               int32_t D, float* dx, int32_t tail_slot, int32_t T, mh_stream_t stream) {
+    MH_REQUIRE(x && dout && dx, "mh_dot_interaction_bwd: null argument");
+    MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dot_interaction_bwd: F=%d outside [2,%d]", F, IMAXF);
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 256, "mh_dot_interaction_bwd: D=%d must be a multiple of 4 in [4,256]", D);
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "mh_dot_interaction_bwd: x must be 16-byte aligned");
+    const int P = F * (F - 1) / 2;
+    if (tail_slot < 0) T = 0;
+    MH_REQUIRE(tail_slot < F && T >= 0 && T <= D && ldo >= P + T, "mh_dot_interaction_bwd: bad tail_slot/T/ldo");
+    if (B <= 0) return MH_OK;
+    const size_t lds = 1024 + (size_t)4 * (IMAXF * (D + 16) + IMAXF * LDS_S) * sizeof(float);
+    const int64_t want = mh_ceil_div(B, 4);
+    const int64_t cap = (int64_t)mh_num_cus() * 8;
+    dim3 grid((unsigned)(want < cap ? want : cap));
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dot_interaction_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            mh_set_error("mh_dot_interaction_bwd: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return MH_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(dot_interaction_bwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, dout, ldo, B, F, D,
+                       dx, tail_slot, T);
+    MH_CHECK_LAUNCH("mh_dot_interaction_bwd");
     return MH_OK;
 }
 

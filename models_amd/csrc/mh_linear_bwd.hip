@@ -1,0 +1,290 @@
+// Backward of the Dense layer (gfx950, fp32 MFMA).
+// Reference: the GradientTape backward of keras Dense inside BaseModel.train_step
+// (merlin/models/tf/models/base.py:1121-1174); forward at blocks/mlp.py:275-280.
+//
+//   dz = dy * act'(y)                      (in place; per-block column sums -> db partials)
+//   dx[M,K] = dz[M,N] W[K,N]^T             "NT" GEMM, contraction over N
+//   dW[K,N] = x[M,K]^T dz[M,N]             "TN" GEMM, contraction over the batch: split over M
+//                                          into S slices, partial [S,K,N] slabs, fixed-order reduce
+// Every reduction has a fixed order (no float atomics): results are run-to-run deterministic.
+#include "mh_gemm_core.h"
+
+using namespace mhgemm;
+
+namespace {
+
+constexpr int ACT_ROWS = 256;  // rows per act-grad block
+
+// dz in place + column partial sums.  block = 256 threads = RG row groups x CW columns
+// (CW = 32/64/128/256 >= min(N,256)); row-group partials are combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __restrict__ y, int64_t ldy,
+                                                             float* __restrict__ dy, int64_t lddy,
+                                                             int64_t M, int N, int act, int CW,
+                                                             float* __restrict__ db_partial) {
+    __shared__ float red[256];
+    const int RG = 256 / CW;
+    const int rg = threadIdx.x / CW, c = threadIdx.x - rg * CW;
+    const int64_t r0 = (int64_t)blockIdx.x * ACT_ROWS;
+    const int64_t r1 = (r0 + ACT_ROWS < M) ? r0 + ACT_ROWS : M;
+    for (int n0 = 0; n0 < N; n0 += CW) {
+        const int n = n0 + c;
+        float s = 0.f;
+        if (n < N) {
+            for (int64_t r = r0 + rg; r < r1; r += RG) {
+                float g = dy[r * lddy + n];
+                if (act == MH_ACT_RELU) {
+                    g = (y[r * ldy + n] > 0.f) ? g : 0.f;
+                    dy[r * lddy + n] = g;
+                } else if (act == MH_ACT_SIGMOID) {
+                    const float yy = y[r * ldy + n];
+                    g = g * yy * (1.f - yy);
+                    dy[r * lddy + n] = g;
+                }
+                s += g;
+            }
+        }
+        if (db_partial) {
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (rg == 0 && n < N) {
+                float t = 0.f;
+                for (int k = 0; k < RG; ++k) t += red[k * CW + c];
+                db_partial[(int64_t)blockIdx.x * N + n] = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[i] = sum_s part[s*len + i] in ascending s (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int S,
+                                                             int64_t len, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(int64_t)k * len + i];
+    out[i] = s;
+}
+
+// C[M, Nout] = A[M, Kc] * B[Nout, Kc]^T   (both operands contraction-contiguous)
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
+                                                     const float* __restrict__ Bm, int64_t ldb, int64_t M,
+                                                     int Nout, int Kc, float* __restrict__ Cm, int64_t ldc,
+                                                     int vec_a, int vec_b) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
+    float* As0 = smem;
+    float* As1 = smem + BM * LDK;
+    float* Bs0 = smem + 2 * BM * LDK;
+    float* Bs1 = Bs0 + BN * LDK;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    KMajorTile<BM> ta;
+    KMajorTile<BN> tb;
+    f32x16 acc[TM][TN];
+    zero_acc<TM, TN>(acc);
+    const int nk = (Kc + BK - 1) / BK;
+    ta.load(A, lda, row0, M, 0, Kc, vec_a);
+    tb.load(Bm, ldb, n0, Nout, 0, Kc, vec_b);
+    ta.store(As0);
+    tb.store(Bs0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        float* Ac = (kt & 1) ? As1 : As0;
+        float* Bc = (kt & 1) ? Bs1 : Bs0;
+        float* An = (kt & 1) ? As0 : As1;
+        float* Bn = (kt & 1) ? Bs0 : Bs1;
+        if (more) {
+            ta.load(A, lda, row0, M, (kt + 1) * BK, Kc, vec_a);
+            tb.load(Bm, ldb, n0, Nout, (kt + 1) * BK, Kc, vec_b);
+        }
+        mma_ktile<TM, TN, true>(Ac, wm * TM * 32, Bc, wn * TN * 32, 0, acc);
+        if (more) {
+            ta.store(An);
+            tb.store(Bn);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + acc_col(lane);
+        if (col >= Nout) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
+                if (row < M) Cm[row * ldc + col] = acc[tm][tn][r];
+            }
+    }
+}
+
+// Split-M "TN" GEMM: part[s][K, N] = x[m in slice s][K]^T dz[m in slice s][N].
+// Both operands are staged n-major ([BK contraction rows][cols]); fragments are ds_read_b32.
+template <int BMO, int BNO>
+__global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ Z, int64_t ldz,
+                                                            int64_t M, int K, int N, int64_t rows_per_split,
+                                                            float* __restrict__ part, int vec_x, int vec_z) {
+    constexpr int TM = BMO / 2 / 32, TN = BNO / 2 / 32;  // waves 2 x 2
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * BMO + 2 * BK * BNO];
+    float* As0 = smem;
+    float* As1 = smem + BK * BMO;
+    float* Bs0 = smem + 2 * BK * BMO;
+    float* Bs1 = Bs0 + BK * BNO;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int k0 = blockIdx.x * BMO;  // output row tile (over K)
+    const int n0 = blockIdx.y * BNO;  // output col tile (over N)
+    const int s = blockIdx.z;
+    const int64_t m_beg = (int64_t)s * rows_per_split;
+    const int64_t m_end = (m_beg + rows_per_split < M) ? m_beg + rows_per_split : M;
+    const int nk = (int)((m_end - m_beg + BK - 1) / BK);
+
+    NMajorTile<BMO> ta;
+    NMajorTile<BNO> tb;
+    f32x16 acc[TM][TN];
+    zero_acc<TM, TN>(acc);
+    // NMajorTile::load(W, ldw, k0(contraction row start), K(contraction end), n0, N, vec)
+    auto lda_ = [&](int kt) { ta.load(X + m_beg * ldx, ldx, kt * BK, (int)(m_end - m_beg), k0, K, vec_x); };
+    auto ldb_ = [&](int kt) { tb.load(Z + m_beg * ldz, ldz, kt * BK, (int)(m_end - m_beg), n0, N, vec_z); };
+    if (nk > 0) {
+        lda_(0);
+        ldb_(0);
+        ta.store(As0);
+        tb.store(Bs0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        const float* Ac = (kt & 1) ? As1 : As0;
+        const float* Bc = (kt & 1) ? Bs1 : Bs0;
+        float* An = (kt & 1) ? As0 : As1;
+        float* Bn = (kt & 1) ? Bs0 : Bs1;
+        if (more) {
+            lda_(kt + 1);
+            ldb_(kt + 1);
+        }
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = Ac[(2 * st + h) * BMO + wm * TM * 32 + tm * 32 + l31];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn] = Bc[(2 * st + h) * BNO + wn * TN * 32 + tn * 32 + l31];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(a[tm], b[tn], acc[tm][tn]);
+        }
+        if (more) {
+            ta.store(An);
+            tb.store(Bn);
+        }
+        __syncthreads();
+    }
+    float* P = part + (int64_t)s * K * N;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + acc_col(lane);
+        if (col >= N) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = k0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
+                if (row < K) P[(int64_t)row * N + col] = acc[tm][tn][r];
+            }
+    }
+}
+
+struct BwdPlan {
+    int act_blocks;
+    int splits;
+    int64_t rows_per_split;
+    int64_t dw_floats, db_floats;
+};
+
+BwdPlan make_plan(int64_t M, int K, int N) {
+    BwdPlan p;
+    p.act_blocks = (int)mh_ceil_div(M, ACT_ROWS);
+    const int64_t tiles = mh_ceil_div(K, 64) * mh_ceil_div(N, 64);
+    int64_t want = mh_ceil_div(1024, tiles);             // ~4 blocks per CU
+    const int64_t max_by_rows = mh_ceil_div(M, 256);       // >= 256 rows (8 k-tiles) per split
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    int64_t rps = mh_ceil_div(M, want);
+    rps = mh_ceil_div(rps, BK) * BK;
+    p.rows_per_split = rps;
+    p.splits = (int)mh_ceil_div(M, rps);
+    p.dw_floats = (int64_t)p.splits * K * N;
+    p.db_floats = (int64_t)p.act_blocks * N;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mh_linear_bwd_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    const BwdPlan p = make_plan(M, K, N);
+    return (p.dw_floats + p.db_floats) * (int64_t)sizeof(float);
+}
+
+int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, const float* y, int64_t ldy,
+                               float* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t act,
+                               float* dx, int64_t lddx, float* dW, float* db, void* workspace,
+                               int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(x && W && dy && dW, "mh_linear_bias_act_bwd: null argument");
+    MH_REQUIRE(M >= 1 && K >= 1 && N >= 1, "mh_linear_bias_act_bwd: bad shape");
+    MH_REQUIRE(act == MH_ACT_NONE || y, "mh_linear_bias_act_bwd: y is required for the activation derivative");
+    MH_REQUIRE(ldx >= K && lddy >= N && (!dx || lddx >= K), "mh_linear_bias_act_bwd: bad leading dimension");
+    const BwdPlan p = make_plan(M, K, N);
+    MH_REQUIRE(workspace && workspace_bytes >= (p.dw_floats + p.db_floats) * (int64_t)sizeof(float),
+               "mh_linear_bias_act_bwd: workspace too small (%lld bytes given)", (long long)workspace_bytes);
+    hipStream_t s = mh_stream(stream);
+    float* ws_dw = static_cast<float*>(workspace);
+    float* ws_db = ws_dw + p.dw_floats;
+
+    if (act != MH_ACT_NONE || db) {
+        const int CW = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
+        hipLaunchKernelGGL(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
+                           act, CW, db ? ws_db : nullptr);
+        if (db)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 256)), dim3(256), 0, s,
+                               ws_db, p.act_blocks, (int64_t)N, db);
+    }
+    const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
+    if (dx) {
+        const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
+        if (K > 64) {
+            dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(K, 128));
+            hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, vec_dy, vec_w);
+        } else if (K > 32) {
+            dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
+            hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, vec_dy, vec_w);
+        } else {
+            dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
+            hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, vec_dy, vec_w);
+        }
+    }
+    {
+        const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
+        dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), (unsigned)p.splits);
+        hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
+                           p.rows_per_split, ws_dw, vec_x, vec_dy);
+        const int64_t len = (int64_t)K * N;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(len, 256)), dim3(256), 0, s, ws_dw,
+                           p.splits, len, dW);
+    }
+    MH_CHECK_LAUNCH("mh_linear_bias_act_bwd");
+    return MH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// Small HBM-bound kernels around the GEMMs: BCE head loss, L2 row normalisation, row-wise dot,
+// dense optimizer step.
+#include "mh_common.h"
+
+namespace {
+
+// keras binary_crossentropy on probabilities (BinaryOutput, outputs/classification.py:72-123):
+// clip to [1e-7, 1-1e-7]; dlogit = (p - y) * scale is the gradient w.r.t. the pre-sigmoid logit.
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, const float* __restrict__ label,
+                                                 int64_t M, float scale, float* __restrict__ loss,
+                                                 float* __restrict__ dlogit) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float pi = p[i], y = label[i];
+    if (loss) {
+        const float eps = 1e-7f;
+        const float pc = fminf(fmaxf(pi, eps), 1.f - eps);
+        loss[i] = -(y * logf(pc) + (1.f - y) * logf(1.f - pc));
+    }
+    if (dlogit) dlogit[i] = (pi - y) * scale;
+}
+
+// one 64-lane wavefront per row: tf.linalg.l2_normalize(x, axis=-1) = x * rsqrt(max(sum x^2, eps^2))
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int64_t M, int N, float eps,
+                                                    float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * N;
+    float s = 0.f;
+    for (int k = lane; k < N; k += 64) s = fmaf(xr[k], xr[k], s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float inv = rsqrtf(fmaxf(s, eps * eps));
+    for (int k = lane; k < N; k += 64) y[row * N + k] = xr[k] * inv;
+}
+
+// DotProduct.call (outputs/base.py:307-310): out[b] = sum_d a[b,d] * b[b,d], k-ascending per
+// 16-lane partial chains + shuffle tree.
+__global__ __launch_bounds__(256) void rowwise_dot_kernel(const float* __restrict__ a, int64_t lda,
+                                                         const float* __restrict__ b, int64_t ldb, int64_t M,
+                                                         int N, float* __restrict__ out) {
+    const int sub = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float s = 0.f;
+    if (row < M)
+        for (int k = sub; k < N; k += 16) s = fmaf(a[row * lda + k], b[row * ldb + k], s);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (row < M && sub == 0) out[row] = s;
+}
+
+// keras SGD: w -= lr*g ; keras Adagrad: acc += g^2 ; w -= lr * g / (sqrt(acc) + eps)
+__global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                       float* __restrict__ acc, int64_t n, int opt, float lr,
+                                                       float eps) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    if (opt == MH_OPT_ADAGRAD) {
+        const float a = acc[i] + gi * gi;
+        acc[i] = a;
+        w[i] -= lr * gi / (sqrtf(a) + eps);
+    } else {
+        w[i] -= lr * gi;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale, float* loss,
+                       float* dlogit, mh_stream_t stream) {
+    MH_REQUIRE(p && label, "mh_bce_fwd_bwd: null argument");
+    if (M <= 0) return MH_OK;
+    hipLaunchKernelGGL(bce_kernel, dim3((unsigned)mh_ceil_div(M, 256)), dim3(256), 0, mh_stream(stream), p, label,
+                       M, grad_scale, loss, dlogit);
+    MH_CHECK_LAUNCH("mh_bce_fwd_bwd");
+    return MH_OK;
+}
+
+int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y, mh_stream_t stream) {
+    MH_REQUIRE(x && y && N >= 1, "mh_l2norm_rows: bad argument");
+    if (M <= 0) return MH_OK;
+    hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, M, N,
+                       eps, y);
+    MH_CHECK_LAUNCH("mh_l2norm_rows");
+    return MH_OK;
+}
+
+int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M, int32_t N,
+                       float* out, mh_stream_t stream) {
+    MH_REQUIRE(a && b && out && N >= 1 && lda >= N && ldb >= N, "mh_rowwise_dot: bad argument");
+    if (M <= 0) return MH_OK;
+    hipLaunchKernelGGL(rowwise_dot_kernel, dim3((unsigned)mh_ceil_div(M, 16)), dim3(256), 0, mh_stream(stream), a,
+                       lda, b, ldb, M, N, out);
+    MH_CHECK_LAUNCH("mh_rowwise_dot");
+    return MH_OK;
+}
+
+int32_t mh_dense_optimizer_step(float* w, const float* grad, float* state, int64_t n, int32_t optimizer,
+                                float lr, float eps, mh_stream_t stream) {
+    MH_REQUIRE(w && grad, "mh_dense_optimizer_step: null argument");
+    MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state), "mh_dense_optimizer_step: bad optimizer/state");
+    if (n <= 0) return MH_OK;
+    hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), w,
+                       grad, state, n, optimizer, lr, eps);
+    MH_CHECK_LAUNCH("mh_dense_optimizer_step");
+    return MH_OK;
+}
+
+}  // extern "C"

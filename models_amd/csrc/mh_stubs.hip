@@ -8,28 +8,9 @@
 
 extern "C" {
 
-int64_t mh_embedding_bwd_workspace_bytes(int64_t, int32_t, int32_t) { return 0; }
-int32_t mh_embedding_gather_bwd(float* const*, float* const*, const int64_t*, const void* const*,
-                                int32_t, int64_t, int32_t, int32_t, const float*, int64_t,
-                                const int32_t*, int32_t, float, float, void*, int64_t, mh_stream_t) {
-    MH_STUB("mh_embedding_gather_bwd");
-}
-int64_t mh_linear_bwd_workspace_bytes(int64_t, int32_t, int32_t) { return 0; }
-int32_t mh_linear_bias_act_bwd(const float*, int64_t, const float*, const float*, int64_t, float*,
-                               int64_t, int64_t, int32_t, int32_t, int32_t, float*, int64_t, float*,
-                               float*, void*, int64_t, mh_stream_t) {
-    MH_STUB("mh_linear_bias_act_bwd");
-}
-int32_t mh_dot_interaction_bwd(const float*, const float*, int64_t, int64_t, int32_t, int32_t, float*,
-                               float*, int64_t, int32_t, mh_stream_t) {
-    MH_STUB("mh_dot_interaction_bwd");
-}
 int32_t mh_cross_layer_fwd(const float*, const float*, const float*, const float*, int64_t, int32_t,
                            float*, mh_stream_t) {
     MH_STUB("mh_cross_layer_fwd");
-}
-int32_t mh_l2norm_rows(const float*, int64_t, int32_t, float, float*, mh_stream_t) {
-    MH_STUB("mh_l2norm_rows");
 }
 int32_t mh_inbatch_softmax_fwd(const float*, const float*, const float*, const void*, const void*,
                                int32_t, int64_t, int64_t, int32_t, float, float, float*, int64_t,
@@ -45,9 +26,6 @@ int64_t mh_topk_workspace_bytes(int64_t, int64_t, int32_t) { return 0; }
 int32_t mh_topk_dot(const float*, const float*, const int32_t*, int64_t, int64_t, int32_t, int32_t,
                     float*, int32_t*, int32_t*, void*, int64_t, mh_stream_t) {
     MH_STUB("mh_topk_dot");
-}
-int32_t mh_bce_fwd_bwd(const float*, const float*, int64_t, float, float*, float*, mh_stream_t) {
-    MH_STUB("mh_bce_fwd_bwd");
 }
 
 }  // extern "C"

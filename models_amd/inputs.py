@@ -195,6 +195,42 @@ class EmbeddingsBlock(ParallelBlock):
     def tables(self) -> Dict[str, EmbeddingTable]:
         return self.parallel_layers  # type: ignore[return-value]
 
+    # --- training: fused backward + sparse optimizer step -------------------------------------
+    def set_pending_grad(self, grad: torch.Tensor, offsets: Dict[str, int]) -> None:
+        """``grad`` is a contiguous [B, ...] buffer; feature n's gradient row starts
+        ``offsets[n]`` floats into each row (same layout the forward wrote)."""
+        self._pending = (grad, offsets)
+
+    def backward(self, grad):
+        if isinstance(grad, dict):
+            raise NotImplementedError("dict-shaped embedding gradients: use the fused input block")
+        return None
+
+    def apply_sparse(self, opt) -> None:
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            return
+        grad, offsets = pending
+        self._pending = None
+        names = [n for n in offsets if n in self._last and self.feature_table[n].table.trainable]
+        for n in names:
+            if not self._is_onehot(self._last[n]):
+                raise NotImplementedError("backward of list / ragged lookups is not on the HIP path yet")
+        for d in sorted({self.feature_table[n].dim for n in names}):
+            grp = [n for n in names if self.feature_table[n].dim == d]
+            tabs = [self.feature_table[n].table for n in grp]
+            states = None
+            if opt.name == "adagrad":
+                for t in tabs:
+                    if "accumulator" not in t.state:
+                        t.state["accumulator"] = torch.full_like(t.data, opt.initial_accumulator_value)
+                states = [t.state["accumulator"] for t in tabs]
+            for start in range(0, len(grp), 64):
+                sl = slice(start, start + 64)
+                ops.embedding_gather_backward([t.data for t in tabs[sl]], None if states is None else states[sl],
+                                              [self._last[n] for n in grp[sl]], grad, [offsets[n] for n in grp[sl]],
+                                              opt.name, opt.learning_rate, opt.epsilon)
+
 
 def Embeddings(schema: Schema, dim: Optional[Union[Dict[str, int], int]] = None,
                infer_dim_fn: Callable[[ColumnSchema], int] = infer_embedding_dim,

@@ -110,6 +110,7 @@ def embedding_gather(
     out: Optional[torch.Tensor] = None,
     out_slot: Optional[Sequence[int]] = None,
     n_slots: Optional[int] = None,
+    out_offset: Optional[Sequence[int]] = None,
 ) -> torch.Tensor:
     """One-hot lookup of F features in one launch -> stacked ``[B, n_slots, D]``.
 
@@ -143,9 +144,12 @@ def embedding_gather(
         out = torch.empty((B, n_slots, D), dtype=torch.float32, device=tables[0].device)
     else:
         _dev(out, "out", torch.float32)
-        if out.dim() != 3 or out.shape[0] != B or out.shape[2] != D or not out.is_contiguous():
-            raise ValueError("out must be contiguous [B, n_slots, D]")
-    row_stride = out.shape[1] * D
+        if out_offset is None and (out.dim() != 3 or out.shape[2] != D):
+            raise ValueError("out must be [B, n_slots, D] (or pass out_offset for a [B, W] concat buffer)")
+        if out.shape[0] != B or not out.is_contiguous():
+            raise ValueError("out must be contiguous with B rows")
+    row_stride = out.numel() // max(B, 1)
+    offsets = [s_ * D for s_ in slots] if out_offset is None else [int(o) for o in out_offset]
     if B == 0:
         return out
     for start in range(0, F, _lib.MAX_FEATURES):
@@ -154,7 +158,7 @@ def embedding_gather(
         tab = _host_ptr_array([w.data_ptr() for w in tables[sl]])
         idp = _host_ptr_array([i.data_ptr() for i in flat_ids[sl]])
         rows = (C.c_int64 * n)(*[w.shape[0] for w in tables[sl]])
-        slot = (C.c_int32 * n)(*slots[sl])
+        slot = (C.c_int64 * n)(*offsets[sl])
         with _timed("embedding_gather"):
             check(
                 lib.mh_embedding_gather_fwd(tab, rows, idp, idt, B, n, D, _ptr(out), row_stride, slot, _stream()),
@@ -285,3 +289,157 @@ def dot_interaction(
             "mh_dot_interaction_fwd",
         )
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# backward / training ops
+# --------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
+    """Grow-only per-(device, tag) scratch buffers (caller-provided workspaces of the C ABI)."""
+    key = (str(device), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True):
+    """Backward of ``linear``: returns (dx | None, dW, db | None).  ``dy`` is overwritten with
+    dz = dy * act'(y) when an activation is given."""
+    lib = _lib.load()
+    _rowmajor_2d(x, "x")
+    _rowmajor_2d(dy, "dy")
+    M, K = x.shape
+    N = W.shape[1]
+    if dy.shape != (M, N):
+        raise ValueError(f"dy must be [{M}, {N}]")
+    if activation not in ACT:
+        raise ValueError(f"unsupported activation {activation!r}")
+    act = ACT[activation]
+    if act != 0:
+        _rowmajor_2d(y, "y")
+    dx = torch.empty((M, K), dtype=torch.float32, device=x.device) if need_dx else None
+    dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
+    db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
+    nbytes = lib.mh_linear_bwd_workspace_bytes(M, K, N)
+    ws = _workspace(nbytes, x.device, "linear_bwd")
+    with _timed(f"linear_bwd_{K}x{N}"):
+        check(
+            lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(y if act != 0 else None),
+                                       y.stride(0) if act != 0 else 0, _ptr(dy), dy.stride(0), M, K, N, act,
+                                       _ptr(dx), K, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+            "mh_linear_bias_act_bwd",
+        )
+    return dx, dW, db
+
+
+def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int = -1, tail_width: int = 0):
+    """dx[B,F,D] of ``dot_interaction``; the appended-tail gradient is folded into slot ``tail_slot``."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    _rowmajor_2d(dout, "dout")
+    B, F, D = x.shape
+    dx = torch.empty_like(x)
+    with _timed("dot_interaction_bwd"):
+        check(
+            lib.mh_dot_interaction_bwd(_ptr(x), _ptr(dout), dout.stride(0), B, F, D, _ptr(dx), tail_slot,
+                                       tail_width, _stream()),
+            "mh_dot_interaction_bwd",
+        )
+    return dx
+
+
+def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[Sequence[Optional[torch.Tensor]]],
+                              ids: Sequence[torch.Tensor], grad: torch.Tensor, grad_offset: Sequence[int],
+                              optimizer: str = "sgd", lr: float = 0.01, eps: float = 1e-7) -> None:
+    """Fused backward + sparse optimizer step for the one-hot lookup.  ``grad`` is a contiguous
+    ``[B, ...]`` buffer; feature f's gradient row starts ``grad_offset[f]`` floats into row b."""
+    lib = _lib.load()
+    F = len(tables)
+    if F == 0:
+        return
+    if F > _lib.MAX_FEATURES:
+        raise ValueError(f"at most {_lib.MAX_FEATURES} features per backward call")
+    _dev(grad, "grad", torch.float32)
+    if not grad.is_contiguous():
+        raise ValueError("grad must be contiguous")
+    B = grad.shape[0]
+    D = tables[0].shape[1]
+    row_stride = grad.numel() // max(B, 1)
+    idt = _ids_dtype(ids[0], "ids[0]")
+    flat = [i.reshape(-1) for i in ids]
+    tab = _host_ptr_array([w.data_ptr() for w in tables])
+    st = None
+    if optimizer == "adagrad":
+        if states is None or any(s is None for s in states):
+            raise ValueError("adagrad needs an accumulator per table")
+        st = _host_ptr_array([s.data_ptr() for s in states])
+    idp = _host_ptr_array([i.data_ptr() for i in flat])
+    rows = (C.c_int64 * F)(*[w.shape[0] for w in tables])
+    slot = (C.c_int64 * F)(*[int(s) for s in grad_offset])
+    nbytes = lib.mh_embedding_bwd_workspace_bytes(B, F, D)
+    if nbytes < 0:
+        raise _lib.MerlinHipError("mh_embedding_bwd_workspace_bytes failed")
+    ws = _workspace(nbytes, grad.device, "embedding_bwd")
+    with _timed("embedding_bwd"):
+        check(
+            lib.mh_embedding_gather_bwd(tab, st, rows, idp, idt, B, F, D, _ptr(grad), row_stride, slot,
+                                        _lib.OPT[optimizer], lr, eps, _ptr(ws), ws.numel(), _stream()),
+            "mh_embedding_gather_bwd",
+        )
+
+
+def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
+    """Mean binary cross-entropy of probabilities ``p`` (Keras semantics) and d(mean)/d(logit)."""
+    lib = _lib.load()
+    _dev(p, "p", torch.float32)
+    _dev(label, "label", torch.float32)
+    p, label = p.reshape(-1), label.reshape(-1)
+    M = p.shape[0]
+    loss = torch.empty_like(p)
+    dlogit = torch.empty_like(p) if need_grad else None
+    with _timed("bce"):
+        check(lib.mh_bce_fwd_bwd(_ptr(p), _ptr(label), M, 1.0 / max(M, 1), _ptr(loss), _ptr(dlogit), _stream()),
+              "mh_bce_fwd_bwd")
+    return loss.mean(), (None if dlogit is None else dlogit.reshape(-1, 1))
+
+
+def l2norm(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """tf.linalg.l2_normalize(x, axis=-1) (epsilon = 1e-12 on the squared norm)."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(lib.mh_l2norm_rows(_ptr(x), x.shape[0], x.shape[1], eps, _ptr(y), _stream()), "mh_l2norm_rows")
+    return y
+
+
+def rowwise_dot(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """sum(a * b, -1, keepdims=True)."""
+    lib = _lib.load()
+    _rowmajor_2d(a, "a")
+    _rowmajor_2d(b, "b")
+    if a.shape != b.shape:
+        raise ValueError("rowwise_dot: shape mismatch")
+    out = torch.empty((a.shape[0], 1), dtype=torch.float32, device=a.device)
+    check(lib.mh_rowwise_dot(_ptr(a), a.stride(0), _ptr(b), b.stride(0), a.shape[0], a.shape[1], _ptr(out), _stream()),
+          "mh_rowwise_dot")
+    return out
+
+
+def dense_optimizer_step(opt, p) -> None:
+    """In-place SGD / Adagrad step on a dense Parameter (``p.grad`` must be set)."""
+    lib = _lib.load()
+    state = None
+    if opt.name == "adagrad":
+        state = p.state.get("accumulator")
+        if state is None:
+            state = torch.full_like(p.data, opt.initial_accumulator_value)
+            p.state["accumulator"] = state
+    g = p.grad.contiguous()
+    check(lib.mh_dense_optimizer_step(_ptr(p.data), _ptr(g), _ptr(state), p.data.numel(), _lib.OPT[opt.name],
+                                      opt.learning_rate, opt.epsilon, _stream()), "mh_dense_optimizer_step")

@@ -27,6 +27,15 @@ class Optimizer:
                 continue
             ops.dense_optimizer_step(self, p)
             p.grad = None
+        for blk in _walk(model):
+            if hasattr(blk, "apply_sparse"):
+                blk.apply_sparse(self)
+
+
+def _walk(block):
+    yield block
+    for c in block.children():
+        yield from _walk(c)
 
 
 class SGD(Optimizer):

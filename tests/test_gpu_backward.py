@@ -1,0 +1,179 @@
+"""Backward / optimizer HIP kernels vs a plain PyTorch fp32 CPU reference."""
+import numpy as np
+import pytest
+import torch
+
+from models_amd import ops
+from tests import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 13, 128), (1000, 128, 64), (700, 415, 128), (129, 64, 32), (515, 32, 1), (65, 100, 200)])
+@pytest.mark.parametrize("act", [None, "relu", "sigmoid"])
+def test_linear_backward(device, M, K, N, act):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g, requires_grad=True)
+    W = (torch.randn(K, N, generator=g) * 0.2).requires_grad_()
+    b = (torch.randn(N, generator=g) * 0.1).requires_grad_()
+    dy = torch.randn(M, N, generator=g)
+    y = R.act(x @ W + b, act)
+    y.backward(dy)
+    yd = ops.linear(x.detach().to(device), W.detach().to(device), b.detach().to(device), act)
+    dx, dW, db = ops.linear_backward(x.detach().to(device), W.detach().to(device), yd, dy.clone().to(device), act)
+    tol = dict(atol=2e-4 * max(1.0, M / 256) ** 0.5, rtol=1e-4)
+    torch.testing.assert_close(dx.cpu(), x.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dW.cpu(), W.grad, **tol)
+    torch.testing.assert_close(db.cpu(), b.grad, **tol)
+
+
+def test_linear_backward_strided_dy_and_no_dx(device):
+    g = torch.Generator().manual_seed(1)
+    M, K, N = 260, 13, 64
+    x = torch.randn(M, K, generator=g)
+    W = (torch.randn(K, N, generator=g) * 0.2).requires_grad_()
+    big = torch.randn(M, 5, N, generator=g)
+    y = torch.relu(x @ W)
+    y.backward(big[:, 2])
+    bd = big.clone().to(device)
+    yd = ops.linear(x.to(device), W.detach().to(device), None, "relu")
+    dx, dW, db = ops.linear_backward(x.to(device), W.detach().to(device), yd, bd[:, 2], "relu", need_dx=False, need_db=False)
+    assert dx is None and db is None
+    torch.testing.assert_close(dW.cpu(), W.grad, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("F,D", [(27, 64), (5, 8), (16, 32), (17, 128), (3, 40)])
+@pytest.mark.parametrize("with_tail", [False, True])
+def test_dot_interaction_backward(device, F, D, with_tail):
+    g = torch.Generator().manual_seed(F * D)
+    B = 131
+    X = torch.randn(B, F, D, generator=g, requires_grad=True)
+    slot = F - 2
+    tail = X[:, slot] if with_tail else None
+    out = R.dot_interaction(X, tail)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    dx = ops.dot_interaction_backward(X.detach().to(device), dout.to(device), slot if with_tail else -1, D if with_tail else 0)
+    torch.testing.assert_close(dx.cpu(), X.grad, atol=2e-4 * max(1.0, D / 64), rtol=1e-4)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_embedding_backward_dedup_and_optimizers(device, opt, idt):
+    g = torch.Generator().manual_seed(5)
+    rows = [4, 1000, 37, 50000]  # tiny tables -> very long duplicate runs crossing many chunks
+    B, D, S = 3001, 64, 6
+    tabs = [torch.randn(r, D, generator=g) for r in rows]
+    ids = [torch.randint(0, r, (B,), generator=g).to(idt) for r in rows]
+    ids[1][:5] = torch.tensor([-1, rows[1], 7, 7, 7]).to(idt)  # OOR ids are skipped
+    grad = torch.randn(B, S, D, generator=g)
+    slots = [4, 0, 2, 5]
+    lr, eps, acc0 = 0.05, 1e-7, 0.1
+    exp_w, exp_acc = [], []
+    for t, i, s in zip(tabs, ids, slots):
+        i64 = i.long()
+        ok = (i64 >= 0) & (i64 < t.shape[0])
+        gsum = torch.zeros_like(t).index_add_(0, i64[ok], grad[ok][:, s])
+        touched = torch.zeros(t.shape[0], dtype=torch.bool)
+        touched[i64[ok]] = True
+        if opt == "sgd":
+            exp_w.append(t - lr * gsum)
+            exp_acc.append(None)
+        else:
+            acc = torch.full_like(t, acc0)
+            w2, a2 = R.adagrad_update(t, gsum, acc, lr, eps)
+            exp_w.append(torch.where(touched[:, None], w2, t))
+            exp_acc.append(torch.where(touched[:, None], a2, acc))
+    dt = [t.clone().to(device) for t in tabs]
+    st = [torch.full_like(t, acc0) for t in dt] if opt == "adagrad" else None
+    ops.embedding_gather_backward(dt, st, [i.to(device) for i in ids], grad.to(device), [s * D for s in slots], opt, lr, eps)
+    for k in range(len(rows)):
+        torch.testing.assert_close(dt[k].cpu(), exp_w[k], atol=2e-4, rtol=1e-4)
+        if opt == "adagrad":
+            torch.testing.assert_close(st[k].cpu(), exp_acc[k], atol=2e-3, rtol=1e-4)
+
+
+def test_embedding_backward_shared_table(device):
+    """Two features sharing one table: their gradients are summed before the single update."""
+    g = torch.Generator().manual_seed(6)
+    B, D = 500, 16
+    t = torch.randn(20, D, generator=g)
+    ia, ib = torch.randint(0, 20, (B,), generator=g), torch.randint(0, 20, (B,), generator=g)
+    grad = torch.randn(B, 2, D, generator=g)
+    gsum = torch.zeros_like(t).index_add_(0, ia, grad[:, 0]).index_add_(0, ib, grad[:, 1])
+    acc = torch.full_like(t, 0.1)
+    w2, _ = R.adagrad_update(t, gsum, acc, 0.1)
+    touched = torch.zeros(20, dtype=torch.bool)
+    touched[ia] = True
+    touched[ib] = True
+    td = t.clone().to(device)
+    sd = torch.full_like(td, 0.1)
+    ops.embedding_gather_backward([td, td], [sd, sd], [ia.to(device), ib.to(device)], grad.to(device), [0, D], "adagrad", 0.1, 1e-7)
+    torch.testing.assert_close(td.cpu(), torch.where(touched[:, None], w2, t), atol=2e-4, rtol=1e-4)
+
+
+def test_bce_matches_keras_definition(device):
+    g = torch.Generator().manual_seed(7)
+    p = torch.rand(1000, 1, generator=g)
+    p[:3, 0] = torch.tensor([0.0, 1.0, 0.5])
+    y = torch.randint(0, 2, (1000, 1), generator=g).float()
+    loss, dlogit = ops.bce(p.to(device), y.to(device))
+    assert abs(loss.item() - R.keras_bce(p, y).item()) < 1e-5
+    torch.testing.assert_close(dlogit.cpu(), (p - y) / 1000, atol=1e-8, rtol=1e-6)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_dlrm_train_steps_match_torch(device, opt):
+    """3 explicit train steps of mm.DLRMModel vs torch autograd + (Keras) SGD / Adagrad."""
+    import models_amd as mm
+    from models_amd import schema as S
+
+    cards = {"C1": 50, "C10": 7, "C2": 1000, "a": 3}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+    D, B, lr = 16, 257, 0.05
+    model = mm.DLRMModel(schema, embedding_dim=D, bottom_block=mm.MLPBlock([32, D], device=device),
+                         top_block=mm.MLPBlock([32, 8], device=device), device=device)
+    model.compile(optimizer=opt, learning_rate=lr)
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for _ in range(3):
+        x = {n: torch.randint(0, v, (B, 1), generator=g) for n, v in cards.items()}
+        x.update({f"I{i}": torch.rand(B, 1, generator=g) for i in range(1, 4)})
+        y = torch.randint(0, 2, (B, 1), generator=g).float()
+        batches.append((x, y))
+    dev = lambda d: {k: v.to(device) for k, v in d.items()}
+    model(dev(batches[0][0]))  # build lazy layers
+    body = model.body
+    tables = {n: body.embeddings.feature_table[n].table.data.cpu().clone().requires_grad_() for n in cards}
+    lay = lambda blk: [(l.kernel.data.cpu().clone().requires_grad_(), l.bias.data.cpu().clone().requires_grad_(), l.activation) for l in blk.layers]
+    bottom, top = lay(body.bottom_block), lay(body.top_block)
+    hd = model.output.to_call
+    head = (hd.kernel.data.cpu().clone().requires_grad_(), hd.bias.data.cpu().clone().requires_grad_())
+    params = list(tables.values()) + [t for l in bottom + top for t in l[:2]] + list(head)
+    accs = [torch.full_like(p, 0.1) for p in params]
+    for x, y in batches:
+        loss = model.train_step(dev(x), y.to(device))
+        cat = {n: x[n] for n in cards}
+        cont = {k: v for k, v in x.items() if k.startswith("I")}
+        ref_loss = R.keras_bce(R.dlrm_forward(cat, cont, tables, bottom, top, head), y)
+        assert abs(loss.item() - ref_loss.item()) < 1e-4
+        grads = torch.autograd.grad(ref_loss, params, allow_unused=True)
+        with torch.no_grad():
+            for k, (p, gr) in enumerate(zip(params, grads)):
+                if gr is None:
+                    continue
+                if opt == "sgd":
+                    p -= lr * gr
+                else:
+                    touched = (gr != 0).any(dim=-1, keepdim=True) if p.dim() == 2 and p in list(tables.values()) else torch.ones_like(p, dtype=torch.bool)
+                    w2, a2 = R.adagrad_update(p, gr, accs[k], lr)
+                    p.copy_(torch.where(touched, w2, p))
+                    accs[k] = torch.where(touched, a2, accs[k])
+    for n in cards:
+        torch.testing.assert_close(body.embeddings.feature_table[n].table.data.cpu(), tables[n].detach(), atol=1e-4, rtol=1e-4)
+    for l, (W, b, _) in zip(body.bottom_block.layers + body.top_block.layers, bottom + top):
+        torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(l.bias.data.cpu(), b.detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(hd.kernel.data.cpu(), head[0].detach(), atol=1e-4, rtol=1e-4)
