@@ -167,7 +167,7 @@ def test_dlrm_train_steps_match_torch(device, opt):
                 if opt == "sgd":
                     p -= lr * gr
                 else:
-                    touched = (gr != 0).any(dim=-1, keepdim=True) if p.dim() == 2 and p in list(tables.values()) else torch.ones_like(p, dtype=torch.bool)
+                    touched = (gr != 0).any(dim=-1, keepdim=True) if k < len(tables) else torch.ones_like(p, dtype=torch.bool)
                     w2, a2 = R.adagrad_update(p, gr, accs[k], lr)
                     p.copy_(torch.where(touched, w2, p))
                     accs[k] = torch.where(touched, a2, accs[k])
