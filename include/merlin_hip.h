@@ -184,28 +184,35 @@ int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb,
  *   loss[b]   = logsumexp(logits[b]) - logits[b, 0];  lse[b] = logsumexp(logits[b])
  * logits may be NULL (fused mode: nothing of size B*Nn is written); loss / lse may be NULL.
  * q, item: [B, E]; neg_item: [Nn, E] (pass item and Nn = B for in-batch negatives).
- * ids int32 or int64.  E % 4 == 0, E <= 512. */
+ * ids int32 or int64.  E % 4 == 0, E <= 1024.
+ * workspace: mh_inbatch_softmax_workspace_bytes(B, Nn, backward = 0 | 1). */
+int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t backward);
 int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* neg_item,
                                const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                int64_t B, int64_t Nn, int32_t E, float temperature,
                                float false_neg_score, float* logits, int64_t ld_logits,
-                               float* loss, float* lse, mh_stream_t stream);
+                               float* loss, float* lse, void* workspace, int64_t workspace_bytes,
+                               mh_stream_t stream);
 
-/* Backward of mean_b(loss[b]) * grad_scale w.r.t. q, item (positive role) and neg_item:
- * recomputes the logits tile by tile from (q, neg_item, lse) -- nothing of size B*Nn is read
- * or written.  dneg_item accumulates (caller zero-fills, may alias ditem for in-batch). */
+/* Backward of sum_b(loss[b]) * grad_scale (pass grad_scale = 1/B for the Keras mean) w.r.t.
+ * q (dq[B,E]), item in its positive role (ditem[B,E], may be NULL) and neg_item (dneg_item[Nn,E]);
+ * all three are overwritten.  For in-batch negatives the caller adds ditem + dneg_item.
+ * Round-1 implementation: the probabilities tile ds[B,Nn] is recomputed from (q, neg_item, lse)
+ * into the workspace and contracted with two fp32-MFMA GEMMs. */
 int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* neg_item,
                                const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                int64_t B, int64_t Nn, int32_t E, float temperature,
                                float false_neg_score, const float* lse, float grad_scale,
-                               float* dq, float* ditem, float* dneg_item, mh_stream_t stream);
+                               float* dq, float* ditem, float* dneg_item, void* workspace,
+                               int64_t workspace_bytes, mh_stream_t stream);
 
 /* ---- a14: brute-force top-k retrieval ----------------------------------------------------
  * Replaces BruteForce.call (outputs/topk.py:182-237): scores = q C^T (:113-115),
  * tf.math.top_k(scores, k) (values descending, ties -> lower candidate index first),
  * tf.gather(ids, idx).  q[Bq, E], cand[N, E] fp32, cand_ids[N] int32 (NULL -> index itself).
  * Each score is a k-ascending fp32 fmaf chain (bit-reproducible by oracle/oracle_c.c).
- * out_scores[Bq, k] fp32, out_ids[Bq, k] int32, out_idx[Bq, k] int32 (may be NULL).
+ * out_scores[Bq, k] fp32 and out_idx[Bq, k] int32 (candidate row indices) are required (they hold the
+ * running lists between candidate chunks); out_ids[Bq, k] int32 may be NULL.
  * k <= 1024, k <= N.  workspace: mh_topk_workspace_bytes(Bq, N, k). */
 int64_t mh_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k);
 int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, int64_t Bq,

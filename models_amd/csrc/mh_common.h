@@ -37,3 +37,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Number of workgroups that fill the chip a few times over for grid-stride kernels.
 int mh_num_cus();
+
+// ---- internal GEMM launchers shared across translation units (fp32 MFMA, k-ascending chains) ----
+// y[M,N] = act(x[M,K] W[K,N] + b)  (optionally the cross epilogue x0 * (.) + xres)
+int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N,
+                           int act, float* y, int64_t ldy, const float* x0, const float* xres, hipStream_t s);
+// C[M,Nout] = A[M,Kc] B[Nout,Kc]^T
+int32_t mh_internal_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int Nout, int Kc,
+                            float* C, int64_t ldc, hipStream_t s);
+// out[K,N] = X[M,K]^T Z[M,N], single slice (no split): deterministic k-ascending over M
+int32_t mh_internal_gemm_tn(const float* X, int64_t ldx, const float* Z, int64_t ldz, int64_t M, int K, int N,
+                            float* out, hipStream_t s);

@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                                                         const float* __restrict__ W,
                                                         const float* __restrict__ bias, int64_t M,
                                                         int K, int N, int act, float* __restrict__ y,
-                                                        int64_t ldy, int vec_x, int vec_w) {
+                                                        int64_t ldy, int vec_x, int vec_w,
+                                                        const float* __restrict__ x0,
+                                                        const float* __restrict__ xres) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BK * BN];
     float* As0 = smem;
@@ -74,7 +76,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
-                if (row < M) y[row * ldy + col] = apply_act(acc[tm][tn][r] + bv, act);
+                if (row < M) {
+                    float v = acc[tm][tn][r] + bv;
+                    // DCN-v2 cross epilogue (blocks/cross.py:188-202): x0 * (x W + b) + x
+                    if (x0) v = x0[row * (int64_t)N + col] * v + xres[row * (int64_t)N + col];
+                    y[row * ldy + col] = apply_act(v, act);
+                }
             }
         }
     }
@@ -134,20 +141,33 @@ int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, cons
         MH_CHECK_LAUNCH("mh_linear_bias_act_fwd");
         return MH_OK;
     }
+    return mh_internal_linear(x, ldx, W, b, M, K, N, act, y, ldy, nullptr, nullptr, s);
+}
+
+int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, const float* b, int64_t M,
+                           int32_t d, float* out, mh_stream_t stream) {
+    MH_REQUIRE(x0 && x && W && out, "mh_cross_layer_fwd: null argument");
+    MH_REQUIRE(M >= 0 && d >= 5, "mh_cross_layer_fwd: bad shape M=%lld d=%d (d must be > 4)", (long long)M, d);
+    if (M == 0) return MH_OK;
+    return mh_internal_linear(x, d, W, b, M, d, d, MH_ACT_NONE, out, d, x0, x, mh_stream(stream));
+}
+
+}  // extern "C"
+
+int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N,
+                           int act, float* y, int64_t ldy, const float* x0, const float* xres, hipStream_t s) {
     const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
     const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
     if (N > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(N, 128));
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     } else if (N > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     } else {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     }
     MH_CHECK_LAUNCH("mh_linear_bias_act_fwd");
     return MH_OK;
 }
-
-}  // extern "C"

@@ -229,6 +229,35 @@ BwdPlan make_plan(int64_t M, int K, int N) {
 
 }  // namespace
 
+int32_t mh_internal_gemm_nt(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout, int Kc,
+                            float* Cm, int64_t ldc, hipStream_t s) {
+    const int vec_a = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+    const int vec_b = ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0) && (ldb % 4 == 0);
+    if (Nout > 64) {
+        dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(Nout, 128));
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b);
+    } else if (Nout > 32) {
+        dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b);
+    } else {
+        dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b);
+    }
+    MH_CHECK_LAUNCH("gemm_nt");
+    return MH_OK;
+}
+
+int32_t mh_internal_gemm_tn(const float* X, int64_t ldx, const float* Z, int64_t ldz, int64_t M, int K, int N,
+                            float* out, hipStream_t s) {
+    const int vec_x = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx % 4 == 0);
+    const int vec_z = ((reinterpret_cast<uintptr_t>(Z) & 15) == 0) && (ldz % 4 == 0);
+    const int64_t rps = mh_ceil_div(M, BK) * BK;
+    dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), 1);
+    hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, X, ldx, Z, ldz, M, K, N, rps, out, vec_x, vec_z);
+    MH_CHECK_LAUNCH("gemm_tn");
+    return MH_OK;
+}
+
 extern "C" {
 
 int64_t mh_linear_bwd_workspace_bytes(int64_t M, int32_t K, int32_t N) {
@@ -262,17 +291,8 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
     }
     const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
     if (dx) {
-        const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
-        if (K > 64) {
-            dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(K, 128));
-            hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, vec_dy, vec_w);
-        } else if (K > 32) {
-            dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-            hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, vec_dy, vec_w);
-        } else {
-            dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-            hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, vec_dy, vec_w);
-        }
+        const int32_t st = mh_internal_gemm_nt(dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, s);
+        if (st != MH_OK) return st;
     }
     {
         const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);

@@ -8,7 +8,7 @@ test infrastructure only).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import NamedTuple, Optional, Sequence
 
 import torch
 
@@ -443,3 +443,108 @@ def dense_optimizer_step(opt, p) -> None:
     g = p.grad.contiguous()
     check(lib.mh_dense_optimizer_step(_ptr(p.data), _ptr(g), _ptr(state), p.data.numel(), _lib.OPT[opt.name],
                                       opt.learning_rate, opt.epsilon, _stream()), "mh_dense_optimizer_step")
+
+
+# --------------------------------------------------------------------------------------------
+# retrieval: scorer, top-k, cross
+# --------------------------------------------------------------------------------------------
+class ScorerResult(NamedTuple):
+    logits: Optional[torch.Tensor]  # [B, 1 + Nn] or None (fused mode)
+    loss: torch.Tensor  # [B]   logsumexp(logits) - logits[:, 0]
+    lse: torch.Tensor  # [B]
+
+
+def _ids_pair(pos_ids, neg_ids):
+    if pos_ids is None or neg_ids is None:
+        return None, None, MH_I32
+    _dev(pos_ids, "pos_ids")
+    _dev(neg_ids, "neg_ids")
+    pos_ids, neg_ids = pos_ids.reshape(-1).contiguous(), neg_ids.reshape(-1).contiguous()
+    if neg_ids.dtype != pos_ids.dtype:
+        neg_ids = neg_ids.to(pos_ids.dtype)  # reference casts positive ids to the negatives' dtype
+    return pos_ids, neg_ids, _ids_dtype(pos_ids, "pos_ids")
+
+
+def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: float = 1.0,
+                    false_neg_score: float = -655.04, materialize: bool = True) -> ScorerResult:
+    """Sampled-softmax scorer: positives ``<q, item>`` in column 0, negatives ``q @ neg_item^T``
+    with false negatives rescored, temperature scaling and the softmax cross-entropy fused."""
+    lib = _lib.load()
+    for n_, t in (("q", q), ("item", item), ("neg_item", neg_item)):
+        _dev(t, n_, torch.float32)
+        if t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"{n_} must be contiguous 2-D")
+    B, E = q.shape
+    Nn = neg_item.shape[0]
+    pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
+    logits = torch.empty((B, Nn + 1), dtype=torch.float32, device=q.device) if materialize else None
+    loss = torch.empty((B,), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B,), dtype=torch.float32, device=q.device)
+    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, 0), q.device, "scorer_fwd")
+    with _timed("inbatch_softmax_fwd"):
+        check(
+            lib.mh_inbatch_softmax_fwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
+                                       temperature, false_neg_score, _ptr(logits), Nn + 1, _ptr(loss), _ptr(lse),
+                                       _ptr(ws), ws.numel(), _stream()),
+            "mh_inbatch_softmax_fwd",
+        )
+    return ScorerResult(logits, loss, lse)
+
+
+def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None, temperature: float = 1.0,
+                             false_neg_score: float = -655.04, grad_scale: Optional[float] = None):
+    """Gradients of ``grad_scale * sum_b loss[b]`` (default 1/B: the Keras mean): (dq, ditem, dneg)."""
+    lib = _lib.load()
+    B, E = q.shape
+    Nn = neg_item.shape[0]
+    pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
+    dq = torch.empty_like(q)
+    ditem = torch.empty_like(item)
+    dneg = torch.empty_like(neg_item)
+    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, 1), q.device, "scorer_bwd")
+    with _timed("inbatch_softmax_bwd"):
+        check(
+            lib.mh_inbatch_softmax_bwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
+                                       temperature, false_neg_score, _ptr(lse), 1.0 / B if grad_scale is None else grad_scale,
+                                       _ptr(dq), _ptr(ditem), _ptr(dneg), _ptr(ws), ws.numel(), _stream()),
+            "mh_inbatch_softmax_bwd",
+        )
+    return dq, ditem, dneg
+
+
+def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch.Tensor], k: int):
+    """Brute-force retrieval: (scores[Bq,k] desc, ids[Bq,k] int32, idx[Bq,k] int32); ties -> lower index."""
+    lib = _lib.load()
+    _dev(q, "q", torch.float32)
+    _dev(candidates, "candidates", torch.float32)
+    q, candidates = q.contiguous(), candidates.contiguous()
+    Bq, E = q.shape
+    N = candidates.shape[0]
+    if cand_ids is not None:
+        _dev(cand_ids, "cand_ids", torch.int32)
+        cand_ids = cand_ids.contiguous()
+    scores = torch.empty((Bq, k), dtype=torch.float32, device=q.device)
+    ids = torch.empty((Bq, k), dtype=torch.int32, device=q.device)
+    idx = torch.empty((Bq, k), dtype=torch.int32, device=q.device)
+    ws = _workspace(lib.mh_topk_workspace_bytes(Bq, N, k), q.device, "topk")
+    with _timed("topk_dot"):
+        check(
+            lib.mh_topk_dot(_ptr(q), _ptr(candidates), _ptr(cand_ids), Bq, N, E, k, _ptr(scores), _ptr(ids), _ptr(idx),
+                            _ptr(ws), ws.numel(), _stream()),
+            "mh_topk_dot",
+        )
+    return scores, ids, idx
+
+
+def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """DCN-v2 cross layer ``x0 * (x @ W + b) + x`` (full-rank W [d, d])."""
+    lib = _lib.load()
+    for n_, t in (("x0", x0), ("x", x), ("W", W)):
+        _dev(t, n_, torch.float32)
+        if t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"{n_} must be contiguous 2-D")
+    M, d = x.shape
+    out = torch.empty_like(x)
+    with _timed(f"cross_{d}"):
+        check(lib.mh_cross_layer_fwd(_ptr(x0), _ptr(x), _ptr(W), _ptr(b), M, d, _ptr(out), _stream()), "mh_cross_layer_fwd")
+    return out

@@ -1,0 +1,148 @@
+"""Scorer / top-k / cross HIP kernels vs the oracle and the reference's known answers."""
+import numpy as np
+import pytest
+import torch
+
+from models_amd import ops
+from oracle import cbind, oracle as O
+from tests import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4  # north-star fp32 logits tolerance
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def test_scorer_reference_known_answers(device):
+    # tests/unit/torch/outputs/test_constrastive.py:31-47 (no downscore)
+    q = np.array([[0.1, 0.2, 0, 0], [0.3, 0.4, 0, 0]], np.float32)
+    p = np.array([[0.5, 0.6, 0, 0], [0.7, 0.8, 0, 0]], np.float32)
+    n = np.array([[0.9, 1.0, 0, 0], [1.1, 1.2, 0, 0], [1.3, 1.4, 0, 0]], np.float32)
+    r = ops.inbatch_softmax(_t(q, device), _t(p, device), _t(n, device))
+    exp = np.array([[0.17, 0.29, 0.35, 0.41], [0.53, 0.67, 0.81, 0.95]], np.float32)
+    np.testing.assert_allclose(r.logits.cpu().numpy(), exp, atol=ATOL)
+    # :49-73 (false negative -> -100)
+    q1, p1 = q[:1], p[:1]
+    n1 = np.array([[0.5, 0.6, 0, 0], [0.9, 1.0, 0, 0]], np.float32)
+    r = ops.inbatch_softmax(_t(q1, device), _t(p1, device), _t(n1, device), _t(np.array([0]), device),
+                            _t(np.array([0, 1]), device), false_neg_score=-100.0)
+    np.testing.assert_allclose(r.logits.cpu().numpy(), [[0.17, -100.0, 0.29]], atol=ATOL)
+
+
+@pytest.mark.parametrize("B,E", [(300, 32), (1000, 128), (129, 64), (64, 8)])
+@pytest.mark.parametrize("temperature", [1.0, 0.25])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_inbatch_scorer_matches_oracle(device, B, E, temperature, idt):
+    rng = np.random.default_rng(B + E)
+    q = rng.normal(size=(B, E)).astype(np.float32) * 0.3
+    it = rng.normal(size=(B, E)).astype(np.float32) * 0.3
+    ids = rng.integers(0, max(B // 3, 2), size=B).astype(idt)  # many duplicate ids -> off-diagonal false negatives
+    logits, _ = O.contrastive_outputs(q, it, it, ids, ids, temperature=temperature)
+    loss, lse = O.softmax_ce_first_column(logits)
+    r = ops.inbatch_softmax(_t(q, device), _t(it, device), _t(it, device), _t(ids, device), _t(ids, device), temperature)
+    got = r.logits.cpu().numpy()
+    np.testing.assert_allclose(got, logits, atol=ATOL * max(1.0, 1.0 / temperature), rtol=1e-5)
+    np.testing.assert_allclose(r.lse.cpu().numpy(), lse, atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(r.loss.cpu().numpy(), loss, atol=ATOL, rtol=1e-4)
+    # diagonal always masked (tests/unit/tf/outputs/test_contrastive.py:173-206)
+    assert np.all(np.diag(got[:, 1:]) == np.float32(np.float32(O.MIN_FLOAT) * np.float32(1.0 / temperature)))
+    # fused mode: identical loss without materialising the logits
+    r2 = ops.inbatch_softmax(_t(q, device), _t(it, device), _t(it, device), _t(ids, device), _t(ids, device), temperature,
+                             materialize=False)
+    assert r2.logits is None
+    torch.testing.assert_close(r2.loss, r.loss, atol=0, rtol=0)
+
+
+def test_scorer_scores_are_fmaf_chains(device):
+    rng = np.random.default_rng(5)
+    B, Nn, E = 257, 300, 96
+    q, it, ng = (rng.normal(size=s).astype(np.float32) for s in ((B, E), (B, E), (Nn, E)))
+    r = ops.inbatch_softmax(_t(q, device), _t(it, device), _t(ng, device))
+    np.testing.assert_array_equal(r.logits[:, 1:].cpu().numpy(), cbind.gemm_nt_fmaf(q, ng))
+
+
+def test_scorer_backward_matches_autograd(device):
+    g = torch.Generator().manual_seed(3)
+    B, E, T = 300, 64, 0.5
+    q = (torch.randn(B, E, generator=g) * 0.3).requires_grad_()
+    it = (torch.randn(B, E, generator=g) * 0.3).requires_grad_()
+    ids = torch.randint(0, 100, (B,), generator=g)
+    pos = (q * it).sum(-1, keepdim=True)
+    neg = q @ it.T
+    neg = torch.where(ids[:, None] == ids[None, :], torch.full_like(neg, O.MIN_FLOAT), neg)
+    logits = torch.cat([pos, neg], 1) / T
+    loss = (torch.logsumexp(logits, 1) - logits[:, 0]).mean()
+    loss.backward()
+    qd, itd, idd = q.detach().to(device), it.detach().to(device), ids.to(device)
+    r = ops.inbatch_softmax(qd, itd, itd, idd, idd, T, materialize=False)
+    assert abs(r.loss.mean().item() - loss.item()) < 1e-4
+    dq, ditem, dneg = ops.inbatch_softmax_backward(qd, itd, itd, r.lse, idd, idd, T)
+    torch.testing.assert_close(dq.cpu(), q.grad, atol=1e-5, rtol=1e-3)
+    torch.testing.assert_close((ditem + dneg).cpu(), it.grad, atol=1e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("Bq,N,E,k", [(5, 40, 8, 7), (130, 5000, 64, 100), (64, 70000, 128, 10), (3, 300, 32, 300), (257, 1025, 16, 1)])
+def test_topk_bit_exact_vs_c_oracle(device, Bq, N, E, k):
+    rng = np.random.default_rng(Bq + N)
+    q = rng.normal(size=(Bq, E)).astype(np.float32)
+    c = rng.normal(size=(N, E)).astype(np.float32)
+    ids = rng.permutation(10 * N)[:N].astype(np.int32)
+    vals, out_ids, idx = cbind.bruteforce_topk(q, c, ids, k)
+    s, i, ix = ops.topk_dot(_t(q, device), _t(c, device), _t(ids, device), k)
+    np.testing.assert_array_equal(ix.cpu().numpy(), idx)   # indices bit-exact
+    np.testing.assert_array_equal(i.cpu().numpy(), out_ids)
+    np.testing.assert_array_equal(s.cpu().numpy(), vals)    # same fmaf chains -> same bits
+    assert i.dtype == torch.int32
+
+
+def test_topk_ties_lowest_index_first(device):
+    # tests/unit/tf/utils/test_tf_utils.py:42-75 row 3: all-equal scores -> indices 0..k-1
+    q = np.ones((3, 4), np.float32)
+    c = np.ones((500, 4), np.float32)
+    c[100:] *= 0.5
+    s, i, ix = ops.topk_dot(_t(q, device), _t(c, device), None, 20)
+    np.testing.assert_array_equal(ix.cpu().numpy(), np.tile(np.arange(20, dtype=np.int32), (3, 1)))
+    # quantised scores: massive ties across chunk boundaries
+    rng = np.random.default_rng(0)
+    q = rng.integers(-2, 3, size=(17, 8)).astype(np.float32)
+    c = rng.integers(-2, 3, size=(3000, 8)).astype(np.float32)
+    s, i, ix = ops.topk_dot(_t(q, device), _t(c, device), None, 50)
+    v0, i0 = O.top_k(q @ c.T, 50)
+    np.testing.assert_array_equal(ix.cpu().numpy(), i0)
+    np.testing.assert_array_equal(s.cpu().numpy(), v0)
+
+
+def test_topk_full_size_property(device):
+    """BASELINE config-3 shape (1M x 128 catalogue, k=100) on a query block: the k-th score is a
+    threshold -- exactly k candidates are >= it after tie handling, and results are sorted."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    N, E, Bq, k = 1_000_000, 128, 256, 100
+    c = torch.randn(N, E, generator=g).to(device)
+    q = torch.randn(Bq, E, generator=g).to(device)
+    s, i, ix = ops.topk_dot(q, c, None, k)
+    assert torch.all(s[:, :-1] >= s[:, 1:])
+    full = q[:8] @ c.T  # torch GEMM as an independent (non-bit-exact) cross-check on 8 rows
+    ref_s, ref_i = torch.topk(full, k, dim=1)
+    torch.testing.assert_close(s[:8], ref_s, atol=1e-3, rtol=1e-5)
+    assert (ix[:8].long() == ref_i).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("M,d", [(300, 96), (129, 200), (64, 3341)])
+def test_cross_layer_matches_oracle(device, M, d):
+    rng = np.random.default_rng(d)
+    x0 = rng.normal(size=(M, d)).astype(np.float32)
+    x = rng.normal(size=(M, d)).astype(np.float32)
+    W = (rng.normal(size=(d, d)) * 0.05).astype(np.float32)
+    b = (rng.normal(size=d) * 0.1).astype(np.float32)
+    out = ops.cross_layer(_t(x0, device), _t(x, device), _t(W, device), _t(b, device)).cpu().numpy()
+    np.testing.assert_allclose(out, O.cross_layer(x0, x, W, b), atol=ATOL * max(1.0, d / 512), rtol=1e-4)
+
+
+def test_l2norm_and_rowwise_dot(device):
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(300, 128)).astype(np.float32)
+    y = rng.normal(size=(300, 128)).astype(np.float32)
+    np.testing.assert_allclose(ops.l2norm(_t(x, device)).cpu().numpy(), O.l2norm(x), atol=1e-6)
+    np.testing.assert_allclose(ops.rowwise_dot(_t(x, device), _t(y, device)).cpu().numpy()[:, 0], (x * y).sum(-1), atol=1e-4)
