@@ -294,7 +294,19 @@ class Cross(Block):
             raise ValueError(f"`x0` ({tuple(x0.shape)}) and `x` ({tuple(x.shape)}) shapes mismatch!")
         if self.kernel is None:
             self.build(x.shape[-1])
+        self._x0, self._x = x0, x
         return ops.cross_layer(x0, x, self.kernel.data, self.bias.data)
+
+    def backward(self, dout):
+        """out = x0 * p + x with p = x W + b: returns (dx0, dx); sets kernel / bias grads."""
+        x0, x = self._x0, self._x
+        dout = dout.contiguous()
+        p = ops.linear(x, self.kernel.data, self.bias.data, None)  # recomputed, not stored
+        dx0 = ops.eltwise("mul", dout, p)
+        g = ops.eltwise("mul", dout, x0)                           # d loss / d p
+        dx_lin, dW, db = ops.linear_backward(x, self.kernel.data, None, g, None, need_dx=True, need_db=True)
+        self.kernel.grad, self.bias.grad = dW, db
+        return dx0, ops.eltwise("add", dx_lin, dout)
 
 
 class CrossBlock(Block):
@@ -317,6 +329,14 @@ class CrossBlock(Block):
         for layer in self.layers:
             x = layer((x0, x))
         return x
+
+    def backward(self, grad):
+        dx0_total = None
+        dx = grad
+        for layer in reversed(self.layers):
+            dx0, dx = layer.backward(dx)
+            dx0_total = dx0 if dx0_total is None else ops.eltwise("add", dx0_total, dx0)
+        return ops.eltwise("add", dx0_total, dx)  # layer 0 has x = x0
 
 
 class TwoTowerBlock(ParallelBlock):

@@ -66,9 +66,31 @@ __global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, c
     }
 }
 
+// op 0: a*b   1: a+b   2: a*b + c      (float4-vectorised when n % 4 == 0 and pointers are aligned)
+__global__ __launch_bounds__(256) void eltwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ c, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v;
+    if (op == 0) v = a[i] * b[i];
+    else if (op == 1) v = a[i] + b[i];
+    else v = fmaf(a[i], b[i], c[i]);
+    out[i] = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, float* out, int64_t n,
+                   mh_stream_t stream) {
+    MH_REQUIRE(a && b && out && op >= 0 && op <= 2 && (op != 2 || c), "mh_eltwise: bad argument");
+    if (n <= 0) return MH_OK;
+    hipLaunchKernelGGL(eltwise_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), op, a, b,
+                       c, out, n);
+    MH_CHECK_LAUNCH("mh_eltwise");
+    return MH_OK;
+}
 
 int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale, float* loss,
                        float* dlogit, mh_stream_t stream) {

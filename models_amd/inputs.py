@@ -295,21 +295,87 @@ class ContinuousFeatures(Block):
 Continuous = ContinuousFeatures
 
 
-def InputBlockV2(schema: Schema, categorical: Optional[Block] = None, continuous: Optional[Block] = None,
-                 aggregation="concat", dim=None, device=None, **kwargs) -> ParallelBlock:
-    """base.py:216-341: ParallelBlock{"categorical": Embeddings, "continuous": Continuous} with a
-    "concat" aggregation over the merged (sorted) feature dict."""
-    branches: Dict[str, Block] = {}
-    cat_schema = schema.select_by_tag(Tags.CATEGORICAL).excluding_by_tag(Tags.TARGET)
-    con_schema = schema.select_by_tag(Tags.CONTINUOUS).excluding_by_tag(Tags.TARGET)
-    if categorical is None and len(cat_schema):
-        categorical = Embeddings(cat_schema, dim=dim, device=device, **kwargs)
-    if categorical is not None:
-        branches["categorical"] = categorical
-    if continuous is None and len(con_schema):
-        continuous = ContinuousFeatures.from_schema(con_schema)
-    if continuous is not None:
-        branches["continuous"] = continuous
-    if not branches:
-        raise ValueError("InputBlockV2: the schema has neither categorical nor continuous features")
-    return ParallelBlock(branches, aggregation=aggregation, name="input_block", schema=schema)
+class InputBlockV2(Block):
+    """base.py:216-341: {"categorical": Embeddings, "continuous": Continuous} merged and aggregated.
+
+    With the default ``aggregation="concat"`` the block is fused: ONE multi-table gather writes
+    every embedding straight into its sorted-name column range of the ``[B, W]`` concat buffer
+    (ConcatFeatures order, core/aggregation.py:54-66) and the continuous columns are copied next
+    to them -- no per-feature tensors, no torch.cat.  The backward hands the ``[B, W]`` gradient
+    to the fused embedding backward with the same column offsets.
+    """
+
+    def __init__(self, schema: Schema, categorical: Optional[Block] = None, continuous: Optional[Block] = None,
+                 aggregation="concat", dim=None, device=None, name: Optional[str] = None, **kwargs):
+        super().__init__(name or "input_block")
+        cat_schema = schema.select_by_tag(Tags.CATEGORICAL).excluding_by_tag(Tags.TARGET)
+        con_schema = schema.select_by_tag(Tags.CONTINUOUS).excluding_by_tag(Tags.TARGET)
+        if categorical is None and len(cat_schema):
+            categorical = Embeddings(cat_schema, dim=dim, device=device, **kwargs)
+        if continuous is None and len(con_schema):
+            continuous = ContinuousFeatures.from_schema(con_schema)
+        if categorical is None and continuous is None:
+            raise ValueError("InputBlockV2: the schema has neither categorical nor continuous features")
+        if aggregation not in ("concat", None):
+            raise NotImplementedError("InputBlockV2 supports aggregation='concat' or None on the HIP path")
+        self.schema = schema
+        self.categorical: Optional[EmbeddingsBlock] = categorical
+        self.continuous: Optional[ContinuousFeatures] = continuous
+        self.aggregation = aggregation
+        self.parallel_layers = {k: v for k, v in (("categorical", categorical), ("continuous", continuous)) if v is not None}
+
+    def children(self):
+        return list(self.parallel_layers.values())
+
+    def forward(self, inputs: TabularData):
+        cat_names = [n for n in (self.categorical.feature_names if self.categorical else []) if n in inputs]
+        con = self.continuous(inputs) if self.continuous is not None else {}
+        if self.aggregation is None:
+            out = dict(self.categorical({n: inputs[n] for n in cat_names})) if cat_names else {}
+            out.update(con)
+            return out
+        widths = {n: self.categorical.feature_table[n].dim for n in cat_names}
+        widths.update({n: (v.shape[1] if v.dim() == 2 else v[0].numel()) for n, v in con.items()})
+        order = sorted(widths)
+        offsets, o = {}, 0
+        for n in order:
+            offsets[n] = o
+            o += widths[n]
+        W = o
+        ld = (W + 3) // 4 * 4
+        first = inputs[cat_names[0]] if cat_names else next(iter(con.values()))
+        B = first.offsets.shape[0] - 1 if isinstance(first, Ragged) else first.shape[0]
+        dev = (self.categorical.feature_table[cat_names[0]].table.data.device if cat_names else first.device)
+        buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        if ld != W:
+            buf[:, W:].zero_()
+        aligned = all(offsets[n] % 4 == 0 for n in cat_names)
+        self._fused = aligned and len({widths[n] for n in cat_names}) <= 1 and all(
+            self.categorical._is_onehot(inputs[n]) for n in cat_names)
+        if cat_names:
+            if self._fused:
+                ops.embedding_gather([self.categorical.feature_table[n].table.data for n in cat_names],
+                                     [inputs[n] for n in cat_names], out=buf, out_offset=[offsets[n] for n in cat_names])
+                self.categorical._last = {n: inputs[n] for n in cat_names}
+            else:
+                emb = self.categorical({n: inputs[n] for n in cat_names})
+                for n in cat_names:
+                    buf[:, offsets[n]:offsets[n] + widths[n]] = emb[n]
+        for n, v in con.items():
+            buf[:, offsets[n]:offsets[n] + widths[n]] = v.reshape(B, -1)
+        self._offsets, self._W, self._ld, self._cat_names = offsets, W, ld, cat_names
+        return buf[:, :W]
+
+    def backward(self, grad):
+        if grad is None or not self._cat_names:
+            return None
+        if not self._fused:
+            raise NotImplementedError("backward needs 16-byte aligned one-hot embedding columns (fused layout)")
+        B = grad.shape[0]
+        if grad.is_contiguous() and grad.shape[1] == self._W and self._W % 4 == 0 and grad.data_ptr() % 16 == 0:
+            g = grad
+        else:  # re-pitch to the 16-byte aligned row stride the fused backward needs
+            g = torch.zeros((B, self._ld), dtype=torch.float32, device=grad.device)
+            g[:, :self._W] = grad
+        self.categorical.set_pending_grad(g, {n: self._offsets[n] for n in self._cat_names})
+        return None

@@ -153,6 +153,13 @@ class DCNBody(Block):
             return self.deep(self.cross(x))
         return torch.cat([self.cross(x), self.deep(x)], dim=-1)
 
+    def backward(self, grad):
+        if not self.stacked:
+            raise NotImplementedError("backward of the parallel DCN variant is not on the HIP path yet")
+        g = self.deep.backward(grad)
+        g = self.cross.backward(g)
+        return self.input_block.backward(g)
+
 
 def DCNModel(schema: Schema, depth: int, deep_block: Optional[Block] = None, stacked: bool = True,
              input_block=None, embedding_dim: Optional[int] = None, prediction_tasks=None, device=None) -> RankingModel:
@@ -175,6 +182,27 @@ class RetrievalModel(Model):
         emb = self.body(x)
         return self.output.forward({"query": emb["query"], "candidate": emb["item"]}, features=x,
                                    training=training, testing=testing)
+
+    def train_step(self, inputs: TabularData, targets=None) -> torch.Tensor:
+        """fwd (fused scorer: no [B, B] logits in HBM) -> bwd -> fused updates."""
+        if self.optimizer is None:
+            self.compile()
+        if self.body.l2_normalization:
+            raise NotImplementedError("training with l2_normalization is not on the HIP path yet")
+        x = prepare_features(inputs)
+        emb = self.body(x)
+        q, it = emb["query"], emb["item"]
+        out = self.output
+        ids = None
+        if out.downscore_false_negatives:
+            ids = x[out.col_schema.name].reshape(-1)
+        res = ops.inbatch_softmax(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score, materialize=False)
+        dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
+                                                       out.false_negative_score)
+        self.body.parallel_layers["query"].backward(dq)
+        self.body.parallel_layers["item"].backward(ops.eltwise("add", ditem, dneg))
+        self.optimizer.apply(self)
+        return res.loss.mean()
 
     def query_embeddings(self, inputs: TabularData) -> torch.Tensor:
         return self.body.parallel_layers["query"](prepare_features(inputs))

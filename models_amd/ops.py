@@ -548,3 +548,16 @@ def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[
     with _timed(f"cross_{d}"):
         check(lib.mh_cross_layer_fwd(_ptr(x0), _ptr(x), _ptr(W), _ptr(b), M, d, _ptr(out), _stream()), "mh_cross_layer_fwd")
     return out
+
+
+def eltwise(op: str, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``mul``: a*b, ``add``: a+b, ``fma``: a*b+c on contiguous fp32 tensors of one shape."""
+    lib = _lib.load()
+    code = {"mul": 0, "add": 1, "fma": 2}[op]
+    for t in (a, b) + ((c,) if c is not None else ()):
+        _dev(t, "operand", torch.float32)
+        if not t.is_contiguous() or t.shape != a.shape:
+            raise ValueError("eltwise operands must be contiguous and same-shaped")
+    out = torch.empty_like(a)
+    check(lib.mh_eltwise(code, _ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _stream()), "mh_eltwise")
+    return out

@@ -1,0 +1,238 @@
+"""mm.TwoTowerModel / mm.DCNModel / top-k encoder on the HIP path vs oracle + torch reference."""
+import numpy as np
+import pytest
+import torch
+
+import models_amd as mm
+from models_amd import schema as S
+from oracle import oracle as O
+from tests import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def _two_tower_schema():
+    return mm.Schema([
+        S.categorical("user_id", 500, [S.Tags.USER, S.Tags.USER_ID]),
+        S.categorical("user_city", 20, [S.Tags.USER]),
+        S.categorical("item_id", 300, [S.Tags.ITEM, S.Tags.ITEM_ID]),
+        S.categorical("item_category", 12, [S.Tags.ITEM]),
+    ])
+
+
+def _batch(schema, B, g, device):
+    x = {}
+    for c in schema:
+        if S.Tags.CATEGORICAL in c.tags:
+            x[c.name] = torch.randint(0, int(c.int_domain.max) + 1, (B, 1), generator=g)
+        elif S.Tags.CONTINUOUS in c.tags:
+            x[c.name] = torch.rand(B, 1, generator=g)
+    return x, {k: v.to(device) for k, v in x.items()}
+
+
+def _tower_np(tower, x):
+    """oracle forward of SequentialBlock[InputBlockV2, MLP] (concat in sorted-name order)."""
+    inp, mlp = tower.layers[0], tower.layers[1:]
+    feats = {}
+    for n in inp.categorical.feature_names:
+        feats[n] = O.embedding_lookup(inp.categorical.feature_table[n].table.numpy(), x[n].numpy())
+    h = O.concat_features(feats)
+    for l in mlp:
+        h = O.dense(h, l.kernel.numpy(), l.bias.numpy(), l.activation)
+    return h
+
+
+def test_two_tower_forward_matches_oracle(device):
+    schema = _two_tower_schema()
+    model = mm.TwoTowerModel(schema, mm.MLPBlock([64, 32], device=device), embedding_dim=32, device=device, logits_temperature=0.5)
+    g = torch.Generator().manual_seed(0)
+    x, xd = _batch(schema, 257, g, device)
+    pred = model(xd, training=True)
+    q = _tower_np(model.body.parallel_layers["query"], x)
+    it = _tower_np(model.body.parallel_layers["item"], x)
+    ids = x["item_id"].numpy().reshape(-1)
+    logits, targets = O.contrastive_outputs(q, it, it, ids, ids, temperature=0.5)
+    np.testing.assert_allclose(pred.outputs.cpu().numpy(), logits, atol=2 * ATOL, rtol=1e-5)
+    np.testing.assert_array_equal(pred.targets.cpu().numpy(), targets)
+    # inference returns only the positive scores [B, 1] (tests/unit/tf/outputs/test_contrastive.py:209-223)
+    inf = model(xd)
+    assert inf.shape == (257, 1)
+    np.testing.assert_allclose(inf.cpu().numpy()[:, 0], (q * it).sum(-1), atol=ATOL)
+
+
+def test_top_k_encoder_matches_matmul_topk_gather(device):
+    # tests/unit/tf/core/test_index.py:76-121
+    schema = _two_tower_schema()
+    model = mm.TwoTowerModel(schema, mm.MLPBlock([32], device=device), embedding_dim=16, device=device)
+    g = torch.Generator().manual_seed(1)
+    x, xd = _batch(schema, 64, g, device)
+    model(xd)
+    cands = torch.randn(300, 32, generator=g).to(device)
+    ident = torch.randperm(5000, generator=g)[:300].to(device)
+    enc = model.to_top_k_encoder(cands, ident, k=10)
+    out = enc(xd)
+    q = model.query_embeddings(xd).cpu().numpy()
+    vals, ids, _ = O.brute_force_topk(q, cands.cpu().numpy(), ident.cpu().numpy(), 10)
+    np.testing.assert_array_equal(out.identifiers.cpu().numpy(), ids)
+    np.testing.assert_allclose(out.scores.cpu().numpy(), vals, atol=ATOL)
+    assert out.identifiers.dtype == torch.int32
+    with pytest.raises(ValueError):
+        mm.BruteForce(3).forward(cands)  # not indexed (tests/unit/tf/outputs/test_topk.py:21-78)
+    with pytest.raises(ValueError):
+        mm.BruteForce(3).index(cands, ident[:5])
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_two_tower_train_steps_match_torch(device, opt):
+    schema = _two_tower_schema()
+    lr, T = 0.05, 0.7
+    model = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16, device=device, logits_temperature=T)
+    model.compile(optimizer=opt, learning_rate=lr)
+    g = torch.Generator().manual_seed(2)
+    batches = [_batch(schema, 200, g, device) for _ in range(3)]
+    model(batches[0][1])
+    towers = {k: model.body.parallel_layers[k] for k in ("query", "item")}
+    ref = {}
+    for k, tw in towers.items():
+        inp = tw.layers[0]
+        ref[k] = {
+            "tables": {n: inp.categorical.feature_table[n].table.data.cpu().clone().requires_grad_() for n in inp.categorical.feature_names},
+            "mlp": [(l.kernel.data.cpu().clone().requires_grad_(), l.bias.data.cpu().clone().requires_grad_(), l.activation) for l in tw.layers[1:]],
+        }
+
+    def tower_t(k, x):
+        r = ref[k]
+        h = torch.cat([r["tables"][n][x[n].reshape(-1)] for n in sorted(r["tables"])], dim=1)
+        for W, b, a in r["mlp"]:
+            h = R.act(h @ W + b, a)
+        return h
+
+    params = [p for k in ref for p in list(ref[k]["tables"].values()) + [t for l in ref[k]["mlp"] for t in l[:2]]]
+    is_table = [True] * 0
+    is_table = []
+    for k in ref:
+        is_table += [True] * len(ref[k]["tables"]) + [False] * (2 * len(ref[k]["mlp"]))
+    accs = [torch.full_like(p, 0.1) for p in params]
+    for x, xd in batches:
+        loss = model.train_step(xd)
+        q, it = tower_t("query", x), tower_t("item", x)
+        ids = x["item_id"].reshape(-1)
+        pos = (q * it).sum(-1, keepdim=True)
+        neg = q @ it.T
+        neg = torch.where(ids[:, None] == ids[None, :], torch.full_like(neg, O.MIN_FLOAT), neg)
+        logits = torch.cat([pos, neg], 1) / T
+        ref_loss = (torch.logsumexp(logits, 1) - logits[:, 0]).mean()
+        assert abs(loss.item() - ref_loss.item()) < 1e-4
+        grads = torch.autograd.grad(ref_loss, params)
+        with torch.no_grad():
+            for i, (p, gr) in enumerate(zip(params, grads)):
+                if opt == "sgd":
+                    p -= lr * gr
+                else:
+                    touched = (gr != 0).any(dim=-1, keepdim=True) if is_table[i] else torch.ones_like(p, dtype=torch.bool)
+                    w2, a2 = R.adagrad_update(p, gr, accs[i], lr)
+                    p.copy_(torch.where(touched, w2, p))
+                    accs[i] = torch.where(touched, a2, accs[i])
+    for k, tw in towers.items():
+        inp = tw.layers[0]
+        for n, t in ref[k]["tables"].items():
+            torch.testing.assert_close(inp.categorical.feature_table[n].table.data.cpu(), t.detach(), atol=1e-4, rtol=1e-4)
+        for l, (W, b, _) in zip(tw.layers[1:], ref[k]["mlp"]):
+            torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+
+
+def _dcn_schema():
+    cols = [S.categorical(f"C{i}", 30 + i) for i in range(1, 5)] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    return mm.Schema(cols)
+
+
+def test_dcn_forward_and_train_match_reference(device):
+    schema = _dcn_schema()
+    lr = 0.05
+    model = mm.DCNModel(schema, depth=2, deep_block=mm.MLPBlock([32, 16], device=device), embedding_dim=16, device=device)
+    model.compile(optimizer="sgd", learning_rate=lr)
+    g = torch.Generator().manual_seed(4)
+    x, xd = _batch(schema, 150, g, device)
+    y = torch.randint(0, 2, (150, 1), generator=g).float()
+    p = model(xd)
+    body = model.body
+    inp = body.input_block
+    tables = {n: inp.categorical.feature_table[n].table.data.cpu().clone().requires_grad_() for n in inp.categorical.feature_names}
+    cross = [(l.kernel.data.cpu().clone().requires_grad_(), l.bias.data.cpu().clone().requires_grad_()) for l in body.cross.layers]
+    deep = [(l.kernel.data.cpu().clone().requires_grad_(), l.bias.data.cpu().clone().requires_grad_(), l.activation) for l in body.deep.layers]
+    hd = model.output.to_call
+    head = (hd.kernel.data.cpu().clone().requires_grad_(), hd.bias.data.cpu().clone().requires_grad_())
+
+    def fwd():
+        feats = {n: tables[n][x[n].reshape(-1)] for n in tables}
+        feats.update({k: v for k, v in x.items() if k.startswith("I")})
+        h0 = torch.cat([feats[k] for k in sorted(feats)], dim=1)  # C1..C4 then I1..I3 (sorted)
+        h = h0
+        for W, b in cross:
+            h = h0 * (h @ W + b) + h
+        for W, b, a in deep:
+            h = R.act(h @ W + b, a)
+        return torch.sigmoid(h @ head[0] + head[1])
+
+    # forward parity (oracle cross_block on the same numbers)
+    feats_np = {n: O.embedding_lookup(tables[n].detach().numpy(), x[n].numpy()) for n in tables}
+    feats_np.update({k: v.numpy() for k, v in x.items() if k.startswith("I")})
+    h = O.cross_block(O.concat_features(feats_np), [(W.detach().numpy(), b.detach().numpy()) for W, b in cross])
+    h = O.mlp(h, [(W.detach().numpy(), b.detach().numpy(), a) for W, b, a in deep])
+    ref_p = O.dense(h, head[0].detach().numpy(), head[1].detach().numpy(), "sigmoid")
+    np.testing.assert_allclose(p.cpu().numpy(), ref_p, atol=ATOL)
+    # one SGD step
+    loss = model.train_step(xd, y.to(device))
+    ref_loss = R.keras_bce(fwd(), y)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    params = list(tables.values()) + [t for l in cross for t in l] + [t for l in deep for t in l[:2]] + list(head)
+    grads = torch.autograd.grad(ref_loss, params)
+    with torch.no_grad():
+        for pp, gr in zip(params, grads):
+            pp -= lr * gr
+    for n, t in tables.items():
+        torch.testing.assert_close(inp.categorical.feature_table[n].table.data.cpu(), t.detach(), atol=1e-4, rtol=1e-4)
+    for l, (W, b) in zip(body.cross.layers, cross):
+        torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(l.bias.data.cpu(), b.detach(), atol=1e-4, rtol=1e-4)
+    for l, (W, b, _) in zip(body.deep.layers, deep):
+        torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+
+
+def test_dlrm_forward_matches_oracle_criteo_names(device):
+    """Sorted stack order C1, C10, ..., C19, C2, ... , bottom_block."""
+    names = [f"C{i}" for i in range(1, 13)]
+    cols = [S.categorical(n, 40 + i) for i, n in enumerate(names)] + [S.continuous(f"I{i}") for i in range(1, 6)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+    D = 16
+    model = mm.DLRMModel(schema, embedding_dim=D, bottom_block=mm.MLPBlock([32, D], device=device),
+                         top_block=mm.MLPBlock([64, 32], device=device), device=device)
+    assert model.body.stack_order == sorted(names + ["bottom_block"])
+    g = torch.Generator().manual_seed(5)
+    x, xd = _batch(schema, 333, g, device)
+    p = model(xd).cpu().numpy()
+    body = model.body
+    lay = lambda blk: [(l.kernel.numpy(), l.bias.numpy(), l.activation) for l in blk.layers]
+    hd = model.output.to_call
+    ref = O.dlrm_forward({n: x[n].numpy() for n in names}, {k: v.numpy() for k, v in x.items() if k.startswith("I")},
+                         {n: body.embeddings.feature_table[n].table.numpy() for n in names},
+                         lay(body.bottom_block), lay(body.top_block), (hd.kernel.numpy(), hd.bias.numpy()))
+    np.testing.assert_allclose(p, ref["prob"], atol=ATOL)
+    np.testing.assert_allclose(body._top_in.cpu().numpy(), ref["top_in"], atol=ATOL)
+
+
+def test_dlrm_variants_and_errors():
+    # tests/unit/tf/blocks/test_dlrm.py:41-112 (construction-time behaviour, no GPU math needed)
+    cols = [S.categorical("a", 10), S.categorical("b", 10), S.continuous("x")]
+    schema = mm.Schema(cols)
+    with pytest.raises(ValueError, match="needs to match"):
+        mm.DLRMBlock(schema, embedding_dim=8, bottom_block=mm.MLPBlock([16]))
+    with pytest.raises(ValueError, match="bottom_block is required"):
+        mm.DLRMBlock(schema, embedding_dim=8)
+    with pytest.raises(ValueError, match="requires categorical"):
+        mm.DLRMBlock(mm.Schema([S.continuous("x")]), embedding_dim=8, bottom_block=mm.MLPBlock([8]))
+    with pytest.raises(ValueError, match="embedding_dim is required"):
+        mm.DLRMBlock(schema, bottom_block=mm.MLPBlock([8]))
