@@ -356,8 +356,8 @@ class TwoTowerBlock(ParallelBlock):
             item_tower = _copy_mlp(query_tower, device)
         q_in = InputBlockV2(q_schema, dim=embedding_dim, device=device)
         i_in = InputBlockV2(i_schema, dim=embedding_dim, device=device)
-        towers = {"query": SequentialBlock([q_in, query_tower], name="query_tower"),
-                  "item": SequentialBlock([i_in, item_tower], name="item_tower")}
+        towers = {"query": q_in.connect(query_tower, block_name="query_tower"),
+                  "item": i_in.connect(item_tower, block_name="item_tower")}
         super().__init__(towers, name=name or "two_tower")
         self.l2_normalization = l2_normalization
         self.schema = schema

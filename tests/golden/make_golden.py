@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Generate golden vectors by EXECUTING the reference's own Python (run in the authoring
+container, where /root/reference exists; the vectors are committed, the reference is not).
+
+The reference packages cannot be imported here (TensorFlow / merlin-core are absent), so the few
+self-contained functions of its torch backend that restate the hot-path math are extracted from
+the reference SOURCE at run time with ``ast`` and executed with torch-CPU:
+
+  * merlin/models/torch/outputs/contrastive.py: ContrastiveOutput.contrastive_outputs +
+    rescore_false_negatives                      (scorer)
+  * merlin/models/torch/blocks/dlrm.py: DLRMInteraction.forward       (interaction, a7)
+  * merlin/models/torch/blocks/cross.py: CrossBlock.forward loop      (cross, a9)
+  * merlin/models/utils/schema_utils.py: get_embedding_size_from_cardinality (a2)
+
+Nothing is copied into this repository: only inputs/outputs land in tests/golden/*.npz.
+"""
+import ast
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
+OUT = Path(__file__).resolve().parent
+
+
+def extract(path: Path, name: str, cls: str = None):
+    """Return the source of function `name` (optionally a method of class `cls`) in `path`."""
+    src = path.read_text()
+    tree = ast.parse(src)
+    nodes = tree.body
+    if cls is not None:
+        nodes = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    fn = next(n for n in nodes if isinstance(n, ast.FunctionDef) and n.name == name)
+    fn.decorator_list = []
+    for a in fn.args.args + fn.args.kwonlyargs:
+        a.annotation = None
+    fn.returns = None
+    return ast.unparse(fn)
+
+
+def load(path, name, cls=None, extra=None):
+    from typing import Dict, Optional, Tuple, Union
+
+    ns = {"torch": torch, "Optional": Optional, "Tuple": Tuple, "Dict": Dict, "Union": Union, "math": __import__("math")}
+    ns.update(extra or {})
+    exec(extract(REF / path, name, cls), ns)
+    return ns[name]
+
+
+def main():
+    g = torch.Generator().manual_seed(20260925)
+    out = {}
+
+    # --- scorer ---------------------------------------------------------------------------------
+    rescore = load("merlin/models/torch/outputs/contrastive.py", "rescore_false_negatives")
+    contrastive = load("merlin/models/torch/outputs/contrastive.py", "contrastive_outputs", "ContrastiveOutput",
+                       {"rescore_false_negatives": rescore})
+    B, Nn, E = 37, 53, 24
+    q = torch.randn(B, E, generator=g) * 0.5
+    pos = torch.randn(B, E, generator=g) * 0.5
+    neg = torch.randn(Nn, E, generator=g) * 0.5
+    pos_id = torch.randint(0, 20, (B,), generator=g)
+    neg_id = torch.randint(0, 20, (Nn,), generator=g)
+    me = types.SimpleNamespace(downscore_false_negatives=True, false_negative_score=float(np.finfo(np.float16).min) / 100.0)
+    logits = contrastive(me, q, pos, neg, pos_id.unsqueeze(0), neg_id.unsqueeze(0))
+    out.update(sc_q=q, sc_pos=pos, sc_neg=neg, sc_pos_id=pos_id, sc_neg_id=neg_id, sc_logits=logits, sc_target=me.target)
+    # in-batch: negatives are the batch's own items, ids shared (diagonal + duplicate ids masked)
+    ids = torch.randint(0, 12, (B,), generator=g)
+    me2 = types.SimpleNamespace(downscore_false_negatives=True, false_negative_score=-655.04)
+    out.update(ib_ids=ids, ib_logits=contrastive(me2, q, pos, pos, ids.unsqueeze(0), ids.unsqueeze(0)))
+    me3 = types.SimpleNamespace(downscore_false_negatives=False, false_negative_score=0.0)
+    out.update(nd_logits=contrastive(me3, q, pos, neg, None, None))
+
+    # --- DLRM interaction -----------------------------------------------------------------------
+    fwd = load("merlin/models/torch/blocks/dlrm.py", "forward", "DLRMInteraction")
+    Inter = type("Inter", (torch.nn.Module,), {"forward": fwd})
+    for (b, f, d) in [(9, 27, 64), (5, 4, 8), (3, 17, 32)]:
+        X = torch.randn(b, f, d, generator=g)
+        out[f"int_x_{f}_{d}"] = X
+        out[f"int_y_{f}_{d}"] = Inter()(X)
+
+    # --- cross block (loop body of CrossBlock.forward with explicit Linear modules) -------------
+    cross_fwd = load("merlin/models/torch/blocks/cross.py", "forward", "CrossBlock")
+    d, depth = 20, 3
+    lins = [torch.nn.Linear(d, d) for _ in range(depth)]
+    for i, lin in enumerate(lins):
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(d, d, generator=g) * 0.2)
+            lin.bias.copy_(torch.randn(d, generator=g) * 0.1)
+        out[f"cr_W{i}"] = lin.weight.detach().T.contiguous()  # keras layout [in, out]
+        out[f"cr_b{i}"] = lin.bias.detach()
+    me4 = types.SimpleNamespace(values=lins, concat=None)
+    x = torch.randn(11, d, generator=g)
+    out.update(cr_x=x, cr_y=cross_fwd(me4, x).detach())
+
+    # --- inferred embedding dims ----------------------------------------------------------------
+    emb = load("merlin/models/utils/schema_utils.py", "get_embedding_size_from_cardinality")
+    cards = np.array([2, 10, 100, 1000, 10_000, 1_000_000, 10_000_000])
+    out.update(emb_card=cards, emb_dim=np.array([emb(int(c), 2.0, True) for c in cards]),
+               emb_dim_raw=np.array([emb(int(c), 2.0, False) for c in cards]))
+
+    np.savez_compressed(OUT / "reference_vectors.npz",
+                        **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
+    print("wrote", OUT / "reference_vectors.npz", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

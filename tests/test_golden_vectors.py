@@ -1,0 +1,80 @@
+"""Golden vectors produced by executing the reference's own torch functions
+(tests/golden/make_golden.py): the oracle must reproduce them on CPU, the HIP path on the GPU."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = np.load(Path(__file__).resolve().parent / "golden" / "reference_vectors.npz")
+ATOL = 1e-4
+
+
+def test_oracle_scorer_matches_reference_vectors():
+    out, tgt = O.contrastive_outputs(G["sc_q"], G["sc_pos"], G["sc_neg"], G["sc_pos_id"], G["sc_neg_id"])
+    np.testing.assert_allclose(out, G["sc_logits"], atol=1e-5)
+    np.testing.assert_array_equal(tgt, G["sc_target"])
+    out, _ = O.contrastive_outputs(G["sc_q"], G["sc_pos"], G["sc_pos"], G["ib_ids"], G["ib_ids"], false_negative_score=-655.04)
+    np.testing.assert_allclose(out, G["ib_logits"], atol=1e-5)
+    out, _ = O.contrastive_outputs(G["sc_q"], G["sc_pos"], G["sc_neg"], downscore_false_negatives=False)
+    np.testing.assert_allclose(out, G["nd_logits"], atol=1e-5)
+
+
+@pytest.mark.parametrize("f,d", [(27, 64), (4, 8), (17, 32)])
+def test_oracle_interaction_matches_reference_vectors(f, d):
+    np.testing.assert_allclose(O.dot_interaction(G[f"int_x_{f}_{d}"]), G[f"int_y_{f}_{d}"], atol=1e-4, rtol=1e-5)
+
+
+def test_oracle_cross_matches_reference_vectors():
+    layers = [(G[f"cr_W{i}"], G[f"cr_b{i}"]) for i in range(3)]
+    np.testing.assert_allclose(O.cross_block(G["cr_x"], layers), G["cr_y"], atol=1e-4, rtol=1e-5)
+
+
+def test_inferred_embedding_dims_match_reference():
+    from models_amd.schema import infer_embedding_dim
+
+    got = [infer_embedding_dim(int(c), 2.0, True) for c in G["emb_card"]]
+    np.testing.assert_array_equal(got, G["emb_dim"])
+    got = [infer_embedding_dim(int(c), 2.0, False) for c in G["emb_card"]]
+    np.testing.assert_array_equal(got, G["emb_dim_raw"])
+
+
+# ---- the same vectors through the HIP path ------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_scorer_matches_reference_vectors(device):
+    import torch
+
+    from models_amd import ops
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    r = ops.inbatch_softmax(t(G["sc_q"]), t(G["sc_pos"]), t(G["sc_neg"]), t(G["sc_pos_id"]), t(G["sc_neg_id"]))
+    np.testing.assert_allclose(r.logits.cpu().numpy(), G["sc_logits"], atol=ATOL)
+    r = ops.inbatch_softmax(t(G["sc_q"]), t(G["sc_pos"]), t(G["sc_pos"]), t(G["ib_ids"]), t(G["ib_ids"]))
+    np.testing.assert_allclose(r.logits.cpu().numpy(), G["ib_logits"], atol=ATOL)
+    r = ops.inbatch_softmax(t(G["sc_q"]), t(G["sc_pos"]), t(G["sc_neg"]))
+    np.testing.assert_allclose(r.logits.cpu().numpy(), G["nd_logits"], atol=ATOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f,d", [(27, 64), (4, 8), (17, 32)])
+def test_hip_interaction_matches_reference_vectors(device, f, d):
+    import torch
+
+    from models_amd import ops
+
+    out = ops.dot_interaction(torch.from_numpy(G[f"int_x_{f}_{d}"]).to(device)).cpu().numpy()
+    np.testing.assert_allclose(out, G[f"int_y_{f}_{d}"], atol=ATOL, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_cross_matches_reference_vectors(device):
+    import torch
+
+    from models_amd import ops
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    x0 = x = t(G["cr_x"])
+    for i in range(3):
+        x = ops.cross_layer(x0, x, t(G[f"cr_W{i}"]), t(G[f"cr_b{i}"]))
+    np.testing.assert_allclose(x.cpu().numpy(), G["cr_y"], atol=ATOL, rtol=1e-5)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Per-kernel timing at the BASELINE config-2 shapes (development tool; run through gpurun)."""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+
+from models_amd import ops
+
+dev = torch.device("cuda")
+B, F, D = 65536, 27, 64
+
+
+def timeit(name, fn, nbytes=None, flops=None, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    extra = ""
+    if nbytes:
+        extra += f"  {nbytes / ms / 1e6:8.1f} GB/s"
+    if flops:
+        extra += f"  {flops / ms / 1e9:8.1f} TF/s"
+    print(f"{name:40s} {ms * 1e3:9.1f} us{extra}", flush=True)
+    return ms
+
+
+which = set(sys.argv[1:])
+g = torch.Generator(device="cpu").manual_seed(0)
+if not which or "inter" in which:
+    x = torch.randn(B, F, D, device=dev)
+    tail = x[:, 5]
+    P = F * (F - 1) // 2
+    out = torch.empty(B, 416, device=dev)
+    timeit("dot_interaction fwd", lambda: ops.dot_interaction(x, tail, out=out[:, :415]), nbytes=B * (F * D * 4 + 415 * 4))
+    dout = torch.randn(B, 415, device=dev)
+    timeit("dot_interaction bwd", lambda: ops.dot_interaction_backward(x, dout, 5, D), nbytes=B * (2 * F * D * 4 + 415 * 4))
+if not which or "linbwd" in which:
+    for (K, N) in [(415, 128), (128, 64), (64, 32), (13, 128), (32, 1)]:
+        xx = torch.randn(B, K, device=dev)
+        W = torch.randn(K, N, device=dev) * 0.1
+        y = ops.linear(xx, W, None, "relu" if N > 1 else None)
+        dy = torch.randn(B, N, device=dev)
+        timeit(f"linear fwd {K}x{N}", lambda: ops.linear(xx, W, None, "relu"), flops=2 * B * K * N, nbytes=4 * B * (K + N))
+        timeit(f"linear bwd {K}x{N}", lambda: ops.linear_backward(xx, W, y, dy, "relu" if N > 1 else None), flops=4 * B * K * N,
+               nbytes=4 * B * (2 * K + 2 * N))
+if not which or "embbwd" in which:
+    from models_amd.synthetic import CRITEO_CARDINALITIES
+
+    tabs = [torch.rand(v, D, device=dev) for v in CRITEO_CARDINALITIES]
+    st = [torch.full_like(t, 0.1) for t in tabs]
+    ids = [torch.randint(0, v, (B,), dtype=torch.int32, device=dev) for v in CRITEO_CARDINALITIES]
+    grad = torch.randn(B, F, D, device=dev)
+    offs = [i * D for i in range(26)]
+    timeit("embedding bwd adagrad (26 tables)", lambda: ops.embedding_gather_backward(tabs, st, ids, grad, offs, "adagrad", 0.01, 1e-7))
+    timeit("embedding bwd sgd (26 tables)", lambda: ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", 0.01, 1e-7))
+    outb = torch.empty(B, F, D, device=dev)
+    timeit("embedding gather fwd", lambda: ops.embedding_gather(tabs, ids, out=outb), nbytes=B * 26 * (2 * D * 4 + 4))
+    big = torch.rand(50_000_000, D, device=dev)  # 12.8 GB >> 256 MiB MALL
+    idb = [torch.randint(0, 50_000_000, (B * 8,), dtype=torch.int32, device=dev)]
+    outl = torch.empty(B * 8, 1, D, device=dev)
+    timeit("gather fwd, one 12.8 GB table, 512K ids", lambda: ops.embedding_gather([big], idb, out=outl), nbytes=B * 8 * (2 * D * 4 + 4))
+if "scorer" in which:
+    Bs, E = 32768, 128
+    q = torch.randn(Bs, E, device=dev) * 0.1
+    it = torch.randn(Bs, E, device=dev) * 0.1
+    ids = torch.randperm(1_000_000, device=dev)[:Bs].to(torch.int32)
+    timeit("scorer fwd fused 32Kx32Kx128", lambda: ops.inbatch_softmax(q, it, it, ids, ids, materialize=False), flops=2 * Bs * Bs * E, iters=5)
+    r = ops.inbatch_softmax(q, it, it, ids, ids, materialize=False)
+    timeit("scorer bwd 32Kx32Kx128", lambda: ops.inbatch_softmax_backward(q, it, it, r.lse, ids, ids), flops=6 * Bs * Bs * E, iters=3)
+if "topk" in which:
+    N, E, Bq, k = 1_000_000, 128, 4096, 100
+    c = torch.randn(N, E, device=dev)
+    qq = torch.randn(Bq, E, device=dev)
+    timeit("topk 4096 x 1M x 128, k=100", lambda: ops.topk_dot(qq, c, None, k), flops=2 * Bq * N * E, iters=3)
+if "cross" in which:
+    d = 3341
+    x0 = torch.randn(B, d, device=dev)
+    W = torch.randn(d, d, device=dev) * 0.02
+    bb = torch.zeros(d, device=dev)
+    timeit("cross layer 64K x 3341 x 3341", lambda: ops.cross_layer(x0, x0, W, bb), flops=2 * B * d * d, iters=3)
