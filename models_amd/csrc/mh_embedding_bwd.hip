@@ -80,12 +80,33 @@ __device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ 
     return lo;
 }
 
+// chunk c: v[c] = -1 if its first run continues from the previous chunk AND the whole chunk is that one
+// run (the run's home lies further back), else c.  An inclusive max-scan of v gives lasthome[c] = home
+// chunk of the LAST run of chunk c; the head piece of a continuing chunk c then belongs to lasthome[c-1].
+__global__ __launch_bounds__(256) void chunk_flags_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                         int64_t nchunks, int* __restrict__ v) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    const int64_t c0 = c * CHUNK;
+    const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
+    const bool cont = (c0 > 0) && (keys[c0 - 1] == keys[c0]);
+    const bool whole = keys[c1 - 1] == keys[c0];  // sorted: first == last  <=>  one run
+    v[c] = (cont && whole) ? -1 : (int)c;
+}
+
+// One D/4-lane group per chunk of 16 sorted entries: run sums are formed in registers; a run wholly
+// inside the chunk is applied to its table row directly (exclusive owner, no atomics); a run crossing
+// a chunk boundary adds its piece to carry[home chunk] (home from the scanned chunk flags).
+// Latency is hidden by occupancy (~25 waves/CU at ~40 VGPRs) rather than by batching: the batched
+// variants tried in round 1 (all 16 rows in flight, batched read-modify-write) needed 250+ VGPRs and
+// ran slower (profiles/r1_notes.md).
 __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
                                                                   const uint32_t* __restrict__ vals, int64_t n,
                                                                   int D, int LPR, const float* __restrict__ grad,
                                                                   int64_t grad_row_stride, float* __restrict__ carry,
+                                                                  const int* __restrict__ lasthome,
                                                                   int opt, float lr, float eps) {
-    const int groups = 256 / LPR;
+    const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
     if (gi >= groups) return;
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs
         if (starts_here && ends_here) {
             apply_update(a, key, acc, D, c4, opt, lr, eps);
         } else {
-            const int64_t home = starts_here ? chunk : lower_bound_u64(keys, c0, key) / CHUNK;
+            const int64_t home = starts_here ? chunk : (int64_t)lasthome[chunk - 1];
             float* cr = carry + home * D + c4 * 4;
             atomicAdd(cr + 0, acc.x);
             atomicAdd(cr + 1, acc.y);
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs
 __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
                                                          int64_t n, int D, int LPR, const float* __restrict__ carry,
                                                          int opt, float lr, float eps) {
-    const int groups = 256 / LPR;
+    const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
     if (gi >= groups) return;
@@ -156,7 +177,9 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
 
 struct WsLayout {
     int64_t n, nchunks;
-    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_tmp, tmp_bytes, total;
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_flags, off_home, off_tmp, tmp_bytes,
+        scan_bytes, total;
+    int key_bits;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -168,12 +191,20 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                              (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, KEY_BITS);
     if (e != hipSuccess) return false;
+    size_t scan = 0;
+    e = rocprim::inclusive_scan(nullptr, scan, (const int*)nullptr, (int*)nullptr, (size_t)L->nchunks,
+                                rocprim::maximum<int>());
+    if (e != hipSuccess) return false;
+    L->scan_bytes = scan;
+    if (scan > tmp) tmp = scan;
     size_t o = 0;
     L->off_keys_a = o; o = align_up(o + (size_t)L->n * 8, 256);
     L->off_keys_b = o; o = align_up(o + (size_t)L->n * 8, 256);
     L->off_vals_a = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_vals_b = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_carry = o; o = align_up(o + (size_t)L->nchunks * D * 4, 256);
+    L->off_flags = o; o = align_up(o + (size_t)L->nchunks * 4, 256);
+    L->off_home = o; o = align_up(o + (size_t)L->nchunks * 4, 256);
     L->off_tmp = o; L->tmp_bytes = tmp; o = align_up(o + tmp, 256);
     L->total = o;
     return true;
@@ -196,7 +227,7 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
                                 int32_t optimizer, float lr, float eps, void* workspace, int64_t workspace_bytes,
                                 mh_stream_t stream) {
     MH_REQUIRE(tables && table_rows && ids && grad && grad_offset, "mh_embedding_gather_bwd: null argument");
-    MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_embedding_gather_bwd: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
+    MH_REQUIRE(F >= 1 && F < MH_MAX_FEATURES, "mh_embedding_gather_bwd: F=%d outside [1,%d]", F, MH_MAX_FEATURES - 1);
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_bwd: D=%d must be a multiple of 4 in [4,1024]", D);
     MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_gather_bwd: bad ids_dtype");
     MH_REQUIRE(optimizer == MH_OPT_SGD || optimizer == MH_OPT_ADAGRAD, "mh_embedding_gather_bwd: bad optimizer %d", optimizer);
@@ -243,18 +274,49 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     else
         hipLaunchKernelGGL((build_keys_kernel<int64_t>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a);
     size_t tmp_bytes = L.tmp_bytes;
+    // sort only over the key bits in use: id bits of the largest table + the table index at bit 40..
+    // (keys are (table << 40 | id); the sentinel is all ones, so it stays last under any bit window
+    //  that includes the table field) -- two radix passes over [0, idbits) and [40, 40 + tbits) would
+    // need a stable two-stage sort; rocPRIM's single call over [0, 46) costs 6 passes, so instead the
+    // id field is sorted first and the (narrow) table field second, both stable.
+    int idbits = 1;
+    {
+        int64_t maxrows = 1;
+        for (int f = 0; f < F; ++f) maxrows = table_rows[f] > maxrows ? table_rows[f] : maxrows;
+        while ((1ll << idbits) < maxrows) ++idbits;
+        if (idbits > 40) idbits = 40;
+    }
     hipError_t e = rocprim::radix_sort_pairs(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)L.n, 0,
-                                             KEY_BITS, s);
+                                             idbits, s);
+    if (e == hipSuccess) {
+        tmp_bytes = L.tmp_bytes;
+        e = rocprim::radix_sort_pairs(ws + L.off_tmp, tmp_bytes, keys_b, keys_a, vals_b, vals_a, (size_t)L.n, 40,
+                                      KEY_BITS, s);
+    }
+    {   // results are back in the *_a buffers
+        uint64_t* tk = keys_a; keys_a = keys_b; keys_b = tk;
+        uint32_t* tv = vals_a; vals_a = vals_b; vals_b = tv;
+    }
     if (e != hipSuccess) {
         mh_set_error("mh_embedding_gather_bwd: radix sort failed: %s", hipGetErrorString(e));
         return MH_ERR_LAUNCH;
     }
     (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
     const int LPR = D / 4;
-    const int groups = 256 / LPR;
+    const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     dim3 gs((unsigned)mh_ceil_div(L.nchunks, groups));
+    int* flags = reinterpret_cast<int*>(ws + L.off_flags);
+    int* lasthome = reinterpret_cast<int*>(ws + L.off_home);
+    hipLaunchKernelGGL(chunk_flags_kernel, dim3((unsigned)mh_ceil_div(L.nchunks, 256)), dim3(256), 0, s, keys_b, L.n,
+                       L.nchunks, flags);
+    size_t scan_bytes = L.tmp_bytes;
+    e = rocprim::inclusive_scan(ws + L.off_tmp, scan_bytes, flags, lasthome, (size_t)L.nchunks, rocprim::maximum<int>(), s);
+    if (e != hipSuccess) {
+        mh_set_error("mh_embedding_gather_bwd: scan failed: %s", hipGetErrorString(e));
+        return MH_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(segment_reduce_apply_kernel, gs, dim3(256), 0, s, a, keys_b, vals_b, L.n, D, LPR, grad,
-                       grad_row_stride, carry, optimizer, lr, eps);
+                       grad_row_stride, carry, lasthome, optimizer, lr, eps);
     hipLaunchKernelGGL(carry_apply_kernel, gs, dim3(256), 0, s, a, keys_b, L.n, D, LPR, carry, optimizer, lr, eps);
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;

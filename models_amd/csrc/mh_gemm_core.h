@@ -33,6 +33,16 @@ struct KMajorTile {
 
     __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t row0,
                                          int64_t nrows, int k0, int K, bool vec_ok) {
+        // interior tile: unconditional 16-byte loads (workgroup-uniform branch)
+        if (vec_ok && row0 + ROWS <= nrows && k0 + BK <= K && (ROWS * (BK / 4)) % NT == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int r = idx >> 3, c4 = idx & 7;
+                regs[i] = *reinterpret_cast<const f32x4*>(src + (row0 + r) * ld + k0 + c4 * 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * NT;
@@ -77,6 +87,15 @@ struct NMajorTile {
 
     __device__ __forceinline__ void load(const float* __restrict__ W, int64_t ldw, int k0, int K,
                                          int n0, int N, bool vec_ok) {
+        if (vec_ok && k0 + BK <= K && n0 + COLS <= N && (BK * VPR) % NT == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int r = idx / VPR, c4 = idx - r * VPR;
+                regs[i] = *reinterpret_cast<const f32x4*>(W + (int64_t)(k0 + r) * ldw + n0 + c4 * 4);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * NT;
@@ -111,41 +130,50 @@ struct NMajorTile {
 // As: k-major tile, rows a_row0 + tm*32 + (lane&31).
 // B_NT: Bs k-major tile, rows b_row0 + tn*32 + (lane&31); else Bs is n-major [BK][ldb].
 template <int TM, int TN, bool B_NT>
+struct Frag {
+    f32x4 a[TM];
+    f32x4 b[TN];  // 4 consecutive k-steps of one k-slot
+    __device__ __forceinline__ void load(const float* __restrict__ As, int a_row0, const float* __restrict__ Bs,
+                                         int b_row0, int ldb, int g, int l31, int h) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+            a[tm] = *reinterpret_cast<const f32x4*>(As + (a_row0 + tm * 32 + l31) * LDK + h * 16 + g * 4);
+        if (B_NT) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                b[tn] = *reinterpret_cast<const f32x4*>(Bs + (b_row0 + tn * 32 + l31) * LDK + h * 16 + g * 4);
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(2 * (4 * g + j) + h) * ldb + b_row0 + tn * 32 + l31];
+        }
+    }
+};
+
+// LDS -> register fragments are double-buffered across the four 4-step groups of a k-tile: the
+// reads of group g+1 are issued before the 4*TM*TN MFMAs of group g, so the matrix pipe never waits
+// on an LDS round trip (hipcc otherwise places each read right in front of its first use).
+template <int TM, int TN, bool B_NT>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, int a_row0,
                                           const float* __restrict__ Bs, int b_row0, int ldb,
                                           f32x16 (&acc)[TM][TN]) {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, h = lane >> 5;
+    Frag<TM, TN, B_NT> f0, f1;
+    f0.load(As, a_row0, Bs, b_row0, ldb, 0, l31, h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        f32x4 a[TM];
+        Frag<TM, TN, B_NT>& cur = (g & 1) ? f1 : f0;
+        Frag<TM, TN, B_NT>& nxt = (g & 1) ? f0 : f1;
+        if (g < 3) nxt.load(As, a_row0, Bs, b_row0, ldb, g + 1, l31, h);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-            a[tm] = *reinterpret_cast<const f32x4*>(As + (a_row0 + tm * 32 + l31) * LDK + h * 16 + g * 4);
-        if (B_NT) {
-            f32x4 b[TN];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                b[tn] = *reinterpret_cast<const f32x4*>(Bs + (b_row0 + tn * 32 + l31) * LDK + h * 16 + g * 4);
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(a[tm][j], b[tn][j], acc[tm][tn]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float b[TN];
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    b[tn] = Bs[(2 * (4 * g + j) + h) * ldb + b_row0 + tn * 32 + l31];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(a[tm][j], b[tn], acc[tm][tn]);
-            }
-        }
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(cur.a[tm][j], cur.b[tn][j], acc[tm][tn]);
     }
 }
 

@@ -108,6 +108,90 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
 }
 
 
+// Pipelined variant (F*D <= 2048 floats, D % 16 == 0): wavefronts are fully independent (private
+// LDS slab, no workgroup barrier); the NEXT sample's rows are prefetched into registers while the
+// current one is on the matrix pipe, so HBM latency is hidden by MFMA work instead of by occupancy.
+template <int NV>
+__global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const float* __restrict__ x, int64_t B,
+                                                                      int F, int D,
+                                                                      const float* __restrict__ tail,
+                                                                      int64_t ld_tail, int T,
+                                                                      float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = D + 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Xs = smem + wave * IMAXF * LD;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int P = F * (F - 1) / 2;
+    const int vpr = D / 4, nvec = F * vpr;
+    const int qoff = q * (D / 4);
+    const int steps = D / 4;
+    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+
+    int lds_off[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + 64 * i;
+        const int r = idx / vpr, c4 = idx - r * vpr;
+        lds_off[i] = (idx < nvec) ? r * LD + c4 * 4 : -1;
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    f32x4 xr[NV];
+    if (b < B) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + b * (int64_t)F * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lds_off[i] >= 0) xr[i] = src[lane + 64 * i];
+    }
+    const bool two = F > 16;
+    while (b < B) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(Xs + lds_off[i]) = xr[i];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t bn = b + stride;
+        if (bn < B) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + bn * (int64_t)F * D);
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lds_off[i] >= 0) xr[i] = src[lane + 64 * i];
+        }
+        float tv = 0.f;  // tail element of this lane (T <= 64 fast path; longer tails loop below)
+        if (tail && lane < T) tv = tail[b * ld_tail + lane];
+        f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
+        const float* r0 = Xs + i16 * LD + qoff;
+        const float* r1 = Xs + (16 + i16) * LD + qoff;
+        for (int s = 0; s < steps; s += 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0 + s);
+            if (two) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(r1 + s);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc00 = mfma16(a0[j], a0[j], acc00);
+                    acc01 = mfma16(a0[j], a1[j], acc01);
+                    acc11 = mfma16(a1[j], a1[j], acc11);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc00 = mfma16(a0[j], a0[j], acc00);
+            }
+        }
+        float* orow = out + b * ldo;
+        store_tile(acc00, 0, 0, lane, F, orow);
+        if (two) {
+            store_tile(acc01, 0, 1, lane, F, orow);
+            store_tile(acc11, 1, 1, lane, F, orow);
+        }
+        if (tail) {
+            if (lane < T) orow[P + lane] = tv;
+            for (int t = lane + 64; t < T; t += 64) orow[P + t] = tail[b * ld_tail + t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        b = bn;
+    }
+}
+
 // ---- backward -----------------------------------------------------------------------------------
 // dX = (G + G^T) X with G the strict-upper-triangular matrix scattered from dout[:, :P].
 // One wavefront per sample: S = G + G^T ([32][34] fp32 in LDS, zero diagonal / padding) is the
@@ -212,6 +296,136 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* _
     }
 }
 
+// Pipelined backward (D in {16,32,64,128}, F*D <= 2048): independent wavefronts, next-sample prefetch
+// into registers, and the dX tile is transposed through the (dead) X slab so that global stores are
+// full 16-byte-per-lane rows instead of 64-byte fragments.
+template <int DT, int NV>
+__global__ __launch_bounds__(256) void dot_interaction_bwd_pipe_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ dout, int64_t ldo,
+                                                                      int64_t B, int F, float* __restrict__ dx,
+                                                                      int tail_slot, int T) {
+    constexpr int D = DT * 16;
+    constexpr int LD = D + 16;
+    constexpr int NP = 8;  // ceil(496 / 64) gradient values per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = F * (F - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* pair_j = pair_i + 512;
+    float* base = smem + 256;
+    float* Xs = base + wave * (IMAXF * LD + IMAXF * LDS_S);
+    float* Ss = Xs + IMAXF * LD;
+    const int i16 = lane & 15, q = lane >> 4;
+    constexpr int vpr = D / 4;
+    const int nvec = F * vpr;
+
+    for (int p = threadIdx.x; p < P; p += 256) {
+        int i = 0, start = 0;
+        while (start + (F - 1 - i) <= p) {
+            start += F - 1 - i;
+            ++i;
+        }
+        pair_i[p] = (unsigned char)i;
+        pair_j[p] = (unsigned char)(i + 1 + (p - start));
+    }
+    for (int idx = lane; idx < IMAXF * LDS_S; idx += 64) Ss[idx] = 0.f;
+    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+    __syncthreads();  // pair table (the only cross-wave dependency)
+
+    int lds_off[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + 64 * i;
+        const int r = idx / vpr, c4 = idx - r * vpr;
+        lds_off[i] = (idx < nvec) ? r * LD + c4 * 4 : -1;
+    }
+    int s_off0[NP], s_off1[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = lane + 64 * k;
+        if (p < P) {
+            s_off0[k] = pair_i[p] * LDS_S + pair_j[p];
+            s_off1[k] = pair_j[p] * LDS_S + pair_i[p];
+        } else {
+            s_off0[k] = s_off1[k] = -1;
+        }
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    f32x4 xr[NV];
+    float gr[NP];
+    auto prefetch = [&](int64_t bb) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + bb * (int64_t)F * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lds_off[i] >= 0) xr[i] = src[lane + 64 * i];
+        const float* g = dout + bb * ldo;
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (s_off0[k] >= 0) gr[k] = g[lane + 64 * k];
+        // tail gradient for column d = (lane & 15) + 16*tn is fetched lazily below
+    };
+    if (b < B) prefetch(b);
+    const int nti = F > 16 ? 2 : 1;
+    while (b < B) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(Xs + lds_off[i]) = xr[i];
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (s_off0[k] >= 0) {
+                Ss[s_off0[k]] = gr[k];
+                Ss[s_off1[k]] = gr[k];
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int64_t bn = b + stride;
+        const float* gcur = dout + b * ldo;
+        float tgv[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            const int d = 16 * tn + i16;
+            tgv[tn] = (tail_slot >= 0 && d < T) ? gcur[P + d] : 0.f;
+        }
+        if (bn < B) prefetch(bn);
+        float a0[8], a1[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            a0[st] = Ss[i16 * LDS_S + 4 * st + q];
+            a1[st] = (nti == 2) ? Ss[(16 + i16) * LDS_S + 4 * st + q] : 0.f;
+        }
+        f32x4 acc0[DT], acc1[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            acc0[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[tn] = acc0[tn];
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const float bv = Xs[(4 * st + q) * LD + 16 * tn + i16];
+                acc0[tn] = mfma16(a0[st], bv, acc0[tn]);
+                if (nti == 2) acc1[tn] = mfma16(a1[st], bv, acc1[tn]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // all reads of X done: reuse the slab for dX
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            const int d = 16 * tn + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f0 = q * 4 + r, f1 = 16 + f0;
+                Xs[f0 * LD + d] = acc0[tn][r] + (f0 == tail_slot ? tgv[tn] : 0.f);
+                if (nti == 2) Xs[f1 * LD + d] = acc1[tn][r] + (f1 == tail_slot ? tgv[tn] : 0.f);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + b * (int64_t)F * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lds_off[i] >= 0) dst[lane + 64 * i] = *reinterpret_cast<const f32x4*>(Xs + lds_off[i]);
+        __builtin_amdgcn_wave_barrier();
+        b = bn;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -240,8 +454,14 @@ int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, 
             return MH_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
-                       tail, ld_tail, T, out, ldo);
+    if (D % 16 == 0 && F * (D / 4) <= 64 * 8) {
+        auto kern = dot_interaction_fwd_pipe_kernel<8>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, mh_stream(stream), x, B, F, D, tail, ld_tail, T, out, ldo);
+    } else {
+        hipLaunchKernelGGL(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
+                           tail, ld_tail, T, out, ldo);
+    }
     MH_CHECK_LAUNCH("mh_dot_interaction_fwd");
     return MH_OK;
 }
@@ -268,8 +488,24 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
             return MH_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL(dot_interaction_bwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, dout, ldo, B, F, D,
-                       dx, tail_slot, T);
+    const bool pipe = (D == 16 || D == 32 || D == 64 || D == 128) && F * (D / 4) <= 64 * 8;
+    if (pipe) {
+        hipStream_t s_ = mh_stream(stream);
+#define MH_LAUNCH_BWD_PIPE(DT)                                                                                   \
+    {                                                                                                            \
+        auto kern = dot_interaction_bwd_pipe_kernel<DT, 8>;                                                      \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, x, dout, ldo, B, F, dx, tail_slot, T);                \
+    }
+        if (D == 16) MH_LAUNCH_BWD_PIPE(1)
+        else if (D == 32) MH_LAUNCH_BWD_PIPE(2)
+        else if (D == 64) MH_LAUNCH_BWD_PIPE(4)
+        else MH_LAUNCH_BWD_PIPE(8)
+#undef MH_LAUNCH_BWD_PIPE
+    } else {
+        hipLaunchKernelGGL(dot_interaction_bwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, dout, ldo, B, F, D,
+                           dx, tail_slot, T);
+    }
     MH_CHECK_LAUNCH("mh_dot_interaction_bwd");
     return MH_OK;
 }

@@ -56,14 +56,28 @@ __global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __res
     }
 }
 
-// out[i] = sum_s part[s*len + i] in ascending s (deterministic)
+// out[i] = sum_s part[s*len + i].  block = 64 outputs x 4 slice groups; group g sums slices
+// g, g+4, ... with 4 independent loads in flight, then the 4 group sums are combined in fixed order
+// through LDS -> deterministic, and S sequential HBM round trips become S/16.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int S,
                                                              int64_t len, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= len) return;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(int64_t)k * len + i];
-    out[i] = s;
+    __shared__ float red[256];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < len) {
+        int k = g;
+        for (; k + 12 < S; k += 16) {
+            s0 += part[(int64_t)k * len + i];
+            s1 += part[(int64_t)(k + 4) * len + i];
+            s2 += part[(int64_t)(k + 8) * len + i];
+            s3 += part[(int64_t)(k + 12) * len + i];
+        }
+        for (; k < S; k += 4) s0 += part[(int64_t)k * len + i];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < len) out[i] = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
 }
 
 // C[M, Nout] = A[M, Kc] * B[Nout, Kc]^T   (both operands contraction-contiguous)
@@ -286,7 +300,7 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
         hipLaunchKernelGGL(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
                            act, CW, db ? ws_db : nullptr);
         if (db)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(256), 0, s,
                                ws_db, p.act_blocks, (int64_t)N, db);
     }
     const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
@@ -300,7 +314,7 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
         hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
                            p.rows_per_split, ws_dw, vec_x, vec_dy);
         const int64_t len = (int64_t)K * N;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(len, 256)), dim3(256), 0, s, ws_dw,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(len, 64)), dim3(256), 0, s, ws_dw,
                            p.splits, len, dW);
     }
     MH_CHECK_LAUNCH("mh_linear_bias_act_bwd");

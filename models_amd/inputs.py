@@ -225,8 +225,8 @@ class EmbeddingsBlock(ParallelBlock):
                     if "accumulator" not in t.state:
                         t.state["accumulator"] = torch.full_like(t.data, opt.initial_accumulator_value)
                 states = [t.state["accumulator"] for t in tabs]
-            for start in range(0, len(grp), 64):
-                sl = slice(start, start + 64)
+            for start in range(0, len(grp), 63):
+                sl = slice(start, start + 63)
                 ops.embedding_gather_backward([t.data for t in tabs[sl]], None if states is None else states[sl],
                                               [self._last[n] for n in grp[sl]], grad, [offsets[n] for n in grp[sl]],
                                               opt.name, opt.learning_rate, opt.epsilon)

@@ -362,8 +362,8 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     F = len(tables)
     if F == 0:
         return
-    if F > _lib.MAX_FEATURES:
-        raise ValueError(f"at most {_lib.MAX_FEATURES} features per backward call")
+    if F > _lib.MAX_FEATURES - 1:
+        raise ValueError(f"at most {_lib.MAX_FEATURES - 1} features per backward call")
     _dev(grad, "grad", torch.float32)
     if not grad.is_contiguous():
         raise ValueError("grad must be contiguous")

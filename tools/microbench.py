@@ -68,6 +68,15 @@ if not which or "embbwd" in which:
     idb = [torch.randint(0, 50_000_000, (B * 8,), dtype=torch.int32, device=dev)]
     outl = torch.empty(B * 8, 1, D, device=dev)
     timeit("gather fwd, one 12.8 GB table, 512K ids", lambda: ops.embedding_gather([big], idb, out=outl), nbytes=B * 8 * (2 * D * 4 + 4))
+if "embbig" in which:
+    tabs = [torch.rand(1_000_000, D, device=dev) for _ in range(26)]
+    ids = [torch.randint(0, 1_000_000, (B,), dtype=torch.int32, device=dev) for _ in range(26)]
+    grad = torch.randn(B, F, D, device=dev)
+    offs = [i * D for i in range(26)]
+    timeit("embedding bwd sgd, 26 x 1M-row tables", lambda: ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", 0.01, 1e-7))
+    tabs = [torch.rand(16, D, device=dev) for _ in range(26)]
+    ids = [torch.randint(0, 16, (B,), dtype=torch.int32, device=dev) for _ in range(26)]
+    timeit("embedding bwd sgd, 26 x 16-row tables", lambda: ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", 0.01, 1e-7))
 if "scorer" in which:
     Bs, E = 32768, 128
     q = torch.randn(Bs, E, device=dev) * 0.1
