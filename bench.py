@@ -61,21 +61,33 @@ def make_batch(device, B, rank, dist="uniform"):
     return batch, label
 
 
-def cpu_baseline(model, batch, B_cpu, budget_s=20.0):
-    """numpy oracle ("port") of the same forward on the host cores, bounded sample."""
+def cpu_baseline(model, batch, label, B_cpu, mode, optimizer, budget_s=20.0):
+    """numpy oracle ("port") of the SAME step on the host cores, bounded sample.  Works on host copies of
+    the model state, so the timed GPU model is untouched."""
     from oracle import oracle as O
 
     body = model.body
     tables = {n: body.embeddings.feature_table[n].table.data.cpu().numpy() for n in body.cat_names}
     cat = {n: batch[n][:B_cpu].cpu().numpy() for n in body.cat_names}
     cont = {n: batch[n][:B_cpu].cpu().numpy() for n in body.continuous.features}
-    lay = lambda blk: [(l.kernel.numpy(), l.bias.numpy(), l.activation) for l in blk.layers]
+    y = label[:B_cpu].cpu().numpy()
+    lay = lambda blk: [(l.kernel.numpy().copy(), l.bias.numpy().copy(), l.activation) for l in blk.layers]
     head = model.output.to_call
-    args = (cat, cont, tables, lay(body.bottom_block), lay(body.top_block), (head.kernel.numpy(), head.bias.numpy()))
-    O.dlrm_forward(*args)  # first step discarded (tf/logging/callbacks.py:174-189)
+    bottom, top, hd = lay(body.bottom_block), lay(body.top_block), (head.kernel.numpy().copy(), head.bias.numpy().copy())
+    fwd_args = (cat, cont, tables, bottom, top, hd)
+    ref = O.dlrm_forward(*fwd_args)  # parity reference (before any CPU update)
+    state = {"s": None}
+
+    def one():
+        if mode == "fwd":
+            O.dlrm_forward(*fwd_args)
+        else:
+            _, state["s"] = O.dlrm_train_step(cat, cont, y, tables, bottom, top, hd, state["s"], optimizer, 0.01)
+
+    one()  # first step discarded (tf/logging/callbacks.py:174-189)
     n, t0 = 0, time.perf_counter()
     while True:
-        out = O.dlrm_forward(*args)
+        one()
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 50:
             break
@@ -86,8 +98,10 @@ def cpu_baseline(model, batch, B_cpu, budget_s=20.0):
         cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
+    what = "dlrm_forward" if mode == "fwd" else f"dlrm_train_step ({optimizer})"
     return {"value": B_cpu * n / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy oracle dlrm_forward, {n} steps x {B_cpu} samples (same tables/ids as the GPU batch)"}, out
+            "sample": f"numpy oracle {what}, {n} steps x {B_cpu} samples (same tables/ids as the GPU batch; "
+                      "BLAS threads for the GEMMs, single-threaded gather/scatter)"}, ref
 
 
 def main():
@@ -96,7 +110,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=65536)
-    ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--mode", choices=["fwd", "train"], default="train",
+                    help="train = fwd + BCE + bwd + optimizer update (the reference's fit() throughput)")
+    ap.add_argument("--optimizer", choices=["sgd", "adagrad"], default="adagrad")
+    ap.add_argument("--shard-threshold", type=int, default=200_000, help="rows >= this are row-sharded when N > 1")
     ap.add_argument("--ids", choices=["uniform", "lognormal"], default="uniform")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,20 +134,28 @@ def main():
     from models_amd import ops
 
     model, schema = build_model(device)
+    model.compile(optimizer=args.optimizer, learning_rate=0.01)
     batch, label = make_batch(device, args.batch, rank, args.ids)
+    model(batch)  # builds the lazily-shaped dense layers
 
     from models_amd.graph import GraphedStep
 
     static = dict(batch)
     static["__label__"] = label
+    runner = model
+    if world > 1:
+        from models_amd.distributed import DistributedDLRM
+
+        # replicated small tables + row-sharded large tables (all-to-all over xGMI), dense bucket reduce
+        runner = DistributedDLRM(model, shard_threshold=args.shard_threshold)
 
     def eager(inp):
         feats = {k: v for k, v in inp.items() if k != "__label__"}
         if args.mode == "fwd":
-            return model(feats)
-        return model.train_step(feats, inp["__label__"])
+            return runner(feats)
+        return runner.train_step(feats, inp["__label__"])
 
-    if args.eager:
+    if args.eager or world > 1:  # the sharded lookup needs host-side split sizes: not graph-capturable
         step = lambda: eager(static)
     else:
         graphed = GraphedStep(eager, static)  # whole step captured once into a hipGraph
@@ -169,14 +194,30 @@ def main():
     if rank != 0:
         return
     F, D, B = len(model.body.cat_names), model.body.dim, args.batch
-    gather_bytes = B * (F * (D * 4 + D * 4) + F * 4)  # 13 416 B/sample at F=26, D=64, int32 ids
-    g_ms = kernel_ms.get("embedding_gather", {}).get("avg_ms")
-    roofline = None
-    if g_ms:
-        ach = gather_bytes / (g_ms * 1e-3) / 1e9
-        roofline = {"kernel": "gather_fwd_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "algorithmic_bytes_per_launch": gather_bytes, "avg_launch_ms": g_ms}
+    Fs = F + 1
+    P = Fs * (Fs - 1) // 2
+    # algorithmic bytes per launch, keyed by the op names of models_amd/ops.py
+    alg_bytes = {
+        "embedding_gather": B * (F * (D * 4 + D * 4) + F * 4),            # 13 416 B/sample at F=26, D=64, int32 ids
+        "embedding_bwd": B * F * (5 * D * 4 + 4),                          # grad r + weight r/w + state r/w (+ id)
+        "dot_interaction": B * (Fs * D * 4 + (P + D) * 4),
+        "dot_interaction_bwd": B * (2 * Fs * D * 4 + (P + D) * 4),
+    }
+
+    def hbm_roofline(name, kernel):
+        ms = kernel_ms.get(name, {}).get("avg_ms")
+        if not ms:
+            return None
+        ach = alg_bytes[name] / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes[name],
+                "avg_launch_ms": ms, "timing": "hipEvent pair around the launch, eager pass after the timed region"}
+
+    kernels = {"embedding_gather": "gather_fwd_kernel", "embedding_bwd": "segment_reduce_apply_kernel (+sort)",
+               "dot_interaction": "dot_interaction_fwd_pipe_kernel", "dot_interaction_bwd": "dot_interaction_bwd_pipe_kernel"}
+    dominant = max((k for k in kernels if k in kernel_ms), key=lambda k: kernel_ms[k]["avg_ms"], default=None)
+    roofline = hbm_roofline(dominant, kernels[dominant]) if dominant else None
+    roofline_gather = hbm_roofline("embedding_gather", kernels["embedding_gather"])
     res = {
         "metric": "samples/sec at batch 64K (DLRM)", "value": world * B * args.steps / dt, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -184,14 +225,16 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: DLRM 26 cat (Criteo cardinalities capped 1M) + 13 dense, "
                                f"emb_dim=64, bottom [128,64], top [128,64,32], {args.mode}, ids={args.ids}",
                    "global_batch": world * B, "per_gpu_batch": B, "mode": args.mode,
-                   "launch": "eager" if args.eager else "hipGraph replay", "parallelism": f"dp{world}"},
+                   "optimizer": args.optimizer if args.mode == "train" else None,
+                   "launch": "eager" if (args.eager or world > 1) else "hipGraph replay", "parallelism": f"dp{world}"},
         "roofline": roofline,
+        "roofline_gather": roofline_gather,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
     }
     if not args.no_cpu_baseline:
-        base, ref = cpu_baseline(model, batch, min(args.cpu_batch, B))
+        got = runner(batch)[: min(args.cpu_batch, B)].cpu().numpy()  # GPU probabilities with the CURRENT weights
+        base, ref = cpu_baseline(model, batch, label, min(args.cpu_batch, B), args.mode, args.optimizer)
         res["cpu_baseline"] = base
-        got = model(batch)[: ref["prob"].shape[0]].cpu().numpy()
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref["prob"]).max())
     else:
         res["cpu_baseline"] = None
