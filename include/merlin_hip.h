@@ -129,14 +129,18 @@ int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, cons
                                int64_t ldy, mh_stream_t stream);
 
 /* Backward: given dy (leading dim lddy) and the forward OUTPUT y (for the activation
- * derivative), computes dz = dy * act'(y) in place of dy (unless act == NONE), then
- *   dx[M,K] = dz W^T (skipped if dx == NULL), dW[K,N] = x^T dz, db[N] = colsum(dz) (if db).
- * workspace: mh_linear_bwd_workspace_bytes(M, K, N). */
+ * derivative), computes dz = dy * act'(y) in place of dy (skipped when act == NONE, e.g. when the
+ * caller already holds dz), then
+ *   dx[M,K] = (dz W^T) * x_act'(x)   (skipped if dx == NULL).  x_act names the activation whose
+ *             OUTPUT is x (NONE for raw inputs): folding the producer's derivative into the dX
+ *             epilogue hands the previous layer its dz directly, so it can be called with act = NONE;
+ *   dW[K,N] = x^T dz,   db[N] = colsum(dz) (if db != NULL; fused into the dW kernel).
+ * All reductions have a fixed order (deterministic).  workspace: mh_linear_bwd_workspace_bytes. */
 int64_t mh_linear_bwd_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, const float* y,
                                int64_t ldy, float* dy, int64_t lddy, int64_t M, int32_t K,
-                               int32_t N, int32_t act, float* dx, int64_t lddx, float* dW,
-                               float* db, void* workspace, int64_t workspace_bytes,
+                               int32_t N, int32_t act, int32_t x_act, float* dx, int64_t lddx,
+                               float* dW, float* db, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream);
 
 /* ---- a7: DLRM pairwise dot interaction --------------------------------------------------

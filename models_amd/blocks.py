@@ -98,13 +98,32 @@ class _Dense(Block):
                              self.activation, out=out)
         return self._y
 
-    def backward(self, grad, need_dx: bool = True):
-        dx, dW, db = ops.linear_backward(self._x, self.kernel.data, self._y, grad, self.activation,
-                                         need_dx=need_dx, need_db=self.bias is not None)
+    def backward(self, grad, need_dx: bool = True, pre_masked: bool = False, x_activation=None):
+        """``pre_masked``: ``grad`` is already dz (the consumer folded this layer's activation
+        derivative into its dX epilogue).  ``x_activation``: activation that produced this layer's
+        input; its derivative is folded into the returned dx."""
+        dx, dW, db = ops.linear_backward(self._x, self.kernel.data, self._y, grad,
+                                         None if pre_masked else self.activation, need_dx=need_dx,
+                                         need_db=self.bias is not None, x_activation=x_activation)
         self.kernel.grad = dW
         if self.bias is not None:
             self.bias.grad = db
         return dx
+
+
+def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False):
+    """Backward through consecutive _Dense layers, chaining the activation derivative of layer i-1
+    into the dX epilogue of layer i (no separate elementwise pass between layers)."""
+    for i in range(len(layers) - 1, -1, -1):
+        prev_act = layers[i - 1].activation if i > 0 else None
+        grad = layers[i].backward(grad, need_dx=(i > 0) or need_dx, pre_masked=pre_masked, x_activation=prev_act)
+        pre_masked = prev_act is not None
+    return grad
+
+
+def _dense_layers(block):
+    layers = block.layers if isinstance(block, SequentialBlock) else [block]
+    return layers if all(isinstance(l, _Dense) for l in layers) else None
 
 
 def MLPBlock(dimensions: Sequence[int], activation: Union[str, List[str]] = "relu", use_bias: bool = True,
@@ -254,18 +273,28 @@ class DLRMBlock(Block):
         self._top_in = top_in
         return self.top_block(top_in)
 
-    def backward(self, grad):
+    @property
+    def output_activation(self):
+        blk = self.top_block
+        tl = _dense_layers(blk) if blk is not None else None
+        return tl[-1].activation if tl else None
+
+    def backward(self, grad, pre_masked: bool = False):
         D = self.dim
         if self.top_block is not None:
-            grad = self.top_block.backward(grad)
+            tl = _dense_layers(self.top_block)
+            grad = mlp_backward(tl, grad, True, pre_masked) if tl else self.top_block.backward(grad)
         has_tail = self.bottom_block is not None and self.top_block is not None
         slot = self.slots["bottom_block"] if self.bottom_block is not None else -1
         dstack = ops.dot_interaction_backward(self._stacked, grad, slot if has_tail else -1, D if has_tail else 0)
         if self.bottom_block is not None:
             layers = self.bottom_block.layers if isinstance(self.bottom_block, SequentialBlock) else [self.bottom_block]
             g = dstack[:, slot]  # strided [B, D] view; overwritten in place by the activation gradient
-            for i in range(len(layers) - 1, -1, -1):
-                g = layers[i].backward(g, need_dx=i > 0)
+            if all(isinstance(l, _Dense) for l in layers):
+                mlp_backward(layers, g, need_dx=False)
+            else:
+                for i in range(len(layers) - 1, -1, -1):
+                    g = layers[i].backward(g, need_dx=i > 0)
         self.embeddings.set_pending_grad(dstack, {n: self.slots[n] * D for n in self.cat_names})
         return None
 

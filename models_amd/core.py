@@ -148,8 +148,19 @@ class SequentialBlock(Block):
         return x
 
     def backward(self, grad):
-        for layer in reversed(self.layers):
-            grad = layer.backward(grad)
+        from .blocks import _Dense, mlp_backward  # local import: blocks imports core
+
+        layers = list(self.layers)
+        while layers:
+            # peel the longest trailing run of Dense layers and back-propagate it as one fused chain
+            j = len(layers)
+            while j > 0 and isinstance(layers[j - 1], _Dense):
+                j -= 1
+            if j < len(layers):
+                grad = mlp_backward(layers[j:], grad, need_dx=True)
+                layers = layers[:j]
+            else:
+                grad = layers.pop().backward(grad)
         return grad
 
     def children(self):

@@ -85,7 +85,8 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                      const float* __restrict__ Bm, int64_t ldb, int64_t M,
                                                      int Nout, int Kc, float* __restrict__ Cm, int64_t ldc,
-                                                     int vec_a, int vec_b) {
+                                                     int vec_a, int vec_b, const float* __restrict__ maskx,
+                                                     int64_t ldm, int x_act) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
     float* As0 = smem;
@@ -132,7 +133,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
-                if (row < M) Cm[row * ldc + col] = acc[tm][tn][r];
+                if (row < M) {
+                    float v = acc[tm][tn][r];
+                    // fold the producer's activation derivative into dX: x = act(z_prev) is at hand
+                    if (x_act == MH_ACT_RELU) {
+                        v = (maskx[row * ldm + col] > 0.f) ? v : 0.f;
+                    } else if (x_act == MH_ACT_SIGMOID) {
+                        const float xx = maskx[row * ldm + col];
+                        v *= xx * (1.f - xx);
+                    }
+                    Cm[row * ldc + col] = v;
+                }
             }
     }
 }
@@ -143,7 +154,8 @@ template <int BMO, int BNO>
 __global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __restrict__ X, int64_t ldx,
                                                             const float* __restrict__ Z, int64_t ldz,
                                                             int64_t M, int K, int N, int64_t rows_per_split,
-                                                            float* __restrict__ part, int vec_x, int vec_z) {
+                                                            float* __restrict__ part, int vec_x, int vec_z,
+                                                            float* __restrict__ db_part) {
     constexpr int TM = BMO / 2 / 32, TN = BNO / 2 / 32;  // waves 2 x 2
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * BMO + 2 * BK * BNO];
     float* As0 = smem;
@@ -164,6 +176,7 @@ __global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __rest
     NMajorTile<BNO> tb;
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
+    float dbacc = 0.f;
     // NMajorTile::load(W, ldw, k0(contraction row start), K(contraction end), n0, N, vec)
     auto lda_ = [&](int kt) { ta.load(X + m_beg * ldx, ldx, kt * BK, (int)(m_end - m_beg), k0, K, vec_x); };
     auto ldb_ = [&](int kt) { tb.load(Z + m_beg * ldz, ldz, kt * BK, (int)(m_end - m_beg), n0, N, vec_z); };
@@ -184,6 +197,13 @@ __global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __rest
             lda_(kt + 1);
             ldb_(kt + 1);
         }
+        if (db_part && blockIdx.x == 0 && threadIdx.x < BNO) {
+            // column sums of this slice of dz (db = colsum(dz)) ride along on the first row-tile's blocks
+            float cs = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < BK; ++r) cs += Bc[r * BNO + threadIdx.x];
+            dbacc += cs;
+        }
 #pragma unroll
         for (int st = 0; st < BK / 2; ++st) {
             float a[TM], b[TN];
@@ -202,6 +222,8 @@ __global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __rest
         }
         __syncthreads();
     }
+    if (db_part && blockIdx.x == 0 && threadIdx.x < BNO && n0 + (int)threadIdx.x < N)
+        db_part[(int64_t)s * N + n0 + threadIdx.x] = dbacc;
     float* P = part + (int64_t)s * K * N;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -224,10 +246,13 @@ struct BwdPlan {
     int64_t dw_floats, db_floats;
 };
 
+bool big_tiles(int K, int N) { return K > 64 && N > 64; }
+
 BwdPlan make_plan(int64_t M, int K, int N) {
     BwdPlan p;
     p.act_blocks = (int)mh_ceil_div(M, ACT_ROWS);
-    const int64_t tiles = mh_ceil_div(K, 64) * mh_ceil_div(N, 64);
+    const int t = big_tiles(K, N) ? 128 : 64;
+    const int64_t tiles = mh_ceil_div(K, t) * mh_ceil_div(N, t);
     int64_t want = mh_ceil_div(1024, tiles);             // ~4 blocks per CU
     const int64_t max_by_rows = mh_ceil_div(M, 256);       // >= 256 rows (8 k-tiles) per split
     if (want > max_by_rows) want = max_by_rows;
@@ -237,25 +262,35 @@ BwdPlan make_plan(int64_t M, int K, int N) {
     p.rows_per_split = rps;
     p.splits = (int)mh_ceil_div(M, rps);
     p.dw_floats = (int64_t)p.splits * K * N;
-    p.db_floats = (int64_t)p.act_blocks * N;
+    p.db_floats = (int64_t)p.splits * N;
     return p;
 }
 
 }  // namespace
 
+int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout,
+                                 int Kc, float* Cm, int64_t ldc, const float* maskx, int64_t ldm, int x_act,
+                                 hipStream_t s);
+
 int32_t mh_internal_gemm_nt(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout, int Kc,
                             float* Cm, int64_t ldc, hipStream_t s) {
+    return mh_internal_gemm_nt_mask(A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, nullptr, 0, MH_ACT_NONE, s);
+}
+
+int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout,
+                                 int Kc, float* Cm, int64_t ldc, const float* maskx, int64_t ldm, int x_act,
+                                 hipStream_t s) {
     const int vec_a = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     const int vec_b = ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0) && (ldb % 4 == 0);
     if (Nout > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(Nout, 128));
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
     } else if (Nout > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
     } else {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
     }
     MH_CHECK_LAUNCH("gemm_nt");
     return MH_OK;
@@ -267,7 +302,7 @@ int32_t mh_internal_gemm_tn(const float* X, int64_t ldx, const float* Z, int64_t
     const int vec_z = ((reinterpret_cast<uintptr_t>(Z) & 15) == 0) && (ldz % 4 == 0);
     const int64_t rps = mh_ceil_div(M, BK) * BK;
     dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), 1);
-    hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, X, ldx, Z, ldz, M, K, N, rps, out, vec_x, vec_z);
+    hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, X, ldx, Z, ldz, M, K, N, rps, out, vec_x, vec_z, (float*)nullptr);
     MH_CHECK_LAUNCH("gemm_tn");
     return MH_OK;
 }
@@ -282,11 +317,12 @@ int64_t mh_linear_bwd_workspace_bytes(int64_t M, int32_t K, int32_t N) {
 
 int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, const float* y, int64_t ldy,
                                float* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t act,
-                               float* dx, int64_t lddx, float* dW, float* db, void* workspace,
+                               int32_t x_act, float* dx, int64_t lddx, float* dW, float* db, void* workspace,
                                int64_t workspace_bytes, mh_stream_t stream) {
     MH_REQUIRE(x && W && dy && dW, "mh_linear_bias_act_bwd: null argument");
     MH_REQUIRE(M >= 1 && K >= 1 && N >= 1, "mh_linear_bias_act_bwd: bad shape");
     MH_REQUIRE(act == MH_ACT_NONE || y, "mh_linear_bias_act_bwd: y is required for the activation derivative");
+    MH_REQUIRE(x_act >= MH_ACT_NONE && x_act <= MH_ACT_SIGMOID, "mh_linear_bias_act_bwd: bad x_act");
     MH_REQUIRE(ldx >= K && lddy >= N && (!dx || lddx >= K), "mh_linear_bias_act_bwd: bad leading dimension");
     const BwdPlan p = make_plan(M, K, N);
     MH_REQUIRE(workspace && workspace_bytes >= (p.dw_floats + p.db_floats) * (int64_t)sizeof(float),
@@ -295,27 +331,33 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
     float* ws_dw = static_cast<float*>(workspace);
     float* ws_db = ws_dw + p.dw_floats;
 
-    if (act != MH_ACT_NONE || db) {
+    if (act != MH_ACT_NONE) {
         const int CW = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
         hipLaunchKernelGGL(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
-                           act, CW, db ? ws_db : nullptr);
-        if (db)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(256), 0, s,
-                               ws_db, p.act_blocks, (int64_t)N, db);
+                           act, CW, (float*)nullptr);
     }
-    const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
     if (dx) {
-        const int32_t st = mh_internal_gemm_nt(dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, s);
+        const int32_t st = mh_internal_gemm_nt_mask(dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, x, ldx, x_act, s);
         if (st != MH_OK) return st;
     }
     {
         const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
-        dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), (unsigned)p.splits);
-        hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
-                           p.rows_per_split, ws_dw, vec_x, vec_dy);
+        const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
+        if (big_tiles(K, N)) {
+            dim3 grid((unsigned)mh_ceil_div(K, 128), (unsigned)mh_ceil_div(N, 128), (unsigned)p.splits);
+            hipLaunchKernelGGL((gemm_tn_splitm_kernel<128, 128>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
+                               p.rows_per_split, ws_dw, vec_x, vec_dy, db ? ws_db : nullptr);
+        } else {
+            dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), (unsigned)p.splits);
+            hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
+                               p.rows_per_split, ws_dw, vec_x, vec_dy, db ? ws_db : nullptr);
+        }
         const int64_t len = (int64_t)K * N;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(len, 64)), dim3(256), 0, s, ws_dw,
                            p.splits, len, dW);
+        if (db)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(256), 0, s, ws_db,
+                               p.splits, (int64_t)N, db);
     }
     MH_CHECK_LAUNCH("mh_linear_bias_act_bwd");
     return MH_OK;

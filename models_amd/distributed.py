@@ -251,8 +251,9 @@ class DistributedDLRM:
         loss, dlogit = ops.bce(p, targets, need_grad=True)
         if self.world_size > 1:
             dlogit = dlogit / self.world_size
-        dh = model.output.backward(dlogit)
-        body.backward(dh)  # leaves (dstack, offsets) pending on the embeddings block
+        xa = body.output_activation
+        dh = model.output.backward(dlogit, x_activation=xa)
+        body.backward(dh, pre_masked=xa is not None)  # leaves (dstack, offsets) pending on the embeddings block
         dstack, offsets = body.embeddings._pending
         body.embeddings._pending = None
         D = body.dim

@@ -111,8 +111,12 @@ class RankingModel(Model):
         h = self.body(x)
         p = self.output(h)
         loss, dlogit = self.output.loss_and_grad(p, targets)
-        dh = self.output.backward(dlogit)
-        self.body.backward(dh)
+        xa = getattr(self.body, "output_activation", None)
+        dh = self.output.backward(dlogit, x_activation=xa)
+        if xa is not None:
+            self.body.backward(dh, pre_masked=True)
+        else:
+            self.body.backward(dh)
         self.optimizer.apply(self)
         return loss
 

@@ -307,9 +307,10 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     return buf
 
 
-def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True):
+def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True, x_activation=None):
     """Backward of ``linear``: returns (dx | None, dW, db | None).  ``dy`` is overwritten with
-    dz = dy * act'(y) when an activation is given."""
+    dz = dy * act'(y) when an activation is given.  ``x_activation`` names the activation that
+    produced ``x``: its derivative is folded into dx, which is then the producer's dz."""
     lib = _lib.load()
     _rowmajor_2d(x, "x")
     _rowmajor_2d(dy, "dy")
@@ -331,7 +332,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         check(
             lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(y if act != 0 else None),
                                        y.stride(0) if act != 0 else 0, _ptr(dy), dy.stride(0), M, K, N, act,
-                                       _ptr(dx), K, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                                       ACT[x_activation], _ptr(dx), K, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
             "mh_linear_bias_act_bwd",
         )
     return dx, dW, db

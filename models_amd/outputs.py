@@ -52,11 +52,12 @@ class BinaryOutput(Block):
         """Mean BCE over the batch (Keras SUM_OVER_BATCH_SIZE) and d(mean loss)/d(logit)."""
         return ops.bce(predictions, targets, need_grad=need_grad)
 
-    def backward(self, dlogit: torch.Tensor):
-        # dlogit is the gradient w.r.t. the PRE-sigmoid activation -> bypass the sigmoid derivative
+    def backward(self, dlogit: torch.Tensor, x_activation=None):
+        # dlogit is the gradient w.r.t. the PRE-sigmoid activation -> bypass the sigmoid derivative;
+        # x_activation = activation of the body's last layer (its derivative is folded into dx)
         d = self.to_call
         dx, dW, db = ops.linear_backward(d._x, d.kernel.data, d._y, dlogit, None, need_dx=True,
-                                         need_db=d.bias is not None)
+                                         need_db=d.bias is not None, x_activation=x_activation)
         d.kernel.grad = dW
         if d.bias is not None:
             d.bias.grad = db
