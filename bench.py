@@ -143,11 +143,12 @@ def main():
     static = dict(batch)
     static["__label__"] = label
     runner = model
-    if world > 1:
+    force = os.environ.get("MH_FORCE_DISTRIBUTED") == "1"  # exercise the sharded code path on one GPU
+    if world > 1 or force:
         from models_amd.distributed import DistributedDLRM
 
         # replicated small tables + row-sharded large tables (all-to-all over xGMI), dense bucket reduce
-        runner = DistributedDLRM(model, shard_threshold=args.shard_threshold)
+        runner = DistributedDLRM(model, shard_threshold=args.shard_threshold, force_shard=force)
 
     def eager(inp):
         feats = {k: v for k, v in inp.items() if k != "__label__"}
@@ -155,7 +156,7 @@ def main():
             return runner(feats)
         return runner.train_step(feats, inp["__label__"])
 
-    if args.eager or world > 1:  # the sharded lookup needs host-side split sizes: not graph-capturable
+    if args.eager or world > 1 or force:  # the sharded lookup needs host-side split sizes: not graph-capturable
         step = lambda: eager(static)
     else:
         graphed = GraphedStep(eager, static)  # whole step captured once into a hipGraph
@@ -226,7 +227,7 @@ def main():
                                f"emb_dim=64, bottom [128,64], top [128,64,32], {args.mode}, ids={args.ids}",
                    "global_batch": world * B, "per_gpu_batch": B, "mode": args.mode,
                    "optimizer": args.optimizer if args.mode == "train" else None,
-                   "launch": "eager" if (args.eager or world > 1) else "hipGraph replay", "parallelism": f"dp{world}"},
+                   "launch": "eager" if (args.eager or world > 1 or force) else "hipGraph replay", "parallelism": f"dp{world}"},
         "roofline": roofline,
         "roofline_gather": roofline_gather,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},

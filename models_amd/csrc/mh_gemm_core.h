@@ -26,48 +26,60 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 // Global -> registers -> LDS staging of a [ROWS x BK] tile of a row-major matrix whose
 // contraction dimension is contiguous (A[M,K], or B[N,K] of an "NT" product).
-template <int ROWS>
+//
+// The hot loop is branch-free: per-thread row pointers are computed ONCE (rows past the end are
+// CLAMPED to the last valid row -- they only feed output rows/columns that are never stored), full
+// k-tiles use unconditional 16-byte loads, and only the final partial k-tile (K % 32 != 0) or an
+// unaligned operand takes the guarded path (zeros beyond K are required there: they enter sums).
+template <int ROWS, int NTH = NT>
 struct KMajorTile {
-    static constexpr int NV = (ROWS * (BK / 4) + NT - 1) / NT;
+    static constexpr int NV = (ROWS * (BK / 4) + NTH - 1) / NTH;
     f32x4 regs[NV];
+    const float* ptr[NV];
 
-    __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t row0,
-                                         int64_t nrows, int k0, int K, bool vec_ok) {
-        // interior tile: unconditional 16-byte loads (workgroup-uniform branch)
-        if (vec_ok && row0 + ROWS <= nrows && k0 + BK <= K && (ROWS * (BK / 4)) % NT == 0) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int idx = threadIdx.x + i * NT;
-                const int r = idx >> 3, c4 = idx & 7;
-                regs[i] = *reinterpret_cast<const f32x4*>(src + (row0 + r) * ld + k0 + c4 * 4);
-            }
-            return;
-        }
+    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int64_t row0, int64_t nrows) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * NT;
+            const int idx = threadIdx.x + i * NTH;
             const int r = idx >> 3, c4 = idx & 7;
+            int64_t row = row0 + r;
+            if (row > nrows - 1) row = nrows - 1;
+            if (row < 0) row = 0;
+            ptr[i] = src + row * ld + c4 * 4;
+        }
+    }
+    // full tile, 16-byte aligned rows
+    __device__ __forceinline__ void load_fast(int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if ((ROWS * (BK / 4)) % NTH == 0 || (int)(threadIdx.x + i * NTH) < ROWS * (BK / 4))
+                regs[i] = *reinterpret_cast<const f32x4*>(ptr[i] + k0);
+    }
+    // partial tile and/or unaligned rows: element-wise, zero beyond K
+    __device__ __forceinline__ void load_guarded(int k0, int K) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * NTH;
+            const int c4 = idx & 7;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            const int64_t row = row0 + r;
             const int k = k0 + c4 * 4;
-            if (r < ROWS && row < nrows && k < K) {
-                const float* p = src + row * ld + k;
-                if (vec_ok && k + 3 < K) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-                    v.x = p[0];
-                    if (k + 1 < K) v.y = p[1];
-                    if (k + 2 < K) v.z = p[2];
-                    if (k + 3 < K) v.w = p[3];
-                }
+            if (idx < ROWS * (BK / 4) && k < K) {
+                const float* p = ptr[i] + k0;
+                v.x = p[0];
+                if (k + 1 < K) v.y = p[1];
+                if (k + 2 < K) v.z = p[2];
+                if (k + 3 < K) v.w = p[3];
             }
             regs[i] = v;
         }
     }
+    __device__ __forceinline__ void load(int k0, int K, bool vec_ok) {
+        if (vec_ok && k0 + BK <= K) load_fast(k0); else load_guarded(k0, K);
+    }
     __device__ __forceinline__ void store(float* __restrict__ lds) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * NT;
+            const int idx = threadIdx.x + i * NTH;
             const int r = idx >> 3, c4 = idx & 7;
             if (r < ROWS) {
                 float* d = lds + r * LDK + c4 * 2;
@@ -78,48 +90,59 @@ struct KMajorTile {
     }
 };
 
-// Staging of a [BK x COLS] tile of a row-major W[K, N] (the "NN" B operand, n contiguous).
-template <int COLS>
+// Staging of a [BK x COLS] tile of a row-major W[K, N] (n contiguous): the "NN" B operand, and both
+// operands of the split-M "TN" product.  Column groups past N are clamped (never stored), rows past K
+// (the contraction) must read as zero and take the guarded path.
+template <int COLS, int NTH = NT>
 struct NMajorTile {
     static constexpr int VPR = COLS / 4;
-    static constexpr int NV = (BK * VPR + NT - 1) / NT;
+    static constexpr int NV = (BK * VPR + NTH - 1) / NTH;
     f32x4 regs[NV];
+    const float* ptr[NV];  // W + r*ldw + clamped column
+    int col[NV];
 
-    __device__ __forceinline__ void load(const float* __restrict__ W, int64_t ldw, int k0, int K,
-                                         int n0, int N, bool vec_ok) {
-        if (vec_ok && k0 + BK <= K && n0 + COLS <= N && (BK * VPR) % NT == 0) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int idx = threadIdx.x + i * NT;
-                const int r = idx / VPR, c4 = idx - r * VPR;
-                regs[i] = *reinterpret_cast<const f32x4*>(W + (int64_t)(k0 + r) * ldw + n0 + c4 * 4);
-            }
-            return;
-        }
+    __device__ __forceinline__ void init(const float* __restrict__ W, int64_t ldw, int n0, int N) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * NT;
+            const int idx = threadIdx.x + i * NTH;
             const int r = idx / VPR, c4 = idx - r * VPR;
+            int n = n0 + c4 * 4;
+            col[i] = n;
+            if (n > N - 4) n = (N >= 4) ? ((N - 4) / 4) * 4 : 0;  // stay inside the row for the vector path
+            ptr[i] = W + (int64_t)r * ldw + n;
+        }
+    }
+    __device__ __forceinline__ void load_fast(int k0, int64_t ldw) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if ((BK * VPR) % NTH == 0 || (int)(threadIdx.x + i * NTH) < BK * VPR)
+                regs[i] = *reinterpret_cast<const f32x4*>(ptr[i] + (int64_t)k0 * ldw);
+    }
+    __device__ __forceinline__ void load_guarded(const float* __restrict__ W, int64_t ldw, int k0, int K, int N) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + i * NTH;
+            const int r = idx / VPR;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            const int k = k0 + r, n = n0 + c4 * 4;
-            if (r < BK && k < K && n < N) {
+            const int k = k0 + r, n = col[i];
+            if (idx < BK * VPR && k < K && n < N) {
                 const float* p = W + (int64_t)k * ldw + n;
-                if (vec_ok && n + 3 < N) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-                    v.x = p[0];
-                    if (n + 1 < N) v.y = p[1];
-                    if (n + 2 < N) v.z = p[2];
-                    if (n + 3 < N) v.w = p[3];
-                }
+                v.x = p[0];
+                if (n + 1 < N) v.y = p[1];
+                if (n + 2 < N) v.z = p[2];
+                if (n + 3 < N) v.w = p[3];
             }
             regs[i] = v;
         }
     }
+    // vec_ok: 16-byte aligned rows AND N % 4 == 0 (column groups never straddle N)
+    __device__ __forceinline__ void load(const float* __restrict__ W, int64_t ldw, int k0, int K, int N, bool vec_ok) {
+        if (vec_ok && k0 + BK <= K) load_fast(k0, ldw); else load_guarded(W, ldw, k0, K, N);
+    }
     __device__ __forceinline__ void store(float* __restrict__ lds) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int idx = threadIdx.x + i * NT;
+            const int idx = threadIdx.x + i * NTH;
             const int r = idx / VPR, c4 = idx - r * VPR;
             if (r < BK) *reinterpret_cast<f32x4*>(lds + r * COLS + c4 * 4) = regs[i];
         }
@@ -151,29 +174,25 @@ struct Frag {
     }
 };
 
-// LDS -> register fragments are double-buffered across the four 4-step groups of a k-tile: the
-// reads of group g+1 are issued before the 4*TM*TN MFMAs of group g, so the matrix pipe never waits
-// on an LDS round trip (hipcc otherwise places each read right in front of its first use).
+// One k-tile = four groups of 4 MFMA steps; each group's fragments are fetched with ds_read_b128
+// right before use (hipcc emits counted lgkmcnt waits; an explicit register double-buffer of the
+// fragments was measured to be neutral and costs 24 VGPRs -- profiles/r1_notes.md).
 template <int TM, int TN, bool B_NT>
 __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, int a_row0,
                                           const float* __restrict__ Bs, int b_row0, int ldb,
                                           f32x16 (&acc)[TM][TN]) {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, h = lane >> 5;
-    Frag<TM, TN, B_NT> f0, f1;
-    f0.load(As, a_row0, Bs, b_row0, ldb, 0, l31, h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        Frag<TM, TN, B_NT>& cur = (g & 1) ? f1 : f0;
-        Frag<TM, TN, B_NT>& nxt = (g & 1) ? f0 : f1;
-        if (g < 3) nxt.load(As, a_row0, Bs, b_row0, ldb, g + 1, l31, h);
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this group's MFMAs
+        Frag<TM, TN, B_NT> f;
+        f.load(As, a_row0, Bs, b_row0, ldb, g, l31, h);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(cur.a[tm][j], cur.b[tn][j], acc[tm][tn]);
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(f.a[tm][j], f.b[tn][j], acc[tm][tn]);
     }
 }
 

@@ -19,7 +19,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(WM * WN * 64) void linear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ W,
                                                         const float* __restrict__ bias, int64_t M,
                                                         int K, int N, int act, float* __restrict__ y,
@@ -38,14 +38,17 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
-    KMajorTile<BM> ta;
-    NMajorTile<BN> tb;
+    constexpr int NTH = WM * WN * 64;
+    KMajorTile<BM, NTH> ta;
+    NMajorTile<BN, NTH> tb;
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
 
     const int nk = (K + BK - 1) / BK;
-    ta.load(x, ldx, row0, M, 0, K, vec_x);
-    tb.load(W, N, 0, K, n0, N, vec_w);
+    ta.init(x, ldx, row0, M);
+    tb.init(W, N, n0, N);
+    ta.load(0, K, vec_x);
+    tb.load(W, N, 0, K, N, vec_w);
     ta.store(As0);
     tb.store(Bs0);
     __syncthreads();
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         float* An = (kt & 1) ? As0 : As1;
         float* Bn = (kt & 1) ? Bs0 : Bs1;
         if (more) {
-            ta.load(x, ldx, row0, M, (kt + 1) * BK, K, vec_x);
-            tb.load(W, N, (kt + 1) * BK, K, n0, N, vec_w);
+            ta.load((kt + 1) * BK, K, vec_x);
+            tb.load(W, N, (kt + 1) * BK, K, N, vec_w);
         }
         mma_ktile<TM, TN, false>(Ac, wm * TM * 32, Bc, wn * TN * 32, BN, acc);
         if (more) {
@@ -160,7 +163,7 @@ int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const fl
     const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
     if (N > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(N, 128));
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     } else if (N > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
         hipLaunchKernelGGL((linear_fwd_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 
 // C[M, Nout] = A[M, Kc] * B[Nout, Kc]^T   (both operands contraction-contiguous)
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                      const float* __restrict__ Bm, int64_t ldb, int64_t M,
                                                      int Nout, int Kc, float* __restrict__ Cm, int64_t ldc,
                                                      int vec_a, int vec_b, const float* __restrict__ maskx,
@@ -97,13 +97,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     const int wm = wave / WN, wn = wave % WN;
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    KMajorTile<BM> ta;
-    KMajorTile<BN> tb;
+    constexpr int NTH = WM * WN * 64;
+    KMajorTile<BM, NTH> ta;
+    KMajorTile<BN, NTH> tb;
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
     const int nk = (Kc + BK - 1) / BK;
-    ta.load(A, lda, row0, M, 0, Kc, vec_a);
-    tb.load(Bm, ldb, n0, Nout, 0, Kc, vec_b);
+    ta.init(A, lda, row0, M);
+    tb.init(Bm, ldb, n0, Nout);
+    ta.load(0, Kc, vec_a);
+    tb.load(0, Kc, vec_b);
     ta.store(As0);
     tb.store(Bs0);
     __syncthreads();
@@ -114,8 +117,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
         float* An = (kt & 1) ? As0 : As1;
         float* Bn = (kt & 1) ? Bs0 : Bs1;
         if (more) {
-            ta.load(A, lda, row0, M, (kt + 1) * BK, Kc, vec_a);
-            tb.load(Bm, ldb, n0, Nout, (kt + 1) * BK, Kc, vec_b);
+            ta.load((kt + 1) * BK, Kc, vec_a);
+            tb.load((kt + 1) * BK, Kc, vec_b);
         }
         mma_ktile<TM, TN, true>(Ac, wm * TM * 32, Bc, wn * TN * 32, 0, acc);
         if (more) {
@@ -178,8 +181,11 @@ __global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __rest
     zero_acc<TM, TN>(acc);
     float dbacc = 0.f;
     // NMajorTile::load(W, ldw, k0(contraction row start), K(contraction end), n0, N, vec)
-    auto lda_ = [&](int kt) { ta.load(X + m_beg * ldx, ldx, kt * BK, (int)(m_end - m_beg), k0, K, vec_x); };
-    auto ldb_ = [&](int kt) { tb.load(Z + m_beg * ldz, ldz, kt * BK, (int)(m_end - m_beg), n0, N, vec_z); };
+    ta.init(X + m_beg * ldx, ldx, k0, K);
+    tb.init(Z + m_beg * ldz, ldz, n0, N);
+    const int vx = vec_x && (K % 4 == 0), vz = vec_z && (N % 4 == 0);
+    auto lda_ = [&](int kt) { ta.load(X + m_beg * ldx, ldx, kt * BK, (int)(m_end - m_beg), K, vx); };
+    auto ldb_ = [&](int kt) { tb.load(Z + m_beg * ldz, ldz, kt * BK, (int)(m_end - m_beg), N, vz); };
     if (nk > 0) {
         lda_(0);
         ldb_(0);
@@ -284,7 +290,7 @@ int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, i
     const int vec_b = ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0) && (ldb % 4 == 0);
     if (Nout > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(Nout, 128));
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
     } else if (Nout > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
         hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);

@@ -23,12 +23,17 @@ using namespace mhgemm;
 namespace {
 
 constexpr int SBM = 128, SBN = 128;
+constexpr int SWM = 4, SWN = 2;  // 8 wavefronts per workgroup: 4 per SIMD keep the matrix pipe fed during epilogues
 constexpr float NEG_INF = -INFINITY;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32
+constexpr float M_INIT = -1.0e30f;  // finite "minus infinity" of the running max (base-2 domain)
 
 // MODE 0: forward (optional logits store + online LSE partials)
 // MODE 1: backward helper: ds[row, col] = masked ? 0 : exp(z - lse[row]) * gscale   (z = s / T)
-template <int MODE, bool HAS_IDS, typename IdT>
-__global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q, const float* __restrict__ neg,
+template <int MODE, bool HAS_IDS, typename IdT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void scorer_kernel(const float* __restrict__ q, const float* __restrict__ neg,
                                                     const IdT* __restrict__ pos_ids,
                                                     const IdT* __restrict__ neg_ids, int64_t B, int64_t Nn, int E,
                                                     float invT, float fns, float* __restrict__ logits,
@@ -36,7 +41,8 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
                                                     float* __restrict__ part_s, int tiles_per_split,
                                                     const float* __restrict__ lse, float gscale,
                                                     float* __restrict__ ds, int vec_q, int vec_n) {
-    constexpr int TM = 2, TN = 2;
+    constexpr int TM = SBM / WM / 32, TN = SBN / WN / 32, NTH = WM * WN * 64;
+    static_assert(WN == 2, "the cross-wave combine assumes two column halves");
     __shared__ __attribute__((aligned(16))) float smem[2 * SBM * LDK + 2 * SBN * LDK + 2 * SBM + 2 * SBM + SBM];
     float* As0 = smem;
     float* As1 = smem + SBM * LDK;
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
+    constexpr int WROWS = TM * 32, WCOLS = TN * 32;
     const int64_t row0 = (int64_t)blockIdx.x * SBM;
     const int split = blockIdx.y;
     const int nct_all = (int)((Nn + SBN - 1) / SBN);
@@ -60,25 +67,27 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
     if (threadIdx.x < SBM) {
         const int64_t row = row0 + threadIdx.x;
         pid_s[threadIdx.x] = (HAS_IDS && row < B) ? pos_ids[row] : (IdT)0;
-        lse_s[threadIdx.x] = (MODE == 1 && row < B) ? lse[row] : 0.f;
+        lse_s[threadIdx.x] = (MODE == 1 && row < B) ? lse[row] * LOG2E : 0.f;
     }
     float m[TM][16], ssum[TM][16];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            m[tm][r] = NEG_INF;
+            m[tm][r] = M_INIT;
             ssum[tm][r] = 0.f;
         }
 
-    KMajorTile<SBM> ta;
-    KMajorTile<SBN> tb;
+    KMajorTile<SBM, NTH> ta;
+    KMajorTile<SBN, NTH> tb;
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
 
+    ta.init(q, E, row0, B);
+    tb.init(neg, E, (int64_t)ct_beg * SBN, Nn);
     if (total > 0) {
-        ta.load(q, E, row0, B, 0, E, vec_q);
-        tb.load(neg, E, (int64_t)ct_beg * SBN, Nn, 0, E, vec_n);
+        ta.load(0, E, vec_q);
+        tb.load(0, E, vec_n);
         ta.store(As0);
         tb.store(Bs0);
     }
@@ -93,13 +102,14 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
         if (more) {
             const int it2 = it + 1;
             const int ct2 = ct_beg + it2 / nk, kt2 = it2 - (it2 / nk) * nk;
-            ta.load(q, E, row0, B, kt2 * BK, E, vec_q);
-            tb.load(neg, E, (int64_t)ct2 * SBN, Nn, kt2 * BK, E, vec_n);
+            if (kt2 == 0) tb.init(neg, E, (int64_t)ct2 * SBN, Nn);  // next column tile of items
+            ta.load(kt2 * BK, E, vec_q);
+            tb.load(kt2 * BK, E, vec_n);
         }
-        mma_ktile<TM, TN, true>(Ac, wm * 64, Bc, wn * 64, 0, acc);
+        mma_ktile<TM, TN, true>(Ac, wm * WROWS, Bc, wn * WCOLS, 0, acc);
         if (kt == nk - 1) {
-            // ---- tile epilogue -----------------------------------------------------------------
-            const int64_t c0 = (int64_t)ct * SBN + wn * 64;
+            // ---- tile epilogue (branch-free, base-2 domain: z2 = z * log2(e)) ---------------------
+            const int64_t c0 = (int64_t)ct * SBN + wn * WCOLS;
             IdT nid[TN];
             bool cvalid[TN];
 #pragma unroll
@@ -108,47 +118,50 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
                 cvalid[tn] = col < Nn;
                 nid[tn] = (HAS_IDS && cvalid[tn]) ? neg_ids[col] : (IdT)0;
             }
+            const float fns_z = fns * invT;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rl = wm * 64 + tm * 32 + acc_row(r, lane);
-                    const int64_t row = row0 + rl;
+                    const int rl = wm * WROWS + tm * 32 + acc_row(r, lane);
                     const IdT my_pid = HAS_IDS ? pid_s[rl] : (IdT)0;
-                    float t[TN];
+                    float z[TN];
                     bool masked[TN];
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
-                        float v = acc[tm][tn][r];
                         masked[tn] = HAS_IDS && (my_pid == nid[tn]);
-                        if (masked[tn]) v = fns;
-                        v *= invT;
-                        t[tn] = cvalid[tn] ? v : NEG_INF;
+                        z[tn] = masked[tn] ? fns_z : acc[tm][tn][r] * invT;
                     }
                     if (MODE == 0) {
-                        if (logits && row < B) {
+                        if (logits) {
+                            const int64_t row = row0 + rl;
+                            if (row < B) {
 #pragma unroll
-                            for (int tn = 0; tn < TN; ++tn)
-                                if (cvalid[tn]) logits[row * ld_logits + 1 + c0 + tn * 32 + acc_col(lane)] = t[tn];
+                                for (int tn = 0; tn < TN; ++tn)
+                                    if (cvalid[tn]) logits[row * ld_logits + 1 + c0 + tn * 32 + acc_col(lane)] = z[tn];
+                            }
                         }
-                        float tmax = t[0];
+                        float t2[TN];
 #pragma unroll
-                        for (int tn = 1; tn < TN; ++tn) tmax = fmaxf(tmax, t[tn]);
-                        if (tmax > m[tm][r]) {
-                            ssum[tm][r] *= __expf(m[tm][r] - tmax);  // exp(-inf) = 0 on the first tile
-                            m[tm][r] = tmax;
-                        }
-                        if (m[tm][r] > NEG_INF) {
+                        for (int tn = 0; tn < TN; ++tn) t2[tn] = cvalid[tn] ? z[tn] * LOG2E : NEG_INF;
+                        float tmax = t2[0];
 #pragma unroll
-                            for (int tn = 0; tn < TN; ++tn) ssum[tm][r] += __expf(t[tn] - m[tm][r]);
-                        }
+                        for (int tn = 1; tn < TN; ++tn) tmax = fmaxf(tmax, t2[tn]);
+                        const float m_new = fmaxf(m[tm][r], tmax);  // m starts at -1e30 (finite): no inf - inf
+                        float acc_s = ssum[tm][r] * fast_exp2(m[tm][r] - m_new);
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) acc_s += fast_exp2(t2[tn] - m_new);
+                        ssum[tm][r] = acc_s;
+                        m[tm][r] = m_new;
                     } else {
+                        const int64_t row = row0 + rl;
                         if (row < B) {
+                            const float l2 = lse_s[rl];  // lse * log2(e), staged once per row tile
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn)
                                 if (cvalid[tn])
                                     ds[row * Nn + c0 + tn * 32 + acc_col(lane)] =
-                                        masked[tn] ? 0.f : __expf(t[tn] - lse_s[rl]) * gscale;
+                                        masked[tn] ? 0.f : fast_exp2(z[tn] * LOG2E - l2) * gscale;
                         }
                     }
                 }
@@ -172,11 +185,11 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
                 for (int off = 1; off < 32; off <<= 1) {
                     const float mo = __shfl_xor(mm, off), so = __shfl_xor(ss, off);
                     const float M = fmaxf(mm, mo);
-                    if (M > NEG_INF) ss = ss * __expf(mm - M) + so * __expf(mo - M);
+                    ss = ss * fast_exp2(mm - M) + so * fast_exp2(mo - M);
                     mm = M;
                 }
                 if ((lane & 31) == 0) {
-                    const int rl = wm * 64 + tm * 32 + acc_row(r, lane);
+                    const int rl = wm * WROWS + tm * 32 + acc_row(r, lane);
                     // interleave (m, s) of the two wn halves: comb[(wn*2+0)*SBM/... ] keep simple
                     float* cm = comb + wn * SBM;
                     // store m in comb, s in the (now free) A buffer 0
@@ -192,9 +205,8 @@ __global__ __launch_bounds__(256) void scorer_kernel(const float* __restrict__ q
                 const float m0 = comb[rl], m1 = comb[SBM + rl];
                 const float s0 = As0[rl], s1 = As0[SBM + rl];
                 const float M = fmaxf(m0, m1);
-                float S = 0.f;
-                if (M > NEG_INF) S = s0 * __expf(m0 - M) + s1 * __expf(m1 - M);
-                part_m[(int64_t)split * B + row] = M;
+                const float S = s0 * fast_exp2(m0 - M) + s1 * fast_exp2(m1 - M);
+                part_m[(int64_t)split * B + row] = M;  // base-2 running max and sum of 2^(z2 - M)
                 part_s[(int64_t)split * B + row] = S;
             }
         }
@@ -210,14 +222,12 @@ __global__ __launch_bounds__(256) void scorer_finalize_kernel(const float* __res
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= B) return;
     const float z0 = pos[row] * invT;
-    float M = z0;
+    const float z0_2 = z0 * LOG2E;
+    float M = z0_2;
     for (int k = 0; k < nsplit; ++k) M = fmaxf(M, part_m[(int64_t)k * B + row]);
-    float S = expf(z0 - M);
-    for (int k = 0; k < nsplit; ++k) {
-        const float mk = part_m[(int64_t)k * B + row];
-        if (mk > NEG_INF) S += part_s[(int64_t)k * B + row] * expf(mk - M);
-    }
-    const float l = M + logf(S);
+    float S = fast_exp2(z0_2 - M);
+    for (int k = 0; k < nsplit; ++k) S += part_s[(int64_t)k * B + row] * fast_exp2(part_m[(int64_t)k * B + row] - M);
+    const float l = (M + log2f(S)) * LN2;
     if (logits) logits[row * ld_logits] = z0;
     if (lse) lse[row] = l;
     if (loss) loss[row] = l - z0;
@@ -275,15 +285,15 @@ void launch_scorer(const Plan& p, const float* q, const float* neg, const void* 
     const int vec_n = ((reinterpret_cast<uintptr_t>(neg) & 15) == 0) && (E % 4 == 0);
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
     if (!pos_ids) {
-        hipLaunchKernelGGL((scorer_kernel<MODE, false, int32_t>), grid, dim3(256), 0, s, q, neg, (const int32_t*)nullptr,
+        hipLaunchKernelGGL((scorer_kernel<MODE, false, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
                            gscale, ds, vec_q, vec_n);
     } else if (ids_dtype == MH_I32) {
-        hipLaunchKernelGGL((scorer_kernel<MODE, true, int32_t>), grid, dim3(256), 0, s, q, neg, (const int32_t*)pos_ids,
+        hipLaunchKernelGGL((scorer_kernel<MODE, true, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)pos_ids,
                            (const int32_t*)neg_ids, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
                            gscale, ds, vec_q, vec_n);
     } else {
-        hipLaunchKernelGGL((scorer_kernel<MODE, true, int64_t>), grid, dim3(256), 0, s, q, neg, (const int64_t*)pos_ids,
+        hipLaunchKernelGGL((scorer_kernel<MODE, true, int64_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int64_t*)pos_ids,
                            (const int64_t*)neg_ids, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
                            gscale, ds, vec_q, vec_n);
     }

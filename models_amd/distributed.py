@@ -163,7 +163,7 @@ class DistributedDLRM:
     """Wraps an ``mm.DLRMModel`` built on every rank: tables with >= ``shard_threshold`` rows keep only
     their local row shard (all-to-all lookup), the rest stay replicated."""
 
-    def __init__(self, model, shard_threshold: int = 200_000, group=None):
+    def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False):
         from . import ops
 
         self.model = model
@@ -185,7 +185,7 @@ class DistributedDLRM:
 
         for name in self.body.cat_names:
             t = emb.feature_table[name]
-            if self.world_size > 1 and t.input_dim >= shard_threshold:
+            if (self.world_size > 1 or force_shard) and t.input_dim >= shard_threshold:
                 local = shard_table(t.table.data, self.rank, self.world_size)
                 t.table.data = local  # drop the replicated copy
                 self.sharded[name] = ShardedEmbeddingTable(local, t.input_dim, gather_fn, update_fn, group)

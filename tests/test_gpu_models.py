@@ -236,3 +236,44 @@ def test_dlrm_variants_and_errors():
         mm.DLRMBlock(mm.Schema([S.continuous("x")]), embedding_dim=8, bottom_block=mm.MLPBlock([8]))
     with pytest.raises(ValueError, match="embedding_dim is required"):
         mm.DLRMBlock(schema, bottom_block=mm.MLPBlock([8]))
+
+
+def test_distributed_dlrm_world1_matches_plain_model(device):
+    """DistributedDLRM with forced row-sharding (W = 1: the all-to-alls degenerate to copies) must
+    reproduce the plain model's forward and train steps (routing / un-permute / dense-grad path)."""
+    from models_amd.distributed import DistributedDLRM
+
+    cards = {"C1": 5000, "C2": 7, "C3": 3000, "C4": 50}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+    D = 16
+
+    def build():
+        m = mm.DLRMModel(schema, embedding_dim=D, bottom_block=mm.MLPBlock([32, D], device=device, seed=7),
+                         top_block=mm.MLPBlock([32, 8], device=device, seed=17), device=device)
+        m.output.to_call.seed = 99
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for _ in range(3):
+        x, xd = _batch(schema, 300, g, device)
+        batches.append((xd, torch.randint(0, 2, (300, 1), generator=g).float().to(device)))
+    a, b = build(), build()
+    pa = a(batches[0][0])
+    b(batches[0][0])
+    for pa_, pb_ in zip(a.parameters(), b.parameters()):
+        pb_.data.copy_(pa_.data)
+    db = DistributedDLRM(b, shard_threshold=1000, force_shard=True)
+    assert sorted(db.sharded) == ["C1", "C3"]
+    torch.testing.assert_close(db(batches[0][0]), a(batches[0][0]), atol=1e-6, rtol=1e-6)
+    for xd, y in batches:
+        la, lb = a.train_step(xd, y), db.train_step(xd, y)
+        assert abs(la.item() - lb.item()) < 1e-5
+    torch.testing.assert_close(db(batches[0][0]), a(batches[0][0]), atol=1e-5, rtol=1e-4)
+    for n in cards:
+        ta = a.body.embeddings.feature_table[n].table.data
+        tb = db.sharded[n].table if n in db.sharded else b.body.embeddings.feature_table[n].table.data
+        torch.testing.assert_close(tb, ta, atol=1e-5, rtol=1e-4)
