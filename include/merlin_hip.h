@@ -160,6 +160,26 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
                                int32_t F, int32_t D, float* dx, int32_t tail_slot, int32_t T,
                                mh_stream_t stream);
 
+/* ---- a1 + a5 + a7 fused: DLRM gather -> interaction without the stacked [B, F, D] round trip ---
+ * Replaces the whole `ParallelBlock{embeddings, bottom_block} -> StackFeatures -> DotProductInteraction
+ * -> concat shortcut` segment of DLRMBlock (blocks/dlrm.py:110-130).  Slot s (s < F, sorted feature
+ * order, core/aggregation.py:101-108) is either a categorical feature -- slot_tables[s] ([slot_rows[s], D]),
+ * slot_ids[s] ([B] int32/int64) -- or the ONE dense slot (slot_tables[s] == NULL) whose row b is
+ * dense[b * ld_dense .. + D] (the bottom-MLP output).  out[b] = [pairwise dots (row-major i<j) | dense row
+ * if append_dense].  Needs D % 16 == 0 and F*D <= 2048.  HOST arrays as in mh_embedding_gather_fwd. */
+int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int64_t* slot_rows,
+                                      const void* const* slot_ids, int32_t ids_dtype, const float* dense,
+                                      int64_t ld_dense, int64_t B, int32_t F, int32_t D,
+                                      int32_t append_dense, float* out, int64_t ldo, mh_stream_t stream);
+/* Backward of the fused segment: re-gathers the rows (tables are not yet updated), dx[B, F, D] = (G+G^T) X;
+ * with tail_to_dense the gradient of the appended dense copy dout[:, P:P+D] is added to the dense slot.
+ * D in {16, 32, 64, 128}. */
+int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int64_t* slot_rows,
+                                      const void* const* slot_ids, int32_t ids_dtype, const float* dense,
+                                      int64_t ld_dense, const float* dout, int64_t ldo, int64_t B,
+                                      int32_t F, int32_t D, int32_t tail_to_dense, float* dx,
+                                      mh_stream_t stream);
+
 /* ---- a9: DCN-v2 cross layer  out = x0 * (x W + b) + x ----------------------------------
  * Replaces Cross.call (blocks/cross.py:188-202) with a full-rank kernel W[d, d]
  * (DenseMaybeLowRank, blocks/mlp.py:304-396, low_rank_dim=None). x0, x, out: [M, d]. */

@@ -244,11 +244,46 @@ class DLRMBlock(Block):
     def num_features(self) -> int:
         return len(self.stack_order)
 
+    def _fusable(self, inputs) -> bool:
+        # The fused gather->interaction kernels are correct (tests/test_gpu_dense.py) but, in round 1, slower
+        # than gather + interaction back to back (281 vs 259 us forward at C2: one sample per wavefront does not
+        # keep enough row loads in flight) -- opt in with MERLIN_HIP_FUSED_DLRM=1.
+        import os
+
+        if os.environ.get("MERLIN_HIP_FUSED_DLRM") != "1":
+            return False
+        D, F = self.dim, self.num_features
+        if D % 16 != 0 or F * D > 2048 or F > 32 or D not in (16, 32, 64, 128):
+            return False
+        return all(self.embeddings._is_onehot(inputs[n]) for n in self.cat_names)
+
     def forward(self, inputs: TabularData):
         first = inputs[self.cat_names[0]]
         B = first.shape[0] if isinstance(first, torch.Tensor) else first.offsets.shape[0] - 1
         dev = self.embeddings.feature_table[self.cat_names[0]].table.data.device
         F, D = self.num_features, self.dim
+        P = F * (F - 1) // 2
+        self._fused = self._fusable(inputs)
+        if self._fused:
+            # gather -> stack -> interaction in ONE kernel: the stacked [B, F, D] tensor never exists in HBM
+            dense = None
+            if self.bottom_block is not None:
+                dense = self.bottom_block(self.continuous(inputs))
+            slot_tables = [None if k == "bottom_block" else self.embeddings.feature_table[k].table.data for k in self.stack_order]
+            slot_ids = [None if k == "bottom_block" else inputs[k] for k in self.stack_order]
+            self._slots_ctx = (slot_tables, slot_ids, dense)
+            self.embeddings._last = {n: inputs[n] for n in self.cat_names}
+            if self.top_block is None:
+                return ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=False)
+            width = P + (D if dense is not None else 0)
+            ld = (width + 3) // 4 * 4
+            buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
+            if ld != width:
+                buf[:, width:].zero_()
+            top_in = buf[:, :width]
+            ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
+            self._top_in = top_in
+            return self.top_block(top_in)
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
         tail = None
         if self.bottom_block is not None:
@@ -260,7 +295,6 @@ class DLRMBlock(Block):
             layers[-1].forward(x, out=tail)  # last bottom layer writes its slot of the stack
         self.embeddings.gather_into(inputs, stacked, self.slots)
         self._stacked = stacked
-        P = F * (F - 1) // 2
         if self.top_block is None:
             return self.interaction.forward(stacked)  # dlrm.py:120-121: interactions only
         width = P + (D if tail is not None else 0)
@@ -286,7 +320,11 @@ class DLRMBlock(Block):
             grad = mlp_backward(tl, grad, True, pre_masked) if tl else self.top_block.backward(grad)
         has_tail = self.bottom_block is not None and self.top_block is not None
         slot = self.slots["bottom_block"] if self.bottom_block is not None else -1
-        dstack = ops.dot_interaction_backward(self._stacked, grad, slot if has_tail else -1, D if has_tail else 0)
+        if getattr(self, "_fused", False):
+            st, si, dense = self._slots_ctx
+            dstack = ops.dlrm_interaction_fused_backward(st, si, dense, grad, tail_to_dense=has_tail)
+        else:
+            dstack = ops.dot_interaction_backward(self._stacked, grad, slot if has_tail else -1, D if has_tail else 0)
         if self.bottom_block is not None:
             layers = self.bottom_block.layers if isinstance(self.bottom_block, SequentialBlock) else [self.bottom_block]
             g = dstack[:, slot]  # strided [B, D] view; overwritten in place by the activation gradient

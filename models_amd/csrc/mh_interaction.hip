@@ -426,6 +426,254 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_pipe_kernel(const flo
     }
 }
 
+// =================================================================================================
+// Fused gather -> interaction (DLRM forward / backward without the stacked [B, F, D] round trip)
+// =================================================================================================
+// The stacked tensor X[b] = [emb rows in sorted-name order, bottom-MLP row] exists only in LDS: each
+// wavefront gathers the F-1 table rows of its sample straight from the tables (16-byte lanes, the same
+// access pattern as gather_fwd_kernel) plus the dense row, and feeds the matrix pipe.  HBM bytes per
+// sample drop from (gather 13 416 + interaction 8 572) to (F-1)*D*4 + ids + D*4 + out*4 = 8 680 at C2.
+// Ids are prefetched two samples ahead and rows one sample ahead, so both dependent HBM round trips
+// overlap the MFMA work of the current sample.
+struct FusedArgs {
+    const float* table[IMAXF];  // by STACK SLOT (sorted feature order); nullptr = the dense (bottom) slot
+    const void* ids[IMAXF];
+    int64_t rows[IMAXF];
+};
+
+template <typename IdT, int NV>
+struct RowGather {
+    const float* tptr[NV];
+    const IdT* iptr[NV];
+    int64_t nrows[NV];
+    int lds_off[NV];
+    int c4off[NV];
+    int64_t idn[NV];  // ids of the sample whose rows are fetched next
+    f32x4 xr[NV];
+
+    __device__ __forceinline__ void init(const FusedArgs& a, int lane, int F, int D, int LD) {
+        const int vpr = D / 4, nvec = F * vpr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = lane + 64 * i;
+            const int r = idx / vpr, c4 = idx - r * vpr;
+            const bool ok = idx < nvec;
+            lds_off[i] = ok ? r * LD + c4 * 4 : -1;
+            c4off[i] = c4 * 4;
+            tptr[i] = ok ? a.table[r] : nullptr;
+            iptr[i] = ok ? static_cast<const IdT*>(a.ids[r]) : nullptr;
+            nrows[i] = ok ? a.rows[r] : 0;
+        }
+    }
+    __device__ __forceinline__ void load_ids(int64_t b) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) idn[i] = (lds_off[i] >= 0 && tptr[i]) ? (int64_t)iptr[i][b] : 0;
+    }
+    __device__ __forceinline__ void load_rows(int64_t b, const float* __restrict__ dense, int64_t ld_dense, int D) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (lds_off[i] < 0) continue;
+            if (tptr[i]) {
+                const int64_t id = idn[i];
+                xr[i] = (id >= 0 && id < nrows[i])
+                            ? *reinterpret_cast<const f32x4*>(tptr[i] + id * D + c4off[i])
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                xr[i] = *reinterpret_cast<const f32x4*>(dense + b * ld_dense + c4off[i]);
+            }
+        }
+    }
+    __device__ __forceinline__ void to_lds(float* Xs) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(Xs + lds_off[i]) = xr[i];
+    }
+};
+
+template <typename IdT, int NV>
+__global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, const float* __restrict__ dense,
+                                                            int64_t ld_dense, int dense_slot, int64_t B, int F,
+                                                            int D, int append_dense, float* __restrict__ out,
+                                                            int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = D + 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* Xs = smem + wave * IMAXF * LD;
+    const int i16 = lane & 15, q = lane >> 4;
+    const int P = F * (F - 1) / 2;
+    const int qoff = q * (D / 4);
+    const int steps = D / 4;
+    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+    RowGather<IdT, NV> g;
+    g.init(a, lane, F, D, LD);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b < B) {
+        g.load_ids(b);
+        g.load_rows(b, dense, ld_dense, D);
+        if (b + stride < B) g.load_ids(b + stride);
+    }
+    const bool two = F > 16;
+    while (b < B) {
+        g.to_lds(Xs);
+        __builtin_amdgcn_wave_barrier();
+        const int64_t bn = b + stride;
+        if (bn < B) {
+            g.load_rows(bn, dense, ld_dense, D);          // ids of bn were fetched one iteration ago
+            if (bn + stride < B) g.load_ids(bn + stride);  // two samples ahead
+        }
+        f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
+        const float* r0 = Xs + i16 * LD + qoff;
+        const float* r1 = Xs + (16 + i16) * LD + qoff;
+        for (int s = 0; s < steps; s += 4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0 + s);
+            if (two) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(r1 + s);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc00 = mfma16(a0[j], a0[j], acc00);
+                    acc01 = mfma16(a0[j], a1[j], acc01);
+                    acc11 = mfma16(a1[j], a1[j], acc11);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc00 = mfma16(a0[j], a0[j], acc00);
+            }
+        }
+        float* orow = out + b * ldo;
+        store_tile(acc00, 0, 0, lane, F, orow);
+        if (two) {
+            store_tile(acc01, 0, 1, lane, F, orow);
+            store_tile(acc11, 1, 1, lane, F, orow);
+        }
+        if (append_dense && dense_slot >= 0)
+            for (int t = lane; t < D; t += 64) orow[P + t] = Xs[dense_slot * LD + t];
+        __builtin_amdgcn_wave_barrier();
+        b = bn;
+    }
+}
+
+template <typename IdT, int DT, int NV>
+__global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, const float* __restrict__ dense,
+                                                            int64_t ld_dense, const float* __restrict__ dout,
+                                                            int64_t ldo, int64_t B, int F, float* __restrict__ dx,
+                                                            int tail_slot, int T) {
+    constexpr int D = DT * 16;
+    constexpr int LD = D + 16;
+    constexpr int NP = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = F * (F - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* pair_j = pair_i + 512;
+    float* base = smem + 256;
+    float* Xs = base + wave * (IMAXF * LD + IMAXF * LDS_S);
+    float* Ss = Xs + IMAXF * LD;
+    const int i16 = lane & 15, q = lane >> 4;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        int i = 0, start = 0;
+        while (start + (F - 1 - i) <= p) {
+            start += F - 1 - i;
+            ++i;
+        }
+        pair_i[p] = (unsigned char)i;
+        pair_j[p] = (unsigned char)(i + 1 + (p - start));
+    }
+    for (int idx = lane; idx < IMAXF * LDS_S; idx += 64) Ss[idx] = 0.f;
+    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+    __syncthreads();
+    RowGather<IdT, NV> g;
+    g.init(a, lane, F, D, LD);
+    int s_off0[NP], s_off1[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = lane + 64 * k;
+        if (p < P) {
+            s_off0[k] = pair_i[p] * LDS_S + pair_j[p];
+            s_off1[k] = pair_j[p] * LDS_S + pair_i[p];
+        } else {
+            s_off0[k] = s_off1[k] = -1;
+        }
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    float gr[NP];
+    auto load_g = [&](int64_t bb) {
+        const float* gp = dout + bb * ldo;
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (s_off0[k] >= 0) gr[k] = gp[lane + 64 * k];
+    };
+    if (b < B) {
+        g.load_ids(b);
+        g.load_rows(b, dense, ld_dense, D);
+        load_g(b);
+        if (b + stride < B) g.load_ids(b + stride);
+    }
+    const int nti = F > 16 ? 2 : 1;
+    const int vpr = D / 4;
+    while (b < B) {
+        g.to_lds(Xs);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if (s_off0[k] >= 0) {
+                Ss[s_off0[k]] = gr[k];
+                Ss[s_off1[k]] = gr[k];
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int64_t bn = b + stride;
+        const float* gcur = dout + b * ldo;
+        float tgv[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            const int d = 16 * tn + i16;
+            tgv[tn] = (tail_slot >= 0 && d < T) ? gcur[P + d] : 0.f;
+        }
+        if (bn < B) {
+            g.load_rows(bn, dense, ld_dense, D);
+            load_g(bn);
+            if (bn + stride < B) g.load_ids(bn + stride);
+        }
+        float a0[8], a1[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            a0[st] = Ss[i16 * LDS_S + 4 * st + q];
+            a1[st] = (nti == 2) ? Ss[(16 + i16) * LDS_S + 4 * st + q] : 0.f;
+        }
+        f32x4 acc0[DT], acc1[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            acc0[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc1[tn] = acc0[tn];
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const float bv = Xs[(4 * st + q) * LD + 16 * tn + i16];
+                acc0[tn] = mfma16(a0[st], bv, acc0[tn]);
+                if (nti == 2) acc1[tn] = mfma16(a1[st], bv, acc1[tn]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            const int d = 16 * tn + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f0 = q * 4 + r, f1 = 16 + f0;
+                Xs[f0 * LD + d] = acc0[tn][r] + (f0 == tail_slot ? tgv[tn] : 0.f);
+                if (nti == 2) Xs[f1 * LD + d] = acc1[tn][r] + (f1 == tail_slot ? tgv[tn] : 0.f);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + b * (int64_t)F * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (g.lds_off[i] >= 0) dst[lane + 64 * i] = *reinterpret_cast<const f32x4*>(Xs + g.lds_off[i]);
+        __builtin_amdgcn_wave_barrier();
+        b = bn;
+        (void)vpr;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -507,6 +755,113 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
                            dx, tail_slot, T);
     }
     MH_CHECK_LAUNCH("mh_dot_interaction_bwd");
+    return MH_OK;
+}
+
+static int32_t fill_fused_args(FusedArgs* a, const float* const* slot_tables, const int64_t* slot_rows,
+                               const void* const* slot_ids, int32_t F, int32_t* dense_slot, const char* who) {
+    *dense_slot = -1;
+    for (int f = 0; f < F; ++f) {
+        a->table[f] = slot_tables[f];
+        a->ids[f] = slot_ids ? slot_ids[f] : nullptr;
+        a->rows[f] = slot_rows ? slot_rows[f] : 0;
+        if (!slot_tables[f]) {
+            if (*dense_slot >= 0) {
+                mh_set_error("%s: at most one dense (NULL-table) slot", who);
+                return MH_ERR_INVALID_ARGUMENT;
+            }
+            *dense_slot = f;
+        } else if (!a->ids[f]) {
+            mh_set_error("%s: slot %d has a table but no ids", who, f);
+            return MH_ERR_INVALID_ARGUMENT;
+        }
+    }
+    for (int f = F; f < IMAXF; ++f) {
+        a->table[f] = nullptr;
+        a->ids[f] = nullptr;
+        a->rows[f] = 0;
+    }
+    return MH_OK;
+}
+
+int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int64_t* slot_rows,
+                                      const void* const* slot_ids, int32_t ids_dtype, const float* dense,
+                                      int64_t ld_dense, int64_t B, int32_t F, int32_t D, int32_t append_dense,
+                                      float* out, int64_t ldo, mh_stream_t stream) {
+    MH_REQUIRE(slot_tables && slot_rows && slot_ids && out, "mh_dlrm_interaction_fused_fwd: null argument");
+    MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dlrm_interaction_fused_fwd: F=%d outside [2,%d]", F, IMAXF);
+    MH_REQUIRE(D >= 16 && D % 16 == 0 && F * (D / 4) <= 64 * 8, "mh_dlrm_interaction_fused_fwd: needs D %% 16 == 0 and F*D <= 2048 (got F=%d D=%d)", F, D);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_dlrm_interaction_fused_fwd: bad ids_dtype");
+    FusedArgs a;
+    int32_t dense_slot;
+    int32_t st = fill_fused_args(&a, slot_tables, slot_rows, slot_ids, F, &dense_slot, "mh_dlrm_interaction_fused_fwd");
+    if (st != MH_OK) return st;
+    MH_REQUIRE(dense_slot < 0 || (dense && ld_dense >= D && ld_dense % 4 == 0), "mh_dlrm_interaction_fused_fwd: dense slot needs a 16-byte aligned [B, D] source");
+    const int P = F * (F - 1) / 2;
+    const int T = (append_dense && dense_slot >= 0) ? D : 0;
+    MH_REQUIRE(ldo >= P + T, "mh_dlrm_interaction_fused_fwd: ldo too small");
+    if (B <= 0) return MH_OK;
+    const size_t lds = (size_t)4 * IMAXF * (D + 4) * sizeof(float);
+    const int64_t want = mh_ceil_div(B, 4);
+    const int64_t cap = (int64_t)mh_num_cus() * 8;
+    dim3 grid((unsigned)(want < cap ? want : cap));
+    hipStream_t s_ = mh_stream(stream);
+    if (ids_dtype == MH_I32) {
+        auto kern = dlrm_fused_fwd_kernel<int32_t, 8>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, D, append_dense, out, ldo);
+    } else {
+        auto kern = dlrm_fused_fwd_kernel<int64_t, 8>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, D, append_dense, out, ldo);
+    }
+    MH_CHECK_LAUNCH("mh_dlrm_interaction_fused_fwd");
+    return MH_OK;
+}
+
+int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int64_t* slot_rows,
+                                      const void* const* slot_ids, int32_t ids_dtype, const float* dense,
+                                      int64_t ld_dense, const float* dout, int64_t ldo, int64_t B, int32_t F,
+                                      int32_t D, int32_t tail_to_dense, float* dx, mh_stream_t stream) {
+    MH_REQUIRE(slot_tables && slot_rows && slot_ids && dout && dx, "mh_dlrm_interaction_fused_bwd: null argument");
+    MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dlrm_interaction_fused_bwd: F=%d outside [2,%d]", F, IMAXF);
+    MH_REQUIRE((D == 16 || D == 32 || D == 64 || D == 128) && F * (D / 4) <= 64 * 8,
+               "mh_dlrm_interaction_fused_bwd: needs D in {16,32,64,128} and F*D <= 2048 (got F=%d D=%d)", F, D);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_dlrm_interaction_fused_bwd: bad ids_dtype");
+    FusedArgs a;
+    int32_t dense_slot;
+    int32_t st = fill_fused_args(&a, slot_tables, slot_rows, slot_ids, F, &dense_slot, "mh_dlrm_interaction_fused_bwd");
+    if (st != MH_OK) return st;
+    MH_REQUIRE(dense_slot < 0 || (dense && ld_dense >= D && ld_dense % 4 == 0), "mh_dlrm_interaction_fused_bwd: dense slot needs a 16-byte aligned [B, D] source");
+    const int P = F * (F - 1) / 2;
+    const int tail_slot = (tail_to_dense && dense_slot >= 0) ? dense_slot : -1;
+    const int T = tail_slot >= 0 ? D : 0;
+    MH_REQUIRE(ldo >= P + T, "mh_dlrm_interaction_fused_bwd: ldo too small");
+    if (B <= 0) return MH_OK;
+    const size_t lds = 1024 + (size_t)4 * (IMAXF * (D + 16) + IMAXF * LDS_S) * sizeof(float);
+    const int64_t want = mh_ceil_div(B, 4);
+    const int64_t cap = (int64_t)mh_num_cus() * 8;
+    dim3 grid((unsigned)(want < cap ? want : cap));
+    hipStream_t s_ = mh_stream(stream);
+#define MH_LAUNCH_FUSED_BWD(IDT, DT)                                                                             \
+    {                                                                                                            \
+        auto kern = dlrm_fused_bwd_kernel<IDT, DT, 8>;                                                           \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dout, ldo, B, F, dx, tail_slot, T); \
+    }
+    if (ids_dtype == MH_I32) {
+        if (D == 16) MH_LAUNCH_FUSED_BWD(int32_t, 1)
+        else if (D == 32) MH_LAUNCH_FUSED_BWD(int32_t, 2)
+        else if (D == 64) MH_LAUNCH_FUSED_BWD(int32_t, 4)
+        else MH_LAUNCH_FUSED_BWD(int32_t, 8)
+    } else {
+        if (D == 16) MH_LAUNCH_FUSED_BWD(int64_t, 1)
+        else if (D == 32) MH_LAUNCH_FUSED_BWD(int64_t, 2)
+        else if (D == 64) MH_LAUNCH_FUSED_BWD(int64_t, 4)
+        else MH_LAUNCH_FUSED_BWD(int64_t, 8)
+    }
+#undef MH_LAUNCH_FUSED_BWD
+    MH_CHECK_LAUNCH("mh_dlrm_interaction_fused_bwd");
     return MH_OK;
 }
 

@@ -218,6 +218,7 @@ class DistributedDLRM:
             stacked[:, body.slots[n]] = sh.lookup(inputs[n])
         emb._last = {n: inputs[n] for n in body.cat_names}
         body._stacked = stacked
+        body._fused = False  # the sharded path materialises the stacked tensor
         P = F * (F - 1) // 2
         width = P + D
         ld = (width + 3) // 4 * 4

@@ -562,3 +562,69 @@ def eltwise(op: str, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor]
     out = torch.empty_like(a)
     check(lib.mh_eltwise(code, _ptr(a), _ptr(b), _ptr(c), _ptr(out), a.numel(), _stream()), "mh_eltwise")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# fused DLRM segment: gather -> stack (LDS only) -> interaction (+ dense shortcut)
+# --------------------------------------------------------------------------------------------
+def _fused_slot_arrays(slot_tables, slot_ids):
+    F = len(slot_tables)
+    idt = None
+    tabs, ids, rows = [], [], []
+    for t, i in zip(slot_tables, slot_ids):
+        if t is None:
+            tabs.append(0)
+            ids.append(0)
+            rows.append(0)
+            continue
+        _dev(t, "table", torch.float32)
+        _dev(i, "ids")
+        i = i.reshape(-1)
+        d = _ids_dtype(i, "ids")
+        if idt is not None and d != idt:
+            raise TypeError("fused DLRM segment: all ids must share one dtype")
+        idt = d
+        tabs.append(t.data_ptr())
+        ids.append(i.data_ptr())
+        rows.append(t.shape[0])
+    return F, idt if idt is not None else MH_I32, _host_ptr_array(tabs), (C.c_int64 * F)(*rows), _host_ptr_array(ids)
+
+
+def dlrm_interaction_fused(slot_tables, slot_ids, dense: Optional[torch.Tensor], append_dense: bool = True,
+                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``slot_tables[s]`` / ``slot_ids[s]`` per stack slot in sorted feature order; ``None`` marks the
+    dense slot fed by ``dense[B, D]`` (the bottom-MLP output).  Returns [B, P (+ D)]."""
+    lib = _lib.load()
+    F, idt, tab, rows, idp = _fused_slot_arrays(slot_tables, slot_ids)
+    first = next(t for t in slot_tables if t is not None)
+    D = first.shape[1]
+    B = next(i for i in slot_ids if i is not None).reshape(-1).shape[0]
+    if dense is not None:
+        _rowmajor_2d(dense, "dense")
+    P = F * (F - 1) // 2
+    T = D if (append_dense and dense is not None) else 0
+    if out is None:
+        out = torch.empty((B, P + T), dtype=torch.float32, device=first.device)
+    with _timed("dlrm_fused_fwd"):
+        check(lib.mh_dlrm_interaction_fused_fwd(tab, rows, idp, idt, _ptr(dense), 0 if dense is None else dense.stride(0),
+                                                B, F, D, int(bool(append_dense)), _ptr(out), out.stride(0), _stream()),
+              "mh_dlrm_interaction_fused_fwd")
+    return out
+
+
+def dlrm_interaction_fused_backward(slot_tables, slot_ids, dense: Optional[torch.Tensor], dout: torch.Tensor,
+                                    tail_to_dense: bool = True) -> torch.Tensor:
+    """dX [B, F, D] of the fused segment (rows re-gathered from the not-yet-updated tables)."""
+    lib = _lib.load()
+    F, idt, tab, rows, idp = _fused_slot_arrays(slot_tables, slot_ids)
+    first = next(t for t in slot_tables if t is not None)
+    D = first.shape[1]
+    _rowmajor_2d(dout, "dout")
+    B = dout.shape[0]
+    dx = torch.empty((B, F, D), dtype=torch.float32, device=first.device)
+    with _timed("dlrm_fused_bwd"):
+        check(lib.mh_dlrm_interaction_fused_bwd(tab, rows, idp, idt, _ptr(dense), 0 if dense is None else dense.stride(0),
+                                                _ptr(dout), dout.stride(0), B, F, D, int(bool(tail_to_dense)), _ptr(dx),
+                                                _stream()),
+              "mh_dlrm_interaction_fused_bwd")
+    return dx

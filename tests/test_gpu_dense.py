@@ -87,3 +87,35 @@ def test_dot_interaction_asymmetric_order(device):
     exp[0, pairs.index((0, 3))] = 1.0
     exp[1, pairs.index((2, 5))] = 6.0
     np.testing.assert_array_equal(out, exp)
+
+
+@pytest.mark.parametrize("F,D,dense_pos", [(27, 64, 26), (5, 16, 2), (17, 32, 0), (9, 128, None)])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+def test_fused_gather_interaction_fwd_bwd(device, F, D, dense_pos, idt):
+    """Fused segment == gather + stack + interaction (+ shortcut concat) of the unfused kernels/oracle."""
+    rng = np.random.default_rng(F * D)
+    B = 301
+    tabs, ids, rows_np = [], [], []
+    for s_ in range(F):
+        if s_ == dense_pos:
+            tabs.append(None)
+            ids.append(None)
+            rows_np.append(None)
+            continue
+        V = int(rng.integers(3, 400))
+        t = rng.normal(size=(V, D)).astype(np.float32)
+        i = rng.integers(0, V, size=B).astype(idt)
+        i[:3] = [-1, V, 0]  # out-of-range ids -> zero rows
+        tabs.append(_t(t, device))
+        ids.append(_t(i, device))
+        rows_np.append(O.embedding_lookup(t, i))
+    dense = rng.normal(size=(B, D)).astype(np.float32) if dense_pos is not None else None
+    X = np.stack([dense if r is None else r for r in rows_np], axis=1)
+    ref = O.dlrm_interaction_concat(X, dense)
+    out = ops.dlrm_interaction_fused(tabs, ids, None if dense is None else _t(dense, device)).cpu().numpy()
+    np.testing.assert_allclose(out, ref, atol=ATOL * max(1.0, D / 64), rtol=1e-5)
+    dout = rng.normal(size=ref.shape).astype(np.float32)
+    dx = ops.dlrm_interaction_fused_backward(tabs, ids, None if dense is None else _t(dense, device), _t(dout, device))
+    dx_ref = ops.dot_interaction_backward(_t(X, device), _t(dout, device), -1 if dense_pos is None else dense_pos,
+                                          0 if dense_pos is None else D)
+    torch.testing.assert_close(dx, dx_ref, atol=1e-5, rtol=1e-5)
