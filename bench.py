@@ -205,13 +205,21 @@ def main():
         "dot_interaction_bwd": B * (2 * Fs * D * 4 + (P + D) * 4),
     }
 
+    try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh; not re-measured live)
+        pmc = json.load(open(ROOT / "profiles" / "r1_pmc_traffic.json"))
+    except Exception:
+        pmc = {}
+
     def hbm_roofline(name, kernel):
         ms = kernel_ms.get(name, {}).get("avg_ms")
         if not ms:
             return None
         ach = alg_bytes[name] / (ms * 1e-3) / 1e9
+        traffic = pmc.get(name, {}).get("traffic_bytes") if (B == 65536 and args.ids == "uniform") else None
         return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes[name],
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)" if traffic else None,
+                "algorithmic_bytes_per_launch": alg_bytes[name],
                 "avg_launch_ms": ms, "timing": "hipEvent pair around the launch, eager pass after the timed region"}
 
     kernels = {"embedding_gather": "gather_fwd_kernel", "embedding_bwd": "segment_reduce_apply_kernel (+sort)",
