@@ -337,8 +337,26 @@ class DLRMBlock(Block):
         return None
 
 
+def _widen(x: torch.Tensor, d4: int) -> torch.Tensor:
+    """[B, d] -> [B, d4] with zero pad columns (d4 = d rounded up to 4): free when ``x`` is already a view
+    of a zero-padded [B, d4] buffer (what InputBlockV2 / linear_backward hand out), else one padded copy."""
+    B, d = x.shape
+    if d == d4 and x.is_contiguous():
+        return x
+    if x.stride(1) == 1 and x.stride(0) == d4 and x.storage_offset() % 4 == 0:
+        return x.as_strided((B, d4), (d4, 1))
+    out = torch.zeros((B, d4), dtype=x.dtype, device=x.device)
+    out[:, :d] = x
+    return out
+
+
 class Cross(Block):
-    """One DCN-v2 cross layer x0 * (x W + b) + x (cross.py:113-202), full-rank kernel."""
+    """One DCN-v2 cross layer x0 * (x W + b) + x (cross.py:113-202), full-rank kernel.
+
+    The feature width d (3341 on the Criteo DCN config) is rarely a multiple of 4; kernel and bias are stored
+    zero-padded to d4 = ceil(d/4)*4 so that every row of x / W is 16-byte aligned for the vector loads of the
+    MFMA GEMM.  Pad rows / columns stay exactly zero under SGD and Adagrad (their gradients are zero);
+    ``kernel.data[:d, :d]`` is the reference-shaped weight."""
 
     def __init__(self, name: Optional[str] = None, device=None, seed: Optional[int] = None):
         super().__init__(name)
@@ -346,11 +364,15 @@ class Cross(Block):
         self.seed = _next_seed() if seed is None else seed
         self.kernel: Optional[Parameter] = None
         self.bias: Optional[Parameter] = None
+        self.d = self.d4 = None
 
     def build(self, d: int):
         # CrossBlock default kernel_initializer="truncated_normal", bias "zeros" (cross.py:34-35)
-        self.kernel = Parameter(_truncated_normal((d, d), 0.05, self.seed).to(self.device), name=f"{self.name}/kernel")
-        self.bias = Parameter(torch.zeros(d, device=self.device), name=f"{self.name}/bias")
+        self.d, self.d4 = d, (d + 3) // 4 * 4
+        w = torch.zeros((self.d4, self.d4))
+        w[:d, :d] = _truncated_normal((d, d), 0.05, self.seed)
+        self.kernel = Parameter(w.to(self.device), name=f"{self.name}/kernel")
+        self.bias = Parameter(torch.zeros(self.d4, device=self.device), name=f"{self.name}/bias")
 
     def own_parameters(self):
         return [p for p in (self.kernel, self.bias) if p is not None]
@@ -361,19 +383,22 @@ class Cross(Block):
             raise ValueError(f"`x0` ({tuple(x0.shape)}) and `x` ({tuple(x.shape)}) shapes mismatch!")
         if self.kernel is None:
             self.build(x.shape[-1])
-        self._x0, self._x = x0, x
-        return ops.cross_layer(x0, x, self.kernel.data, self.bias.data)
+        d, d4 = self.d, self.d4
+        x0w, xw = _widen(x0, d4), _widen(x, d4)
+        self._x0, self._x = x0w, xw
+        return ops.cross_layer(x0w, xw, self.kernel.data, self.bias.data)[:, :d]
 
     def backward(self, dout):
         """out = x0 * p + x with p = x W + b: returns (dx0, dx); sets kernel / bias grads."""
         x0, x = self._x0, self._x
-        dout = dout.contiguous()
+        d, d4 = self.d, self.d4
+        dout = _widen(dout, d4)
         p = ops.linear(x, self.kernel.data, self.bias.data, None)  # recomputed, not stored
         dx0 = ops.eltwise("mul", dout, p)
         g = ops.eltwise("mul", dout, x0)                           # d loss / d p
         dx_lin, dW, db = ops.linear_backward(x, self.kernel.data, None, g, None, need_dx=True, need_db=True)
         self.kernel.grad, self.bias.grad = dW, db
-        return dx0, ops.eltwise("add", dx_lin, dout)
+        return dx0, ops.eltwise("add", _widen(dx_lin, d4), dout)  # both [B, d4], pad columns zero
 
 
 class CrossBlock(Block):
@@ -392,7 +417,7 @@ class CrossBlock(Block):
     def forward(self, inputs):
         if isinstance(inputs, dict):
             inputs = self.pre_aggregation(inputs)
-        x0 = x = inputs.contiguous()
+        x0 = x = inputs
         for layer in self.layers:
             x = layer((x0, x))
         return x
@@ -401,9 +426,9 @@ class CrossBlock(Block):
         dx0_total = None
         dx = grad
         for layer in reversed(self.layers):
-            dx0, dx = layer.backward(dx)
+            dx0, dx = layer.backward(dx)  # [B, d4] zero-padded
             dx0_total = dx0 if dx0_total is None else ops.eltwise("add", dx0_total, dx0)
-        return ops.eltwise("add", dx0_total, dx)  # layer 0 has x = x0
+        return ops.eltwise("add", dx0_total, dx)[:, :self.layers[0].d]  # layer 0 has x = x0
 
 
 class TwoTowerBlock(ParallelBlock):

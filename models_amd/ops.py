@@ -323,7 +323,13 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
     act = ACT[activation]
     if act != 0:
         _rowmajor_2d(y, "y")
-    dx = torch.empty((M, K), dtype=torch.float32, device=x.device) if need_dx else None
+    dx, lddx = None, K
+    if need_dx:
+        lddx = (K + 3) // 4 * 4  # 16-byte aligned rows for whoever consumes dx next
+        buf = torch.empty((M, lddx), dtype=torch.float32, device=x.device)
+        if lddx != K:
+            buf[:, K:].zero_()
+        dx = buf[:, :K]
     dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
     nbytes = lib.mh_linear_bwd_workspace_bytes(M, K, N)
@@ -332,7 +338,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         check(
             lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(y if act != 0 else None),
                                        y.stride(0) if act != 0 else 0, _ptr(dy), dy.stride(0), M, K, N, act,
-                                       ACT[x_activation], _ptr(dx), K, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                                       ACT[x_activation], _ptr(dx), lddx, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
             "mh_linear_bias_act_bwd",
         )
     return dx, dW, db

@@ -160,7 +160,8 @@ def test_dcn_forward_and_train_match_reference(device):
     body = model.body
     inp = body.input_block
     tables = {n: inp.categorical.feature_table[n].table.data.cpu().clone().requires_grad_() for n in inp.categorical.feature_names}
-    cross = [(l.kernel.data.cpu().clone().requires_grad_(), l.bias.data.cpu().clone().requires_grad_()) for l in body.cross.layers]
+    dc = body.cross.layers[0].d  # cross kernels are stored zero-padded to a multiple of 4
+    cross = [(l.kernel.data[:dc, :dc].cpu().clone().requires_grad_(), l.bias.data[:dc].cpu().clone().requires_grad_()) for l in body.cross.layers]
     deep = [(l.kernel.data.cpu().clone().requires_grad_(), l.bias.data.cpu().clone().requires_grad_(), l.activation) for l in body.deep.layers]
     hd = model.output.to_call
     head = (hd.kernel.data.cpu().clone().requires_grad_(), hd.bias.data.cpu().clone().requires_grad_())
@@ -195,8 +196,9 @@ def test_dcn_forward_and_train_match_reference(device):
     for n, t in tables.items():
         torch.testing.assert_close(inp.categorical.feature_table[n].table.data.cpu(), t.detach(), atol=1e-4, rtol=1e-4)
     for l, (W, b) in zip(body.cross.layers, cross):
-        torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
-        torch.testing.assert_close(l.bias.data.cpu(), b.detach(), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(l.kernel.data[:dc, :dc].cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+        torch.testing.assert_close(l.bias.data[:dc].cpu(), b.detach(), atol=1e-4, rtol=1e-4)
+        assert torch.all(l.kernel.data[dc:] == 0) and torch.all(l.kernel.data[:, dc:] == 0)  # pads stay zero
     for l, (W, b, _) in zip(body.deep.layers, deep):
         torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
 

@@ -91,8 +91,8 @@ if "topk" in which:
     qq = torch.randn(Bq, E, device=dev)
     timeit("topk 4096 x 1M x 128, k=100", lambda: ops.topk_dot(qq, c, None, k), flops=2 * Bq * N * E, iters=3)
 if "cross" in which:
-    d = 3341
-    x0 = torch.randn(B, d, device=dev)
-    W = torch.randn(d, d, device=dev) * 0.02
-    bb = torch.zeros(d, device=dev)
-    timeit("cross layer 64K x 3341 x 3341", lambda: ops.cross_layer(x0, x0, W, bb), flops=2 * B * d * d, iters=3)
+    for d in (3341, 3344):
+        x0 = torch.randn(B, d, device=dev)
+        W = torch.randn(d, d, device=dev) * 0.02
+        bb = torch.zeros(d, device=dev)
+        timeit(f"cross layer 64K x {d} x {d}", lambda: ops.cross_layer(x0, x0, W, bb), flops=2 * B * d * d, iters=3)
