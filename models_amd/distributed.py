@@ -50,14 +50,14 @@ def shard_table(full: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
 
 
 class Route:
-    """Where each local id goes: permutation into owner order + per-peer counts (host ints)."""
+    """Send ``payload[i]`` (int64) to rank ``owner[i]``: permutation into owner order + per-peer counts.
+    ONE host sync per route (RCCL needs host-side split sizes): send and receive counts travel together."""
 
-    def __init__(self, ids: torch.Tensor, world_size: int, group=None):
-        ids = ids.reshape(-1)
-        self.n = ids.shape[0]
+    def __init__(self, owner: torch.Tensor, payload: torch.Tensor, world_size: int, group=None):
+        owner, payload = owner.reshape(-1), payload.reshape(-1)
+        self.n = owner.shape[0]
         self.world_size = world_size
         self.group = group
-        owner = torch.remainder(ids, world_size)
         self.order = torch.argsort(owner, stable=True)
         send_counts = torch.bincount(owner, minlength=world_size)
         recv_counts = torch.empty_like(send_counts)
@@ -65,12 +65,20 @@ class Route:
             dist.all_to_all_single(recv_counts, send_counts, group=group)
         else:
             recv_counts.copy_(send_counts)
-        self.send_counts: List[int] = send_counts.tolist()  # host sync: RCCL needs host-side splits
-        self.recv_counts: List[int] = recv_counts.tolist()
-        local = torch.div(ids, world_size, rounding_mode="floor")
-        send_rows = local[self.order].contiguous()
-        self.recv_rows = torch.empty(sum(self.recv_counts), dtype=ids.dtype, device=ids.device)
-        self._a2a(self.recv_rows, send_rows, self.recv_counts, self.send_counts)
+        both = torch.stack([send_counts, recv_counts]).tolist()  # the one host sync
+        self.send_counts: List[int] = both[0]
+        self.recv_counts: List[int] = both[1]
+        send = payload[self.order].contiguous()
+        self.recv_payload = torch.empty(sum(self.recv_counts), dtype=payload.dtype, device=payload.device)
+        self._a2a(self.recv_payload, send, self.recv_counts, self.send_counts)
+
+    @classmethod
+    def for_rows(cls, ids: torch.Tensor, world_size: int, group=None) -> "Route":
+        """owner = row % W, payload = local row = row // W."""
+        ids = ids.reshape(-1)
+        r = cls(torch.remainder(ids, world_size), torch.div(ids, world_size, rounding_mode="floor"), world_size, group)
+        r.recv_rows = r.recv_payload
+        return r
 
     def _a2a(self, out, inp, out_splits, in_splits):
         if self.world_size > 1:
@@ -79,7 +87,7 @@ class Route:
             out.copy_(inp)
 
     def return_rows(self, rows: torch.Tensor) -> torch.Tensor:
-        """Owner -> requester: ``rows`` is [sum(recv_counts), D]; result is [n, D] in the ORIGINAL id order."""
+        """Owner -> requester: ``rows`` is [sum(recv_counts), D]; result is [n, D] in the ORIGINAL order."""
         D = rows.shape[1]
         back = torch.empty((self.n, D), dtype=rows.dtype, device=rows.device)
         self._a2a(back, rows.contiguous(), self.send_counts, self.recv_counts)
@@ -89,7 +97,7 @@ class Route:
 
     def send_grads(self, grad: torch.Tensor) -> torch.Tensor:
         """Requester -> owner: ``grad`` [n, D] in original order; result [sum(recv_counts), D] aligned
-        with ``recv_rows``."""
+        with ``recv_payload``."""
         D = grad.shape[1]
         g = grad[self.order].contiguous()
         out = torch.empty((sum(self.recv_counts), D), dtype=grad.dtype, device=grad.device)
@@ -112,13 +120,59 @@ class ShardedEmbeddingTable:
         self._route: Optional[Route] = None
 
     def lookup(self, ids: torch.Tensor) -> torch.Tensor:
-        self._route = Route(ids, self.world_size, self.group)
+        self._route = Route.for_rows(ids, self.world_size, self.group)
         rows = self.gather_fn(self.table, self._route.recv_rows)
         return self._route.return_rows(rows)
 
     def backward_update(self, grad: torch.Tensor) -> None:
         g = self._route.send_grads(grad)
         self.update_fn(self.table, self.state, self._route.recv_rows, g)
+
+
+class ShardedEmbeddingGroup:
+    """ALL row-sharded features of a model behind ONE route per step: the local shards live back to back in
+    one [sum V_local, D] buffer, a request is the int64 key (feature << 40 | local_row), the owner turns it
+    into a row of the concatenated buffer -> one gather launch, one fused update launch, three all-to-alls
+    (ids, rows, row-gradients) and one host sync per step regardless of the number of sharded tables."""
+
+    def __init__(self, full_tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None):
+        self.rank, self.world_size = world()
+        self.group = group
+        self.gather_fn, self.update_fn = gather_fn, update_fn
+        shards = [shard_table(t, self.rank, self.world_size) for t in full_tables]
+        self.global_rows = [t.shape[0] for t in full_tables]
+        sizes = [sh.shape[0] for sh in shards]
+        D = full_tables[0].shape[1]
+        self.local = torch.empty((max(sum(sizes), 1), D), dtype=torch.float32, device=full_tables[0].device)
+        base, o = [], 0
+        self.views: List[torch.Tensor] = []
+        for sh, n in zip(shards, sizes):
+            self.local[o:o + n] = sh
+            self.views.append(self.local[o:o + n])
+            base.append(o)
+            o += n
+        self.base = torch.tensor(base, dtype=torch.int64, device=self.local.device)
+        self.state: Optional[torch.Tensor] = None
+        self._route: Optional[Route] = None
+        self._rows: Optional[torch.Tensor] = None
+
+    def lookup(self, ids: Sequence[torch.Tensor]) -> torch.Tensor:
+        """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D]."""
+        W = self.world_size
+        idm = torch.stack([i.reshape(-1).to(torch.int64) for i in ids])  # [F_sh, B]
+        F_sh, B = idm.shape
+        feat = torch.arange(F_sh, device=idm.device, dtype=torch.int64).unsqueeze(1)
+        key = (feat << 40) | torch.div(idm, W, rounding_mode="floor")
+        self._route = Route(torch.remainder(idm, W), key, W, self.group)
+        rk = self._route.recv_payload
+        self._rows = self.base[rk >> 40] + (rk & ((1 << 40) - 1))  # rows of the concatenated local buffer
+        rows = self.gather_fn(self.local, self._rows)
+        return self._route.return_rows(rows).reshape(F_sh, B, -1)
+
+    def backward_update(self, grad: torch.Tensor) -> None:
+        """``grad`` [F_sh, B, D] in the order of ``lookup``."""
+        g = self._route.send_grads(grad.reshape(-1, grad.shape[-1]))
+        self.update_fn(self.local, self.state, self._rows, g)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -183,12 +237,16 @@ class DistributedDLRM:
             ops.embedding_gather_backward([table], None if state is None else [state], [rows], g3, [0], opt.name,
                                           opt.learning_rate, opt.epsilon)
 
-        for name in self.body.cat_names:
-            t = emb.feature_table[name]
-            if (self.world_size > 1 or force_shard) and t.input_dim >= shard_threshold:
-                local = shard_table(t.table.data, self.rank, self.world_size)
-                t.table.data = local  # drop the replicated copy
-                self.sharded[name] = ShardedEmbeddingTable(local, t.input_dim, gather_fn, update_fn, group)
+        names = [n for n in self.body.cat_names
+                 if (self.world_size > 1 or force_shard) and emb.feature_table[n].input_dim >= shard_threshold]
+        self.sharded: Dict[str, torch.Tensor] = {}
+        self.group_sh: Optional[ShardedEmbeddingGroup] = None
+        if names:
+            self.group_sh = ShardedEmbeddingGroup([emb.feature_table[n].table.data for n in names], gather_fn, update_fn, group)
+            for n, view in zip(names, self.group_sh.views):
+                emb.feature_table[n].table.data = view  # drop the replicated copy; keep a view of the local shard
+                self.sharded[n] = view
+        self.sharded_names = names
         self.replicated = [n for n in self.body.cat_names if n not in self.sharded]
         dense = [p.data for p in model.parameters() if not p.sparse]
         rep = [emb.feature_table[n].table.data for n in self.replicated]
@@ -214,8 +272,9 @@ class DistributedDLRM:
             ops.embedding_gather([emb.feature_table[n].table.data for n in self.replicated],
                                  [inputs[n] for n in self.replicated], out=stacked,
                                  out_slot=[body.slots[n] for n in self.replicated])
-        for n, sh in self.sharded.items():
-            stacked[:, body.slots[n]] = sh.lookup(inputs[n])
+        if self.group_sh is not None:
+            rows = self.group_sh.lookup([inputs[n] for n in self.sharded_names])  # [F_sh, B, D]
+            stacked[:, [body.slots[n] for n in self.sharded_names]] = rows.permute(1, 0, 2)
         emb._last = {n: inputs[n] for n in body.cat_names}
         body._stacked = stacked
         body._fused = False  # the sharded path materialises the stacked tensor
@@ -260,10 +319,11 @@ class DistributedDLRM:
         D = body.dim
         emb = body.embeddings
         # 1. sharded tables: route the gradient rows to their owners, fused update there
-        for n, sh in self.sharded.items():
-            if opt.name == "adagrad" and sh.state is None:
-                sh.state = torch.full_like(sh.table, opt.initial_accumulator_value)
-            sh.backward_update(dstack[:, body.slots[n]].contiguous())
+        if self.group_sh is not None:
+            gs = self.group_sh
+            if opt.name == "adagrad" and gs.state is None:
+                gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
+            gs.backward_update(dstack[:, [body.slots[n] for n in self.sharded_names]].permute(1, 0, 2).contiguous())
         # 2. replicated tables: dense [V, D] gradient via the fused backward (SGD, lr = -1, zeroed buffer)
         rep_tabs = [emb.feature_table[n].table for n in self.replicated]
         rep_grads = [torch.zeros_like(t.data) for t in rep_tabs]

@@ -69,6 +69,19 @@ def _worker(rank, world, port, V, Dm, B, q):
         out0 = sh.lookup(ids0)
         torch.testing.assert_close(out0, torch.from_numpy(np.stack([  # table was updated above
             D_row for D_row in (ref[ids0]).numpy()])), atol=1e-5, rtol=1e-5)
+        # grouped route: three sharded tables behind ONE route
+        fulls = [torch.randn(v, Dm, generator=g) for v in (301, 57, 1000)]
+        grp = D.ShardedEmbeddingGroup(fulls, _gather_fn, _update_fn)
+        idg_all = [torch.randint(0, t.shape[0], (world, B), generator=g) for t in fulls]
+        gg_all = torch.randn(world, 3, B, Dm, generator=g)
+        rows = grp.lookup([i[rank] for i in idg_all])
+        for f in range(3):
+            torch.testing.assert_close(rows[f], fulls[f][idg_all[f][rank]])
+        grp.backward_update(gg_all[rank])
+        for f in range(3):
+            ref_f = fulls[f].clone()
+            ref_f.index_add_(0, idg_all[f].reshape(-1), -0.1 * gg_all[:, f].reshape(-1, Dm))
+            torch.testing.assert_close(grp.views[f], D.shard_table(ref_f, rank, world), atol=1e-5, rtol=1e-5)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -107,7 +120,7 @@ def test_row_ownership_arithmetic():
 
 def test_world_size_one_route_is_identity():
     ids = torch.tensor([5, 3, 3, 9, 0])
-    r = D.Route(ids, 1)
+    r = D.Route.for_rows(ids, 1)
     assert r.send_counts == [5] and r.recv_counts == [5]
     rows = torch.arange(10.0).reshape(10, 1)[r.recv_rows]
     assert torch.equal(r.return_rows(rows)[:, 0], ids.float())

@@ -277,5 +277,5 @@ def test_distributed_dlrm_world1_matches_plain_model(device):
     torch.testing.assert_close(db(batches[0][0]), a(batches[0][0]), atol=1e-5, rtol=1e-4)
     for n in cards:
         ta = a.body.embeddings.feature_table[n].table.data
-        tb = db.sharded[n].table if n in db.sharded else b.body.embeddings.feature_table[n].table.data
+        tb = db.sharded[n] if n in db.sharded else b.body.embeddings.feature_table[n].table.data
         torch.testing.assert_close(tb, ta, atol=1e-5, rtol=1e-4)
