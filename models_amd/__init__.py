@@ -8,8 +8,8 @@ from .core import (  # noqa: F401
     Block, ConcatFeatures, Filter, ParallelBlock, Parameter, SequentialBlock, StackFeatures, TabularBlock,
 )
 from .inputs import (  # noqa: F401
-    Continuous, ContinuousFeatures, EmbeddingTable, Embeddings, EmbeddingsBlock, InputBlockV2, Ragged,
-    infer_embedding_dim,
+    Continuous, ContinuousFeatures, EmbeddingFeatures, EmbeddingOptions, EmbeddingTable, Embeddings, EmbeddingsBlock,
+    InputBlock, InputBlockV2, Ragged, infer_embedding_dim,
 )
 from .blocks import (  # noqa: F401
     Cross, CrossBlock, DLRMBlock, DotProductInteraction, DotProductInteractionBlock, MLPBlock, TwoTowerBlock,

@@ -37,7 +37,7 @@ def infer_embedding_dim(col_schema: ColumnSchema, multiplier: float = 2.0, ensur
 def _init_table(initializer, rows: int, dim: int, device, seed: Optional[int]) -> torch.Tensor:
     """keras Embedding default "uniform" = U(-0.05, 0.05) (embedding.py:205); V1 EmbeddingFeatures
     default TruncatedNormal(0, 0.05) (:1051) is available as "truncated_normal"."""
-    if initializer is None or initializer == "uniform":
+    if initializer is None or (isinstance(initializer, str) and initializer == "uniform"):
         g = torch.Generator(device="cpu")
         g.manual_seed(0 if seed is None else seed)
         if rows * dim > (1 << 24) and device.type == "cuda":
@@ -45,7 +45,7 @@ def _init_table(initializer, rows: int, dim: int, device, seed: Optional[int]) -
             gd.manual_seed(0 if seed is None else seed)
             return (torch.rand((rows, dim), generator=gd, device=device) - 0.5) * 0.1
         return ((torch.rand((rows, dim), generator=g) - 0.5) * 0.1).to(device)
-    if initializer == "truncated_normal":
+    if isinstance(initializer, str) and initializer == "truncated_normal":
         g = torch.Generator(device="cpu")
         g.manual_seed(0 if seed is None else seed)
         t = torch.empty((rows, dim))
@@ -379,3 +379,56 @@ class InputBlockV2(Block):
             g[:, :self._W] = grad
         self.categorical.set_pending_grad(g, {n: self._offsets[n] for n in self._cat_names})
         return None
+
+
+# --------------------------------------------------------------------------------------------
+# V1 surface (deprecated in the reference, still the route mm.TwoTowerModel V1 takes)
+# --------------------------------------------------------------------------------------------
+class EmbeddingOptions:
+    """inputs/embedding.py:931-942."""
+
+    def __init__(self, embedding_dims: Optional[Dict[str, int]] = None, embedding_dim_default: Optional[int] = 64,
+                 infer_embedding_sizes: bool = False, infer_embedding_sizes_multiplier: float = 2.0,
+                 infer_embeddings_ensure_dim_multiple_of_8: bool = False, embeddings_initializers=None,
+                 combiner: Optional[str] = "mean"):
+        self.embedding_dims = embedding_dims
+        self.embedding_dim_default = embedding_dim_default
+        self.infer_embedding_sizes = infer_embedding_sizes
+        self.infer_embedding_sizes_multiplier = infer_embedding_sizes_multiplier
+        self.infer_embeddings_ensure_dim_multiple_of_8 = infer_embeddings_ensure_dim_multiple_of_8
+        self.embeddings_initializers = embeddings_initializers
+        self.combiner = combiner
+
+
+class EmbeddingFeatures:
+    """V1 EmbeddingFeatures (inputs/embedding.py:950-1156): same lookup math as EmbeddingTable
+    (``lookup_feature`` :1126-1156 = tf.gather / safe_embedding_lookup_sparse), default initializer
+    TruncatedNormal(0, 0.05) (:1051), default dim 64.  Built on the same fused EmbeddingsBlock."""
+
+    @classmethod
+    def from_schema(cls, schema: Schema, embedding_options: Optional[EmbeddingOptions] = None, aggregation=None,
+                    device=None, **kwargs) -> EmbeddingsBlock:
+        opt = embedding_options or EmbeddingOptions()
+        cat = schema.select_by_tag(Tags.CATEGORICAL)
+        dims: Dict[str, int] = dict(opt.embedding_dims or {})
+        for col in cat:
+            if col.name in dims:
+                continue
+            if opt.infer_embedding_sizes:
+                dims[col.name] = infer_embedding_dim(col, opt.infer_embedding_sizes_multiplier,
+                                                     opt.infer_embeddings_ensure_dim_multiple_of_8)
+            else:
+                dims[col.name] = opt.embedding_dim_default
+        init = opt.embeddings_initializers if opt.embeddings_initializers is not None else "truncated_normal"
+        return Embeddings(cat, dim=dims, sequence_combiner=opt.combiner, embeddings_initializer=init,
+                          aggregation=aggregation, device=device)
+
+
+def InputBlock(schema: Schema, aggregation="concat", embedding_options: Optional[EmbeddingOptions] = None,
+               add_continuous_branch: bool = True, add_embedding_branch: bool = True, device=None, **kwargs) -> InputBlockV2:
+    """V1 InputBlock (inputs/base.py:40-206): continuous + EmbeddingFeatures branches, same aggregation."""
+    cat = EmbeddingFeatures.from_schema(schema, embedding_options, device=device) if (
+        add_embedding_branch and len(schema.select_by_tag(Tags.CATEGORICAL))) else None
+    con_schema = schema.select_by_tag(Tags.CONTINUOUS).excluding_by_tag(Tags.TARGET)
+    con = ContinuousFeatures.from_schema(con_schema) if (add_continuous_branch and len(con_schema)) else None
+    return InputBlockV2(schema, categorical=cat, continuous=con, aggregation=aggregation, device=device)

@@ -1,0 +1,91 @@
+"""Construction-time behaviour of the kept mm surface (no GPU): shapes, sharing, inferred dims, errors.
+Mirrors the reference's tests/unit/tf/inputs/test_embedding.py and tests/unit/tf/blocks/test_dlrm.py."""
+import numpy as np
+import pytest
+import torch
+
+import models_amd as mm
+from models_amd import schema as S
+
+CPU = torch.device("cpu")
+
+
+def test_embedding_table_shapes_and_domain():
+    # input_dim = int_domain.max + 1 (inputs/embedding.py:91-93)
+    col = S.categorical("item_id", 1000)
+    t = mm.EmbeddingTable(16, col, device=CPU)
+    assert t.table.shape == (1000, 16) and t.input_dim == 1000
+    assert abs(float(t.table.data.mean())) < 5e-3 and float(t.table.data.abs().max()) <= 0.05  # uniform(-0.05, 0.05)
+    with pytest.raises(ValueError):
+        mm.EmbeddingTable(16, S.ColumnSchema("no_domain"), device=CPU)
+    with pytest.raises(ValueError):
+        mm.EmbeddingTable(15, col, device=CPU)  # HIP path needs dim % 4 == 0
+
+
+def test_shared_table_by_domain_name():
+    # tests/unit/tf/inputs/test_embedding.py:231-253, 746-781: columns with one int_domain.name share a table
+    a = S.categorical("item_id", 100, domain_name="item")
+    b = S.categorical("last_item", 100, domain_name="item")
+    c = S.categorical("city", 7)
+    emb = mm.Embeddings(mm.Schema([a, b, c]), dim=8, device=CPU)
+    assert sorted(emb.parallel_layers) == ["city", "item"]
+    assert emb.feature_table["item_id"] is emb.feature_table["last_item"]
+    with pytest.raises(ValueError):
+        emb.feature_table["item_id"].add_feature(S.categorical("other", 5))  # different domain size
+
+
+def test_inferred_dims_and_per_feature_dims():
+    # tests/unit/tf/inputs/test_embedding.py:485-588
+    sch = mm.Schema([S.categorical("a", 10), S.categorical("b", 100_000), S.categorical("c", 1_000_000)])
+    emb = mm.Embeddings(sch, device=CPU)
+    assert [emb.feature_table[n].dim for n in "abc"] == [8, 40, 64]
+    emb = mm.Embeddings(sch, dim={"a": 16}, device=CPU)
+    assert emb.feature_table["a"].dim == 16 and emb.feature_table["b"].dim == 40
+    v1 = mm.EmbeddingFeatures.from_schema(sch, device=CPU)
+    assert {emb_.dim for emb_ in v1.parallel_layers.values()} == {64}  # V1 default dim 64
+    w = v1.feature_table["a"].table.data
+    assert float(w.abs().max()) <= 0.1 + 1e-6  # truncated normal, 2 sigma
+
+
+def test_pretrained_table_and_trainable_flag():
+    # tests/unit/tf/inputs/test_embedding.py:203-229
+    w = np.random.default_rng(0).normal(size=(20, 8)).astype(np.float32)
+    t = mm.EmbeddingTable.from_pretrained(w, trainable=False, name="pre", device=CPU)
+    np.testing.assert_array_equal(t.table.numpy(), w)
+    assert t.table.trainable is False and t.table.sparse
+
+
+def test_mlp_block_construction_errors():
+    with pytest.raises(ValueError, match="mismatch"):
+        mm.MLPBlock([8, 4], activation=["relu"])
+    with pytest.raises(NotImplementedError):
+        mm.MLPBlock([8], activation="tanh")
+    blk = mm.MLPBlock([8, 4], no_activation_last_layer=True, device=CPU)
+    assert [l.activation for l in blk.layers] == ["relu", None]
+
+
+def test_sorted_key_orders():
+    sch = mm.Schema([S.categorical(f"C{i}", 10) for i in range(1, 13)] + [S.continuous("I1")])
+    blk = mm.DLRMBlock(sch, embedding_dim=8, bottom_block=mm.MLPBlock([8], device=CPU), device=CPU)
+    # ASCII sort: "C1" < "C10" < "C11" < "C12" < "C2" ... < "bottom_block" (upper-case before lower-case)
+    assert blk.stack_order[:5] == ["C1", "C10", "C11", "C12", "C2"] and blk.stack_order[-1] == "bottom_block"
+
+
+def test_two_tower_requires_user_and_item_tags():
+    sch = mm.Schema([S.categorical("x", 10)])
+    with pytest.raises(ValueError, match="user.*item"):
+        mm.TwoTowerModel(sch, mm.MLPBlock([8], device=CPU), device=CPU)
+
+
+def test_contrastive_output_rejects_other_samplers():
+    with pytest.raises(NotImplementedError):
+        mm.ContrastiveOutput(S.categorical("item_id", 10, [S.Tags.ITEM_ID]), negative_samplers="popularity")
+
+
+def test_prepare_features_ragged_contract():
+    from models_amd.models import prepare_features
+
+    x = {"a": torch.arange(4), "l__values": torch.arange(5), "l__offsets": torch.tensor([0, 2, 5])}
+    out = prepare_features(x)
+    assert out["a"].shape == (4, 1)
+    assert isinstance(out["l"], mm.Ragged) and "l__values" not in out
