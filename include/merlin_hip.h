@@ -237,7 +237,11 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
  * Each score is a k-ascending fp32 fmaf chain (bit-reproducible by oracle/oracle_c.c).
  * out_scores[Bq, k] fp32 and out_idx[Bq, k] int32 (candidate row indices) are required (they hold the
  * running lists between candidate chunks); out_ids[Bq, k] int32 may be NULL.
- * k <= 1024, k <= N.  workspace: mh_topk_workspace_bytes(Bq, N, k). */
+ * k <= 1024, k <= N.  workspace: mh_topk_workspace_bytes(Bq, N, k).
+ * Large catalogues (N > 4 * bootstrap) take the fused-filter path: after a dense bootstrap the remaining
+ * candidates are scored by an MFMA kernel whose epilogue keeps only scores >= the row's current k-th
+ * best; the call then synchronises the stream ONCE to read an overflow flag (adversarially ordered data
+ * falls back to the dense path), so it cannot be captured into a hipGraph. */
 int64_t mh_topk_workspace_bytes(int64_t Bq, int64_t N, int32_t k);
 int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, int64_t Bq,
                     int64_t N, int32_t E, int32_t k, float* out_scores, int32_t* out_ids,

@@ -146,3 +146,23 @@ def test_l2norm_and_rowwise_dot(device):
     y = rng.normal(size=(300, 128)).astype(np.float32)
     np.testing.assert_allclose(ops.l2norm(_t(x, device)).cpu().numpy(), O.l2norm(x), atol=1e-6)
     np.testing.assert_allclose(ops.rowwise_dot(_t(x, device), _t(y, device)).cpu().numpy()[:, 0], (x * y).sum(-1), atol=1e-4)
+
+
+@pytest.mark.parametrize("order", ["random", "ascending", "ties"])
+def test_topk_fused_filter_path_bit_exact(device, order):
+    """N large enough for the fused-filter stages; 'ascending' makes every later candidate a survivor
+    (compact-list overflow -> dense fallback); 'ties' quantises scores so survivors tie across stages."""
+    rng = np.random.default_rng(11)
+    Bq, N, E, k = 33, 300_000, 32, 50
+    q = np.abs(rng.normal(size=(Bq, E))).astype(np.float32)
+    if order == "ties":
+        q = rng.integers(0, 3, size=(Bq, E)).astype(np.float32)
+        c = rng.integers(0, 3, size=(N, E)).astype(np.float32)
+    else:
+        c = np.abs(rng.normal(size=(N, E))).astype(np.float32)
+        if order == "ascending":
+            c = c[np.argsort(c.sum(1))]  # scores grow with the index for every (positive) query
+    vals, out_ids, idx = cbind.bruteforce_topk(q, c, None, k)
+    s, i, ix = ops.topk_dot(_t(q, device), _t(c, device), None, k)
+    np.testing.assert_array_equal(ix.cpu().numpy(), idx)
+    np.testing.assert_array_equal(s.cpu().numpy(), vals)
