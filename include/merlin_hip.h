@@ -260,6 +260,12 @@ int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad
 int32_t mh_dense_optimizer_step(float* w, const float* grad, float* state, int64_t n,
                                 int32_t optimizer, float lr, float eps, mh_stream_t stream);
 
+/* The same update for up to MH_MAX_FEATURES tensors in ONE launch (HOST arrays of device pointers /
+ * element counts): the dense parameters of a DLRM are 12 small tensors, one launch instead of 12. */
+int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad, float* const* state,
+                                      const int64_t* n, int32_t count, int32_t optimizer, float lr, float eps,
+                                      mh_stream_t stream);
+
 /* Elementwise helper of the cross-layer backward (blocks/cross.py:188-202 under GradientTape):
  * op 0: out = a*b;  op 1: out = a+b;  op 2: out = a*b + c.  n contiguous floats. */
 int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, float* out, int64_t n,

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
     "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p]),
     "mh_rowwise_dot": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p]),
+    "mh_dense_optimizer_step_multi": (_i32, [_p, _p, _p, _p, _i32, _i32, _f32, _f32, _p]),
     "mh_eltwise": (_i32, [_i32, _p, _p, _p, _p, _i64, _p]),
     "mh_dense_optimizer_step": (_i32, [_p, _p, _p, _i64, _i32, _f32, _f32, _p]),
     "mh_dlrm_interaction_fused_fwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),

@@ -299,9 +299,7 @@ class DLRMBlock(Block):
             return self.interaction.forward(stacked)  # dlrm.py:120-121: interactions only
         width = P + (D if tail is not None else 0)
         ld = (width + 3) // 4 * 4  # keep rows 16-byte aligned for the next layer's vector loads
-        buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
-        if ld != width:
-            buf[:, width:].zero_()
+        buf = torch.empty((B, ld), dtype=torch.float32, device=dev)  # pad column is never read (guarded k-tail)
         top_in = buf[:, :width]
         self.interaction.forward(stacked, tail, out=top_in)
         self._top_in = top_in

@@ -66,6 +66,32 @@ __global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, c
     }
 }
 
+struct MultiOptArgs {
+    float* w[MH_MAX_FEATURES];
+    const float* g[MH_MAX_FEATURES];
+    float* st[MH_MAX_FEATURES];
+    int64_t n[MH_MAX_FEATURES];
+};
+
+// one launch for every dense parameter of the model: blockIdx.y = tensor, grid-stride over its elements
+__global__ __launch_bounds__(256) void dense_opt_multi_kernel(const MultiOptArgs a, int opt, float lr, float eps) {
+    const int t = blockIdx.y;
+    float* __restrict__ w = a.w[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ acc = a.st[t];
+    const int64_t n = a.n[t];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        if (opt == MH_OPT_ADAGRAD) {
+            const float s2 = acc[i] + gi * gi;
+            acc[i] = s2;
+            w[i] -= lr * gi / (sqrtf(s2) + eps);
+        } else {
+            w[i] -= lr * gi;
+        }
+    }
+}
+
 // op 0: a*b   1: a+b   2: a*b + c      (float4-vectorised when n % 4 == 0 and pointers are aligned)
 __global__ __launch_bounds__(256) void eltwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ c, float* __restrict__ out, int64_t n) {
@@ -81,6 +107,32 @@ __global__ __launch_bounds__(256) void eltwise_kernel(int op, const float* __res
 }  // namespace
 
 extern "C" {
+
+int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad, float* const* state,
+                                      const int64_t* n, int32_t count, int32_t optimizer, float lr, float eps,
+                                      mh_stream_t stream) {
+    MH_REQUIRE(w && grad && n, "mh_dense_optimizer_step_multi: null argument");
+    MH_REQUIRE(count >= 0 && count <= MH_MAX_FEATURES, "mh_dense_optimizer_step_multi: count=%d outside [0,%d]", count, MH_MAX_FEATURES);
+    MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state), "mh_dense_optimizer_step_multi: bad optimizer/state");
+    if (count == 0) return MH_OK;
+    MultiOptArgs a;
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        MH_REQUIRE(w[i] && grad[i] && (optimizer == MH_OPT_SGD || state[i]), "mh_dense_optimizer_step_multi: null tensor %d", i);
+        a.w[i] = w[i];
+        a.g[i] = grad[i];
+        a.st[i] = state ? state[i] : nullptr;
+        a.n[i] = n[i];
+        if (n[i] > nmax) nmax = n[i];
+    }
+    int64_t bx = mh_ceil_div(nmax, 256);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(dense_opt_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, mh_stream(stream), a,
+                       optimizer, lr, eps);
+    MH_CHECK_LAUNCH("mh_dense_optimizer_step_multi");
+    return MH_OK;
+}
 
 int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, float* out, int64_t n,
                    mh_stream_t stream) {

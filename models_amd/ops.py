@@ -634,3 +634,25 @@ def dlrm_interaction_fused_backward(slot_tables, slot_ids, dense: Optional[torch
                                                 _stream()),
               "mh_dlrm_interaction_fused_bwd")
     return dx
+
+
+def dense_optimizer_step_multi(opt, params) -> None:
+    """SGD / Adagrad step on many dense Parameters in one launch (chunks of 64 tensors)."""
+    lib = _lib.load()
+    params = [p for p in params if p.grad is not None]
+    for start in range(0, len(params), _lib.MAX_FEATURES):
+        chunk = params[start:start + _lib.MAX_FEATURES]
+        grads = [p.grad.contiguous() for p in chunk]
+        states = None
+        if opt.name == "adagrad":
+            for p in chunk:
+                if "accumulator" not in p.state:
+                    p.state["accumulator"] = torch.full_like(p.data, opt.initial_accumulator_value)
+            states = _host_ptr_array([p.state["accumulator"].data_ptr() for p in chunk])
+        n = len(chunk)
+        check(lib.mh_dense_optimizer_step_multi(_host_ptr_array([p.data.data_ptr() for p in chunk]),
+                                                _host_ptr_array([g.data_ptr() for g in grads]), states,
+                                                (C.c_int64 * n)(*[p.data.numel() for p in chunk]), n, _lib.OPT[opt.name],
+                                                opt.learning_rate, opt.epsilon, _stream()), "mh_dense_optimizer_step_multi")
+    for p in params:
+        p.grad = None

@@ -22,11 +22,8 @@ class Optimizer:
     def apply(self, model) -> None:
         from . import ops
 
-        for p in model.parameters():
-            if p.sparse or not p.trainable or p.grad is None:
-                continue
-            ops.dense_optimizer_step(self, p)
-            p.grad = None
+        dense = [p for p in model.parameters() if not p.sparse and p.trainable and p.grad is not None]
+        ops.dense_optimizer_step_multi(self, dense)  # one launch for all MLP / cross / head tensors
         for blk in _walk(model):
             if hasattr(blk, "apply_sparse"):
                 blk.apply_sparse(self)
