@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--mode", choices=["fwd", "train"], default="train",
                     help="train = fwd + BCE + bwd + optimizer update (the reference's fit() throughput)")
-    ap.add_argument("--optimizer", choices=["sgd", "adagrad"], default="adagrad")
+    ap.add_argument("--optimizer", choices=["sgd", "adagrad", "adam"], default="adagrad")
     ap.add_argument("--shard-threshold", type=int, default=200_000, help="rows >= this are row-sharded when N > 1")
     ap.add_argument("--ids", choices=["uniform", "lognormal"], default="uniform")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")

@@ -51,6 +51,7 @@ extern "C" {
 /* sparse optimizers for the embedding backward (models/base.py:1121-1174; blocks/optimizer.py) */
 #define MH_OPT_SGD 0
 #define MH_OPT_ADAGRAD 1
+#define MH_OPT_ADAM 2 /* dense: keras Adam; sparse rows: LazyAdam (blocks/optimizer.py:342-437) */
 
 /* max features per gather call (pointer tables travel as kernel arguments) */
 #define MH_MAX_FEATURES 64
@@ -108,7 +109,11 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
  * (Keras _deduplicate_indexed_slices semantics).
  *   SGD:     W[r] -= lr * g[r]
  *   ADAGRAD: acc[r] += g[r]^2 ; W[r] -= lr * g[r] / (sqrt(acc[r]) + eps)   (keras Adagrad)
- * state[f] (Adagrad accumulator, same shape as the table) may be NULL for SGD.
+ *   ADAM:    LazyAdam._resource_apply_sparse (blocks/optimizer.py:412-437), touched rows only:
+ *            m[r] = b1 m[r] + (1-b1) g[r]; v[r] = b2 v[r] + (1-b2) g[r]^2; W[r] -= lr_t m[r]/(sqrt(v[r])+eps)
+ *            with lr_t = lr sqrt(1-b2^t)/(1-b1^t) supplied by the caller (host value `lr`, or the device
+ *            scalar `lr_device` maintained by mh_adam_tick so that a captured hipGraph replays correctly).
+ * state[f] (Adagrad accumulator / Adam m) and state2[f] (Adam v) have the table's shape; NULL when unused.
  * workspace: mh_embedding_bwd_workspace_bytes(B, F, D) bytes. */
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
@@ -116,7 +121,8 @@ int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const*
                                 const void* const* ids /*HOST [F]*/, int32_t ids_dtype,
                                 int64_t B, int32_t F, int32_t D, const float* grad,
                                 int64_t grad_row_stride, const int64_t* grad_offset /*HOST [F]*/,
-                                int32_t optimizer, float lr, float eps, void* workspace,
+                                int32_t optimizer, float lr, float eps, float* const* state2 /*HOST [F]*/,
+                                float beta1, float beta2, const float* lr_device, void* workspace,
                                 int64_t workspace_bytes, mh_stream_t stream);
 
 /* ---- a6: Dense layer  y = act(x W + b) -------------------------------------------------
@@ -256,14 +262,20 @@ int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad
                        float* loss, float* dlogit, mh_stream_t stream);
 
 /* ---- dense optimizer step for MLP / cross / head weights (models/base.py:1161) -----------
- * SGD: w -= lr*g.  ADAGRAD (keras): state += g^2; w -= lr * g / (sqrt(state) + eps). */
+ * SGD: w -= lr*g.  ADAGRAD (keras): state += g^2; w -= lr * g / (sqrt(state) + eps).
+ * ADAM (keras): state = b1 state + (1-b1) g; state2 = b2 state2 + (1-b2) g^2; w -= lr_t state/(sqrt(state2)+eps). */
 int32_t mh_dense_optimizer_step(float* w, const float* grad, float* state, int64_t n,
-                                int32_t optimizer, float lr, float eps, mh_stream_t stream);
+                                int32_t optimizer, float lr, float eps, float* state2, float beta1,
+                                float beta2, const float* lr_device, mh_stream_t stream);
+/* step[0] += 1; lr_t[0] = lr * sqrt(1 - beta2^step) / (1 - beta1^step): the Adam bias correction kept on
+ * the device (two fp32 scalars) so that a hipGraph-captured train step advances it on every replay. */
+int32_t mh_adam_tick(float* step, float lr, float beta1, float beta2, float* lr_t, mh_stream_t stream);
 
 /* The same update for up to MH_MAX_FEATURES tensors in ONE launch (HOST arrays of device pointers /
  * element counts): the dense parameters of a DLRM are 12 small tensors, one launch instead of 12. */
 int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad, float* const* state,
                                       const int64_t* n, int32_t count, int32_t optimizer, float lr, float eps,
+                                      float* const* state2, float beta1, float beta2, const float* lr_device,
                                       mh_stream_t stream);
 
 /* Elementwise helper of the cross-layer backward (blocks/cross.py:188-202 under GradientTape):

@@ -16,7 +16,7 @@ MH_OK = 0
 MH_I32, MH_I64 = 0, 1
 ACT = {"linear": 0, None: 0, "none": 0, "relu": 1, "sigmoid": 2}
 COMBINER = {"sum": 0, "mean": 1, "sqrtn": 2}
-OPT = {"sgd": 0, "adagrad": 1}
+OPT = {"sgd": 0, "adagrad": 1, "adam": 2, "lazy_adam": 2}
 MAX_FEATURES = 64
 
 _p = C.c_void_p
@@ -31,16 +31,17 @@ SIGNATURES = {
     "mh_embedding_bag_fwd": (_i32, [_p, _i64, _p, _i64, _p, _i32, _i64, _i32, _i32, _p, _i64, _p]),
     "mh_embedding_dense_list_fwd": (_i32, [_p, _i64, _p, _i32, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_embedding_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
-    "mh_embedding_gather_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _i64, _p]),
+    "mh_embedding_gather_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _f32, _f32, _p, _p, _i64, _p]),
     "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_linear_bias_act_bwd": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
     "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
     "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p]),
     "mh_rowwise_dot": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p]),
-    "mh_dense_optimizer_step_multi": (_i32, [_p, _p, _p, _p, _i32, _i32, _f32, _f32, _p]),
+    "mh_dense_optimizer_step_multi": (_i32, [_p, _p, _p, _p, _i32, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_eltwise": (_i32, [_i32, _p, _p, _p, _p, _i64, _p]),
-    "mh_dense_optimizer_step": (_i32, [_p, _p, _p, _i64, _i32, _f32, _f32, _p]),
+    "mh_dense_optimizer_step": (_i32, [_p, _p, _p, _i64, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
+    "mh_adam_tick": (_i32, [_p, _f32, _f32, _f32, _p, _p]),
     "mh_dlrm_interaction_fused_fwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_dlrm_interaction_fused_bwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "mh_cross_layer_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p]),

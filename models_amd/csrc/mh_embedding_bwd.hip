@@ -31,6 +31,7 @@ constexpr uint64_t ID_MASK = (1ull << 40) - 1;
 struct BwdArgs {
     float* table[MH_MAX_FEATURES];
     float* state[MH_MAX_FEATURES];
+    float* state2[MH_MAX_FEATURES];  // Adam second moment
     const void* ids[MH_MAX_FEATURES];
     int64_t rows[MH_MAX_FEATURES];
     int64_t offset[MH_MAX_FEATURES];  // float offset of the feature inside a grad row
@@ -50,8 +51,15 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const BwdArgs a, int64_
     vals[idx] = ((uint32_t)f << 26) | (uint32_t)b;
 }
 
+struct OptHyper {
+    float lr, eps, beta1, beta2;
+    const float* lr_dev;  // optional device scalar overriding lr (graph-replayable bias correction)
+};
+
 __device__ __forceinline__ void apply_update(const BwdArgs& a, uint64_t key, f32x4 g, int D, int c4, int opt,
-                                             float lr, float eps) {
+                                             const OptHyper& hp) {
+    const float lr = hp.lr_dev ? *hp.lr_dev : hp.lr;
+    const float eps = hp.eps;
     const int f = (int)(key >> 40);
     const int64_t id = (int64_t)(key & ID_MASK);
     float* w = a.table[f] + id * D + c4 * 4;
@@ -65,6 +73,20 @@ __device__ __forceinline__ void apply_update(const BwdArgs& a, uint64_t key, f32
         wv.y -= lr * g.y / (sqrtf(sv.y) + eps);
         wv.z -= lr * g.z / (sqrtf(sv.z) + eps);
         wv.w -= lr * g.w / (sqrtf(sv.w) + eps);
+    } else if (opt == MH_OPT_ADAM) {
+        // LazyAdam._resource_apply_sparse (blocks/optimizer.py:412-437): only the touched rows' moments move
+        float* mp = a.state[f] + id * D + c4 * 4;
+        float* vp = a.state2[f] + id * D + c4 * 4;
+        f32x4 m = *reinterpret_cast<f32x4*>(mp);
+        f32x4 v = *reinterpret_cast<f32x4*>(vp);
+        m = m * hp.beta1 + g * (1.f - hp.beta1);
+        v = v * hp.beta2 + (g * g) * (1.f - hp.beta2);
+        *reinterpret_cast<f32x4*>(mp) = m;
+        *reinterpret_cast<f32x4*>(vp) = v;
+        wv.x -= lr * m.x / (sqrtf(v.x) + eps);
+        wv.y -= lr * m.y / (sqrtf(v.y) + eps);
+        wv.z -= lr * m.z / (sqrtf(v.z) + eps);
+        wv.w -= lr * m.w / (sqrtf(v.w) + eps);
     } else {
         wv -= g * lr;
     }
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs
                                                                   int D, int LPR, const float* __restrict__ grad,
                                                                   int64_t grad_row_stride, float* __restrict__ carry,
                                                                   const int* __restrict__ lasthome,
-                                                                  int opt, float lr, float eps) {
+                                                                  int opt, const OptHyper hp) {
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
@@ -124,7 +146,7 @@ __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs
         const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
         const bool ends_here = (e < c1) || (e == n) || (keys[e] != key);
         if (starts_here && ends_here) {
-            apply_update(a, key, acc, D, c4, opt, lr, eps);
+            apply_update(a, key, acc, D, c4, opt, hp);
         } else {
             const int64_t home = starts_here ? chunk : (int64_t)lasthome[chunk - 1];
             float* cr = carry + home * D + c4 * 4;
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs
 
 __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
                                                          int64_t n, int D, int LPR, const float* __restrict__ carry,
-                                                         int opt, float lr, float eps) {
+                                                         int opt, const OptHyper hp) {
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
     const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
     if (!starts_here) return;  // an earlier chunk is this run's home
     const f32x4 g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
-    apply_update(a, key, g, D, c4, opt, lr, eps);
+    apply_update(a, key, g, D, c4, opt, hp);
 }
 
 struct WsLayout {
@@ -224,14 +246,16 @@ int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D) {
 int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const int64_t* table_rows,
                                 const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
                                 const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
-                                int32_t optimizer, float lr, float eps, void* workspace, int64_t workspace_bytes,
+                                int32_t optimizer, float lr, float eps, float* const* state2, float beta1, float beta2,
+                                const float* lr_device, void* workspace, int64_t workspace_bytes,
                                 mh_stream_t stream) {
     MH_REQUIRE(tables && table_rows && ids && grad && grad_offset, "mh_embedding_gather_bwd: null argument");
     MH_REQUIRE(F >= 1 && F < MH_MAX_FEATURES, "mh_embedding_gather_bwd: F=%d outside [1,%d]", F, MH_MAX_FEATURES - 1);
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_bwd: D=%d must be a multiple of 4 in [4,1024]", D);
     MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_gather_bwd: bad ids_dtype");
-    MH_REQUIRE(optimizer == MH_OPT_SGD || optimizer == MH_OPT_ADAGRAD, "mh_embedding_gather_bwd: bad optimizer %d", optimizer);
-    MH_REQUIRE(optimizer == MH_OPT_SGD || state, "mh_embedding_gather_bwd: Adagrad needs state tables");
+    MH_REQUIRE(optimizer >= MH_OPT_SGD && optimizer <= MH_OPT_ADAM, "mh_embedding_gather_bwd: bad optimizer %d", optimizer);
+    MH_REQUIRE(optimizer == MH_OPT_SGD || state, "mh_embedding_gather_bwd: Adagrad / Adam need state tables");
+    MH_REQUIRE(optimizer != MH_OPT_ADAM || state2, "mh_embedding_gather_bwd: Adam needs the second-moment tables");
     MH_REQUIRE(grad_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0,
                "mh_embedding_gather_bwd: grad must be 16-byte aligned with grad_row_stride %% 4 == 0");
     if (B <= 0) return MH_OK;
@@ -245,9 +269,11 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     BwdArgs a;
     for (int f = 0; f < F; ++f) {
         MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_bwd: null table/ids for feature %d", f);
-        MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_gather_bwd: null Adagrad state for feature %d", f);
+        MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_gather_bwd: null optimizer state for feature %d", f);
+        MH_REQUIRE(optimizer != MH_OPT_ADAM || state2[f], "mh_embedding_gather_bwd: null second moment for feature %d", f);
         a.table[f] = tables[f];
         a.state[f] = state ? state[f] : nullptr;
+        a.state2[f] = state2 ? state2[f] : nullptr;
         a.ids[f] = ids[f];
         a.rows[f] = table_rows[f];
         MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && grad_offset[f] + D <= grad_row_stride,
@@ -267,6 +293,7 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + L.off_vals_b);
     float* carry = reinterpret_cast<float*>(ws + L.off_carry);
     hipStream_t s = mh_stream(stream);
+    const OptHyper hp = {lr, eps, beta1, beta2, lr_device};
 
     dim3 gk((unsigned)mh_ceil_div(L.n, 256));
     if (ids_dtype == MH_I32)
@@ -316,8 +343,8 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
         return MH_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(segment_reduce_apply_kernel, gs, dim3(256), 0, s, a, keys_b, vals_b, L.n, D, LPR, grad,
-                       grad_row_stride, carry, lasthome, optimizer, lr, eps);
-    hipLaunchKernelGGL(carry_apply_kernel, gs, dim3(256), 0, s, a, keys_b, L.n, D, LPR, carry, optimizer, lr, eps);
+                       grad_row_stride, carry, lasthome, optimizer, hp);
+    hipLaunchKernelGGL(carry_apply_kernel, gs, dim3(256), 0, s, a, keys_b, L.n, D, LPR, carry, optimizer, hp);
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;
 }

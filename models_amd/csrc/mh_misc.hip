@@ -51,45 +51,58 @@ __global__ __launch_bounds__(256) void rowwise_dot_kernel(const float* __restric
 }
 
 // keras SGD: w -= lr*g ; keras Adagrad: acc += g^2 ; w -= lr * g / (sqrt(acc) + eps)
-__global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, const float* __restrict__ g,
-                                                       float* __restrict__ acc, int64_t n, int opt, float lr,
-                                                       float eps) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float gi = g[i];
+__device__ __forceinline__ void opt_elem(float* w, float gi, float* acc, float* acc2, int64_t i, int opt, float lr,
+                                         float eps, float b1, float b2) {
     if (opt == MH_OPT_ADAGRAD) {
         const float a = acc[i] + gi * gi;
         acc[i] = a;
         w[i] -= lr * gi / (sqrtf(a) + eps);
+    } else if (opt == MH_OPT_ADAM) {  // keras Adam: lr already carries sqrt(1-b2^t)/(1-b1^t)
+        const float m = acc[i] * b1 + gi * (1.f - b1);
+        const float v = acc2[i] * b2 + gi * gi * (1.f - b2);
+        acc[i] = m;
+        acc2[i] = v;
+        w[i] -= lr * m / (sqrtf(v) + eps);
     } else {
         w[i] -= lr * gi;
     }
+}
+
+__global__ __launch_bounds__(256) void dense_opt_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                       float* __restrict__ acc, float* __restrict__ acc2, int64_t n,
+                                                       int opt, float lr, float eps, float b1, float b2,
+                                                       const float* __restrict__ lr_dev) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    opt_elem(w, g[i], acc, acc2, i, opt, lr_dev ? *lr_dev : lr, eps, b1, b2);
+}
+
+// Adam bias correction on the device so that a captured graph replays with the right step count:
+// step[0] += 1;  lr_t[0] = lr * sqrt(1 - b2^t) / (1 - b1^t)   (keras Adam / LazyAdam)
+__global__ void adam_tick_kernel(float* __restrict__ step, float lr, float b1, float b2, float* __restrict__ lr_t) {
+    const float t = step[0] + 1.f;
+    step[0] = t;
+    lr_t[0] = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
 }
 
 struct MultiOptArgs {
     float* w[MH_MAX_FEATURES];
     const float* g[MH_MAX_FEATURES];
     float* st[MH_MAX_FEATURES];
+    float* st2[MH_MAX_FEATURES];
     int64_t n[MH_MAX_FEATURES];
 };
 
 // one launch for every dense parameter of the model: blockIdx.y = tensor, grid-stride over its elements
-__global__ __launch_bounds__(256) void dense_opt_multi_kernel(const MultiOptArgs a, int opt, float lr, float eps) {
+__global__ __launch_bounds__(256) void dense_opt_multi_kernel(const MultiOptArgs a, int opt, float lr, float eps,
+                                                             float b1, float b2, const float* __restrict__ lr_dev) {
     const int t = blockIdx.y;
     float* __restrict__ w = a.w[t];
     const float* __restrict__ g = a.g[t];
-    float* __restrict__ acc = a.st[t];
     const int64_t n = a.n[t];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i];
-        if (opt == MH_OPT_ADAGRAD) {
-            const float s2 = acc[i] + gi * gi;
-            acc[i] = s2;
-            w[i] -= lr * gi / (sqrtf(s2) + eps);
-        } else {
-            w[i] -= lr * gi;
-        }
-    }
+    const float lr_ = lr_dev ? *lr_dev : lr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        opt_elem(w, g[i], a.st[t], a.st2[t], i, opt, lr_, eps, b1, b2);
 }
 
 // op 0: a*b   1: a+b   2: a*b + c      (float4-vectorised when n % 4 == 0 and pointers are aligned)
@@ -110,10 +123,12 @@ extern "C" {
 
 int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad, float* const* state,
                                       const int64_t* n, int32_t count, int32_t optimizer, float lr, float eps,
+                                      float* const* state2, float beta1, float beta2, const float* lr_device,
                                       mh_stream_t stream) {
     MH_REQUIRE(w && grad && n, "mh_dense_optimizer_step_multi: null argument");
     MH_REQUIRE(count >= 0 && count <= MH_MAX_FEATURES, "mh_dense_optimizer_step_multi: count=%d outside [0,%d]", count, MH_MAX_FEATURES);
-    MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state), "mh_dense_optimizer_step_multi: bad optimizer/state");
+    MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state) || (optimizer == MH_OPT_ADAM && state && state2),
+               "mh_dense_optimizer_step_multi: bad optimizer/state");
     if (count == 0) return MH_OK;
     MultiOptArgs a;
     int64_t nmax = 0;
@@ -122,6 +137,7 @@ int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad,
         a.w[i] = w[i];
         a.g[i] = grad[i];
         a.st[i] = state ? state[i] : nullptr;
+        a.st2[i] = state2 ? state2[i] : nullptr;
         a.n[i] = n[i];
         if (n[i] > nmax) nmax = n[i];
     }
@@ -129,7 +145,7 @@ int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad,
     if (bx > 1024) bx = 1024;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(dense_opt_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, mh_stream(stream), a,
-                       optimizer, lr, eps);
+                       optimizer, lr, eps, beta1, beta2, lr_device);
     MH_CHECK_LAUNCH("mh_dense_optimizer_step_multi");
     return MH_OK;
 }
@@ -173,13 +189,22 @@ int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb,
     return MH_OK;
 }
 
+int32_t mh_adam_tick(float* step, float lr, float beta1, float beta2, float* lr_t, mh_stream_t stream) {
+    MH_REQUIRE(step && lr_t, "mh_adam_tick: null argument");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, mh_stream(stream), step, lr, beta1, beta2, lr_t);
+    MH_CHECK_LAUNCH("mh_adam_tick");
+    return MH_OK;
+}
+
 int32_t mh_dense_optimizer_step(float* w, const float* grad, float* state, int64_t n, int32_t optimizer,
-                                float lr, float eps, mh_stream_t stream) {
+                                float lr, float eps, float* state2, float beta1, float beta2,
+                                const float* lr_device, mh_stream_t stream) {
     MH_REQUIRE(w && grad, "mh_dense_optimizer_step: null argument");
-    MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state), "mh_dense_optimizer_step: bad optimizer/state");
+    MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state) || (optimizer == MH_OPT_ADAM && state && state2),
+               "mh_dense_optimizer_step: bad optimizer/state");
     if (n <= 0) return MH_OK;
     hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), w,
-                       grad, state, n, optimizer, lr, eps);
+                       grad, state, state2, n, optimizer, lr, eps, beta1, beta2, lr_device);
     MH_CHECK_LAUNCH("mh_dense_optimizer_step");
     return MH_OK;
 }

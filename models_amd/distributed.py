@@ -234,6 +234,8 @@ class DistributedDLRM:
         def update_fn(table, state, rows, grads, _self=self):
             opt = _self.model.optimizer
             g3 = grads.reshape(grads.shape[0], 1, D).contiguous()
+            if opt.name == "adam":
+                raise NotImplementedError("Adam / LazyAdam on row-sharded tables is not wired yet (use sgd or adagrad)")
             ops.embedding_gather_backward([table], None if state is None else [state], [rows], g3, [0], opt.name,
                                           opt.learning_rate, opt.epsilon)
 

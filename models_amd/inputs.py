@@ -219,17 +219,23 @@ class EmbeddingsBlock(ParallelBlock):
         for d in sorted({self.feature_table[n].dim for n in names}):
             grp = [n for n in names if self.feature_table[n].dim == d]
             tabs = [self.feature_table[n].table for n in grp]
-            states = None
+            states = states2 = None
             if opt.name == "adagrad":
                 for t in tabs:
                     if "accumulator" not in t.state:
                         t.state["accumulator"] = torch.full_like(t.data, opt.initial_accumulator_value)
                 states = [t.state["accumulator"] for t in tabs]
+            elif opt.name == "adam":  # LazyAdam rows
+                for t in tabs:
+                    if "m" not in t.state:
+                        t.state["m"], t.state["v"] = torch.zeros_like(t.data), torch.zeros_like(t.data)
+                states, states2 = [t.state["m"] for t in tabs], [t.state["v"] for t in tabs]
             for start in range(0, len(grp), 63):
                 sl = slice(start, start + 63)
                 ops.embedding_gather_backward([t.data for t in tabs[sl]], None if states is None else states[sl],
                                               [self._last[n] for n in grp[sl]], grad, [offsets[n] for n in grp[sl]],
-                                              opt.name, opt.learning_rate, opt.epsilon)
+                                              opt.name, opt.learning_rate, opt.epsilon,
+                                              None if states2 is None else states2[sl], opt.beta_1, opt.beta_2, opt.lr_device)
 
 
 def Embeddings(schema: Schema, dim: Optional[Union[Dict[str, int], int]] = None,

@@ -362,7 +362,9 @@ def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int
 
 def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[Sequence[Optional[torch.Tensor]]],
                               ids: Sequence[torch.Tensor], grad: torch.Tensor, grad_offset: Sequence[int],
-                              optimizer: str = "sgd", lr: float = 0.01, eps: float = 1e-7) -> None:
+                              optimizer: str = "sgd", lr: float = 0.01, eps: float = 1e-7,
+                              states2: Optional[Sequence[torch.Tensor]] = None, beta1: float = 0.9, beta2: float = 0.999,
+                              lr_device: Optional[torch.Tensor] = None) -> None:
     """Fused backward + sparse optimizer step for the one-hot lookup.  ``grad`` is a contiguous
     ``[B, ...]`` buffer; feature f's gradient row starts ``grad_offset[f]`` floats into row b."""
     lib = _lib.load()
@@ -380,11 +382,15 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     idt = _ids_dtype(ids[0], "ids[0]")
     flat = [i.reshape(-1) for i in ids]
     tab = _host_ptr_array([w.data_ptr() for w in tables])
-    st = None
-    if optimizer == "adagrad":
+    st = st2 = None
+    if optimizer in ("adagrad", "adam", "lazy_adam"):
         if states is None or any(s is None for s in states):
-            raise ValueError("adagrad needs an accumulator per table")
+            raise ValueError(f"{optimizer} needs a state tensor per table")
         st = _host_ptr_array([s.data_ptr() for s in states])
+    if optimizer in ("adam", "lazy_adam"):
+        if states2 is None or any(s is None for s in states2):
+            raise ValueError("adam needs a second-moment tensor per table")
+        st2 = _host_ptr_array([s.data_ptr() for s in states2])
     idp = _host_ptr_array([i.data_ptr() for i in flat])
     rows = (C.c_int64 * F)(*[w.shape[0] for w in tables])
     slot = (C.c_int64 * F)(*[int(s) for s in grad_offset])
@@ -395,7 +401,8 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     with _timed("embedding_bwd"):
         check(
             lib.mh_embedding_gather_bwd(tab, st, rows, idp, idt, B, F, D, _ptr(grad), row_stride, slot,
-                                        _lib.OPT[optimizer], lr, eps, _ptr(ws), ws.numel(), _stream()),
+                                        _lib.OPT[optimizer], lr, eps, st2, beta1, beta2, _ptr(lr_device), _ptr(ws), ws.numel(),
+                                        _stream()),
             "mh_embedding_gather_bwd",
         )
 
@@ -447,9 +454,27 @@ def dense_optimizer_step(opt, p) -> None:
         if state is None:
             state = torch.full_like(p.data, opt.initial_accumulator_value)
             p.state["accumulator"] = state
+    state2 = None
+    if opt.name == "adam":
+        state, state2 = _adam_states(p)
     g = p.grad.contiguous()
     check(lib.mh_dense_optimizer_step(_ptr(p.data), _ptr(g), _ptr(state), p.data.numel(), _lib.OPT[opt.name],
-                                      opt.learning_rate, opt.epsilon, _stream()), "mh_dense_optimizer_step")
+                                      opt.learning_rate, opt.epsilon, _ptr(state2), opt.beta_1, opt.beta_2,
+                                      _ptr(opt.lr_device), _stream()), "mh_dense_optimizer_step")
+
+
+def _adam_states(p):
+    if "m" not in p.state:
+        p.state["m"] = torch.zeros_like(p.data)
+        p.state["v"] = torch.zeros_like(p.data)
+    return p.state["m"], p.state["v"]
+
+
+def adam_tick(opt) -> None:
+    """Advance Adam's on-device step counter and bias-corrected learning rate (one tiny launch)."""
+    lib = _lib.load()
+    check(lib.mh_adam_tick(_ptr(opt._step_dev), opt.learning_rate, opt.beta_1, opt.beta_2, _ptr(opt.lr_device), _stream()),
+          "mh_adam_tick")
 
 
 # --------------------------------------------------------------------------------------------
@@ -643,16 +668,21 @@ def dense_optimizer_step_multi(opt, params) -> None:
     for start in range(0, len(params), _lib.MAX_FEATURES):
         chunk = params[start:start + _lib.MAX_FEATURES]
         grads = [p.grad.contiguous() for p in chunk]
-        states = None
+        states = states2 = None
         if opt.name == "adagrad":
             for p in chunk:
                 if "accumulator" not in p.state:
                     p.state["accumulator"] = torch.full_like(p.data, opt.initial_accumulator_value)
             states = _host_ptr_array([p.state["accumulator"].data_ptr() for p in chunk])
+        elif opt.name == "adam":
+            mv = [_adam_states(p) for p in chunk]
+            states = _host_ptr_array([m.data_ptr() for m, _ in mv])
+            states2 = _host_ptr_array([v.data_ptr() for _, v in mv])
         n = len(chunk)
         check(lib.mh_dense_optimizer_step_multi(_host_ptr_array([p.data.data_ptr() for p in chunk]),
                                                 _host_ptr_array([g.data_ptr() for g in grads]), states,
                                                 (C.c_int64 * n)(*[p.data.numel() for p in chunk]), n, _lib.OPT[opt.name],
-                                                opt.learning_rate, opt.epsilon, _stream()), "mh_dense_optimizer_step_multi")
+                                                opt.learning_rate, opt.epsilon, states2, opt.beta_1, opt.beta_2,
+                                                _ptr(opt.lr_device), _stream()), "mh_dense_optimizer_step_multi")
     for p in params:
         p.grad = None

@@ -14,13 +14,24 @@ import torch
 class Optimizer:
     name = "sgd"
 
-    def __init__(self, learning_rate: float = 0.01, epsilon: float = 1e-7, initial_accumulator_value: float = 0.1):
+    def __init__(self, learning_rate: float = 0.01, epsilon: float = 1e-7, initial_accumulator_value: float = 0.1,
+                 beta_1: float = 0.9, beta_2: float = 0.999):
         self.learning_rate = float(learning_rate)
         self.epsilon = float(epsilon)
         self.initial_accumulator_value = float(initial_accumulator_value)
+        self.beta_1, self.beta_2 = float(beta_1), float(beta_2)
+        self.lr_device = None  # Adam: bias-corrected lr kept on the device (graph-replayable)
+        self._step_dev = None
+
+    def begin_step(self, device) -> None:
+        """Per-step prologue (Adam advances its on-device step counter / bias-corrected lr)."""
 
     def apply(self, model) -> None:
         from . import ops
+
+        params = model.parameters()
+        if params:
+            self.begin_step(params[0].data.device)
 
         dense = [p for p in model.parameters() if not p.sparse and p.trainable and p.grad is not None]
         ops.dense_optimizer_step_multi(self, dense)  # one launch for all MLP / cross / head tensors
@@ -48,10 +59,31 @@ class Adagrad(Optimizer):
         super().__init__(learning_rate, **kw)
 
 
+class Adam(Optimizer):
+    """keras Adam for dense tensors; embedding tables get the LazyAdam row-wise variant the reference ships
+    for large tables (blocks/optimizer.py:342-437): only rows present in the batch move their moments."""
+
+    name = "adam"
+
+    def __init__(self, learning_rate: float = 0.001, **kw):
+        super().__init__(learning_rate, **kw)
+
+    def begin_step(self, device) -> None:
+        from . import ops
+
+        if self._step_dev is None:
+            self._step_dev = torch.zeros(1, dtype=torch.float32, device=device)
+            self.lr_device = torch.zeros(1, dtype=torch.float32, device=device)
+        ops.adam_tick(self)
+
+
+LazyAdam = Adam
+
+
 def get(opt: Union[str, Optimizer], **kwargs) -> Optimizer:
     if isinstance(opt, Optimizer):
         return opt
-    table = {"sgd": SGD, "adagrad": Adagrad}
+    table = {"sgd": SGD, "adagrad": Adagrad, "adam": Adam, "lazy_adam": Adam}
     if opt not in table:
         raise ValueError(f"unknown optimizer {opt!r}; on the HIP path: {sorted(table)}")
     return table[opt](**kwargs)
