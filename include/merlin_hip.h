@@ -254,6 +254,13 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
                     int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                     mh_stream_t stream);
 
+/* ---- top-k ranking metrics (metrics/topk.py:48-195) on pre-sorted labels ----------------------------
+ * labels_sorted[b, j] = relevance of the j-th best candidate of query b (what BruteForce.call returns as
+ * targets in testing mode, outputs/topk.py:224-236); relevant_counts[b] = total relevant items (NULL -> 1).
+ * out[b, 0..5] = recall, precision, average precision, dcg, ndcg, mrr @k. */
+int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* relevant_counts, int64_t B,
+                        int32_t k, float* out, mh_stream_t stream);
+
 /* ---- BinaryOutput head loss (outputs/classification.py:72-123): BCE on probabilities ----
  * p[M] = sigmoid output of the head, label[M] in {0,1}: loss[m] = keras binary_crossentropy
  * (clip p to [1e-7, 1-1e-7]); dlogit[m] = (p - label) * grad_scale (gradient w.r.t. the

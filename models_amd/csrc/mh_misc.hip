@@ -105,6 +105,35 @@ __global__ __launch_bounds__(256) void dense_opt_multi_kernel(const MultiOptArgs
         opt_elem(w, g[i], a.st[t], a.st2[t], i, opt, lr_, eps, b1, b2);
 }
 
+// Ranking metrics on PRE-SORTED labels (tf/metrics/topk.py:48-195): one thread per query row walks its k
+// labels once: hits, precision-weighted hits (AP), discounted gain, ideal gain, first hit.
+__global__ __launch_bounds__(256) void topk_metrics_kernel(const float* __restrict__ y, int64_t ld,
+                                                          const float* __restrict__ counts, int64_t B, int k,
+                                                          float* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= B) return;
+    const float* yr = y + row * ld;
+    const float cnt = counts ? counts[row] : 1.f;
+    float hits = 0.f, ap = 0.f, dcg = 0.f, idcg = 0.f, mrr = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const float rel = yr[j];
+        const float disc = 1.f / log2f((float)j + 2.f);
+        hits += rel;
+        ap += rel * (hits / (float)(j + 1));   // precision@(j+1) at relevant positions
+        dcg += rel * disc;
+        if ((float)j < cnt) idcg += disc;
+        if (mrr == 0.f && rel > 0.f) mrr = 1.f / (float)(j + 1);
+    }
+    const float denom = fminf(fmaxf(cnt, 1.f), (float)k);
+    float* o = out + row * 6;
+    o[0] = hits / denom;
+    o[1] = hits / (float)k;
+    o[2] = ap / denom;
+    o[3] = dcg;
+    o[4] = idcg > 0.f ? dcg / idcg : 0.f;
+    o[5] = mrr;
+}
+
 // op 0: a*b   1: a+b   2: a*b + c      (float4-vectorised when n % 4 == 0 and pointers are aligned)
 __global__ __launch_bounds__(256) void eltwise_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
                                                      const float* __restrict__ c, float* __restrict__ out, int64_t n) {
@@ -147,6 +176,16 @@ int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad,
     hipLaunchKernelGGL(dense_opt_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, mh_stream(stream), a,
                        optimizer, lr, eps, beta1, beta2, lr_device);
     MH_CHECK_LAUNCH("mh_dense_optimizer_step_multi");
+    return MH_OK;
+}
+
+int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* relevant_counts, int64_t B, int32_t k,
+                        float* out, mh_stream_t stream) {
+    MH_REQUIRE(labels_sorted && out && k >= 1 && ld >= k, "mh_topk_metrics: bad argument");
+    if (B <= 0) return MH_OK;
+    hipLaunchKernelGGL(topk_metrics_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, mh_stream(stream),
+                       labels_sorted, ld, relevant_counts, B, k, out);
+    MH_CHECK_LAUNCH("mh_topk_metrics");
     return MH_OK;
 }
 

@@ -686,3 +686,22 @@ def dense_optimizer_step_multi(opt, params) -> None:
                                                 _ptr(opt.lr_device), _stream()), "mh_dense_optimizer_step_multi")
     for p in params:
         p.grad = None
+
+
+TOPK_METRIC_NAMES = ("recall", "precision", "map", "dcg", "ndcg", "mrr")
+
+
+def topk_metrics(labels_sorted: torch.Tensor, k: int, relevant_counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-query ranking metrics @k on pre-sorted labels -> [B, 6] (TOPK_METRIC_NAMES order)."""
+    lib = _lib.load()
+    _rowmajor_2d(labels_sorted, "labels_sorted")
+    B = labels_sorted.shape[0]
+    if k > labels_sorted.shape[1]:
+        raise ValueError("k exceeds the number of sorted labels per row")
+    if relevant_counts is not None:
+        _dev(relevant_counts, "relevant_counts", torch.float32)
+        relevant_counts = relevant_counts.reshape(-1).contiguous()
+    out = torch.empty((B, 6), dtype=torch.float32, device=labels_sorted.device)
+    check(lib.mh_topk_metrics(_ptr(labels_sorted), labels_sorted.stride(0), _ptr(relevant_counts), B, k, _ptr(out),
+                              _stream()), "mh_topk_metrics")
+    return out

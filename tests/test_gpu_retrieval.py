@@ -166,3 +166,30 @@ def test_topk_fused_filter_path_bit_exact(device, order):
     s, i, ix = ops.topk_dot(_t(q, device), _t(c, device), None, k)
     np.testing.assert_array_equal(ix.cpu().numpy(), idx)
     np.testing.assert_array_equal(s.cpu().numpy(), vals)
+
+
+def test_topk_metrics_match_reference_literals_and_oracle(device):
+    # tests/unit/tf/metrics/test_metrics_topk.py:49-140
+    labels = np.array([[0, 1, 0, 1, 0], [1, 0, 0, 1, 0], [0, 0, 0, 0, 1]], np.float32)
+    preds = np.array([[10, 9, 8, 7, 6], [1, 4, 3, 2, 5], [10, 9, 8, 7, 6]], np.float32)
+    _, y, cnt = O.extract_topk(5, preds, labels)
+    got = ops.topk_metrics(_t(y, device), 4, _t(cnt.astype(np.float32), device)).cpu().numpy()
+    np.testing.assert_allclose(got[:, 0], [1.0, 0.5, 0.0], atol=1e-6)            # recall
+    np.testing.assert_allclose(got[:, 1], [0.5, 0.25, 0.0], atol=1e-6)           # precision
+    np.testing.assert_allclose(got[:, 2], [(1 / 2 + 2 / 4) / 2, (1 / 4) / 2, 0], atol=1e-6)  # MAP
+    np.testing.assert_allclose(got[:, 5], [0.5, 0.25, 0.0], atol=1e-6)           # MRR
+    np.testing.assert_allclose(got, O.topk_metrics(y, cnt, 4), atol=1e-6)
+    rng = np.random.default_rng(0)
+    y2 = (rng.random((500, 100)) < 0.05).astype(np.float32)
+    c2 = y2.sum(1) + rng.integers(0, 3, 500)
+    got = ops.topk_metrics(_t(y2, device), 20, _t(c2.astype(np.float32), device)).cpu().numpy()
+    np.testing.assert_allclose(got, O.topk_metrics(y2, c2, 20), atol=1e-5, rtol=1e-5)
+    # retrieval evaluation loop: BruteForce testing mode -> one-hot hit labels -> recall@k
+    q = rng.normal(size=(64, 16)).astype(np.float32)
+    c = rng.normal(size=(500, 16)).astype(np.float32)
+    target = np.argsort(-(q @ c.T), axis=1)[:, 3]  # the true item is always ranked 4th
+    import models_amd as mm
+    pred = mm.BruteForce(10).index(_t(c, device)).forward(_t(q, device), targets=_t(target.astype(np.int64), device), testing=True)
+    m = ops.topk_metrics(pred.targets, 10).cpu().numpy()
+    np.testing.assert_allclose(m[:, 0], 1.0)
+    np.testing.assert_allclose(m[:, 5], 0.25)

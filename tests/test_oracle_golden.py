@@ -128,10 +128,20 @@ def test_fmaf_gemm_close_to_blas():
 
 
 def test_topk_metrics_known_answers():
-    # tests/unit/tf/metrics/test_metrics_topk.py:49-140 style literals (recall/precision/MRR)
-    lab = np.array([[0, 1, 0, 1, 0], [1, 0, 0, 0, 0], [0, 0, 0, 0, 0]], np.float64)
-    cnt = np.array([3, 1, 2], np.float64)
-    np.testing.assert_allclose(O.recall_at(lab, cnt, 5), [2 / 3, 1.0, 0.0])
-    np.testing.assert_allclose(O.precision_at(lab, 5), [0.4, 0.2, 0.0])
-    np.testing.assert_allclose(O.mrr_at(lab, 5), [0.5, 1.0, 0.0])
-    np.testing.assert_allclose(O.dcg_at(lab, 5)[0], 1 / np.log2(3) + 1 / np.log2(5))
+    # tests/unit/tf/metrics/test_metrics_topk.py:49-140: fixture (labels sorted by the predictions) + literals
+    labels = np.array([[0, 1, 0, 1, 0], [1, 0, 0, 1, 0], [0, 0, 0, 0, 1]], np.float32)
+    preds = np.array([[10, 9, 8, 7, 6], [1, 4, 3, 2, 5], [10, 9, 8, 7, 6]], np.float32)
+    _, y, cnt = O.extract_topk(5, preds, labels)
+    np.testing.assert_array_equal(cnt, [2, 2, 1])
+    dcg_probe = lambda pos: 1.0 / np.log2(pos + 1)
+    np.testing.assert_allclose(O.recall_at(y, cnt, 4), [2 / 2, 1 / 2, 0 / 1])
+    np.testing.assert_allclose(O.precision_at(y, 4), [2 / 4, 1 / 4, 0])
+    np.testing.assert_allclose(O.average_precision_at(y, cnt, 4), [(1 / 2 + 2 / 4) / 2, (1 / 4) / 2, 0])
+    np.testing.assert_allclose(O.dcg_at(y, 4), [dcg_probe(2) + dcg_probe(4), dcg_probe(4), 0])
+    ideal = dcg_probe(1) + dcg_probe(2)
+    np.testing.assert_allclose(O.ndcg_at(y, cnt, 4), [(dcg_probe(2) + dcg_probe(4)) / ideal, dcg_probe(4) / ideal, 0])
+    np.testing.assert_allclose(O.mrr_at(y, 4), [1 / 2, 1 / 4, 0])
+    from sklearn.metrics import ndcg_score
+
+    ref = ndcg_score(labels, preds, k=4, ignore_ties=True)  # the reference cross-checks against sklearn too
+    np.testing.assert_allclose(O.ndcg_at(y, cnt, 4).mean(), ref, atol=1e-6)
