@@ -33,7 +33,7 @@ constexpr float M_INIT = -1.0e30f;  // finite "minus infinity" of the running ma
 // MODE 0: forward (optional logits store + online LSE partials)
 // MODE 1: backward helper: ds[row, col] = masked ? 0 : exp(z - lse[row]) * gscale   (z = s / T)
 template <int MODE, bool HAS_IDS, typename IdT, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void scorer_kernel(const float* __restrict__ q, const float* __restrict__ neg,
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 8 : WM * WN / 2) void scorer_kernel(const float* __restrict__ q, const float* __restrict__ neg,
                                                     const IdT* __restrict__ pos_ids,
                                                     const IdT* __restrict__ neg_ids, int64_t B, int64_t Nn, int E,
                                                     float invT, float fns, float* __restrict__ logits,
@@ -42,7 +42,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void scorer_kernel(const
                                                     const float* __restrict__ lse, float gscale,
                                                     float* __restrict__ ds, int vec_q, int vec_n) {
     constexpr int TM = SBM / WM / 32, TN = SBN / WN / 32, NTH = WM * WN * 64;
-    static_assert(WN == 2, "the cross-wave combine assumes two column halves");
     __shared__ __attribute__((aligned(16))) float smem[2 * SBM * LDK + 2 * SBN * LDK + 2 * SBM + 2 * SBM + SBM];
     float* As0 = smem;
     float* As1 = smem + SBM * LDK;
@@ -53,7 +52,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void scorer_kernel(const
     float* lse_s = comb + 4 * SBM;                         // [SBM] row lse (MODE 1)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     constexpr int WROWS = TM * 32, WCOLS = TN * 32;
     const int64_t row0 = (int64_t)blockIdx.x * SBM;
     const int split = blockIdx.y;
@@ -190,11 +189,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void scorer_kernel(const
                 }
                 if ((lane & 31) == 0) {
                     const int rl = wm * WROWS + tm * 32 + acc_row(r, lane);
-                    // interleave (m, s) of the two wn halves: comb[(wn*2+0)*SBM/... ] keep simple
-                    float* cm = comb + wn * SBM;
-                    // store m in comb, s in the (now free) A buffer 0
-                    cm[rl] = mm;
-                    As0[wn * SBM + rl] = ss;
+                    As0[wn * SBM + rl] = mm;  // the k-tile buffers are dead after the loop: [WN][SBM] scratch
+                    As1[wn * SBM + rl] = ss;
                 }
             }
         __syncthreads();
@@ -202,10 +198,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 2) void scorer_kernel(const
             const int rl = threadIdx.x;
             const int64_t row = row0 + rl;
             if (row < B) {
-                const float m0 = comb[rl], m1 = comb[SBM + rl];
-                const float s0 = As0[rl], s1 = As0[SBM + rl];
-                const float M = fmaxf(m0, m1);
-                const float S = s0 * fast_exp2(m0 - M) + s1 * fast_exp2(m1 - M);
+                float M = As0[rl];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) M = fmaxf(M, As0[w * SBM + rl]);
+                float S = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) S += As1[w * SBM + rl] * fast_exp2(As0[w * SBM + rl] - M);
                 part_m[(int64_t)split * B + row] = M;  // base-2 running max and sum of 2^(z2 - M)
                 part_s[(int64_t)split * B + row] = S;
             }
