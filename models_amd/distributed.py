@@ -156,8 +156,9 @@ class ShardedEmbeddingGroup:
         self._route: Optional[Route] = None
         self._rows: Optional[torch.Tensor] = None
 
-    def lookup(self, ids: Sequence[torch.Tensor]) -> torch.Tensor:
-        """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D]."""
+    def lookup(self, ids: Sequence[torch.Tensor], scatter_into=None) -> Optional[torch.Tensor]:
+        """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D], or, with
+        ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``."""
         W = self.world_size
         idm = torch.stack([i.reshape(-1).to(torch.int64) for i in ids])  # [F_sh, B]
         F_sh, B = idm.shape
@@ -167,11 +168,36 @@ class ShardedEmbeddingGroup:
         rk = self._route.recv_payload
         self._rows = self.base[rk >> 40] + (rk & ((1 << 40) - 1))  # rows of the concatenated local buffer
         rows = self.gather_fn(self.local, self._rows)
-        return self._route.return_rows(rows).reshape(F_sh, B, -1)
+        if scatter_into is None:
+            return self._route.return_rows(rows).reshape(F_sh, B, -1)
+        # returned rows arrive in owner order; position of request (f, b) in that order = inverse permutation.
+        # ONE multi-"table" gather writes them straight into their stack slots (no un-permute pass, no index_put).
+        r = self._route
+        D = rows.shape[1]
+        back = torch.empty((r.n, D), dtype=rows.dtype, device=rows.device)
+        r._a2a(back, rows.contiguous(), r.send_counts, r.recv_counts)
+        inv = torch.empty_like(r.order)
+        inv[r.order] = torch.arange(r.n, device=inv.device, dtype=inv.dtype)
+        inv = inv.reshape(F_sh, B)
+        stacked, slots, scatter_fn = scatter_into
+        scatter_fn([back] * F_sh, [inv[f] for f in range(F_sh)], stacked, slots)
+        return None
 
-    def backward_update(self, grad: torch.Tensor) -> None:
-        """``grad`` [F_sh, B, D] in the order of ``lookup``."""
-        g = self._route.send_grads(grad.reshape(-1, grad.shape[-1]))
+    def backward_update(self, grad: torch.Tensor, from_stacked=None) -> None:
+        """``grad`` [F_sh, B, D] in the order of ``lookup``; or ``from_stacked = (dstack [B, F, D], slots,
+        gather_fn)``: the gradient rows are pulled out of dstack already in owner order by one gather launch."""
+        r = self._route
+        if from_stacked is None:
+            g = r.send_grads(grad.reshape(-1, grad.shape[-1]))
+        else:
+            dstack, slots, gather_fn = from_stacked
+            B, F, D = dstack.shape
+            F_sh = len(slots)
+            b = torch.arange(B, device=dstack.device, dtype=torch.int64)
+            flat = (b.unsqueeze(0) * F + torch.tensor(slots, device=dstack.device, dtype=torch.int64).unsqueeze(1)).reshape(-1)
+            send = gather_fn(dstack.reshape(B * F, D), flat[r.order])  # [n, D] in owner order
+            g = torch.empty((sum(r.recv_counts), D), dtype=send.dtype, device=send.device)
+            r._a2a(g, send, r.recv_counts, r.send_counts)
         self.update_fn(self.local, self.state, self._rows, g)
 
 
@@ -262,7 +288,15 @@ class DistributedDLRM:
         B = inputs[body.cat_names[0]].shape[0]
         dev = inputs[body.cat_names[0]].device
         F, D = body.num_features, body.dim
+        # 1. route FIRST: its one host sync then waits only for the tiny bucketing kernels, and everything
+        #    below is enqueued back to back; the row all-to-all overlaps the bottom MLP / replicated gather
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
+        if self.group_sh is not None:
+            def scatter_fn(tabs, idx, out, slots):
+                ops.embedding_gather(tabs, idx, out=out, out_slot=slots)
+
+            self.group_sh.lookup([inputs[n] for n in self.sharded_names],
+                                 scatter_into=(stacked, [body.slots[n] for n in self.sharded_names], scatter_fn))
         x = body.continuous(inputs)
         layers = body.bottom_block.layers
         for layer in layers[:-1]:
@@ -274,9 +308,6 @@ class DistributedDLRM:
             ops.embedding_gather([emb.feature_table[n].table.data for n in self.replicated],
                                  [inputs[n] for n in self.replicated], out=stacked,
                                  out_slot=[body.slots[n] for n in self.replicated])
-        if self.group_sh is not None:
-            rows = self.group_sh.lookup([inputs[n] for n in self.sharded_names])  # [F_sh, B, D]
-            stacked[:, [body.slots[n] for n in self.sharded_names]] = rows.permute(1, 0, 2)
         emb._last = {n: inputs[n] for n in body.cat_names}
         body._stacked = stacked
         body._fused = False  # the sharded path materialises the stacked tensor
@@ -325,7 +356,8 @@ class DistributedDLRM:
             gs = self.group_sh
             if opt.name == "adagrad" and gs.state is None:
                 gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
-            gs.backward_update(dstack[:, [body.slots[n] for n in self.sharded_names]].permute(1, 0, 2).contiguous())
+            gs.backward_update(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
+                                                   lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
         # 2. replicated tables: dense [V, D] gradient via the fused backward (SGD, lr = -1, zeroed buffer)
         rep_tabs = [emb.feature_table[n].table for n in self.replicated]
         rep_grads = [torch.zeros_like(t.data) for t in rep_tabs]
@@ -335,13 +367,10 @@ class DistributedDLRM:
         # 3. one flat bucket for MLP / head gradients and the replicated-table gradients
         dense = [q for q in model.parameters() if not q.sparse and q.grad is not None]
         allreduce_sum_([q.grad for q in dense] + rep_grads, self.group)
-        for q in dense:
-            ops.dense_optimizer_step(opt, q)
-            q.grad = None
         for t, g in zip(rep_tabs, rep_grads):
             t.grad = g
-            ops.dense_optimizer_step(opt, t)
-            t.grad = None
+        opt.begin_step(dstack.device)
+        ops.dense_optimizer_step_multi(opt, dense + rep_tabs)  # one launch per 64 tensors
         if self.world_size > 1:
             l = loss.detach().clone()
             dist.all_reduce(l, group=self.group)

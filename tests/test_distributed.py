@@ -82,6 +82,28 @@ def _worker(rank, world, port, V, Dm, B, q):
             ref_f = fulls[f].clone()
             ref_f.index_add_(0, idg_all[f].reshape(-1), -0.1 * gg_all[:, f].reshape(-1, Dm))
             torch.testing.assert_close(grp.views[f], D.shard_table(ref_f, rank, world), atol=1e-5, rtol=1e-5)
+        # fused-permutation variants (what DistributedDLRM uses): scatter straight into stack slots, pull
+        # gradient rows out of dstack in owner order
+        grp2 = D.ShardedEmbeddingGroup(fulls, _gather_fn, _update_fn)
+        Fst = 5
+        slots = [4, 0, 2]
+        stacked = torch.zeros(B, Fst, Dm)
+
+        def scatter_fn(tabs, idx, out, sl):
+            for t, i, s_ in zip(tabs, idx, sl):
+                out[:, s_] = t[i]
+
+        grp2.lookup([i[rank] for i in idg_all], scatter_into=(stacked, slots, scatter_fn))
+        for f in range(3):
+            torch.testing.assert_close(stacked[:, slots[f]], fulls[f][idg_all[f][rank]])
+        dstack = torch.zeros(B, Fst, Dm)
+        for f in range(3):
+            dstack[:, slots[f]] = gg_all[rank, f]
+        grp2.backward_update(None, from_stacked=(dstack, slots, lambda tab, idx: tab[idx]))
+        for f in range(3):
+            ref_f = fulls[f].clone()
+            ref_f.index_add_(0, idg_all[f].reshape(-1), -0.1 * gg_all[:, f].reshape(-1, Dm))
+            torch.testing.assert_close(grp2.views[f], D.shard_table(ref_f, rank, world), atol=1e-5, rtol=1e-5)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
