@@ -119,32 +119,48 @@ __global__ __launch_bounds__(256) void chunk_flags_kernel(const uint64_t* __rest
 // One D/4-lane group per chunk of 16 sorted entries: run sums are formed in registers; a run wholly
 // inside the chunk is applied to its table row directly (exclusive owner, no atomics); a run crossing
 // a chunk boundary adds its piece to carry[home chunk] (home from the scanned chunk flags).
-// Latency is hidden by occupancy (~25 waves/CU at ~40 VGPRs) rather than by batching: the batched
-// variants tried in round 1 (all 16 rows in flight, batched read-modify-write) needed 250+ VGPRs and
-// ran slower (profiles/r1_notes.md).
+// The block's keys / packed values are staged in LDS with coalesced loads (one dependent HBM round trip
+// per block instead of two per entry) and gradient rows are fetched four at a time ahead of the sequential
+// run logic: enough memory-level parallelism at ~70 VGPRs (fully batching all 16 rows + the table
+// read-modify-writes needed 250 VGPRs and ran slower -- profiles/r1_notes.md).
 __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
                                                                   const uint32_t* __restrict__ vals, int64_t n,
                                                                   int D, int LPR, const float* __restrict__ grad,
                                                                   int64_t grad_row_stride, float* __restrict__ carry,
                                                                   const int* __restrict__ lasthome,
                                                                   int opt, const OptHyper hp) {
+    __shared__ uint64_t key_s[64 * CHUNK + 2];
+    __shared__ uint32_t val_s[64 * CHUNK];
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
+    const int64_t blk0 = (int64_t)blockIdx.x * groups * CHUNK;
+    const int span = groups * CHUNK;
+    for (int t = threadIdx.x; t < span + 2; t += 256) {
+        const int64_t i = blk0 - 1 + t;
+        key_s[t] = (i >= 0 && i < n) ? keys[i] : SENTINEL;
+    }
+    for (int t = threadIdx.x; t < span; t += 256) {
+        const int64_t i = blk0 + t;
+        val_s[t] = (i < n) ? vals[i] : 0u;
+    }
+    __syncthreads();
     if (gi >= groups) return;
     const int64_t chunk = (int64_t)blockIdx.x * groups + gi;
     const int64_t c0 = chunk * CHUNK;
     if (c0 >= n) return;
-    const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
-
-    uint64_t cur = keys[c0];
+    const int cnt_all = (int)(((c0 + CHUNK < n) ? c0 + CHUNK : n) - c0);
+    const uint64_t* kk = key_s + 1 + gi * CHUNK;  // kk[-1]: key before the chunk, kk[cnt_all]: key after
+    const uint32_t* vv = val_s + gi * CHUNK;
+    uint64_t cur = kk[0];
     if (cur == SENTINEL) return;
-    int64_t run_start = c0;
+    const bool head_cont = (c0 > 0) && (kk[-1] == cur);
+    int run_start = 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
-    auto flush = [&](uint64_t key, int64_t s, int64_t e) {
-        const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
-        const bool ends_here = (e < c1) || (e == n) || (keys[e] != key);
+    auto flush = [&](uint64_t key, int s_, int e_) {
+        const bool starts_here = (s_ > 0) || !head_cont;
+        const bool ends_here = (e_ < cnt_all) || (c0 + e_ == n) || (kk[e_] != key);
         if (starts_here && ends_here) {
             apply_update(a, key, acc, D, c4, opt, hp);
         } else {
@@ -157,20 +173,39 @@ __global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs
         }
     };
 
-    int64_t i = c0;
-    for (; i < c1; ++i) {
-        const uint64_t k = keys[i];
-        if (k == SENTINEL) break;
-        if (k != cur) {
-            flush(cur, run_start, i);
-            acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            cur = k;
-            run_start = i;
+    int i = 0;
+    bool done = false;
+    for (int base = 0; base < CHUNK && !done; base += 4) {
+        f32x4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = base + j;
+            r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < cnt_all && kk[u] != SENTINEL) {
+                const uint32_t v = vv[u];
+                const int f = (int)(v >> 26);
+                r[j] = *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
+                                                       a.offset[f] + c4 * 4);
+            }
         }
-        const uint32_t v = vals[i];
-        const int f = (int)(v >> 26);
-        const float* g = grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + a.offset[f] + c4 * 4;
-        acc += *reinterpret_cast<const f32x4*>(g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int u = base + j;
+            if (done || u >= cnt_all) continue;
+            const uint64_t k = kk[u];
+            if (k == SENTINEL) {
+                done = true;
+                continue;
+            }
+            if (k != cur) {
+                flush(cur, run_start, u);
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                cur = k;
+                run_start = u;
+            }
+            acc += r[j];
+            i = u + 1;
+        }
     }
     flush(cur, run_start, i);
 }

@@ -187,6 +187,8 @@ def embedding_bag(
     offsets = offsets.reshape(-1).contiguous()
     if out is None:
         out = torch.empty((B, D), dtype=torch.float32, device=table.device)
+    if B == 0:
+        return out
     check(
         lib.mh_embedding_bag_fwd(_ptr(table), table.shape[0], _ptr(values), values.shape[0], _ptr(offsets),
                                  idt, B, D, COMBINER[combiner], _ptr(out), out.stride(0), _stream()),
@@ -254,6 +256,8 @@ def linear(
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     else:
         _rowmajor_2d(out, "out")
+    if M == 0:
+        return out
     with _timed(f"linear_{K}x{N}"):
         check(
             lib.mh_linear_bias_act_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation],
@@ -282,6 +286,8 @@ def dot_interaction(
         out = torch.empty((B, P + T), dtype=torch.float32, device=x.device)
     else:
         _rowmajor_2d(out, "out")
+    if B == 0:
+        return out
     with _timed("dot_interaction"):
         check(
             lib.mh_dot_interaction_fwd(_ptr(x), B, F, D, _ptr(tail), 0 if tail is None else tail.stride(0), T,
@@ -558,6 +564,8 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
     scores = torch.empty((Bq, k), dtype=torch.float32, device=q.device)
     ids = torch.empty((Bq, k), dtype=torch.int32, device=q.device)
     idx = torch.empty((Bq, k), dtype=torch.int32, device=q.device)
+    if Bq == 0:
+        return scores, ids, idx
     ws = _workspace(lib.mh_topk_workspace_bytes(Bq, N, k), q.device, "topk")
     with _timed("topk_dot"):
         check(
