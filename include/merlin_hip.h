@@ -290,6 +290,24 @@ int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad,
 int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, float* out, int64_t n,
                    mh_stream_t stream);
 
+/* ---- multi-GPU: row-sharded embedding exchange --------------------------------------
+ * The reference scales the embedding lookup by handing the table to SparseOperationKit behind
+ * `merlin/models/tf/distributed/embedding.py:16-150` (SOKEmbedding: the table is spread over the Horovod
+ * workers, `sok.lookup_sparse` exchanges ids and rows; SOK itself is a closed third-party dependency).  Here the shard rule is owner = row % W, local row = row / W, and the send order is built
+ * on the device by a stable counting sort over the owners of the F id columns:
+ *   entry e = f*B + b;  send_keys[p] = f << 40 | ids[f][b] / W, grouped by owner, input order within an owner;
+ *   pos_of[e] = p (inverse permutation);  src_row[p] = b*F_total + slots[f] (row of a [B, F_total, D] gradient
+ *   stack that request p back-propagates into);  counts[w] = requests for owner w (int64, device).
+ * ids: HOST array of F device pointers; slots: HOST array. */
+int64_t mh_route_workspace_bytes(int64_t n, int32_t W);
+int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int64_t B, int32_t W,
+                       const int32_t* slots, int32_t F_total, int64_t* send_keys, int64_t* pos_of,
+                       int64_t* src_row, int64_t* counts, void* workspace, int64_t workspace_bytes,
+                       mh_stream_t stream);
+/* Owner side: rows[i] = base[key >> 40] + (key & (2^40 - 1)): row of the rank's concatenated local shards. */
+int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, int32_t F, int64_t* rows,
+                            mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

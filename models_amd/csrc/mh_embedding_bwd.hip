@@ -239,13 +239,17 @@ struct WsLayout {
     int key_bits;
 };
 
+// rocPRIM switches to a merge sort (dozens of 5 us launches) below 1M items; Onesweep already wins from ~64K.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 65536>;
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->n = B * F;
     L->nchunks = mh_ceil_div(L->n, CHUNK);
     size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                              (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, KEY_BITS);
     if (e != hipSuccess) return false;
     size_t scan = 0;
@@ -348,11 +352,11 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
         while ((1ll << idbits) < maxrows) ++idbits;
         if (idbits > 40) idbits = 40;
     }
-    hipError_t e = rocprim::radix_sort_pairs(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)L.n, 0,
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)L.n, 0,
                                              idbits, s);
     if (e == hipSuccess) {
         tmp_bytes = L.tmp_bytes;
-        e = rocprim::radix_sort_pairs(ws + L.off_tmp, tmp_bytes, keys_b, keys_a, vals_b, vals_a, (size_t)L.n, 40,
+        e = rocprim::radix_sort_pairs<SortConfig>(ws + L.off_tmp, tmp_bytes, keys_b, keys_a, vals_b, vals_a, (size_t)L.n, 40,
                                       KEY_BITS, s);
     }
     {   // results are back in the *_a buffers

@@ -1,0 +1,229 @@
+// Row-sharded embedding exchange: build the all-to-all send order on the device.
+//
+// A request is entry e = f*B + b of F id columns; it goes to rank owner = id % W and asks for local row
+// id / W of feature f (key = f << 40 | local row).  The send buffer must hold the requests grouped by owner;
+// this is a STABLE counting sort by owner (W <= 64 buckets), so the order -- and therefore the order in which
+// the owner's fused backward sums duplicate rows -- is a pure function of the ids:
+//   pass 1  per-tile owner histogram                      -> hist[w][tile]
+//   scan    exclusive prefix over the (w, tile) sequence  -> first send slot of every (owner, tile) pair
+//   pass 2  per-tile stable ranks (wave ballots), scatter keys / inverse permutation / gradient source rows
+// Replaces ~45 framework launches (stack, shifts, remainder, merge sort, bincount, index ...) per step.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "mh_common.h"
+
+namespace {
+
+constexpr int TILE_IT = 8;
+constexpr int TILE = 256 * TILE_IT;  // entries per workgroup
+constexpr int MAX_W = 64;
+
+struct RouteArgs {
+    const void* ids[MH_MAX_FEATURES];
+    int32_t slot[MH_MAX_FEATURES];
+};
+
+// ids are row numbers (>= 0); a stray negative id must not index outside the histogram
+__device__ __forceinline__ int owner_of(int64_t id, int W) {
+    const int o = (int)(id % W);
+    return o < 0 ? o + W : o;
+}
+
+template <typename IdT>
+__device__ __forceinline__ int64_t load_id(const RouteArgs& a, int64_t e, int64_t B, int& f, int64_t& b) {
+    f = (int)(e / B);
+    b = e - (int64_t)f * B;
+    return (int64_t) reinterpret_cast<const IdT*>(a.ids[f])[b];
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void route_count_kernel(const RouteArgs a, int64_t n, int64_t B, int W,
+                                                          int64_t ntiles, int* __restrict__ hist) {
+    __shared__ int h[MAX_W];
+    if (threadIdx.x < MAX_W) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * TILE;
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+        const int64_t e = e0 + it * 256 + threadIdx.x;
+        if (e < n) {
+            int f;
+            int64_t b;
+            const int64_t id = load_id<IdT>(a, e, B, f, b);
+            atomicAdd(&h[owner_of(id, W)], 1);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < W) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// counts[w] = requests for owner w = scan[(w+1)*ntiles] - scan[w*ntiles] (exclusive scan; last from n)
+__global__ void route_counts_kernel(const int* __restrict__ scan, int64_t ntiles, int W, int64_t n,
+                                    int64_t* __restrict__ counts) {
+    const int w = threadIdx.x;
+    if (w >= W) return;
+    const int64_t lo = scan[(int64_t)w * ntiles];
+    const int64_t hi = (w + 1 < W) ? (int64_t)scan[(int64_t)(w + 1) * ntiles] : n;
+    counts[w] = hi - lo;
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void route_scatter_kernel(const RouteArgs a, int64_t n, int64_t B, int W,
+                                                            int64_t ntiles, int F_total,
+                                                            const int* __restrict__ scan,
+                                                            int64_t* __restrict__ send_keys,
+                                                            int64_t* __restrict__ pos_of,
+                                                            int64_t* __restrict__ src_row) {
+    __shared__ int run[MAX_W];         // slots of this tile already handed out, per owner
+    __shared__ int wave_cnt[2][4][MAX_W];  // per-wave counts, double-buffered by iteration parity
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)threadIdx.x < W) run[threadIdx.x] = scan[(int64_t)threadIdx.x * ntiles + blockIdx.x];
+    const int64_t e0 = (int64_t)blockIdx.x * TILE;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int it = 0; it < TILE_IT; ++it) {
+        const int64_t e = e0 + it * 256 + threadIdx.x;
+        int owner = -1, f = 0;
+        int64_t b = 0, id = 0;
+        if (e < n) {
+            id = load_id<IdT>(a, e, B, f, b);
+            owner = owner_of(id, W);
+        }
+        int rank = 0;
+        for (int w = 0; w < W; ++w) {
+            const uint64_t m = __ballot(owner == w);
+            if (owner == w) rank = __popcll(m & lt_mask);
+            if (lane == 0) wave_cnt[it & 1][wave][w] = __popcll(m);
+        }
+        __syncthreads();  // wave_cnt complete; run[] of the previous iteration visible
+        if (owner >= 0) {
+            int p = run[owner] + rank;
+            for (int wv = 0; wv < wave; ++wv) p += wave_cnt[it & 1][wv][owner];
+            send_keys[p] = ((int64_t)f << 40) | (id / W);
+            pos_of[e] = p;
+            src_row[p] = b * F_total + a.slot[f];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < W)
+            run[threadIdx.x] += wave_cnt[it & 1][0][threadIdx.x] + wave_cnt[it & 1][1][threadIdx.x] +
+                                wave_cnt[it & 1][2][threadIdx.x] + wave_cnt[it & 1][3][threadIdx.x];
+    }
+}
+
+__global__ void route_local_rows_kernel(const int64_t* __restrict__ keys, int64_t n,
+                                        const int64_t* __restrict__ base, int F, int64_t* __restrict__ rows,
+                                        int* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t k = keys[i];
+    const int f = (int)(k >> 40);
+    if (f < 0 || f >= F) {
+        rows[i] = 0;
+        if (bad) *bad = 1;
+        return;
+    }
+    rows[i] = base[f] + (k & ((1ll << 40) - 1));
+}
+
+struct RouteWs {
+    int64_t ntiles;
+    size_t off_hist, off_scan, off_tmp, tmp_bytes, total;
+};
+
+size_t up(size_t v) { return (v + 255) / 256 * 256; }
+
+bool route_ws(int64_t n, int W, RouteWs* L) {
+    L->ntiles = mh_ceil_div(n, TILE);
+    const size_t cells = (size_t)L->ntiles * W;
+    size_t tmp = 0;
+    if (rocprim::exclusive_scan(nullptr, tmp, (const int*)nullptr, (int*)nullptr, 0, cells, rocprim::plus<int>()) !=
+        hipSuccess)
+        return false;
+    L->tmp_bytes = tmp;
+    L->off_hist = 0;
+    L->off_scan = up(cells * sizeof(int));
+    L->off_tmp = L->off_scan + up(cells * sizeof(int));
+    L->total = L->off_tmp + up(tmp);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mh_route_workspace_bytes(int64_t n, int32_t W) {
+    if (n <= 0 || W <= 0 || W > MAX_W) return 0;
+    RouteWs L;
+    if (!route_ws(n, W, &L)) return -1;
+    return (int64_t)L.total;
+}
+
+int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int64_t B, int32_t W,
+                       const int32_t* slots, int32_t F_total, int64_t* send_keys, int64_t* pos_of,
+                       int64_t* src_row, int64_t* counts, void* workspace, int64_t workspace_bytes,
+                       mh_stream_t stream) {
+    MH_REQUIRE(ids && slots && counts, "mh_route_build: null argument");
+    MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_route_build: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
+    MH_REQUIRE(W >= 1 && W <= MAX_W, "mh_route_build: world size %d outside [1,%d]", W, MAX_W);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_route_build: bad ids_dtype");
+    MH_REQUIRE(F_total >= 1, "mh_route_build: F_total must be >= 1");
+    hipStream_t s = mh_stream(stream);
+    if (B <= 0) {
+        if (hipMemsetAsync(counts, 0, sizeof(int64_t) * W, s) != hipSuccess) {
+            mh_set_error("mh_route_build: memset failed");
+            return MH_ERR_LAUNCH;
+        }
+        return MH_OK;
+    }
+    MH_REQUIRE(send_keys && pos_of && src_row && workspace, "mh_route_build: null output");
+    const int64_t n = B * F;
+    MH_REQUIRE(n < (1ll << 31), "mh_route_build: F*B must be < 2^31");
+    RouteWs L;
+    MH_REQUIRE(route_ws(n, W, &L), "mh_route_build: rocprim size query failed");
+    MH_REQUIRE(workspace_bytes >= (int64_t)L.total, "mh_route_build: workspace too small (%lld < %lld)",
+               (long long)workspace_bytes, (long long)L.total);
+    RouteArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int f = 0; f < F; ++f) {
+        MH_REQUIRE(ids[f], "mh_route_build: ids[%d] is null", f);
+        MH_REQUIRE(slots[f] >= 0 && slots[f] < F_total, "mh_route_build: slot %d outside [0,%d)", slots[f], F_total);
+        a.ids[f] = ids[f];
+        a.slot[f] = slots[f];
+    }
+    char* ws = static_cast<char*>(workspace);
+    int* hist = reinterpret_cast<int*>(ws + L.off_hist);
+    int* scan = reinterpret_cast<int*>(ws + L.off_scan);
+    const dim3 grid((unsigned)L.ntiles);
+    if (ids_dtype == MH_I32)
+        hipLaunchKernelGGL(route_count_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
+    else
+        hipLaunchKernelGGL(route_count_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
+    size_t tmp = L.tmp_bytes;
+    if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, hist, scan, 0, (size_t)L.ntiles * W, rocprim::plus<int>(), s) !=
+        hipSuccess) {
+        mh_set_error("mh_route_build: rocprim scan failed");
+        return MH_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(route_counts_kernel, dim3(1), dim3(64), 0, s, scan, L.ntiles, W, n, counts);
+    if (ids_dtype == MH_I32)
+        hipLaunchKernelGGL(route_scatter_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
+                           send_keys, pos_of, src_row);
+    else
+        hipLaunchKernelGGL(route_scatter_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
+                           send_keys, pos_of, src_row);
+    MH_CHECK_LAUNCH("mh_route_build");
+    return MH_OK;
+}
+
+int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, int32_t F, int64_t* rows,
+                            mh_stream_t stream) {
+    if (n <= 0) return MH_OK;
+    MH_REQUIRE(recv_keys && base && rows, "mh_route_local_rows: null argument");
+    MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_route_local_rows: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
+    hipLaunchKernelGGL(route_local_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream),
+                       recv_keys, n, base, F, rows, (int*)nullptr);
+    MH_CHECK_LAUNCH("mh_route_local_rows");
+    return MH_OK;
+}
+
+}  // extern "C"

@@ -129,16 +129,42 @@ class ShardedEmbeddingTable:
         self.update_fn(self.table, self.state, self._route.recv_rows, g)
 
 
+def route_build_torch(ids: Sequence[torch.Tensor], world_size: int, slots: Sequence[int], n_slots: int):
+    """Framework-op statement of ``mh_route_build`` (same contract, any device): what the gloo tests inject and
+    what the HIP kernel is checked against.  Entry e = f*B + b; stable order within an owner."""
+    idm = torch.stack([i.reshape(-1).to(torch.int64) for i in ids])  # [F, B]
+    F, B = idm.shape
+    owner = torch.remainder(idm, world_size).reshape(-1)
+    order = torch.argsort(owner, stable=True)
+    feat = torch.arange(F, device=idm.device, dtype=torch.int64).unsqueeze(1)
+    key = ((feat << 40) | torch.div(idm, world_size, rounding_mode="floor")).reshape(-1)
+    pos_of = torch.empty_like(order)
+    pos_of[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)
+    b = torch.arange(B, device=idm.device, dtype=torch.int64).unsqueeze(0)
+    src = (b * n_slots + torch.tensor(list(slots), device=idm.device, dtype=torch.int64).unsqueeze(1)).reshape(-1)
+    return key[order], pos_of.reshape(F, B), src[order], torch.bincount(owner, minlength=world_size)
+
+
+def route_local_rows_torch(recv_keys: torch.Tensor, base: torch.Tensor) -> torch.Tensor:
+    return base[recv_keys >> 40] + (recv_keys & ((1 << 40) - 1))
+
+
 class ShardedEmbeddingGroup:
     """ALL row-sharded features of a model behind ONE route per step: the local shards live back to back in
     one [sum V_local, D] buffer, a request is the int64 key (feature << 40 | local_row), the owner turns it
     into a row of the concatenated buffer -> one gather launch, one fused update launch, three all-to-alls
-    (ids, rows, row-gradients) and one host sync per step regardless of the number of sharded tables."""
+    (ids, rows, row-gradients) and one host sync per step regardless of the number of sharded tables.
 
-    def __init__(self, full_tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None):
+    ``route_fn`` / ``rows_fn`` build the send order and the owner-side rows: ``ops.route_build`` /
+    ``ops.route_local_rows`` (HIP) in production, the framework-op statements above in the gloo tests."""
+
+    def __init__(self, full_tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None,
+                 route_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None):
         self.rank, self.world_size = world()
         self.group = group
         self.gather_fn, self.update_fn = gather_fn, update_fn
+        self.route_fn = route_fn or route_build_torch
+        self.rows_fn = rows_fn or route_local_rows_torch
         shards = [shard_table(t, self.rank, self.world_size) for t in full_tables]
         self.global_rows = [t.shape[0] for t in full_tables]
         sizes = [sh.shape[0] for sh in shards]
@@ -153,75 +179,91 @@ class ShardedEmbeddingGroup:
             o += n
         self.base = torch.tensor(base, dtype=torch.int64, device=self.local.device)
         self.state: Optional[torch.Tensor] = None
-        self._route: Optional[Route] = None
         self._rows: Optional[torch.Tensor] = None
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if self.world_size > 1:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+        else:
+            out.copy_(inp)
 
     def lookup(self, ids: Sequence[torch.Tensor], scatter_into=None) -> Optional[torch.Tensor]:
         """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D], or, with
         ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``."""
         W = self.world_size
-        idm = torch.stack([i.reshape(-1).to(torch.int64) for i in ids])  # [F_sh, B]
-        F_sh, B = idm.shape
-        feat = torch.arange(F_sh, device=idm.device, dtype=torch.int64).unsqueeze(1)
-        key = (feat << 40) | torch.div(idm, W, rounding_mode="floor")
-        self._route = Route(torch.remainder(idm, W), key, W, self.group)
-        rk = self._route.recv_payload
-        self._rows = self.base[rk >> 40] + (rk & ((1 << 40) - 1))  # rows of the concatenated local buffer
+        F_sh, B = len(ids), ids[0].numel()
+        if scatter_into is not None:
+            stacked, slots, scatter_fn = scatter_into
+            n_slots = stacked.shape[1]
+        else:
+            slots, n_slots = list(range(F_sh)), F_sh
+        send_keys, pos_of, src_row, send_counts = self.route_fn(ids, W, slots, n_slots)
+        recv_counts = torch.empty_like(send_counts)
+        if W > 1:
+            dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        else:
+            recv_counts.copy_(send_counts)
+        both = torch.stack([send_counts, recv_counts]).tolist()  # the one host sync of the step
+        self._send_counts, self._recv_counts = both[0], both[1]
+        self._pos_of, self._src_row, self._n = pos_of, src_row, F_sh * B
+        recv_keys = torch.empty(sum(self._recv_counts), dtype=torch.int64, device=send_keys.device)
+        self._a2a(recv_keys, send_keys, self._recv_counts, self._send_counts)
+        self._rows = self.rows_fn(recv_keys, self.base)  # rows of the concatenated local buffer
         rows = self.gather_fn(self.local, self._rows)
-        if scatter_into is None:
-            return self._route.return_rows(rows).reshape(F_sh, B, -1)
-        # returned rows arrive in owner order; position of request (f, b) in that order = inverse permutation.
-        # ONE multi-"table" gather writes them straight into their stack slots (no un-permute pass, no index_put).
-        r = self._route
         D = rows.shape[1]
-        back = torch.empty((r.n, D), dtype=rows.dtype, device=rows.device)
-        r._a2a(back, rows.contiguous(), r.send_counts, r.recv_counts)
-        inv = torch.empty_like(r.order)
-        inv[r.order] = torch.arange(r.n, device=inv.device, dtype=inv.dtype)
-        inv = inv.reshape(F_sh, B)
-        stacked, slots, scatter_fn = scatter_into
-        scatter_fn([back] * F_sh, [inv[f] for f in range(F_sh)], stacked, slots)
+        back = torch.empty((self._n, D), dtype=rows.dtype, device=rows.device)
+        self._a2a(back, rows.contiguous(), self._send_counts, self._recv_counts)
+        if scatter_into is None:
+            return back[pos_of.reshape(-1)].reshape(F_sh, B, D)
+        # returned rows arrive in owner order; request (f, b) sits at pos_of[f, b]: ONE multi-"table" gather
+        # writes them straight into their stack slots (no un-permute pass, no index_put)
+        scatter_fn([back] * F_sh, [pos_of[f] for f in range(F_sh)], stacked, slots)
         return None
 
     def backward_update(self, grad: torch.Tensor, from_stacked=None) -> None:
         """``grad`` [F_sh, B, D] in the order of ``lookup``; or ``from_stacked = (dstack [B, F, D], slots,
-        gather_fn)``: the gradient rows are pulled out of dstack already in owner order by one gather launch."""
-        r = self._route
+        gather_fn)``: the gradient rows are pulled out of dstack already in owner order by one gather launch
+        (``src_row`` of the route)."""
         if from_stacked is None:
-            g = r.send_grads(grad.reshape(-1, grad.shape[-1]))
+            D = grad.shape[-1]
+            send = torch.empty((self._n, D), dtype=grad.dtype, device=grad.device)
+            send[self._pos_of.reshape(-1)] = grad.reshape(-1, D)
         else:
             dstack, slots, gather_fn = from_stacked
             B, F, D = dstack.shape
-            F_sh = len(slots)
-            b = torch.arange(B, device=dstack.device, dtype=torch.int64)
-            flat = (b.unsqueeze(0) * F + torch.tensor(slots, device=dstack.device, dtype=torch.int64).unsqueeze(1)).reshape(-1)
-            send = gather_fn(dstack.reshape(B * F, D), flat[r.order])  # [n, D] in owner order
-            g = torch.empty((sum(r.recv_counts), D), dtype=send.dtype, device=send.device)
-            r._a2a(g, send, r.recv_counts, r.send_counts)
+            send = gather_fn(dstack.reshape(B * F, D), self._src_row)  # [n, D] in owner order
+        g = torch.empty((sum(self._recv_counts), D), dtype=send.dtype, device=send.device)
+        self._a2a(g, send, self._recv_counts, self._send_counts)
         self.update_fn(self.local, self.state, self._rows, g)
 
 
 # ------------------------------------------------------------------------------------------------
 # dense gradients
 # ------------------------------------------------------------------------------------------------
+def allreduce_flat_(flat: torch.Tensor, group=None) -> None:
+    """In-place SUM of one flat fp32 bucket across ranks.  On RCCL: reduce-scatter + all-gather, so every xGMI
+    link carries 1/W of the bucket per phase (needs ``numel % W == 0``; callers pad the bucket)."""
+    rank, W = world()
+    if W == 1 or flat.numel() == 0:
+        return
+    n = flat.numel()
+    if dist.get_backend(group) == "nccl" and n % W == 0:
+        shard = torch.empty(n // W, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(shard, flat, group=group)
+        dist.all_gather_into_tensor(flat, shard, group=group)
+    else:
+        dist.all_reduce(flat, group=group)
+
+
 def allreduce_sum_(tensors: Sequence[torch.Tensor], group=None) -> None:
     """Sum a list of tensors across ranks through ONE flat bucket (in place)."""
     rank, W = world()
     if W == 1 or not tensors:
         return
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    n = flat.numel()
-    backend = dist.get_backend(group)
-    if backend == "nccl" and n >= W:
-        pad = (-n) % W
-        if pad:
-            flat = torch.cat([flat, flat.new_zeros(pad)])
-        shard = torch.empty(flat.numel() // W, dtype=flat.dtype, device=flat.device)
-        dist.reduce_scatter_tensor(shard, flat, group=group)  # every xGMI link carries 1/W of the bucket
-        dist.all_gather_into_tensor(flat, shard, group=group)
-        flat = flat[:n]
-    else:
-        dist.all_reduce(flat, group=group)
+    n = sum(t.numel() for t in tensors)
+    flat = torch.zeros((n + W - 1) // W * W, dtype=tensors[0].dtype, device=tensors[0].device)
+    torch.cat([t.reshape(-1) for t in tensors], out=flat[:n])
+    allreduce_flat_(flat, group)
     o = 0
     for t in tensors:
         t.copy_(flat[o:o + t.numel()].reshape(t.shape))
@@ -270,11 +312,13 @@ class DistributedDLRM:
         self.sharded: Dict[str, torch.Tensor] = {}
         self.group_sh: Optional[ShardedEmbeddingGroup] = None
         if names:
-            self.group_sh = ShardedEmbeddingGroup([emb.feature_table[n].table.data for n in names], gather_fn, update_fn, group)
+            self.group_sh = ShardedEmbeddingGroup([emb.feature_table[n].table.data for n in names], gather_fn, update_fn, group,
+                                                  route_fn=ops.route_build, rows_fn=ops.route_local_rows)
             for n, view in zip(names, self.group_sh.views):
                 emb.feature_table[n].table.data = view  # drop the replicated copy; keep a view of the local shard
                 self.sharded[n] = view
         self.sharded_names = names
+        self._bucket: Optional[torch.Tensor] = None
         self.replicated = [n for n in self.body.cat_names if n not in self.sharded]
         dense = [p.data for p in model.parameters() if not p.sparse]
         rep = [emb.feature_table[n].table.data for n in self.replicated]
@@ -358,21 +402,36 @@ class DistributedDLRM:
                 gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
             gs.backward_update(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
                                                    lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
-        # 2. replicated tables: dense [V, D] gradient via the fused backward (SGD, lr = -1, zeroed buffer)
+        # 2 + 3. ONE persistent flat bucket [MLP / head gradients | dense [V, D] gradients of the replicated
+        #    tables]: the table part is zeroed by one fill and accumulated by the fused backward (SGD, lr = -1),
+        #    the MLP part is packed by one cat; after the in-place reduction the gradients are VIEWS of the bucket
         rep_tabs = [emb.feature_table[n].table for n in self.replicated]
-        rep_grads = [torch.zeros_like(t.data) for t in rep_tabs]
+        dense = [q for q in model.parameters() if not q.sparse and q.grad is not None]
+        n_dense = sum(q.grad.numel() for q in dense)
+        n_rep = sum(t.data.numel() for t in rep_tabs)
+        n_head = (n_dense + 1 + 63) // 64 * 64  # + one slot for the loss; table gradients start 256-byte aligned
+        total = (n_head + n_rep + 63) // 64 * 64
+        if self._bucket is None or self._bucket.numel() != total:
+            self._bucket = torch.zeros(total, dtype=torch.float32, device=dstack.device)
+        bucket = self._bucket
+        rep_grads, o = [], n_head
+        for t in rep_tabs:
+            rep_grads.append(bucket[o:o + t.data.numel()].view_as(t.data))
+            o += t.data.numel()
         if rep_tabs:
+            bucket[n_head:n_head + n_rep].zero_()
             ops.embedding_gather_backward(rep_grads, None, [x[n] for n in self.replicated], dstack,
                                           [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
-        # 3. one flat bucket for MLP / head gradients and the replicated-table gradients
-        dense = [q for q in model.parameters() if not q.sparse and q.grad is not None]
-        allreduce_sum_([q.grad for q in dense] + rep_grads, self.group)
+        # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
+        torch.cat([q.grad.reshape(-1) for q in dense] + [loss.detach().reshape(1)], out=bucket[:n_dense + 1])
+        allreduce_flat_(bucket, self.group)
+        loss = bucket[n_dense] / self.world_size
+        o = 0
+        for q in dense:
+            q.grad = bucket[o:o + q.data.numel()].view_as(q.data)
+            o += q.data.numel()
         for t, g in zip(rep_tabs, rep_grads):
             t.grad = g
         opt.begin_step(dstack.device)
         ops.dense_optimizer_step_multi(opt, dense + rep_tabs)  # one launch per 64 tensors
-        if self.world_size > 1:
-            l = loss.detach().clone()
-            dist.all_reduce(l, group=self.group)
-            loss = l / self.world_size
         return loss

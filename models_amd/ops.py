@@ -713,3 +713,54 @@ def topk_metrics(labels_sorted: torch.Tensor, k: int, relevant_counts: Optional[
     check(lib.mh_topk_metrics(_ptr(labels_sorted), labels_sorted.stride(0), _ptr(relevant_counts), B, k, _ptr(out),
                               _stream()), "mh_topk_metrics")
     return out
+
+
+# --- multi-GPU: row-sharded embedding exchange --------------------------------------------------
+def route_build(ids: Sequence[torch.Tensor], world_size: int, slots: Optional[Sequence[int]] = None,
+                n_slots: Optional[int] = None):
+    """Send order of the row-sharded lookup (``mh_route_build``): stable counting sort of the F*B requests
+    by owner = id % W.  Returns ``(send_keys [n] int64, pos_of [F, B] int64, src_row [n] int64,
+    counts [W] int64)``; see include/merlin_hip.h for the meaning of each."""
+    lib = _lib.load()
+    F = len(ids)
+    if F == 0:
+        raise ValueError("route_build: need at least one id column")
+    idt = _ids_dtype(ids[0], "ids[0]")
+    B = ids[0].numel()
+    flat = []
+    for f, i in enumerate(ids):
+        _dev(i, f"ids[{f}]")
+        if _ids_dtype(i, f"ids[{f}]") != idt:
+            raise TypeError("route_build: all ids must share one dtype")
+        i = i.reshape(-1)
+        if i.shape[0] != B or not i.is_contiguous():
+            raise ValueError(f"ids[{f}] must be contiguous with {B} entries")
+        flat.append(i)
+    slots = list(range(F)) if slots is None else [int(s_) for s_ in slots]
+    n_slots = (max(slots) + 1) if n_slots is None else int(n_slots)
+    dev = flat[0].device
+    n = F * B
+    send_keys = torch.empty(n, dtype=torch.int64, device=dev)
+    pos_of = torch.empty((F, B), dtype=torch.int64, device=dev)
+    src_row = torch.empty(n, dtype=torch.int64, device=dev)
+    counts = torch.empty(world_size, dtype=torch.int64, device=dev)
+    nbytes = lib.mh_route_workspace_bytes(n, world_size)
+    if nbytes < 0:
+        raise _lib.MerlinHipError("mh_route_workspace_bytes failed")
+    ws = _workspace(nbytes, dev, "route")
+    check(lib.mh_route_build(_host_ptr_array([i.data_ptr() for i in flat]), idt, F, B, world_size,
+                             (C.c_int32 * F)(*slots), n_slots, _ptr(send_keys), _ptr(pos_of), _ptr(src_row),
+                             _ptr(counts), _ptr(ws), ws.numel(), _stream()), "mh_route_build")
+    return send_keys, pos_of, src_row, counts
+
+
+def route_local_rows(recv_keys: torch.Tensor, base: torch.Tensor) -> torch.Tensor:
+    """rows[i] = base[key >> 40] + (key & (2^40 - 1)) (``mh_route_local_rows``)."""
+    lib = _lib.load()
+    _dev(recv_keys, "recv_keys", torch.int64)
+    _dev(base, "base", torch.int64)
+    rows = torch.empty_like(recv_keys)
+    if recv_keys.numel():
+        check(lib.mh_route_local_rows(_ptr(recv_keys), recv_keys.numel(), _ptr(base), base.numel(), _ptr(rows),
+                                      _stream()), "mh_route_local_rows")
+    return rows
