@@ -181,13 +181,18 @@ class ShardedEmbeddingGroup:
         self.state: Optional[torch.Tensor] = None
         self._rows: Optional[torch.Tensor] = None
 
-    def _a2a(self, out, inp, out_splits, in_splits):
+    def _a2a(self, out, inp, out_splits, in_splits, async_op: bool = False):
+        """Returns a work handle (``.wait()`` orders the CURRENT stream after the exchange) or None."""
         if self.world_size > 1:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
-        else:
-            out.copy_(inp)
+            return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
+        out.copy_(inp)
+        return None
 
     def lookup(self, ids: Sequence[torch.Tensor], scatter_into=None) -> Optional[torch.Tensor]:
+        self.lookup_begin(ids, scatter_into)
+        return self.lookup_end()
+
+    def lookup_begin(self, ids: Sequence[torch.Tensor], scatter_into=None) -> None:
         """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D], or, with
         ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``."""
         W = self.world_size
@@ -212,18 +217,33 @@ class ShardedEmbeddingGroup:
         rows = self.gather_fn(self.local, self._rows)
         D = rows.shape[1]
         back = torch.empty((self._n, D), dtype=rows.dtype, device=rows.device)
-        self._a2a(back, rows.contiguous(), self._send_counts, self._recv_counts)
+        rows = rows.contiguous()
+        # the row exchange runs on RCCL's stream: whatever the caller enqueues before lookup_end() overlaps it
+        work = self._a2a(back, rows, self._send_counts, self._recv_counts, async_op=True)
+        self._pending_lookup = (work, back, rows, scatter_into, F_sh, B)
+
+    def lookup_end(self) -> Optional[torch.Tensor]:
+        work, back, _rows_alive, scatter_into, F_sh, B = self._pending_lookup
+        self._pending_lookup = None
+        if work is not None:
+            work.wait()
+        pos_of, D = self._pos_of, back.shape[1]
         if scatter_into is None:
             return back[pos_of.reshape(-1)].reshape(F_sh, B, D)
+        stacked, slots, scatter_fn = scatter_into
         # returned rows arrive in owner order; request (f, b) sits at pos_of[f, b]: ONE multi-"table" gather
         # writes them straight into their stack slots (no un-permute pass, no index_put)
         scatter_fn([back] * F_sh, [pos_of[f] for f in range(F_sh)], stacked, slots)
         return None
 
     def backward_update(self, grad: torch.Tensor, from_stacked=None) -> None:
+        self.backward_begin(grad, from_stacked)
+        self.backward_end()
+
+    def backward_begin(self, grad: torch.Tensor, from_stacked=None) -> None:
         """``grad`` [F_sh, B, D] in the order of ``lookup``; or ``from_stacked = (dstack [B, F, D], slots,
         gather_fn)``: the gradient rows are pulled out of dstack already in owner order by one gather launch
-        (``src_row`` of the route)."""
+        (``src_row`` of the route).  Starts the gradient exchange; ``backward_end`` applies the fused update."""
         if from_stacked is None:
             D = grad.shape[-1]
             send = torch.empty((self._n, D), dtype=grad.dtype, device=grad.device)
@@ -233,26 +253,35 @@ class ShardedEmbeddingGroup:
             B, F, D = dstack.shape
             send = gather_fn(dstack.reshape(B * F, D), self._src_row)  # [n, D] in owner order
         g = torch.empty((sum(self._recv_counts), D), dtype=send.dtype, device=send.device)
-        self._a2a(g, send, self._recv_counts, self._send_counts)
+        work = self._a2a(g, send, self._recv_counts, self._send_counts, async_op=True)
+        self._pending_bwd = (work, g, send)
+
+    def backward_end(self) -> None:
+        work, g, _send_alive = self._pending_bwd
+        self._pending_bwd = None
+        if work is not None:
+            work.wait()
         self.update_fn(self.local, self.state, self._rows, g)
 
 
 # ------------------------------------------------------------------------------------------------
 # dense gradients
 # ------------------------------------------------------------------------------------------------
-def allreduce_flat_(flat: torch.Tensor, group=None) -> None:
+def allreduce_flat_(flat: torch.Tensor, group=None, async_op: bool = False):
     """In-place SUM of one flat fp32 bucket across ranks.  On RCCL: reduce-scatter + all-gather, so every xGMI
-    link carries 1/W of the bucket per phase (needs ``numel % W == 0``; callers pad the bucket)."""
+    link carries 1/W of the bucket per phase (needs ``numel % W == 0``; callers pad the bucket).
+    ``async_op``: returns the work handles (wait on all of them before reading ``flat``)."""
     rank, W = world()
     if W == 1 or flat.numel() == 0:
-        return
+        return []
     n = flat.numel()
     if dist.get_backend(group) == "nccl" and n % W == 0:
         shard = torch.empty(n // W, dtype=flat.dtype, device=flat.device)
-        dist.reduce_scatter_tensor(shard, flat, group=group)
-        dist.all_gather_into_tensor(flat, shard, group=group)
+        works = [dist.reduce_scatter_tensor(shard, flat, group=group, async_op=async_op),
+                 dist.all_gather_into_tensor(flat, shard, group=group, async_op=async_op)]
     else:
-        dist.all_reduce(flat, group=group)
+        works = [dist.all_reduce(flat, group=group, async_op=async_op)]
+    return [w for w in works if w is not None] if async_op else []
 
 
 def allreduce_sum_(tensors: Sequence[torch.Tensor], group=None) -> None:
@@ -339,8 +368,8 @@ class DistributedDLRM:
             def scatter_fn(tabs, idx, out, slots):
                 ops.embedding_gather(tabs, idx, out=out, out_slot=slots)
 
-            self.group_sh.lookup([inputs[n] for n in self.sharded_names],
-                                 scatter_into=(stacked, [body.slots[n] for n in self.sharded_names], scatter_fn))
+            self.group_sh.lookup_begin([inputs[n] for n in self.sharded_names],
+                                       scatter_into=(stacked, [body.slots[n] for n in self.sharded_names], scatter_fn))
         x = body.continuous(inputs)
         layers = body.bottom_block.layers
         for layer in layers[:-1]:
@@ -352,6 +381,8 @@ class DistributedDLRM:
             ops.embedding_gather([emb.feature_table[n].table.data for n in self.replicated],
                                  [inputs[n] for n in self.replicated], out=stacked,
                                  out_slot=[body.slots[n] for n in self.replicated])
+        if self.group_sh is not None:
+            self.group_sh.lookup_end()  # rows are in: scatter them into their stack slots
         emb._last = {n: inputs[n] for n in body.cat_names}
         body._stacked = stacked
         body._fused = False  # the sharded path materialises the stacked tensor
@@ -395,13 +426,14 @@ class DistributedDLRM:
         body.embeddings._pending = None
         D = body.dim
         emb = body.embeddings
-        # 1. sharded tables: route the gradient rows to their owners, fused update there
+        # 1. sharded tables: route the gradient rows to their owners (fused update there, in step 3)
         if self.group_sh is not None:
             gs = self.group_sh
             if opt.name == "adagrad" and gs.state is None:
                 gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
-            gs.backward_update(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
-                                                   lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
+            # starts the gradient all-to-all; it overlaps the replicated-table gradient pass below
+            gs.backward_begin(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
+                                                  lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
         # 2 + 3. ONE persistent flat bucket [MLP / head gradients | dense [V, D] gradients of the replicated
         #    tables]: the table part is zeroed by one fill and accumulated by the fused backward (SGD, lr = -1),
         #    the MLP part is packed by one cat; after the in-place reduction the gradients are VIEWS of the bucket
@@ -424,7 +456,11 @@ class DistributedDLRM:
                                           [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
         # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
         torch.cat([q.grad.reshape(-1) for q in dense] + [loss.detach().reshape(1)], out=bucket[:n_dense + 1])
-        allreduce_flat_(bucket, self.group)
+        works = allreduce_flat_(bucket, self.group, async_op=True)
+        if self.group_sh is not None:
+            self.group_sh.backward_end()  # fused update of the local shards overlaps the bucket reduction
+        for w in works:
+            w.wait()
         loss = bucket[n_dense] / self.world_size
         o = 0
         for q in dense:
