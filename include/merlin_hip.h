@@ -94,6 +94,19 @@ int32_t mh_embedding_bag_fwd(const float* table, int64_t rows, const void* value
                              int32_t combiner, float* out, int64_t out_row_stride,
                              mh_stream_t stream);
 
+/* Backward of the two list lookups (ragged CSR above, dense [B, L] below) with the optimizer fused in, as
+ * in mh_embedding_gather_bwd: the gradient of `tf.nn.safe_embedding_lookup_sparse` /
+ * `process_str_sequence_combiner` w.r.t. the table is an IndexedSlices over the nnz values with rows
+ * scale(b) * grad[b], scale = 1 | 1/kept | 1/sqrt(kept) for sum | mean | sqrtn (kept = non-pruned ids of
+ * bag b; every position for a dense list).  Pruned (< 0) and out-of-range ids receive no update.
+ * offsets == NULL selects the dense list of length L (nnz must equal B*L).  nnz < 2^26. */
+int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D);
+int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t rows, const void* values,
+                             int64_t nnz, const void* offsets, int64_t L, int32_t ids_dtype, int64_t B, int32_t D,
+                             int32_t combiner, const float* grad, int64_t grad_row_stride, int32_t optimizer,
+                             float lr, float eps, float beta1, float beta2, const float* lr_device,
+                             void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+
 /* Dense fixed-length list [B, L] with a string combiner over axis 1 (mean / sum):
  * process_str_sequence_combiner (inputs/embedding.py:1556-1587): every position counts
  * (id 0 is NOT padding-aware). */

@@ -271,6 +271,67 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     return true;
 }
 
+
+// ---- ragged / list lookups: backward = one-hot backward over the nnz values ------------------------------
+// d table[values[j]] += grad[bag(j)] / div(bag(j))   with div = 1 | kept | sqrt(kept) (sum | mean | sqrtn).
+// bag_scale_kernel: one wave per bag counts the kept (non-negative) ids; bag_expand_kernel writes the scaled
+// gradient row of every value, which then goes through the sort / segment-reduce / fused-optimizer pipeline
+// above with B := nnz, F := 1.
+template <typename IdT>
+__global__ __launch_bounds__(256) void bag_scale_kernel(const IdT* __restrict__ values,
+                                                        const IdT* __restrict__ offsets, int64_t L, int64_t B,
+                                                        int combiner, float* __restrict__ scale) {
+    const int64_t bag = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bag >= B) return;
+    const int lane = threadIdx.x & 63;
+    int64_t kept;
+    if (offsets) {  // safe_embedding_lookup_sparse: negative ids are pruned and not counted
+        const int64_t beg = (int64_t)offsets[bag], end = (int64_t)offsets[bag + 1];
+        int cnt = 0;
+        for (int64_t p = beg + lane; p < end; p += 64) cnt += (values[p] >= 0) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        kept = cnt;
+    } else {
+        kept = L;  // dense list: every position counts
+    }
+    if (lane == 0) {
+        // the DIVISOR of the forward (sum / n, sum / sqrt(n)): the backward divides too, like the gradient of
+        // div_no_nan in the reference graph (a bag with nothing kept has no value that receives an update)
+        float dv = 1.f;
+        if (combiner == MH_COMBINER_MEAN && kept > 0) dv = (float)kept;
+        if (combiner == MH_COMBINER_SQRTN && kept > 0) dv = sqrtf((float)kept);
+        scale[bag] = dv;
+    }
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void bag_expand_kernel(const IdT* __restrict__ offsets, int64_t L, int64_t B,
+                                                         int64_t nnz, int LPR, const float* __restrict__ scale,
+                                                         const float* __restrict__ grad, int64_t ldg,
+                                                         float* __restrict__ gexp) {
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    if (gi >= groups) return;
+    for (int64_t j = (int64_t)blockIdx.x * groups + gi; j < nnz; j += (int64_t)gridDim.x * groups) {
+        int64_t bag;
+        if (offsets) {  // last bag whose offset is <= j (empty bags share an offset with their successor)
+            int64_t lo = 0, hi = B;  // invariant: offsets[lo] <= j < offsets[hi]
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)offsets[mid] <= j) lo = mid; else hi = mid;
+            }
+            bag = lo;
+        } else {
+            bag = j / L;
+        }
+        const float dv = scale[bag];
+        const f32x4 g = *reinterpret_cast<const f32x4*>(grad + bag * ldg + c4 * 4);
+        *reinterpret_cast<f32x4*>(gexp + j * (int64_t)(LPR * 4) + c4 * 4) = g / dv;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -387,5 +448,67 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;
 }
+
+int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D) {
+    if (B <= 0 || nnz <= 0 || D <= 0) return 0;
+    const int64_t inner = mh_embedding_bwd_workspace_bytes(nnz, 1, D);
+    if (inner < 0) return -1;
+    return (int64_t)align_up((size_t)B * sizeof(float), 256) + (int64_t)align_up((size_t)nnz * D * sizeof(float), 256) + inner;
+}
+
+int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t rows, const void* values,
+                             int64_t nnz, const void* offsets, int64_t L, int32_t ids_dtype, int64_t B, int32_t D,
+                             int32_t combiner, const float* grad, int64_t grad_row_stride, int32_t optimizer, float lr,
+                             float eps, float beta1, float beta2, const float* lr_device, void* workspace,
+                             int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(table && grad, "mh_embedding_bag_bwd: null argument");
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_bag_bwd: bad ids_dtype");
+    MH_REQUIRE(combiner >= MH_COMBINER_SUM && combiner <= MH_COMBINER_SQRTN, "mh_embedding_bag_bwd: bad combiner %d", combiner);
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_bag_bwd: D=%d must be a multiple of 4 in [4,1024]", D);
+    MH_REQUIRE(grad_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0,
+               "mh_embedding_bag_bwd: grad must be 16-byte aligned with grad_row_stride %% 4 == 0");
+    MH_REQUIRE(offsets || L >= 1, "mh_embedding_bag_bwd: need CSR offsets or a list length L >= 1");
+    if (B <= 0 || nnz <= 0) return MH_OK;
+    MH_REQUIRE(values && workspace, "mh_embedding_bag_bwd: null values / workspace");
+    MH_REQUIRE(offsets || nnz == B * L, "mh_embedding_bag_bwd: dense list needs nnz == B*L");
+    MH_REQUIRE(nnz < (1ll << 26), "mh_embedding_bag_bwd: nnz must be < 2^26");
+    const int64_t need = mh_embedding_bag_bwd_workspace_bytes(B, nnz, D);
+    MH_REQUIRE(need >= 0 && workspace_bytes >= need, "mh_embedding_bag_bwd: workspace too small (%lld < %lld)",
+               (long long)workspace_bytes, (long long)need);
+    hipStream_t s = mh_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* scale = reinterpret_cast<float*>(ws);
+    ws += align_up((size_t)B * sizeof(float), 256);
+    float* gexp = reinterpret_cast<float*>(ws);
+    ws += align_up((size_t)nnz * D * sizeof(float), 256);
+    const int LPR = D / 4;
+    const int groups = 256 / LPR;
+    const dim3 gs((unsigned)mh_ceil_div(B, 4));
+    int64_t nb = mh_ceil_div(nnz, groups);
+    const int64_t cap = (int64_t)mh_num_cus() * 16;
+    if (nb > cap) nb = cap;
+    if (ids_dtype == MH_I32) {
+        hipLaunchKernelGGL((bag_scale_kernel<int32_t>), gs, dim3(256), 0, s, (const int32_t*)values,
+                           (const int32_t*)offsets, L, B, combiner, scale);
+        hipLaunchKernelGGL((bag_expand_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int32_t*)offsets, L,
+                           B, nnz, LPR, scale, grad, grad_row_stride, gexp);
+    } else {
+        hipLaunchKernelGGL((bag_scale_kernel<int64_t>), gs, dim3(256), 0, s, (const int64_t*)values,
+                           (const int64_t*)offsets, L, B, combiner, scale);
+        hipLaunchKernelGGL((bag_expand_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int64_t*)offsets, L,
+                           B, nnz, LPR, scale, grad, grad_row_stride, gexp);
+    }
+    MH_CHECK_LAUNCH("mh_embedding_bag_bwd");
+    float* tabs[1] = {table};
+    float* st1[1] = {state};
+    float* st2[1] = {state2};
+    const int64_t trows[1] = {rows};
+    const void* idp[1] = {values};
+    const int64_t off[1] = {0};
+    return mh_embedding_gather_bwd(tabs, state ? st1 : nullptr, trows, idp, ids_dtype, nnz, 1, D, gexp, D, off, optimizer,
+                                   lr, eps, state2 ? st2 : nullptr, beta1, beta2, lr_device, ws,
+                                   workspace_bytes - (ws - static_cast<char*>(workspace)), stream);
+}
+
 
 }  // extern "C"

@@ -213,9 +213,30 @@ class EmbeddingsBlock(ParallelBlock):
         grad, offsets = pending
         self._pending = None
         names = [n for n in offsets if n in self._last and self.feature_table[n].table.trainable]
-        for n in names:
-            if not self._is_onehot(self._last[n]):
-                raise NotImplementedError("backward of list / ragged lookups is not on the HIP path yet")
+        lists = [n for n in names if not self._is_onehot(self._last[n])]
+        names = [n for n in names if n not in lists]
+
+        def _states(t):
+            if opt.name == "adagrad":
+                if "accumulator" not in t.state:
+                    t.state["accumulator"] = torch.full_like(t.data, opt.initial_accumulator_value)
+                return t.state["accumulator"], None
+            if opt.name == "adam":
+                if "m" not in t.state:
+                    t.state["m"], t.state["v"] = torch.zeros_like(t.data), torch.zeros_like(t.data)
+                return t.state["m"], t.state["v"]
+            return None, None
+
+        # ragged / dense-list features: gradient rows scale with the combiner, one fused launch chain each
+        g2 = grad.reshape(grad.shape[0], -1)
+        for n in lists:
+            ft = self.feature_table[n]
+            x = self._last[n]
+            st, st2 = _states(ft.table)
+            gcol = g2[:, offsets[n]:offsets[n] + ft.dim]
+            vals, offs = (x.values, x.offsets) if isinstance(x, Ragged) else (x, None)
+            ops.embedding_bag_backward(ft.table.data, st, vals, offs, gcol, ft.sequence_combiner, opt.name,
+                                       opt.learning_rate, opt.epsilon, st2, opt.beta_1, opt.beta_2, opt.lr_device)
         for d in sorted({self.feature_table[n].dim for n in names}):
             grp = [n for n in names if self.feature_table[n].dim == d]
             tabs = [self.feature_table[n].table for n in grp]

@@ -413,6 +413,61 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
         )
 
 
+def embedding_bag_backward(table: torch.Tensor, state: Optional[torch.Tensor], values: torch.Tensor,
+                           offsets: Optional[torch.Tensor], grad: torch.Tensor, combiner: str = "mean",
+                           optimizer: str = "sgd", lr: float = 0.01, eps: float = 1e-7,
+                           state2: Optional[torch.Tensor] = None, beta1: float = 0.9, beta2: float = 0.999,
+                           lr_device: Optional[torch.Tensor] = None) -> None:
+    """Fused backward + sparse optimizer step of ``embedding_bag`` (``offsets`` given, CSR) or
+    ``embedding_dense_list`` (``offsets=None``, ``values`` is ``[B, L]``).  ``grad`` is ``[B, D]`` with unit
+    inner stride (a column slice of a wider buffer is fine)."""
+    lib = _lib.load()
+    _dev(table, "table", torch.float32)
+    _dev(values, "values")
+    _dev(grad, "grad", torch.float32)
+    idt = _ids_dtype(values, "values")
+    if combiner not in COMBINER:
+        raise ValueError(f"combiner must be one of {sorted(COMBINER)}, got {combiner!r}")
+    D = table.shape[1]
+    if grad.dim() != 2 or grad.shape[1] != D or grad.stride(1) != 1:
+        raise ValueError(f"grad must be [B, {D}] with unit inner stride")
+    B = grad.shape[0]
+    L = 0
+    if offsets is None:
+        if values.dim() == 3 and values.shape[-1] == 1:
+            values = values.squeeze(-1)
+        if values.dim() != 2 or values.shape[0] != B:
+            raise ValueError("dense list values must be [B, L]")
+        L = values.shape[1]
+    else:
+        _dev(offsets, "offsets")
+        if offsets.dtype != values.dtype:
+            raise TypeError("offsets and values must share one integer dtype")
+        offsets = offsets.reshape(-1).contiguous()
+        if offsets.shape[0] != B + 1:
+            raise ValueError(f"offsets must have B + 1 = {B + 1} entries")
+    values = values.reshape(-1).contiguous()
+    nnz = values.shape[0]
+    if B == 0 or nnz == 0:
+        return
+    if optimizer in ("adagrad", "adam", "lazy_adam") and state is None:
+        raise ValueError(f"{optimizer} needs a state tensor")
+    if optimizer in ("adam", "lazy_adam") and state2 is None:
+        raise ValueError("adam needs a second-moment tensor")
+    nbytes = lib.mh_embedding_bag_bwd_workspace_bytes(B, nnz, D)
+    if nbytes < 0:
+        raise _lib.MerlinHipError("mh_embedding_bag_bwd_workspace_bytes failed")
+    ws = _workspace(nbytes, grad.device, "embedding_bag_bwd")
+    with _timed("embedding_bag_bwd"):
+        check(
+            lib.mh_embedding_bag_bwd(_ptr(table), _ptr(state), _ptr(state2), table.shape[0], _ptr(values), nnz,
+                                     _ptr(offsets), L, idt, B, D, COMBINER[combiner], _ptr(grad), grad.stride(0),
+                                     _lib.OPT[optimizer], lr, eps, beta1, beta2, _ptr(lr_device), _ptr(ws), ws.numel(),
+                                     _stream()),
+            "mh_embedding_bag_bwd",
+        )
+
+
 def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
     """Mean binary cross-entropy of probabilities ``p`` (Keras semantics) and d(mean)/d(logit)."""
     lib = _lib.load()

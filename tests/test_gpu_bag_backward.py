@@ -1,0 +1,116 @@
+"""Backward of the ragged / dense-list lookups (mh_embedding_bag_bwd) against oracle.embedding_bag_grad."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def _csr(rng, B, V, max_len, neg_frac=0.05, oob_frac=0.02):
+    lens = rng.integers(0, max_len + 1, size=B)
+    lens[B // 3] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = rng.integers(0, V, size=int(offsets[-1])).astype(np.int64)
+    values[rng.random(values.shape) < neg_frac] = -1
+    values[rng.random(values.shape) < oob_frac] = V + 7
+    return values, offsets
+
+
+@pytest.mark.parametrize("combiner", ["sum", "mean", "sqrtn"])
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("D", [8, 64])
+def test_bag_backward_dense_gradient(combiner, dtype, D):
+    from models_amd import ops
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(D + len(combiner))
+    V, B = 300, 257
+    values, offsets = _csr(rng, B, V, 9)
+    grad = rng.standard_normal((B, D)).astype(np.float32)
+    want = O.embedding_bag_grad(V, values, offsets, grad, combiner)
+    dW = torch.zeros(V, D, device=dev)
+    ops.embedding_bag_backward(dW, None, torch.from_numpy(values).to(dtype).to(dev),
+                               torch.from_numpy(offsets).to(dtype).to(dev), torch.from_numpy(grad).to(dev),
+                               combiner, "sgd", -1.0)
+    np.testing.assert_allclose(dW.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_bag_backward_strided_grad_adagrad_and_giant_bag():
+    from models_amd import ops
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(11)
+    V, B, D = 64, 5, 16
+    lens = np.array([0, 40000, 1, 0, 3])
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = rng.integers(0, V, size=int(offsets[-1])).astype(np.int64)
+    wide = rng.standard_normal((B, 3 * D)).astype(np.float32)  # the feature's gradient is a column slice
+    g = torch.from_numpy(wide).to(dev)
+    W0 = rng.standard_normal((V, D)).astype(np.float32)
+    W = torch.from_numpy(W0.copy()).to(dev)
+    acc = torch.full((V, D), 0.1, device=dev)
+    ops.embedding_bag_backward(W, acc, torch.from_numpy(values).to(dev), torch.from_numpy(offsets).to(dev),
+                               g[:, D:2 * D], "mean", "adagrad", 0.05, 1e-7)
+    dW = O.embedding_bag_grad(V, values, offsets, wide[:, D:2 * D], "mean")
+    a = np.full((V, D), 0.1, np.float32)
+    w = W0.copy()
+    touched = np.zeros(V, bool)
+    touched[np.unique(values)] = True
+    a[touched] += dW[touched] ** 2
+    w[touched] -= 0.05 * dW[touched] / (np.sqrt(a[touched]) + 1e-7)
+    np.testing.assert_allclose(acc.cpu().numpy(), a, rtol=2e-4, atol=1e-5)  # 40000-term sums: order differs
+    np.testing.assert_allclose(W.cpu().numpy(), w, rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("combiner", ["sum", "mean"])
+def test_dense_list_backward(combiner):
+    from models_amd import ops
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    V, B, L, D = 100, 64, 7, 32
+    ids = rng.integers(0, V, size=(B, L)).astype(np.int64)
+    grad = rng.standard_normal((B, D)).astype(np.float32)
+    dW = torch.zeros(V, D, device=dev)
+    ops.embedding_bag_backward(dW, None, torch.from_numpy(ids).to(dev), None, torch.from_numpy(grad).to(dev),
+                               combiner, "sgd", -1.0)
+    np.testing.assert_allclose(dW.cpu().numpy(), O.embedding_bag_grad(V, ids, None, grad, combiner), rtol=1e-5, atol=1e-6)
+
+
+def test_embeddings_block_trains_ragged_feature():
+    """EmbeddingsBlock.apply_sparse routes a Ragged feature through the bag backward and a one-hot feature
+    through the gather backward in the same step."""
+    import models_amd as mm
+    from models_amd import optim
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(9)
+    B, D = 33, 8
+    schema = mm.Schema([mm.schema.categorical("a", 50), mm.schema.categorical("l", 40)])
+    emb = mm.Embeddings(schema, dim=D, sequence_combiner="mean", device=dev)
+    values, offsets = _csr(rng, B, 40, 5, neg_frac=0.0, oob_frac=0.0)
+    a = rng.integers(0, 50, size=B).astype(np.int64)
+    inputs = {"a": torch.from_numpy(a).to(dev),
+              "l": mm.Ragged(torch.from_numpy(values).to(dev), torch.from_numpy(offsets).to(dev))}
+    out = emb(inputs)
+    Wa0, Wl0 = emb.feature_table["a"].table.numpy().copy(), emb.feature_table["l"].table.numpy().copy()
+    np.testing.assert_allclose(out["l"].cpu().numpy(), O.embedding_bag(Wl0, values, offsets, "mean"), rtol=1e-5, atol=1e-6)
+    grad = rng.standard_normal((B, 2, D)).astype(np.float32)
+    emb.set_pending_grad(torch.from_numpy(grad).to(dev), {"a": 0, "l": D})
+    opt = optim.SGD(learning_rate=0.5)
+    emb.apply_sparse(opt)
+    dWa = np.zeros_like(Wa0)
+    np.add.at(dWa, a, grad[:, 0])
+    np.testing.assert_allclose(emb.feature_table["a"].table.numpy(), Wa0 - 0.5 * dWa, rtol=1e-5, atol=1e-6)
+    dWl = O.embedding_bag_grad(40, values, offsets, grad[:, 1], "mean")
+    np.testing.assert_allclose(emb.feature_table["l"].table.numpy(), Wl0 - 0.5 * dWl, rtol=1e-5, atol=1e-6)

@@ -42,3 +42,51 @@ def test_oracle_dlrm_train_step_matches_torch_autograd():
         np.testing.assert_allclose(tables[n], tt[n].detach().numpy(), atol=1e-5)
     np.testing.assert_allclose(top[0][0], tp[0][0].detach().numpy(), atol=1e-5)
     np.testing.assert_allclose(head[0], th[0].detach().numpy(), atol=1e-5)
+
+
+# ---- list lookups: oracle gradient vs torch autograd (CPU) -------------------------------------------
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("combiner", ["sum", "mean", "sqrtn"])
+def test_embedding_bag_grad_matches_autograd(combiner):
+    import torch
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(3)
+    V, D, B = 50, 8, 17
+    lens = rng.integers(0, 6, size=B)
+    lens[3] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = rng.integers(0, V, size=int(offsets[-1])).astype(np.int64)
+    grad = rng.standard_normal((B, D)).astype(np.float32)
+    W = torch.randn(V, D, requires_grad=True)
+    rows = []
+    for b in range(B):
+        seg = W[torch.from_numpy(values[offsets[b]:offsets[b + 1]])]
+        n = seg.shape[0]
+        r = seg.sum(0)
+        if n and combiner == "mean":
+            r = r / n
+        if n and combiner == "sqrtn":
+            r = r / np.sqrt(np.float32(n))
+        rows.append(r)
+    (torch.stack(rows) * torch.from_numpy(grad)).sum().backward()
+    got = O.embedding_bag_grad(V, values, offsets, grad, combiner)
+    np.testing.assert_allclose(got, W.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # forward of the same oracle agrees with the graph it differentiates
+    np.testing.assert_allclose(O.embedding_bag(W.detach().numpy(), values, offsets, combiner),
+                               torch.stack(rows).detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_embedding_bag_grad_prunes_and_dense_list():
+    from oracle import oracle as O
+
+    grad = np.ones((2, 4), np.float32)
+    # bag 0 = [-1, 2, 99(out of range)], bag 1 = [2, 2]; mean divides by kept (non-negative) ids
+    dW = O.embedding_bag_grad(5, np.array([-1, 2, 99, 2, 2]), np.array([0, 3, 5]), grad, "mean")
+    np.testing.assert_allclose(dW[2], np.full(4, 0.5 + 0.5 + 0.5, np.float32))
+    assert np.count_nonzero(dW) == 4
+    dL = O.embedding_bag_grad(5, np.array([[0, 1, 1], [4, 4, 4]]), None, grad, "mean")
+    np.testing.assert_allclose(dL[1], np.full(4, 2 / 3, np.float32), rtol=1e-6)
+    np.testing.assert_allclose(dL[4], np.full(4, 1.0, np.float32), rtol=1e-6)
