@@ -4,15 +4,17 @@
 // the optimizer row-wise, so the update must see the SUM of a row's gradients exactly once.
 //
 // Pipeline (all on one stream, no host sync):
-//   1. build 64-bit keys (table << 40 | id) + packed (feature, sample) for every (feature, sample)
-//      -- features sharing one table share its key space, so shared rows are updated once;
-//      out-of-range ids get the all-ones sentinel and sort to the end;
-//   2. rocPRIM radix sort of the (key, sample) pairs (46 key bits) -- library plumbing;
-//   3. segmented reduce over fixed chunks of 16 sorted entries: one D/4-lane group per chunk sums
-//      the gradient rows of each run in registers; a run wholly inside the chunk is applied to
-//      the table row directly (exclusive owner, no atomics); a run crossing a chunk boundary adds
-//      its piece to carry[home chunk] (home = chunk holding the run's first entry, found by a
-//      binary search for continuing runs) -- long runs of hot ids are pre-summed 16:1;
+//   1. build COMPACT keys: key = first_row[table] + id, i.e. the row number in the concatenation of the
+//      distinct tables (features sharing one table share its key range, so shared rows are updated once),
+//      + the packed (feature, sample) of every entry; out-of-range ids get the all-ones sentinel and sort
+//      to the end.  Keys are 32-bit whenever the tables hold < 2^32 - 1 rows together (64-bit otherwise);
+//   2. ONE stable rocPRIM radix sort of the (key, sample) pairs over ceil(log2(total rows + 1)) bits --
+//      23 bits = 3 Onesweep passes for the 26 Criteo tables of the headline config (library plumbing);
+//   3. segmented reduce over PIECES (a run cut at every 16th sorted index): one D/4-lane group per piece
+//      sums its gradient rows in registers; a piece that is a whole run is applied to the table row
+//      directly (exclusive owner, no atomics); the pieces of a run crossing a chunk boundary add to
+//      carry[home chunk] (home = chunk holding the run's first entry, from a max-scan of chunk flags)
+//      -- long runs of hot ids are pre-summed 16:1 in registers and 16:1 again through LDS;
 //   4. each chunk that is home to a crossing run applies the carried sum.
 // HBM traffic: grad rows read once (random), table (+state) rows read+written once per UNIQUE id.
 #include <cstring>
@@ -24,9 +26,11 @@
 namespace {
 
 constexpr int CHUNK = 16;
-constexpr uint64_t SENTINEL = ~0ull;
-constexpr int KEY_BITS = 46;
-constexpr uint64_t ID_MASK = (1ull << 40) - 1;
+
+template <typename KeyT>
+struct KeyTraits {
+    static constexpr KeyT sentinel = (KeyT)~(KeyT)0;
+};
 
 struct BwdArgs {
     float* table[MH_MAX_FEATURES];
@@ -35,19 +39,21 @@ struct BwdArgs {
     const void* ids[MH_MAX_FEATURES];
     int64_t rows[MH_MAX_FEATURES];
     int64_t offset[MH_MAX_FEATURES];  // float offset of the feature inside a grad row
-    int32_t tid[MH_MAX_FEATURES];  // first feature sharing the same table (shared embeddings)
+    int64_t first[MH_MAX_FEATURES];   // first compact key of the feature's table (shared tables share it)
 };
 
-template <typename IdT>
-__global__ __launch_bounds__(256) void build_keys_kernel(const BwdArgs a, int64_t B, int F,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+template <typename IdT, typename KeyT>
+__global__ __launch_bounds__(256) void build_keys_kernel(const BwdArgs a, int64_t B, int F, KeyT* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals,
+                                                        unsigned int* __restrict__ counter) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) *counter = 0u;  // piece counter of step 3 (saves a memset launch)
     if (idx >= B * F) return;
     const int f = (int)(idx / B);
     const int64_t b = idx - (int64_t)f * B;
     const int64_t id = (int64_t) static_cast<const IdT*>(a.ids[f])[b];
     const bool ok = id >= 0 && id < a.rows[f];
-    keys[idx] = ok ? (((uint64_t)a.tid[f] << 40) | (uint64_t)id) : SENTINEL;
+    keys[idx] = ok ? (KeyT)(a.first[f] + id) : KeyTraits<KeyT>::sentinel;
     vals[idx] = ((uint32_t)f << 26) | (uint32_t)b;
 }
 
@@ -56,33 +62,47 @@ struct OptHyper {
     const float* lr_dev;  // optional device scalar overriding lr (graph-replayable bias correction)
 };
 
-__device__ __forceinline__ void apply_update(const BwdArgs& a, uint64_t key, f32x4 g, int D, int c4, int opt,
-                                             const OptHyper& hp) {
+// A table row update in two halves, so that the row (+ optimizer state) loads can be issued BEFORE the gradient
+// rows they do not depend on: load_row() fetches, finish_row() applies the optimizer and stores.
+struct RowRmw {
+    float* w;
+    float* s1;
+    float* s2;
+    f32x4 wv, m, v;
+};
+
+// f: any feature of the run (features sharing a table share pointers and key range); key: compact key.
+__device__ __forceinline__ void load_row(const BwdArgs& a, int f, int64_t key, int D, int c4, int opt, RowRmw& r) {
+    const int64_t off = (key - a.first[f]) * D + c4 * 4;
+    r.w = a.table[f] + off;
+    r.wv = *reinterpret_cast<const f32x4*>(r.w);
+    if (opt != MH_OPT_SGD) {
+        r.s1 = a.state[f] + off;
+        r.m = *reinterpret_cast<const f32x4*>(r.s1);
+    }
+    if (opt == MH_OPT_ADAM) {
+        r.s2 = a.state2[f] + off;
+        r.v = *reinterpret_cast<const f32x4*>(r.s2);
+    }
+}
+
+__device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const OptHyper& hp) {
     const float lr = hp.lr_dev ? *hp.lr_dev : hp.lr;
     const float eps = hp.eps;
-    const int f = (int)(key >> 40);
-    const int64_t id = (int64_t)(key & ID_MASK);
-    float* w = a.table[f] + id * D + c4 * 4;
-    f32x4 wv = *reinterpret_cast<f32x4*>(w);
+    f32x4 wv = r.wv;
     if (opt == MH_OPT_ADAGRAD) {
-        float* st = a.state[f] + id * D + c4 * 4;
-        f32x4 sv = *reinterpret_cast<f32x4*>(st);
-        sv += g * g;
-        *reinterpret_cast<f32x4*>(st) = sv;
+        const f32x4 sv = r.m + g * g;
+        *reinterpret_cast<f32x4*>(r.s1) = sv;
         wv.x -= lr * g.x / (sqrtf(sv.x) + eps);
         wv.y -= lr * g.y / (sqrtf(sv.y) + eps);
         wv.z -= lr * g.z / (sqrtf(sv.z) + eps);
         wv.w -= lr * g.w / (sqrtf(sv.w) + eps);
     } else if (opt == MH_OPT_ADAM) {
         // LazyAdam._resource_apply_sparse (blocks/optimizer.py:412-437): only the touched rows' moments move
-        float* mp = a.state[f] + id * D + c4 * 4;
-        float* vp = a.state2[f] + id * D + c4 * 4;
-        f32x4 m = *reinterpret_cast<f32x4*>(mp);
-        f32x4 v = *reinterpret_cast<f32x4*>(vp);
-        m = m * hp.beta1 + g * (1.f - hp.beta1);
-        v = v * hp.beta2 + (g * g) * (1.f - hp.beta2);
-        *reinterpret_cast<f32x4*>(mp) = m;
-        *reinterpret_cast<f32x4*>(vp) = v;
+        const f32x4 m = r.m * hp.beta1 + g * (1.f - hp.beta1);
+        const f32x4 v = r.v * hp.beta2 + (g * g) * (1.f - hp.beta2);
+        *reinterpret_cast<f32x4*>(r.s1) = m;
+        *reinterpret_cast<f32x4*>(r.s2) = v;
         wv.x -= lr * m.x / (sqrtf(v.x) + eps);
         wv.y -= lr * m.y / (sqrtf(v.y) + eps);
         wv.z -= lr * m.z / (sqrtf(v.z) + eps);
@@ -90,23 +110,16 @@ __device__ __forceinline__ void apply_update(const BwdArgs& a, uint64_t key, f32
     } else {
         wv -= g * lr;
     }
-    *reinterpret_cast<f32x4*>(w) = wv;
+    *reinterpret_cast<f32x4*>(r.w) = wv;
 }
 
-__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ keys, int64_t n, uint64_t key) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 
 // chunk c: v[c] = -1 if its first run continues from the previous chunk AND the whole chunk is that one
 // run (the run's home lies further back), else c.  An inclusive max-scan of v gives lasthome[c] = home
 // chunk of the LAST run of chunk c; the head piece of a continuing chunk c then belongs to lasthome[c-1].
-__global__ __launch_bounds__(256) void chunk_flags_kernel(const uint64_t* __restrict__ keys, int64_t n,
-                                                         int64_t nchunks, int* __restrict__ v) {
+template <typename KeyT>
+__global__ __launch_bounds__(256) void chunk_flags_kernel(const KeyT* __restrict__ keys, int64_t n, int64_t nchunks,
+                                                         int* __restrict__ v) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nchunks) return;
     const int64_t c0 = c * CHUNK;
@@ -116,103 +129,157 @@ __global__ __launch_bounds__(256) void chunk_flags_kernel(const uint64_t* __rest
     v[c] = (cont && whole) ? -1 : (int)c;
 }
 
-// One D/4-lane group per chunk of 16 sorted entries: run sums are formed in registers; a run wholly
-// inside the chunk is applied to its table row directly (exclusive owner, no atomics); a run crossing
-// a chunk boundary adds its piece to carry[home chunk] (home from the scanned chunk flags).
-// The block's keys / packed values are staged in LDS with coalesced loads (one dependent HBM round trip
-// per block instead of two per entry) and gradient rows are fetched four at a time ahead of the sequential
-// run logic: enough memory-level parallelism at ~70 VGPRs (fully batching all 16 rows + the table
-// read-modify-writes needed 250 VGPRs and ran slower -- profiles/r1_notes.md).
-__global__ __launch_bounds__(256) void segment_reduce_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
-                                                                  const uint32_t* __restrict__ vals, int64_t n,
-                                                                  int D, int LPR, const float* __restrict__ grad,
-                                                                  int64_t grad_row_stride, float* __restrict__ carry,
-                                                                  const int* __restrict__ lasthome,
-                                                                  int opt, const OptHyper hp) {
-    __shared__ uint64_t key_s[64 * CHUNK + 2];
-    __shared__ uint32_t val_s[64 * CHUNK];
+// A PIECE is a maximal range of sorted entries with one key inside one chunk of 16 (cuts at run starts and at
+// every 16th index).  piece_list_kernel enumerates the pieces of the valid (non-sentinel) prefix into a
+// compact list -- one 16-byte record {start:32 | len:5 | starts_run:1 | ends_run:1 | feature:6, key} each (one
+// load gives the consumer everything the table-row address needs).  A workgroup walks LIST_TILES tiles of 256
+// entries and bumps the global counter ONCE (same-address atomics retire at ~12 ns each: one bump per 256
+// entries cost 79 us for 1.7M entries); the list is ordered inside a workgroup, unordered across workgroups.
+constexpr int LIST_TILES = 8;
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void piece_list_kernel(const KeyT* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals, int64_t n,
+                                                         ulonglong2* __restrict__ pieces,
+                                                         unsigned int* __restrict__ counter) {
+    constexpr KeyT SENT = KeyTraits<KeyT>::sentinel;
+    __shared__ unsigned int wave_cnt[LIST_TILES][4];
+    __shared__ unsigned int block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint64_t rec[LIST_TILES];
+    KeyT kk[LIST_TILES];
+    unsigned int rank[LIST_TILES];
+#pragma unroll
+    for (int t = 0; t < LIST_TILES; ++t) {
+        const int64_t i = ((int64_t)blockIdx.x * LIST_TILES + t) * 256 + threadIdx.x;
+        const KeyT k = (i < n) ? keys[i] : SENT;
+        const bool valid = k != SENT;
+        const bool run_start = valid && (i == 0 || keys[i - 1] != k);
+        const bool cut = valid && (run_start || (i & (CHUNK - 1)) == 0);
+        const uint64_t cuts = __ballot(cut);
+        const uint64_t valids = __ballot(valid);
+        rec[t] = 0;
+        kk[t] = k;
+        if (cut) {
+            // the piece ends before the next cut of this wave, or with the wave's valid entries (64 | chunk
+            // size, so a wave boundary is always a cut or the end of the valid prefix)
+            const uint64_t later = (lane == 63) ? 0ull : (cuts >> (lane + 1));
+            const int nvalid = __popcll(valids);  // valid entries are a prefix of the wave (sentinels sort last)
+            const int len = later ? (__ffsll((unsigned long long)later)) : (nvalid - lane);
+            const int64_t e = i + len;
+            const bool ends = (e >= n) || (keys[e] != k);
+            rec[t] = (uint64_t)i | ((uint64_t)len << 32) | ((uint64_t)(run_start ? 1 : 0) << 37) |
+                     ((uint64_t)(ends ? 1 : 0) << 38) | ((uint64_t)(vals[i] >> 26) << 39) | (1ull << 63);
+        }
+        rank[t] = __popcll(cuts & lt_mask);
+        if (lane == 0) wave_cnt[t][wave] = __popcll(cuts);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int t = 0; t < LIST_TILES; ++t) tot += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
+        block_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int o = block_base;
+#pragma unroll
+    for (int t = 0; t < LIST_TILES; ++t) {
+        unsigned int before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[t][w];
+        if (rec[t]) pieces[o + before + rank[t]] = make_ulonglong2(rec[t], (uint64_t)kk[t]);
+        o += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
+    }
+}
+
+// One D/4-lane group per piece (grid-stride over the list): the piece's gradient rows are summed in sorted
+// order, four loads in flight; a piece that is a whole run is applied to its table row directly (exclusive
+// owner, no atomics); a piece of a run that crosses a chunk boundary adds its sum to carry[home chunk]
+// (home from the scanned chunk flags).  Every piece is independent, so the random 256-byte read-modify-writes
+// of different rows overlap freely -- tools/exp/rmw_bench.hip measures the same traffic pattern at ~5 TB/s,
+// which the earlier one-group-per-chunk serial walk (2.3 TB/s) could not reach.
+__global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a, const uint32_t* __restrict__ vals,
+                                                                int D, int LPR, const float* __restrict__ grad,
+                                                                int64_t grad_row_stride, float* __restrict__ carry,
+                                                                const int* __restrict__ lasthome,
+                                                                const ulonglong2* __restrict__ pieces,
+                                                                const unsigned int* __restrict__ counter, int opt,
+                                                                const OptHyper hp) {
+    __shared__ f32x4 part_s[256];      // partial sum of every group (one f32x4 per thread)
+    __shared__ uint64_t part_key[64];  // key of a group's partial-run piece, ~0 if it has none
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
-    const int64_t blk0 = (int64_t)blockIdx.x * groups * CHUNK;
-    const int span = groups * CHUNK;
-    for (int t = threadIdx.x; t < span + 2; t += 256) {
-        const int64_t i = blk0 - 1 + t;
-        key_s[t] = (i >= 0 && i < n) ? keys[i] : SENTINEL;
-    }
-    for (int t = threadIdx.x; t < span; t += 256) {
-        const int64_t i = blk0 + t;
-        val_s[t] = (i < n) ? vals[i] : 0u;
-    }
-    __syncthreads();
-    if (gi >= groups) return;
-    const int64_t chunk = (int64_t)blockIdx.x * groups + gi;
-    const int64_t c0 = chunk * CHUNK;
-    if (c0 >= n) return;
-    const int cnt_all = (int)(((c0 + CHUNK < n) ? c0 + CHUNK : n) - c0);
-    const uint64_t* kk = key_s + 1 + gi * CHUNK;  // kk[-1]: key before the chunk, kk[cnt_all]: key after
-    const uint32_t* vv = val_s + gi * CHUNK;
-    uint64_t cur = kk[0];
-    if (cur == SENTINEL) return;
-    const bool head_cont = (c0 > 0) && (kk[-1] == cur);
-    int run_start = 0;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-
-    auto flush = [&](uint64_t key, int s_, int e_) {
-        const bool starts_here = (s_ > 0) || !head_cont;
-        const bool ends_here = (e_ < cnt_all) || (c0 + e_ == n) || (kk[e_] != key);
-        if (starts_here && ends_here) {
-            apply_update(a, key, acc, D, c4, opt, hp);
-        } else {
-            const int64_t home = starts_here ? chunk : (int64_t)lasthome[chunk - 1];
-            float* cr = carry + home * D + c4 * 4;
-            atomicAdd(cr + 0, acc.x);
-            atomicAdd(cr + 1, acc.y);
-            atomicAdd(cr + 2, acc.z);
-            atomicAdd(cr + 3, acc.w);
-        }
+    const int64_t np = (int64_t)*counter;
+    const int64_t stride = (int64_t)gridDim.x * groups;
+    auto row = [&](uint32_t v) -> f32x4 {
+        const int f = (int)(v >> 26);
+        return *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + a.offset[f] +
+                                               c4 * 4);
     };
-
-    int i = 0;
-    bool done = false;
-    for (int base = 0; base < CHUNK && !done; base += 4) {
-        f32x4 r[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int u = base + j;
-            r[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < cnt_all && kk[u] != SENTINEL) {
-                const uint32_t v = vv[u];
-                const int f = (int)(v >> 26);
-                r[j] = *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
-                                                       a.offset[f] + c4 * 4);
-            }
+    int64_t base = (int64_t)blockIdx.x * groups;  // block-uniform: the loop carries barriers
+    ulonglong2 next = make_ulonglong2(0ull, ~0ull);
+    if (gi < groups && base + gi < np) next = pieces[base + gi];
+    for (; base < np; base += stride) {
+        const int64_t p = base + gi;
+        const bool active = gi < groups && p < np;
+        const ulonglong2 cur = next;
+        if (gi < groups && p + stride < np) next = pieces[p + stride];  // next record in flight during this piece
+        const uint64_t rec = cur.x, key = cur.y;
+        const int64_t s0 = (int64_t)(rec & 0xffffffffull);
+        const int len = active ? (int)((rec >> 32) & 31) : 0;
+        const bool starts = (rec >> 37) & 1, ends = (rec >> 38) & 1;
+        const int fk = (int)((rec >> 39) & 63);
+        const bool whole = active && starts && ends;
+        const bool partial = active && !whole;
+        RowRmw rr;
+        if (whole) load_row(a, fk, (int64_t)key, D, c4, opt, rr);  // independent of the gradient rows: overlaps them
+        const uint32_t* vv = vals + s0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 4 <= len; i += 4) {
+            const uint32_t v0 = vv[i], v1 = vv[i + 1], v2 = vv[i + 2], v3 = vv[i + 3];
+            const f32x4 r0 = row(v0), r1 = row(v1), r2 = row(v2), r3 = row(v3);
+            acc += r0;
+            acc += r1;
+            acc += r2;
+            acc += r3;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int u = base + j;
-            if (done || u >= cnt_all) continue;
-            const uint64_t k = kk[u];
-            if (k == SENTINEL) {
-                done = true;
-                continue;
-            }
-            if (k != cur) {
-                flush(cur, run_start, u);
-                acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                cur = k;
-                run_start = u;
-            }
-            acc += r[j];
-            i = u + 1;
+        if (i + 2 <= len) {
+            const uint32_t v0 = vv[i], v1 = vv[i + 1];
+            const f32x4 r0 = row(v0), r1 = row(v1);
+            acc += r0;
+            acc += r1;
+            i += 2;
         }
+        if (i < len) acc += row(vv[i]);
+        if (whole) finish_row(rr, acc, opt, hp);
+        // Pieces of ONE long run sit next to each other in the list, i.e. in neighbouring groups of this block:
+        // they are summed through LDS first and the leader issues a single set of atomics.  Without this a hot
+        // row (a 3-row table takes 21K gradients of a 64K batch) serialises ~1400 same-line atomics in L2 and
+        // the whole kernel waits for it (measured: ~330 us floor independent of everything else).
+        part_s[threadIdx.x] = acc;
+        if (c4 == 0 && gi < 64) part_key[gi] = partial ? key : ~0ull;
+        __syncthreads();
+        if (partial && (gi == 0 || part_key[gi - 1] != key)) {
+            f32x4 sum = acc;
+            for (int g2 = gi + 1; g2 < groups && part_key[g2] == key; ++g2) sum += part_s[g2 * LPR + c4];
+            const int64_t chunk = s0 / CHUNK;
+            const int64_t home = starts ? chunk : (int64_t)lasthome[chunk - 1];
+            float* cr = carry + home * D + c4 * 4;
+            atomicAdd(cr + 0, sum.x);
+            atomicAdd(cr + 1, sum.y);
+            atomicAdd(cr + 2, sum.z);
+            atomicAdd(cr + 3, sum.w);
+        }
+        __syncthreads();
     }
-    flush(cur, run_start, i);
 }
 
-__global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const uint64_t* __restrict__ keys,
-                                                         int64_t n, int D, int LPR, const float* __restrict__ carry,
-                                                         int opt, const OptHyper hp) {
+template <typename KeyT>
+__global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const KeyT* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals, int64_t n, int D, int LPR,
+                                                         const float* __restrict__ carry, int opt, const OptHyper hp) {
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
@@ -222,21 +289,22 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
     if (c0 >= n) return;
     const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
     if (c1 == n) return;  // the last chunk cannot be crossed
-    const uint64_t key = keys[c1 - 1];
-    if (key == SENTINEL || keys[c1] != key) return;  // last run ends here
+    const KeyT key = keys[c1 - 1];
+    if (key == KeyTraits<KeyT>::sentinel || keys[c1] != key) return;  // last run ends here
     int64_t s = c1 - 1;
     while (s > c0 && keys[s - 1] == key) --s;
     const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
     if (!starts_here) return;  // an earlier chunk is this run's home
     const f32x4 g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
-    apply_update(a, key, g, D, c4, opt, hp);
+    RowRmw rr;
+    load_row(a, (int)(vals[c1 - 1] >> 26), (int64_t)key, D, c4, opt, rr);
+    finish_row(rr, g, opt, hp);
 }
 
 struct WsLayout {
     int64_t n, nchunks;
-    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_flags, off_home, off_tmp, tmp_bytes,
-        scan_bytes, total;
-    int key_bits;
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_flags, off_home, off_pieces, off_counter,
+        off_tmp, tmp_bytes, total;
 };
 
 // rocPRIM switches to a merge sort (dozens of 5 us launches) below 1M items; Onesweep already wins from ~64K.
@@ -245,18 +313,22 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Sized for the 64-bit key variant (the 32-bit one uses the front of the same buffers).
 bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->n = B * F;
     L->nchunks = mh_ceil_div(L->n, CHUNK);
-    size_t tmp = 0;
+    size_t tmp = 0, tmp32 = 0;
     hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, KEY_BITS);
+                                                         (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, 64);
     if (e != hipSuccess) return false;
+    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                              (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, 32);
+    if (e != hipSuccess) return false;
+    if (tmp32 > tmp) tmp = tmp32;
     size_t scan = 0;
     e = rocprim::inclusive_scan(nullptr, scan, (const int*)nullptr, (int*)nullptr, (size_t)L->nchunks,
                                 rocprim::maximum<int>());
     if (e != hipSuccess) return false;
-    L->scan_bytes = scan;
     if (scan > tmp) tmp = scan;
     size_t o = 0;
     L->off_keys_a = o; o = align_up(o + (size_t)L->n * 8, 256);
@@ -266,11 +338,71 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->off_carry = o; o = align_up(o + (size_t)L->nchunks * D * 4, 256);
     L->off_flags = o; o = align_up(o + (size_t)L->nchunks * 4, 256);
     L->off_home = o; o = align_up(o + (size_t)L->nchunks * 4, 256);
+    L->off_pieces = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 16, 256);  // <= one cut per run + per chunk
+    L->off_counter = o; o = align_up(o + 4, 256);
     L->off_tmp = o; L->tmp_bytes = tmp; o = align_up(o + tmp, 256);
     L->total = o;
     return true;
 }
 
+template <typename KeyT>
+int32_t run_pipeline(const BwdArgs& a, const WsLayout& L, char* ws, int ids_dtype, int64_t B, int F, int D, int bits,
+                     const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp, hipStream_t s) {
+    KeyT* keys_a = reinterpret_cast<KeyT*>(ws + L.off_keys_a);
+    KeyT* keys_b = reinterpret_cast<KeyT*>(ws + L.off_keys_b);
+    uint32_t* vals_a = reinterpret_cast<uint32_t*>(ws + L.off_vals_a);
+    uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + L.off_vals_b);
+    float* carry = reinterpret_cast<float*>(ws + L.off_carry);
+    int* flags = reinterpret_cast<int*>(ws + L.off_flags);
+    int* lasthome = reinterpret_cast<int*>(ws + L.off_home);
+    ulonglong2* pieces = reinterpret_cast<ulonglong2*>(ws + L.off_pieces);
+    unsigned int* counter = reinterpret_cast<unsigned int*>(ws + L.off_counter);
+
+    dim3 gk((unsigned)mh_ceil_div(L.n, 256));
+    if (ids_dtype == MH_I32)
+        hipLaunchKernelGGL((build_keys_kernel<int32_t, KeyT>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a, counter);
+    else
+        hipLaunchKernelGGL((build_keys_kernel<int64_t, KeyT>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a, counter);
+    // stable sort over the key bits in use only; the all-ones sentinel stays last because no valid key has all
+    // of those bits set (bits = ceil(log2(total rows + 1)))
+    size_t tmp_bytes = L.tmp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b,
+                                                         (size_t)L.n, 0, bits, s);
+    if (e != hipSuccess) {
+        mh_set_error("mh_embedding_gather_bwd: radix sort failed: %s", hipGetErrorString(e));
+        return MH_ERR_LAUNCH;
+    }
+    (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
+    const int LPR = D / 4;
+    const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
+    dim3 gs((unsigned)mh_ceil_div(L.nchunks, groups));
+    hipLaunchKernelGGL((chunk_flags_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, 256)), dim3(256), 0, s, keys_b,
+                       L.n, L.nchunks, flags);
+    size_t scan_bytes = L.tmp_bytes;
+    e = rocprim::inclusive_scan(ws + L.off_tmp, scan_bytes, flags, lasthome, (size_t)L.nchunks, rocprim::maximum<int>(), s);
+    if (e != hipSuccess) {
+        mh_set_error("mh_embedding_gather_bwd: scan failed: %s", hipGetErrorString(e));
+        return MH_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s,
+                       keys_b, vals_b, L.n, pieces, counter);
+    {
+        int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
+        static int resident = 0;  // workgroups per CU the kernel's register budget allows: exactly one resident wave
+        if (resident == 0) {
+            int r = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, piece_reduce_apply_kernel, 256, 0) != hipSuccess || r < 1) r = 4;
+            resident = r;
+        }
+        const int64_t cap = (int64_t)mh_num_cus() * resident;
+        if (nb > cap) nb = cap;
+        hipLaunchKernelGGL(piece_reduce_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, vals_b, D, LPR, grad,
+                           grad_row_stride, carry, lasthome, pieces, counter, optimizer, hp);
+    }
+    hipLaunchKernelGGL((carry_apply_kernel<KeyT>), gs, dim3(256), 0, s, a, keys_b, vals_b, L.n, D, LPR, carry, optimizer, hp);
+    MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
+    return MH_OK;
+}
 
 // ---- ragged / list lookups: backward = one-hot backward over the nnz values ------------------------------
 // d table[values[j]] += grad[bag(j)] / div(bag(j))   with div = 1 | kept | sqrt(kept) (sum | mean | sqrtn).
@@ -360,6 +492,7 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
                "mh_embedding_gather_bwd: grad must be 16-byte aligned with grad_row_stride %% 4 == 0");
     if (B <= 0) return MH_OK;
     MH_REQUIRE(B < (1ll << 26), "mh_embedding_gather_bwd: B must be < 2^26");
+    MH_REQUIRE(B * F < (1ll << 31), "mh_embedding_gather_bwd: B*F must be < 2^31");
     WsLayout L;
     MH_REQUIRE(ws_layout(B, F, D, &L), "mh_embedding_gather_bwd: rocprim size query failed");
     if (!workspace || workspace_bytes < (int64_t)L.total) {
@@ -367,7 +500,10 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
         return MH_ERR_WORKSPACE;
     }
     BwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    int64_t total_rows = 0;  // rows of the distinct tables back to back = the compact key space
     for (int f = 0; f < F; ++f) {
+        MH_REQUIRE(table_rows[f] >= 1, "mh_embedding_gather_bwd: table %d has no rows", f);
         MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_bwd: null table/ids for feature %d", f);
         MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_gather_bwd: null optimizer state for feature %d", f);
         MH_REQUIRE(optimizer != MH_OPT_ADAM || state2[f], "mh_embedding_gather_bwd: null second moment for feature %d", f);
@@ -379,74 +515,26 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
         MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && grad_offset[f] + D <= grad_row_stride,
                    "mh_embedding_gather_bwd: grad offset of feature %d misaligned or out of row", f);
         a.offset[f] = grad_offset[f];
-        a.tid[f] = f;
+        a.first[f] = -1;
         for (int g = 0; g < f; ++g)
             if (tables[g] == tables[f]) {
-                a.tid[f] = g;
+                MH_REQUIRE(table_rows[g] == table_rows[f], "mh_embedding_gather_bwd: features %d and %d share a table but not its row count", g, f);
+                a.first[f] = a.first[g];
                 break;
             }
+        if (a.first[f] < 0) {
+            a.first[f] = total_rows;
+            total_rows += table_rows[f];
+        }
     }
     char* ws = static_cast<char*>(workspace);
-    uint64_t* keys_a = reinterpret_cast<uint64_t*>(ws + L.off_keys_a);
-    uint64_t* keys_b = reinterpret_cast<uint64_t*>(ws + L.off_keys_b);
-    uint32_t* vals_a = reinterpret_cast<uint32_t*>(ws + L.off_vals_a);
-    uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + L.off_vals_b);
-    float* carry = reinterpret_cast<float*>(ws + L.off_carry);
     hipStream_t s = mh_stream(stream);
     const OptHyper hp = {lr, eps, beta1, beta2, lr_device};
-
-    dim3 gk((unsigned)mh_ceil_div(L.n, 256));
-    if (ids_dtype == MH_I32)
-        hipLaunchKernelGGL((build_keys_kernel<int32_t>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a);
-    else
-        hipLaunchKernelGGL((build_keys_kernel<int64_t>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a);
-    size_t tmp_bytes = L.tmp_bytes;
-    // sort only over the key bits in use: id bits of the largest table + the table index at bit 40..
-    // (keys are (table << 40 | id); the sentinel is all ones, so it stays last under any bit window
-    //  that includes the table field) -- two radix passes over [0, idbits) and [40, 40 + tbits) would
-    // need a stable two-stage sort; rocPRIM's single call over [0, 46) costs 6 passes, so instead the
-    // id field is sorted first and the (narrow) table field second, both stable.
-    int idbits = 1;
-    {
-        int64_t maxrows = 1;
-        for (int f = 0; f < F; ++f) maxrows = table_rows[f] > maxrows ? table_rows[f] : maxrows;
-        while ((1ll << idbits) < maxrows) ++idbits;
-        if (idbits > 40) idbits = 40;
-    }
-    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)L.n, 0,
-                                             idbits, s);
-    if (e == hipSuccess) {
-        tmp_bytes = L.tmp_bytes;
-        e = rocprim::radix_sort_pairs<SortConfig>(ws + L.off_tmp, tmp_bytes, keys_b, keys_a, vals_b, vals_a, (size_t)L.n, 40,
-                                      KEY_BITS, s);
-    }
-    {   // results are back in the *_a buffers
-        uint64_t* tk = keys_a; keys_a = keys_b; keys_b = tk;
-        uint32_t* tv = vals_a; vals_a = vals_b; vals_b = tv;
-    }
-    if (e != hipSuccess) {
-        mh_set_error("mh_embedding_gather_bwd: radix sort failed: %s", hipGetErrorString(e));
-        return MH_ERR_LAUNCH;
-    }
-    (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
-    const int LPR = D / 4;
-    const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
-    dim3 gs((unsigned)mh_ceil_div(L.nchunks, groups));
-    int* flags = reinterpret_cast<int*>(ws + L.off_flags);
-    int* lasthome = reinterpret_cast<int*>(ws + L.off_home);
-    hipLaunchKernelGGL(chunk_flags_kernel, dim3((unsigned)mh_ceil_div(L.nchunks, 256)), dim3(256), 0, s, keys_b, L.n,
-                       L.nchunks, flags);
-    size_t scan_bytes = L.tmp_bytes;
-    e = rocprim::inclusive_scan(ws + L.off_tmp, scan_bytes, flags, lasthome, (size_t)L.nchunks, rocprim::maximum<int>(), s);
-    if (e != hipSuccess) {
-        mh_set_error("mh_embedding_gather_bwd: scan failed: %s", hipGetErrorString(e));
-        return MH_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(segment_reduce_apply_kernel, gs, dim3(256), 0, s, a, keys_b, vals_b, L.n, D, LPR, grad,
-                       grad_row_stride, carry, lasthome, optimizer, hp);
-    hipLaunchKernelGGL(carry_apply_kernel, gs, dim3(256), 0, s, a, keys_b, L.n, D, LPR, carry, optimizer, hp);
-    MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
-    return MH_OK;
+    int bits = 1;
+    while (bits < 64 && (1ull << bits) < (uint64_t)total_rows + 1) ++bits;
+    if ((uint64_t)total_rows < 0xffffffffull)
+        return run_pipeline<uint32_t>(a, L, ws, ids_dtype, B, F, D, bits, grad, grad_row_stride, optimizer, hp, s);
+    return run_pipeline<uint64_t>(a, L, ws, ids_dtype, B, F, D, bits, grad, grad_row_stride, optimizer, hp, s);
 }
 
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D) {

@@ -179,6 +179,7 @@ class ShardedEmbeddingGroup:
             o += n
         self.base = torch.tensor(base, dtype=torch.int64, device=self.local.device)
         self.state: Optional[torch.Tensor] = None
+        self.state2: Optional[torch.Tensor] = None
         self._rows: Optional[torch.Tensor] = None
 
     def _a2a(self, out, inp, out_splits, in_splits, async_op: bool = False):
@@ -331,10 +332,10 @@ class DistributedDLRM:
         def update_fn(table, state, rows, grads, _self=self):
             opt = _self.model.optimizer
             g3 = grads.reshape(grads.shape[0], 1, D).contiguous()
-            if opt.name == "adam":
-                raise NotImplementedError("Adam / LazyAdam on row-sharded tables is not wired yet (use sgd or adagrad)")
+            st2 = _self.group_sh.state2  # LazyAdam second moment of the local shards
             ops.embedding_gather_backward([table], None if state is None else [state], [rows], g3, [0], opt.name,
-                                          opt.learning_rate, opt.epsilon)
+                                          opt.learning_rate, opt.epsilon, None if st2 is None else [st2],
+                                          opt.beta_1, opt.beta_2, opt.lr_device)
 
         names = [n for n in self.body.cat_names
                  if (self.world_size > 1 or force_shard) and emb.feature_table[n].input_dim >= shard_threshold]
@@ -426,11 +427,14 @@ class DistributedDLRM:
         body.embeddings._pending = None
         D = body.dim
         emb = body.embeddings
+        opt.begin_step(dstack.device)  # Adam: advance the on-device step / bias-corrected lr once per step
         # 1. sharded tables: route the gradient rows to their owners (fused update there, in step 3)
         if self.group_sh is not None:
             gs = self.group_sh
             if opt.name == "adagrad" and gs.state is None:
                 gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
+            if opt.name == "adam" and gs.state is None:
+                gs.state, gs.state2 = torch.zeros_like(gs.local), torch.zeros_like(gs.local)
             # starts the gradient all-to-all; it overlaps the replicated-table gradient pass below
             gs.backward_begin(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
                                                   lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
@@ -468,6 +472,5 @@ class DistributedDLRM:
             o += q.data.numel()
         for t, g in zip(rep_tabs, rep_grads):
             t.grad = g
-        opt.begin_step(dstack.device)
         ops.dense_optimizer_step_multi(opt, dense + rep_tabs)  # one launch per 64 tensors
         return loss
