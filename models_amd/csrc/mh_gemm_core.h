@@ -55,22 +55,23 @@ struct KMajorTile {
             if ((ROWS * (BK / 4)) % NTH == 0 || (int)(threadIdx.x + i * NTH) < ROWS * (BK / 4))
                 regs[i] = *reinterpret_cast<const f32x4*>(ptr[i] + k0);
     }
-    // partial tile and/or unaligned rows: element-wise, zero beyond K
+    // partial tile and/or unaligned rows: element-wise, zero beyond K.  Branch-free: every lane loads from a
+    // valid address (its row start when the element is out of range) and the select happens afterwards, so the
+    // four scalar loads of a group are in flight together instead of one dependent round trip each.
     __device__ __forceinline__ void load_guarded(int k0, int K) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * NTH;
             const int c4 = idx & 7;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int k = k0 + c4 * 4;
-            if (idx < ROWS * (BK / 4) && k < K) {
-                const float* p = ptr[i] + k0;
-                v.x = p[0];
-                if (k + 1 < K) v.y = p[1];
-                if (k + 2 < K) v.z = p[2];
-                if (k + 3 < K) v.w = p[3];
-            }
-            regs[i] = v;
+            const bool in = idx < ROWS * (BK / 4);
+            const float* row = ptr[i] - c4 * 4;  // element 0 of the (clamped) row: always readable
+            const bool o0 = in && k < K, o1 = in && k + 1 < K, o2 = in && k + 2 < K, o3 = in && k + 3 < K;
+            const float x0 = *(o0 ? row + k : row);
+            const float x1 = *(o1 ? row + k + 1 : row);
+            const float x2 = *(o2 ? row + k + 2 : row);
+            const float x3 = *(o3 ? row + k + 3 : row);
+            regs[i] = f32x4{o0 ? x0 : 0.f, o1 ? x1 : 0.f, o2 ? x2 : 0.f, o3 ? x3 : 0.f};
         }
     }
     __device__ __forceinline__ void load(int k0, int K, bool vec_ok) {
@@ -101,6 +102,10 @@ struct NMajorTile {
     const float* ptr[NV];  // W + r*ldw + clamped column
     int col[NV];
 
+    // Column groups are clamped to the leading dimension, not to N: in vector mode (16-byte aligned rows,
+    // ldw % 4 == 0) the group straddling N reads the row's padding (it only feeds outputs that are never
+    // stored), so an ld-padded operand such as x[M, 415] with ld 416 takes the 16-byte path for every group.
+    // Every row -- the last included -- must therefore own ldw floats.
     __device__ __forceinline__ void init(const float* __restrict__ W, int64_t ldw, int n0, int N) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -108,7 +113,8 @@ struct NMajorTile {
             const int r = idx / VPR, c4 = idx - r * VPR;
             int n = n0 + c4 * 4;
             col[i] = n;
-            if (n > N - 4) n = (N >= 4) ? ((N - 4) / 4) * 4 : 0;  // stay inside the row for the vector path
+            const int last = (ldw >= 4) ? (int)((ldw - 4) / 4) * 4 : 0;
+            if (n > last) n = last;
             ptr[i] = W + (int64_t)r * ldw + n;
         }
     }
@@ -118,24 +124,24 @@ struct NMajorTile {
             if ((BK * VPR) % NTH == 0 || (int)(threadIdx.x + i * NTH) < BK * VPR)
                 regs[i] = *reinterpret_cast<const f32x4*>(ptr[i] + (int64_t)k0 * ldw);
     }
+    // rows past K (the contraction) and columns past N read as zero; branch-free like KMajorTile::load_guarded
     __device__ __forceinline__ void load_guarded(const float* __restrict__ W, int64_t ldw, int k0, int K, int N) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + i * NTH;
             const int r = idx / VPR;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int k = k0 + r, n = col[i];
-            if (idx < BK * VPR && k < K && n < N) {
-                const float* p = W + (int64_t)k * ldw + n;
-                v.x = p[0];
-                if (n + 1 < N) v.y = p[1];
-                if (n + 2 < N) v.z = p[2];
-                if (n + 3 < N) v.w = p[3];
-            }
-            regs[i] = v;
+            const bool in = idx < BK * VPR && k < K;
+            const float* p = W + (int64_t)k * ldw + n;
+            const bool o0 = in && n < N, o1 = in && n + 1 < N, o2 = in && n + 2 < N, o3 = in && n + 3 < N;
+            const float x0 = *(o0 ? p : W);
+            const float x1 = *(o1 ? p + 1 : W);
+            const float x2 = *(o2 ? p + 2 : W);
+            const float x3 = *(o3 ? p + 3 : W);
+            regs[i] = f32x4{o0 ? x0 : 0.f, o1 ? x1 : 0.f, o2 ? x2 : 0.f, o3 ? x3 : 0.f};
         }
     }
-    // vec_ok: 16-byte aligned rows AND N % 4 == 0 (column groups never straddle N)
+    // vec_ok: 16-byte aligned rows AND ldw % 4 == 0
     __device__ __forceinline__ void load(const float* __restrict__ W, int64_t ldw, int k0, int K, int N, bool vec_ok) {
         if (vec_ok && k0 + BK <= K) load_fast(k0, ldw); else load_guarded(W, ldw, k0, K, N);
     }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_tn_splitm_kernel(const float* __rest
     // NMajorTile::load(W, ldw, k0(contraction row start), K(contraction end), n0, N, vec)
     ta.init(X + m_beg * ldx, ldx, k0, K);
     tb.init(Z + m_beg * ldz, ldz, n0, N);
-    const int vx = vec_x && (K % 4 == 0), vz = vec_z && (N % 4 == 0);
+    const int vx = vec_x, vz = vec_z;  // ld-padded operands take the 16-byte path (NMajorTile::init)
     auto lda_ = [&](int kt) { ta.load(X + m_beg * ldx, ldx, kt * BK, (int)(m_end - m_beg), K, vx); };
     auto ldb_ = [&](int kt) { tb.load(Z + m_beg * ldz, ldz, kt * BK, (int)(m_end - m_beg), N, vz); };
     if (nk > 0) {
