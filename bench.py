@@ -316,7 +316,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes[name],
                 "avg_launch_ms": ms, "timing": "hipEvent pair around the launch, eager pass after the timed region"}
 
-    kernels = {"embedding_gather": "gather_fwd_kernel", "embedding_bwd": "segment_reduce_apply_kernel (+sort)",
+    kernels = {"embedding_gather": "gather_fwd_kernel", "embedding_bwd": "mh_embedding_gather_bwd = build_keys + rocPRIM Onesweep sort (3 passes) + chunk_flags/scan + "
+                                "piece_list + piece_reduce_apply_kernel (dominant) + carry_apply: ONE C-ABI launch",
                "dot_interaction": "dot_interaction_fwd_pipe_kernel", "dot_interaction_bwd": "dot_interaction_bwd_pipe_kernel"}
     dominant = max((k for k in kernels if k in kernel_ms), key=lambda k: kernel_ms[k]["avg_ms"], default=None)
     roofline = hbm_roofline(dominant, kernels[dominant]) if dominant else None

@@ -45,7 +45,7 @@ if not which or "inter" in which:
     timeit("dot_interaction bwd", lambda: ops.dot_interaction_backward(x, dout, 5, D), nbytes=B * (2 * F * D * 4 + 415 * 4))
 if not which or "linbwd" in which:
     for (K, N) in [(415, 128), (128, 64), (64, 32), (13, 128), (32, 1)]:
-        xx = torch.randn(B, K, device=dev)
+        xx = torch.randn(B, (K + 3) // 4 * 4, device=dev)[:, :K]  # the product's layout: rows padded to 16 bytes
         W = torch.randn(K, N, device=dev) * 0.1
         y = ops.linear(xx, W, None, "relu" if N > 1 else None)
         dy = torch.randn(B, N, device=dev)

@@ -14,10 +14,10 @@ for d, name in (("gpurun_out/pmc_fetch", "FETCH_SIZE"), ("gpurun_out/pmc_write",
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] == name:
-            agg[(r["Kernel_Name"][:70], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+            agg[(r["Kernel_Name"][:70] + ("|onesweep" if "onesweep" in r["Kernel_Name"] else ""), r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out[k][name] = (sum(v) / len(v), len(v))
 for k, v in sorted(out.items()):
-    if any(s in k[0] for s in ("gather", "segment", "interaction", "linear_fwd", "scorer")):
+    if any(s in k[0] for s in ("gather", "piece", "carry_apply", "build_keys", "chunk_flags", "onesweep", "interaction", "linear_fwd", "scorer")):
         print(k, {a: f"{b[0]:.4g} (n={b[1]})" for a, b in v.items()})
 PY
