@@ -280,6 +280,10 @@ int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* rel
  * pre-sigmoid logit).  Either output may be NULL. */
 int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale,
                        float* loss, float* dlogit, mh_stream_t stream);
+/* The same with the batch mean (the scalar `compute_loss` returns, models/base.py:1137-1151) formed on the device
+ * in a fixed order; workspace: 256 floats.  loss_mean[1]. */
+int32_t mh_bce_mean_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale, float* loss_mean,
+                            float* dlogit, float* workspace, mh_stream_t stream);
 
 /* ---- dense optimizer step for MLP / cross / head weights (models/base.py:1161) -----------
  * SGD: w -= lr*g.  ADAGRAD (keras): state += g^2; w -= lr * g / (sqrt(state) + eps).

@@ -276,25 +276,23 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
     }
 }
 
+// Chunk c is home to a carried sum iff a run starts inside it (flags[c] == c, see chunk_flags_kernel) and its last
+// run continues into chunk c + 1.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const KeyT* __restrict__ keys,
-                                                         const uint32_t* __restrict__ vals, int64_t n, int D, int LPR,
+                                                         const uint32_t* __restrict__ vals,
+                                                         const int* __restrict__ flags, int64_t n, int D, int LPR,
                                                          const float* __restrict__ carry, int opt, const OptHyper hp) {
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
     if (gi >= groups) return;
     const int64_t chunk = (int64_t)blockIdx.x * groups + gi;
-    const int64_t c0 = chunk * CHUNK;
-    if (c0 >= n) return;
-    const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
-    if (c1 == n) return;  // the last chunk cannot be crossed
+    const int64_t c1 = (chunk + 1) * CHUNK;
+    if (c1 >= n) return;  // the last chunk cannot be crossed
+    if (flags[chunk] < 0) return;  // one run that began earlier: an earlier chunk is its home
     const KeyT key = keys[c1 - 1];
     if (key == KeyTraits<KeyT>::sentinel || keys[c1] != key) return;  // last run ends here
-    int64_t s = c1 - 1;
-    while (s > c0 && keys[s - 1] == key) --s;
-    const bool starts_here = (s > c0) || (c0 == 0) || (keys[c0 - 1] != key);
-    if (!starts_here) return;  // an earlier chunk is this run's home
     const f32x4 g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
     RowRmw rr;
     load_row(a, (int)(vals[c1 - 1] >> 26), (int64_t)key, D, c4, opt, rr);
@@ -399,7 +397,7 @@ int32_t run_pipeline(const BwdArgs& a, const WsLayout& L, char* ws, int ids_dtyp
         hipLaunchKernelGGL(piece_reduce_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, vals_b, D, LPR, grad,
                            grad_row_stride, carry, lasthome, pieces, counter, optimizer, hp);
     }
-    hipLaunchKernelGGL((carry_apply_kernel<KeyT>), gs, dim3(256), 0, s, a, keys_b, vals_b, L.n, D, LPR, carry, optimizer, hp);
+    hipLaunchKernelGGL((carry_apply_kernel<KeyT>), gs, dim3(256), 0, s, a, keys_b, vals_b, flags, L.n, D, LPR, carry, optimizer, hp);
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;
 }

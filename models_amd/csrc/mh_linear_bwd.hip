@@ -60,10 +60,20 @@ __global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __res
 // g, g+4, ... with 4 independent loads in flight, then the 4 group sums are combined in fixed order
 // through LDS -> deterministic, and S sequential HBM round trips become S/16.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int S,
-                                                             int64_t len, float* __restrict__ out) {
+                                                             int64_t len, float* __restrict__ out,
+                                                             const float* __restrict__ part2, int64_t len2,
+                                                             float* __restrict__ out2, int blocks1) {
     __shared__ float red[256];
+    // second (optional) reduction rides in the same launch: blocks >= blocks1 sum part2 (db next to dW)
+    int bx = blockIdx.x;
+    if (bx >= blocks1) {
+        bx -= blocks1;
+        part = part2;
+        len = len2;
+        out = out2;
+    }
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    const int64_t i = (int64_t)bx * 64 + o;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < len) {
         int k = g;
@@ -78,6 +88,29 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && i < len) out[i] = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
+}
+
+// dz = dy * act'(y) in place, 16 bytes per lane (N % 4 == 0, 16-byte aligned rows): the streaming form of
+// act_grad_colsum_kernel for the common case where the column sums ride on the dW GEMM.
+__global__ __launch_bounds__(256) void act_grad_vec_kernel(const float* __restrict__ y, int64_t ldy,
+                                                          float* __restrict__ dy, int64_t lddy, int64_t M, int N4,
+                                                          int act) {
+    const int64_t total = M * N4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / N4;
+        const int c = (int)(i - r * N4) * 4;
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * ldy + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + c);
+        if (act == MH_ACT_RELU) {
+            g.x = yy.x > 0.f ? g.x : 0.f;
+            g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f;
+            g.w = yy.w > 0.f ? g.w : 0.f;
+        } else {
+            g = g * yy * (f32x4{1.f, 1.f, 1.f, 1.f} - yy);
+        }
+        *reinterpret_cast<f32x4*>(dy + r * lddy + c) = g;
+    }
 }
 
 // C[M, Nout] = A[M, Kc] * B[Nout, Kc]^T   (both operands contraction-contiguous)
@@ -338,9 +371,18 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
     float* ws_db = ws_dw + p.dw_floats;
 
     if (act != MH_ACT_NONE) {
-        const int CW = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
-        hipLaunchKernelGGL(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
-                           act, CW, (float*)nullptr);
+        const bool vec = (N % 4 == 0) && (ldy % 4 == 0) && (lddy % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+        if (vec) {
+            int64_t nb = mh_ceil_div(M * (N / 4), 256);
+            const int64_t cap = (int64_t)mh_num_cus() * 16;
+            if (nb > cap) nb = cap;
+            hipLaunchKernelGGL(act_grad_vec_kernel, dim3((unsigned)nb), dim3(256), 0, s, y, ldy, dy, lddy, M, N / 4, act);
+        } else {
+            const int CW = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
+            hipLaunchKernelGGL(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
+                               act, CW, (float*)nullptr);
+        }
     }
     if (dx) {
         const int32_t st = mh_internal_gemm_nt_mask(dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, x, ldx, x_act, s);
@@ -359,11 +401,9 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
                                p.rows_per_split, ws_dw, vec_x, vec_dy, db ? ws_db : nullptr);
         }
         const int64_t len = (int64_t)K * N;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(len, 64)), dim3(256), 0, s, ws_dw,
-                           p.splits, len, dW);
-        if (db)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(256), 0, s, ws_db,
-                               p.splits, (int64_t)N, db);
+        const int b1 = (int)mh_ceil_div(len, 64), b2 = db ? (int)mh_ceil_div(N, 64) : 0;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(b1 + b2)), dim3(256), 0, s, ws_dw, p.splits, len, dW,
+                           ws_db, (int64_t)N, db, b1);  // dW and db slabs in ONE launch
     }
     MH_CHECK_LAUNCH("mh_linear_bias_act_bwd");
     return MH_OK;

@@ -20,6 +20,36 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, c
     if (dlogit) dlogit[i] = (pi - y) * scale;
 }
 
+// Same loss with the batch mean formed on the device in a fixed order: <= 256 workgroups grid-stride over the
+// samples and write one partial each, bce_mean_finish_kernel adds the partials sequentially -> deterministic.
+__global__ __launch_bounds__(256) void bce_mean_kernel(const float* __restrict__ p, const float* __restrict__ label,
+                                                      int64_t M, float scale, float* __restrict__ partial,
+                                                      float* __restrict__ dlogit) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const float pi = p[i], y = label[i];
+        const float eps = 1e-7f;
+        const float pc = fminf(fmaxf(pi, eps), 1.f - eps);
+        acc += -(y * logf(pc) + (1.f - y) * logf(1.f - pc));
+        if (dlogit) dlogit[i] = (pi - y) * scale;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void bce_mean_finish_kernel(const float* __restrict__ partial, int nb, int64_t M, float* __restrict__ mean) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t = 0.f;
+    for (int i = 0; i < nb; ++i) t += partial[i];
+    *mean = t / (float)M;
+}
+
 // one 64-lane wavefront per row: tf.linalg.l2_normalize(x, axis=-1) = x * rsqrt(max(sum x^2, eps^2))
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int64_t M, int N, float eps,
                                                     float* __restrict__ y) {
@@ -206,6 +236,19 @@ int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad
     hipLaunchKernelGGL(bce_kernel, dim3((unsigned)mh_ceil_div(M, 256)), dim3(256), 0, mh_stream(stream), p, label,
                        M, grad_scale, loss, dlogit);
     MH_CHECK_LAUNCH("mh_bce_fwd_bwd");
+    return MH_OK;
+}
+
+int32_t mh_bce_mean_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale, float* loss_mean,
+                            float* dlogit, float* workspace, mh_stream_t stream) {
+    MH_REQUIRE(p && label && loss_mean && workspace, "mh_bce_mean_fwd_bwd: null argument");
+    MH_REQUIRE(M >= 1, "mh_bce_mean_fwd_bwd: empty batch has no mean");
+    int64_t nb = mh_ceil_div(M, 256);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(bce_mean_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), p, label, M, grad_scale,
+                       workspace, dlogit);
+    hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, M, loss_mean);
+    MH_CHECK_LAUNCH("mh_bce_mean_fwd_bwd");
     return MH_OK;
 }
 

@@ -475,12 +475,28 @@ def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
     _dev(label, "label", torch.float32)
     p, label = p.reshape(-1), label.reshape(-1)
     M = p.shape[0]
-    loss = torch.empty_like(p)
     dlogit = torch.empty_like(p) if need_grad else None
+    mean = torch.empty(1, dtype=torch.float32, device=p.device)
+    if M == 0:
+        mean.fill_(float("nan"))
+        return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
+    ws = _workspace(1024, p.device, "bce")
     with _timed("bce"):
-        check(lib.mh_bce_fwd_bwd(_ptr(p), _ptr(label), M, 1.0 / max(M, 1), _ptr(loss), _ptr(dlogit), _stream()),
-              "mh_bce_fwd_bwd")
-    return loss.mean(), (None if dlogit is None else dlogit.reshape(-1, 1))
+        check(lib.mh_bce_mean_fwd_bwd(_ptr(p), _ptr(label), M, 1.0 / M, _ptr(mean), _ptr(dlogit), _ptr(ws), _stream()),
+              "mh_bce_mean_fwd_bwd")
+    return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
+
+
+def bce_per_sample(p: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    """Per-sample binary cross-entropy (``mh_bce_fwd_bwd`` without the gradient)."""
+    lib = _lib.load()
+    _dev(p, "p", torch.float32)
+    _dev(label, "label", torch.float32)
+    p, label = p.reshape(-1), label.reshape(-1)
+    loss = torch.empty_like(p)
+    if p.shape[0]:
+        check(lib.mh_bce_fwd_bwd(_ptr(p), _ptr(label), p.shape[0], 1.0, _ptr(loss), None, _stream()), "mh_bce_fwd_bwd")
+    return loss
 
 
 def l2norm(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
