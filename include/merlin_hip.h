@@ -154,7 +154,10 @@ int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, cons
  *             OUTPUT is x (NONE for raw inputs): folding the producer's derivative into the dX
  *             epilogue hands the previous layer its dz directly, so it can be called with act = NONE;
  *   dW[K,N] = x^T dz,   db[N] = colsum(dz) (if db != NULL; fused into the dW kernel).
- * All reductions have a fixed order (deterministic).  workspace: mh_linear_bwd_workspace_bytes. */
+ * All reductions have a fixed order (deterministic).  workspace: mh_linear_bwd_workspace_bytes.
+ * The three parts can be issued separately (dx and dW are independent once dz exists, so a caller may run
+ * the dW pass on a second stream): dx == NULL skips dX, dW == NULL (then db == NULL, no workspace) skips
+ * dW/db, and with both NULL only the in-place activation gradient is applied. */
 int64_t mh_linear_bwd_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, const float* y,
                                int64_t ldy, float* dy, int64_t lddy, int64_t M, int32_t K,

@@ -114,10 +114,11 @@ class _Dense(Block):
 def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False):
     """Backward through consecutive _Dense layers, chaining the activation derivative of layer i-1
     into the dX epilogue of layer i (no separate elementwise pass between layers)."""
-    for i in range(len(layers) - 1, -1, -1):
-        prev_act = layers[i - 1].activation if i > 0 else None
-        grad = layers[i].backward(grad, need_dx=(i > 0) or need_dx, pre_masked=pre_masked, x_activation=prev_act)
-        pre_masked = prev_act is not None
+    with ops.SIDE.deferred():  # the dW GEMMs of all layers overlap the dX chain; joined at the outermost exit
+        for i in range(len(layers) - 1, -1, -1):
+            prev_act = layers[i - 1].activation if i > 0 else None
+            grad = layers[i].backward(grad, need_dx=(i > 0) or need_dx, pre_masked=pre_masked, x_activation=prev_act)
+            pre_masked = prev_act is not None
     return grad
 
 
@@ -323,6 +324,8 @@ class DLRMBlock(Block):
             dstack = ops.dlrm_interaction_fused_backward(st, si, dense, grad, tail_to_dense=has_tail)
         else:
             dstack = ops.dot_interaction_backward(self._stacked, grad, slot if has_tail else -1, D if has_tail else 0)
+        # the embedding gradients are final here: the fused sparse update may start now, beside the bottom MLP
+        self.embeddings.set_pending_grad(dstack, {n: self.slots[n] * D for n in self.cat_names}, ready=True)
         if self.bottom_block is not None:
             layers = self.bottom_block.layers if isinstance(self.bottom_block, SequentialBlock) else [self.bottom_block]
             g = dstack[:, slot]  # strided [B, D] view; overwritten in place by the activation gradient
@@ -331,7 +334,6 @@ class DLRMBlock(Block):
             else:
                 for i in range(len(layers) - 1, -1, -1):
                     g = layers[i].backward(g, need_dx=i > 0)
-        self.embeddings.set_pending_grad(dstack, {n: self.slots[n] * D for n in self.cat_names})
         return None
 
 

@@ -358,14 +358,16 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
                                float* dy, int64_t lddy, int64_t M, int32_t K, int32_t N, int32_t act,
                                int32_t x_act, float* dx, int64_t lddx, float* dW, float* db, void* workspace,
                                int64_t workspace_bytes, mh_stream_t stream) {
-    MH_REQUIRE(x && W && dy && dW, "mh_linear_bias_act_bwd: null argument");
+    MH_REQUIRE(x && dy, "mh_linear_bias_act_bwd: null argument");
+    MH_REQUIRE(!dx || W, "mh_linear_bias_act_bwd: W is required for dx");
     MH_REQUIRE(M >= 1 && K >= 1 && N >= 1, "mh_linear_bias_act_bwd: bad shape");
     MH_REQUIRE(act == MH_ACT_NONE || y, "mh_linear_bias_act_bwd: y is required for the activation derivative");
     MH_REQUIRE(x_act >= MH_ACT_NONE && x_act <= MH_ACT_SIGMOID, "mh_linear_bias_act_bwd: bad x_act");
     MH_REQUIRE(ldx >= K && lddy >= N && (!dx || lddx >= K), "mh_linear_bias_act_bwd: bad leading dimension");
     const BwdPlan p = make_plan(M, K, N);
-    MH_REQUIRE(workspace && workspace_bytes >= (p.dw_floats + p.db_floats) * (int64_t)sizeof(float),
+    MH_REQUIRE(!dW || (workspace && workspace_bytes >= (p.dw_floats + p.db_floats) * (int64_t)sizeof(float)),
                "mh_linear_bias_act_bwd: workspace too small (%lld bytes given)", (long long)workspace_bytes);
+    MH_REQUIRE(dW || !db, "mh_linear_bias_act_bwd: db rides on the dW pass (pass dW too)");
     hipStream_t s = mh_stream(stream);
     float* ws_dw = static_cast<float*>(workspace);
     float* ws_db = ws_dw + p.dw_floats;
@@ -388,7 +390,7 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
         const int32_t st = mh_internal_gemm_nt_mask(dy, lddy, W, (int64_t)N, M, K, N, dx, lddx, x, ldx, x_act, s);
         if (st != MH_OK) return st;
     }
-    {
+    if (dW) {
         const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
         const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
         if (big_tiles(K, N)) {

@@ -421,8 +421,9 @@ class DistributedDLRM:
         if self.world_size > 1:
             dlogit = dlogit / self.world_size
         xa = body.output_activation
-        dh = model.output.backward(dlogit, x_activation=xa)
-        body.backward(dh, pre_masked=xa is not None)  # leaves (dstack, offsets) pending on the embeddings block
+        with ops.SIDE.deferred():
+            dh = model.output.backward(dlogit, x_activation=xa)
+            body.backward(dh, pre_masked=xa is not None)  # leaves (dstack, offsets) pending on the embeddings block
         dstack, offsets = body.embeddings._pending
         body.embeddings._pending = None
         D = body.dim
@@ -458,6 +459,7 @@ class DistributedDLRM:
             bucket[n_head:n_head + n_rep].zero_()
             ops.embedding_gather_backward(rep_grads, None, [x[n] for n in self.replicated], dstack,
                                           [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
+        ops.SIDE.join()  # the dW / db GEMMs ran on their side stream: the bucket below reads them
         # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
         torch.cat([q.grad.reshape(-1) for q in dense] + [loss.detach().reshape(1)], out=bucket[:n_dense + 1])
         works = allreduce_flat_(bucket, self.group, async_op=True)

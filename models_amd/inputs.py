@@ -196,10 +196,16 @@ class EmbeddingsBlock(ParallelBlock):
         return self.parallel_layers  # type: ignore[return-value]
 
     # --- training: fused backward + sparse optimizer step -------------------------------------
-    def set_pending_grad(self, grad: torch.Tensor, offsets: Dict[str, int]) -> None:
+    def set_pending_grad(self, grad: torch.Tensor, offsets: Dict[str, int], ready: bool = False) -> None:
         """``grad`` is a contiguous [B, ...] buffer; feature n's gradient row starts
-        ``offsets[n]`` floats into each row (same layout the forward wrote)."""
+        ``offsets[n]`` floats into each row (same layout the forward wrote).  ``ready``: the buffer is final at
+        this point of the launch stream (an event is recorded so that the sparse update can start from here on a
+        side stream while the caller keeps enqueueing independent work)."""
         self._pending = (grad, offsets)
+        self._pending_event = None
+        if ready and grad.is_cuda and ops.SIDE.active():
+            self._pending_event = torch.cuda.Event()
+            self._pending_event.record()
 
     def backward(self, grad):
         if isinstance(grad, dict):
@@ -212,6 +218,19 @@ class EmbeddingsBlock(ParallelBlock):
             return
         grad, offsets = pending
         self._pending = None
+        ev = getattr(self, "_pending_event", None)
+        self._pending_event = None
+        if ev is not None and ops.SIDE.active():
+            side = ops.SIDE.fork_after("sparse", ev, keep=(grad,) + tuple(self._last.values()))
+            if getattr(opt, "_wait_event", None) is not None:
+                side.wait_event(opt._wait_event)
+            with torch.cuda.stream(side):
+                self._apply_sparse_now(opt, grad, offsets)
+            ops.SIDE.maybe_join()
+            return
+        self._apply_sparse_now(opt, grad, offsets)
+
+    def _apply_sparse_now(self, opt, grad, offsets) -> None:
         names = [n for n in offsets if n in self._last and self.feature_table[n].table.trainable]
         lists = [n for n in names if not self._is_onehot(self._last[n])]
         names = [n for n in names if n not in lists]

@@ -110,14 +110,16 @@ class RankingModel(Model):
         x = prepare_features(inputs)
         h = self.body(x)
         p = self.output(h)
+        self.optimizer.ensure_begun(p.device)
         loss, dlogit = self.output.loss_and_grad(p, targets)
         xa = getattr(self.body, "output_activation", None)
-        dh = self.output.backward(dlogit, x_activation=xa)
-        if xa is not None:
-            self.body.backward(dh, pre_masked=True)
-        else:
-            self.body.backward(dh)
-        self.optimizer.apply(self)
+        with ops.SIDE.deferred():  # dW GEMMs and the sparse update run on side streams, joined after the update
+            dh = self.output.backward(dlogit, x_activation=xa)
+            if xa is not None:
+                self.body.backward(dh, pre_masked=True)
+            else:
+                self.body.backward(dh)
+            self.optimizer.apply(self)
         return loss
 
 
@@ -203,9 +205,10 @@ class RetrievalModel(Model):
         res = ops.inbatch_softmax(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score, materialize=False)
         dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
                                                        out.false_negative_score)
-        self.body.parallel_layers["query"].backward(dq)
-        self.body.parallel_layers["item"].backward(ops.eltwise("add", ditem, dneg))
-        self.optimizer.apply(self)
+        with ops.SIDE.deferred():
+            self.body.parallel_layers["query"].backward(dq)
+            self.body.parallel_layers["item"].backward(ops.eltwise("add", ditem, dneg))
+            self.optimizer.apply(self)
         return res.loss.mean()
 
     def query_embeddings(self, inputs: TabularData) -> torch.Tensor:

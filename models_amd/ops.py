@@ -72,6 +72,93 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _SideStreams:
+    """Independent work of one train step on extra HIP streams: the dW / db GEMMs of an MLP backward (stream
+    "dw") run beside the dX chain, the fused embedding backward (stream "sparse") beside the bottom-MLP backward.
+    Fork = the side stream waits for an event on the launch stream; join = the launch stream waits for the side
+    streams.  Tensors a side stream reads are kept alive until the join (the caching allocator would otherwise
+    hand their memory to later launch-stream kernels).  Used by eager steps only (see ``active``);
+    ``MERLIN_HIP_SIDE_STREAMS=0`` turns it off; the per-op timer of bench.py runs single-stream."""
+
+    def __init__(self):
+        import os
+
+        self.enabled = os.environ.get("MERLIN_HIP_SIDE_STREAMS", "1") != "0"
+        self._streams = {}
+        self._pending = set()
+        self._keep = []
+        self._defer = 0
+
+    def active(self) -> bool:
+        # not under hipGraph capture: ROCm 7 replays a captured graph on ONE hardware queue (measured: the kernel
+        # trace of a replayed multi-branch step shows no overlap and the event nodes cost ~2 %), so side streams only
+        # pay in eager steps (the sharded multi-GPU step: 2.13 -> 2.01 ms at W = 1)
+        return (self.enabled and not TIMER.enabled and torch.cuda.is_available()
+                and not torch.cuda.is_current_stream_capturing())
+
+    def stream(self, name: str):
+        dev = torch.cuda.current_device()
+        st = self._streams.get((dev, name))
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            self._streams[(dev, name)] = st
+        return st
+
+    def fork(self, name: str, keep=()):
+        """Returns the side stream, ordered after everything enqueued so far on the current stream."""
+        st = self.stream(name)
+        st.wait_stream(torch.cuda.current_stream())
+        self._pending.add(st)
+        self._keep.extend(keep)
+        return st
+
+    def fork_after(self, name: str, event, keep=()):
+        st = self.stream(name)
+        st.wait_event(event)
+        self._pending.add(st)
+        self._keep.extend(keep)
+        return st
+
+    def join(self) -> None:
+        if self._pending:
+            cur = torch.cuda.current_stream()
+            for st in self._pending:
+                cur.wait_stream(st)
+            self._pending.clear()
+        self._keep.clear()
+
+    def join_stream(self, name: str) -> None:
+        """The current stream waits for ONE side stream (its kept tensors stay alive until the full join)."""
+        st = self._streams.get((torch.cuda.current_device(), name)) if torch.cuda.is_available() else None
+        if st is not None and st in self._pending:
+            torch.cuda.current_stream().wait_stream(st)
+            self._pending.discard(st)
+
+    def maybe_join(self) -> None:
+        if self._defer == 0:
+            self.join()
+
+    class _Deferred:
+        def __init__(self, owner):
+            self.owner = owner
+
+        def __enter__(self):
+            self.owner._defer += 1
+
+        def __exit__(self, *exc):
+            self.owner._defer -= 1
+            if self.owner._defer == 0:
+                self.owner.join()
+            return False
+
+    def deferred(self):
+        """Within this context side work is joined only at exit (or by an explicit ``join()``)."""
+        return _SideStreams._Deferred(self)
+
+
+SIDE = _SideStreams()
+
+
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
@@ -339,11 +426,28 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
     dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
     nbytes = lib.mh_linear_bwd_workspace_bytes(M, K, N)
+    yp, ldy = (_ptr(y), y.stride(0)) if act != 0 else (None, 0)
+    if SIDE.active():
+        # dz first (in place), then dX on this stream while dW / db run on the "dw" side stream
+        if act != 0:
+            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
+                                             0, None, 0, None, None, None, 0, _stream()), "mh_linear_bias_act_bwd")
+        side = SIDE.fork("dw", keep=(x, dy))
+        ws = _workspace(nbytes, x.device, "linear_bwd_side")
+        with torch.cuda.stream(side):
+            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
+                                             None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                  "mh_linear_bias_act_bwd")
+        if need_dx:
+            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
+                                             ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
+                  "mh_linear_bias_act_bwd")
+        SIDE.maybe_join()
+        return dx, dW, db
     ws = _workspace(nbytes, x.device, "linear_bwd")
     with _timed(f"linear_bwd_{K}x{N}"):
         check(
-            lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), _ptr(y if act != 0 else None),
-                                       y.stride(0) if act != 0 else 0, _ptr(dy), dy.stride(0), M, K, N, act,
+            lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
                                        ACT[x_activation], _ptr(dx), lddx, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
             "mh_linear_bias_act_bwd",
         )

@@ -26,18 +26,36 @@ class Optimizer:
     def begin_step(self, device) -> None:
         """Per-step prologue (Adam advances its on-device step counter / bias-corrected lr)."""
 
+    def ensure_begun(self, device) -> None:
+        """Run the per-step prologue once per step.  train_step calls this BEFORE the backward so that the
+        sparse update, which starts on a side stream as soon as the embedding gradients are final, is ordered
+        after it."""
+        if not getattr(self, "_begun", False):
+            self.begin_step(device)
+            self._begun = True
+
     def apply(self, model) -> None:
         from . import ops
 
         params = model.parameters()
+        late = not getattr(self, "_begun", False)
         if params:
-            self.begin_step(params[0].data.device)
-
-        dense = [p for p in model.parameters() if not p.sparse and p.trainable and p.grad is not None]
-        ops.dense_optimizer_step_multi(self, dense)  # one launch for all MLP / cross / head tensors
-        for blk in _walk(model):
-            if hasattr(blk, "apply_sparse"):
-                blk.apply_sparse(self)
+            self.ensure_begun(params[0].data.device)
+        # prologue ran only now: a sparse update forked from an earlier event must also wait for it
+        self._wait_event = None
+        if late and self.lr_device is not None and ops.SIDE.active():
+            self._wait_event = torch.cuda.Event()
+            self._wait_event.record()
+        with ops.SIDE.deferred():
+            # sparse first: it leaves for its side stream (if the gradients were announced ready) and runs beside
+            # the tail of the backward and the dense update below
+            for blk in _walk(model):
+                if hasattr(blk, "apply_sparse"):
+                    blk.apply_sparse(self)
+            ops.SIDE.join_stream("dw")  # the dW / db GEMMs of the MLP backward ran on their own stream
+            dense = [p for p in model.parameters() if not p.sparse and p.trainable and p.grad is not None]
+            ops.dense_optimizer_step_multi(self, dense)  # one launch for all MLP / cross / head tensors
+        self._begun = False
 
 
 def _walk(block):
