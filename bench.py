@@ -210,13 +210,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from models_amd import ops
 
@@ -285,9 +285,10 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    if rank != 0:
-        return
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     F, D, B = len(model.body.cat_names), model.body.dim, args.batch
     Fs = F + 1
     P = Fs * (Fs - 1) // 2
@@ -335,14 +336,18 @@ def main():
         "roofline_gather": roofline_gather,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
     }
-    if not args.no_cpu_baseline:
-        got = runner(batch)[: min(args.cpu_batch, B)].cpu().numpy()  # GPU probabilities with the CURRENT weights
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: at N > 1 the tables are sharded and a
+        got = runner(batch)                       # forward is a collective[: min(args.cpu_batch, B)].cpu().numpy()  # GPU probabilities with the CURRENT weights
         base, ref = cpu_baseline(model, batch, label, min(args.cpu_batch, B), args.mode, args.optimizer)
         res["cpu_baseline"] = base
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref["prob"]).max())
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res))
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

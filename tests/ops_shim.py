@@ -1,0 +1,153 @@
+"""Framework-op (torch, any device) statements of the ``models_amd.ops`` entry points the DLRM step uses.
+
+TEST INFRASTRUCTURE ONLY: ``install()`` monkeypatches them over the HIP wrappers so that the HOST logic of
+``models_amd`` (block wiring, gradient scaling, the sharded multi-GPU step, bucket layout) can be exercised on CPU
+with ``gloo`` at world size > 1, where no HIP device exists.  The numerics of the kernels themselves are checked
+by the ``-m gpu`` tests against ``oracle/``; nothing here is reachable from the product."""
+from __future__ import annotations
+
+import torch
+
+from models_amd import distributed as D
+
+
+def _act(x, name):
+    if name in (None, "linear"):
+        return x
+    if name == "relu":
+        return torch.relu(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    raise ValueError(name)
+
+
+def _act_grad(y, g, name):
+    if name in (None, "linear"):
+        return g
+    if name == "relu":
+        return g * (y > 0).to(g.dtype)
+    if name == "sigmoid":
+        return g * y * (1 - y)
+    raise ValueError(name)
+
+
+def embedding_gather(tables, ids, out=None, out_slot=None, n_slots=None, out_offset=None):
+    F, D = len(tables), tables[0].shape[1]
+    B = ids[0].reshape(-1).shape[0]
+    slots = list(range(F)) if out_slot is None else list(out_slot)
+    if n_slots is None:
+        n_slots = (max(slots) + 1) if out is None else out.shape[1]
+    if out is None:
+        out = torch.empty((B, n_slots, D), dtype=torch.float32, device=tables[0].device)
+    flat = out.view(B, -1)
+    offs = [s * D for s in slots] if out_offset is None else list(out_offset)
+    for t, i, o in zip(tables, ids, offs):
+        flat[:, o:o + D] = t[i.reshape(-1).long()]
+    return out
+
+
+def linear(x, W, b=None, activation=None, out=None):
+    y = x @ W
+    if b is not None:
+        y = y + b
+    y = _act(y, activation)
+    if out is None:
+        return y
+    out.copy_(y)
+    return out
+
+
+def dot_interaction(x, tail=None, out=None):
+    B, F, _ = x.shape
+    iu = torch.triu_indices(F, F, offset=1)
+    inter = torch.bmm(x, x.transpose(1, 2))[:, iu[0], iu[1]]
+    res = inter if tail is None else torch.cat([inter, tail], dim=1)
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def dot_interaction_backward(x, dout, tail_slot=-1, tail_width=0):
+    B, F, D = x.shape
+    P = F * (F - 1) // 2
+    iu = torch.triu_indices(F, F, offset=1)
+    G = torch.zeros(B, F, F, dtype=x.dtype, device=x.device)
+    G[:, iu[0], iu[1]] = dout[:, :P]
+    dx = torch.bmm(G + G.transpose(1, 2), x)
+    if tail_slot >= 0 and tail_width > 0:
+        dx[:, tail_slot, :tail_width] += dout[:, P:P + tail_width]
+    return dx
+
+
+def linear_backward(x, W, y, dy, activation=None, need_dx=True, need_db=True, x_activation=None):
+    if activation not in (None, "linear"):
+        dy.copy_(_act_grad(y, dy, activation))  # in place, like the kernel
+    dx = None
+    if need_dx:
+        dx = _act_grad(x, dy @ W.t(), x_activation)
+    return dx, x.t() @ dy, (dy.sum(0) if need_db else None)
+
+
+def embedding_gather_backward(tables, states, ids, grad, grad_offset, optimizer="sgd", lr=0.01, eps=1e-7,
+                              states2=None, beta1=0.9, beta2=0.999, lr_device=None):
+    if optimizer not in ("sgd", "adagrad"):
+        raise NotImplementedError("shim: sgd / adagrad only")
+    B = grad.shape[0]
+    g2 = grad.reshape(B, -1)
+    D = tables[0].shape[1]
+    seen = {}
+    for f, t in enumerate(tables):
+        key = t.data_ptr()
+        if key not in seen:
+            seen[key] = (t, None if states is None else states[f], torch.zeros_like(t))
+        idx = ids[f].reshape(-1).long()
+        ok = (idx >= 0) & (idx < t.shape[0])
+        seen[key][2].index_add_(0, idx[ok], g2[:, grad_offset[f]:grad_offset[f] + D][ok])
+    for t, st, g in seen.values():
+        if optimizer == "adagrad":
+            st += g * g
+            t -= lr * g / (st.sqrt() + eps)
+        else:
+            t -= lr * g
+
+
+def bce(p, label, need_grad=True):
+    p, label = p.reshape(-1), label.reshape(-1)
+    pc = p.clamp(1e-7, 1 - 1e-7)
+    loss = -(label * pc.log() + (1 - label) * (1 - pc).log())
+    dlogit = ((p - label) / p.shape[0]).reshape(-1, 1) if need_grad else None
+    return loss.mean(), dlogit
+
+
+def dense_optimizer_step_multi(opt, params):
+    for p in params:
+        if p.grad is None:
+            continue
+        g = p.grad.reshape(p.data.shape)
+        if opt.name == "adagrad":
+            if "accumulator" not in p.state:
+                p.state["accumulator"] = torch.full_like(p.data, opt.initial_accumulator_value)
+            p.state["accumulator"] += g * g
+            p.data -= opt.learning_rate * g / (p.state["accumulator"].sqrt() + opt.epsilon)
+        elif opt.name == "sgd":
+            p.data -= opt.learning_rate * g
+        else:
+            raise NotImplementedError("shim: sgd / adagrad only")
+        p.grad = None
+
+
+def route_build(ids, world_size, slots=None, n_slots=None):
+    F = len(ids)
+    slots = list(range(F)) if slots is None else list(slots)
+    return D.route_build_torch(ids, world_size, slots, (max(slots) + 1) if n_slots is None else n_slots)
+
+
+def install():
+    """Replace the HIP wrappers of ``models_amd.ops`` by the statements above (this process only)."""
+    from models_amd import ops
+
+    for name in ("embedding_gather", "linear", "dot_interaction", "dot_interaction_backward", "linear_backward",
+                 "embedding_gather_backward", "bce", "dense_optimizer_step_multi", "route_build"):
+        setattr(ops, name, globals()[name])
+    ops.route_local_rows = D.route_local_rows_torch

@@ -3,6 +3,7 @@ The compute callables are injected (oracle gather / plain index_add update): the
 row % W ownership arithmetic and the bucketed dense reduction are what is under test."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -59,6 +60,12 @@ def _worker(rank, world, port, V, Dm, B, q):
         tot = sum(range(1, world + 1))
         torch.testing.assert_close(a, torch.full((3, 5), float(tot)))
         torch.testing.assert_close(b, torch.arange(7, dtype=torch.float32) * tot)
+        # the same bucket reduction issued asynchronously (what the DLRM step overlaps with the sparse update)
+        flat = torch.arange(64, dtype=torch.float32) * (rank + 1)
+        works = D.allreduce_flat_(flat, async_op=True)
+        for w in works:
+            w.wait()
+        torch.testing.assert_close(flat, torch.arange(64, dtype=torch.float32) * tot)
         # broadcast from rank 0
         p = torch.full((4,), float(rank))
         D.broadcast_parameters([p], 0)
@@ -146,3 +153,106 @@ def test_world_size_one_route_is_identity():
     assert r.send_counts == [5] and r.recv_counts == [5]
     rows = torch.arange(10.0).reshape(10, 1)[r.recv_rows]
     assert torch.equal(r.return_rows(rows)[:, 0], ids.float())
+
+
+# ---- the whole sharded DLRM train step at world size 2 (host logic; kernels replaced by tests/ops_shim.py) ----
+def _dlrm_parts(seed=5):
+    import models_amd as mm
+    from models_amd import schema as S
+
+    cards = {"C1": 4001, "C2": 7, "C3": 2500, "C4": 33}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+    dev = torch.device("cpu")
+    m = mm.DLRMModel(schema, embedding_dim=8, bottom_block=mm.MLPBlock([16, 8], device=dev, seed=7),
+                     top_block=mm.MLPBlock([16, 8], device=dev, seed=17), device=dev)
+    m.output.to_call.seed = 99
+    m.compile(optimizer="adagrad", learning_rate=0.05)
+    return m, schema, cards
+
+
+def _dlrm_batches(cards, world, B, steps, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        x = {n: torch.randint(0, v, (world, B), generator=g) for n, v in cards.items()}
+        x.update({f"I{i}": torch.rand(world, B, 1, generator=g) for i in range(1, 4)})
+        y = torch.randint(0, 2, (world, B, 1), generator=g).float()
+        out.append((x, y))
+    return out
+
+
+def _dlrm_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import ops_shim
+
+        ops_shim.install()
+        B, steps = 64, 3
+        model, schema, cards = _dlrm_parts()
+        batches = _dlrm_batches(cards, world, B, steps)
+        model({k: v[rank] for k, v in batches[0][0].items()})  # build lazily-shaped layers
+        dd = D.DistributedDLRM(model, shard_threshold=1000)
+        assert sorted(dd.sharded) == ["C1", "C3"]
+        losses = []
+        for x, y in batches:
+            losses.append(float(dd.train_step({k: v[rank] for k, v in x.items()}, y[rank])))
+        state = {"loss": losses,
+                 "dense": [p.data.clone() for p in model.parameters() if not p.sparse],
+                 "rep": {n: model.body.embeddings.feature_table[n].table.data.clone() for n in dd.replicated},
+                 "shard": {n: dd.sharded[n].clone() for n in dd.sharded}}
+        q.put((rank, "ok", state))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_dlrm_step_world2_matches_full_batch_model():
+    """Two ranks, half a batch each, row-sharded C1/C3 + replicated C2/C4: after three Adagrad steps every rank
+    holds the parameters a single model trained on the concatenated batch holds (and reports its loss)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ops_shim
+    from models_amd import ops
+
+    world, B, steps = 2, 64, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dlrm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+    assert all(m == "ok" for _, m, _ in res), [m for _, m, _ in res]
+    # single-process reference on the full batch (same shim ops, plain RankingModel.train_step)
+    saved = {n: getattr(ops, n) for n in dir(ops)}
+    try:
+        ops_shim.install()
+        model, schema, cards = _dlrm_parts()
+        batches = _dlrm_batches(cards, world, B, steps)
+        model({k: v[0] for k, v in batches[0][0].items()})
+        ref_losses = []
+        for x, y in batches:
+            full = {k: v.reshape(world * B, *v.shape[2:]) for k, v in x.items()}
+            ref_losses.append(float(model.train_step(full, y.reshape(world * B, 1))))
+    finally:
+        for n, v in saved.items():
+            setattr(ops, n, v)
+    ref_dense = [p.data for p in model.parameters() if not p.sparse]
+    for rank, _, st in res:
+        np.testing.assert_allclose(st["loss"], ref_losses, rtol=1e-5, atol=1e-6)
+        for a, b in zip(st["dense"], ref_dense):
+            torch.testing.assert_close(a, b, atol=2e-5, rtol=1e-4)
+        for n, t in st["rep"].items():
+            torch.testing.assert_close(t, model.body.embeddings.feature_table[n].table.data, atol=2e-5, rtol=1e-4)
+        for n, t in st["shard"].items():
+            full_t = model.body.embeddings.feature_table[n].table.data
+            torch.testing.assert_close(t, D.shard_table(full_t, rank, world), atol=2e-5, rtol=1e-4)
