@@ -20,5 +20,6 @@ from .outputs import (  # noqa: F401
 from .models import (  # noqa: F401
     DCNModel, DLRMModel, Model, RankingModel, RetrievalModel, TopKEncoder, TwoTowerModel, TwoTowerModelV2,
 )
+from .loader import Loader  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,202 @@
+"""Batches for the hot path from a Parquet dataset / DataFrame / dict of arrays.
+
+The reference feeds its models through ``merlin.models.tf.loader.Loader`` (tf/loader.py:247-333, a thin wrapper of
+the external ``merlin.dataloader``): per batch a dict ``name -> tensor`` in the ``PrepareFeatures`` input contract
+(tf/transforms/features.py:143-379) plus the target column(s):
+
+  * scalar categorical column  -> ``[B]`` int32/int64 ids (``prepare_features`` makes them ``[B, 1]``);
+  * scalar continuous column   -> ``[B, 1]`` float32;
+  * list column (ragged or fixed length) -> CSR ``name__values [nnz]`` + ``name__offsets [B + 1]``;
+  * target column(s)           -> ``[B, 1]`` float32 (a dict of them if there are several);
+  * ranks of a multi-GPU job read contiguous, equally sized slices of the row range (loader.py:308-311).
+
+This is IO plumbing, not a kernel: pyarrow decodes the columns once into host arrays; every batch is staged through
+pinned host memory and copied on a dedicated HIP stream, one batch ahead of the consumer, so the copy of batch i + 1
+overlaps the train step of batch i (`MI355X: overlap copies with compute on separate streams`).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .schema import Schema, Tags
+
+
+def _column_arrays(data, names: List[str]) -> Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]]:
+    """name -> numpy array (scalar column) or (values, offsets) (list column)."""
+    try:
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("models_amd.loader needs pyarrow to read Parquet / DataFrames") from e
+    if isinstance(data, (str, Path)):
+        p = Path(data)
+        files = sorted(p.glob("*.parquet")) if p.is_dir() else [p]
+        if not files:
+            raise FileNotFoundError(f"no parquet files under {p}")
+        table = pa.concat_tables([pq.read_table(f, columns=names) for f in files])
+    elif isinstance(data, dict):
+        out = {}
+        for n in names:
+            v = data[n]
+            out[n] = (np.asarray(v[0]), np.asarray(v[1])) if isinstance(v, tuple) else np.asarray(v)
+        return out
+    else:  # pandas DataFrame (or anything pyarrow can convert)
+        table = pa.Table.from_pandas(data[names], preserve_index=False) if hasattr(data, "columns") else pa.table(data)
+    out = {}
+    for n in names:
+        col = table.column(n).combine_chunks()
+        if pa.types.is_list(col.type) or pa.types.is_large_list(col.type) or pa.types.is_fixed_size_list(col.type):
+            if pa.types.is_fixed_size_list(col.type):
+                L = col.type.list_size
+                values = col.flatten().to_numpy(zero_copy_only=False)
+                offsets = np.arange(len(col) + 1, dtype=np.int64) * L
+            else:
+                if col.null_count:
+                    raise ValueError(f"list column {n!r} has null rows; fill them with empty lists first")
+                offsets = col.offsets.to_numpy(zero_copy_only=False).astype(np.int64)
+                values = col.values.to_numpy(zero_copy_only=False)[offsets[0]:offsets[-1]]
+                offsets = offsets - offsets[0]
+            out[n] = (values, offsets)
+        else:
+            if col.null_count:
+                raise ValueError(f"column {n!r} has nulls; the hot path expects dense, preprocessed features")
+            out[n] = col.to_numpy(zero_copy_only=False)
+    return out
+
+
+class Loader:
+    """``for inputs, targets in Loader(path_or_df, schema, batch_size): model.train_step(inputs, targets)``."""
+
+    def __init__(self, paths_or_dataset, schema: Schema, batch_size: int, shuffle: bool = True, seed: int = 0,
+                 drop_last: bool = False, device=None, global_rank: Optional[int] = None,
+                 global_size: Optional[int] = None, prefetch: bool = True):
+        if batch_size < 1:
+            raise ValueError("batch_size must be >= 1")
+        self.schema, self.batch_size, self.shuffle, self.seed, self.drop_last = schema, int(batch_size), shuffle, seed, drop_last
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        self.prefetch = prefetch and self.device.type == "cuda"
+        if global_size is None:
+            import torch.distributed as dist
+
+            ready = dist.is_available() and dist.is_initialized()
+            global_rank, global_size = (dist.get_rank(), dist.get_world_size()) if ready else (0, 1)
+        self.rank, self.world = int(global_rank or 0), int(global_size)
+        self.label_names = [c.name for c in schema.select_by_tag(Tags.TARGET)]
+        self.cat_names = [c.name for c in schema.select_by_tag(Tags.CATEGORICAL).excluding_by_tag(Tags.TARGET)]
+        self.cont_names = [c.name for c in schema.select_by_tag(Tags.CONTINUOUS).excluding_by_tag(Tags.TARGET)]
+        names = self.cat_names + self.cont_names + self.label_names
+        if not names:
+            raise ValueError("the schema selects no columns")
+        cols = _column_arrays(paths_or_dataset, names)
+        rows = {n: (len(v[1]) - 1 if isinstance(v, tuple) else len(v)) for n, v in cols.items()}
+        if len(set(rows.values())) != 1:
+            raise ValueError(f"columns have different lengths: {rows}")
+        total = next(iter(rows.values()))
+        per = total // self.world  # equal contiguous slices; the remainder rows are dropped so that ranks stay in step
+        self.lo, self.n_rows = self.rank * per, per
+        self.columns: Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]] = {}
+        for n in self.cat_names:
+            v = cols[n]
+            if isinstance(v, tuple):
+                vals, offs = v
+                vals = vals.astype(np.int64 if vals.dtype.itemsize > 4 else np.int32, copy=False)
+                self.columns[n] = (vals, offs.astype(vals.dtype))  # kernels want one integer dtype for both
+            else:
+                if not np.issubdtype(v.dtype, np.integer):
+                    raise TypeError(f"categorical column {n!r} must hold integer ids, got {v.dtype}")
+                self.columns[n] = v.astype(np.int64 if v.dtype.itemsize > 4 else np.int32, copy=False)
+        for n in self.cont_names + self.label_names:
+            v = cols[n]
+            if isinstance(v, tuple):
+                raise TypeError(f"list-valued continuous / target column {n!r} is outside the hot path")
+            self.columns[n] = v.astype(np.float32, copy=False)
+        self._epoch = 0
+
+    def __len__(self) -> int:
+        full, rem = divmod(self.n_rows, self.batch_size)
+        return full + (1 if rem and not self.drop_last else 0)
+
+    # --- host side: one batch as numpy arrays -------------------------------------------------------------
+    def _host_batch(self, idx: np.ndarray, contiguous: Optional[Tuple[int, int]]):
+        out: Dict[str, np.ndarray] = {}
+        for n, v in self.columns.items():
+            if isinstance(v, tuple):
+                vals, offs = v
+                if contiguous is not None:
+                    a, b = contiguous
+                    o = offs[a:b + 1]
+                    out[n + "__values"] = vals[o[0]:o[-1]]
+                    out[n + "__offsets"] = o - o[0]
+                else:
+                    lens = (offs[idx + 1] - offs[idx]).astype(np.int64)
+                    new_offs = np.zeros(len(idx) + 1, dtype=offs.dtype)
+                    np.cumsum(lens, out=new_offs[1:])
+                    # gather the value ranges of the selected rows
+                    starts = np.repeat(offs[idx].astype(np.int64) - new_offs[:-1].astype(np.int64), lens)
+                    out[n + "__values"] = vals[starts + np.arange(int(new_offs[-1]), dtype=np.int64)]
+                    out[n + "__offsets"] = new_offs
+            else:
+                out[n] = v[contiguous[0]:contiguous[1]] if contiguous is not None else v[idx]
+        return out
+
+    def _to_device(self, host: Dict[str, np.ndarray]):
+        dev = {}
+        for k, a in host.items():
+            a = np.ascontiguousarray(a)
+            if self.device.type == "cuda":
+                if not a.flags.writeable:  # arrow-backed views are read-only; torch only wraps writable arrays
+                    a = a.copy()
+                t = torch.from_numpy(a).pin_memory().to(self.device, non_blocking=True)
+            else:
+                t = torch.from_numpy(a.copy() if not a.flags.writeable else a)
+            base = k.split("__")[0]
+            if base in self.cont_names or base in self.label_names:
+                t = t.reshape(-1, 1)
+            dev[k] = t
+        if not self.label_names:
+            return dev, None
+        labels = {n: dev.pop(n) for n in self.label_names}
+        return dev, (labels[self.label_names[0]] if len(labels) == 1 else labels)
+
+    def __iter__(self) -> Iterator:
+        order = None
+        if self.shuffle:
+            order = np.random.default_rng(self.seed + self._epoch).permutation(self.n_rows) + self.lo
+        self._epoch += 1
+        nb = len(self)
+
+        def host(i):
+            a = i * self.batch_size
+            b = min(a + self.batch_size, self.n_rows)
+            if order is None:
+                return self._host_batch(None, (self.lo + a, self.lo + b))
+            return self._host_batch(order[a:b], None)
+
+        if not self.prefetch:
+            for i in range(nb):
+                yield self._to_device(host(i))
+            return
+        copy_stream = torch.cuda.Stream(device=self.device)
+        cur_stream = torch.cuda.current_stream(self.device)
+
+        def stage(i):
+            with torch.cuda.stream(copy_stream):
+                batch = self._to_device(host(i))
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return batch, ev
+
+        nxt = stage(0) if nb else None
+        for i in range(nb):
+            (inputs, targets), ev = nxt
+            nxt = stage(i + 1) if i + 1 < nb else None  # copy of the next batch overlaps this batch's step
+            cur_stream.wait_event(ev)
+            for t in list(inputs.values()) + ([targets] if isinstance(targets, torch.Tensor) else list((targets or {}).values())):
+                t.record_stream(cur_stream)  # allocated on the copy stream, consumed on the compute stream
+            yield inputs, targets

@@ -10,6 +10,7 @@ from __future__ import annotations
 import time
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
+import numpy as np
 import torch
 
 from . import ops, optim
@@ -231,6 +232,40 @@ class TopKEncoder(Block):
 
     def forward(self, inputs: TabularData, **kwargs):
         return self.topk_layer(self.query_encoder(prepare_features(inputs)), **kwargs)
+
+    @property
+    def k(self) -> int:
+        return self.topk_layer.to_call.k
+
+    def batch_predict(self, dataset, batch_size: Optional[int] = None, output_schema: Optional[Schema] = None,
+                      schema: Optional[Schema] = None) -> Dict[str, np.ndarray]:
+        """core/encoder.py:602-656: top-k prediction over a whole dataset in batches.  ``dataset`` is a
+        ``models_amd.loader.Loader`` (read in order) or anything it accepts plus ``schema``.  Returns the columns of a
+        prediction frame: ``score_0..score_{k-1}``, ``id_0..id_{k-1}`` (``TopKPrediction.output_names``), preceded by
+        the input columns named in ``output_schema``."""
+        from .loader import Loader
+        from .outputs import TopKPrediction
+
+        if not isinstance(dataset, Loader):
+            if schema is None or batch_size is None:
+                raise ValueError("batch_predict needs a Loader, or a dataset together with `schema` and `batch_size`")
+            dataset = Loader(dataset, schema, batch_size, shuffle=False)
+        if dataset.shuffle:
+            raise ValueError("batch_predict reads the dataset in order: build the Loader with shuffle=False")
+        keep = [c.name for c in output_schema] if output_schema is not None else []
+        scores, ids, kept = [], [], {n: [] for n in keep}
+        for inputs, _ in dataset:
+            pred = self.forward(inputs)
+            scores.append(pred.scores.cpu().numpy())
+            ids.append(pred.identifiers.cpu().numpy())
+            for n in keep:
+                kept[n].append(inputs[n].reshape(inputs[n].shape[0], -1)[:, 0].cpu().numpy())
+        S, I = np.concatenate(scores), np.concatenate(ids)
+        out = {n: np.concatenate(v) for n, v in kept.items()}
+        k = S.shape[1]
+        for name, col in zip(TopKPrediction.output_names(k), list(S.T) + list(I.T)):
+            out[name] = col
+        return out
 
 
 def TwoTowerModel(schema: Schema, query_tower: Block, item_tower: Optional[Block] = None,

@@ -33,6 +33,11 @@ class TopKPrediction(NamedTuple):
     scores: torch.Tensor
     identifiers: torch.Tensor
 
+    @staticmethod
+    def output_names(k: int):
+        """Column names of a batch-prediction frame (core/prediction.py:107-115)."""
+        return [f"score_{i}" for i in range(k)] + [f"id_{i}" for i in range(k)]
+
 
 class BinaryOutput(Block):
     """classification.py:72-123: Dense(1, activation="sigmoid") head, binary cross-entropy loss."""

@@ -282,3 +282,48 @@ def test_distributed_dlrm_world1_matches_plain_model(device, optimizer):
         ta = a.body.embeddings.feature_table[n].table.data
         tb = db.sharded[n] if n in db.sharded else b.body.embeddings.feature_table[n].table.data
         torch.testing.assert_close(tb, ta, atol=1e-5, rtol=1e-4)
+
+
+def test_loader_feeds_train_steps_and_batch_predict(device):
+    """models_amd.Loader (pinned staging + copy stream, one batch ahead) -> train_step / TopKEncoder.batch_predict:
+    same result as handing the same rows over as device tensors."""
+    schema = _two_tower_schema()
+    rng = np.random.default_rng(4)
+    n = 200
+    data = {}
+    for c in schema:
+        if S.Tags.CATEGORICAL in c.tags:
+            data[c.name] = rng.integers(0, int(c.int_domain.max) + 1, size=n).astype(np.int64)
+        elif S.Tags.CONTINUOUS in c.tags:
+            data[c.name] = rng.random(n).astype(np.float32)
+
+    def build():
+        m = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device, seed=3), embedding_dim=16, device=device)
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    a, b = build(), build()
+    first = {k: torch.from_numpy(v[:50]).to(device) for k, v in data.items()}
+    a(first), b(first)
+    for pa_, pb_ in zip(a.parameters(), b.parameters()):
+        pb_.data.copy_(pa_.data)
+    ld = mm.Loader(data, schema, batch_size=50, shuffle=False, device=device)
+    assert ld.prefetch and len(ld) == 4
+    for i, (inputs, targets) in enumerate(ld):
+        assert targets is None and inputs[next(iter(inputs))].is_cuda
+        la = a.train_step(inputs)
+        lb = b.train_step({k: torch.from_numpy(v[50 * i:50 * i + 50]).to(device) for k, v in data.items()})
+        assert abs(float(la) - float(lb)) < 1e-6
+    for pa_, pb_ in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pa_.data, pb_.data, atol=1e-6, rtol=1e-6)
+    g = torch.Generator().manual_seed(2)
+    cands = torch.randn(300, 16, generator=g).to(device)
+    ident = torch.randperm(5000, generator=g)[:300].to(device)
+    enc = a.to_top_k_encoder(cands, ident, k=7)
+    qschema = schema.select_by_tag(S.Tags.USER)
+    frame = enc.batch_predict(data, batch_size=64, schema=qschema, output_schema=mm.Schema([qschema.first]))
+    whole = enc({c.name: torch.from_numpy(data[c.name]).to(device) for c in qschema})
+    assert list(frame)[0] == qschema.first.name and list(frame)[1:] == mm.TopKPrediction.output_names(7)
+    np.testing.assert_array_equal(np.stack([frame[f"id_{i}"] for i in range(7)], 1), whole.identifiers.cpu().numpy())
+    np.testing.assert_allclose(np.stack([frame[f"score_{i}"] for i in range(7)], 1), whole.scores.cpu().numpy(), atol=1e-6)
+    np.testing.assert_array_equal(frame[qschema.first.name], data[qschema.first.name])

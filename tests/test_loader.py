@@ -1,0 +1,109 @@
+"""models_amd.loader.Loader: the PrepareFeatures input contract from Parquet / DataFrames (host logic, CPU)."""
+import numpy as np
+import pytest
+import torch
+
+import models_amd as mm
+from models_amd import schema as S
+
+pa = pytest.importorskip("pyarrow")
+pq = pytest.importorskip("pyarrow.parquet")
+
+
+def _frame(n=103, seed=0):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 5, size=n)
+    lists = [rng.integers(0, 50, size=int(l)).tolist() for l in lens]
+    return {
+        "user": rng.integers(0, 1000, size=n).astype(np.int64),
+        "item": rng.integers(0, 200, size=n).astype(np.int32),
+        "genres": lists,
+        "price": rng.random(n).astype(np.float64),
+        "click": rng.integers(0, 2, size=n).astype(np.int8),
+    }, lists
+
+
+def _schema():
+    return mm.Schema([S.categorical("user", 1000), S.categorical("item", 200), S.categorical("genres", 50, is_list=True, is_ragged=True),
+                      S.continuous("price"), S.binary_target("click")])
+
+
+@pytest.fixture()
+def parquet_path(tmp_path):
+    data, lists = _frame()
+    table = pa.table({k: (pa.array(v) if k != "genres" else pa.array(v, type=pa.list_(pa.int64()))) for k, v in data.items()})
+    p = tmp_path / "part0.parquet"
+    pq.write_table(table, p)
+    return p, data, lists
+
+
+def test_sequential_batches_reproduce_the_file(parquet_path):
+    p, data, lists = parquet_path
+    ld = mm.Loader(p, _schema(), batch_size=32, shuffle=False, device="cpu")
+    assert len(ld) == 4
+    seen = 0
+    for inputs, y in ld:
+        B = y.shape[0]
+        assert inputs["user"].dtype == torch.int64 and inputs["item"].dtype == torch.int32
+        assert inputs["price"].shape == (B, 1) and inputs["price"].dtype == torch.float32 and y.shape == (B, 1)
+        np.testing.assert_array_equal(inputs["user"].numpy(), data["user"][seen:seen + B])
+        np.testing.assert_allclose(inputs["price"].numpy()[:, 0], data["price"][seen:seen + B].astype(np.float32))
+        np.testing.assert_array_equal(y.numpy()[:, 0], data["click"][seen:seen + B].astype(np.float32))
+        offs, vals = inputs["genres__offsets"].numpy(), inputs["genres__values"].numpy()
+        assert offs[0] == 0 and offs.shape[0] == B + 1 and offs.dtype == vals.dtype
+        for b in range(B):
+            assert vals[offs[b]:offs[b + 1]].tolist() == lists[seen + b]
+        seen += B
+    assert seen == 103
+    # the dict is exactly what prepare_features consumes
+    from models_amd.models import prepare_features
+
+    x = prepare_features(inputs)
+    assert isinstance(x["genres"], mm.Ragged) and x["user"].shape[1] == 1
+
+
+def test_shuffle_is_a_permutation_and_reseeds_per_epoch(parquet_path):
+    p, data, lists = parquet_path
+    ld = mm.Loader(p, _schema(), batch_size=16, shuffle=True, seed=3, device="cpu", drop_last=True)
+    assert len(ld) == 6
+    e1 = np.concatenate([i["user"].numpy() for i, _ in ld])
+    e2 = np.concatenate([i["user"].numpy() for i, _ in ld])
+    assert e1.shape[0] == 96 and not np.array_equal(e1, e2)
+    full = mm.Loader(p, _schema(), batch_size=16, shuffle=True, seed=3, device="cpu")
+    users, genres = [], []
+    for i, _ in full:
+        users.append(i["user"].numpy())
+        o, v = i["genres__offsets"].numpy(), i["genres__values"].numpy()
+        genres += [v[o[b]:o[b + 1]].tolist() for b in range(len(o) - 1)]
+    users = np.concatenate(users)
+    assert sorted(users.tolist()) == sorted(data["user"].tolist())
+    # rows stay intact under the shuffle: every (user, genres) pair of the output exists in the file
+    want = {}
+    for u, g in zip(data["user"].tolist(), lists):
+        want.setdefault(u, []).append(g)
+    for u, g in zip(users.tolist(), genres):
+        assert g in want[u]
+
+
+def test_ranks_read_disjoint_equal_slices_and_dict_input():
+    data, lists = _frame(100)
+    offs = np.concatenate([[0], np.cumsum([len(l) for l in lists])])
+    arrays = dict(data)
+    arrays["genres"] = (np.concatenate([np.asarray(l, dtype=np.int64) for l in lists]), offs)
+    got = []
+    for r in range(4):
+        ld = mm.Loader(arrays, _schema(), batch_size=10, shuffle=False, device="cpu", global_rank=r, global_size=4)
+        assert ld.n_rows == 25 and len(ld) == 3
+        got.append(np.concatenate([i["user"].numpy() for i, _ in ld]))
+    np.testing.assert_array_equal(np.concatenate(got), data["user"])
+
+
+def test_errors():
+    data, _ = _frame(10)
+    with pytest.raises(ValueError):
+        mm.Loader(data, _schema(), batch_size=0, device="cpu")
+    bad = dict(data)
+    bad["user"] = bad["user"].astype(np.float32)
+    bad["genres"] = (np.zeros(0, np.int64), np.zeros(11, np.int64))
+    with pytest.raises(TypeError):
+        mm.Loader(bad, _schema(), batch_size=4, device="cpu")
