@@ -9,8 +9,10 @@ resident in HBM: 26 categorical lookups (Criteo cardinalities capped at 1 M rows
 dense features -> bottom MLP [128, 64] -> pairwise dot interaction -> top MLP [128, 64, 32] ->
 sigmoid head (``--mode fwd``), plus loss, backward and the optimizer update (``--mode train``).
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel: the multi-table embedding gather, HBM-bound) and ``cpu_baseline``
-(the numpy oracle timed on the host cores on a bounded sample of the same workload).
+``roofline`` (the launch that takes the most time of the step -- the fused embedding backward in train mode, HBM-bound;
+``roofline_gather`` carries the multi-table gather next to it) and ``cpu_baseline`` (the numpy oracle timed on the
+host cores on a bounded sample of the same workload, at N = 1).  At N > 1 large tables are row-sharded and the
+step runs eagerly (RCCL all-to-all needs host-side split sizes).
 """
 from __future__ import annotations
 
