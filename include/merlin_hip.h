@@ -207,6 +207,11 @@ int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int
  * (DenseMaybeLowRank, blocks/mlp.py:304-396, low_rank_dim=None). x0, x, out: [M, d]. */
 int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, const float* b,
                            int64_t M, int32_t d, float* out, mh_stream_t stream);
+/* Low-rank form W = U V (DCN-v2 Eq. 2; DenseMaybeLowRank with low_rank_dim = r, blocks/mlp.py:365-396):
+ * h[M, r] = x U comes from mh_linear_bias_act_fwd (no bias, no activation); this call finishes the layer,
+ * out = x0 * (h V + b) + x with V[r, d].  All matrices contiguous. */
+int32_t mh_cross_layer_lowrank_fwd(const float* x0, const float* x, const float* h, const float* V, const float* b,
+                                   int64_t M, int32_t d, int32_t r, float* out, mh_stream_t stream);
 
 /* ---- a10: L2 row normalisation (transforms/regularization.py:26-80) --------------------
  * y = x / max(||x||_2, eps) per row  == tf.linalg.l2_normalize(x, axis=-1, epsilon=eps^2). */

@@ -351,31 +351,46 @@ def _widen(x: torch.Tensor, d4: int) -> torch.Tensor:
 
 
 class Cross(Block):
-    """One DCN-v2 cross layer x0 * (x W + b) + x (cross.py:113-202), full-rank kernel.
+    """One DCN-v2 cross layer x0 * (x W + b) + x (cross.py:113-202): full-rank kernel W [d, d], or, with
+    ``low_rank_dim = r``, W = U V with U [d, r] (no bias) and V [r, d] (DenseMaybeLowRank, mlp.py:365-396).
 
-    The feature width d (3341 on the Criteo DCN config) is rarely a multiple of 4; kernel and bias are stored
-    zero-padded to d4 = ceil(d/4)*4 so that every row of x / W is 16-byte aligned for the vector loads of the
+    The feature width d (3341 on the Criteo DCN config) is rarely a multiple of 4; kernels and bias are stored
+    zero-padded to d4 = ceil(d/4)*4 (r4 likewise) so that every row is 16-byte aligned for the vector loads of the
     MFMA GEMM.  Pad rows / columns stay exactly zero under SGD and Adagrad (their gradients are zero);
-    ``kernel.data[:d, :d]`` is the reference-shaped weight."""
+    ``kernel.data[:d, :d]`` (``kernel_u.data[:d, :r]``, ``kernel.data[:r, :d]``) is the reference-shaped weight."""
 
-    def __init__(self, name: Optional[str] = None, device=None, seed: Optional[int] = None):
+    def __init__(self, low_rank_dim: Optional[int] = None, name: Optional[str] = None, device=None,
+                 seed: Optional[int] = None):
         super().__init__(name)
+        if low_rank_dim is not None and low_rank_dim < 1:
+            raise ValueError("low_rank_dim must be positive")
+        self.low_rank_dim = low_rank_dim
         self.device = torch.device(device) if device is not None else default_device()
         self.seed = _next_seed() if seed is None else seed
         self.kernel: Optional[Parameter] = None
+        self.kernel_u: Optional[Parameter] = None
         self.bias: Optional[Parameter] = None
-        self.d = self.d4 = None
+        self.d = self.d4 = self.r4 = None
 
     def build(self, d: int):
         # CrossBlock default kernel_initializer="truncated_normal", bias "zeros" (cross.py:34-35)
         self.d, self.d4 = d, (d + 3) // 4 * 4
-        w = torch.zeros((self.d4, self.d4))
-        w[:d, :d] = _truncated_normal((d, d), 0.05, self.seed)
+        if self.low_rank_dim is None:
+            w = torch.zeros((self.d4, self.d4))
+            w[:d, :d] = _truncated_normal((d, d), 0.05, self.seed)
+        else:
+            r = self.low_rank_dim
+            self.r4 = (r + 3) // 4 * 4
+            u = torch.zeros((self.d4, self.r4))
+            u[:d, :r] = _truncated_normal((d, r), 0.05, self.seed + 1)
+            self.kernel_u = Parameter(u.to(self.device), name=f"{self.name}/kernel_u")
+            w = torch.zeros((self.r4, self.d4))
+            w[:r, :d] = _truncated_normal((r, d), 0.05, self.seed)
         self.kernel = Parameter(w.to(self.device), name=f"{self.name}/kernel")
         self.bias = Parameter(torch.zeros(self.d4, device=self.device), name=f"{self.name}/bias")
 
     def own_parameters(self):
-        return [p for p in (self.kernel, self.bias) if p is not None]
+        return [p for p in (self.kernel_u, self.kernel, self.bias) if p is not None]
 
     def forward(self, inputs):
         x0, x = inputs if isinstance(inputs, tuple) else (inputs, inputs)
@@ -386,19 +401,27 @@ class Cross(Block):
         d, d4 = self.d, self.d4
         x0w, xw = _widen(x0, d4), _widen(x, d4)
         self._x0, self._x = x0w, xw
-        return ops.cross_layer(x0w, xw, self.kernel.data, self.bias.data)[:, :d]
+        if self.kernel_u is None:
+            return ops.cross_layer(x0w, xw, self.kernel.data, self.bias.data)[:, :d]
+        self._h = ops.linear(xw, self.kernel_u.data, None, None)  # [B, r4], pad columns exactly zero
+        return ops.cross_layer_lowrank(x0w, xw, self._h, self.kernel.data, self.bias.data)[:, :d]
 
     def backward(self, dout):
-        """out = x0 * p + x with p = x W + b: returns (dx0, dx); sets kernel / bias grads."""
+        """out = x0 * p + x with p = x W + b (W = U V when low-rank): returns (dx0, dx); sets the grads."""
         x0, x = self._x0, self._x
         d, d4 = self.d, self.d4
         dout = _widen(dout, d4)
-        p = ops.linear(x, self.kernel.data, self.bias.data, None)  # recomputed, not stored
+        src = x if self.kernel_u is None else self._h
+        p = ops.linear(src, self.kernel.data, self.bias.data, None)  # recomputed, not stored
         dx0 = ops.eltwise("mul", dout, p)
-        g = ops.eltwise("mul", dout, x0)                           # d loss / d p
-        dx_lin, dW, db = ops.linear_backward(x, self.kernel.data, None, g, None, need_dx=True, need_db=True)
+        g = ops.eltwise("mul", dout, x0)                             # d loss / d p
+        dsrc, dW, db = ops.linear_backward(src, self.kernel.data, None, g, None, need_dx=True, need_db=True)
         self.kernel.grad, self.bias.grad = dW, db
-        return dx0, ops.eltwise("add", _widen(dx_lin, d4), dout)  # both [B, d4], pad columns zero
+        if self.kernel_u is not None:
+            dh = _widen(dsrc, self.r4)
+            dsrc, dU, _ = ops.linear_backward(x, self.kernel_u.data, None, dh, None, need_dx=True, need_db=False)
+            self.kernel_u.grad = dU
+        return dx0, ops.eltwise("add", _widen(dsrc, d4), dout)  # both [B, d4], pad columns zero
 
 
 class CrossBlock(Block):
@@ -406,9 +429,9 @@ class CrossBlock(Block):
 
     def __init__(self, depth: int = 1, low_rank_dim: Optional[int] = None, name: Optional[str] = None, device=None):
         super().__init__(name)
-        if low_rank_dim is not None:
-            raise NotImplementedError("low-rank cross kernels are not on the HIP hot path yet")
-        self.layers = [Cross(device=device) for _ in range(depth)]
+        if depth <= 0:
+            raise ValueError(f"Number of cross layers (depth) should be positive but is {depth}.")
+        self.layers = [Cross(low_rank_dim=low_rank_dim, device=device) for _ in range(depth)]
         self.pre_aggregation = ConcatFeatures()
 
     def children(self):

@@ -155,6 +155,14 @@ int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, cons
     return mh_internal_linear(x, d, W, b, M, d, d, MH_ACT_NONE, out, d, x0, x, mh_stream(stream));
 }
 
+int32_t mh_cross_layer_lowrank_fwd(const float* x0, const float* x, const float* h, const float* V, const float* b,
+                                   int64_t M, int32_t d, int32_t r, float* out, mh_stream_t stream) {
+    MH_REQUIRE(x0 && x && h && V && out, "mh_cross_layer_lowrank_fwd: null argument");
+    MH_REQUIRE(M >= 0 && d >= 5 && r >= 1, "mh_cross_layer_lowrank_fwd: bad shape M=%lld d=%d r=%d", (long long)M, d, r);
+    if (M == 0) return MH_OK;
+    return mh_internal_linear(h, r, V, b, M, r, d, MH_ACT_NONE, out, d, x0, x, mh_stream(stream));
+}
+
 }  // extern "C"
 
 int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N,

@@ -144,10 +144,10 @@ class DCNBody(Block):
     concat(cross, deep) (parallel)."""
 
     def __init__(self, schema: Schema, depth: int, deep_block: Block, stacked: bool = True, input_block=None,
-                 embedding_dim: Optional[int] = None, device=None):
+                 embedding_dim: Optional[int] = None, device=None, low_rank_dim: Optional[int] = None):
         super().__init__("dcn_body")
         self.input_block = input_block or InputBlockV2(schema, dim=embedding_dim, device=device)
-        self.cross = CrossBlock(depth, device=device)
+        self.cross = CrossBlock(depth, low_rank_dim=low_rank_dim, device=device)
         self.deep = deep_block
         self.stacked = stacked
 
@@ -161,18 +161,24 @@ class DCNBody(Block):
         return torch.cat([self.cross(x), self.deep(x)], dim=-1)
 
     def backward(self, grad):
-        if not self.stacked:
-            raise NotImplementedError("backward of the parallel DCN variant is not on the HIP path yet")
-        g = self.deep.backward(grad)
-        g = self.cross.backward(g)
-        return self.input_block.backward(g)
+        if self.stacked:
+            g = self.deep.backward(grad)
+            g = self.cross.backward(g)
+            return self.input_block.backward(g)
+        # parallel form: the head saw concat([cross(x), deep(x)]); both branches read the same x
+        d = self.cross.layers[0].d
+        gc = self.cross.backward(grad[:, :d].contiguous())
+        gd = self.deep.backward(grad[:, d:].contiguous())
+        return self.input_block.backward(ops.eltwise("add", gc.contiguous(), gd.contiguous()))
 
 
 def DCNModel(schema: Schema, depth: int, deep_block: Optional[Block] = None, stacked: bool = True,
-             input_block=None, embedding_dim: Optional[int] = None, prediction_tasks=None, device=None) -> RankingModel:
-    """ranking.py:95-168 (deep_block default MLPBlock([512, 256]), :98)."""
+             input_block=None, embedding_dim: Optional[int] = None, prediction_tasks=None, device=None,
+             low_rank_dim: Optional[int] = None) -> RankingModel:
+    """ranking.py:95-168 (deep_block default MLPBlock([512, 256]), :98; ``**kwargs`` of the reference reach
+    ``CrossBlock``, of which ``low_rank_dim`` is the one on the hot path)."""
     deep_block = deep_block or MLPBlock([512, 256], device=device)
-    body = DCNBody(schema, depth, deep_block, stacked, input_block, embedding_dim, device)
+    body = DCNBody(schema, depth, deep_block, stacked, input_block, embedding_dim, device, low_rank_dim)
     head = prediction_tasks or BinaryOutput(_target_column(schema), device=device)
     return RankingModel(body, head, schema, name="dcn_model")
 

@@ -765,6 +765,25 @@ def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[
     return out
 
 
+def cross_layer_lowrank(x0: torch.Tensor, x: torch.Tensor, h: torch.Tensor, V: torch.Tensor,
+                        b: Optional[torch.Tensor]) -> torch.Tensor:
+    """Second half of a low-rank cross layer: ``x0 * (h @ V + b) + x`` with ``h = x @ U`` [M, r], ``V`` [r, d]."""
+    lib = _lib.load()
+    for n_, t in (("x0", x0), ("x", x), ("h", h), ("V", V)):
+        _dev(t, n_, torch.float32)
+        if t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"{n_} must be contiguous 2-D")
+    M, d = x.shape
+    r = h.shape[1]
+    if V.shape != (r, d) or x0.shape != x.shape or h.shape[0] != M:
+        raise ValueError("cross_layer_lowrank: shapes must be x0, x [M, d], h [M, r], V [r, d]")
+    out = torch.empty_like(x)
+    with _timed(f"cross_lowrank_{d}x{r}"):
+        check(lib.mh_cross_layer_lowrank_fwd(_ptr(x0), _ptr(x), _ptr(h), _ptr(V), _ptr(b), M, d, r, _ptr(out), _stream()),
+              "mh_cross_layer_lowrank_fwd")
+    return out
+
+
 def eltwise(op: str, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mul``: a*b, ``add``: a+b, ``fma``: a*b+c on contiguous fp32 tensors of one shape."""
     lib = _lib.load()

@@ -95,6 +95,21 @@ def main():
     me4 = types.SimpleNamespace(values=lins, concat=None)
     x = torch.randn(11, d, generator=g)
     out.update(cr_x=x, cr_y=cross_fwd(me4, x).detach())
+    # low-rank variant (DCN-v2 Eq. 2; TF: DenseMaybeLowRank = Dense(r, no bias) then Dense(d), blocks/mlp.py:365-396)
+    r = 6
+    lows = []
+    for i in range(depth):
+        u, v = torch.nn.Linear(d, r, bias=False), torch.nn.Linear(r, d)
+        with torch.no_grad():
+            u.weight.copy_(torch.randn(r, d, generator=g) * 0.2)
+            v.weight.copy_(torch.randn(d, r, generator=g) * 0.2)
+            v.bias.copy_(torch.randn(d, generator=g) * 0.1)
+        out[f"crl_U{i}"] = u.weight.detach().T.contiguous()  # [d, r]
+        out[f"crl_V{i}"] = v.weight.detach().T.contiguous()  # [r, d]
+        out[f"crl_b{i}"] = v.bias.detach()
+        lows.append(torch.nn.Sequential(u, v))
+    me5 = types.SimpleNamespace(values=lows, concat=None)
+    out.update(crl_y=cross_fwd(me5, x).detach())
 
     # --- inferred embedding dims ----------------------------------------------------------------
     emb = load("merlin/models/utils/schema_utils.py", "get_embedding_size_from_cardinality")

@@ -29,6 +29,8 @@ def test_oracle_interaction_matches_reference_vectors(f, d):
 def test_oracle_cross_matches_reference_vectors():
     layers = [(G[f"cr_W{i}"], G[f"cr_b{i}"]) for i in range(3)]
     np.testing.assert_allclose(O.cross_block(G["cr_x"], layers), G["cr_y"], atol=1e-4, rtol=1e-5)
+    low = [(G[f"crl_U{i}"], G[f"crl_V{i}"], G[f"crl_b{i}"]) for i in range(3)]
+    np.testing.assert_allclose(O.cross_block(G["cr_x"], low), G["crl_y"], atol=1e-4, rtol=1e-5)
 
 
 def test_inferred_embedding_dims_match_reference():
@@ -78,3 +80,8 @@ def test_hip_cross_matches_reference_vectors(device):
     for i in range(3):
         x = ops.cross_layer(x0, x, t(G[f"cr_W{i}"]), t(G[f"cr_b{i}"]))
     np.testing.assert_allclose(x.cpu().numpy(), G["cr_y"], atol=ATOL, rtol=1e-5)
+    x = x0  # low-rank layers: h = x U (Dense without bias), then the cross epilogue on h V + b
+    for i in range(3):
+        h = ops.linear(x, t(G[f"crl_U{i}"]), None, None)
+        x = ops.cross_layer_lowrank(x0, x, h, t(G[f"crl_V{i}"]), t(G[f"crl_b{i}"]))
+    np.testing.assert_allclose(x.cpu().numpy(), G["crl_y"], atol=ATOL, rtol=1e-5)

@@ -327,3 +327,71 @@ def test_loader_feeds_train_steps_and_batch_predict(device):
     np.testing.assert_array_equal(np.stack([frame[f"id_{i}"] for i in range(7)], 1), whole.identifiers.cpu().numpy())
     np.testing.assert_allclose(np.stack([frame[f"score_{i}"] for i in range(7)], 1), whole.scores.cpu().numpy(), atol=1e-6)
     np.testing.assert_array_equal(frame[qschema.first.name], data[qschema.first.name])
+
+
+@pytest.mark.parametrize("stacked", [True, False])
+@pytest.mark.parametrize("low_rank_dim", [None, 6])
+def test_dcn_variants_train_step_matches_torch(device, stacked, low_rank_dim):
+    """Low-rank cross kernels (W = U V) and the parallel DCN form (concat(cross, deep)): forward and one SGD step
+    against torch autograd on the reference-shaped weights."""
+    schema = _dcn_schema()
+    lr = 0.05
+    model = mm.DCNModel(schema, depth=2, deep_block=mm.MLPBlock([32, 16], device=device), embedding_dim=16,
+                        device=device, stacked=stacked, low_rank_dim=low_rank_dim)
+    model.compile(optimizer="sgd", learning_rate=lr)
+    g = torch.Generator().manual_seed(4)
+    x, xd = _batch(schema, 150, g, device)
+    y = torch.randint(0, 2, (150, 1), generator=g).float()
+    p = model(xd)
+    body = model.body
+    inp = body.input_block
+    tables = {n: inp.categorical.feature_table[n].table.data.cpu().clone().requires_grad_() for n in inp.categorical.feature_names}
+    dc, r = body.cross.layers[0].d, low_rank_dim
+
+    def leaf(t):
+        return t.cpu().clone().requires_grad_()
+
+    if r is None:
+        cross = [(leaf(l.kernel.data[:dc, :dc]), leaf(l.bias.data[:dc])) for l in body.cross.layers]
+    else:
+        cross = [(leaf(l.kernel_u.data[:dc, :r]), leaf(l.kernel.data[:r, :dc]), leaf(l.bias.data[:dc])) for l in body.cross.layers]
+    deep = [(leaf(l.kernel.data), leaf(l.bias.data), l.activation) for l in body.deep.layers]
+    hd = model.output.to_call
+    head = (leaf(hd.kernel.data), leaf(hd.bias.data))
+
+    def fwd():
+        feats = {n: tables[n][x[n].reshape(-1)] for n in tables}
+        feats.update({k: v for k, v in x.items() if k.startswith("I")})
+        h0 = torch.cat([feats[k] for k in sorted(feats)], dim=1)
+        h = h0
+        for layer in cross:
+            proj = (h @ layer[0] + layer[1]) if r is None else ((h @ layer[0]) @ layer[1] + layer[2])
+            h = h0 * proj + h
+        dd = h if stacked else h0
+        for W, b, a in deep:
+            dd = R.act(dd @ W + b, a)
+        out = dd if stacked else torch.cat([h, dd], dim=1)
+        return torch.sigmoid(out @ head[0] + head[1])
+
+    np.testing.assert_allclose(p.cpu().numpy(), fwd().detach().numpy(), atol=ATOL)
+    loss = model.train_step(xd, y.to(device))
+    ref_loss = R.keras_bce(fwd(), y)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    params = list(tables.values()) + [t for l in cross for t in l] + [t for l in deep for t in l[:2]] + list(head)
+    grads = torch.autograd.grad(ref_loss, params)
+    with torch.no_grad():
+        for pp, gr in zip(params, grads):
+            pp -= lr * gr
+    for n, t in tables.items():
+        torch.testing.assert_close(inp.categorical.feature_table[n].table.data.cpu(), t.detach(), atol=1e-4, rtol=1e-4)
+    for l, ref in zip(body.cross.layers, cross):
+        if r is None:
+            torch.testing.assert_close(l.kernel.data[:dc, :dc].cpu(), ref[0].detach(), atol=1e-4, rtol=1e-4)
+        else:
+            torch.testing.assert_close(l.kernel_u.data[:dc, :r].cpu(), ref[0].detach(), atol=1e-4, rtol=1e-4)
+            torch.testing.assert_close(l.kernel.data[:r, :dc].cpu(), ref[1].detach(), atol=1e-4, rtol=1e-4)
+            assert torch.all(l.kernel_u.data[dc:] == 0) and torch.all(l.kernel_u.data[:, r:] == 0)  # pads stay zero
+        torch.testing.assert_close(l.bias.data[:dc].cpu(), ref[-1].detach(), atol=1e-4, rtol=1e-4)
+    for l, (W, b, _) in zip(body.deep.layers, deep):
+        torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(hd.kernel.data.cpu(), head[0].detach(), atol=1e-4, rtol=1e-4)
