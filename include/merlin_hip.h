@@ -217,6 +217,10 @@ int32_t mh_cross_layer_lowrank_fwd(const float* x0, const float* x, const float*
  * y = x / max(||x||_2, eps) per row  == tf.linalg.l2_normalize(x, axis=-1, epsilon=eps^2). */
 int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y,
                        mh_stream_t stream);
+/* Backward of the same (x is the forward INPUT): dx = (dy - y (y . dy)) / max(||x||, eps), and dx = dy / eps
+ * for rows below the clamp.  x, dy, dx contiguous [M, N]. */
+int32_t mh_l2norm_rows_bwd(const float* x, const float* dy, int64_t M, int32_t N, float eps, float* dx,
+                           mh_stream_t stream);
 
 /* DotProduct.call (outputs/base.py:307-310): out[m] = sum_n a[m,n] * b[m,n]  (positive scores;
  * the inference branch of ContrastiveOutput, outputs/contrastive.py:221). */

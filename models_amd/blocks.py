@@ -480,6 +480,7 @@ class TwoTowerBlock(ParallelBlock):
     def forward(self, inputs: TabularData):
         out = super().forward(inputs)
         if self.l2_normalization:
+            self._raw = out  # tower outputs before the normalisation: its backward needs them
             out = {k: ops.l2norm(v) for k, v in out.items()}
         return out
 

@@ -65,6 +65,31 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
     for (int k = lane; k < N; k += 64) y[row * N + k] = xr[k] * inv;
 }
 
+// backward of the row normalisation: with s = sum x^2, inv = rsqrt(max(s, eps^2)) and y = x * inv,
+//   s >= eps^2:  dx = inv * (dy - y * (y . dy))        (the Jacobian of x / ||x||)
+//   s <  eps^2:  dx = inv * dy                          (the clamp makes inv a constant)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        int64_t M, int N, float eps, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * N;
+    const float* gr = dy + row * N;
+    float s = 0.f, xg = 0.f;
+    for (int k = lane; k < N; k += 64) {
+        s = fmaf(xr[k], xr[k], s);
+        xg = fmaf(xr[k], gr[k], xg);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off);
+        xg += __shfl_xor(xg, off);
+    }
+    const float inv = rsqrtf(fmaxf(s, eps * eps));
+    const float c = (s >= eps * eps) ? xg * inv * inv : 0.f;  // (y . dy) * inv, folded: dx = inv * (dy - x * c)
+    for (int k = lane; k < N; k += 64) dx[row * N + k] = inv * (gr[k] - xr[k] * c);
+}
+
 // DotProduct.call (outputs/base.py:307-310): out[b] = sum_d a[b,d] * b[b,d], k-ascending per
 // 16-lane partial chains + shuffle tree.
 __global__ __launch_bounds__(256) void rowwise_dot_kernel(const float* __restrict__ a, int64_t lda,
@@ -258,6 +283,16 @@ int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y
     hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, M, N,
                        eps, y);
     MH_CHECK_LAUNCH("mh_l2norm_rows");
+    return MH_OK;
+}
+
+int32_t mh_l2norm_rows_bwd(const float* x, const float* dy, int64_t M, int32_t N, float eps, float* dx,
+                           mh_stream_t stream) {
+    MH_REQUIRE(x && dy && dx && N >= 1, "mh_l2norm_rows_bwd: bad argument");
+    if (M <= 0) return MH_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, dy, M,
+                       N, eps, dx);
+    MH_CHECK_LAUNCH("mh_l2norm_rows_bwd");
     return MH_OK;
 }
 

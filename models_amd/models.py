@@ -200,8 +200,6 @@ class RetrievalModel(Model):
         """fwd (fused scorer: no [B, B] logits in HBM) -> bwd -> fused updates."""
         if self.optimizer is None:
             self.compile()
-        if self.body.l2_normalization:
-            raise NotImplementedError("training with l2_normalization is not on the HIP path yet")
         x = prepare_features(inputs)
         emb = self.body(x)
         q, it = emb["query"], emb["item"]
@@ -212,9 +210,13 @@ class RetrievalModel(Model):
         res = ops.inbatch_softmax(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score, materialize=False)
         dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
                                                        out.false_negative_score)
+        ditem = ops.eltwise("add", ditem, dneg)
+        if self.body.l2_normalization:  # L2Norm sits between the towers and the scorer (retrieval/base.py:98-121)
+            dq = ops.l2norm_backward(self.body._raw["query"], dq)
+            ditem = ops.l2norm_backward(self.body._raw["item"], ditem)
         with ops.SIDE.deferred():
             self.body.parallel_layers["query"].backward(dq)
-            self.body.parallel_layers["item"].backward(ops.eltwise("add", ditem, dneg))
+            self.body.parallel_layers["item"].backward(ditem)
             self.optimizer.apply(self)
         return res.loss.mean()
 

@@ -613,6 +613,19 @@ def l2norm(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     return y
 
 
+def l2norm_backward(x: torch.Tensor, dy: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """Gradient of ``l2norm`` w.r.t. its input ``x``."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    _dev(dy, "dy", torch.float32)
+    x, dy = x.contiguous(), dy.contiguous()
+    if x.shape != dy.shape or x.dim() != 2:
+        raise ValueError("l2norm_backward: x and dy must be [M, N]")
+    dx = torch.empty_like(x)
+    check(lib.mh_l2norm_rows_bwd(_ptr(x), _ptr(dy), x.shape[0], x.shape[1], eps, _ptr(dx), _stream()), "mh_l2norm_rows_bwd")
+    return dx
+
+
 def rowwise_dot(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """sum(a * b, -1, keepdims=True)."""
     lib = _lib.load()

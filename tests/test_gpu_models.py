@@ -83,11 +83,12 @@ def test_top_k_encoder_matches_matmul_topk_gather(device):
         mm.BruteForce(3).index(cands, ident[:5])
 
 
-@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
-def test_two_tower_train_steps_match_torch(device, opt):
+@pytest.mark.parametrize("opt,l2", [("sgd", False), ("adagrad", False), ("sgd", True)])
+def test_two_tower_train_steps_match_torch(device, opt, l2):
     schema = _two_tower_schema()
     lr, T = 0.05, 0.7
-    model = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16, device=device, logits_temperature=T)
+    model = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16, device=device,
+                             logits_temperature=T, l2_normalization=l2)
     model.compile(optimizer=opt, learning_rate=lr)
     g = torch.Generator().manual_seed(2)
     batches = [_batch(schema, 200, g, device) for _ in range(3)]
@@ -117,6 +118,9 @@ def test_two_tower_train_steps_match_torch(device, opt):
     for x, xd in batches:
         loss = model.train_step(xd)
         q, it = tower_t("query", x), tower_t("item", x)
+        if l2:  # tf.linalg.l2_normalize(x, axis=-1): x * rsqrt(max(sum x^2, 1e-12))
+            q = q * torch.rsqrt(torch.clamp((q * q).sum(-1, keepdim=True), min=1e-12))
+            it = it * torch.rsqrt(torch.clamp((it * it).sum(-1, keepdim=True), min=1e-12))
         ids = x["item_id"].reshape(-1)
         pos = (q * it).sum(-1, keepdim=True)
         neg = q @ it.T

@@ -193,3 +193,17 @@ def test_topk_metrics_match_reference_literals_and_oracle(device):
     m = ops.topk_metrics(pred.targets, 10).cpu().numpy()
     np.testing.assert_allclose(m[:, 0], 1.0)
     np.testing.assert_allclose(m[:, 5], 0.25)
+
+
+def test_l2norm_backward_matches_autograd_including_clamped_rows(device):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 48, generator=g)
+    x[5] = 0.0        # below the clamp: y = x / eps, constant scale
+    x[9] *= 1e-9
+    dy = torch.randn(37, 48, generator=g)
+    xr = x.clone().requires_grad_()
+    y = xr * torch.rsqrt(torch.clamp((xr * xr).sum(-1, keepdim=True), min=1e-12))
+    (y * dy).sum().backward()
+    got = ops.l2norm_backward(x.to(device), dy.to(device)).cpu()
+    torch.testing.assert_close(got, xr.grad, atol=1e-3, rtol=1e-4)  # rows 5 / 9 carry a 1e6 scale
+    torch.testing.assert_close(got[[0, 1, 2, 20]], xr.grad[[0, 1, 2, 20]], atol=1e-6, rtol=1e-5)
