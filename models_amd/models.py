@@ -72,6 +72,26 @@ class Model(Block):
     def train_step(self, inputs: TabularData, targets: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
+    @staticmethod
+    def _split(batch):
+        """A batch is ``inputs`` or ``(inputs, targets)`` (what ``models_amd.Loader`` yields)."""
+        if isinstance(batch, tuple):
+            return batch[0], (batch[1] if len(batch) > 1 else None)
+        return batch, None
+
+    def predict(self, batches) -> np.ndarray:
+        """Minimal ``Model.predict`` (models/base.py): forward over the batches, outputs concatenated on the host."""
+        outs = []
+        for batch in batches:
+            x, _ = self._split(batch)
+            y = self(x)
+            y = y.outputs if isinstance(y, Prediction) else y
+            outs.append(y.cpu().numpy())
+        return np.concatenate(outs) if outs else np.zeros((0, 1), np.float32)
+
+    def evaluate(self, batches, **kwargs) -> Dict[str, float]:
+        raise NotImplementedError
+
     def fit(self, batches: Iterable[Tuple[TabularData, torch.Tensor]], epochs: int = 1, steps_per_epoch: Optional[int] = None):
         """Minimal fit loop; samples/sec follows ExamplesPerSecondCallback
         (tf/logging/callbacks.py:174-189): batch_size * steps / elapsed, first step discarded."""
@@ -122,6 +142,45 @@ class RankingModel(Model):
                 self.body.backward(dh)
             self.optimizer.apply(self)
         return loss
+
+    def evaluate(self, batches, **kwargs) -> Dict[str, float]:
+        return _ranking_evaluate(self, batches)
+
+
+def _ranking_evaluate(model, batches) -> Dict[str, float]:
+    """loss = mean BCE over all samples, binary_accuracy at threshold 0.5 and AUC (the default metrics of
+    BinaryOutput, outputs/classification.py:72-123, minus precision / recall): losses come from the HIP BCE kernel,
+    the rank statistic of the AUC is host bookkeeping over the collected predictions."""
+    ps, ys, loss_sum, n = [], [], 0.0, 0
+    for batch in batches:
+        x, y = model._split(batch)
+        if y is None:
+            raise ValueError("evaluate needs (inputs, targets) batches")
+        p = model(x)
+        loss, _ = model.output.loss_and_grad(p, y, need_grad=False)
+        b = p.shape[0]
+        loss_sum += float(loss) * b
+        n += b
+        ps.append(p.reshape(-1).cpu().numpy())
+        ys.append(y.reshape(-1).cpu().numpy())
+    if n == 0:
+        return {"loss": float("nan"), "binary_accuracy": float("nan"), "auc": float("nan")}
+    p, y = np.concatenate(ps), np.concatenate(ys)
+    pos, neg = int((y > 0.5).sum()), int((y <= 0.5).sum())
+    auc = float("nan")
+    if pos and neg:
+        order = np.argsort(p, kind="stable")
+        ranks = np.empty(len(p), dtype=np.float64)
+        sp = p[order]
+        i = 0
+        while i < len(sp):  # average ranks over ties
+            j = i
+            while j + 1 < len(sp) and sp[j + 1] == sp[i]:
+                j += 1
+            ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+            i = j + 1
+        auc = float((ranks[y > 0.5].sum() - pos * (pos + 1) / 2.0) / (pos * neg))
+    return {"loss": loss_sum / n, "binary_accuracy": float(((p > 0.5) == (y > 0.5)).mean()), "auc": auc}
 
 
 def _target_column(schema: Schema) -> Optional[ColumnSchema]:
@@ -220,6 +279,30 @@ class RetrievalModel(Model):
             self.optimizer.apply(self)
         return res.loss.mean()
 
+    def evaluate(self, batches, k: int = 10, **kwargs) -> Dict[str, float]:
+        """In-batch evaluation as the reference runs it under ``testing=True`` (outputs/contrastive.py:223-344): every
+        sample is ranked against the other items of its batch (duplicates of its own item masked), the positive sits
+        in column 0 of the logits, and the top-k metrics of tf/metrics/topk.py are averaged over the samples."""
+        tot, n, loss_sum = None, 0, 0.0
+        for batch in batches:
+            x, _ = self._split(batch)
+            pred = self.forward(x, testing=True)
+            logits = pred.outputs  # [B, 1 + B]
+            B = logits.shape[0]
+            kk = min(k, logits.shape[1])
+            rank = (logits[:, 1:] > logits[:, :1]).sum(dim=1)  # ties resolve to the lower index = the positive
+            labels = (torch.arange(kk, device=logits.device).unsqueeze(0) == rank.unsqueeze(1)).float()
+            m = ops.topk_metrics(labels, kk, torch.ones(B, device=logits.device)).sum(dim=0)
+            tot = m if tot is None else tot + m
+            loss_sum += float(self.output.last_loss.mean()) * B
+            n += B
+        if n == 0:
+            return {}
+        vals = (tot / n).cpu().tolist()
+        out = {f"{name}_at_{k}": v for name, v in zip(ops.TOPK_METRIC_NAMES, vals)}
+        out["loss"] = loss_sum / n
+        return out
+
     def query_embeddings(self, inputs: TabularData) -> torch.Tensor:
         return self.body.parallel_layers["query"](prepare_features(inputs))
 
@@ -243,7 +326,25 @@ class TopKEncoder(Block):
 
     @property
     def k(self) -> int:
-        return self.topk_layer.to_call.k
+        return self.topk_layer.to_call._k
+
+    def evaluate(self, batches, item_id: str, k: Optional[int] = None) -> Dict[str, float]:
+        """Retrieval evaluation against the indexed catalogue (core/encoder.py:427-482 + outputs/topk.py:224-236):
+        the true item id of every query (feature ``item_id`` of the batch, or the batch's targets) is compared with
+        the top-k identifiers and the ranking metrics of tf/metrics/topk.py are averaged over the queries."""
+        k = self.k if k is None else k
+        tot, n = None, 0
+        for batch in batches:
+            x, y = Model._split(batch)
+            truth = y if y is not None else x[item_id]
+            pred = self.forward({kk_: v for kk_, v in x.items()}, targets=truth, testing=True, k=k)
+            B = pred.targets.shape[0]
+            m = ops.topk_metrics(pred.targets.contiguous(), k, torch.ones(B, device=pred.targets.device)).sum(dim=0)
+            tot = m if tot is None else tot + m
+            n += B
+        if n == 0:
+            return {}
+        return {f"{name}_at_{k}": v for name, v in zip(ops.TOPK_METRIC_NAMES, (tot / n).cpu().tolist())}
 
     def batch_predict(self, dataset, batch_size: Optional[int] = None, output_schema: Optional[Schema] = None,
                       schema: Optional[Schema] = None) -> Dict[str, np.ndarray]:

@@ -399,3 +399,57 @@ def test_dcn_variants_train_step_matches_torch(device, stacked, low_rank_dim):
     for l, (W, b, _) in zip(body.deep.layers, deep):
         torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(hd.kernel.data.cpu(), head[0].detach(), atol=1e-4, rtol=1e-4)
+
+
+def test_predict_and_evaluate_ranking_and_retrieval(device):
+    """Minimal Model.predict / evaluate (SURVEY 8b kept surface): BCE loss, accuracy and AUC for the ranking head;
+    in-batch top-k metrics for the retrieval model; catalogue top-k metrics for the TopKEncoder."""
+    from sklearn.metrics import roc_auc_score
+
+    # --- ranking ---
+    schema = _dcn_schema()
+    model = mm.DCNModel(schema, depth=1, deep_block=mm.MLPBlock([16], device=device), embedding_dim=8, device=device)
+    g = torch.Generator().manual_seed(8)
+    batches = []
+    for _ in range(3):
+        x, xd = _batch(schema, 90, g, device)
+        batches.append((xd, torch.randint(0, 2, (90, 1), generator=g).float().to(device)))
+    p = model.predict(batches)
+    y = np.concatenate([b[1].cpu().numpy() for b in batches])
+    assert p.shape == (270, 1)
+    np.testing.assert_allclose(p[:90], model(batches[0][0]).cpu().numpy(), atol=1e-7)
+    ev = model.evaluate(batches)
+    assert abs(ev["loss"] - float(O.binary_crossentropy(p, y).mean())) < 1e-5
+    assert abs(ev["binary_accuracy"] - float(((p > 0.5) == (y > 0.5)).mean())) < 1e-7
+    assert abs(ev["auc"] - roc_auc_score(y.reshape(-1), p.reshape(-1))) < 1e-9
+    # --- retrieval, in-batch ---
+    schema = _two_tower_schema()
+    tt = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16, device=device, logits_temperature=0.8)
+    rb = [_batch(schema, 120, g, device)[1] for _ in range(2)]
+    ev = tt.evaluate(rb, k=5)
+    want = np.zeros(6)
+    loss = 0.0
+    for xd in rb:
+        logits = tt(xd, testing=True).outputs.cpu().numpy()
+        srt = np.argsort(-logits, axis=1, kind="stable")[:, :5]  # ties -> lower index first (tf.math.top_k)
+        labels = (srt == 0).astype(np.float32)
+        want += O.topk_metrics(labels, np.ones(len(labels)), 5).sum(0)
+        lse = np.log(np.exp(logits - logits.max(1, keepdims=True)).sum(1)) + logits.max(1)
+        loss += float((lse - logits[:, 0]).sum())
+    want /= 240
+    for name, w in zip(("recall", "precision", "map", "dcg", "ndcg", "mrr"), want):
+        assert abs(ev[f"{name}_at_5"] - w) < 1e-5, name
+    assert abs(ev["loss"] - loss / 240) < 1e-4
+    # --- retrieval against an indexed catalogue ---
+    cands = torch.randn(300, 16, generator=g).to(device)
+    ident = torch.arange(300, dtype=torch.int32).to(device)
+    enc = tt.to_top_k_encoder(cands, ident, k=10)
+    ev = enc.evaluate(rb, item_id="item_id")
+    want = np.zeros(6)
+    for xd in rb:
+        ids = enc(xd).identifiers.cpu().numpy()
+        labels = (ids == xd["item_id"].cpu().numpy().reshape(-1, 1)).astype(np.float32)
+        want += O.topk_metrics(labels, np.ones(len(labels)), 10).sum(0)
+    want /= 240
+    for name, w in zip(("recall", "precision", "map", "dcg", "ndcg", "mrr"), want):
+        assert abs(ev[f"{name}_at_10"] - w) < 1e-5, name
