@@ -34,12 +34,22 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 
-def build_model(device, emb_dim=64, seed=0, dcn=False):
+def _cat_columns(extra_rows=0):
+    """(name, cardinality) of the categorical features: the 26 Criteo columns, plus one big table for config C4."""
+    from models_amd.synthetic import CRITEO_CARDINALITIES, CRITEO_CAT_NAMES
+
+    cols = list(zip(CRITEO_CAT_NAMES, CRITEO_CARDINALITIES))
+    if extra_rows:
+        cols.append(("C27", int(extra_rows)))
+    return cols
+
+
+def build_model(device, emb_dim=64, seed=0, dcn=False, extra_rows=0):
     import models_amd as mm
     from models_amd import schema as S
-    from models_amd.synthetic import CRITEO_CARDINALITIES, CRITEO_CAT_NAMES, CRITEO_CONT_NAMES
+    from models_amd.synthetic import CRITEO_CONT_NAMES
 
-    cols = [S.categorical(n, v) for n, v in zip(CRITEO_CAT_NAMES, CRITEO_CARDINALITIES)]
+    cols = [S.categorical(n, v) for n, v in _cat_columns(extra_rows)]
     cols += [S.continuous(n) for n in CRITEO_CONT_NAMES]
     cols.append(S.binary_target("label"))
     schema = mm.Schema(cols)
@@ -51,12 +61,12 @@ def build_model(device, emb_dim=64, seed=0, dcn=False):
     return model, schema
 
 
-def make_batch(device, B, rank, dist="uniform"):
-    from models_amd.synthetic import CRITEO_CARDINALITIES, CRITEO_CAT_NAMES, CRITEO_CONT_NAMES, lognormal_ids
+def make_batch(device, B, rank, dist="uniform", extra_rows=0):
+    from models_amd.synthetic import CRITEO_CONT_NAMES, lognormal_ids
 
     rng = np.random.default_rng(1234 + rank)
     batch = {}
-    for n, v in zip(CRITEO_CAT_NAMES, CRITEO_CARDINALITIES):
+    for n, v in _cat_columns(extra_rows):
         ids = rng.integers(0, v, size=B) if dist == "uniform" else lognormal_ids(rng, B, v - 1)
         batch[n] = torch.from_numpy(ids.astype(np.int32)).to(device)
     dense = rng.random(size=(B, len(CRITEO_CONT_NAMES)), dtype=np.float32)
@@ -204,6 +214,9 @@ def main():
     ap.add_argument("--optimizer", choices=["sgd", "adagrad", "adam"], default="adagrad")
     ap.add_argument("--shard-threshold", type=int, default=200_000, help="rows >= this are row-sharded when N > 1")
     ap.add_argument("--ids", choices=["uniform", "lognormal"], default="uniform")
+    ap.add_argument("--extra-table-rows", type=int, default=0,
+                    help="BASELINE configs[3] (C4): add one table of this many rows (100000000 = 25.6 GB fp32 at D=64), "
+                         "row-sharded over the ranks; the default 0 is the headline config C2")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16384)
@@ -229,9 +242,9 @@ def main():
         print(json.dumps(res))
         return
 
-    model, schema = build_model(device)
+    model, schema = build_model(device, extra_rows=args.extra_table_rows)
     model.compile(optimizer=args.optimizer, learning_rate=0.01)
-    batch, label = make_batch(device, args.batch, rank, args.ids)
+    batch, label = make_batch(device, args.batch, rank, args.ids, args.extra_table_rows)
     model(batch)  # builds the lazily-shaped dense layers
 
     from models_amd.graph import GraphedStep
@@ -312,7 +325,7 @@ def main():
         if not ms:
             return None
         ach = alg_bytes[name] / (ms * 1e-3) / 1e9
-        traffic = pmc.get(name, {}).get("traffic_bytes") if (B == 65536 and args.ids == "uniform") else None
+        traffic = pmc.get(name, {}).get("traffic_bytes") if (B == 65536 and args.ids == "uniform" and not args.extra_table_rows) else None
         return {"kernel": kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2)" if traffic else None,
@@ -329,8 +342,11 @@ def main():
         "metric": "samples/sec at batch 64K (DLRM)", "value": world * B * args.steps / dt, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: DLRM 26 cat (Criteo cardinalities capped 1M) + 13 dense, "
-                               f"emb_dim=64, bottom [128,64], top [128,64,32], {args.mode}, ids={args.ids}",
+        "config": {"workload": (f"BASELINE configs[1]: DLRM 26 cat (Criteo cardinalities capped 1M) + 13 dense, "
+                                f"emb_dim=64, bottom [128,64], top [128,64,32], {args.mode}, ids={args.ids}"
+                                if not args.extra_table_rows else
+                                f"BASELINE configs[3]: configs[1] + one {args.extra_table_rows}-row table (row-sharded at N > 1), "
+                                f"{args.mode}, ids={args.ids}"),
                    "global_batch": world * B, "per_gpu_batch": B, "mode": args.mode,
                    "optimizer": args.optimizer if args.mode == "train" else None,
                    "launch": "eager" if (args.eager or world > 1 or force) else "hipGraph replay", "parallelism": f"dp{world}"},
@@ -338,7 +354,7 @@ def main():
         "roofline_gather": roofline_gather,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
     }
-    if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: at N > 1 the tables are sharded and a
+    if not args.no_cpu_baseline and world == 1 and not args.extra_table_rows:  # rank 0 at N = 1 only: at N > 1 the tables are sharded and a
         got = runner(batch)                       # forward is a collective[: min(args.cpu_batch, B)].cpu().numpy()  # GPU probabilities with the CURRENT weights
         base, ref = cpu_baseline(model, batch, label, min(args.cpu_batch, B), args.mode, args.optimizer)
         res["cpu_baseline"] = base
