@@ -354,8 +354,9 @@ def main():
         "roofline_gather": roofline_gather,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
     }
-    if not args.no_cpu_baseline and world == 1 and not args.extra_table_rows:  # rank 0 at N = 1 only: at N > 1 the tables are sharded and a
-        got = runner(batch)                       # forward is a collective[: min(args.cpu_batch, B)].cpu().numpy()  # GPU probabilities with the CURRENT weights
+    # CPU baseline on rank 0 at N = 1 only: at N > 1 the tables are sharded and a forward is a collective
+    if not args.no_cpu_baseline and world == 1 and not args.extra_table_rows:
+        got = runner(batch)[: min(args.cpu_batch, B)].cpu().numpy()  # GPU probabilities with the CURRENT weights
         base, ref = cpu_baseline(model, batch, label, min(args.cpu_batch, B), args.mode, args.optimizer)
         res["cpu_baseline"] = base
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref["prob"]).max())
