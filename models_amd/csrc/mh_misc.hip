@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p, c
 }
 
 // Same loss with the batch mean formed on the device in a fixed order: <= 256 workgroups grid-stride over the
-// samples and write one partial each, bce_mean_finish_kernel adds the partials sequentially -> deterministic.
+// samples and write one partial each, bce_mean_finish_kernel adds the partials in a fixed order -> deterministic.
 __global__ __launch_bounds__(256) void bce_mean_kernel(const float* __restrict__ p, const float* __restrict__ label,
                                                       int64_t M, float scale, float* __restrict__ partial,
                                                       float* __restrict__ dlogit) {
@@ -43,11 +43,15 @@ __global__ __launch_bounds__(256) void bce_mean_kernel(const float* __restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void bce_mean_finish_kernel(const float* __restrict__ partial, int nb, int64_t M, float* __restrict__ mean) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wavefront: lane l adds partials l, l + 64, l + 128, l + 192 in that order, then a fixed xor-shuffle tree
+__global__ __launch_bounds__(64) void bce_mean_finish_kernel(const float* __restrict__ partial, int nb, int64_t M,
+                                                            float* __restrict__ mean) {
+    const int lane = threadIdx.x;
     float t = 0.f;
-    for (int i = 0; i < nb; ++i) t += partial[i];
-    *mean = t / (float)M;
+    for (int i = lane; i < nb; i += 64) t += partial[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) *mean = t / (float)M;
 }
 
 // one 64-lane wavefront per row: tf.linalg.l2_normalize(x, axis=-1) = x * rsqrt(max(sum x^2, eps^2))

@@ -10,7 +10,7 @@ python bench.py
 python bench.py --mode fwd --no-cpu-baseline
 python bench.py --ids lognormal --no-cpu-baseline
 MH_FORCE_DISTRIBUTED=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline
-} 2>/dev/null | grep '^{' > $O/bench_lines.jsonl
+} 2>$O/bench_err.log | grep "^{" > $O/bench_lines.jsonl; test $(wc -l < $O/bench_lines.jsonl) -eq 4 || echo "!! a bench.py invocation printed no JSON line (see $O/bench_err.log)"
 {
 python bench.py --workload twotower
 python bench.py --workload topk
