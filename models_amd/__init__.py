@@ -18,7 +18,7 @@ from .outputs import (  # noqa: F401
     MIN_FLOAT, BinaryOutput, BruteForce, ContrastiveOutput, DotProduct, Prediction, TopKOutput, TopKPrediction,
 )
 from .models import (  # noqa: F401
-    DCNModel, DLRMModel, Model, RankingModel, RetrievalModel, TopKEncoder, TwoTowerModel, TwoTowerModelV2,
+    DCNModel, DLRMModel, Encoder, Model, RankingModel, RetrievalModel, TopKEncoder, TwoTowerModel, TwoTowerModelV2,
 )
 from .loader import Loader  # noqa: F401
 

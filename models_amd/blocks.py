@@ -477,6 +477,16 @@ class TwoTowerBlock(ParallelBlock):
         self.l2_normalization = l2_normalization
         self.schema = schema
 
+    @classmethod
+    def from_towers(cls, query: Block, item: Block, schema: Optional[Schema] = None, l2_normalization: bool = False,
+                    name: Optional[str] = None) -> "TwoTowerBlock":
+        """Two ready-made towers (``mm.Encoder``s of the V2 API) instead of a schema + MLP pair."""
+        self = cls.__new__(cls)
+        ParallelBlock.__init__(self, {"query": query, "item": item}, name=name or "two_tower")
+        self.l2_normalization = l2_normalization
+        self.schema = schema
+        return self
+
     def forward(self, inputs: TabularData):
         out = super().forward(inputs)
         if self.l2_normalization:

@@ -393,4 +393,54 @@ def TwoTowerModel(schema: Schema, query_tower: Block, item_tower: Optional[Block
     return RetrievalModel(body, out, schema, name="two_tower_model")
 
 
-TwoTowerModelV2 = TwoTowerModel
+class Encoder(SequentialBlock):
+    """core/encoder.py:41-239: ``InputBlockV2(schema)`` followed by the given blocks -- one tower of the V2 API.
+    ``encode`` is the batched embedding export of ``Encoder.encode / batch_predict`` (:155-208)."""
+
+    def __init__(self, inputs: Union[Schema, Block], *blocks: Block, device=None, name: Optional[str] = None):
+        if isinstance(inputs, Schema):
+            self._schema = inputs
+            input_block: Block = InputBlockV2(inputs, device=device)
+        else:
+            input_block = inputs
+            self._schema = getattr(inputs, "schema", None)
+        layers: List[Block] = [input_block]
+        for b in blocks:
+            layers.extend(b.layers if isinstance(b, SequentialBlock) else [b])
+        super().__init__(layers, name=name or "encoder")
+
+    @property
+    def schema(self) -> Optional[Schema]:
+        return self._schema
+
+    def forward(self, inputs, **kwargs):
+        return super().forward(prepare_features(inputs) if isinstance(inputs, dict) else inputs, **kwargs)
+
+    def encode(self, dataset, batch_size: Optional[int] = None) -> np.ndarray:
+        """Embeddings of a whole dataset (a ``Loader`` read in order, or anything it accepts + ``batch_size``)."""
+        from .loader import Loader
+
+        if not isinstance(dataset, Loader):
+            if batch_size is None or self._schema is None:
+                raise ValueError("encode needs a Loader, or a dataset together with `batch_size` (and a schema)")
+            dataset = Loader(dataset, self._schema, batch_size, shuffle=False)
+        if dataset.shuffle:
+            raise ValueError("encode reads the dataset in order: build the Loader with shuffle=False")
+        return np.concatenate([self.forward(x).cpu().numpy() for x, _ in dataset])
+
+
+def TwoTowerModelV2(query_tower: Encoder, candidate_tower: Encoder, candidate_id_tag=Tags.ITEM_ID, outputs=None,
+                    logits_temperature: float = 1.0, negative_samplers=None, schema: Optional[Schema] = None,
+                    downscore_false_negatives: bool = True) -> RetrievalModel:
+    """retrieval.py:409-486: two ``Encoder``s -> ContrastiveOutput(DotProduct, in-batch negatives)."""
+    if not isinstance(query_tower, Encoder) or not isinstance(candidate_tower, Encoder):
+        raise ValueError("The query and candidate towers should be instances of the `Encoder` class")
+    if negative_samplers and list(negative_samplers) != ["in-batch"]:
+        raise NotImplementedError("only the in-batch sampler is on the HIP hot path")
+    if outputs is None:
+        item_id = candidate_tower.schema.select_by_tag(candidate_id_tag) if candidate_tower.schema is not None else []
+        outputs = ContrastiveOutput(item_id.first if len(item_id) else None, "in-batch",
+                                    downscore_false_negatives=downscore_false_negatives and len(item_id) > 0,
+                                    logits_temperature=logits_temperature)
+    body = TwoTowerBlock.from_towers(query_tower, candidate_tower, schema)
+    return RetrievalModel(body, outputs, schema, name="two_tower_model")

@@ -89,3 +89,23 @@ def test_prepare_features_ragged_contract():
     out = prepare_features(x)
     assert out["a"].shape == (4, 1)
     assert isinstance(out["l"], mm.Ragged) and "l__values" not in out
+
+
+def test_encoder_and_two_tower_v2_signature():
+    """mm.Encoder(schema, *blocks) + mm.TwoTowerModelV2(query, candidate, ...) (models/retrieval.py:409-486)."""
+    from models_amd import schema as S
+
+    schema = mm.Schema([S.categorical("user_id", 500, [S.Tags.USER, S.Tags.USER_ID]),
+                        S.categorical("item_id", 300, [S.Tags.ITEM, S.Tags.ITEM_ID]),
+                        S.categorical("item_cat", 12, [S.Tags.ITEM])])
+    q = mm.Encoder(schema.select_by_tag(S.Tags.USER), mm.MLPBlock([16], device="cpu"), device="cpu")
+    c = mm.Encoder(schema.select_by_tag(S.Tags.ITEM), mm.MLPBlock([32, 16], device="cpu"), device="cpu")
+    assert [type(l).__name__ for l in c.layers] == ["InputBlockV2", "_Dense", "_Dense"]
+    assert c.schema.column_names == ["item_id", "item_cat"]
+    model = mm.TwoTowerModelV2(q, c, schema=schema, logits_temperature=0.5)
+    assert isinstance(model, mm.RetrievalModel) and model.output.col_schema.name == "item_id"
+    assert model.output.logits_temperature == 0.5 and model.body.parallel_layers["item"] is c
+    with pytest.raises(ValueError):
+        mm.TwoTowerModelV2(mm.MLPBlock([8], device="cpu"), c)
+    with pytest.raises(NotImplementedError):
+        mm.TwoTowerModelV2(q, c, negative_samplers=["popularity"])

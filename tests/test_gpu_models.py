@@ -453,3 +453,27 @@ def test_predict_and_evaluate_ranking_and_retrieval(device):
     want /= 240
     for name, w in zip(("recall", "precision", "map", "dcg", "ndcg", "mrr"), want):
         assert abs(ev[f"{name}_at_10"] - w) < 1e-5, name
+
+
+def test_two_tower_v2_encoders_equal_v1_model(device):
+    """TwoTowerModelV2(Encoder, Encoder) is the same computation as the V1 constructor on the same weights."""
+    schema = _two_tower_schema()
+    v1 = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16, device=device, logits_temperature=0.6)
+    q = mm.Encoder(mm.InputBlockV2(schema.select_by_tag(S.Tags.USER), dim=16, device=device), mm.MLPBlock([32, 16], device=device))
+    c = mm.Encoder(mm.InputBlockV2(schema.select_by_tag(S.Tags.ITEM), dim=16, device=device), mm.MLPBlock([32, 16], device=device))
+    v2 = mm.TwoTowerModelV2(q, c, schema=schema, logits_temperature=0.6)
+    for m in (v1, v2):
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+    g = torch.Generator().manual_seed(6)
+    batches = [_batch(schema, 100, g, device)[1] for _ in range(3)]
+    v1(batches[0]), v2(batches[0])
+    assert len(v1.parameters()) == len(v2.parameters())
+    for a, b in zip(v1.parameters(), v2.parameters()):
+        b.data.copy_(a.data)
+    for xd in batches:
+        la, lb = v1.train_step(xd), v2.train_step(xd)
+        assert abs(float(la) - float(lb)) < 1e-6
+    for a, b in zip(v1.parameters(), v2.parameters()):
+        torch.testing.assert_close(a.data, b.data, atol=1e-6, rtol=1e-6)
+    emb = q.encode({k: v.cpu().numpy().reshape(-1) for k, v in batches[0].items() if k.startswith("user")}, batch_size=40)
+    np.testing.assert_allclose(emb, v2.query_embeddings(batches[0]).cpu().numpy(), atol=1e-6)
