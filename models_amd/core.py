@@ -38,6 +38,11 @@ class Parameter:
     def shape(self):
         return self.data.shape
 
+    @property
+    def embeddings(self) -> torch.Tensor:
+        """``EmbeddingTable.table.embeddings`` of the reference (the Keras Embedding layer's weight variable)."""
+        return self.data
+
     def numpy(self):
         return self.data.detach().cpu().numpy()
 

@@ -89,11 +89,16 @@ class ContrastiveOutput(Block):
                  negative_samplers: Union[str, Sequence[str]] = "in-batch", downscore_false_negatives: bool = True,
                  false_negative_score: float = MIN_FLOAT, logits_temperature: float = 1.0,
                  store_negative_ids: bool = False, query_name: str = "query", candidate_name: str = "candidate",
-                 name: Optional[str] = None):
+                 logq_sampling_correction: bool = False, name: Optional[str] = None):
         super().__init__(name)
         samplers = [negative_samplers] if isinstance(negative_samplers, str) else list(negative_samplers)
         if samplers != ["in-batch"]:
             raise NotImplementedError("only the 'in-batch' negative sampler is on the HIP hot path")
+        if logq_sampling_correction:
+            # contrastive.py:309-319 needs sampling probabilities, which only the popularity sampler provides
+            # (outputs/sampling/popularity.py); the in-batch sampler has none (the reference warns and fails there)
+            raise NotImplementedError("logq_sampling_correction needs a sampler with sampling probabilities "
+                                      "(popularity-based); only the in-batch sampler is on the HIP hot path")
         if isinstance(to_call, Schema):
             to_call = to_call.select_by_tag(Tags.ITEM_ID).first
         self.col_schema = to_call if isinstance(to_call, ColumnSchema) else None
