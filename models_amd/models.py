@@ -92,6 +92,46 @@ class Model(Block):
     def evaluate(self, batches, **kwargs) -> Dict[str, float]:
         raise NotImplementedError
 
+    # --- checkpoint / resume (the reference relies on Keras `model.save_weights` / `load_weights`) ---
+    def save_weights(self, path) -> None:
+        """Parameters (by position and name), their optimizer state (Adagrad accumulators, Adam moments) and the
+        optimizer's step counter into one ``.npz``.  The model must have been built (called once)."""
+        arrays: Dict[str, np.ndarray] = {}
+        names = []
+        for i, p in enumerate(self.parameters()):
+            names.append(p.name)
+            arrays[f"p{i}"] = p.data.detach().cpu().numpy()
+            for k, v in p.state.items():
+                arrays[f"s{i}:{k}"] = v.detach().cpu().numpy()
+        arrays["__names__"] = np.array(names)
+        opt = self.optimizer
+        if opt is not None and getattr(opt, "_step_dev", None) is not None:
+            arrays["__adam_step__"] = opt._step_dev.detach().cpu().numpy()
+        np.savez(path, **arrays)
+
+    def load_weights(self, path) -> None:
+        """Inverse of ``save_weights`` for an identically constructed (and built) model."""
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        params = self.parameters()
+        names = [str(n) for n in z["__names__"]]
+        if len(names) != len(params):
+            raise ValueError(f"checkpoint has {len(names)} parameters, the model has {len(params)}")
+        for i, p in enumerate(params):
+            w = z[f"p{i}"]
+            if tuple(w.shape) != tuple(p.data.shape):
+                raise ValueError(f"parameter {i} ({p.name}): checkpoint shape {w.shape} != model shape {tuple(p.data.shape)}")
+            p.data.copy_(torch.from_numpy(w))
+            p.state = {}
+            prefix = f"s{i}:"
+            for key in z.files:
+                if key.startswith(prefix):
+                    p.state[key[len(prefix):]] = torch.from_numpy(z[key]).to(p.data.device)
+        if "__adam_step__" in z.files and self.optimizer is not None and getattr(self.optimizer, "name", "") == "adam":
+            dev = params[0].data.device
+            self.optimizer._step_dev = torch.from_numpy(z["__adam_step__"]).to(dev)  # next tick recomputes lr_device
+            if self.optimizer.lr_device is None:
+                self.optimizer.lr_device = torch.zeros(1, dtype=torch.float32, device=dev)
+
     def fit(self, batches: Iterable[Tuple[TabularData, torch.Tensor]], epochs: int = 1, steps_per_epoch: Optional[int] = None):
         """Minimal fit loop; samples/sec follows ExamplesPerSecondCallback
         (tf/logging/callbacks.py:174-189): batch_size * steps / elapsed, first step discarded."""

@@ -109,3 +109,34 @@ def test_encoder_and_two_tower_v2_signature():
         mm.TwoTowerModelV2(mm.MLPBlock([8], device="cpu"), c)
     with pytest.raises(NotImplementedError):
         mm.TwoTowerModelV2(q, c, negative_samplers=["popularity"])
+
+
+def test_save_and_load_weights_round_trip(tmp_path):
+    """Checkpoint / resume: parameters + optimizer state survive save_weights -> load_weights (CPU tensors here;
+    the same code moves device tensors)."""
+    import torch
+    from models_amd import schema as S
+
+    schema = mm.Schema([S.categorical("a", 50), S.categorical("b", 20), S.continuous("x"), S.binary_target("y")])
+
+    def build(seed):
+        m = mm.DLRMModel(schema, embedding_dim=8, bottom_block=mm.MLPBlock([8], device="cpu", seed=seed),
+                         top_block=mm.MLPBlock([8, 4], device="cpu", seed=seed + 1), device="cpu")
+        m.compile(optimizer="adagrad", learning_rate=0.1)
+        m.body.bottom_block.layers[0].build(1)
+        m.body.top_block.layers[0].build(3 + 8)
+        m.body.top_block.layers[1].build(8)
+        m.output.to_call.build(4)
+        return m
+
+    a, b = build(1), build(7)
+    for i, p in enumerate(a.parameters()):
+        p.state["accumulator"] = torch.full_like(p.data, 0.1 + i)
+    assert any(not torch.equal(pa.data, pb.data) for pa, pb in zip(a.parameters(), b.parameters()))
+    a.save_weights(tmp_path / "ckpt")
+    b.load_weights(tmp_path / "ckpt")
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa.data, pb.data) and torch.equal(pa.state["accumulator"], pb.state["accumulator"])
+    c = mm.DLRMModel(schema, embedding_dim=8, bottom_block=mm.MLPBlock([8], device="cpu"), device="cpu")
+    with pytest.raises(ValueError):
+        c.load_weights(tmp_path / "ckpt")
