@@ -97,8 +97,8 @@ int32_t mh_embedding_bag_fwd(const float* table, int64_t rows, const void* value
 /* Backward of the two list lookups (ragged CSR above, dense [B, L] below) with the optimizer fused in, as
  * in mh_embedding_gather_bwd: the gradient of `tf.nn.safe_embedding_lookup_sparse` /
  * `process_str_sequence_combiner` w.r.t. the table is an IndexedSlices over the nnz values with rows
- * scale(b) * grad[b], scale = 1 | 1/kept | 1/sqrt(kept) for sum | mean | sqrtn (kept = non-pruned ids of
- * bag b; every position for a dense list).  Pruned (< 0) and out-of-range ids receive no update.
+ * grad[b] / div(b), div = 1 | kept | sqrt(kept) for sum | mean | sqrtn (kept = non-pruned ids of bag b; every
+ * position for a dense list) -- a division, like the gradient of the forward's div_no_nan.  Pruned (< 0) and out-of-range ids receive no update.
  * offsets == NULL selects the dense list of length L (nnz must equal B*L).  nnz < 2^26. */
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D);
 int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t rows, const void* values,
@@ -127,7 +127,9 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
  *            with lr_t = lr sqrt(1-b2^t)/(1-b1^t) supplied by the caller (host value `lr`, or the device
  *            scalar `lr_device` maintained by mh_adam_tick so that a captured hipGraph replays correctly).
  * state[f] (Adagrad accumulator / Adam m) and state2[f] (Adam v) have the table's shape; NULL when unused.
- * workspace: mh_embedding_bwd_workspace_bytes(B, F, D) bytes. */
+ * workspace: mh_embedding_bwd_workspace_bytes(B, F, D) bytes.  Limits: F < 64, B < 2^26, B*F < 2^31, D % 4 == 0,
+ * D <= 1024.  Runs whose gradients fit one 16-entry piece are summed in sorted (sample) order -> reproducible;
+ * hot rows spanning several pieces are combined with float atomics (order-dependent in the last bits). */
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
                                 const int64_t* table_rows /*HOST [F]*/,
