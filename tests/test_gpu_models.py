@@ -477,3 +477,51 @@ def test_two_tower_v2_encoders_equal_v1_model(device):
         torch.testing.assert_close(a.data, b.data, atol=1e-6, rtol=1e-6)
     emb = q.encode({k: v.cpu().numpy().reshape(-1) for k, v in batches[0].items() if k.startswith("user")}, batch_size=40)
     np.testing.assert_allclose(emb, v2.query_embeddings(batches[0]).cpu().numpy(), atol=1e-6)
+
+
+def test_graph_replayed_train_steps_equal_eager_steps(device):
+    """The headline number of bench.py is a hipGraph replay of the whole train step: replaying it on a sequence of
+    NEW batches must leave the model exactly where eager steps on the same batches leave it."""
+    from models_amd.graph import GraphedStep
+
+    cards = {"C1": 5000, "C2": 7, "C3": 300, "C4": 50}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+
+    def build():
+        m = mm.DLRMModel(schema, embedding_dim=16, bottom_block=mm.MLPBlock([32, 16], device=device, seed=7),
+                         top_block=mm.MLPBlock([32, 8], device=device, seed=17), device=device)
+        m.output.to_call.seed = 99
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    g = torch.Generator().manual_seed(12)
+    batches = []
+    for _ in range(4):
+        x, xd = _batch(schema, 256, g, device)
+        batches.append((xd, torch.randint(0, 2, (256, 1), generator=g).float().to(device)))
+    a, b = build(), build()
+    a(batches[0][0]), b(batches[0][0])
+    init = [p.data.clone() for p in a.parameters()]
+    for pb, w in zip(b.parameters(), init):
+        pb.data.copy_(w)
+
+    def step(inp):
+        return b.train_step({k: v for k, v in inp.items() if k != "__label__"}, inp["__label__"])
+
+    static = dict(batches[0][0])
+    static["__label__"] = batches[0][1]
+    gs = GraphedStep(step, static, warmup=2)  # warm-up steps DO train b: put it back to the initial state in place
+    for pb, w in zip(b.parameters(), init):
+        pb.data.copy_(w)
+        for v in pb.state.values():
+            v.fill_(0.1)  # Adagrad initial_accumulator_value; the graph holds these tensors' addresses
+    for xd, y in batches:
+        la = a.train_step(xd, y)
+        new = dict(xd)
+        new["__label__"] = y
+        lb = gs.replay(new)
+        assert abs(float(la) - float(lb)) < 1e-6
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pb.data, pa.data, atol=1e-6, rtol=1e-5)
