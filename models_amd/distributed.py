@@ -421,45 +421,45 @@ class DistributedDLRM:
         if self.world_size > 1:
             dlogit = dlogit / self.world_size
         xa = body.output_activation
-        with ops.SIDE.deferred():
+        with ops.SIDE.deferred():  # side work (dW GEMMs) is joined below, right before the bucket reads the gradients
             dh = model.output.backward(dlogit, x_activation=xa)
             body.backward(dh, pre_masked=xa is not None)  # leaves (dstack, offsets) pending on the embeddings block
-        dstack, offsets = body.embeddings._pending
-        body.embeddings._pending = None
-        D = body.dim
-        emb = body.embeddings
-        opt.begin_step(dstack.device)  # Adam: advance the on-device step / bias-corrected lr once per step
-        # 1. sharded tables: route the gradient rows to their owners (fused update there, in step 3)
-        if self.group_sh is not None:
-            gs = self.group_sh
-            if opt.name == "adagrad" and gs.state is None:
-                gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
-            if opt.name == "adam" and gs.state is None:
-                gs.state, gs.state2 = torch.zeros_like(gs.local), torch.zeros_like(gs.local)
-            # starts the gradient all-to-all; it overlaps the replicated-table gradient pass below
-            gs.backward_begin(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
-                                                  lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
-        # 2 + 3. ONE persistent flat bucket [MLP / head gradients | dense [V, D] gradients of the replicated
-        #    tables]: the table part is zeroed by one fill and accumulated by the fused backward (SGD, lr = -1),
-        #    the MLP part is packed by one cat; after the in-place reduction the gradients are VIEWS of the bucket
-        rep_tabs = [emb.feature_table[n].table for n in self.replicated]
-        dense = [q for q in model.parameters() if not q.sparse and q.grad is not None]
-        n_dense = sum(q.grad.numel() for q in dense)
-        n_rep = sum(t.data.numel() for t in rep_tabs)
-        n_head = (n_dense + 1 + 63) // 64 * 64  # + one slot for the loss; table gradients start 256-byte aligned
-        total = (n_head + n_rep + 63) // 64 * 64
-        if self._bucket is None or self._bucket.numel() != total:
-            self._bucket = torch.zeros(total, dtype=torch.float32, device=dstack.device)
-        bucket = self._bucket
-        rep_grads, o = [], n_head
-        for t in rep_tabs:
-            rep_grads.append(bucket[o:o + t.data.numel()].view_as(t.data))
-            o += t.data.numel()
-        if rep_tabs:
-            bucket[n_head:n_head + n_rep].zero_()
-            ops.embedding_gather_backward(rep_grads, None, [x[n] for n in self.replicated], dstack,
-                                          [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
-        ops.SIDE.join()  # the dW / db GEMMs ran on their side stream: the bucket below reads them
+            dstack, offsets = body.embeddings._pending
+            body.embeddings._pending = None
+            D = body.dim
+            emb = body.embeddings
+            opt.begin_step(dstack.device)  # Adam: advance the on-device step / bias-corrected lr once per step
+            # 1. sharded tables: route the gradient rows to their owners (fused update there, in step 3)
+            if self.group_sh is not None:
+                gs = self.group_sh
+                if opt.name == "adagrad" and gs.state is None:
+                    gs.state = torch.full_like(gs.local, opt.initial_accumulator_value)
+                if opt.name == "adam" and gs.state is None:
+                    gs.state, gs.state2 = torch.zeros_like(gs.local), torch.zeros_like(gs.local)
+                # starts the gradient all-to-all; it overlaps the replicated-table gradient pass below
+                gs.backward_begin(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
+                                                      lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
+            # 2 + 3. ONE persistent flat bucket [MLP / head gradients | dense [V, D] gradients of the replicated
+            #    tables]: the table part is zeroed by one fill and accumulated by the fused backward (SGD, lr = -1),
+            #    the MLP part is packed by one cat; after the in-place reduction the gradients are VIEWS of the bucket
+            rep_tabs = [emb.feature_table[n].table for n in self.replicated]
+            dense = [q for q in model.parameters() if not q.sparse and q.grad is not None]
+            n_dense = sum(q.grad.numel() for q in dense)
+            n_rep = sum(t.data.numel() for t in rep_tabs)
+            n_head = (n_dense + 1 + 63) // 64 * 64  # + one slot for the loss; table gradients start 256-byte aligned
+            total = (n_head + n_rep + 63) // 64 * 64
+            if self._bucket is None or self._bucket.numel() != total:
+                self._bucket = torch.zeros(total, dtype=torch.float32, device=dstack.device)
+            bucket = self._bucket
+            rep_grads, o = [], n_head
+            for t in rep_tabs:
+                rep_grads.append(bucket[o:o + t.data.numel()].view_as(t.data))
+                o += t.data.numel()
+            if rep_tabs:
+                bucket[n_head:n_head + n_rep].zero_()
+                ops.embedding_gather_backward(rep_grads, None, [x[n] for n in self.replicated], dstack,
+                                              [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
+            ops.SIDE.join()  # the dW / db GEMMs ran on their side stream: the bucket below reads them
         # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
         torch.cat([q.grad.reshape(-1) for q in dense] + [loss.detach().reshape(1)], out=bucket[:n_dense + 1])
         works = allreduce_flat_(bucket, self.group, async_op=True)
