@@ -287,6 +287,18 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # distribution of single-step times (median and p10 / p90), hipEvent pair around each step, after
+    # the timed region so that the event records do not perturb `value`
+    n_ev = min(max(args.steps, 1), 100)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for a_ev, b_ev in evs:
+        a_ev.record()
+        step()
+        b_ev.record()
+    torch.cuda.synchronize()
+    step_ms = sorted(a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs)
+    pct = lambda q: step_ms[min(n_ev - 1, int(q * n_ev))]
+    step_stats = {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "n": n_ev, "timing": "hipEvent pair per step"}
     # per-kernel durations: the same launches issued eagerly with a hipEvent pair around each
     # C-ABI call on the launch stream (events cannot be read back from inside a replayed graph)
     ops.TIMER.enable()
@@ -353,6 +365,7 @@ def main():
         "roofline": roofline,
         "roofline_gather": roofline_gather,
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kernel_ms.items()},
+        "step_ms": step_stats,
     }
     # CPU baseline on rank 0 at N = 1 only: at N > 1 the tables are sharded and a forward is a collective
     if not args.no_cpu_baseline and world == 1 and not args.extra_table_rows:
