@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from models_amd import ops
+from oracle import oracle as O
 from tests import torch_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -231,3 +232,43 @@ def test_dlrm_train_steps_adam_lazyadam_match_reference_formulas(device):
         torch.testing.assert_close(body.embeddings.feature_table[n].table.data.cpu(), tables[n].detach(), atol=1e-4, rtol=1e-4)
     for l, (W, b, _) in zip(body.bottom_block.layers + body.top_block.layers, bottom + top):
         torch.testing.assert_close(l.kernel.data.cpu(), W.detach(), atol=1e-4, rtol=1e-4)
+
+
+def test_lazy_adam_reproduces_the_reference_known_answers(device):
+    """The two sparse LazyAdam scenarios of the reference's own suite (tests/unit/tf/blocks/test_optimizer.py):
+    `test_lazy_adam_sparse` (:353-395: rows {0, 2} of a 3-row variable get gradients, row 1 must not move, three
+    steps against `adam_update_numpy`) and `test_lazy_adam_sparse_repeated_indices` (:420-445: a repeated index is
+    the same as its aggregated gradient).  Scalars of the reference become 4-wide rows (D % 4 == 0 on the HIP path)."""
+    from models_amd import optim
+
+    D = 4
+    opt = optim.Adam(learning_rate=0.001)
+    for var_np, grad_val in ((np.array([1.0, 1.0, 2.0], np.float32), 0.1), (np.array([3.0, 3.0, 4.0], np.float32), 0.01)):
+        table = torch.from_numpy(np.repeat(var_np[:, None], D, 1).copy()).to(device)
+        m, v = torch.zeros_like(table), torch.zeros_like(table)
+        ids = torch.tensor([0, 2], dtype=torch.int32, device=device)
+        grad = torch.full((2, 1, D), grad_val, device=device)
+        ref, m_np, v_np = var_np.astype(np.float64).copy(), np.zeros(3), np.zeros(3)
+        opt._step_dev = None
+        for t in range(3):
+            opt.begin_step(device)
+            ops.embedding_gather_backward([table], [m], [ids], grad, [0], "adam", opt.learning_rate, opt.epsilon, [v],
+                                          opt.beta_1, opt.beta_2, opt.lr_device)
+            for r in (0, 2):
+                ref[r], m_np[r], v_np[r] = O.adam_update(ref[r], grad_val, t, m_np[r], v_np[r])
+            np.testing.assert_allclose(table.cpu().numpy(), np.repeat(ref[:, None], D, 1), rtol=1e-6, atol=1e-6)
+        assert np.all(table.cpu().numpy()[1] == var_np[1])  # the untouched row never moves (lazy)
+    # repeated index == aggregated gradient
+    rep, agg = (torch.tensor([[1.0] * D, [2.0] * D], device=device) for _ in range(2))
+    st = [torch.zeros(2, D, device=device) for _ in range(4)]
+    o1, o2 = optim.Adam(), optim.Adam()
+    for _ in range(3):
+        o1.begin_step(device)
+        ops.embedding_gather_backward([rep], [st[0]], [torch.tensor([1, 1], dtype=torch.int64, device=device)],
+                                      torch.full((2, 1, D), 0.1, device=device), [0], "adam", o1.learning_rate, o1.epsilon,
+                                      [st[1]], o1.beta_1, o1.beta_2, o1.lr_device)
+        o2.begin_step(device)
+        ops.embedding_gather_backward([agg], [st[2]], [torch.tensor([1], dtype=torch.int64, device=device)],
+                                      torch.full((1, 1, D), 0.2, device=device), [0], "adam", o2.learning_rate, o2.epsilon,
+                                      [st[3]], o2.beta_1, o2.beta_2, o2.lr_device)
+        np.testing.assert_allclose(agg.cpu().numpy(), rep.cpu().numpy(), rtol=1e-6)
