@@ -140,3 +140,21 @@ def test_save_and_load_weights_round_trip(tmp_path):
     c = mm.DLRMModel(schema, embedding_dim=8, bottom_block=mm.MLPBlock([8], device="cpu"), device="cpu")
     with pytest.raises(ValueError):
         c.load_weights(tmp_path / "ckpt")
+
+
+def test_embedding_initializer_statistics():
+    """tests/unit/tf/inputs/test_embedding.py:372-393, 591-629: the keras Embedding default "uniform" draws from
+    U(-0.05, 0.05); the V1 EmbeddingFeatures default is TruncatedNormal(0, 0.05) (two-sigma truncation)."""
+    from models_amd import schema as S
+
+    col = S.categorical("item", 20000)
+    t = mm.EmbeddingTable(16, col, device="cpu", seed=1)
+    w = t.table.embeddings.numpy()
+    assert w.shape == (20000, 16) and abs(w.mean()) < 1e-3
+    assert w.min() >= -0.05 and w.max() <= 0.05 and abs(w.std() - 0.05 / np.sqrt(3)) < 5e-4
+    tn = mm.EmbeddingTable(16, col, device="cpu", seed=1, embeddings_initializer="truncated_normal").table.numpy()
+    assert abs(tn.mean()) < 1e-3 and np.abs(tn).max() <= 0.1 + 1e-6  # truncated at two standard deviations
+    assert 0.040 < tn.std() < 0.050                                   # 0.05 * 0.8796 for a 2-sigma truncation
+    a = mm.EmbeddingTable(16, col, device="cpu", seed=5).table.numpy()
+    b = mm.EmbeddingTable(16, col, device="cpu", seed=5).table.numpy()
+    assert np.array_equal(a, b)  # seeded
