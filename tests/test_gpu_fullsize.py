@@ -67,3 +67,65 @@ def test_c3_scorer_full_batch_properties(device):
     ref_lse = torch.logsumexp(full.logits[:1024].double(), dim=1).float()
     torch.testing.assert_close(full.lse[:1024], ref_lse, atol=1e-4, rtol=1e-5)
     assert bool((full.lse >= full.logits.max(dim=1).values - 1e-6).all())
+
+
+def test_c2_embedding_backward_full_batch_properties(device):
+    """configs[1] shapes (26 Criteo tables, D = 64, B = 65536), fused backward + SGD.  Size-independent properties:
+    (a) checksum: the column sums of a table's change equal -lr x the column sums of its feature's gradients;
+    (b) rows whose id does not occur do not change, every row whose id occurs does (gradients are non-zero);
+    (c) order invariance: permuting the batch (ids and gradient rows together) gives the same tables."""
+    from models_amd.synthetic import CRITEO_CARDINALITIES
+
+    D, B, lr = 64, 65536, 0.5
+    F = len(CRITEO_CARDINALITIES)
+    g = torch.Generator().manual_seed(21)
+    tabs0 = [torch.rand(v, D, generator=g).to(device) for v in CRITEO_CARDINALITIES[:F]]
+    ids = [torch.randint(0, v, (B,), generator=g).to(torch.int32).to(device) for v in CRITEO_CARDINALITIES[:F]]
+    grad = (torch.rand(B, F, D, generator=g) + 0.5).to(device)  # strictly positive: every touched row moves
+    offs = [f * D for f in range(F)]
+    tabs = [t.clone() for t in tabs0]
+    ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", lr, 0.0)
+    for f in range(F):
+        delta = tabs[f].double() - tabs0[f].double()
+        want = -lr * grad[:, f].double().sum(0)
+        torch.testing.assert_close(delta.sum(0), want, rtol=1e-6, atol=2e-3)  # fp32 rounding of each row update
+        touched = torch.zeros(tabs[f].shape[0], dtype=torch.bool, device=device)
+        touched[ids[f].long()] = True
+        changed = (delta != 0).any(dim=1)
+        assert torch.equal(changed, touched), f
+    perm = torch.randperm(B, generator=g).to(device)
+    tabs_p = [t.clone() for t in tabs0]
+    ops.embedding_gather_backward(tabs_p, None, [i[perm].contiguous() for i in ids], grad[perm].contiguous(), offs,
+                                  "sgd", lr, 0.0)
+    for a, b in zip(tabs, tabs_p):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)  # only the summation order of duplicates differs
+
+
+def test_route_full_size_is_a_stable_partition(device):
+    """Row-sharded exchange at full size (8 sharded features x 65536 requests, 8 ranks): pos_of is a permutation,
+    the send order is grouped by owner, stable inside an owner, and keys / gradient source rows follow it."""
+    F, B, W, NS = 8, 65536, 8, 27
+    g = torch.Generator().manual_seed(5)
+    ids = [torch.randint(0, 1_000_000, (B,), generator=g).to(torch.int32).to(device) for _ in range(F)]
+    slots = list(range(3, 3 + F))
+    keys, pos_of, src_row, counts = ops.route_build(ids, W, slots, NS)
+    n = F * B
+    assert int(counts.sum()) == n
+    flat_pos = pos_of.reshape(-1)
+    assert torch.equal(torch.sort(flat_pos).values, torch.arange(n, device=device))
+    idm = torch.stack([i.long() for i in ids]).reshape(-1)
+    owner_in_send_order = torch.empty(n, dtype=torch.int64, device=device)
+    owner_in_send_order[flat_pos] = idm % W
+    assert bool((owner_in_send_order[1:] >= owner_in_send_order[:-1]).all())           # grouped by owner
+    assert torch.equal(torch.bincount(owner_in_send_order, minlength=W), counts)
+    entry_in_send_order = torch.empty(n, dtype=torch.int64, device=device)
+    entry_in_send_order[flat_pos] = torch.arange(n, device=device)
+    same = owner_in_send_order[1:] == owner_in_send_order[:-1]
+    assert bool((entry_in_send_order[1:][same] > entry_in_send_order[:-1][same]).all())  # stable inside an owner
+    feat = torch.arange(F, device=device).repeat_interleave(B)
+    want_keys = torch.empty(n, dtype=torch.int64, device=device)
+    want_keys[flat_pos] = (feat << 40) | (idm // W)
+    assert torch.equal(keys, want_keys)
+    want_src = torch.empty(n, dtype=torch.int64, device=device)
+    want_src[flat_pos] = torch.arange(B, device=device).repeat(F) * NS + torch.tensor(slots, device=device).repeat_interleave(B)
+    assert torch.equal(src_row, want_src)
