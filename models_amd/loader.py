@@ -25,27 +25,10 @@ import torch
 from .schema import Schema, Tags
 
 
-def _column_arrays(data, names: List[str]) -> Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]]:
-    """name -> numpy array (scalar column) or (values, offsets) (list column)."""
-    try:
-        import pyarrow as pa
-        import pyarrow.parquet as pq
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("models_amd.loader needs pyarrow to read Parquet / DataFrames") from e
-    if isinstance(data, (str, Path)):
-        p = Path(data)
-        files = sorted(p.glob("*.parquet")) if p.is_dir() else [p]
-        if not files:
-            raise FileNotFoundError(f"no parquet files under {p}")
-        table = pa.concat_tables([pq.read_table(f, columns=names) for f in files])
-    elif isinstance(data, dict):
-        out = {}
-        for n in names:
-            v = data[n]
-            out[n] = (np.asarray(v[0]), np.asarray(v[1])) if isinstance(v, tuple) else np.asarray(v)
-        return out
-    else:  # pandas DataFrame (or anything pyarrow can convert)
-        table = pa.Table.from_pandas(data[names], preserve_index=False) if hasattr(data, "columns") else pa.table(data)
+def _table_to_columns(table, names: List[str]) -> Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]]:
+    """pyarrow Table -> name -> numpy array (scalar column) or (values, offsets) (list column)."""
+    import pyarrow as pa
+
     out = {}
     for n in names:
         col = table.column(n).combine_chunks()
@@ -68,12 +51,95 @@ def _column_arrays(data, names: List[str]) -> Dict[str, Union[np.ndarray, Tuple[
     return out
 
 
+def _column_arrays(data, names: List[str]) -> Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]]:
+    """Whole dataset (Parquet path / DataFrame / dict of arrays) -> columns."""
+    try:
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("models_amd.loader needs pyarrow to read Parquet / DataFrames") from e
+    if isinstance(data, (str, Path)):
+        p = Path(data)
+        files = sorted(p.glob("*.parquet")) if p.is_dir() else [p]
+        if not files:
+            raise FileNotFoundError(f"no parquet files under {p}")
+        table = pa.concat_tables([pq.read_table(f, columns=names) for f in files])
+    elif isinstance(data, dict):
+        out = {}
+        for n in names:
+            v = data[n]
+            out[n] = (np.asarray(v[0]), np.asarray(v[1])) if isinstance(v, tuple) else np.asarray(v)
+        return out
+    else:  # pandas DataFrame (or anything pyarrow can convert)
+        table = pa.Table.from_pandas(data[names], preserve_index=False) if hasattr(data, "columns") else pa.table(data)
+    return _table_to_columns(table, names)
+
+
+Columns = Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]]
+
+
+def _n_rows(cols: Columns) -> int:
+    v = next(iter(cols.values()))
+    return len(v[1]) - 1 if isinstance(v, tuple) else len(v)
+
+
+def _slice_rows(cols: Columns, a: int, b: int) -> Columns:
+    out: Columns = {}
+    for n, v in cols.items():
+        if isinstance(v, tuple):
+            vals, offs = v
+            o = offs[a:b + 1]
+            out[n] = (vals[o[0]:o[-1]], o - o[0])
+        else:
+            out[n] = v[a:b]
+    return out
+
+
+def _take_rows(cols: Columns, idx: np.ndarray) -> Columns:
+    out: Columns = {}
+    for n, v in cols.items():
+        if isinstance(v, tuple):
+            vals, offs = v
+            lens = (offs[idx + 1] - offs[idx]).astype(np.int64)
+            new_offs = np.zeros(len(idx) + 1, dtype=offs.dtype)
+            np.cumsum(lens, out=new_offs[1:])
+            starts = np.repeat(offs[idx].astype(np.int64) - new_offs[:-1].astype(np.int64), lens)  # value ranges of the rows
+            out[n] = (vals[starts + np.arange(int(new_offs[-1]), dtype=np.int64)], new_offs)
+        else:
+            out[n] = v[idx]
+    return out
+
+
+def _concat_rows(parts: List[Columns]) -> Columns:
+    if len(parts) == 1:
+        return parts[0]
+    out: Columns = {}
+    for n in parts[0]:
+        if isinstance(parts[0][n], tuple):
+            vals = np.concatenate([p[n][0] for p in parts])
+            offs, base = [np.zeros(1, dtype=parts[0][n][1].dtype)], 0
+            for p in parts:
+                o = p[n][1]
+                offs.append(o[1:] + base)
+                base += int(o[-1])
+            out[n] = (vals, np.concatenate(offs).astype(parts[0][n][1].dtype))
+        else:
+            out[n] = np.concatenate([p[n] for p in parts])
+    return out
+
+
 class Loader:
-    """``for inputs, targets in Loader(path_or_df, schema, batch_size): model.train_step(inputs, targets)``."""
+    """``for inputs, targets in Loader(path_or_df, schema, batch_size): model.train_step(inputs, targets)``.
+
+    ``buffer_rows`` (Parquet paths only) switches to STREAMING: instead of decoding the dataset into host memory
+    once, row groups are read on the fly and batches are cut from chunks of at least ``buffer_rows`` rows (shuffled
+    inside a chunk, row groups visited in a shuffled order -- the ``buffer_size`` / ``parts_per_chunk`` scheme of
+    the reference loader, tf/loader.py:247-333).  Ranks take every W-th row group and all stop after the same number
+    of rows, so that collective train steps stay aligned."""
 
     def __init__(self, paths_or_dataset, schema: Schema, batch_size: int, shuffle: bool = True, seed: int = 0,
                  drop_last: bool = False, device=None, global_rank: Optional[int] = None,
-                 global_size: Optional[int] = None, prefetch: bool = True):
+                 global_size: Optional[int] = None, prefetch: bool = True, buffer_rows: Optional[int] = None):
         if batch_size < 1:
             raise ValueError("batch_size must be >= 1")
         self.schema, self.batch_size, self.shuffle, self.seed, self.drop_last = schema, int(batch_size), shuffle, seed, drop_last
@@ -93,6 +159,12 @@ class Loader:
         names = self.cat_names + self.cont_names + self.label_names
         if not names:
             raise ValueError("the schema selects no columns")
+        self._names = names
+        self._epoch = 0
+        self._stream: Optional[List[Tuple[str, int, int]]] = None  # (file, row group, rows) of this rank
+        if buffer_rows is not None:
+            self._init_streaming(paths_or_dataset, int(buffer_rows))
+            return
         cols = _column_arrays(paths_or_dataset, names)
         rows = {n: (len(v[1]) - 1 if isinstance(v, tuple) else len(v)) for n, v in cols.items()}
         if len(set(rows.values())) != 1:
@@ -100,50 +172,112 @@ class Loader:
         total = next(iter(rows.values()))
         per = total // self.world  # equal contiguous slices; the remainder rows are dropped so that ranks stay in step
         self.lo, self.n_rows = self.rank * per, per
-        self.columns: Dict[str, Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]] = {}
+        self.columns = self._typed(cols)
+
+    def _init_streaming(self, path, buffer_rows: int) -> None:
+        import pyarrow.parquet as pq
+
+        if not isinstance(path, (str, Path)):
+            raise TypeError("buffer_rows (streaming) needs a Parquet file or directory")
+        p = Path(path)
+        files = sorted(p.glob("*.parquet")) if p.is_dir() else [p]
+        if not files:
+            raise FileNotFoundError(f"no parquet files under {p}")
+        groups = []
+        for f in files:
+            md = pq.ParquetFile(f).metadata
+            groups += [(str(f), g, md.row_group(g).num_rows) for g in range(md.num_row_groups)]
+        per_rank = [groups[r::self.world] for r in range(self.world)]
+        totals = [sum(g[2] for g in gs) for gs in per_rank]
+        if min(totals) == 0:
+            raise ValueError(f"{len(groups)} row group(s) cannot feed {self.world} ranks: rewrite the dataset with more "
+                             "row groups or load it without buffer_rows")
+        self._stream = per_rank[self.rank]
+        self.n_rows = min(totals)  # every rank stops after the same number of rows
+        self.lo = 0
+        self.buffer_rows = max(buffer_rows, self.batch_size)
+        self.columns = {}
+
+    def _typed(self, cols: Columns) -> Columns:
+        """ids -> int32 / int64 (values and offsets of a list share the dtype), continuous / targets -> float32."""
+        out: Columns = {}
         for n in self.cat_names:
             v = cols[n]
             if isinstance(v, tuple):
                 vals, offs = v
                 vals = vals.astype(np.int64 if vals.dtype.itemsize > 4 else np.int32, copy=False)
-                self.columns[n] = (vals, offs.astype(vals.dtype))  # kernels want one integer dtype for both
+                out[n] = (vals, offs.astype(vals.dtype))  # kernels want one integer dtype for both
             else:
                 if not np.issubdtype(v.dtype, np.integer):
                     raise TypeError(f"categorical column {n!r} must hold integer ids, got {v.dtype}")
-                self.columns[n] = v.astype(np.int64 if v.dtype.itemsize > 4 else np.int32, copy=False)
+                out[n] = v.astype(np.int64 if v.dtype.itemsize > 4 else np.int32, copy=False)
         for n in self.cont_names + self.label_names:
             v = cols[n]
             if isinstance(v, tuple):
                 raise TypeError(f"list-valued continuous / target column {n!r} is outside the hot path")
-            self.columns[n] = v.astype(np.float32, copy=False)
-        self._epoch = 0
+            out[n] = v.astype(np.float32, copy=False)
+        return out
 
     def __len__(self) -> int:
         full, rem = divmod(self.n_rows, self.batch_size)
         return full + (1 if rem and not self.drop_last else 0)
 
     # --- host side: one batch as numpy arrays -------------------------------------------------------------
-    def _host_batch(self, idx: np.ndarray, contiguous: Optional[Tuple[int, int]]):
+    @staticmethod
+    def _flatten(cols: Columns) -> Dict[str, np.ndarray]:
         out: Dict[str, np.ndarray] = {}
-        for n, v in self.columns.items():
+        for n, v in cols.items():
             if isinstance(v, tuple):
-                vals, offs = v
-                if contiguous is not None:
-                    a, b = contiguous
-                    o = offs[a:b + 1]
-                    out[n + "__values"] = vals[o[0]:o[-1]]
-                    out[n + "__offsets"] = o - o[0]
-                else:
-                    lens = (offs[idx + 1] - offs[idx]).astype(np.int64)
-                    new_offs = np.zeros(len(idx) + 1, dtype=offs.dtype)
-                    np.cumsum(lens, out=new_offs[1:])
-                    # gather the value ranges of the selected rows
-                    starts = np.repeat(offs[idx].astype(np.int64) - new_offs[:-1].astype(np.int64), lens)
-                    out[n + "__values"] = vals[starts + np.arange(int(new_offs[-1]), dtype=np.int64)]
-                    out[n + "__offsets"] = new_offs
+                out[n + "__values"], out[n + "__offsets"] = v
             else:
-                out[n] = v[contiguous[0]:contiguous[1]] if contiguous is not None else v[idx]
+                out[n] = v
         return out
+
+    def _host_batch(self, idx: Optional[np.ndarray], contiguous: Optional[Tuple[int, int]]):
+        cols = _slice_rows(self.columns, *contiguous) if contiguous is not None else _take_rows(self.columns, idx)
+        return self._flatten(cols)
+
+    def _host_batches_streaming(self, epoch: int) -> Iterator[Dict[str, np.ndarray]]:
+        """Row groups -> chunks of >= buffer_rows rows -> batches; the tail of a chunk is carried into the next."""
+        import pyarrow.parquet as pq
+
+        rng = np.random.default_rng(self.seed + epoch) if self.shuffle else None
+        groups = list(self._stream)
+        if rng is not None:
+            groups = [groups[i] for i in rng.permutation(len(groups))]
+        left = self.n_rows  # rows this rank may still emit (every rank emits the same number)
+        carry: Optional[Columns] = None
+        parts: List[Columns] = []
+        have = 0
+        files: Dict[str, "pq.ParquetFile"] = {}
+        for gi, (f, g, _) in enumerate(groups):
+            if left <= 0:
+                break
+            pf = files.get(f)
+            if pf is None:
+                pf = files[f] = pq.ParquetFile(f)
+            parts.append(self._typed(_table_to_columns(pf.read_row_group(g, columns=self._names), self._names)))
+            have += _n_rows(parts[-1])
+            if have < self.buffer_rows and gi != len(groups) - 1:
+                continue
+            chunk = _concat_rows(([carry] if carry is not None else []) + parts)
+            parts, have, carry = [], 0, None
+            n = _n_rows(chunk)
+            if rng is not None:
+                chunk = _take_rows(chunk, rng.permutation(n))
+            a = 0
+            while left > 0:
+                take = min(self.batch_size, left)
+                if n - a < take:
+                    break  # not enough rows left in this chunk: carry them over
+                if take < self.batch_size and self.drop_last:
+                    left = 0
+                    break
+                yield self._flatten(_slice_rows(chunk, a, a + take))
+                left -= take
+                a += take
+            if left > 0 and a < n:
+                carry = _slice_rows(chunk, a, n)
 
     def _to_device(self, host: Dict[str, np.ndarray]):
         dev = {}
@@ -165,37 +299,44 @@ class Loader:
         return dev, (labels[self.label_names[0]] if len(labels) == 1 else labels)
 
     def __iter__(self) -> Iterator:
-        order = None
-        if self.shuffle:
-            order = np.random.default_rng(self.seed + self._epoch).permutation(self.n_rows) + self.lo
+        epoch = self._epoch
         self._epoch += 1
+        order = None
+        if self.shuffle and self._stream is None:
+            order = np.random.default_rng(self.seed + epoch).permutation(self.n_rows) + self.lo
         nb = len(self)
 
-        def host(i):
-            a = i * self.batch_size
-            b = min(a + self.batch_size, self.n_rows)
-            if order is None:
-                return self._host_batch(None, (self.lo + a, self.lo + b))
-            return self._host_batch(order[a:b], None)
-
-        if not self.prefetch:
+        def in_memory():
             for i in range(nb):
-                yield self._to_device(host(i))
+                a = i * self.batch_size
+                b = min(a + self.batch_size, self.n_rows)
+                if order is None:
+                    yield self._host_batch(None, (self.lo + a, self.lo + b))
+                else:
+                    yield self._host_batch(order[a:b], None)
+
+        source = self._host_batches_streaming(epoch) if self._stream is not None else in_memory()
+        if not self.prefetch:
+            for host in source:
+                yield self._to_device(host)
             return
         copy_stream = torch.cuda.Stream(device=self.device)
         cur_stream = torch.cuda.current_stream(self.device)
 
-        def stage(i):
+        def stage():
+            host = next(source, None)
+            if host is None:
+                return None
             with torch.cuda.stream(copy_stream):
-                batch = self._to_device(host(i))
+                batch = self._to_device(host)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return batch, ev
 
-        nxt = stage(0) if nb else None
-        for i in range(nb):
+        nxt = stage()
+        while nxt is not None:
             (inputs, targets), ev = nxt
-            nxt = stage(i + 1) if i + 1 < nb else None  # copy of the next batch overlaps this batch's step
+            nxt = stage()  # copy of the next batch overlaps this batch's step
             cur_stream.wait_event(ev)
             for t in list(inputs.values()) + ([targets] if isinstance(targets, torch.Tensor) else list((targets or {}).values())):
                 t.record_stream(cur_stream)  # allocated on the copy stream, consumed on the compute stream

@@ -107,3 +107,67 @@ def test_errors():
     bad["genres"] = (np.zeros(0, np.int64), np.zeros(11, np.int64))
     with pytest.raises(TypeError):
         mm.Loader(bad, _schema(), batch_size=4, device="cpu")
+
+
+@pytest.fixture()
+def parquet_dir(tmp_path):
+    """Three files x several small row groups (311 rows in total)."""
+    data, lists = _frame(311, seed=9)
+    d = tmp_path / "ds"
+    d.mkdir()
+    bounds = [0, 100, 230, 311]
+    for i in range(3):
+        a, b = bounds[i], bounds[i + 1]
+        table = pa.table({k: (pa.array(v[a:b]) if k != "genres" else pa.array(v[a:b], type=pa.list_(pa.int64()))) for k, v in data.items()})
+        pq.write_table(table, d / f"part{i}.parquet", row_group_size=37)
+    return d, data, lists
+
+
+def test_streaming_reads_every_row_once_in_order(parquet_dir):
+    d, data, lists = parquet_dir
+    ld = mm.Loader(d, _schema(), batch_size=50, shuffle=False, device="cpu", buffer_rows=120)
+    assert ld.n_rows == 311 and len(ld) == 7
+    users, genres, sizes = [], [], []
+    for inputs, y in ld:
+        sizes.append(y.shape[0])
+        users.append(inputs["user"].numpy())
+        o, v = inputs["genres__offsets"].numpy(), inputs["genres__values"].numpy()
+        assert o[0] == 0 and o[-1] == len(v)
+        genres += [v[o[b]:o[b + 1]].tolist() for b in range(len(o) - 1)]
+    assert sizes == [50] * 6 + [11]
+    np.testing.assert_array_equal(np.concatenate(users), data["user"])  # batches straddle row groups and chunks
+    assert genres == lists
+    dl = mm.Loader(d, _schema(), batch_size=50, shuffle=False, device="cpu", buffer_rows=120, drop_last=True)
+    assert [y.shape[0] for _, y in dl] == [50] * 6
+
+
+def test_streaming_shuffle_is_a_row_preserving_permutation(parquet_dir):
+    d, data, lists = parquet_dir
+    ld = mm.Loader(d, _schema(), batch_size=32, shuffle=True, seed=4, device="cpu", buffer_rows=100)
+    e1 = [(int(u), tuple(g)) for i, _ in ld for u, g in zip(i["user"].numpy(), _rows_of(i))]
+    e2 = [(int(u), tuple(g)) for i, _ in ld for u, g in zip(i["user"].numpy(), _rows_of(i))]
+    want = sorted((int(u), tuple(g)) for u, g in zip(data["user"], lists))
+    assert sorted(e1) == want and sorted(e2) == want and e1 != e2 and e1 != [w for w in want]
+
+
+def _rows_of(inputs):
+    o, v = inputs["genres__offsets"].numpy(), inputs["genres__values"].numpy()
+    return [v[o[b]:o[b + 1]].tolist() for b in range(len(o) - 1)]
+
+
+def test_streaming_ranks_take_disjoint_row_groups_and_equal_row_counts(parquet_dir):
+    d, data, lists = parquet_dir
+    seen, counts = [], []
+    for r in range(2):
+        ld = mm.Loader(d, _schema(), batch_size=40, shuffle=False, device="cpu", buffer_rows=80, global_rank=r, global_size=2)
+        u = np.concatenate([i["user"].numpy() for i, _ in ld])
+        counts.append(len(u))
+        seen.append(u)
+    assert counts[0] == counts[1] == min(counts)  # ranks stay in step
+    both = np.concatenate(seen)
+    # disjoint row groups: no (position-wise) row is delivered twice -- compare as multisets against the file
+    from collections import Counter
+
+    assert not (Counter(both.tolist()) - Counter(data["user"].tolist()))
+    with pytest.raises(ValueError):
+        mm.Loader(d, _schema(), batch_size=40, device="cpu", buffer_rows=80, global_rank=0, global_size=64)
