@@ -242,8 +242,11 @@ int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb,
  * logits may be NULL (fused mode: nothing of size B*Nn is written); loss / lse may be NULL.
  * q, item: [B, E]; neg_item: [Nn, E] (pass item and Nn = B for in-batch negatives).
  * ids int32 or int64.  E % 4 == 0, E <= 1024.
- * workspace: mh_inbatch_softmax_workspace_bytes(B, Nn, backward = 0 | 1). */
-int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t backward);
+ * workspace: mh_inbatch_softmax_workspace_bytes(B, Nn, E, pass) with pass 0 = _fwd, 1 = _bwd, 2 = _fwd_dq.
+ * E <= 128 runs on the row-stationary streaming kernels (a workgroup keeps 256 rows of one matrix in registers and
+ * streams the other through LDS by direct-to-LDS DMA); other E are zero-padded to 32 / 64 / 128 inside the
+ * workspace (scores unchanged bit for bit).  E > 128 takes tiled kernels whose backward materialises ds[B, Nn]. */
+int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t E, int32_t pass);
 int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* neg_item,
                                const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                int64_t B, int64_t Nn, int32_t E, float temperature,
@@ -251,11 +254,28 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
                                float* loss, float* lse, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream);
 
+/* Training-mode forward (the forward half of BaseModel.train_step, models/base.py:1121-1174, for the in-batch
+ * softmax): loss / lse as above (fused mode, no logits) AND, from the same pass over the score tiles,
+ *   dq[B,E]    = d (grad_scale * sum_b loss[b]) / d q     (complete, positive column included)
+ *   ditem[B,E] = the positive-role part of the item gradient (may be NULL)
+ * -- dq is a softmax-weighted sum of item rows, i.e. exactly an attention output with the items as values, so it
+ * is accumulated flash-style while the log-sum-exp is still running (lazy rescaling against a reference max that
+ * starts at the positive logit).  The caller then needs only the column pass of mh_inbatch_softmax_bwd
+ * (dq = NULL).  E <= 128 only (MH_ERR_UNSUPPORTED otherwise: call _fwd then _bwd). */
+int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float* neg_item,
+                                  const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
+                                  int64_t B, int64_t Nn, int32_t E, float temperature,
+                                  float false_neg_score, float grad_scale, float* loss, float* lse,
+                                  float* dq, float* ditem, void* workspace, int64_t workspace_bytes,
+                                  mh_stream_t stream);
+
 /* Backward of sum_b(loss[b]) * grad_scale (pass grad_scale = 1/B for the Keras mean) w.r.t.
  * q (dq[B,E]), item in its positive role (ditem[B,E], may be NULL) and neg_item (dneg_item[Nn,E]);
- * all three are overwritten.  For in-batch negatives the caller adds ditem + dneg_item.
- * Round-1 implementation: the probabilities tile ds[B,Nn] is recomputed from (q, neg_item, lse)
- * into the workspace and contracted with two fp32-MFMA GEMMs. */
+ * all are overwritten.  For in-batch negatives the caller adds ditem + dneg_item.
+ * Flash-style for E <= 128: the probability tiles are recomputed from (q, neg_item, lse) inside the MFMA kernels
+ * and contracted on the spot -- a row pass (q stationary) for dq / ditem and a column pass (neg_item stationary)
+ * for dneg_item; nothing of size B x Nn is written and every output is written once, in a fixed order
+ * (deterministic).  dq == NULL (then ditem == NULL) skips the row pass: use it after mh_inbatch_softmax_fwd_dq. */
 int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* neg_item,
                                const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                int64_t B, int64_t Nn, int32_t E, float temperature,

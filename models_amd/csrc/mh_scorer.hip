@@ -1,4 +1,6 @@
-// In-batch sampled-softmax scorer for gfx950 (fp32 MFMA + fused epilogue).
+// In-batch sampled-softmax scorer for gfx950: C-ABI entry points.  E <= 128 (every BASELINE configuration) runs on the
+// row-stationary streaming core of mh_scorer_stream.hip (forward, forward + dq, flash-style backward: nothing of size
+// B x Nn is written).  The tiled kernels below remain for E > 128 only.
 // Reference: ItemRetrievalScorer.call_outputs (merlin/models/tf/blocks/retrieval/base.py:283-429),
 // ContrastiveOutput.outputs (tf/outputs/contrastive.py:276-344), rescore_false_negatives
 // (tf/utils/tf_utils.py:126-154), LogitsTemperatureScaler (tf/transforms/bias.py:65-68),
@@ -33,7 +35,7 @@ constexpr float M_INIT = -1.0e30f;  // finite "minus infinity" of the running ma
 // MODE 0: forward (optional logits store + online LSE partials)
 // MODE 1: backward helper: ds[row, col] = masked ? 0 : exp(z - lse[row]) * gscale   (z = s / T)
 template <int MODE, bool HAS_IDS, typename IdT, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 16) ? 8 : WM * WN / 2) void scorer_kernel(const float* __restrict__ q, const float* __restrict__ neg,
+__global__ __launch_bounds__(WM * WN * 64, 2) void scorer_kernel(const float* __restrict__ q, const float* __restrict__ neg,
                                                     const IdT* __restrict__ pos_ids,
                                                     const IdT* __restrict__ neg_ids, int64_t B, int64_t Nn, int E,
                                                     float invT, float fns, float* __restrict__ logits,
@@ -299,14 +301,90 @@ void launch_scorer(const Plan& p, const float* q, const float* neg, const void* 
 
 }  // namespace
 
+// ---- streaming core (mh_scorer_stream.hip) -----------------------------------------------------------------------------
+struct MhStreamPlan {
+    int bn, row_tiles, nt, nsplit, tps;
+    size_t lds;
+};
+enum { SM_FWD = 0, SM_GRAD = 1, SM_FWD_GRAD = 2 };
+MhStreamPlan mh_stream_plan(int mode, int64_t Nx, int64_t Ny, int E, int ids_bytes);
+int32_t mh_stream_launch(int mode, int lse_stream, const MhStreamPlan& p, const float* X, int64_t Nx, const float* Y,
+                         int64_t Ny, int E, const void* x_ids, const void* y_ids, int ids_dtype, const float* lse,
+                         const float* pos, float invT, float fns, float gscale, float* logits, int64_t ld_logits,
+                         float* part_m, float* part_s, float* opart, hipStream_t s);
+void mh_stream_fwd_finalize(const float* pos, int64_t B, int nsplit, const float* part_m, const float* part_s, float invT,
+                            float* logits, int64_t ld_logits, float* loss, float* lse, hipStream_t s);
+void mh_stream_fwd_grad_combine(const float* q, const float* item, const float* pos, int64_t B, int E, int nsplit,
+                                const float* part_m, const float* part_s, const float* opart, float invT, float g,
+                                float* loss, float* lse, float* dq, float* ditem, hipStream_t s);
+void mh_stream_grad_combine(const float* opart, int64_t N, int E, int nsplit, const float* pos, const float* lse,
+                            const float* other, const float* self, float invT, float g, float* out, float* out_pos,
+                            hipStream_t s);
+void mh_stream_pad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s);
+void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s);
+
+namespace {
+
+inline int padded_E(int E) { return E <= 32 ? 32 : (E <= 64 ? 64 : 128); }
+inline int64_t align64(int64_t n) { return (n + 63) / 64 * 64; }  // floats: keeps every sub-buffer 256-byte aligned
+
+// Workspace layout of the streaming path (floats), identical for the query and the calls:
+//   pos[B] | qp[B,Ep] itemp[B,Ep] negp[Nn,Ep] (only when E != Ep; negp omitted for in-batch negatives is NOT assumed)
+//   | pass-specific partials
+struct StreamWs {
+    int Ep;
+    bool pad;
+    int64_t pos, qp, itemp, negp, part_m, part_s, opart_row, opart_col, outp_row, outp_col, outp_item, total;
+    MhStreamPlan row, col;
+};
+
+StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
+    StreamWs w;
+    w.Ep = padded_E(E);
+    w.pad = (w.Ep != E);
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += align64(n); return at; };
+    w.pos = take(B);
+    w.qp = w.itemp = w.negp = w.outp_row = w.outp_col = w.outp_item = 0;
+    if (w.pad) {
+        w.qp = take(B * w.Ep);
+        w.itemp = take(B * w.Ep);
+        w.negp = take(Nn * w.Ep);
+    }
+    const int row_mode = (pass == 0) ? SM_FWD : (pass == 2 ? SM_FWD_GRAD : SM_GRAD);
+    w.row = mh_stream_plan(row_mode, B, Nn, w.Ep, ids_bytes);
+    w.col = mh_stream_plan(SM_GRAD, Nn, B, w.Ep, ids_bytes);
+    w.part_m = w.part_s = w.opart_row = w.opart_col = 0;
+    if (pass == 0 || pass == 2) {
+        w.part_m = take((int64_t)w.row.nsplit * B);
+        w.part_s = take((int64_t)w.row.nsplit * B);
+    }
+    if (pass == 1 || pass == 2) w.opart_row = take((int64_t)w.row.nsplit * B * w.Ep);
+    if (pass == 1) w.opart_col = take((int64_t)w.col.nsplit * Nn * w.Ep);
+    if (w.pad && pass != 0) {
+        w.outp_row = take(B * w.Ep);
+        w.outp_item = take(B * w.Ep);
+        if (pass == 1) w.outp_col = take(Nn * w.Ep);
+    }
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
 extern "C" {
 
-int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t backward) {
-    if (B <= 0) return 0;
-    const Plan p = make_plan(B, Nn > 0 ? Nn : 1);
-    int64_t floats = B + 2 * (int64_t)p.nsplit * B;
-    if (backward) floats = B + B * (Nn > 0 ? Nn : 0);
-    return floats * (int64_t)sizeof(float);
+int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t E, int32_t pass) {
+    if (B <= 0 || E <= 0) return 0;
+    if (Nn < 1) Nn = 1;
+    if (E > 128) {  // tiled kernels
+        const Plan p = make_plan(B, Nn);
+        int64_t floats = B + 2 * (int64_t)p.nsplit * B;
+        if (pass != 0) floats = B + B * Nn;
+        return floats * (int64_t)sizeof(float);
+    }
+    // ids of either width: size for the larger plan (the plan only depends on ids_bytes through the LDS size)
+    return stream_ws(pass, B, Nn, E, 8).total * (int64_t)sizeof(float);
 }
 
 int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* neg_item, const void* pos_ids,
@@ -321,22 +399,95 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
     MH_REQUIRE(!pos_ids || ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_inbatch_softmax_fwd: bad ids_dtype");
     MH_REQUIRE(temperature > 0.f, "mh_inbatch_softmax_fwd: temperature must be > 0");
     MH_REQUIRE(!logits || ld_logits >= Nn + 1, "mh_inbatch_softmax_fwd: ld_logits < 1 + Nn");
-    const Plan p = make_plan(B, Nn);
-    const int64_t need = (B + 2 * (int64_t)p.nsplit * B) * (int64_t)sizeof(float);
+    const int64_t need = mh_inbatch_softmax_workspace_bytes(B, Nn, E, 0);
     if (!workspace || workspace_bytes < need) {
         mh_set_error("mh_inbatch_softmax_fwd: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
         return MH_ERR_WORKSPACE;
     }
     hipStream_t s = mh_stream(stream);
-    float* pos = static_cast<float*>(workspace);
-    float* part_m = pos + B;
-    float* part_s = part_m + (int64_t)p.nsplit * B;
+    float* ws = static_cast<float*>(workspace);
+    const float invT = 1.f / temperature;
+    if (E > 128) {
+        const Plan p = make_plan(B, Nn);
+        float* pos = ws;
+        float* part_m = pos + B;
+        float* part_s = part_m + (int64_t)p.nsplit * B;
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+        launch_scorer<0>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, logits, ld_logits,
+                         part_m, part_s, nullptr, 0.f, nullptr, s);
+        hipLaunchKernelGGL(scorer_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, p.nsplit,
+                           part_m, part_s, invT, logits, ld_logits, loss, lse);
+        MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
+        return MH_OK;
+    }
+    const StreamWs w = stream_ws(0, B, Nn, E, 8);
+    const MhStreamPlan& plan = w.row;
+    float* pos = ws + w.pos;
     hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
-    launch_scorer<0>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, 1.f / temperature, false_neg_score, logits,
-                     ld_logits, part_m, part_s, nullptr, 0.f, nullptr, s);
-    hipLaunchKernelGGL(scorer_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, p.nsplit,
-                       part_m, part_s, 1.f / temperature, logits, ld_logits, loss, lse);
+    const float* qx = q;
+    const float* nx = neg_item;
+    if (w.pad) {
+        mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);
+        mh_stream_pad_rows(neg_item, Nn, E, w.Ep, ws + w.negp, s);
+        qx = ws + w.qp;
+        nx = ws + w.negp;
+    }
+    int32_t st = mh_stream_launch(SM_FWD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, nullptr, invT,
+                                  false_neg_score, 0.f, logits, ld_logits, ws + w.part_m, ws + w.part_s, nullptr, s);
+    if (st != MH_OK) return st;
+    mh_stream_fwd_finalize(pos, B, plan.nsplit, ws + w.part_m, ws + w.part_s, invT, logits, ld_logits, loss, lse, s);
     MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
+    return MH_OK;
+}
+
+int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float* neg_item, const void* pos_ids,
+                                  const void* neg_ids, int32_t ids_dtype, int64_t B, int64_t Nn, int32_t E,
+                                  float temperature, float false_neg_score, float grad_scale, float* loss, float* lse,
+                                  float* dq, float* ditem, void* workspace, int64_t workspace_bytes,
+                                  mh_stream_t stream) {
+    MH_REQUIRE(q && item && neg_item && lse && dq, "mh_inbatch_softmax_fwd_dq: null argument");
+    MH_REQUIRE(B >= 1 && Nn >= 1 && E >= 4 && E % 4 == 0, "mh_inbatch_softmax_fwd_dq: bad shape");
+    if (E > 128) {
+        mh_set_error("mh_inbatch_softmax_fwd_dq: E > 128 is not supported (call _fwd then _bwd)");
+        return MH_ERR_UNSUPPORTED;
+    }
+    MH_REQUIRE((pos_ids == nullptr) == (neg_ids == nullptr), "mh_inbatch_softmax_fwd_dq: pass both id arrays or neither");
+    MH_REQUIRE(!pos_ids || ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_inbatch_softmax_fwd_dq: bad ids_dtype");
+    MH_REQUIRE(temperature > 0.f, "mh_inbatch_softmax_fwd_dq: temperature must be > 0");
+    const int64_t need = mh_inbatch_softmax_workspace_bytes(B, Nn, E, 2);
+    if (!workspace || workspace_bytes < need) {
+        mh_set_error("mh_inbatch_softmax_fwd_dq: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
+        return MH_ERR_WORKSPACE;
+    }
+    hipStream_t s = mh_stream(stream);
+    float* ws = static_cast<float*>(workspace);
+    const float invT = 1.f / temperature;
+    const float g = grad_scale * invT;  // d loss / d score = d loss / d z * (1/T)
+    const StreamWs w = stream_ws(2, B, Nn, E, 8);
+    const MhStreamPlan& plan = w.row;
+    float* pos = ws + w.pos;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+    const float *qx = q, *ix = item, *nx = neg_item;
+    if (w.pad) {
+        mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);
+        mh_stream_pad_rows(item, B, E, w.Ep, ws + w.itemp, s);
+        mh_stream_pad_rows(neg_item, Nn, E, w.Ep, ws + w.negp, s);
+        qx = ws + w.qp;
+        ix = ws + w.itemp;
+        nx = ws + w.negp;
+    }
+    int32_t st = mh_stream_launch(SM_FWD_GRAD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT,
+                                  false_neg_score, 1.f, nullptr, 0, ws + w.part_m, ws + w.part_s, ws + w.opart_row, s);
+    if (st != MH_OK) return st;
+    float* dq_o = w.pad ? ws + w.outp_row : dq;
+    float* di_o = ditem ? (w.pad ? ws + w.outp_item : ditem) : nullptr;
+    mh_stream_fwd_grad_combine(qx, ix, pos, B, w.Ep, plan.nsplit, ws + w.part_m, ws + w.part_s, ws + w.opart_row, invT, g,
+                               loss, lse, dq_o, di_o, s);
+    if (w.pad) {
+        mh_stream_unpad_rows(dq_o, B, E, w.Ep, dq, s);
+        if (ditem) mh_stream_unpad_rows(di_o, B, E, w.Ep, ditem, s);
+    }
+    MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd_dq");
     return MH_OK;
 }
 
@@ -345,32 +496,75 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
                                float temperature, float false_neg_score, const float* lse, float grad_scale,
                                float* dq, float* ditem, float* dneg_item, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream) {
-    MH_REQUIRE(q && item && neg_item && lse && dq && dneg_item, "mh_inbatch_softmax_bwd: null argument");
+    MH_REQUIRE(q && item && neg_item && lse && dneg_item, "mh_inbatch_softmax_bwd: null argument");
     MH_REQUIRE(B >= 1 && Nn >= 1 && E >= 8 && E % 4 == 0 && E <= 1024, "mh_inbatch_softmax_bwd: bad shape");
     MH_REQUIRE((pos_ids == nullptr) == (neg_ids == nullptr), "mh_inbatch_softmax_bwd: pass both id arrays or neither");
     MH_REQUIRE(temperature > 0.f, "mh_inbatch_softmax_bwd: temperature must be > 0");
-    const int64_t need = (B + B * Nn) * (int64_t)sizeof(float);
+    const int64_t need = mh_inbatch_softmax_workspace_bytes(B, Nn, E, 1);
     if (!workspace || workspace_bytes < need) {
         mh_set_error("mh_inbatch_softmax_bwd: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
         return MH_ERR_WORKSPACE;
     }
     hipStream_t s = mh_stream(stream);
+    float* ws = static_cast<float*>(workspace);
     const float invT = 1.f / temperature;
     const float gscale = grad_scale * invT;  // d loss / d score = d loss / d z * (1/T)
-    float* pos = static_cast<float*>(workspace);
-    float* ds = pos + B;
-    Plan p = make_plan(B, Nn);
+    if (E > 128) {
+        MH_REQUIRE(dq != nullptr, "mh_inbatch_softmax_bwd: dq is required for E > 128");
+        float* pos = ws;
+        float* ds = pos + B;
+        Plan p = make_plan(B, Nn);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+        launch_scorer<1>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, nullptr, 0, nullptr,
+                         nullptr, lse, gscale, ds, s);
+        int32_t st = mh_internal_linear(ds, Nn, neg_item, nullptr, B, (int)Nn, E, MH_ACT_NONE, dq, E, nullptr, nullptr, s);
+        if (st != MH_OK) return st;
+        st = mh_internal_gemm_tn(ds, Nn, q, E, B, (int)Nn, E, dneg_item, s);
+        if (st != MH_OK) return st;
+        hipLaunchKernelGGL(scorer_pos_grad_kernel, dim3((unsigned)mh_ceil_div(B * E, 256)), dim3(256), 0, s, q, item, pos, lse,
+                           B, E, invT, gscale, dq, ditem);
+        MH_CHECK_LAUNCH("mh_inbatch_softmax_bwd");
+        return MH_OK;
+    }
+    // flash-style: the probability tiles are recomputed inside the MFMA kernels.
+    //   row pass (skipped when dq == NULL, e.g. after mh_inbatch_softmax_fwd_dq): X = q,   Y = neg -> dq
+    //   column pass:                                                              X = neg, Y = q   -> dneg_item
+    const StreamWs w = stream_ws(1, B, Nn, E, 8);
+    float* pos = ws + w.pos;
     hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
-    launch_scorer<1>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, nullptr, 0, nullptr,
-                     nullptr, lse, gscale, ds, s);
-    // dq = ds neg   (NN GEMM, contraction over the Nn negatives)
-    int32_t st = mh_internal_linear(ds, Nn, neg_item, nullptr, B, (int)Nn, E, MH_ACT_NONE, dq, E, nullptr, nullptr, s);
+    const float *qx = q, *ix = item, *nx = neg_item;
+    if (w.pad) {
+        mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);
+        mh_stream_pad_rows(item, B, E, w.Ep, ws + w.itemp, s);
+        mh_stream_pad_rows(neg_item, Nn, E, w.Ep, ws + w.negp, s);
+        qx = ws + w.qp;
+        ix = ws + w.itemp;
+        nx = ws + w.negp;
+    }
+    int32_t st;
+    if (dq) {
+        const MhStreamPlan& pr = w.row;
+        st = mh_stream_launch(SM_GRAD, 0, pr, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT,
+                              false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_row, s);
+        if (st != MH_OK) return st;
+        float* dq_o = w.pad ? ws + w.outp_row : dq;
+        float* di_o = ditem ? (w.pad ? ws + w.outp_item : ditem) : nullptr;
+        mh_stream_grad_combine(ws + w.opart_row, B, w.Ep, pr.nsplit, pos, lse, ix, qx, invT, gscale, dq_o, di_o, s);
+        if (w.pad) {
+            mh_stream_unpad_rows(dq_o, B, E, w.Ep, dq, s);
+            if (ditem) mh_stream_unpad_rows(di_o, B, E, w.Ep, ditem, s);
+        }
+    } else {
+        MH_REQUIRE(ditem == nullptr, "mh_inbatch_softmax_bwd: ditem needs dq (both come from the row pass)");
+    }
+    const MhStreamPlan& pc = w.col;
+    st = mh_stream_launch(SM_GRAD, 1, pc, nx, Nn, qx, B, w.Ep, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT,
+                          false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_col, s);
     if (st != MH_OK) return st;
-    // dneg = ds^T q (TN GEMM, contraction over the batch)
-    st = mh_internal_gemm_tn(ds, Nn, q, E, B, (int)Nn, E, dneg_item, s);
-    if (st != MH_OK) return st;
-    hipLaunchKernelGGL(scorer_pos_grad_kernel, dim3((unsigned)mh_ceil_div(B * E, 256)), dim3(256), 0, s, q, item, pos, lse,
-                       B, E, invT, gscale, dq, ditem);
+    float* dn_o = w.pad ? ws + w.outp_col : dneg_item;
+    mh_stream_grad_combine(ws + w.opart_col, Nn, w.Ep, pc.nsplit, nullptr, nullptr, nullptr, nullptr, invT, gscale, dn_o,
+                           nullptr, s);
+    if (w.pad) mh_stream_unpad_rows(dn_o, Nn, E, w.Ep, dneg_item, s);
     MH_CHECK_LAUNCH("mh_inbatch_softmax_bwd");
     return MH_OK;
 }

@@ -306,9 +306,16 @@ class RetrievalModel(Model):
         ids = None
         if out.downscore_false_negatives:
             ids = x[out.col_schema.name].reshape(-1)
-        res = ops.inbatch_softmax(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score, materialize=False)
-        dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
-                                                       out.false_negative_score)
+        # one pass over the score tiles gives loss, lse AND dq (flash-style); the column pass then gives dneg
+        fused = ops.inbatch_softmax_train(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score)
+        if fused is not None:
+            res, dq, ditem = fused
+            _, _, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
+                                                      out.false_negative_score, need_dq=False)
+        else:  # E > 128: tiled kernels
+            res = ops.inbatch_softmax(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score, materialize=False)
+            dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
+                                                           out.false_negative_score)
         ditem = ops.eltwise("add", ditem, dneg)
         if self.body.l2_normalization:  # L2Norm sits between the towers and the scorer (retrieval/base.py:98-121)
             dq = ops.l2norm_backward(self.body._raw["query"], dq)

@@ -706,7 +706,7 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
     logits = torch.empty((B, Nn + 1), dtype=torch.float32, device=q.device) if materialize else None
     loss = torch.empty((B,), dtype=torch.float32, device=q.device)
     lse = torch.empty((B,), dtype=torch.float32, device=q.device)
-    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, 0), q.device, "scorer_fwd")
+    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 0), q.device, "scorer_fwd")
     with _timed("inbatch_softmax_fwd"):
         check(
             lib.mh_inbatch_softmax_fwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
@@ -717,17 +717,51 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
     return ScorerResult(logits, loss, lse)
 
 
+def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: float = 1.0,
+                          false_neg_score: float = -655.04, grad_scale: Optional[float] = None):
+    """Training-mode forward (``mh_inbatch_softmax_fwd_dq``): one pass over the score tiles yields the per-row
+    loss / lse AND dq, ditem (positive role) of ``grad_scale * sum_b loss[b]`` (default 1/B).  Returns
+    ``(ScorerResult(None, loss, lse), dq, ditem)``; follow with ``inbatch_softmax_backward(..., need_dq=False)``
+    for dneg.  Falls back to forward + full backward when E > 128."""
+    lib = _lib.load()
+    for n_, t in (("q", q), ("item", item), ("neg_item", neg_item)):
+        _dev(t, n_, torch.float32)
+        if t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"{n_} must be contiguous 2-D")
+    B, E = q.shape
+    Nn = neg_item.shape[0]
+    if E > 128:
+        return None
+    pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
+    loss = torch.empty((B,), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B,), dtype=torch.float32, device=q.device)
+    dq = torch.empty_like(q)
+    ditem = torch.empty_like(item)
+    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 2), q.device, "scorer_fwd_dq")
+    with _timed("inbatch_softmax_fwd_dq"):
+        check(
+            lib.mh_inbatch_softmax_fwd_dq(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
+                                          temperature, false_neg_score, 1.0 / B if grad_scale is None else grad_scale,
+                                          _ptr(loss), _ptr(lse), _ptr(dq), _ptr(ditem), _ptr(ws), ws.numel(), _stream()),
+            "mh_inbatch_softmax_fwd_dq",
+        )
+    return ScorerResult(None, loss, lse), dq, ditem
+
+
 def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None, temperature: float = 1.0,
-                             false_neg_score: float = -655.04, grad_scale: Optional[float] = None):
-    """Gradients of ``grad_scale * sum_b loss[b]`` (default 1/B: the Keras mean): (dq, ditem, dneg)."""
+                             false_neg_score: float = -655.04, grad_scale: Optional[float] = None, need_dq: bool = True):
+    """Gradients of ``grad_scale * sum_b loss[b]`` (default 1/B: the Keras mean): (dq, ditem, dneg).
+    ``need_dq=False`` runs the column pass only and returns ``(None, None, dneg)``."""
     lib = _lib.load()
     B, E = q.shape
     Nn = neg_item.shape[0]
+    if not need_dq and E > 128:
+        raise ValueError("need_dq=False requires E <= 128 (the streaming scorer)")
     pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
-    dq = torch.empty_like(q)
-    ditem = torch.empty_like(item)
+    dq = torch.empty_like(q) if need_dq else None
+    ditem = torch.empty_like(item) if need_dq else None
     dneg = torch.empty_like(neg_item)
-    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, 1), q.device, "scorer_bwd")
+    ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 1), q.device, "scorer_bwd")
     with _timed("inbatch_softmax_bwd"):
         check(
             lib.mh_inbatch_softmax_bwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,

@@ -83,6 +83,74 @@ def test_scorer_backward_matches_autograd(device):
     torch.testing.assert_close((ditem + dneg).cpu(), it.grad, atol=1e-5, rtol=1e-3)
 
 
+def _autograd_scorer(q, it, ng, pid, nid, T, fns=O.MIN_FLOAT):
+    """fp64 autograd statement of the sampled-softmax loss mean and its gradients (separate negatives)."""
+    q, it, ng = (torch.from_numpy(a).double().requires_grad_() for a in (q, it, ng))
+    pos = (q * it).sum(-1, keepdim=True)
+    neg = q @ ng.T
+    if pid is not None:
+        m = torch.from_numpy(pid.astype(np.int64))[:, None] == torch.from_numpy(nid.astype(np.int64))[None, :]
+        neg = torch.where(m, torch.full_like(neg, float(np.float32(fns))), neg)
+    logits = torch.cat([pos, neg], 1) / T
+    per_row = torch.logsumexp(logits, 1) - logits[:, 0]
+    per_row.mean().backward()
+    return per_row.detach().numpy(), q.grad.numpy(), it.grad.numpy(), ng.grad.numpy()
+
+
+@pytest.mark.parametrize("B,Nn,E,idt", [(300, 300, 64, np.int64), (513, 700, 128, np.int32), (1000, 257, 32, np.int32),
+                                        (130, 130, 96, np.int64), (70, 90, 8, None), (257, 64, 128, None)])
+def test_scorer_flash_backward_matches_autograd(device, B, Nn, E, idt):
+    """Streaming kernels (mh_scorer_stream.hip): standalone row + column passes, and the fused forward+dq pass followed
+    by the column pass, against fp64 autograd -- ragged sizes, separate negatives, both id widths, padded E."""
+    rng = np.random.default_rng(B * 7 + Nn + E)
+    T = 0.5
+    q, it, ng = (rng.normal(size=s).astype(np.float32) * 0.4 for s in ((B, E), (B, E), (Nn, E)))
+    pid = nid = None
+    if idt is not None:
+        pid = rng.integers(0, 60, size=B).astype(idt)
+        nid = rng.integers(0, 60, size=Nn).astype(idt)
+    loss, gq, git, gng = _autograd_scorer(q, it, ng, pid, nid, T)
+    qd, itd, ngd = _t(q, device), _t(it, device), _t(ng, device)
+    pd = None if pid is None else _t(pid, device)
+    nd = None if nid is None else _t(nid, device)
+    r = ops.inbatch_softmax(qd, itd, ngd, pd, nd, T, materialize=False)
+    np.testing.assert_allclose(r.loss.cpu().numpy(), loss, atol=1e-4, rtol=1e-4)
+    dq, ditem, dneg = ops.inbatch_softmax_backward(qd, itd, ngd, r.lse, pd, nd, T)
+    tol = dict(atol=2e-6, rtol=2e-4)
+    np.testing.assert_allclose(dq.cpu().numpy(), gq, **tol)
+    np.testing.assert_allclose(ditem.cpu().numpy(), git, **tol)
+    np.testing.assert_allclose(dneg.cpu().numpy(), gng, **tol)
+    fused = ops.inbatch_softmax_train(qd, itd, ngd, pd, nd, T)
+    assert fused is not None
+    r2, dq2, ditem2 = fused
+    np.testing.assert_allclose(r2.loss.cpu().numpy(), loss, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(r2.lse.cpu().numpy(), r.lse.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(dq2.cpu().numpy(), gq, **tol)
+    np.testing.assert_allclose(ditem2.cpu().numpy(), git, **tol)
+    _, _, dneg2 = ops.inbatch_softmax_backward(qd, itd, ngd, r2.lse, pd, nd, T, need_dq=False)
+    np.testing.assert_allclose(dneg2.cpu().numpy(), gng, **tol)
+
+
+def test_scorer_fused_pass_rescale_branch(device):
+    """The fused forward+dq pass rescales its accumulators lazily (only when a tile exceeds the reference max by 2^16).
+    Force that branch: negatives far above the positive logit, growing along the stream, and one late spike."""
+    rng = np.random.default_rng(11)
+    B, Nn, E, T = 300, 900, 64, 0.1
+    q = rng.normal(size=(B, E)).astype(np.float32) * 0.5
+    it = (-q + rng.normal(size=(B, E)).astype(np.float32) * 0.1).astype(np.float32)  # strongly negative positives
+    ng = rng.normal(size=(Nn, E)).astype(np.float32) * 0.5
+    ng *= np.linspace(0.2, 3.0, Nn, dtype=np.float32)[:, None]   # maxima keep growing along the stream
+    ng[700] = q[17] * 6.0                                         # late spike for one row
+    loss, gq, git, gng = _autograd_scorer(q, it, ng, None, None, T)
+    qd, itd, ngd = _t(q, device), _t(it, device), _t(ng, device)
+    r, dq, ditem = ops.inbatch_softmax_train(qd, itd, ngd, None, None, T)
+    np.testing.assert_allclose(r.loss.cpu().numpy(), loss, atol=1e-3, rtol=1e-5)
+    np.testing.assert_allclose(dq.cpu().numpy(), gq, atol=5e-6, rtol=5e-4)
+    np.testing.assert_allclose(ditem.cpu().numpy(), git, atol=5e-6, rtol=5e-4)
+    ref = ops.inbatch_softmax(qd, itd, ngd, None, None, T, materialize=False)
+    np.testing.assert_allclose(r.lse.cpu().numpy(), ref.lse.cpu().numpy(), atol=1e-4, rtol=1e-6)
+
+
 @pytest.mark.parametrize("Bq,N,E,k", [(5, 40, 8, 7), (130, 5000, 64, 100), (64, 70000, 128, 10), (3, 300, 32, 300), (257, 1025, 16, 1)])
 def test_topk_bit_exact_vs_c_oracle(device, Bq, N, E, k):
     rng = np.random.default_rng(Bq + N)
