@@ -12,11 +12,48 @@ from typing import Callable, Dict, Optional
 import torch
 
 
-class GraphedStep:
-    """Capture ``fn(static_inputs)`` once; ``replay(new_inputs)`` copies + replays."""
+class PackedBatch:
+    """A batch (dict of tensors) stored as views of ONE contiguous buffer per dtype, so that loading the next batch
+    into the static inputs of a captured step is one device copy per dtype (two for ids + floats) instead of one per
+    column -- 40 columns would otherwise cost 40 copy launches per 1.5 ms step."""
 
-    def __init__(self, fn: Callable, inputs: Dict[str, torch.Tensor], warmup: int = 3):
-        self.inputs = {k: v.clone() for k, v in inputs.items()}
+    def __init__(self, tensors: Dict[str, torch.Tensor]):
+        self.layout = []  # (name, dtype, offset, shape)
+        sizes: Dict[torch.dtype, int] = {}
+        for k, v in tensors.items():
+            n = (v.numel() + 63) // 64 * 64  # 256-byte aligned columns
+            self.layout.append((k, v.dtype, sizes.get(v.dtype, 0), tuple(v.shape)))
+            sizes[v.dtype] = sizes.get(v.dtype, 0) + n
+        dev = next(iter(tensors.values())).device
+        self.buffers = {dt: torch.empty(n, dtype=dt, device=dev) for dt, n in sizes.items()}
+        self.tensors: Dict[str, torch.Tensor] = {}
+        for k, dt, off, shape in self.layout:
+            n = 1
+            for d in shape:
+                n *= d
+            view = self.buffers[dt][off:off + n].view(shape)
+            view.copy_(tensors[k])
+            self.tensors[k] = view
+
+    def copy_from(self, other: "PackedBatch") -> None:
+        for dt, buf in self.buffers.items():
+            buf.copy_(other.buffers[dt], non_blocking=True)
+
+    def nbytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b in self.buffers.values())
+
+
+class GraphedStep:
+    """Capture ``fn(static_inputs)`` once; ``replay(new_inputs)`` copies + replays.  ``inputs`` is a dict of tensors
+    or a ``PackedBatch`` (then ``new_inputs`` must be a ``PackedBatch`` of the same layout)."""
+
+    def __init__(self, fn: Callable, inputs, warmup: int = 3):
+        self.packed = None
+        if isinstance(inputs, PackedBatch):
+            self.packed = PackedBatch(inputs.tensors)
+            self.inputs = self.packed.tensors
+        else:
+            self.inputs = {k: v.clone() for k, v in inputs.items()}
         self.fn = fn
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -29,10 +66,13 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.output = fn(self.inputs)
 
-    def replay(self, new_inputs: Optional[Dict[str, torch.Tensor]] = None):
+    def replay(self, new_inputs=None):
         if new_inputs is not None:
-            for k, v in new_inputs.items():
-                self.inputs[k].copy_(v, non_blocking=True)
+            if self.packed is not None:
+                self.packed.copy_from(new_inputs)
+            else:
+                for k, v in new_inputs.items():
+                    self.inputs[k].copy_(v, non_blocking=True)
         self.graph.replay()
         return self.output
 

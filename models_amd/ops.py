@@ -26,7 +26,9 @@ __all__ = [
 
 class _KernelTimer:
     """Optional per-op HIP-event timing (bench.py): events are recorded on the stream the kernels
-    are launched on (torch's current stream), one (start, end) pair around each C-ABI call."""
+    are launched on (torch's current stream), one (start, end) pair around each C-ABI call.  Every launch also
+    records the ALGORITHMIC bytes / flops of exactly that launch (computed from its own arguments), so a
+    roofline figure never mixes launches of different sizes (sharded vs replicated lookups share an op name)."""
 
     def __init__(self):
         self.enabled = False
@@ -42,8 +44,9 @@ class _KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for name, evs in self.events.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = {"avg_ms": sum(ms) / len(ms), "launches": len(ms)}
+            ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+            out[name] = {"avg_ms": sum(ms) / len(ms), "launches": len(ms), "total_ms": sum(ms),
+                         "bytes": sum(e[2] for e in evs), "flops": sum(e[3] for e in evs)}
         return out
 
 
@@ -51,8 +54,8 @@ TIMER = _KernelTimer()
 
 
 class _timed:
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, nbytes=0, flops=0):
+        self.name, self.nbytes, self.flops = name, nbytes, flops
 
     def __enter__(self):
         if TIMER.enabled:
@@ -64,8 +67,11 @@ class _timed:
     def __exit__(self, *exc):
         if TIMER.enabled:
             self.b.record()
-            TIMER.events.setdefault(self.name, []).append((self.a, self.b))
+            TIMER.events.setdefault(self.name, []).append((self.a, self.b, self.nbytes, self.flops))
         return False
+
+
+_OPT_ROW_PASSES = {"sgd": 3, "adagrad": 5, "adam": 7, "lazy_adam": 7}  # grad r + (weight, state...) r/w per touched row
 
 
 def _stream() -> C.c_void_p:
@@ -246,7 +252,7 @@ def embedding_gather(
         idp = _host_ptr_array([i.data_ptr() for i in flat_ids[sl]])
         rows = (C.c_int64 * n)(*[w.shape[0] for w in tables[sl]])
         slot = (C.c_int64 * n)(*offsets[sl])
-        with _timed("embedding_gather"):
+        with _timed("embedding_gather", nbytes=B * n * (2 * D * 4 + flat_ids[0].element_size())):
             check(
                 lib.mh_embedding_gather_fwd(tab, rows, idp, idt, B, n, D, _ptr(out), row_stride, slot, _stream()),
                 "mh_embedding_gather_fwd",
@@ -345,7 +351,7 @@ def linear(
         _rowmajor_2d(out, "out")
     if M == 0:
         return out
-    with _timed(f"linear_{K}x{N}"):
+    with _timed(f"linear_{K}x{N}", nbytes=4 * (M * K + K * N + M * N), flops=2 * M * K * N):
         check(
             lib.mh_linear_bias_act_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation],
                                        _ptr(out), out.stride(0), _stream()),
@@ -375,7 +381,7 @@ def dot_interaction(
         _rowmajor_2d(out, "out")
     if B == 0:
         return out
-    with _timed("dot_interaction"):
+    with _timed("dot_interaction", nbytes=B * (F * D + P + T) * 4, flops=B * D * F * (F - 1)):
         check(
             lib.mh_dot_interaction_fwd(_ptr(x), B, F, D, _ptr(tail), 0 if tail is None else tail.stride(0), T,
                                        _ptr(out), out.stride(0), _stream()),
@@ -445,7 +451,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         SIDE.maybe_join()
         return dx, dW, db
     ws = _workspace(nbytes, x.device, "linear_bwd")
-    with _timed(f"linear_bwd_{K}x{N}"):
+    with _timed(f"linear_bwd_{K}x{N}", nbytes=4 * (2 * M * K + 2 * K * N + 2 * M * N), flops=(4 if need_dx else 2) * M * K * N):
         check(
             lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
                                        ACT[x_activation], _ptr(dx), lddx, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
@@ -461,7 +467,7 @@ def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int
     _rowmajor_2d(dout, "dout")
     B, F, D = x.shape
     dx = torch.empty_like(x)
-    with _timed("dot_interaction_bwd"):
+    with _timed("dot_interaction_bwd", nbytes=B * (2 * F * D + dout.shape[1]) * 4, flops=2 * B * D * F * (F - 1)):
         check(
             lib.mh_dot_interaction_bwd(_ptr(x), _ptr(dout), dout.stride(0), B, F, D, _ptr(dx), tail_slot,
                                        tail_width, _stream()),
@@ -508,7 +514,7 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_embedding_bwd_workspace_bytes failed")
     ws = _workspace(nbytes, grad.device, "embedding_bwd")
-    with _timed("embedding_bwd"):
+    with _timed("embedding_bwd", nbytes=B * F * (_OPT_ROW_PASSES[optimizer] * D * 4 + flat[0].element_size())):
         check(
             lib.mh_embedding_gather_bwd(tab, st, rows, idp, idt, B, F, D, _ptr(grad), row_stride, slot,
                                         _lib.OPT[optimizer], lr, eps, st2, beta1, beta2, _ptr(lr_device), _ptr(ws), ws.numel(),
@@ -707,7 +713,7 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
     loss = torch.empty((B,), dtype=torch.float32, device=q.device)
     lse = torch.empty((B,), dtype=torch.float32, device=q.device)
     ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 0), q.device, "scorer_fwd")
-    with _timed("inbatch_softmax_fwd"):
+    with _timed("inbatch_softmax_fwd", nbytes=4 * (2 * B + Nn) * E, flops=2 * B * Nn * E + 2 * B * E):
         check(
             lib.mh_inbatch_softmax_fwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
                                        temperature, false_neg_score, _ptr(logits), Nn + 1, _ptr(loss), _ptr(lse),
@@ -738,7 +744,7 @@ def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, tempera
     dq = torch.empty_like(q)
     ditem = torch.empty_like(item)
     ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 2), q.device, "scorer_fwd_dq")
-    with _timed("inbatch_softmax_fwd_dq"):
+    with _timed("inbatch_softmax_fwd_dq", nbytes=4 * (4 * B + Nn) * E, flops=4 * B * Nn * E):
         check(
             lib.mh_inbatch_softmax_fwd_dq(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
                                           temperature, false_neg_score, 1.0 / B if grad_scale is None else grad_scale,
@@ -762,7 +768,7 @@ def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None,
     ditem = torch.empty_like(item) if need_dq else None
     dneg = torch.empty_like(neg_item)
     ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 1), q.device, "scorer_bwd")
-    with _timed("inbatch_softmax_bwd"):
+    with _timed("inbatch_softmax_bwd", nbytes=4 * (3 * B + 2 * Nn) * E, flops=(8 if dq is not None else 4) * B * Nn * E):
         check(
             lib.mh_inbatch_softmax_bwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
                                        temperature, false_neg_score, _ptr(lse), 1.0 / B if grad_scale is None else grad_scale,
@@ -789,7 +795,7 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
     if Bq == 0:
         return scores, ids, idx
     ws = _workspace(lib.mh_topk_workspace_bytes(Bq, N, k), q.device, "topk")
-    with _timed("topk_dot"):
+    with _timed("topk_dot", nbytes=4 * (N + Bq) * E, flops=2 * Bq * N * E):
         check(
             lib.mh_topk_dot(_ptr(q), _ptr(candidates), _ptr(cand_ids), Bq, N, E, k, _ptr(scores), _ptr(ids), _ptr(idx),
                             _ptr(ws), ws.numel(), _stream()),
@@ -807,7 +813,7 @@ def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[
             raise ValueError(f"{n_} must be contiguous 2-D")
     M, d = x.shape
     out = torch.empty_like(x)
-    with _timed(f"cross_{d}"):
+    with _timed(f"cross_{d}", nbytes=4 * (4 * M * d + d * d), flops=2 * M * d * d):
         check(lib.mh_cross_layer_fwd(_ptr(x0), _ptr(x), _ptr(W), _ptr(b), M, d, _ptr(out), _stream()), "mh_cross_layer_fwd")
     return out
 
