@@ -7,6 +7,7 @@ ops raises.  PyTorch tensors are only buffer carriers (``tensor.data_ptr()``), t
 from __future__ import annotations
 
 import ctypes as C
+import os
 import shutil
 from pathlib import Path
 
@@ -99,8 +100,36 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("MERLIN_HIP_TRACE") == "1":
+        lib = _Traced(lib)
     _LIB = lib
     return lib
+
+
+class _Traced:
+    """Debug aid (MERLIN_HIP_TRACE=1): print every C-ABI call before it is issued and synchronise after it, so that a
+    GPU memory fault (which aborts the process) is attributed to the call that caused it."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in ("mh_last_error", "mh_version") or name.endswith("_workspace_bytes"):
+            return fn
+
+        def call(*a):
+            import sys
+
+            import torch
+
+            print(f"[mh-trace] {name}", file=sys.stderr, flush=True)
+            r = fn(*a)
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
+            return r
+
+        return call
 
 
 def check(status: int, what: str) -> None:

@@ -3,23 +3,28 @@
 // 1121-1174): Keras sums duplicate indices first (_deduplicate_indexed_slices) and then applies
 // the optimizer row-wise, so the update must see the SUM of a row's gradients exactly once.
 //
-// Pipeline (all on one stream, no host sync):
-//   1. build COMPACT keys: key = first_row[table] + id, i.e. the row number in the concatenation of the
-//      distinct tables (features sharing one table share its key range, so shared rows are updated once),
-//      + the packed (feature, sample) of every entry; out-of-range ids get the all-ones sentinel and sort
-//      to the end.  Keys are 32-bit whenever the tables hold < 2^32 - 1 rows together (64-bit otherwise);
-//   2. ONE stable rocPRIM radix sort of the (key, sample) pairs over ceil(log2(total rows + 1)) bits --
-//      23 bits = 3 Onesweep passes for the 26 Criteo tables of the headline config (library plumbing);
-//   3. segmented reduce over PIECES (a run cut at every 16th sorted index): one D/4-lane group per piece
-//      sums its gradient rows in registers; a piece that is a whole run is applied to the table row
-//      directly (exclusive owner, no atomics); the pieces of a run crossing a chunk boundary add to
-//      carry[home chunk] (home = chunk holding the run's first entry, from a max-scan of chunk flags)
-//      -- long runs of hot ids are pre-summed 16:1 in registers and 16:1 again through LDS;
+// Pipeline (all on one stream, no host sync, no scratch memory: the whole launch replays from a hipGraph):
+//   1. SEGMENTED stable LSD radix sort of the (id, packed (feature, sample)) pairs, hand-written (radix_*_kernel
+//      below).  A segment = the entries of the features that share one table (the host orders features so that a
+//      segment is contiguous); its sort key is the id itself (invalid ids -> rows, which sorts last), so the
+//      number of passes follows the LARGEST table (20 bits = 2 passes of 10 bits for 1M-row tables), not the
+//      total row count.  Pass 1 reads the ids directly (no key-build pass); the last pass emits COMPACT keys
+//      first_row[table] + id (the row number in the concatenation of the distinct tables; sentinel = all ones).
+//      Per pass: per-tile digit histograms -> per-segment exclusive scan -> stable scatter (wave-private digit
+//      counters in LDS, ranks from a ballot match);
+//   2. PIECES (a run cut at every 16th sorted index) enumerated into a compact list, each with the chunk its run
+//      starts in (found inside the workgroup's window, or by one binary search per workgroup for a run that began
+//      before it);
+//   3. segmented reduce over the pieces: one D/4-lane group per piece sums its gradient rows in registers; a
+//      piece that is a whole run is applied to the table row directly (exclusive owner, no atomics); the pieces of
+//      a run crossing a chunk boundary add to carry[home chunk] -- long runs of hot ids are pre-summed 16:1 in
+//      registers and 16:1 again through LDS;
 //   4. each chunk that is home to a crossing run applies the carried sum.
+//   MERLIN_HIP_DETERMINISTIC=1: step 3 skips the crossing pieces and step 4 walks every crossing run in sorted
+//   (sample) order instead -- no float atomics, bit-reproducible, slow for very hot rows (parity runs).
 // HBM traffic: grad rows read once (random), table (+state) rows read+written once per UNIQUE id.
+#include <cstdlib>
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "mh_common.h"
 
@@ -42,19 +47,179 @@ struct BwdArgs {
     int64_t first[MH_MAX_FEATURES];   // first compact key of the feature's table (shared tables share it)
 };
 
-template <typename IdT, typename KeyT>
-__global__ __launch_bounds__(256) void build_keys_kernel(const BwdArgs a, int64_t B, int F, KeyT* __restrict__ keys,
-                                                        uint32_t* __restrict__ vals,
-                                                        unsigned int* __restrict__ counter) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx == 0) *counter = 0u;  // piece counter of step 3 (saves a memset launch)
-    if (idx >= B * F) return;
-    const int f = (int)(idx / B);
-    const int64_t b = idx - (int64_t)f * B;
-    const int64_t id = (int64_t) static_cast<const IdT*>(a.ids[f])[b];
-    const bool ok = id >= 0 && id < a.rows[f];
-    keys[idx] = ok ? (KeyT)(a.first[f] + id) : KeyTraits<KeyT>::sentinel;
-    vals[idx] = ((uint32_t)f << 26) | (uint32_t)b;
+// ---- segmented LSD radix sort ---------------------------------------------------------------------------------------
+constexpr int RTILE = 4096;     // entries per workgroup tile (256 threads x 16)
+constexpr int RITEMS = 16;
+constexpr int RBITS_MAX = 11;   // digit width: 4 wave-private counter sets of 2^11 ints = 32 KB of LDS
+constexpr int MAX_SEG = MH_MAX_FEATURES;
+
+struct SortArgs {
+    const void* ids[MH_MAX_FEATURES];  // id column of feature f (features ordered so that a segment is contiguous)
+    int64_t rows[MAX_SEG];             // rows of the segment's table = its sentinel key
+    int64_t first[MAX_SEG];            // compact key of the table's row 0
+    int seg_f0[MAX_SEG + 1];           // first feature of segment s
+    int tile0[MAX_SEG + 1];            // first tile of segment s
+    int nseg;
+    int64_t B;
+};
+
+__device__ __forceinline__ int seg_of_tile(const SortArgs& a, int tile) {
+    int s = 0;
+    while (s + 1 < a.nseg && a.tile0[s + 1] <= tile) ++s;
+    return s;
+}
+
+// key of entry e of segment s in pass `first_pass` (straight from the ids) or from the previous pass's buffer
+template <typename IdT>
+__device__ __forceinline__ uint32_t load_local_key(const SortArgs& a, int s, int64_t e, bool first_pass,
+                                                   const uint32_t* __restrict__ keys_in, int64_t seg_base) {
+    if (!first_pass) return keys_in[seg_base + e];
+    const int64_t fo = e / a.B;
+    const int64_t b = e - fo * a.B;
+    const int64_t id = (int64_t) static_cast<const IdT*>(a.ids[a.seg_f0[s] + fo])[b];
+    return (id >= 0 && id < a.rows[s]) ? (uint32_t)id : (uint32_t)a.rows[s];
+}
+
+// cnt[tile0[s] * R + d * ntiles_s + t] = number of entries of tile t of segment s whose digit is d
+template <typename IdT>
+__global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const uint32_t* __restrict__ keys_in,
+                                                        int first_pass, int shift, int rbits, int* __restrict__ cnt) {
+    __shared__ int hist[1 << RBITS_MAX];
+    const int R = 1 << rbits;
+    for (int d = threadIdx.x; d < R; d += 256) hist[d] = 0;
+    __syncthreads();
+    const int s = seg_of_tile(a, blockIdx.x);
+    const int t = blockIdx.x - a.tile0[s];
+    const int nt = a.tile0[s + 1] - a.tile0[s];
+    const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
+    const int64_t n_s = (int64_t)(a.seg_f0[s + 1] - a.seg_f0[s]) * a.B;
+    const int64_t e0 = (int64_t)t * RTILE;
+#pragma unroll 4
+    for (int it = 0; it < RITEMS; ++it) {
+        const int64_t e = e0 + it * 256 + threadIdx.x;
+        if (e < n_s) {
+            const uint32_t k = load_local_key<IdT>(a, s, e, first_pass, keys_in, seg_base);
+            atomicAdd(&hist[(k >> shift) & (R - 1)], 1);
+        }
+    }
+    __syncthreads();
+    int* out = cnt + (int64_t)a.tile0[s] * R;
+    for (int d = threadIdx.x; d < R; d += 256) out[(int64_t)d * nt + t] = hist[d];
+}
+
+// one workgroup per segment: exclusive scan of its [R][ntiles] counters in place (digit-major = output order)
+__global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int rbits, int* __restrict__ cnt) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int s = blockIdx.x;
+    const int R = 1 << rbits;
+    const int nt = a.tile0[s + 1] - a.tile0[s];
+    int* c = cnt + (int64_t)a.tile0[s] * R;
+    const int64_t len = (int64_t)R * nt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < len; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = (i < len) ? c[i] : 0;
+        int x = v;  // inclusive scan inside the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < len) c[i] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + x;
+        __syncthreads();
+    }
+}
+
+// stable scatter of one tile: rank of an entry = entries with the same digit earlier in the tile (wave-private
+// counters, 16 rounds of 64 consecutive entries per wavefront; inside a round a ballot match gives the lanes that
+// share the digit) + the scanned global offset of (digit, tile).  LAST: emit compact keys instead of local ones.
+template <typename IdT, typename KeyT, bool LAST>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, const uint32_t* __restrict__ keys_in,
+                                                           const uint32_t* __restrict__ vals_in, int first_pass,
+                                                           int shift, int rbits, const int* __restrict__ cnt,
+                                                           void* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ int wcnt[4][1 << RBITS_MAX];
+    const int R = 1 << rbits;
+    for (int d = threadIdx.x; d < 4 * (1 << RBITS_MAX); d += 256) (&wcnt[0][0])[d] = 0;
+    const int s = seg_of_tile(a, blockIdx.x);
+    const int t = blockIdx.x - a.tile0[s];
+    const int nt = a.tile0[s + 1] - a.tile0[s];
+    const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
+    const int64_t n_s = (int64_t)(a.seg_f0[s + 1] - a.seg_f0[s]) * a.B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t e0 = (int64_t)t * RTILE + wave * (RTILE / 4);
+    uint32_t key[RITEMS], val[RITEMS];
+    int off[RITEMS];  // digit | rank-inside-(wave, digit) << 11
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RITEMS; ++it) {
+        const int64_t e = e0 + it * 64 + lane;
+        const bool live = e < n_s;
+        uint32_t k = 0, v = 0;
+        if (live) {
+            k = load_local_key<IdT>(a, s, e, first_pass, keys_in, seg_base);
+            if (first_pass) {
+                const int64_t fo = e / a.B;
+                v = ((uint32_t)(a.seg_f0[s] + fo) << 26) | (uint32_t)(e - fo * a.B);
+            } else {
+                v = vals_in[seg_base + e];
+            }
+        }
+        const int d = (int)((k >> shift) & (uint32_t)(R - 1));
+        // lanes of this round that hold the same digit (dead lanes match nobody)
+        uint64_t peers = __ballot(live);
+        for (int bit = 0; bit < rbits; ++bit) {
+            const uint64_t m = __ballot((d >> bit) & 1);
+            peers &= ((d >> bit) & 1) ? m : ~m;
+        }
+        int rank = 0;
+        if (live) {
+            const int leader = __ffsll((unsigned long long)peers) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&wcnt[wave][d], __popcll(peers));  // wave-private: only this wave adds
+            base = __shfl(base, leader);
+            rank = base + __popcll(peers & lt_mask);
+        }
+        key[it] = k;
+        val[it] = v;
+        off[it] = live ? (d | (rank << RBITS_MAX)) : -1;
+    }
+    __syncthreads();
+    // wcnt[w][d] := global offset of (d, tile) + entries of waves < w with digit d
+    const int* c = cnt + (int64_t)a.tile0[s] * R;
+    for (int d = threadIdx.x; d < R; d += 256) {
+        int run = c[(int64_t)d * nt + t];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int n = wcnt[w][d];
+            wcnt[w][d] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RITEMS; ++it) {
+        if (off[it] < 0) continue;
+        const int d = off[it] & ((1 << RBITS_MAX) - 1);
+        const int64_t pos = seg_base + wcnt[wave][d] + (off[it] >> RBITS_MAX);
+        if (LAST) {
+            const KeyT out = (key[it] < (uint32_t)a.rows[s]) ? (KeyT)(a.first[s] + (int64_t)key[it]) : KeyTraits<KeyT>::sentinel;
+            static_cast<KeyT*>(keys_out)[pos] = out;
+        } else {
+            static_cast<uint32_t*>(keys_out)[pos] = key[it];
+        }
+        vals_out[pos] = val[it];
+    }
 }
 
 struct OptHyper {
@@ -114,72 +279,91 @@ __device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const Op
 }
 
 
-// chunk c: v[c] = -1 if its first run continues from the previous chunk AND the whole chunk is that one
-// run (the run's home lies further back), else c.  An inclusive max-scan of v gives lasthome[c] = home
-// chunk of the LAST run of chunk c; the head piece of a continuing chunk c then belongs to lasthome[c-1].
-template <typename KeyT>
-__global__ __launch_bounds__(256) void chunk_flags_kernel(const KeyT* __restrict__ keys, int64_t n, int64_t nchunks,
-                                                         int* __restrict__ v) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
-    const int64_t c0 = c * CHUNK;
-    const int64_t c1 = (c0 + CHUNK < n) ? c0 + CHUNK : n;
-    const bool cont = (c0 > 0) && (keys[c0 - 1] == keys[c0]);
-    const bool whole = keys[c1 - 1] == keys[c0];  // sorted: first == last  <=>  one run
-    v[c] = (cont && whole) ? -1 : (int)c;
-}
-
 // A PIECE is a maximal range of sorted entries with one key inside one chunk of 16 (cuts at run starts and at
-// every 16th index).  piece_list_kernel enumerates the pieces of the valid (non-sentinel) prefix into a
-// compact list -- one 16-byte record {start:32 | len:5 | starts_run:1 | ends_run:1 | feature:6, key} each (one
-// load gives the consumer everything the table-row address needs).  A workgroup walks LIST_TILES tiles of 256
-// entries and bumps the global counter ONCE (same-address atomics retire at ~12 ns each: one bump per 256
-// entries cost 79 us for 1.7M entries); the list is ordered inside a workgroup, unordered across workgroups.
+// every 16th index; invalid entries -- the sentinels at the end of each segment -- belong to no piece).
+// piece_list_kernel enumerates the pieces into a compact list -- one 16-byte record {start:32 | len:5 |
+// starts_run:1 | ends_run:1 | feature:6, key} each (one load gives the consumer everything the table-row address
+// needs) -- plus, for a piece that continues a run begun earlier, home[p] = the chunk holding the run's first entry
+// (where the pieces of a crossing run meet: carry[home]).  The run start is the latest run start at or before the
+// piece inside the workgroup's window of LIST_TILES x 256 entries; a run that began before the window is located by
+// ONE binary search per workgroup (valid keys are sorted inside a segment, and everything before a valid entry of
+// a segment is valid).  A workgroup bumps the global counter ONCE (same-address atomics retire at ~12 ns each: one
+// bump per 256 entries cost 79 us for 1.7M entries); the list is ordered inside a workgroup, unordered across.
 constexpr int LIST_TILES = 8;
 
 template <typename KeyT>
-__global__ __launch_bounds__(256) void piece_list_kernel(const KeyT* __restrict__ keys,
+__global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, const KeyT* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals, int64_t n,
-                                                         ulonglong2* __restrict__ pieces,
+                                                         ulonglong2* __restrict__ pieces, int* __restrict__ home,
                                                          unsigned int* __restrict__ counter) {
     constexpr KeyT SENT = KeyTraits<KeyT>::sentinel;
     __shared__ unsigned int wave_cnt[LIST_TILES][4];
+    __shared__ int64_t wave_last_start[LIST_TILES][4];  // last run start inside (tile, wave), -1 if none
+    __shared__ int64_t start_before[LIST_TILES][4];     // latest run start before (tile, wave): in-window or searched
     __shared__ unsigned int block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint64_t le_mask = lt_mask | (1ull << lane);
     uint64_t rec[LIST_TILES];
     KeyT kk[LIST_TILES];
     unsigned int rank[LIST_TILES];
+    int64_t my_start[LIST_TILES];  // run start of this entry if it lies in the same wave, else -1
+    const int64_t w0 = (int64_t)blockIdx.x * LIST_TILES * 256;
 #pragma unroll
     for (int t = 0; t < LIST_TILES; ++t) {
-        const int64_t i = ((int64_t)blockIdx.x * LIST_TILES + t) * 256 + threadIdx.x;
+        const int64_t i = w0 + t * 256 + threadIdx.x;
         const KeyT k = (i < n) ? keys[i] : SENT;
         const bool valid = k != SENT;
         const bool run_start = valid && (i == 0 || keys[i - 1] != k);
         const bool cut = valid && (run_start || (i & (CHUNK - 1)) == 0);
         const uint64_t cuts = __ballot(cut);
-        const uint64_t valids = __ballot(valid);
+        const uint64_t stops = cuts | ~__ballot(valid);  // a piece ends before the next cut or the next invalid entry
+        const uint64_t starts = __ballot(run_start);
         rec[t] = 0;
         kk[t] = k;
+        my_start[t] = -1;
         if (cut) {
-            // the piece ends before the next cut of this wave, or with the wave's valid entries (64 | chunk
-            // size, so a wave boundary is always a cut or the end of the valid prefix)
-            const uint64_t later = (lane == 63) ? 0ull : (cuts >> (lane + 1));
-            const int nvalid = __popcll(valids);  // valid entries are a prefix of the wave (sentinels sort last)
-            const int len = later ? (__ffsll((unsigned long long)later)) : (nvalid - lane);
+            const uint64_t later = (lane == 63) ? 0ull : (stops >> (lane + 1));
+            const int len = later ? (__ffsll((unsigned long long)later)) : (64 - lane);  // 64 | chunk: a wave end is a cut
             const int64_t e = i + len;
             const bool ends = (e >= n) || (keys[e] != k);
             rec[t] = (uint64_t)i | ((uint64_t)len << 32) | ((uint64_t)(run_start ? 1 : 0) << 37) |
                      ((uint64_t)(ends ? 1 : 0) << 38) | ((uint64_t)(vals[i] >> 26) << 39) | (1ull << 63);
+            const uint64_t sb = starts & le_mask;
+            if (sb) my_start[t] = i - lane + (63 - __clzll((unsigned long long)sb));
         }
         rank[t] = __popcll(cuts & lt_mask);
-        if (lane == 0) wave_cnt[t][wave] = __popcll(cuts);
+        if (lane == 0) {
+            wave_cnt[t][wave] = __popcll(cuts);
+            wave_last_start[t][wave] = starts ? (i + (63 - __clzll((unsigned long long)starts))) : -1;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int tot = 0;
         for (int t = 0; t < LIST_TILES; ++t) tot += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
         block_base = tot ? atomicAdd(counter, tot) : 0u;
+        // the run that reaches into this window from before it (if any): lower bound of its key inside the segment
+        int64_t pre = -1;
+        if (w0 > 0 && w0 < n) {
+            const KeyT k0 = keys[w0];
+            if (k0 != SENT && keys[w0 - 1] == k0) {
+                int sg = 0;
+                while (sg + 1 < sa.nseg && (int64_t)sa.seg_f0[sg + 1] * sa.B <= w0) ++sg;
+                int64_t lo = (int64_t)sa.seg_f0[sg] * sa.B, hi = w0 - 1;  // keys[hi] == k0; find the first index with k0
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (keys[mid] < k0) lo = mid + 1; else hi = mid;
+                }
+                pre = lo;
+            }
+        }
+        int64_t run = pre;
+        for (int t = 0; t < LIST_TILES; ++t)
+            for (int w = 0; w < 4; ++w) {
+                start_before[t][w] = run;
+                if (wave_last_start[t][w] >= 0) run = wave_last_start[t][w];
+            }
     }
     __syncthreads();
     unsigned int o = block_base;
@@ -187,7 +371,12 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const KeyT* __restrict_
     for (int t = 0; t < LIST_TILES; ++t) {
         unsigned int before = 0;
         for (int w = 0; w < wave; ++w) before += wave_cnt[t][w];
-        if (rec[t]) pieces[o + before + rank[t]] = make_ulonglong2(rec[t], (uint64_t)kk[t]);
+        if (rec[t]) {
+            const unsigned int p = o + before + rank[t];
+            pieces[p] = make_ulonglong2(rec[t], (uint64_t)kk[t]);
+            const int64_t st = (my_start[t] >= 0) ? my_start[t] : start_before[t][wave];
+            home[p] = (int)(st / CHUNK);
+        }
         o += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
     }
 }
@@ -201,10 +390,10 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const KeyT* __restrict_
 __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a, const uint32_t* __restrict__ vals,
                                                                 int D, int LPR, const float* __restrict__ grad,
                                                                 int64_t grad_row_stride, float* __restrict__ carry,
-                                                                const int* __restrict__ lasthome,
+                                                                const int* __restrict__ home,
                                                                 const ulonglong2* __restrict__ pieces,
                                                                 const unsigned int* __restrict__ counter, int opt,
-                                                                const OptHyper hp) {
+                                                                const OptHyper hp, int deterministic) {
     __shared__ f32x4 part_s[256];      // partial sum of every group (one f32x4 per thread)
     __shared__ uint64_t part_key[64];  // key of a group's partial-run piece, ~0 if it has none
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
@@ -231,7 +420,7 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         const bool starts = (rec >> 37) & 1, ends = (rec >> 38) & 1;
         const int fk = (int)((rec >> 39) & 63);
         const bool whole = active && starts && ends;
-        const bool partial = active && !whole;
+        const bool partial = active && !whole && !deterministic;  // deterministic: carry_apply walks crossing runs itself
         RowRmw rr;
         if (whole) load_row(a, fk, (int64_t)key, D, c4, opt, rr);  // independent of the gradient rows: overlaps them
         const uint32_t* vv = vals + s0;
@@ -264,9 +453,7 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         if (partial && (gi == 0 || part_key[gi - 1] != key)) {
             f32x4 sum = acc;
             for (int g2 = gi + 1; g2 < groups && part_key[g2] == key; ++g2) sum += part_s[g2 * LPR + c4];
-            const int64_t chunk = s0 / CHUNK;
-            const int64_t home = starts ? chunk : (int64_t)lasthome[chunk - 1];
-            float* cr = carry + home * D + c4 * 4;
+            float* cr = carry + (int64_t)home[p] * D + c4 * 4;
             atomicAdd(cr + 0, sum.x);
             atomicAdd(cr + 1, sum.y);
             atomicAdd(cr + 2, sum.z);
@@ -276,114 +463,124 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
     }
 }
 
-// Chunk c is home to a carried sum iff a run starts inside it (flags[c] == c, see chunk_flags_kernel) and its last
-// run continues into chunk c + 1.
+// Chunk c is home to a carried sum iff its last run starts inside it and continues into chunk c + 1.
+// deterministic != 0: nothing was carried; the group walks the whole crossing run in sorted (sample) order.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const KeyT* __restrict__ keys,
-                                                         const uint32_t* __restrict__ vals,
-                                                         const int* __restrict__ flags, int64_t n, int D, int LPR,
-                                                         const float* __restrict__ carry, int opt, const OptHyper hp) {
+                                                         const uint32_t* __restrict__ vals, int64_t n, int D, int LPR,
+                                                         const float* __restrict__ carry, int opt, const OptHyper hp,
+                                                         const float* __restrict__ grad, int64_t grad_row_stride,
+                                                         int deterministic) {
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
     if (gi >= groups) return;
     const int64_t chunk = (int64_t)blockIdx.x * groups + gi;
-    const int64_t c1 = (chunk + 1) * CHUNK;
+    const int64_t c0 = chunk * CHUNK;
+    const int64_t c1 = c0 + CHUNK;
     if (c1 >= n) return;  // the last chunk cannot be crossed
-    if (flags[chunk] < 0) return;  // one run that began earlier: an earlier chunk is its home
     const KeyT key = keys[c1 - 1];
     if (key == KeyTraits<KeyT>::sentinel || keys[c1] != key) return;  // last run ends here
-    const f32x4 g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
+    int64_t st = c1 - 1;                                              // first entry of that run inside the chunk
+    while (st > c0 && keys[st - 1] == key) --st;
+    if (st == c0 && c0 > 0 && keys[c0 - 1] == key) return;  // the run began in an earlier chunk: that one is its home
+    f32x4 g;
+    if (!deterministic) {
+        g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
+    } else {
+        g = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t i = st; i < n && keys[i] == key; ++i) {
+            const uint32_t v = vals[i];
+            g += *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
+                                                 a.offset[v >> 26] + c4 * 4);
+        }
+    }
     RowRmw rr;
     load_row(a, (int)(vals[c1 - 1] >> 26), (int64_t)key, D, c4, opt, rr);
     finish_row(rr, g, opt, hp);
 }
 
 struct WsLayout {
-    int64_t n, nchunks;
-    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_flags, off_home, off_pieces, off_counter,
-        off_tmp, tmp_bytes, total;
+    int64_t n, nchunks, max_tiles;
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_home, off_pieces, off_counter, off_cnt, total;
 };
-
-// rocPRIM switches to a merge sort (dozens of 5 us launches) below 1M items; Onesweep already wins from ~64K.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, 65536>;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Sized for the 64-bit key variant (the 32-bit one uses the front of the same buffers).
+// digit width of the sort for n entries: 11 bits, narrower for very long inputs (bounds the counter array)
+int radix_bits_for(int64_t n) { return n > (1ll << 24) ? 8 : RBITS_MAX; }
+
+// Sized for 64-bit final keys (the 32-bit variant uses the front of the same buffers).
 bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->n = B * F;
     L->nchunks = mh_ceil_div(L->n, CHUNK);
-    size_t tmp = 0, tmp32 = 0;
-    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                                         (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, 64);
-    if (e != hipSuccess) return false;
-    e = rocprim::radix_sort_pairs<SortConfig>(nullptr, tmp32, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                              (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)L->n, 0, 32);
-    if (e != hipSuccess) return false;
-    if (tmp32 > tmp) tmp = tmp32;
-    size_t scan = 0;
-    e = rocprim::inclusive_scan(nullptr, scan, (const int*)nullptr, (int*)nullptr, (size_t)L->nchunks,
-                                rocprim::maximum<int>());
-    if (e != hipSuccess) return false;
-    if (scan > tmp) tmp = scan;
+    L->max_tiles = mh_ceil_div(L->n, RTILE) + F;  // every segment rounds its last tile up
     size_t o = 0;
     L->off_keys_a = o; o = align_up(o + (size_t)L->n * 8, 256);
     L->off_keys_b = o; o = align_up(o + (size_t)L->n * 8, 256);
     L->off_vals_a = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_vals_b = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_carry = o; o = align_up(o + (size_t)L->nchunks * D * 4, 256);
-    L->off_flags = o; o = align_up(o + (size_t)L->nchunks * 4, 256);
-    L->off_home = o; o = align_up(o + (size_t)L->nchunks * 4, 256);
     L->off_pieces = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 16, 256);  // <= one cut per run + per chunk
+    L->off_home = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 4, 256);
     L->off_counter = o; o = align_up(o + 4, 256);
-    L->off_tmp = o; L->tmp_bytes = tmp; o = align_up(o + tmp, 256);
+    L->off_cnt = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << radix_bits_for(L->n)) * 4, 256);
     L->total = o;
     return true;
 }
 
-template <typename KeyT>
-int32_t run_pipeline(const BwdArgs& a, const WsLayout& L, char* ws, int ids_dtype, int64_t B, int F, int D, int bits,
-                     const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp, hipStream_t s) {
-    KeyT* keys_a = reinterpret_cast<KeyT*>(ws + L.off_keys_a);
-    KeyT* keys_b = reinterpret_cast<KeyT*>(ws + L.off_keys_b);
-    uint32_t* vals_a = reinterpret_cast<uint32_t*>(ws + L.off_vals_a);
-    uint32_t* vals_b = reinterpret_cast<uint32_t*>(ws + L.off_vals_b);
+bool deterministic_mode() {
+    const char* v = getenv("MERLIN_HIP_DETERMINISTIC");
+    return v && v[0] == '1';
+}
+
+template <typename IdT, typename KeyT>
+int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int max_bits, const WsLayout& L, char* ws, int64_t B, int F,
+                       int D, const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp,
+                       hipStream_t s) {
+    void* kbuf[2] = {ws + L.off_keys_a, ws + L.off_keys_b};
+    uint32_t* vbuf[2] = {reinterpret_cast<uint32_t*>(ws + L.off_vals_a), reinterpret_cast<uint32_t*>(ws + L.off_vals_b)};
     float* carry = reinterpret_cast<float*>(ws + L.off_carry);
-    int* flags = reinterpret_cast<int*>(ws + L.off_flags);
-    int* lasthome = reinterpret_cast<int*>(ws + L.off_home);
+    int* home = reinterpret_cast<int*>(ws + L.off_home);
     ulonglong2* pieces = reinterpret_cast<ulonglong2*>(ws + L.off_pieces);
     unsigned int* counter = reinterpret_cast<unsigned int*>(ws + L.off_counter);
+    int* cnt = reinterpret_cast<int*>(ws + L.off_cnt);
+    const int det = deterministic_mode() ? 1 : 0;
 
-    dim3 gk((unsigned)mh_ceil_div(L.n, 256));
-    if (ids_dtype == MH_I32)
-        hipLaunchKernelGGL((build_keys_kernel<int32_t, KeyT>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a, counter);
-    else
-        hipLaunchKernelGGL((build_keys_kernel<int64_t, KeyT>), gk, dim3(256), 0, s, a, B, F, keys_a, vals_a, counter);
-    // stable sort over the key bits in use only; the all-ones sentinel stays last because no valid key has all
-    // of those bits set (bits = ceil(log2(total rows + 1)))
-    size_t tmp_bytes = L.tmp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs<SortConfig>(ws + L.off_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b,
-                                                         (size_t)L.n, 0, bits, s);
-    if (e != hipSuccess) {
-        mh_set_error("mh_embedding_gather_bwd: radix sort failed: %s", hipGetErrorString(e));
-        return MH_ERR_LAUNCH;
+    // ---- 1. segmented stable LSD radix sort: passes of equal width over the bits of the largest table ----------------
+    const int rmax = radix_bits_for(L.n);
+    const int npass = (max_bits + rmax - 1) / rmax;
+    const int rbits = (max_bits + npass - 1) / npass;
+    const int ntiles = sa.tile0[sa.nseg];
+    int src = 0;                            // buffer holding the previous pass's output
+    int dst = (npass % 2 == 1) ? 1 : 0;     // the LAST pass must land in buffer 1 (keys_b / vals_b)
+    for (int p = 0; p < npass; ++p) {
+        const int shift = p * rbits;
+        const bool first = (p == 0), last = (p == npass - 1);
+        const uint32_t* kin = first ? nullptr : static_cast<const uint32_t*>(kbuf[src]);
+        const uint32_t* vin = first ? nullptr : vbuf[src];
+        hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, kin, first ? 1 : 0, shift,
+                           rbits, cnt);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, rbits, cnt);
+        if (last)
+            hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT, true>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, kin, vin,
+                               first ? 1 : 0, shift, rbits, cnt, kbuf[dst], vbuf[dst]);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT, false>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, kin, vin,
+                               first ? 1 : 0, shift, rbits, cnt, kbuf[dst], vbuf[dst]);
+        src = dst;
+        dst ^= 1;
     }
-    (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
+    const KeyT* keys = static_cast<const KeyT*>(kbuf[1]);
+    const uint32_t* vals = vbuf[1];
+
+    // ---- 2. piece list, 3. segmented reduce + fused optimizer, 4. carried runs -------------------------------------------
+    (void)hipMemsetAsync(counter, 0, sizeof(unsigned int), s);
+    if (!det) (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
     const int LPR = D / 4;
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
-    dim3 gs((unsigned)mh_ceil_div(L.nchunks, groups));
-    hipLaunchKernelGGL((chunk_flags_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, 256)), dim3(256), 0, s, keys_b,
-                       L.n, L.nchunks, flags);
-    size_t scan_bytes = L.tmp_bytes;
-    e = rocprim::inclusive_scan(ws + L.off_tmp, scan_bytes, flags, lasthome, (size_t)L.nchunks, rocprim::maximum<int>(), s);
-    if (e != hipSuccess) {
-        mh_set_error("mh_embedding_gather_bwd: scan failed: %s", hipGetErrorString(e));
-        return MH_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s,
-                       keys_b, vals_b, L.n, pieces, counter);
+    hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
+                       keys, vals, L.n, pieces, home, counter);
     {
         int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
         static int resident = 0;  // workgroups per CU the kernel's register budget allows: exactly one resident wave
@@ -394,10 +591,11 @@ int32_t run_pipeline(const BwdArgs& a, const WsLayout& L, char* ws, int ids_dtyp
         }
         const int64_t cap = (int64_t)mh_num_cus() * resident;
         if (nb > cap) nb = cap;
-        hipLaunchKernelGGL(piece_reduce_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, vals_b, D, LPR, grad,
-                           grad_row_stride, carry, lasthome, pieces, counter, optimizer, hp);
+        hipLaunchKernelGGL(piece_reduce_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad,
+                           grad_row_stride, carry, home, pieces, counter, optimizer, hp, det);
     }
-    hipLaunchKernelGGL((carry_apply_kernel<KeyT>), gs, dim3(256), 0, s, a, keys_b, vals_b, flags, L.n, D, LPR, carry, optimizer, hp);
+    hipLaunchKernelGGL((carry_apply_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, groups)), dim3(256), 0, s, a, keys,
+                       vals, L.n, D, LPR, carry, optimizer, hp, grad, grad_row_stride, det);
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;
 }
@@ -492,47 +690,76 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     MH_REQUIRE(B < (1ll << 26), "mh_embedding_gather_bwd: B must be < 2^26");
     MH_REQUIRE(B * F < (1ll << 31), "mh_embedding_gather_bwd: B*F must be < 2^31");
     WsLayout L;
-    MH_REQUIRE(ws_layout(B, F, D, &L), "mh_embedding_gather_bwd: rocprim size query failed");
+    ws_layout(B, F, D, &L);
     if (!workspace || workspace_bytes < (int64_t)L.total) {
         mh_set_error("mh_embedding_gather_bwd: workspace too small (%lld < %zu)", (long long)workspace_bytes, L.total);
         return MH_ERR_WORKSPACE;
     }
+    // features ordered so that those sharing a table are adjacent: a SEGMENT of the sort (first-appearance order)
+    int order[MH_MAX_FEATURES], seg_of[MH_MAX_FEATURES], nseg = 0, pos = 0;
+    bool placed[MH_MAX_FEATURES] = {false};
     BwdArgs a;
+    SortArgs sa;
     std::memset(&a, 0, sizeof(a));
+    std::memset(&sa, 0, sizeof(sa));
     int64_t total_rows = 0;  // rows of the distinct tables back to back = the compact key space
+    int64_t max_rows = 1;
     for (int f = 0; f < F; ++f) {
         MH_REQUIRE(table_rows[f] >= 1, "mh_embedding_gather_bwd: table %d has no rows", f);
+        MH_REQUIRE(table_rows[f] < 0xffffffffll, "mh_embedding_gather_bwd: table %d has 2^32 - 1 rows or more", f);
         MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_bwd: null table/ids for feature %d", f);
         MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_gather_bwd: null optimizer state for feature %d", f);
         MH_REQUIRE(optimizer != MH_OPT_ADAM || state2[f], "mh_embedding_gather_bwd: null second moment for feature %d", f);
-        a.table[f] = tables[f];
-        a.state[f] = state ? state[f] : nullptr;
-        a.state2[f] = state2 ? state2[f] : nullptr;
-        a.ids[f] = ids[f];
-        a.rows[f] = table_rows[f];
         MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && grad_offset[f] + D <= grad_row_stride,
                    "mh_embedding_gather_bwd: grad offset of feature %d misaligned or out of row", f);
-        a.offset[f] = grad_offset[f];
-        a.first[f] = -1;
-        for (int g = 0; g < f; ++g)
-            if (tables[g] == tables[f]) {
-                MH_REQUIRE(table_rows[g] == table_rows[f], "mh_embedding_gather_bwd: features %d and %d share a table but not its row count", g, f);
-                a.first[f] = a.first[g];
-                break;
+        if (placed[f]) continue;
+        sa.seg_f0[nseg] = pos;
+        sa.rows[nseg] = table_rows[f];
+        sa.first[nseg] = total_rows;
+        for (int g = f; g < F; ++g)
+            if (!placed[g] && tables[g] == tables[f]) {
+                MH_REQUIRE(table_rows[g] == table_rows[f], "mh_embedding_gather_bwd: features %d and %d share a table but not its row count", f, g);
+                placed[g] = true;
+                order[pos] = g;
+                seg_of[pos] = nseg;
+                ++pos;
             }
-        if (a.first[f] < 0) {
-            a.first[f] = total_rows;
-            total_rows += table_rows[f];
-        }
+        total_rows += table_rows[f];
+        if (table_rows[f] > max_rows) max_rows = table_rows[f];
+        ++nseg;
+    }
+    sa.seg_f0[nseg] = F;
+    sa.nseg = nseg;
+    sa.B = B;
+    int tiles = 0;
+    for (int sg = 0; sg < nseg; ++sg) {
+        sa.tile0[sg] = tiles;
+        tiles += (int)mh_ceil_div((int64_t)(sa.seg_f0[sg + 1] - sa.seg_f0[sg]) * B, RTILE);
+    }
+    sa.tile0[nseg] = tiles;
+    for (int i = 0; i < F; ++i) {  // position i of the kernel-side arrays = original feature order[i]
+        const int f = order[i];
+        a.table[i] = tables[f];
+        a.state[i] = state ? state[f] : nullptr;
+        a.state2[i] = state2 ? state2[f] : nullptr;
+        a.ids[i] = ids[f];
+        a.rows[i] = table_rows[f];
+        a.offset[i] = grad_offset[f];
+        a.first[i] = sa.first[seg_of[i]];
+        sa.ids[i] = ids[f];
     }
     char* ws = static_cast<char*>(workspace);
     hipStream_t s = mh_stream(stream);
     const OptHyper hp = {lr, eps, beta1, beta2, lr_device};
-    int bits = 1;
-    while (bits < 64 && (1ull << bits) < (uint64_t)total_rows + 1) ++bits;
-    if ((uint64_t)total_rows < 0xffffffffull)
-        return run_pipeline<uint32_t>(a, L, ws, ids_dtype, B, F, D, bits, grad, grad_row_stride, optimizer, hp, s);
-    return run_pipeline<uint64_t>(a, L, ws, ids_dtype, B, F, D, bits, grad, grad_row_stride, optimizer, hp, s);
+    int max_bits = 1;  // bits of the largest local key: ids 0 .. rows-1 and the sentinel `rows`
+    while (max_bits < 32 && (1ull << max_bits) < (uint64_t)max_rows + 1) ++max_bits;
+    const bool wide = (uint64_t)total_rows >= 0xffffffffull;
+    if (ids_dtype == MH_I32) {
+        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+        return run_pipeline_t<int32_t, uint64_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+    }
+    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+    return run_pipeline_t<int64_t, uint64_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
 }
 
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D) {

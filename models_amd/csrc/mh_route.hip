@@ -5,11 +5,10 @@
 // this is a STABLE counting sort by owner (W <= 64 buckets), so the order -- and therefore the order in which
 // the owner's fused backward sums duplicate rows -- is a pure function of the ids:
 //   pass 1  per-tile owner histogram                      -> hist[w][tile]
-//   scan    exclusive prefix over the (w, tile) sequence  -> first send slot of every (owner, tile) pair
+//   scan    exclusive prefix over the (w, tile) sequence  -> first send slot of every (owner, tile) pair (one workgroup)
 //   pass 2  per-tile stable ranks (wave ballots), scatter keys / inverse permutation / gradient source rows
 // Replaces ~45 framework launches (stack, shifts, remainder, merge sort, bincount, index ...) per step.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "mh_common.h"
 
@@ -125,9 +124,36 @@ __global__ void route_local_rows_kernel(const int64_t* __restrict__ keys, int64_
     rows[i] = base[f] + (k & ((1ll << 40) - 1));
 }
 
+// exclusive prefix of the (owner, tile) histogram, one workgroup (the sequence is W * ntiles ints: a few thousand)
+__global__ __launch_bounds__(1024) void route_scan_kernel(const int* __restrict__ in, int* __restrict__ out, int64_t len) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < len; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = (i < len) ? in[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < len) out[i] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + x;
+        __syncthreads();
+    }
+}
+
 struct RouteWs {
     int64_t ntiles;
-    size_t off_hist, off_scan, off_tmp, tmp_bytes, total;
+    size_t off_hist, off_scan, total;
 };
 
 size_t up(size_t v) { return (v + 255) / 256 * 256; }
@@ -135,15 +161,9 @@ size_t up(size_t v) { return (v + 255) / 256 * 256; }
 bool route_ws(int64_t n, int W, RouteWs* L) {
     L->ntiles = mh_ceil_div(n, TILE);
     const size_t cells = (size_t)L->ntiles * W;
-    size_t tmp = 0;
-    if (rocprim::exclusive_scan(nullptr, tmp, (const int*)nullptr, (int*)nullptr, 0, cells, rocprim::plus<int>()) !=
-        hipSuccess)
-        return false;
-    L->tmp_bytes = tmp;
     L->off_hist = 0;
     L->off_scan = up(cells * sizeof(int));
-    L->off_tmp = L->off_scan + up(cells * sizeof(int));
-    L->total = L->off_tmp + up(tmp);
+    L->total = L->off_scan + up(cells * sizeof(int));
     return true;
 }
 
@@ -179,7 +199,7 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
     const int64_t n = B * F;
     MH_REQUIRE(n < (1ll << 31), "mh_route_build: F*B must be < 2^31");
     RouteWs L;
-    MH_REQUIRE(route_ws(n, W, &L), "mh_route_build: rocprim size query failed");
+    route_ws(n, W, &L);
     MH_REQUIRE(workspace_bytes >= (int64_t)L.total, "mh_route_build: workspace too small (%lld < %lld)",
                (long long)workspace_bytes, (long long)L.total);
     RouteArgs a;
@@ -198,12 +218,7 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
         hipLaunchKernelGGL(route_count_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
     else
         hipLaunchKernelGGL(route_count_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
-    size_t tmp = L.tmp_bytes;
-    if (rocprim::exclusive_scan(ws + L.off_tmp, tmp, hist, scan, 0, (size_t)L.ntiles * W, rocprim::plus<int>(), s) !=
-        hipSuccess) {
-        mh_set_error("mh_route_build: rocprim scan failed");
-        return MH_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, s, hist, scan, L.ntiles * W);
     hipLaunchKernelGGL(route_counts_kernel, dim3(1), dim3(64), 0, s, scan, L.ntiles, W, n, counts);
     if (ids_dtype == MH_I32)
         hipLaunchKernelGGL(route_scatter_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,

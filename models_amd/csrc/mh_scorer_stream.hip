@@ -22,6 +22,7 @@
 
 #include <math.h>
 
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -33,7 +34,7 @@ constexpr float LN2 = 0.6931471805599453f;
 constexpr float NEG_BIG = -1.0e30f;  // finite "minus infinity" in the base-2 domain
 constexpr float LAZY_THR = 16.f;     // FWD_GRAD: rescale only when a tile exceeds the reference max by 2^16
 
-enum { SM_FWD = 0, SM_GRAD = 1, SM_FWD_GRAD = 2 };
+enum { SM_FWD = 0, SM_GRAD = 1, SM_FWD_GRAD = 2, SM_FILTER = 3 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -57,6 +58,13 @@ struct StreamArgs {
     int bn;               // streamed rows per LDS tile (multiple of 32; 64 or 128)
     int tiles_per_split;  // tiles of bn rows per blockIdx.y
     int prio;             // 1: the second half of the workgroup's wavefronts runs at s_setprio 1
+    // SM_FILTER (top-k threshold filter, mh_topk.hip): scores >= tau[x] are appended to the row's compact list
+    const float* tau;  // [Nx] current k-th best score of every stationary (query) row
+    int* cnt;          // [Nx] entries in the row's list
+    float* cs;         // [Nx, cap] scores
+    int32_t* ci;       // [Nx, cap] candidate indices (idx0 + streamed row)
+    int cap;
+    int64_t idx0;
 };
 
 // Lane id recomputed on the spot (volatile asm is neither CSE'd nor hoisted): the DMA issue code at the top of a tile
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
     float xf[2][NC];
     bool xvalid[2];
     IdT x_id[2];
-    float lse2_x[2], m_run[2], s_run[2];
+    float lse2_x[2], m_run[2], s_run[2], tau_x[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         int64_t xrow = x0 + 16 * q + l15;
@@ -181,13 +189,15 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
         if (MODE == SM_GRAD && !LSE_STREAM) lse2_x[q] = a.lse[xrow] * LOG2E;
         m_run[q] = NEG_BIG;
         s_run[q] = 0.f;
+        tau_x[q] = 0.f;
+        if (MODE == SM_FILTER) tau_x[q] = xvalid[q] ? a.tau[xrow] : INFINITY;
         if (MODE == SM_FWD_GRAD) m_run[q] = a.pos[xrow] * a.invT * LOG2E;  // the reference max starts at the positive logit
     }
     const float scale2 = a.invT * LOG2E;
     const float fns_z = a.fns * a.invT;
     const float fns_z2 = fns_z * LOG2E;
     f32x4 o[2][TN];
-    if (MODE != SM_FWD) {
+    if (MODE == SM_GRAD || MODE == SM_FWD_GRAD) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -248,6 +258,25 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
             }
             // ---- epilogue: this lane holds x = 16 q + l15 and j = ju*16 + 4 slot + reg ----------------------------------
             const int jl0 = ju * 16 + 4 * slot;
+            if (MODE == SM_FILTER) {  // rare survivors (k / n_seen of the scores): one atomic each
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 acc = q ? acc1 : acc0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jl = jl0 + r;
+                        if (acc[r] >= tau_x[q] && jl < nvalid) {
+                            const int64_t row = x0 + 16 * q + l15;
+                            const int pos = atomicAdd(&a.cnt[row], 1);
+                            if (pos < a.cap) {
+                                a.cs[row * a.cap + pos] = acc[r];
+                                a.ci[row * a.cap + pos] = (int32_t)(a.idx0 + j_tile + jl);
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
             bool msk[4];
             float lsej[4];
 #pragma unroll
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
             }
         }
     }
-    if (MODE != SM_FWD) {
+    if (MODE == SM_GRAD || MODE == SM_FWD_GRAD) {
         // C layout of GEMM 2: column e = 16 tn + l15, row x = 16 q + 4 slot + reg
         float* op = a.opart + (int64_t)split * a.Nx * E;
 #pragma unroll
@@ -530,13 +559,14 @@ MhStreamPlan mh_stream_plan(int mode, int64_t Nx, int64_t Ny, int E, int ids_byt
     MhStreamPlan p;
     // forward: 64-row tiles (64 KB of LDS -> two workgroups per CU); gradient modes hold ~200 registers -> one
     // workgroup per CU anyway, so they take 128-row tiles (half as many barriers)
-    p.bn = env_int(mode == SM_FWD ? "MERLIN_HIP_SCORER_BN_FWD" : "MERLIN_HIP_SCORER_BN_GRAD", mode == SM_FWD ? 64 : 128);
+    const bool light = (mode == SM_FWD || mode == SM_FILTER);  // no second GEMM: ~110 registers, two workgroups per CU
+    p.bn = env_int(light ? "MERLIN_HIP_SCORER_BN_FWD" : "MERLIN_HIP_SCORER_BN_GRAD", light ? 64 : 128);
     if (p.bn != 64 && p.bn != 128) p.bn = 128;
     if (Ny <= 64) p.bn = 64;
     p.row_tiles = (int)mh_ceil_div(Nx, SX);
     p.nt = (int)mh_ceil_div(Ny, p.bn);
     if (p.nt < 1) p.nt = 1;
-    const int wg_per_cu = (mode == SM_FWD && p.bn == 64) ? 2 : 1;
+    const int wg_per_cu = (light && p.bn == 64) ? 2 : 1;
     int want = (int)((int64_t)mh_num_cus() * wg_per_cu / p.row_tiles);
     if (want < 1) want = 1;
     if (want > p.nt) want = p.nt;
@@ -556,11 +586,13 @@ int32_t mh_stream_launch(int mode, int lse_stream, const MhStreamPlan& p, const 
     a.invT = invT; a.fns = fns; a.gscale = gscale; a.logits = logits; a.ld_logits = ld_logits;
     a.part_m = part_m; a.part_s = part_s; a.opart = opart; a.bn = p.bn; a.tiles_per_split = p.tps;
     a.prio = env_int("MERLIN_HIP_SCORER_PRIO", 1);
+    a.tau = nullptr; a.cnt = nullptr; a.cs = nullptr; a.ci = nullptr; a.cap = 0; a.idx0 = 0;
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
 #define MH_MODE_E(EE)                                                                                      \
     do {                                                                                                   \
         if (mode == SM_FWD) return launch_mode<SM_FWD, EE, false>(a, ids_dtype, grid, p.lds, s);           \
         if (mode == SM_FWD_GRAD) return launch_mode<SM_FWD_GRAD, EE, false>(a, ids_dtype, grid, p.lds, s); \
+        if (mode == SM_FILTER) return launch_mode<SM_FILTER, EE, false>(a, ids_dtype, grid, p.lds, s);     \
         if (lse_stream) return launch_mode<SM_GRAD, EE, true>(a, ids_dtype, grid, p.lds, s);               \
         return launch_mode<SM_GRAD, EE, false>(a, ids_dtype, grid, p.lds, s);                              \
     } while (0)
@@ -597,4 +629,21 @@ void mh_stream_pad_rows(const float* src, int64_t N, int E, int Ep, float* dst, 
 }
 void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s) {
     hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)mh_ceil_div(N * E, 256)), dim3(256), 0, s, src, N, E, Ep, dst);
+}
+
+// top-k threshold filter on the same core (mh_topk.hip): X = queries (stationary), Y = candidates n_beg .. n_end
+int32_t mh_stream_filter(const float* q, int64_t Bq, const float* cand, int64_t n_cand, int E, const float* tau, int* cnt,
+                         float* cs, int32_t* ci, int cap, int64_t idx0, hipStream_t s) {
+    const MhStreamPlan p = mh_stream_plan(SM_FILTER, Bq, n_cand, E, 0);
+    StreamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.X = q; a.Y = cand; a.Nx = Bq; a.Ny = n_cand; a.invT = 1.f; a.bn = p.bn; a.tiles_per_split = p.tps;
+    a.prio = env_int("MERLIN_HIP_SCORER_PRIO", 1);
+    a.tau = tau; a.cnt = cnt; a.cs = cs; a.ci = ci; a.cap = cap; a.idx0 = idx0;
+    dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
+    if (E == 128) return launch_mode<SM_FILTER, 128, false>(a, MH_I32, grid, p.lds, s);
+    if (E == 64) return launch_mode<SM_FILTER, 64, false>(a, MH_I32, grid, p.lds, s);
+    if (E == 32) return launch_mode<SM_FILTER, 32, false>(a, MH_I32, grid, p.lds, s);
+    mh_set_error("top-k stream filter: E must be 32, 64 or 128");
+    return MH_ERR_UNSUPPORTED;
 }

@@ -18,6 +18,10 @@
 
 using namespace mhgemm;
 
+// top-k threshold filter on the row-stationary streaming core (mh_scorer_stream.hip)
+int32_t mh_stream_filter(const float* q, int64_t Bq, const float* cand, int64_t n_cand, int E, const float* tau, int* cnt,
+                         float* cs, int32_t* ci, int cap, int64_t idx0, hipStream_t s);
+
 namespace {
 
 constexpr int TOPK_MAX = 1024;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
 // from 8 B per score to ~8 B per SURVIVOR (k/n_seen of the scores).
 constexpr int FBM = 128, FBN = 128, FWM = 4, FWN = 2;
 
-__global__ __launch_bounds__(FWM * FWN * 64, FWM * FWN / 2) void topk_filter_gemm_kernel(
+__global__ __launch_bounds__(FWM * FWN * 64, 2) void topk_filter_gemm_kernel(
     const float* __restrict__ q, const float* __restrict__ cand, int64_t Bq, int64_t n_beg, int64_t n_end, int E,
     const float* __restrict__ tau, int* __restrict__ cnt, float* __restrict__ cs, int32_t* __restrict__ ci, int cap,
     int tiles_per_split, int vec_q, int vec_c) {
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void topk_merge_compact_kernel(const float* __
     }
     int n = cnt[row];
     if (n > cap) {
-        if (lane == 0) atomicExch(overflow, 1);
+        if (lane == 0) overflow[row] = 1;  // this row's list lost survivors: topk_redo_rows_kernel recomputes it
         n = cap;
     }
     float tl = __shfl(Ls[k - 1], 0);
@@ -282,6 +286,81 @@ __global__ __launch_bounds__(256) void topk_merge_compact_kernel(const float* __
     }
 }
 
+// Exact recomputation of the rows whose compact list overflowed (adversarially ordered candidates, e.g. scores
+// ascending with the index: every candidate passes the threshold): one wavefront per dirty row scores ALL candidates
+// itself -- each lane one candidate, one k-ascending fmaf chain (bitwise the MFMA result) -- and runs the streaming
+// select of topk_select_kernel.  Launched unconditionally (clean rows exit at once), so the call needs no host
+// read-back and can be captured into a hipGraph.
+__global__ __launch_bounds__(256) void topk_redo_rows_kernel(const float* __restrict__ q, const float* __restrict__ cand,
+                                                            int64_t Bq, int64_t N, int E, int k,
+                                                            const int* __restrict__ dirty, float* __restrict__ best_s,
+                                                            int32_t* __restrict__ best_i,
+                                                            const int32_t* __restrict__ cand_ids,
+                                                            int32_t* __restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= Bq || !dirty[row]) return;
+    float* Ls = smem + wave * 4 * k;
+    float* Lsn = Ls + k;
+    int* Li = reinterpret_cast<int*>(Lsn + k);
+    int* Lin = Li + k;
+    for (int e = lane; e < k; e += 64) {
+        Ls[e] = NAN;  // unfilled sentinel: compares false
+        Li[e] = 0x7fffffff;
+    }
+    int cnt = 0;
+    float tau = -INFINITY;
+    const float* qr = q + row * E;
+    for (int64_t j0 = 0; j0 < N; j0 += 64) {
+        const int64_t j = j0 + lane;
+        float v = -INFINITY;
+        if (j < N) {
+            const float* cr = cand + j * E;
+            float acc = 0.f;
+            for (int e = 0; e < E; ++e) acc = fmaf(qr[e], cr[e], acc);
+            v = acc;
+        }
+        const bool pass = (v > tau) || (cnt < k && j < N);
+        unsigned long long mask = __ballot(pass);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float sc = __shfl(v, l);
+            if (!((sc > tau) || cnt < k)) continue;  // tau may have risen inside this batch
+            const int idx = (int)(j0 + l);
+            int pos = 0;
+            for (int e0 = 0; e0 < k; e0 += 64) {
+                const int e = e0 + lane;
+                const bool ahead = (e < k) && (Ls[e] >= sc);
+                pos += __popcll(__ballot(ahead));
+            }
+            if (pos >= k) continue;  // only possible for NaN scores
+            for (int e = lane; e < k; e += 64) {
+                float s_new;
+                int i_new;
+                if (e < pos) { s_new = Ls[e]; i_new = Li[e]; }
+                else if (e == pos) { s_new = sc; i_new = idx; }
+                else { s_new = Ls[e - 1]; i_new = Li[e - 1]; }
+                Lsn[e] = s_new;
+                Lin[e] = i_new;
+            }
+            float* ts = Ls; Ls = Lsn; Lsn = ts;
+            int* ti = Li; Li = Lin; Lin = ti;
+            if (cnt < k) ++cnt;
+            if (cnt == k) tau = __shfl(Ls[k - 1], 0);
+        }
+    }
+    for (int e = lane; e < k; e += 64) {
+        best_s[row * k + e] = Ls[e];
+        best_i[row * k + e] = Li[e];
+        if (out_ids) {
+            const int i = Li[e];
+            out_ids[row * k + e] = cand_ids ? cand_ids[i] : i;
+        }
+    }
+}
+
 int64_t chunk_cols(int64_t Bq, int64_t N) {
     int64_t nc = (32ll << 20) / (Bq > 0 ? Bq : 1);  // 128 MiB of fp32 scores
     if (nc > 65536) nc = 65536;
@@ -310,7 +389,7 @@ FusedPlan make_fused_plan(int64_t Bq, int64_t N, int k) {
     int64_t o = p.dense_floats * 4;
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
     o = al(o); p.off_tau = o; o += Bq * 4;
-    o = al(o); p.off_cnt = o; o += (Bq + 1) * 4;  // +1: overflow flag
+    o = al(o); p.off_cnt = o; o += 2 * Bq * 4;  // counts, then the per-row overflow (dirty) flags
     o = al(o); p.off_cs = o;  o += p.fused ? Bq * (int64_t)p.cap * 4 : 0;
     o = al(o); p.off_ci = o;  o += p.fused ? Bq * (int64_t)p.cap * 4 : 0;
     p.total = al(o);
@@ -347,6 +426,7 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_redo_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     // ---- dense bootstrap over [0, n0): chunked score GEMM + streaming select ----
     for (int64_t c0 = 0; c0 < p.n0; c0 += nc) {
@@ -361,10 +441,10 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
     if (p.fused) {
         float* tau = reinterpret_cast<float*>(ws + p.off_tau);
         int* cnt = reinterpret_cast<int*>(ws + p.off_cnt);
-        int* overflow = cnt + Bq;
+        int* overflow = cnt + Bq;  // [Bq] per-row dirty flags
         float* cs = reinterpret_cast<float*>(ws + p.off_cs);
         int32_t* ci = reinterpret_cast<int32_t*>(ws + p.off_ci);
-        (void)hipMemsetAsync(cnt, 0, (size_t)(Bq + 1) * sizeof(int), s);
+        (void)hipMemsetAsync(cnt, 0, (size_t)(2 * Bq) * sizeof(int), s);
         // tau[row] = current k-th best (strided copy out of the running list)
         (void)hipMemcpy2DAsync(tau, sizeof(float), out_scores + (k - 1), (size_t)k * sizeof(float), sizeof(float), (size_t)Bq,
                                hipMemcpyDeviceToDevice, s);
@@ -376,33 +456,28 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         while (beg < N) {
             int64_t end = beg * 8;
             if (end > N || N - end < beg) end = N;
-            const int nct = (int)mh_ceil_div(end - beg, FBN);
-            int want = (int)mh_ceil_div(2 * mh_num_cus(), row_tiles);
-            if (want < 1) want = 1;
-            if (want > nct) want = nct;
-            const int tps = (int)mh_ceil_div(nct, want);
-            const int nsplit = (int)mh_ceil_div(nct, tps);
-            hipLaunchKernelGGL(topk_filter_gemm_kernel, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(FWM * FWN * 64), 0, s,
-                               q, cand, Bq, beg, end, E, tau, cnt, cs, ci, p.cap, tps, vec_q, vec_c);
+            if (E == 32 || E == 64 || E == 128) {
+                // row-stationary streaming core (mh_scorer_stream.hip): queries in registers, candidates by LDS DMA
+                const int32_t st = mh_stream_filter(q, Bq, cand + beg * E, end - beg, E, tau, cnt, cs, ci, p.cap, beg, s);
+                if (st != MH_OK) return st;
+            } else {
+                const int nct = (int)mh_ceil_div(end - beg, FBN);
+                int want = (int)mh_ceil_div(2 * mh_num_cus(), row_tiles);
+                if (want < 1) want = 1;
+                if (want > nct) want = nct;
+                const int tps = (int)mh_ceil_div(nct, want);
+                const int nsplit = (int)mh_ceil_div(nct, tps);
+                hipLaunchKernelGGL(topk_filter_gemm_kernel, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(FWM * FWN * 64), 0,
+                                   s, q, cand, Bq, beg, end, E, tau, cnt, cs, ci, p.cap, tps, vec_q, vec_c);
+            }
             hipLaunchKernelGGL(topk_merge_compact_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, cs, ci, cnt,
                                p.cap, Bq, k, out_scores, out_idx, tau, overflow, cand_ids, end >= N ? 1 : 0, out_ids);
             beg = end;
         }
-        // a compact list can only overflow on adversarial (e.g. ascending-sorted) data: detect and redo densely
-        int h_overflow = 0;
-        (void)hipMemcpyAsync(&h_overflow, overflow, sizeof(int), hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        if (h_overflow) {
-            for (int64_t c0 = 0; c0 < N; c0 += nc) {
-                const int64_t ncur = (c0 + nc < N) ? nc : N - c0;
-                const int32_t st = mh_internal_gemm_nt(q, E, cand + c0 * E, E, Bq, (int)ncur, E, sc, nc, s);
-                if (st != MH_OK) return st;
-                const int last = (c0 + nc >= N);
-                const int seen = (int)(c0 < k ? c0 : k);
-                hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, sc, nc, Bq,
-                                   (int)ncur, c0, k, seen, out_scores, out_idx, cand_ids, last, out_ids);
-            }
-        }
+        // a compact list can only overflow on adversarial (e.g. ascending-sorted) data: those rows are recomputed
+        // exactly on the device (clean rows exit at once) -- no host read-back, the call stays graph-capturable
+        hipLaunchKernelGGL(topk_redo_rows_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, q, cand, Bq, N, E, k,
+                           overflow, out_scores, out_idx, cand_ids, out_ids);
     }
     MH_CHECK_LAUNCH("mh_topk_dot");
     return MH_OK;

@@ -101,6 +101,63 @@ def test_c2_embedding_backward_full_batch_properties(device):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)  # only the summation order of duplicates differs
 
 
+def _adagrad_oracle(tabs0, acc0, ids, grad, lr, eps):
+    """numpy statement of the IndexedSlices Adagrad apply (duplicates summed in sample order, touched rows only)."""
+    import numpy as np
+
+    out_t, out_a = [], []
+    for f, (t0, a0, i) in enumerate(zip(tabs0, acc0, ids)):
+        t, a = t0.copy(), a0.copy()
+        uniq, inv = np.unique(i, return_inverse=True)
+        gsum = np.zeros((len(uniq), t.shape[1]), np.float32)
+        np.add.at(gsum, inv, grad[:, f])
+        ar = a[uniq] + gsum * gsum
+        a[uniq] = ar
+        t[uniq] = t[uniq] - np.float32(lr) * gsum / (np.sqrt(ar) + np.float32(eps))
+        out_t.append(t)
+        out_a.append(a)
+    return out_t, out_a
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_c2_embedding_backward_full_batch_adagrad_vs_oracle(device, deterministic, monkeypatch):
+    """configs[1] shapes (26 Criteo tables, D = 64, B = 65536), fused backward + Adagrad, compared with the numpy
+    statement row for row (weights AND accumulators).  MERLIN_HIP_DETERMINISTIC=1 removes the float atomics of the
+    hot-row path: two runs are then bit-identical."""
+    import numpy as np
+
+    from models_amd.synthetic import CRITEO_CARDINALITIES
+
+    monkeypatch.setenv("MERLIN_HIP_DETERMINISTIC", "1" if deterministic else "0")
+    D, B, lr, eps = 64, 65536, 0.05, 1e-7
+    F = len(CRITEO_CARDINALITIES)
+    rng = np.random.default_rng(33)
+    tabs0 = [rng.random((v, D), dtype=np.float32) for v in CRITEO_CARDINALITIES]
+    acc0 = [np.full((v, D), 0.1, np.float32) for v in CRITEO_CARDINALITIES]
+    ids = [rng.integers(0, v, size=B).astype(np.int32) for v in CRITEO_CARDINALITIES]
+    grad = rng.normal(size=(B, F, D)).astype(np.float32) * 0.01
+    want_t, want_a = _adagrad_oracle(tabs0, acc0, ids, grad, lr, eps)
+    offs = [f * D for f in range(F)]
+    gd = torch.from_numpy(grad).to(device)
+    idd = [torch.from_numpy(i).to(device) for i in ids]
+
+    def run():
+        tabs = [torch.from_numpy(t).to(device) for t in tabs0]
+        acc = [torch.from_numpy(a).to(device) for a in acc0]
+        ops.embedding_gather_backward(tabs, acc, idd, gd, offs, "adagrad", lr, eps)
+        return tabs, acc
+
+    tabs, acc = run()
+    for f in range(F):
+        # hot rows (a 4-row table takes 16K gradients) sum thousands of terms: fp32 summation-order noise only
+        np.testing.assert_allclose(tabs[f].cpu().numpy(), want_t[f], rtol=2e-5, atol=2e-6, err_msg=f"table {f}")
+        np.testing.assert_allclose(acc[f].cpu().numpy(), want_a[f], rtol=1e-4, atol=1e-7, err_msg=f"accumulator {f}")
+    if deterministic:
+        tabs2, acc2 = run()
+        for a, b in zip(tabs + acc, tabs2 + acc2):
+            assert torch.equal(a, b)
+
+
 def test_route_full_size_is_a_stable_partition(device):
     """Row-sharded exchange at full size (8 sharded features x 65536 requests, 8 ranks): pos_of is a permutation,
     the send order is grouped by owner, stable inside an owner, and keys / gradient source rows follow it."""
