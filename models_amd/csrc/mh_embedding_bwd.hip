@@ -59,6 +59,7 @@ struct SortArgs {
     int64_t first[MAX_SEG];            // compact key of the table's row 0
     int seg_f0[MAX_SEG + 1];           // first feature of segment s
     int tile0[MAX_SEG + 1];            // first tile of segment s
+    int npass[MAX_SEG];                // passes this segment needs (its key bits / the digit widths); later passes skip it
     int nseg;
     int64_t B;
 };
@@ -69,60 +70,95 @@ __device__ __forceinline__ int seg_of_tile(const SortArgs& a, int tile) {
     return s;
 }
 
-// key of entry e of segment s in pass `first_pass` (straight from the ids) or from the previous pass's buffer
+// (feature offset inside the segment, sample) of entry e: one 64-bit division per call -- callers hoist it out of
+// their per-entry loops with EntryPos
+struct EntryPos {
+    int64_t fo, b;  // feature offset, sample
+    __device__ __forceinline__ void init(int64_t e, int64_t B) {
+        fo = e / B;
+        b = e - fo * B;
+    }
+    __device__ __forceinline__ void advance(int64_t step, int64_t B) {  // e += step
+        b += step;
+        while (b >= B) {
+            b -= B;
+            ++fo;
+        }
+    }
+};
+
 template <typename IdT>
-__device__ __forceinline__ uint32_t load_local_key(const SortArgs& a, int s, int64_t e, bool first_pass,
-                                                   const uint32_t* __restrict__ keys_in, int64_t seg_base) {
-    if (!first_pass) return keys_in[seg_base + e];
-    const int64_t fo = e / a.B;
-    const int64_t b = e - fo * a.B;
+__device__ __forceinline__ uint32_t id_to_local_key(const SortArgs& a, int s, int64_t fo, int64_t b) {
     const int64_t id = (int64_t) static_cast<const IdT*>(a.ids[a.seg_f0[s] + fo])[b];
     return (id >= 0 && id < a.rows[s]) ? (uint32_t)id : (uint32_t)a.rows[s];
 }
 
 // cnt[tile0[s] * R + d * ntiles_s + t] = number of entries of tile t of segment s whose digit is d
 template <typename IdT>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const uint32_t* __restrict__ keys_in,
-                                                        int first_pass, int shift, int rbits, int* __restrict__ cnt) {
-    __shared__ int hist[1 << RBITS_MAX];
-    const int R = 1 << rbits;
-    for (int d = threadIdx.x; d < R; d += 256) hist[d] = 0;
-    __syncthreads();
+__global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const void* keys0, const void* keys1, int pass,
+                                                        int shift, int rbits, int* __restrict__ cnt) {
+    __shared__ int hist[4][1 << RBITS_MAX];  // one per wavefront: a quarter of the same-address traffic of a hot digit
     const int s = seg_of_tile(a, blockIdx.x);
+    if (pass >= a.npass[s]) return;  // this segment is already sorted
+    // input of pass p = output of pass p - 1 (see radix_scatter_kernel for the buffer parity)
+    const uint32_t* keys_in = static_cast<const uint32_t*>(((a.npass[s] - pass) & 1) ? keys0 : keys1);
+    const int R = 1 << rbits;
+    for (int d = threadIdx.x; d < 4 * R; d += 256) hist[d / R][d % R] = 0;
+    __syncthreads();
     const int t = blockIdx.x - a.tile0[s];
     const int nt = a.tile0[s + 1] - a.tile0[s];
     const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
     const int64_t n_s = (int64_t)(a.seg_f0[s + 1] - a.seg_f0[s]) * a.B;
-    const int64_t e0 = (int64_t)t * RTILE;
-#pragma unroll 4
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e0 = (int64_t)t * RTILE + wave * (RTILE / 4);
+    EntryPos pos;
+    if (pass == 0) pos.init(e0 + lane, a.B);
     for (int it = 0; it < RITEMS; ++it) {
-        const int64_t e = e0 + it * 256 + threadIdx.x;
-        if (e < n_s) {
-            const uint32_t k = load_local_key<IdT>(a, s, e, first_pass, keys_in, seg_base);
-            atomicAdd(&hist[(k >> shift) & (R - 1)], 1);
+        const int64_t e = e0 + it * 64 + lane;
+        const bool live = e < n_s;
+        uint32_t k = 0;
+        if (live) k = (pass == 0) ? id_to_local_key<IdT>(a, s, pos.fo, pos.b) : keys_in[seg_base + e];
+        if (pass == 0) pos.advance(64, a.B);
+        const int d = (int)((k >> shift) & (uint32_t)(R - 1));
+        // a round whose live lanes all hold one digit (tiny tables, sorted input) costs one LDS atomic, not 64
+        const uint64_t lives = __ballot(live);
+        const int d0 = __shfl(d, lives ? (__ffsll((unsigned long long)lives) - 1) : 0);
+        const bool same = __ballot(live && d != d0) == 0ull;
+        if (same) {
+            if (lives && lane == __ffsll((unsigned long long)lives) - 1) atomicAdd(&hist[wave][d0], __popcll(lives));
+        } else if (live) {
+            atomicAdd(&hist[wave][d], 1);
         }
     }
     __syncthreads();
-    int* out = cnt + (int64_t)a.tile0[s] * R;
-    for (int d = threadIdx.x; d < R; d += 256) out[(int64_t)d * nt + t] = hist[d];
+    int* out = cnt + (int64_t)a.tile0[s] * (1 << RBITS_MAX);
+    for (int d = threadIdx.x; d < R; d += 256) out[(int64_t)d * nt + t] = hist[0][d] + hist[1][d] + hist[2][d] + hist[3][d];
 }
 
-// one workgroup per segment: exclusive scan of its [R][ntiles] counters in place (digit-major = output order)
-__global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int rbits, int* __restrict__ cnt) {
+// one workgroup per segment: exclusive scan of its [R][ntiles] counters in place (digit-major = output order).
+// A thread owns 16 consecutive counters (four 16-byte loads), so 16 K counters are one block-wide scan step.
+__global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int pass, int rbits, int* __restrict__ cnt) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int s = blockIdx.x;
+    if (pass >= a.npass[s]) return;
     const int R = 1 << rbits;
     const int nt = a.tile0[s + 1] - a.tile0[s];
-    int* c = cnt + (int64_t)a.tile0[s] * R;
+    int* c = cnt + (int64_t)a.tile0[s] * (1 << RBITS_MAX);
     const int64_t len = (int64_t)R * nt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int64_t base = 0; base < len; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const int v = (i < len) ? c[i] : 0;
-        int x = v;  // inclusive scan inside the wavefront
+    for (int64_t base = 0; base < len; base += 1024 * 16) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * 16;
+        int v[16];
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v[j] = (i0 + j < len) ? c[i0 + j] : 0;
+            tot += v[j];
+        }
+        int x = tot;  // inclusive scan of the per-thread totals inside the wavefront
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(x, o);
@@ -130,27 +166,40 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int 
         }
         if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        int before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < len) c[i] = before + x - v;
+        int run = carry_s;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        run += x - tot;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (i0 + j < len) c[i0 + j] = run;
+            run += v[j];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = before + x;
+        if (threadIdx.x == 1023) carry_s = run;
         __syncthreads();
     }
 }
 
 // stable scatter of one tile: rank of an entry = entries with the same digit earlier in the tile (wave-private
 // counters, 16 rounds of 64 consecutive entries per wavefront; inside a round a ballot match gives the lanes that
-// share the digit) + the scanned global offset of (digit, tile).  LAST: emit compact keys instead of local ones.
-template <typename IdT, typename KeyT, bool LAST>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, const uint32_t* __restrict__ keys_in,
-                                                           const uint32_t* __restrict__ vals_in, int first_pass,
-                                                           int shift, int rbits, const int* __restrict__ cnt,
-                                                           void* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+// share the digit) + the scanned global offset of (digit, tile).  A segment's LAST pass emits compact keys.  The
+// passes of a segment alternate between the two buffers such that its last pass lands in buffer 1.
+template <typename IdT, typename KeyT>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, int pass, int shift, int rbits,
+                                                           const int* __restrict__ cnt, void* keys0, uint32_t* vals0,
+                                                           void* keys1, uint32_t* vals1) {
     __shared__ int wcnt[4][1 << RBITS_MAX];
-    const int R = 1 << rbits;
-    for (int d = threadIdx.x; d < 4 * (1 << RBITS_MAX); d += 256) (&wcnt[0][0])[d] = 0;
     const int s = seg_of_tile(a, blockIdx.x);
+    const int np = a.npass[s];
+    if (pass >= np) return;
+    const int R = 1 << rbits;
+    for (int d = threadIdx.x; d < 4 * R; d += 256) wcnt[d / R][d % R] = 0;
+    const bool last = (pass == np - 1);
+    const int dst = ((np - 1 - pass) & 1) ? 0 : 1;  // last pass -> buffer 1, the one before -> 0, ...
+    const uint32_t* keys_in = static_cast<const uint32_t*>(dst ? keys0 : keys1);
+    const uint32_t* vals_in = dst ? vals0 : vals1;
+    void* keys_out = dst ? keys1 : keys0;
+    uint32_t* vals_out = dst ? vals1 : vals0;
     const int t = blockIdx.x - a.tile0[s];
     const int nt = a.tile0[s + 1] - a.tile0[s];
     const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
@@ -160,6 +209,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, co
     const int64_t e0 = (int64_t)t * RTILE + wave * (RTILE / 4);
     uint32_t key[RITEMS], val[RITEMS];
     int off[RITEMS];  // digit | rank-inside-(wave, digit) << 11
+    EntryPos pos;
+    if (pass == 0) pos.init(e0 + lane, a.B);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < RITEMS; ++it) {
@@ -167,14 +218,15 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, co
         const bool live = e < n_s;
         uint32_t k = 0, v = 0;
         if (live) {
-            k = load_local_key<IdT>(a, s, e, first_pass, keys_in, seg_base);
-            if (first_pass) {
-                const int64_t fo = e / a.B;
-                v = ((uint32_t)(a.seg_f0[s] + fo) << 26) | (uint32_t)(e - fo * a.B);
+            if (pass == 0) {
+                k = id_to_local_key<IdT>(a, s, pos.fo, pos.b);
+                v = ((uint32_t)(a.seg_f0[s] + pos.fo) << 26) | (uint32_t)pos.b;
             } else {
+                k = keys_in[seg_base + e];
                 v = vals_in[seg_base + e];
             }
         }
+        if (pass == 0) pos.advance(64, a.B);
         const int d = (int)((k >> shift) & (uint32_t)(R - 1));
         // lanes of this round that hold the same digit (dead lanes match nobody)
         uint64_t peers = __ballot(live);
@@ -196,7 +248,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, co
     }
     __syncthreads();
     // wcnt[w][d] := global offset of (d, tile) + entries of waves < w with digit d
-    const int* c = cnt + (int64_t)a.tile0[s] * R;
+    const int* c = cnt + (int64_t)a.tile0[s] * (1 << RBITS_MAX);
     for (int d = threadIdx.x; d < R; d += 256) {
         int run = c[(int64_t)d * nt + t];
 #pragma unroll
@@ -211,14 +263,14 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, co
     for (int it = 0; it < RITEMS; ++it) {
         if (off[it] < 0) continue;
         const int d = off[it] & ((1 << RBITS_MAX) - 1);
-        const int64_t pos = seg_base + wcnt[wave][d] + (off[it] >> RBITS_MAX);
-        if (LAST) {
+        const int64_t p = seg_base + wcnt[wave][d] + (off[it] >> RBITS_MAX);
+        if (last) {
             const KeyT out = (key[it] < (uint32_t)a.rows[s]) ? (KeyT)(a.first[s] + (int64_t)key[it]) : KeyTraits<KeyT>::sentinel;
-            static_cast<KeyT*>(keys_out)[pos] = out;
+            static_cast<KeyT*>(keys_out)[p] = out;
         } else {
-            static_cast<uint32_t*>(keys_out)[pos] = key[it];
+            static_cast<uint32_t*>(keys_out)[p] = key[it];
         }
-        vals_out[pos] = val[it];
+        vals_out[p] = val[it];
     }
 }
 
@@ -481,9 +533,13 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
     if (c1 >= n) return;  // the last chunk cannot be crossed
     const KeyT key = keys[c1 - 1];
     if (key == KeyTraits<KeyT>::sentinel || keys[c1] != key) return;  // last run ends here
-    int64_t st = c1 - 1;                                              // first entry of that run inside the chunk
-    while (st > c0 && keys[st - 1] == key) --st;
-    if (st == c0 && c0 > 0 && keys[c0 - 1] == key) return;  // the run began in an earlier chunk: that one is its home
+    int64_t st = c0;  // first entry of that run inside the chunk
+    if (keys[c0] == key) {  // sorted: the whole chunk is this run
+        if (c0 > 0 && keys[c0 - 1] == key) return;  // ... and it began in an earlier chunk: that one is its home
+    } else {
+        st = c1 - 1;
+        while (keys[st - 1] == key) --st;  // stops inside the chunk: keys[c0] differs
+    }
     f32x4 g;
     if (!deterministic) {
         g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
@@ -524,7 +580,7 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->off_pieces = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 16, 256);  // <= one cut per run + per chunk
     L->off_home = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 4, 256);
     L->off_counter = o; o = align_up(o + 4, 256);
-    L->off_cnt = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << radix_bits_for(L->n)) * 4, 256);
+    L->off_cnt = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << RBITS_MAX) * 4, 256);
     L->total = o;
     return true;
 }
@@ -535,7 +591,7 @@ bool deterministic_mode() {
 }
 
 template <typename IdT, typename KeyT>
-int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int max_bits, const WsLayout& L, char* ws, int64_t B, int F,
+int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbits, const WsLayout& L, char* ws, int64_t B, int F,
                        int D, const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp,
                        hipStream_t s) {
     void* kbuf[2] = {ws + L.off_keys_a, ws + L.off_keys_b};
@@ -547,29 +603,16 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int max_bits, const
     int* cnt = reinterpret_cast<int*>(ws + L.off_cnt);
     const int det = deterministic_mode() ? 1 : 0;
 
-    // ---- 1. segmented stable LSD radix sort: passes of equal width over the bits of the largest table ----------------
-    const int rmax = radix_bits_for(L.n);
-    const int npass = (max_bits + rmax - 1) / rmax;
-    const int rbits = (max_bits + npass - 1) / npass;
+    // ---- 1. segmented stable LSD radix sort: digit width rbits per pass; a segment runs only the passes its own
+    //         key bits need (sa.npass) and alternates buffers so that its last pass lands in buffer 1 ---------------------
     const int ntiles = sa.tile0[sa.nseg];
-    int src = 0;                            // buffer holding the previous pass's output
-    int dst = (npass % 2 == 1) ? 1 : 0;     // the LAST pass must land in buffer 1 (keys_b / vals_b)
     for (int p = 0; p < npass; ++p) {
         const int shift = p * rbits;
-        const bool first = (p == 0), last = (p == npass - 1);
-        const uint32_t* kin = first ? nullptr : static_cast<const uint32_t*>(kbuf[src]);
-        const uint32_t* vin = first ? nullptr : vbuf[src];
-        hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, kin, first ? 1 : 0, shift,
-                           rbits, cnt);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, rbits, cnt);
-        if (last)
-            hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT, true>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, kin, vin,
-                               first ? 1 : 0, shift, rbits, cnt, kbuf[dst], vbuf[dst]);
-        else
-            hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT, false>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, kin, vin,
-                               first ? 1 : 0, shift, rbits, cnt, kbuf[dst], vbuf[dst]);
-        src = dst;
-        dst ^= 1;
+        hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
+                           (const void*)kbuf[1], p, shift, rbits, cnt);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt);
+        hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, p, shift, rbits, cnt,
+                           kbuf[0], vbuf[0], kbuf[1], vbuf[1]);
     }
     const KeyT* keys = static_cast<const KeyT*>(kbuf[1]);
     const uint32_t* vals = vbuf[1];
@@ -753,13 +796,21 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     const OptHyper hp = {lr, eps, beta1, beta2, lr_device};
     int max_bits = 1;  // bits of the largest local key: ids 0 .. rows-1 and the sentinel `rows`
     while (max_bits < 32 && (1ull << max_bits) < (uint64_t)max_rows + 1) ++max_bits;
+    const int rmax = radix_bits_for(B * F);
+    const int npass = (max_bits + rmax - 1) / rmax;
+    const int rbits = (npass == 1) ? max_bits : rmax;  // full-width digits first: a <= 2^rmax-row table is done in ONE pass
+    for (int sg = 0; sg < nseg; ++sg) {
+        int bits = 1;
+        while (bits < 32 && (1ull << bits) < (uint64_t)sa.rows[sg] + 1) ++bits;
+        sa.npass[sg] = (bits + rbits - 1) / rbits;
+    }
     const bool wide = (uint64_t)total_rows >= 0xffffffffull;
     if (ids_dtype == MH_I32) {
-        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
-        return run_pipeline_t<int32_t, uint64_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+        return run_pipeline_t<int32_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
     }
-    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
-    return run_pipeline_t<int64_t, uint64_t>(a, sa, max_bits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+    return run_pipeline_t<int64_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
 }
 
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D) {

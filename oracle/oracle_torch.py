@@ -16,9 +16,39 @@ import numpy as np
 import torch
 
 
-def use_all_threads() -> int:
-    n = os.cpu_count() or 1
-    torch.set_num_threads(n)
+def usable_cpus() -> int:
+    """CPUs this process may actually run on: the affinity mask, clipped by the cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001 -- no cgroup v2 file: keep the affinity count
+        pass
+    return n
+
+
+def use_all_threads(probe=None) -> int:
+    """Use every usable host thread -- unless ``probe`` (a callable running a short sample of the workload) shows that
+    fewer threads are FASTER on this box (SMT siblings / container quotas can make 256 OpenMP threads crawl on 65 536
+    tiny batched matmuls): the candidates are all, half and a quarter of the usable CPUs, the fastest one is kept and
+    reported as ``cores``."""
+    import time
+
+    n = usable_cpus()
+    if probe is None:
+        torch.set_num_threads(n)
+        return torch.get_num_threads()
+    best, best_t = n, None
+    for cand in sorted({n, max(1, n // 2), max(1, n // 4), min(n, 32)}, reverse=True):
+        torch.set_num_threads(cand)
+        probe()
+        t0 = time.perf_counter()
+        probe()
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = cand, dt
+    torch.set_num_threads(best)
     return torch.get_num_threads()
 
 
