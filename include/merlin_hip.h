@@ -242,6 +242,12 @@ int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb,
  * logits may be NULL (fused mode: nothing of size B*Nn is written); loss / lse may be NULL.
  * q, item: [B, E]; neg_item: [Nn, E] (pass item and Nn = B for in-batch negatives).
  * ids int32 or int64.  E % 4 == 0, E <= 1024.
+ * logQ sampling correction (pos_logq[B], neg_logq[Nn]; both NULL = off): the reference subtracts
+ * log(sampling probability + 1e-16) of each candidate from its score -- ContrastiveOutput.outputs with
+ * logq_sampling_correction=True (outputs/contrastive.py:309-319: BEFORE the false-negative rescoring, so rescored
+ * entries stay at false_neg_score; logq_after_mask = 0) or the PopularityLogitsCorrection `post` block
+ * (transforms/bias.py:238-254: on every column AFTER the rescoring, scaled by reg_factor; logq_after_mask = 1).  The
+ * caller passes the (scaled) log-probabilities; pos[b] -= pos_logq[b], neg[b, j] -= neg_logq[j].
  * workspace: mh_inbatch_softmax_workspace_bytes(B, Nn, E, pass) with pass 0 = _fwd, 1 = _bwd, 2 = _fwd_dq.
  * E <= 128 runs on the row-stationary streaming kernels (a workgroup keeps 256 rows of one matrix in registers and
  * streams the other through LDS by direct-to-LDS DMA); other E are zero-padded to 32 / 64 / 128 inside the
@@ -250,7 +256,8 @@ int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t E, int
 int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* neg_item,
                                const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                int64_t B, int64_t Nn, int32_t E, float temperature,
-                               float false_neg_score, float* logits, int64_t ld_logits,
+                               float false_neg_score, const float* pos_logq,
+                               const float* neg_logq, int32_t logq_after_mask, float* logits, int64_t ld_logits,
                                float* loss, float* lse, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream);
 
@@ -265,7 +272,8 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
 int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float* neg_item,
                                   const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                   int64_t B, int64_t Nn, int32_t E, float temperature,
-                                  float false_neg_score, float grad_scale, float* loss, float* lse,
+                                  float false_neg_score, const float* pos_logq,
+                               const float* neg_logq, int32_t logq_after_mask, float grad_scale, float* loss, float* lse,
                                   float* dq, float* ditem, void* workspace, int64_t workspace_bytes,
                                   mh_stream_t stream);
 
@@ -279,7 +287,8 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
 int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* neg_item,
                                const void* pos_ids, const void* neg_ids, int32_t ids_dtype,
                                int64_t B, int64_t Nn, int32_t E, float temperature,
-                               float false_neg_score, const float* lse, float grad_scale,
+                               float false_neg_score, const float* pos_logq,
+                               const float* neg_logq, int32_t logq_after_mask, const float* lse, float grad_scale,
                                float* dq, float* ditem, float* dneg_item, void* workspace,
                                int64_t workspace_bytes, mh_stream_t stream);
 

@@ -21,5 +21,9 @@ from .models import (  # noqa: F401
     DCNModel, DLRMModel, Encoder, Model, RankingModel, RetrievalModel, TopKEncoder, TwoTowerModel, TwoTowerModelV2,
 )
 from .loader import Loader  # noqa: F401
+from .sampling import (  # noqa: F401
+    CachedCrossBatchSampler, Candidate, CandidateSampler, FIFOQueue, InBatchSamplerV2, PopularityBasedSamplerV2,
+    PopularityLogitsCorrection,
+)
 
 __version__ = "0.1.0"

@@ -55,9 +55,9 @@ SIGNATURES = {
     "mh_l2norm_rows": (_i32, [_p, _i64, _i32, _f32, _p, _p]),
     "mh_l2norm_rows_bwd": (_i32, [_p, _p, _i64, _i32, _f32, _p, _p]),
     "mh_inbatch_softmax_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
-    "mh_inbatch_softmax_fwd_dq": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _f32, _p, _p, _p, _p, _p, _i64, _p]),
-    "mh_inbatch_softmax_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _i64, _p, _p, _p, _i64, _p]),
-    "mh_inbatch_softmax_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _f32, _p, _p, _p, _p, _i64, _p]),
+    "mh_inbatch_softmax_fwd_dq": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _p, _i32, _f32, _p, _p, _p, _p, _p, _i64, _p]),
+    "mh_inbatch_softmax_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _p, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_inbatch_softmax_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _p, _i32, _p, _f32, _p, _p, _p, _p, _i64, _p]),
     "mh_topk_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "mh_topk_dot": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "mh_topk_metrics": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p]),

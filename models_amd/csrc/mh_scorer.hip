@@ -42,7 +42,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void scorer_kernel(const float* __
                                                     int64_t ld_logits, float* __restrict__ part_m,
                                                     float* __restrict__ part_s, int tiles_per_split,
                                                     const float* __restrict__ lse, float gscale,
-                                                    float* __restrict__ ds, int vec_q, int vec_n) {
+                                                    float* __restrict__ ds, int vec_q, int vec_n,
+                                                    const float* __restrict__ neg_corr, int corr_after_mask) {
     constexpr int TM = SBM / WM / 32, TN = SBN / WN / 32, NTH = WM * WN * 64;
     __shared__ __attribute__((aligned(16))) float smem[2 * SBM * LDK + 2 * SBN * LDK + 2 * SBM + 2 * SBM + SBM];
     float* As0 = smem;
@@ -113,13 +114,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void scorer_kernel(const float* __
             const int64_t c0 = (int64_t)ct * SBN + wn * WCOLS;
             IdT nid[TN];
             bool cvalid[TN];
+            float ncorr[TN];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const int64_t col = c0 + tn * 32 + acc_col(lane);
                 cvalid[tn] = col < Nn;
                 nid[tn] = (HAS_IDS && cvalid[tn]) ? neg_ids[col] : (IdT)0;
+                ncorr[tn] = (neg_corr && cvalid[tn]) ? neg_corr[col] : 0.f;
             }
-            const float fns_z = fns * invT;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void scorer_kernel(const float* __
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) {
                         masked[tn] = HAS_IDS && (my_pid == nid[tn]);
-                        z[tn] = masked[tn] ? fns_z : acc[tm][tn][r] * invT;
+                        const float sc = corr_after_mask ? acc[tm][tn][r] : acc[tm][tn][r] - ncorr[tn];
+                        z[tn] = ((masked[tn] ? fns : sc) - (corr_after_mask ? ncorr[tn] : 0.f)) * invT;
                     }
                     if (MODE == 0) {
                         if (logits) {
@@ -234,7 +237,8 @@ __global__ __launch_bounds__(256) void scorer_finalize_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                    int64_t M, int N, float* __restrict__ out) {
+                                                    int64_t M, int N, float* __restrict__ out,
+                                                    const float* __restrict__ corr = nullptr) {
     const int sub = threadIdx.x & 15;
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     float s = 0.f;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
         for (int k = sub; k < N; k += 16) s = fmaf(a[row * N + k], b[row * N + k], s);
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (row < M && sub == 0) out[row] = s;
+    if (row < M && sub == 0) out[row] = corr ? s - corr[row] : s;  // corr: logQ of the positives
 }
 
 // positive-column gradient: ds0 = (exp(z0 - lse) - 1) * gscale ; dq += ds0 * item ; ditem = ds0 * q
@@ -280,22 +284,22 @@ template <int MODE>
 void launch_scorer(const Plan& p, const float* q, const float* neg, const void* pos_ids, const void* neg_ids,
                    int ids_dtype, int64_t B, int64_t Nn, int E, float invT, float fns, float* logits,
                    int64_t ld_logits, float* part_m, float* part_s, const float* lse, float gscale, float* ds,
-                   hipStream_t s) {
+                   const float* neg_corr, int corr_after_mask, hipStream_t s) {
     const int vec_q = ((reinterpret_cast<uintptr_t>(q) & 15) == 0) && (E % 4 == 0);
     const int vec_n = ((reinterpret_cast<uintptr_t>(neg) & 15) == 0) && (E % 4 == 0);
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
     if (!pos_ids) {
         hipLaunchKernelGGL((scorer_kernel<MODE, false, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
-                           gscale, ds, vec_q, vec_n);
+                           gscale, ds, vec_q, vec_n, neg_corr, corr_after_mask);
     } else if (ids_dtype == MH_I32) {
         hipLaunchKernelGGL((scorer_kernel<MODE, true, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)pos_ids,
                            (const int32_t*)neg_ids, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
-                           gscale, ds, vec_q, vec_n);
+                           gscale, ds, vec_q, vec_n, neg_corr, corr_after_mask);
     } else {
         hipLaunchKernelGGL((scorer_kernel<MODE, true, int64_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int64_t*)pos_ids,
                            (const int64_t*)neg_ids, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
-                           gscale, ds, vec_q, vec_n);
+                           gscale, ds, vec_q, vec_n, neg_corr, corr_after_mask);
     }
 }
 
@@ -311,7 +315,8 @@ MhStreamPlan mh_stream_plan(int mode, int64_t Nx, int64_t Ny, int E, int ids_byt
 int32_t mh_stream_launch(int mode, int lse_stream, const MhStreamPlan& p, const float* X, int64_t Nx, const float* Y,
                          int64_t Ny, int E, const void* x_ids, const void* y_ids, int ids_dtype, const float* lse,
                          const float* pos, float invT, float fns, float gscale, float* logits, int64_t ld_logits,
-                         float* part_m, float* part_s, float* opart, hipStream_t s);
+                         float* part_m, float* part_s, float* opart, const float* x_corr, const float* y_corr,
+                         int corr_after_mask, hipStream_t s);
 void mh_stream_fwd_finalize(const float* pos, int64_t B, int nsplit, const float* part_m, const float* part_s, float invT,
                             float* logits, int64_t ld_logits, float* loss, float* lse, hipStream_t s);
 void mh_stream_fwd_grad_combine(const float* q, const float* item, const float* pos, int64_t B, int E, int nsplit,
@@ -389,7 +394,8 @@ int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t E, int
 
 int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* neg_item, const void* pos_ids,
                                const void* neg_ids, int32_t ids_dtype, int64_t B, int64_t Nn, int32_t E,
-                               float temperature, float false_neg_score, float* logits, int64_t ld_logits,
+                               float temperature, float false_neg_score, const float* pos_logq,
+                               const float* neg_logq, int32_t logq_after_mask, float* logits, int64_t ld_logits,
                                float* loss, float* lse, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream) {
     MH_REQUIRE(q && item && neg_item, "mh_inbatch_softmax_fwd: null argument");
@@ -412,9 +418,9 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
         float* pos = ws;
         float* part_m = pos + B;
         float* part_s = part_m + (int64_t)p.nsplit * B;
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
         launch_scorer<0>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, logits, ld_logits,
-                         part_m, part_s, nullptr, 0.f, nullptr, s);
+                         part_m, part_s, nullptr, 0.f, nullptr, neg_logq, logq_after_mask, s);
         hipLaunchKernelGGL(scorer_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, p.nsplit,
                            part_m, part_s, invT, logits, ld_logits, loss, lse);
         MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
@@ -423,7 +429,7 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
     const StreamWs w = stream_ws(0, B, Nn, E, 8);
     const MhStreamPlan& plan = w.row;
     float* pos = ws + w.pos;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
     const float* qx = q;
     const float* nx = neg_item;
     if (w.pad) {
@@ -433,7 +439,8 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
         nx = ws + w.negp;
     }
     int32_t st = mh_stream_launch(SM_FWD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, nullptr, invT,
-                                  false_neg_score, 0.f, logits, ld_logits, ws + w.part_m, ws + w.part_s, nullptr, s);
+                                  false_neg_score, 0.f, logits, ld_logits, ws + w.part_m, ws + w.part_s, nullptr, nullptr, neg_logq,
+                                  logq_after_mask, s);
     if (st != MH_OK) return st;
     mh_stream_fwd_finalize(pos, B, plan.nsplit, ws + w.part_m, ws + w.part_s, invT, logits, ld_logits, loss, lse, s);
     MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
@@ -442,7 +449,8 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
 
 int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float* neg_item, const void* pos_ids,
                                   const void* neg_ids, int32_t ids_dtype, int64_t B, int64_t Nn, int32_t E,
-                                  float temperature, float false_neg_score, float grad_scale, float* loss, float* lse,
+                                  float temperature, float false_neg_score, const float* pos_logq,
+                               const float* neg_logq, int32_t logq_after_mask, float grad_scale, float* loss, float* lse,
                                   float* dq, float* ditem, void* workspace, int64_t workspace_bytes,
                                   mh_stream_t stream) {
     MH_REQUIRE(q && item && neg_item && lse && dq, "mh_inbatch_softmax_fwd_dq: null argument");
@@ -466,7 +474,7 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
     const StreamWs w = stream_ws(2, B, Nn, E, 8);
     const MhStreamPlan& plan = w.row;
     float* pos = ws + w.pos;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
     const float *qx = q, *ix = item, *nx = neg_item;
     if (w.pad) {
         mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);
@@ -477,7 +485,8 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
         nx = ws + w.negp;
     }
     int32_t st = mh_stream_launch(SM_FWD_GRAD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT,
-                                  false_neg_score, 1.f, nullptr, 0, ws + w.part_m, ws + w.part_s, ws + w.opart_row, s);
+                                  false_neg_score, 1.f, nullptr, 0, ws + w.part_m, ws + w.part_s, ws + w.opart_row, nullptr, neg_logq,
+                                  logq_after_mask, s);
     if (st != MH_OK) return st;
     float* dq_o = w.pad ? ws + w.outp_row : dq;
     float* di_o = ditem ? (w.pad ? ws + w.outp_item : ditem) : nullptr;
@@ -493,7 +502,8 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
 
 int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* neg_item, const void* pos_ids,
                                const void* neg_ids, int32_t ids_dtype, int64_t B, int64_t Nn, int32_t E,
-                               float temperature, float false_neg_score, const float* lse, float grad_scale,
+                               float temperature, float false_neg_score, const float* pos_logq,
+                               const float* neg_logq, int32_t logq_after_mask, const float* lse, float grad_scale,
                                float* dq, float* ditem, float* dneg_item, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream) {
     MH_REQUIRE(q && item && neg_item && lse && dneg_item, "mh_inbatch_softmax_bwd: null argument");
@@ -514,9 +524,9 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
         float* pos = ws;
         float* ds = pos + B;
         Plan p = make_plan(B, Nn);
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
         launch_scorer<1>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, nullptr, 0, nullptr,
-                         nullptr, lse, gscale, ds, s);
+                         nullptr, lse, gscale, ds, neg_logq, logq_after_mask, s);
         int32_t st = mh_internal_linear(ds, Nn, neg_item, nullptr, B, (int)Nn, E, MH_ACT_NONE, dq, E, nullptr, nullptr, s);
         if (st != MH_OK) return st;
         st = mh_internal_gemm_tn(ds, Nn, q, E, B, (int)Nn, E, dneg_item, s);
@@ -531,7 +541,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
     //   column pass:                                                              X = neg, Y = q   -> dneg_item
     const StreamWs w = stream_ws(1, B, Nn, E, 8);
     float* pos = ws + w.pos;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
     const float *qx = q, *ix = item, *nx = neg_item;
     if (w.pad) {
         mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);
@@ -545,7 +555,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
     if (dq) {
         const MhStreamPlan& pr = w.row;
         st = mh_stream_launch(SM_GRAD, 0, pr, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT,
-                              false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_row, s);
+                              false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_row, nullptr, neg_logq, logq_after_mask, s);
         if (st != MH_OK) return st;
         float* dq_o = w.pad ? ws + w.outp_row : dq;
         float* di_o = ditem ? (w.pad ? ws + w.outp_item : ditem) : nullptr;
@@ -559,7 +569,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
     }
     const MhStreamPlan& pc = w.col;
     st = mh_stream_launch(SM_GRAD, 1, pc, nx, Nn, qx, B, w.Ep, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT,
-                          false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_col, s);
+                          false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_col, neg_logq, nullptr, logq_after_mask, s);
     if (st != MH_OK) return st;
     float* dn_o = w.pad ? ws + w.outp_col : dneg_item;
     mh_stream_grad_combine(ws + w.opart_col, Nn, w.Ep, pc.nsplit, nullptr, nullptr, nullptr, nullptr, invT, gscale, dn_o,

@@ -58,6 +58,11 @@ struct StreamArgs {
     int bn;               // streamed rows per LDS tile (multiple of 32; 64 or 128)
     int tiles_per_split;  // tiles of bn rows per blockIdx.y
     int prio;             // 1: the second half of the workgroup's wavefronts runs at s_setprio 1
+    // logQ sampling correction (outputs/contrastive.py:309-319, transforms/bias.py:238-254): score -= x_corr[x] + y_corr[j]
+    // (either may be NULL); corr_after_mask = 1 applies it AFTER the false-negative rescoring (the `post` block form)
+    const float* x_corr;
+    const float* y_corr;
+    int corr_after_mask;
     // SM_FILTER (top-k threshold filter, mh_topk.hip): scores >= tau[x] are appended to the row's compact list
     const float* tau;  // [Nx] current k-th best score of every stationary (query) row
     int* cnt;          // [Nx] entries in the row's list
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
     const int tile_bytes = bn * RB;
     const int ids_off = 2 * tile_bytes;
     const int aux_off = ids_off + 2 * bn * (int)sizeof(IdT);
+    const int aux2_off = aux_off + 2 * bn * 4;  // y_corr of the streamed rows
     char* const smem_b = reinterpret_cast<char*>(smem);
     const uint32_t smem_a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;  // LDS byte address of smem
 
@@ -168,12 +174,13 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
         if (HAS_IDS)
             issue_words(a.y_ids, (int64_t)t_beg * bn * IDW, a.Ny * IDW - 1, bn * IDW, smem_b + ids_off, wave, 1);
         if (MODE == SM_GRAD && LSE_STREAM) issue_words(a.lse, (int64_t)t_beg * bn, a.Ny - 1, bn, smem_b + aux_off, wave, 3);
+        if (MODE != SM_FILTER && a.y_corr) issue_words(a.y_corr, (int64_t)t_beg * bn, a.Ny - 1, bn, smem_b + aux2_off, wave, 5);
     }
     // two sets of 16 stationary rows per wavefront: lane (l15, slot) holds X[x0 + 16 q + l15][4 c + slot], c < NC
     float xf[2][NC];
     bool xvalid[2];
     IdT x_id[2];
-    float lse2_x[2], m_run[2], s_run[2], tau_x[2];
+    float lse2_x[2], m_run[2], s_run[2], tau_x[2], xc[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         int64_t xrow = x0 + 16 * q + l15;
@@ -190,12 +197,11 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
         m_run[q] = NEG_BIG;
         s_run[q] = 0.f;
         tau_x[q] = 0.f;
+        xc[q] = (MODE != SM_FILTER && a.x_corr) ? a.x_corr[xrow] : 0.f;
         if (MODE == SM_FILTER) tau_x[q] = xvalid[q] ? a.tau[xrow] : INFINITY;
         if (MODE == SM_FWD_GRAD) m_run[q] = a.pos[xrow] * a.invT * LOG2E;  // the reference max starts at the positive logit
     }
     const float scale2 = a.invT * LOG2E;
-    const float fns_z = a.fns * a.invT;
-    const float fns_z2 = fns_z * LOG2E;
     f32x4 o[2][TN];
     if (MODE == SM_GRAD || MODE == SM_FWD_GRAD) {
 #pragma unroll
@@ -221,6 +227,8 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
                             smem_b + ids_off + (odd ^ 1) * bn * (int)sizeof(IdT), wave, 1);
             if (MODE == SM_GRAD && LSE_STREAM)
                 issue_words(a.lse, (int64_t)(t + 1) * bn, a.Ny - 1, bn, smem_b + aux_off + (odd ^ 1) * bn * 4, wave, 3);
+            if (MODE != SM_FILTER && a.y_corr)
+                issue_words(a.y_corr, (int64_t)(t + 1) * bn, a.Ny - 1, bn, smem_b + aux2_off + (odd ^ 1) * bn * 4, wave, 5);
         }
         const int64_t j_tile = (int64_t)t * bn;
         const int nvalid = (j_tile + bn <= a.Ny) ? bn : (int)(a.Ny - j_tile);  // valid streamed rows of this tile
@@ -228,6 +236,8 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
         const uint32_t tile_a = smem_a + odd * tile_bytes;
         const IdT* ids = reinterpret_cast<const IdT*>(smem_b + ids_off + odd * bn * (int)sizeof(IdT));
         const float* aux = reinterpret_cast<const float*>(smem_b + aux_off + odd * bn * 4);
+        const float* aux2 = reinterpret_cast<const float*>(smem_b + aux2_off + odd * bn * 4);
+        const bool has_corr = (MODE != SM_FILTER) && (a.x_corr != nullptr || a.y_corr != nullptr);  // wave-uniform
 
         for (int ju = 0; ju < nunits; ++ju) {
             const uint32_t ub = tile_a + ju * 16 * RB;
@@ -290,10 +300,23 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) yid[r] = ids[jl0 + r];
             }
+            float yc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_corr && a.y_corr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yc[r] = aux2[jl0 + r];
+            }
             float p[2][4];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x4 acc = q ? acc1 : acc0;
+                f32x4 acc = q ? acc1 : acc0;
+                float post[4] = {0.f, 0.f, 0.f, 0.f};  // correction applied after the mask (`post` block form)
+                if (has_corr) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float c = xc[q] + yc[r];
+                        if (a.corr_after_mask) post[r] = c; else acc[r] -= c;
+                    }
+                }
                 float t2[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -303,14 +326,14 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
                     msk[r] = masked;
                     float v2;
                     if (MODE == SM_FWD) {
-                        const float z = masked ? fns_z : acc[r] * a.invT;
+                        const float z = ((masked ? a.fns : acc[r]) - post[r]) * a.invT;
                         if (a.logits != nullptr) {
                             if (xvalid[q] && jl < nvalid)
                                 a.logits[(x0 + 16 * q + l15) * a.ld_logits + 1 + j_tile + jl] = z;
                         }
                         v2 = z * LOG2E;
                     } else {
-                        v2 = masked ? fns_z2 : acc[r] * scale2;
+                        v2 = ((masked ? a.fns : acc[r]) - post[r]) * scale2;
                     }
                     if (jl >= nvalid) v2 = -INFINITY;  // only the last tile of Y can be partial
                     t2[r] = v2;
@@ -572,7 +595,7 @@ MhStreamPlan mh_stream_plan(int mode, int64_t Nx, int64_t Ny, int E, int ids_byt
     if (want > p.nt) want = p.nt;
     p.tps = (int)mh_ceil_div(p.nt, want);
     p.nsplit = (int)mh_ceil_div(p.nt, p.tps);
-    p.lds = (size_t)2 * p.bn * E * 4 + (size_t)2 * p.bn * (ids_bytes ? ids_bytes : 4) + (size_t)2 * p.bn * 4;
+    p.lds = (size_t)2 * p.bn * E * 4 + (size_t)2 * p.bn * (ids_bytes ? ids_bytes : 4) + (size_t)4 * p.bn * 4;
     return p;
 }
 
@@ -580,13 +603,15 @@ MhStreamPlan mh_stream_plan(int mode, int64_t Nx, int64_t Ny, int E, int ids_byt
 int32_t mh_stream_launch(int mode, int lse_stream, const MhStreamPlan& p, const float* X, int64_t Nx, const float* Y,
                          int64_t Ny, int E, const void* x_ids, const void* y_ids, int ids_dtype, const float* lse,
                          const float* pos, float invT, float fns, float gscale, float* logits, int64_t ld_logits,
-                         float* part_m, float* part_s, float* opart, hipStream_t s) {
+                         float* part_m, float* part_s, float* opart, const float* x_corr, const float* y_corr,
+                         int corr_after_mask, hipStream_t s) {
     StreamArgs a;
     a.X = X; a.Y = Y; a.Nx = Nx; a.Ny = Ny; a.x_ids = x_ids; a.y_ids = y_ids; a.lse = lse; a.pos = pos;
     a.invT = invT; a.fns = fns; a.gscale = gscale; a.logits = logits; a.ld_logits = ld_logits;
     a.part_m = part_m; a.part_s = part_s; a.opart = opart; a.bn = p.bn; a.tiles_per_split = p.tps;
     a.prio = env_int("MERLIN_HIP_SCORER_PRIO", 1);
     a.tau = nullptr; a.cnt = nullptr; a.cs = nullptr; a.ci = nullptr; a.cap = 0; a.idx0 = 0;
+    a.x_corr = x_corr; a.y_corr = y_corr; a.corr_after_mask = corr_after_mask;
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
 #define MH_MODE_E(EE)                                                                                      \
     do {                                                                                                   \

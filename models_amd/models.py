@@ -304,19 +304,27 @@ class RetrievalModel(Model):
         q, it = emb["query"], emb["item"]
         out = self.output
         ids = None
-        if out.downscore_false_negatives:
+        if out.downscore_false_negatives or out.post is not None or out.logq_sampling_correction:
             ids = x[out.col_schema.name].reshape(-1)
+        neg = out.negatives(it, ids, x, training=True)
+        B = q.shape[0]
+        if neg.n_inbatch not in (0, B):
+            raise ValueError("in-batch negatives must cover the whole batch")
+        pid, nid = (ids, neg.ids) if out.downscore_false_negatives else (None, None)
+        kw = dict(pos_logq=neg.pos_logq, neg_logq=neg.neg_logq, logq_after_mask=neg.logq_after_mask)
         # one pass over the score tiles gives loss, lse AND dq (flash-style); the column pass then gives dneg
-        fused = ops.inbatch_softmax_train(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score)
+        fused = ops.inbatch_softmax_train(q, it, neg.embedding, pid, nid, out.logits_temperature, out.false_negative_score, **kw)
         if fused is not None:
             res, dq, ditem = fused
-            _, _, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
-                                                      out.false_negative_score, need_dq=False)
+            _, _, dneg = ops.inbatch_softmax_backward(q, it, neg.embedding, res.lse, pid, nid, out.logits_temperature,
+                                                      out.false_negative_score, need_dq=False, **kw)
         else:  # E > 128: tiled kernels
-            res = ops.inbatch_softmax(q, it, it, ids, ids, out.logits_temperature, out.false_negative_score, materialize=False)
-            dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, out.logits_temperature,
-                                                           out.false_negative_score)
-        ditem = ops.eltwise("add", ditem, dneg)
+            res = ops.inbatch_softmax(q, it, neg.embedding, pid, nid, out.logits_temperature, out.false_negative_score,
+                                      materialize=False, **kw)
+            dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, neg.embedding, res.lse, pid, nid, out.logits_temperature,
+                                                           out.false_negative_score, **kw)
+        if neg.n_inbatch:  # rows 0..B of the negatives ARE this batch's items; cached / sampled rows are constants here
+            ditem = ops.eltwise("add", ditem, dneg if dneg.shape[0] == B else dneg[:B].contiguous())
         if self.body.l2_normalization:  # L2Norm sits between the towers and the scorer (retrieval/base.py:98-121)
             dq = ops.l2norm_backward(self.body._raw["query"], dq)
             ditem = ops.l2norm_backward(self.body._raw["item"], ditem)
@@ -426,17 +434,17 @@ class TopKEncoder(Block):
 
 def TwoTowerModel(schema: Schema, query_tower: Block, item_tower: Optional[Block] = None,
                   query_tower_tag=Tags.USER, item_tower_tag=Tags.ITEM, embedding_dim: Optional[int] = None,
-                  samplers: Sequence[str] = (), logits_temperature: float = 1.0, l2_normalization: bool = False,
-                  downscore_false_negatives: bool = True, device=None) -> RetrievalModel:
-    """retrieval.py:106-203 (V1 route; same scorer math, item branch key "item")."""
-    if samplers and list(samplers) != ["in-batch"]:
-        raise NotImplementedError("only the in-batch sampler is on the HIP hot path")
+                  samplers=(), logits_temperature: float = 1.0, l2_normalization: bool = False,
+                  downscore_false_negatives: bool = True, post_logits=None, device=None) -> RetrievalModel:
+    """retrieval.py:106-203 (V1 route; same scorer math, item branch key "item").  ``samplers``: "in-batch" (default)
+    and / or sampler objects of ``models_amd.sampling`` (e.g. ``CachedCrossBatchSampler``); ``post_logits``: a
+    ``PopularityLogitsCorrection`` (the reference's logQ correction for popularity-biased in-batch negatives)."""
     body = TwoTowerBlock(schema, query_tower, item_tower, query_tower_tag, item_tower_tag, embedding_dim,
                          l2_normalization, device)
     item_id = schema.select_by_tag(Tags.ITEM_ID)
-    out = ContrastiveOutput(item_id.first if len(item_id) else None, "in-batch",
+    out = ContrastiveOutput(item_id.first if len(item_id) else None, list(samplers) if samplers else "in-batch",
                             downscore_false_negatives=downscore_false_negatives and len(item_id) > 0,
-                            logits_temperature=logits_temperature)
+                            logits_temperature=logits_temperature, post=post_logits)
     return RetrievalModel(body, out, schema, name="two_tower_model")
 
 
@@ -482,11 +490,9 @@ def TwoTowerModelV2(query_tower: Encoder, candidate_tower: Encoder, candidate_id
     """retrieval.py:409-486: two ``Encoder``s -> ContrastiveOutput(DotProduct, in-batch negatives)."""
     if not isinstance(query_tower, Encoder) or not isinstance(candidate_tower, Encoder):
         raise ValueError("The query and candidate towers should be instances of the `Encoder` class")
-    if negative_samplers and list(negative_samplers) != ["in-batch"]:
-        raise NotImplementedError("only the in-batch sampler is on the HIP hot path")
     if outputs is None:
         item_id = candidate_tower.schema.select_by_tag(candidate_id_tag) if candidate_tower.schema is not None else []
-        outputs = ContrastiveOutput(item_id.first if len(item_id) else None, "in-batch",
+        outputs = ContrastiveOutput(item_id.first if len(item_id) else None, negative_samplers or "in-batch",
                                     downscore_false_negatives=downscore_false_negatives and len(item_id) > 0,
                                     logits_temperature=logits_temperature)
     body = TwoTowerBlock.from_towers(query_tower, candidate_tower, schema)

@@ -697,8 +697,22 @@ def _ids_pair(pos_ids, neg_ids):
     return pos_ids, neg_ids, _ids_dtype(pos_ids, "pos_ids")
 
 
+def _logq_pair(pos_logq, neg_logq, B, Nn):
+    """(pos_logq[B], neg_logq[Nn]) fp32 device vectors or (None, None); see include/merlin_hip.h."""
+    if pos_logq is None and neg_logq is None:
+        return None, None
+    if pos_logq is None or neg_logq is None:
+        raise ValueError("logQ correction needs the log-probabilities of BOTH the positive and the negative candidates")
+    pos_logq = _dev(pos_logq, "pos_logq", torch.float32).reshape(-1).contiguous()
+    neg_logq = _dev(neg_logq, "neg_logq", torch.float32).reshape(-1).contiguous()
+    if pos_logq.shape[0] != B or neg_logq.shape[0] != Nn:
+        raise ValueError(f"pos_logq / neg_logq must have {B} / {Nn} entries")
+    return pos_logq, neg_logq
+
+
 def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: float = 1.0,
-                    false_neg_score: float = -655.04, materialize: bool = True) -> ScorerResult:
+                    false_neg_score: float = -655.04, materialize: bool = True, pos_logq=None, neg_logq=None,
+                    logq_after_mask: bool = False) -> ScorerResult:
     """Sampled-softmax scorer: positives ``<q, item>`` in column 0, negatives ``q @ neg_item^T``
     with false negatives rescored, temperature scaling and the softmax cross-entropy fused."""
     lib = _lib.load()
@@ -709,6 +723,7 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
     B, E = q.shape
     Nn = neg_item.shape[0]
     pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
+    pos_logq, neg_logq = _logq_pair(pos_logq, neg_logq, B, Nn)
     logits = torch.empty((B, Nn + 1), dtype=torch.float32, device=q.device) if materialize else None
     loss = torch.empty((B,), dtype=torch.float32, device=q.device)
     lse = torch.empty((B,), dtype=torch.float32, device=q.device)
@@ -716,7 +731,8 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
     with _timed("inbatch_softmax_fwd", nbytes=4 * (2 * B + Nn) * E, flops=2 * B * Nn * E + 2 * B * E):
         check(
             lib.mh_inbatch_softmax_fwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
-                                       temperature, false_neg_score, _ptr(logits), Nn + 1, _ptr(loss), _ptr(lse),
+                                       temperature, false_neg_score, _ptr(pos_logq), _ptr(neg_logq), int(logq_after_mask),
+                                       _ptr(logits), Nn + 1, _ptr(loss), _ptr(lse),
                                        _ptr(ws), ws.numel(), _stream()),
             "mh_inbatch_softmax_fwd",
         )
@@ -724,7 +740,8 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
 
 
 def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: float = 1.0,
-                          false_neg_score: float = -655.04, grad_scale: Optional[float] = None):
+                          false_neg_score: float = -655.04, grad_scale: Optional[float] = None, pos_logq=None,
+                          neg_logq=None, logq_after_mask: bool = False):
     """Training-mode forward (``mh_inbatch_softmax_fwd_dq``): one pass over the score tiles yields the per-row
     loss / lse AND dq, ditem (positive role) of ``grad_scale * sum_b loss[b]`` (default 1/B).  Returns
     ``(ScorerResult(None, loss, lse), dq, ditem)``; follow with ``inbatch_softmax_backward(..., need_dq=False)``
@@ -739,6 +756,7 @@ def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, tempera
     if E > 128:
         return None
     pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
+    pos_logq, neg_logq = _logq_pair(pos_logq, neg_logq, B, Nn)
     loss = torch.empty((B,), dtype=torch.float32, device=q.device)
     lse = torch.empty((B,), dtype=torch.float32, device=q.device)
     dq = torch.empty_like(q)
@@ -747,7 +765,8 @@ def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, tempera
     with _timed("inbatch_softmax_fwd_dq", nbytes=4 * (4 * B + Nn) * E, flops=4 * B * Nn * E):
         check(
             lib.mh_inbatch_softmax_fwd_dq(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
-                                          temperature, false_neg_score, 1.0 / B if grad_scale is None else grad_scale,
+                                          temperature, false_neg_score, _ptr(pos_logq), _ptr(neg_logq), int(logq_after_mask),
+                                          1.0 / B if grad_scale is None else grad_scale,
                                           _ptr(loss), _ptr(lse), _ptr(dq), _ptr(ditem), _ptr(ws), ws.numel(), _stream()),
             "mh_inbatch_softmax_fwd_dq",
         )
@@ -755,7 +774,8 @@ def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, tempera
 
 
 def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None, temperature: float = 1.0,
-                             false_neg_score: float = -655.04, grad_scale: Optional[float] = None, need_dq: bool = True):
+                             false_neg_score: float = -655.04, grad_scale: Optional[float] = None, need_dq: bool = True,
+                             pos_logq=None, neg_logq=None, logq_after_mask: bool = False):
     """Gradients of ``grad_scale * sum_b loss[b]`` (default 1/B: the Keras mean): (dq, ditem, dneg).
     ``need_dq=False`` runs the column pass only and returns ``(None, None, dneg)``."""
     lib = _lib.load()
@@ -764,6 +784,7 @@ def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None,
     if not need_dq and E > 128:
         raise ValueError("need_dq=False requires E <= 128 (the streaming scorer)")
     pos_ids, neg_ids, idt = _ids_pair(pos_ids, neg_ids)
+    pos_logq, neg_logq = _logq_pair(pos_logq, neg_logq, B, Nn)
     dq = torch.empty_like(q) if need_dq else None
     ditem = torch.empty_like(item) if need_dq else None
     dneg = torch.empty_like(neg_item)
@@ -771,7 +792,8 @@ def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None,
     with _timed("inbatch_softmax_bwd", nbytes=4 * (3 * B + 2 * Nn) * E, flops=(8 if dq is not None else 4) * B * Nn * E):
         check(
             lib.mh_inbatch_softmax_bwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
-                                       temperature, false_neg_score, _ptr(lse), 1.0 / B if grad_scale is None else grad_scale,
+                                       temperature, false_neg_score, _ptr(pos_logq), _ptr(neg_logq), int(logq_after_mask),
+                                       _ptr(lse), 1.0 / B if grad_scale is None else grad_scale,
                                        _ptr(dq), _ptr(ditem), _ptr(dneg), _ptr(ws), ws.numel(), _stream()),
             "mh_inbatch_softmax_bwd",
         )

@@ -117,6 +117,32 @@ def main():
     out.update(emb_card=cards, emb_dim=np.array([emb(int(c), 2.0, True) for c in cards]),
                emb_dim_raw=np.array([emb(int(c), 2.0, False) for c in cards]))
 
+    # --- popularity sampler distribution + logQ-corrected logits (appended: earlier draws are unchanged) -------
+    # The reference's torch twin of the log-uniform sampler (torch/outputs/sampling/popularity.py) states the same
+    # distribution as tf/outputs/sampling/popularity.py:139-166, whose range is one longer: TF(max_id) == twin(max_id + 1).
+    lu = load("merlin/models/torch/outputs/sampling/popularity.py", "get_log_uniform_distr", "LogUniformSampler")
+    # (the twin's "sampled at least once" formula is 1 - (1 + p)^-n, TF's is 1 - (1 - p)^n: only the base distribution
+    # is pinned here, the unique-sampling form follows tf/outputs/sampling/popularity.py:152-158)
+    for tag, (max_id, min_id, n) in {"a": (999, 2, 10), "b": (57, 0, 20)}.items():
+        out[f"pop_{tag}_args"] = np.array([max_id, min_id, n])
+        out[f"pop_{tag}_dist"] = lu(None, max_id + 1, min_id)
+    # logQ BEFORE the false-negative rescoring (tf/outputs/contrastive.py:309-319): scores - log(p + 1e-16) are the dot
+    # products of vectors augmented by one coordinate, so the reference's own contrastive_outputs produces them
+    ppos = torch.rand(B, generator=g) * 0.2 + 1e-3
+    pneg = torch.rand(Nn, generator=g) * 0.2 + 1e-3
+    qa = torch.cat([q, torch.ones(B, 1)], 1)
+    posa = torch.cat([pos, -torch.log(ppos + 1e-16).unsqueeze(1)], 1)
+    nega = torch.cat([neg, -torch.log(pneg + 1e-16).unsqueeze(1)], 1)
+    me6 = types.SimpleNamespace(downscore_false_negatives=True, false_negative_score=float(np.finfo(np.float16).min) / 100.0)
+    out.update(lq_ppos=ppos, lq_pneg=pneg, lq_logits=contrastive(me6, qa, posa, nega, pos_id.unsqueeze(0), neg_id.unsqueeze(0)))
+    # PopularityLogitsCorrection as `post` (tf/transforms/bias.py:238-254): every column of the rescored logits,
+    # reg_factor * log(prob + 1e-16) subtracted -- the reference's own logits minus the stated correction
+    reg = 0.7
+    probs = torch.rand(20, generator=g) + 0.05
+    probs = probs / probs.sum()
+    corr = torch.cat([probs[pos_id].unsqueeze(1), probs[neg_id].unsqueeze(0).expand(B, Nn)], 1)
+    out.update(pc_probs=probs, pc_reg=np.array(reg), pc_logits=logits - reg * torch.log(corr + 1e-16))
+
     np.savez_compressed(OUT / "reference_vectors.npz",
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     print("wrote", OUT / "reference_vectors.npz", len(out), "arrays")

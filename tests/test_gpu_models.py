@@ -525,3 +525,72 @@ def test_graph_replayed_train_steps_equal_eager_steps(device):
         assert abs(float(la) - float(lb)) < 1e-6
     for pa, pb in zip(a.parameters(), b.parameters()):
         torch.testing.assert_close(pb.data, pa.data, atol=1e-6, rtol=1e-5)
+
+
+def _tt_schema():
+    return mm.Schema([S.categorical("user_id", 500, [S.Tags.USER, S.Tags.USER_ID]), S.categorical("user_age", 10, [S.Tags.USER]),
+                      S.categorical("item_id", 300, [S.Tags.ITEM, S.Tags.ITEM_ID]), S.categorical("item_cat", 20, [S.Tags.ITEM])])
+
+
+def _tt_batch(device, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"user_id": torch.randint(0, 500, (B, 1), generator=g).to(device), "user_age": torch.randint(0, 10, (B, 1), generator=g).to(device),
+            "item_id": torch.randint(0, 300, (B, 1), generator=g).to(device), "item_cat": torch.randint(0, 20, (B, 1), generator=g).to(device)}
+
+
+def test_two_tower_with_popularity_logits_correction_and_cross_batch_negatives(device):
+    """SURVEY 8f-4 through the mm surface: TwoTowerModel with (a) the PopularityLogitsCorrection post block -- logits
+    equal the oracle's, training reduces the loss; (b) in-batch + cached cross-batch negatives -- the negative set
+    grows by the cached rows of the previous batches and the step still trains."""
+    torch.manual_seed(0)
+    schema = _tt_schema()
+    freq = torch.arange(300, 0, -1).float()
+    post = mm.PopularityLogitsCorrection(freq, schema=schema, reg_factor=0.5)
+    model = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16, post_logits=post, device=device)
+    model.compile(optimizer="adagrad", learning_rate=0.05)
+    b = _tt_batch(device, 256, 1)
+    pred = model(b, training=True)
+    emb = model.body(b)
+    ids = b["item_id"].reshape(-1).cpu().numpy()
+    p = (freq / freq.sum()).numpy()
+    want, _ = O.contrastive_outputs(emb["query"].cpu().numpy(), emb["item"].cpu().numpy(), emb["item"].cpu().numpy(), ids, ids,
+                                    post_positive_prob=p[ids], post_negative_prob=p[ids], post_reg_factor=0.5)
+    np.testing.assert_allclose(pred.outputs.cpu().numpy(), want, atol=1e-4)
+    losses = [float(model.train_step(b)) for _ in range(8)]
+    assert losses[-1] < losses[0]
+    # (b)
+    sampler = mm.CachedCrossBatchSampler(capacity=300)
+    model2 = mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=device), embedding_dim=16,
+                              samplers=["in-batch", sampler], device=device)
+    model2.compile(optimizer="adagrad", learning_rate=0.05)
+    l0 = float(model2.train_step(_tt_batch(device, 128, 2)))
+    assert model2.output._neg.embedding.shape[0] == 128 if hasattr(model2.output, "_neg") else True
+    l1 = float(model2.train_step(_tt_batch(device, 128, 3)))  # 128 in-batch + 128 cached
+    pr = model2(_tt_batch(device, 128, 4), training=True)     # 128 in-batch + 256 cached (the pending batch landed)
+    assert pr.outputs.shape == (128, 1 + 128 + 256)
+    assert np.isfinite(l0) and np.isfinite(l1)
+    ls = [float(model2.train_step(_tt_batch(device, 128, 2))) for _ in range(6)]
+    assert ls[-1] < l0
+
+
+def test_contrastive_output_over_candidate_table_with_popularity_sampler(device):
+    """ContrastiveOutput(to_call=EmbeddingTable, PopularityBasedSamplerV2, logq_sampling_correction=True)
+    (tests/unit/tf/outputs/test_contrastive.py:104-133): sampled-softmax logits over the table's rows equal the oracle's
+    with the sampler's probabilities."""
+    torch.manual_seed(1)
+    col = S.categorical("item_category", 101, [S.Tags.ITEM])
+    table = mm.EmbeddingTable(16, col, device=device)
+    sampler = mm.PopularityBasedSamplerV2(max_id=100, max_num_samples=20, min_id=1, seed=5)
+    out = mm.ContrastiveOutput(table, negative_samplers=sampler, logq_sampling_correction=True, store_negative_ids=True)
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(50, 16, generator=g).to(device)
+    tgt = torch.randint(1, 101, (50, 1), generator=g).to(device)
+    pred = out({"query": q}, features={}, targets=tgt, training=True)
+    nid = pred.negative_candidate_ids.cpu().numpy()
+    assert pred.outputs.shape == (50, 21) and len(np.unique(nid)) == 20 and nid.min() >= 1
+    W = table.table.data.cpu().numpy()
+    dist = sampler.sampling_dist.cpu().numpy()
+    t = tgt.reshape(-1).cpu().numpy()
+    want, _ = O.contrastive_outputs(q.cpu().numpy(), W[t], W[nid], t, nid, positive_sampling_prob=dist[t],
+                                    negative_sampling_prob=dist[nid])
+    np.testing.assert_allclose(pred.outputs.cpu().numpy(), want, atol=1e-4)

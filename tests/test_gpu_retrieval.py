@@ -151,6 +151,74 @@ def test_scorer_fused_pass_rescale_branch(device):
     np.testing.assert_allclose(r.lse.cpu().numpy(), ref.lse.cpu().numpy(), atol=1e-4, rtol=1e-6)
 
 
+def test_scorer_logq_golden_vectors(device):
+    """logQ sampling correction through the HIP scorer against vectors produced by the reference's own code
+    (tests/golden/make_golden.py): before the false-negative rescoring (contrastive.py:309-319) and as the
+    PopularityLogitsCorrection post block (transforms/bias.py:238-254)."""
+    from pathlib import Path
+
+    G = np.load(Path(__file__).parent / "golden" / "reference_vectors.npz")
+    t = lambda a: _t(a, device)
+    q, pos, neg, pid, nid = t(G["sc_q"]), t(G["sc_pos"]), t(G["sc_neg"]), t(G["sc_pos_id"]), t(G["sc_neg_id"])
+    r = ops.inbatch_softmax(q, pos, neg, pid, nid, pos_logq=torch.log(t(G["lq_ppos"]) + 1e-16),
+                            neg_logq=torch.log(t(G["lq_pneg"]) + 1e-16))
+    np.testing.assert_allclose(r.logits.cpu().numpy(), G["lq_logits"], atol=ATOL)
+    probs, reg = t(G["pc_probs"]), float(G["pc_reg"])
+    r = ops.inbatch_softmax(q, pos, neg, pid, nid, pos_logq=reg * torch.log(probs[pid.long()] + 1e-16),
+                            neg_logq=reg * torch.log(probs[nid.long()] + 1e-16), logq_after_mask=True)
+    np.testing.assert_allclose(r.logits.cpu().numpy(), G["pc_logits"], atol=ATOL)
+
+
+@pytest.mark.parametrize("after_mask", [False, True])
+@pytest.mark.parametrize("B,Nn,E", [(300, 450, 64), (129, 129, 128), (70, 33, 24), (64, 200, 160)])
+def test_scorer_logq_forward_backward(device, B, Nn, E, after_mask):
+    """Forward (materialised and fused), the fused forward+dq pass and both backward passes with the logQ terms,
+    against the oracle and fp64 autograd of the corrected logits (E = 160 takes the tiled E > 128 kernels)."""
+    rng = np.random.default_rng(B + Nn + E)
+    T = 0.7
+    q, it, ng = (rng.normal(size=s).astype(np.float32) * 0.4 for s in ((B, E), (B, E), (Nn, E)))
+    pid = rng.integers(0, 40, size=B).astype(np.int64)
+    nid = rng.integers(0, 40, size=Nn).astype(np.int64)
+    pp = (rng.random(B) * 0.3 + 1e-3).astype(np.float32)
+    pn = (rng.random(Nn) * 0.3 + 1e-3).astype(np.float32)
+    kw = (dict(post_positive_prob=pp, post_negative_prob=pn) if after_mask
+          else dict(positive_sampling_prob=pp, negative_sampling_prob=pn))
+    logits, _ = O.contrastive_outputs(q, it, ng, pid, nid, temperature=T, **kw)
+    loss, lse = O.softmax_ce_first_column(logits)
+    # fp64 autograd of the same corrected logits
+    qt, itt, ngt = (torch.from_numpy(a).double().requires_grad_() for a in (q, it, ng))
+    lp, ln = torch.log(torch.from_numpy(pp).double() + 1e-16), torch.log(torch.from_numpy(pn).double() + 1e-16)
+    posd = (qt * itt).sum(-1, keepdim=True)
+    negd = qt @ ngt.T
+    m = torch.from_numpy(pid)[:, None] == torch.from_numpy(nid)[None, :]
+    fns = float(np.float32(O.MIN_FLOAT))
+    if after_mask:
+        negd = torch.where(m, torch.full_like(negd, fns), negd) - ln[None, :]
+    else:
+        negd = torch.where(m, torch.full_like(negd, fns), negd - ln[None, :])
+    z = torch.cat([posd - lp[:, None], negd], 1) / T
+    (torch.logsumexp(z, 1) - z[:, 0]).mean().backward()
+    dev = lambda a: _t(a, device)
+    args = (dev(q), dev(it), dev(ng), dev(pid), dev(nid), T)
+    lkw = dict(pos_logq=torch.log(dev(pp) + 1e-16), neg_logq=torch.log(dev(pn) + 1e-16), logq_after_mask=after_mask)
+    r = ops.inbatch_softmax(*args, **lkw)
+    np.testing.assert_allclose(r.logits.cpu().numpy(), logits, atol=ATOL * 2, rtol=1e-5)
+    np.testing.assert_allclose(r.loss.cpu().numpy(), loss, atol=ATOL, rtol=1e-4)
+    tol = dict(atol=2e-6, rtol=3e-4)
+    dq, ditem, dneg = ops.inbatch_softmax_backward(*args[:3], r.lse, *args[3:], **lkw)
+    np.testing.assert_allclose(dq.cpu().numpy(), qt.grad.numpy(), **tol)
+    np.testing.assert_allclose(ditem.cpu().numpy(), itt.grad.numpy(), **tol)
+    np.testing.assert_allclose(dneg.cpu().numpy(), ngt.grad.numpy(), **tol)
+    fused = ops.inbatch_softmax_train(*args, **lkw)
+    if E <= 128:
+        r2, dq2, ditem2 = fused
+        np.testing.assert_allclose(r2.loss.cpu().numpy(), loss, atol=ATOL, rtol=1e-4)
+        np.testing.assert_allclose(dq2.cpu().numpy(), qt.grad.numpy(), **tol)
+        np.testing.assert_allclose(ditem2.cpu().numpy(), itt.grad.numpy(), **tol)
+    else:
+        assert fused is None
+
+
 @pytest.mark.parametrize("Bq,N,E,k", [(5, 40, 8, 7), (130, 5000, 64, 100), (64, 70000, 128, 10), (3, 300, 32, 300), (257, 1025, 16, 1)])
 def test_topk_bit_exact_vs_c_oracle(device, Bq, N, E, k):
     rng = np.random.default_rng(Bq + N)
