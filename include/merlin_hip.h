@@ -47,6 +47,7 @@ extern "C" {
 #define MH_COMBINER_SUM 0
 #define MH_COMBINER_MEAN 1
 #define MH_COMBINER_SQRTN 2
+#define MH_COMBINER_MAX 3 /* dense lists only: process_str_sequence_combiner "max" (inputs/embedding.py:1579-1580) */
 
 /* sparse optimizers for the embedding backward (models/base.py:1121-1174; blocks/optimizer.py) */
 #define MH_OPT_SGD 0
@@ -99,7 +100,9 @@ int32_t mh_embedding_bag_fwd(const float* table, int64_t rows, const void* value
  * `process_str_sequence_combiner` w.r.t. the table is an IndexedSlices over the nnz values with rows
  * grad[b] / div(b), div = 1 | kept | sqrt(kept) for sum | mean | sqrtn (kept = non-pruned ids of bag b; every
  * position for a dense list) -- a division, like the gradient of the forward's div_no_nan.  Pruned (< 0) and out-of-range ids receive no update.
- * offsets == NULL selects the dense list of length L (nnz must equal B*L).  nnz < 2^26. */
+ * offsets == NULL selects the dense list of length L (nnz must equal B*L).  nnz < 2^26.
+ * MAX (dense lists only): the gradient of tf.reduce_max -- grad[b, d] goes to the positions whose row attains the maximum
+ * of component d, split equally among ties (the rows are re-gathered from the not-yet-updated table). */
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D);
 int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t rows, const void* values,
                              int64_t nnz, const void* offsets, int64_t L, int32_t ids_dtype, int64_t B, int32_t D,
@@ -109,7 +112,7 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
 
 /* Dense fixed-length list [B, L] with a string combiner over axis 1 (mean / sum):
  * process_str_sequence_combiner (inputs/embedding.py:1556-1587): every position counts
- * (id 0 is NOT padding-aware). */
+ * (id 0 is NOT padding-aware).  combiner: SUM, MEAN or MAX (elementwise maximum over the L rows). */
 int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void* ids /*[B,L]*/,
                                     int32_t ids_dtype, int64_t B, int32_t L, int32_t D,
                                     int32_t combiner, float* out, int64_t out_row_stride,
@@ -139,6 +142,13 @@ int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const*
                                 int32_t optimizer, float lr, float eps, float* const* state2 /*HOST [F]*/,
                                 float beta1, float beta2, const float* lr_device, void* workspace,
                                 int64_t workspace_bytes, mh_stream_t stream);
+
+/* l2_batch_regularization_factor of EmbeddingTable (inputs/embedding.py:463-464): the layer adds
+ * factor * sum(out^2) over the batch of looked-up rows to the loss.  out[B, D] / grad[B, D] are views with row strides
+ * ld_out / ld_grad (e.g. one slot of the stacked [B, F, D] buffers): grad += 2 factor out (skipped if grad == NULL),
+ * loss_accum[0] += factor * sum(out^2) (fixed summation order).  workspace: 256 floats. */
+int32_t mh_l2_batch_reg(const float* out, int64_t ld_out, float* grad, int64_t ld_grad, int64_t B, int32_t D,
+                        float factor, float* loss_accum, float* workspace, mh_stream_t stream);
 
 /* ---- a6: Dense layer  y = act(x W + b) -------------------------------------------------
  * Replaces keras Dense inside _Dense.call (blocks/mlp.py:275-280).  x[M, K] (leading dim ldx),

@@ -16,7 +16,7 @@ from . import build as _build
 MH_OK = 0
 MH_I32, MH_I64 = 0, 1
 ACT = {"linear": 0, None: 0, "none": 0, "relu": 1, "sigmoid": 2}
-COMBINER = {"sum": 0, "mean": 1, "sqrtn": 2}
+COMBINER = {"sum": 0, "mean": 1, "sqrtn": 2, "max": 3}
 OPT = {"sgd": 0, "adagrad": 1, "adam": 2, "lazy_adam": 2}
 MAX_FEATURES = 64
 
@@ -35,6 +35,7 @@ SIGNATURES = {
     "mh_embedding_bag_bwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "mh_embedding_bag_bwd": (_i32, [_p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _p, _i64, _i32, _f32, _f32, _f32, _f32, _p, _p, _i64, _p]),
     "mh_embedding_gather_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _f32, _f32, _p, _p, _i64, _p]),
+    "mh_l2_batch_reg": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _f32, _p, _p, _p]),
     "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_linear_bias_act_bwd": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),

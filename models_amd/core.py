@@ -114,6 +114,19 @@ class Block:
                     out.append(p)
         return out
 
+    def blocks_of_type(self, cls) -> List["Block"]:
+        """Every distinct descendant (self included) that is an instance of ``cls``."""
+        seen, out, stack = set(), [], [self]
+        while stack:
+            b = stack.pop()
+            if id(b) in seen:
+                continue
+            seen.add(id(b))
+            if isinstance(b, cls):
+                out.append(b)
+            stack.extend(b.children())
+        return out
+
     def train(self, mode: bool = True) -> "Block":
         self.training = mode
         for c in self.children():

@@ -98,7 +98,18 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
     }
     const int64_t beg = offsets ? (int64_t)offsets[bag] : bag * L;
     const int64_t end = offsets ? (int64_t)offsets[bag + 1] : beg + L;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // MAX (dense lists only, process_str_sequence_combiner "max", inputs/embedding.py:1579-1580): elementwise maximum
+    // over the L rows; a position whose id is out of range contributes the zero row, like every other combiner here
+    const bool is_max = combiner == MH_COMBINER_MAX;
+    const float a0 = is_max ? -INFINITY : 0.f;
+    f32x4 acc = {a0, a0, a0, a0};
+    auto comb = [is_max](f32x4& a, const f32x4 v) {
+        if (is_max) {
+            a.x = fmaxf(a.x, v.x); a.y = fmaxf(a.y, v.y); a.z = fmaxf(a.z, v.z); a.w = fmaxf(a.w, v.w);
+        } else {
+            a += v;
+        }
+    };
     int cnt = 0;
     const int64_t stride = (int64_t)LPR * 4;
     int64_t p = beg + g;
@@ -114,29 +125,29 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
         f32x4 v1 = o1 ? *reinterpret_cast<const f32x4*>(table + i1 * stride + c * 4) : z;
         f32x4 v2 = o2 ? *reinterpret_cast<const f32x4*>(table + i2 * stride + c * 4) : z;
         f32x4 v3 = o3 ? *reinterpret_cast<const f32x4*>(table + i3 * stride + c * 4) : z;
-        acc += v0;
-        acc += v1;
-        acc += v2;
-        acc += v3;
+        comb(acc, v0);
+        comb(acc, v1);
+        comb(acc, v2);
+        comb(acc, v3);
         cnt += (int)k0 + (int)k1 + (int)k2 + (int)k3;
     }
     for (; p < end; p += G) {
         int64_t i0 = values[p];
         const bool k0 = !(prune_neg && i0 < 0);
         const bool o0 = i0 >= 0 && i0 < rows;
-        if (o0) acc += *reinterpret_cast<const f32x4*>(table + i0 * stride + c * 4);
+        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+        comb(acc, o0 ? *reinterpret_cast<const f32x4*>(table + i0 * stride + c * 4) : zz);
         cnt += (int)k0;
     }
     if (COOP) {
         for (int off = LPR; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off);
-            acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off);
-            acc.w += __shfl_xor(acc.w, off);
+            const f32x4 o = {__shfl_xor(acc.x, off), __shfl_xor(acc.y, off), __shfl_xor(acc.z, off), __shfl_xor(acc.w, off)};
+            comb(acc, o);
             cnt += __shfl_xor(cnt, off);
         }
         if (g != 0) return;
     }
+    if (is_max && acc.x == -INFINITY) acc = f32x4{0.f, 0.f, 0.f, 0.f};  // a group that saw no position (cannot happen for L >= 1)
     if (cnt > 0) {
         if (combiner == MH_COMBINER_MEAN) {
             const float n = (float)cnt;
@@ -241,7 +252,8 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_dense_list_fwd: D=%d must be a multiple of 4 in [4,1024]", D);
     MH_REQUIRE(L >= 1, "mh_embedding_dense_list_fwd: L must be >= 1");
     MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_dense_list_fwd: bad ids_dtype %d", ids_dtype);
-    MH_REQUIRE(combiner == MH_COMBINER_SUM || combiner == MH_COMBINER_MEAN, "mh_embedding_dense_list_fwd: combiner must be sum or mean");
+    MH_REQUIRE(combiner == MH_COMBINER_SUM || combiner == MH_COMBINER_MEAN || combiner == MH_COMBINER_MAX,
+               "mh_embedding_dense_list_fwd: combiner must be sum, mean or max");
     MH_REQUIRE(out_row_stride % 4 == 0 && out_row_stride >= D, "mh_embedding_dense_list_fwd: bad out_row_stride");
     if (B <= 0) return MH_OK;
     hipStream_t s = mh_stream(stream);

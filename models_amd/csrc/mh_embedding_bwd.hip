@@ -700,6 +700,45 @@ __global__ __launch_bounds__(256) void bag_expand_kernel(const IdT* __restrict__
     }
 }
 
+// Dense list with the "max" combiner: gexp[b*L + l][d] = grad[b][d] / ties(b, d) if row(ids[b, l])[d] is the maximum of
+// component d over the list, else 0 (tf.reduce_max gradient: indicators / number selected).  One LPR-lane group per bag;
+// the rows are read three times (maximum, tie count, expansion) -- they stay in L1 / L2.
+template <typename IdT>
+__global__ __launch_bounds__(256) void bag_expand_max_kernel(const float* __restrict__ table, int64_t rows,
+                                                            const IdT* __restrict__ ids, int64_t L, int64_t B, int LPR,
+                                                            const float* __restrict__ grad, int64_t ldg,
+                                                            float* __restrict__ gexp) {
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    if (gi >= groups) return;
+    const int64_t D = (int64_t)LPR * 4;
+    auto row = [&](int64_t j) -> f32x4 {
+        const int64_t id = (int64_t)ids[j];
+        if (id < 0 || id >= rows) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(table + id * D + c4 * 4);
+    };
+    for (int64_t b = (int64_t)blockIdx.x * groups + gi; b < B; b += (int64_t)gridDim.x * groups) {
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int64_t l = 0; l < L; ++l) {
+            const f32x4 x = row(b * L + l);
+            m.x = fmaxf(m.x, x.x); m.y = fmaxf(m.y, x.y); m.z = fmaxf(m.z, x.z); m.w = fmaxf(m.w, x.w);
+        }
+        f32x4 n = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t l = 0; l < L; ++l) {
+            const f32x4 x = row(b * L + l);
+            n.x += (x.x == m.x); n.y += (x.y == m.y); n.z += (x.z == m.z); n.w += (x.w == m.w);
+        }
+        f32x4 g = *reinterpret_cast<const f32x4*>(grad + b * ldg + c4 * 4);
+        g.x /= n.x; g.y /= n.y; g.z /= n.z; g.w /= n.w;
+        for (int64_t l = 0; l < L; ++l) {
+            const f32x4 x = row(b * L + l);
+            const f32x4 o = {x.x == m.x ? g.x : 0.f, x.y == m.y ? g.y : 0.f, x.z == m.z ? g.z : 0.f, x.w == m.w ? g.w : 0.f};
+            *reinterpret_cast<f32x4*>(gexp + (b * L + l) * D + c4 * 4) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -824,7 +863,8 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
                              int64_t workspace_bytes, mh_stream_t stream) {
     MH_REQUIRE(table && grad, "mh_embedding_bag_bwd: null argument");
     MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_bag_bwd: bad ids_dtype");
-    MH_REQUIRE(combiner >= MH_COMBINER_SUM && combiner <= MH_COMBINER_SQRTN, "mh_embedding_bag_bwd: bad combiner %d", combiner);
+    MH_REQUIRE(combiner >= MH_COMBINER_SUM && combiner <= MH_COMBINER_MAX, "mh_embedding_bag_bwd: bad combiner %d", combiner);
+    MH_REQUIRE(combiner != MH_COMBINER_MAX || !offsets, "mh_embedding_bag_bwd: the max combiner is defined for dense lists only");
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_bag_bwd: D=%d must be a multiple of 4 in [4,1024]", D);
     MH_REQUIRE(grad_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0,
                "mh_embedding_bag_bwd: grad must be 16-byte aligned with grad_row_stride %% 4 == 0");
@@ -848,7 +888,14 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
     int64_t nb = mh_ceil_div(nnz, groups);
     const int64_t cap = (int64_t)mh_num_cus() * 16;
     if (nb > cap) nb = cap;
-    if (ids_dtype == MH_I32) {
+    if (combiner == MH_COMBINER_MAX) {
+        if (ids_dtype == MH_I32)
+            hipLaunchKernelGGL((bag_expand_max_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
+                               (const int32_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
+        else
+            hipLaunchKernelGGL((bag_expand_max_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
+                               (const int64_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
+    } else if (ids_dtype == MH_I32) {
         hipLaunchKernelGGL((bag_scale_kernel<int32_t>), gs, dim3(256), 0, s, (const int32_t*)values,
                            (const int32_t*)offsets, L, B, combiner, scale);
         hipLaunchKernelGGL((bag_expand_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int32_t*)offsets, L,

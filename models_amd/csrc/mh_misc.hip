@@ -205,9 +205,61 @@ __global__ __launch_bounds__(256) void eltwise_kernel(int op, const float* __res
     out[i] = v;
 }
 
+// l2_batch_regularization (inputs/embedding.py:463-464): loss += factor * sum(out^2), d loss / d out = 2 factor out.
+// Pass 1: grad[b, d] += 2 factor out[b, d] over the [B, D] view (row strides ld_out / ld_grad), per-workgroup partial of
+// sum(out^2); pass 2 adds the partials in a fixed order into loss_accum (deterministic).
+__global__ __launch_bounds__(256) void l2_batch_reg_kernel(const float* __restrict__ out, int64_t ld_out,
+                                                          float* __restrict__ grad, int64_t ld_grad, int64_t B, int D4,
+                                                          float factor, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    const int64_t n = B * D4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / D4;
+        const int c = (int)(i - b * D4);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(out + b * ld_out + c * 4);
+        acc += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+        if (grad) {
+            f32x4* g = reinterpret_cast<f32x4*>(grad + b * ld_grad + c * 4);
+            *g = *g + o * (2.f * factor);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void l2_batch_reg_finish_kernel(const float* __restrict__ partial, int nb, float factor,
+                                                                float* __restrict__ loss_accum) {
+    const int lane = threadIdx.x;
+    float t = 0.f;
+    for (int i = lane; i < nb; i += 64) t += partial[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) *loss_accum += factor * t;
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t mh_l2_batch_reg(const float* out, int64_t ld_out, float* grad, int64_t ld_grad, int64_t B, int32_t D, float factor,
+                        float* loss_accum, float* workspace, mh_stream_t stream) {
+    MH_REQUIRE(out && loss_accum && workspace, "mh_l2_batch_reg: null argument");
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && ld_out % 4 == 0 && (!grad || ld_grad % 4 == 0), "mh_l2_batch_reg: D and strides must be multiples of 4");
+    if (B <= 0) return MH_OK;
+    int64_t nb = mh_ceil_div(B * (D / 4), 256);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(l2_batch_reg_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), out, ld_out, grad, ld_grad, B,
+                       D / 4, factor, workspace);
+    hipLaunchKernelGGL(l2_batch_reg_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, factor, loss_accum);
+    MH_CHECK_LAUNCH("mh_l2_batch_reg");
+    return MH_OK;
+}
 
 int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad, float* const* state,
                                       const int64_t* n, int32_t count, int32_t optimizer, float lr, float eps,

@@ -70,7 +70,7 @@ class EmbeddingTable(Block):
 
     def __init__(self, dim: int, *col_schemas: ColumnSchema, sequence_combiner: Optional[str] = None,
                  embeddings_initializer="uniform", trainable: bool = True, name: Optional[str] = None,
-                 device=None, seed: Optional[int] = None):
+                 device=None, seed: Optional[int] = None, l2_batch_regularization_factor: float = 0.0):
         if not col_schemas:
             raise ValueError("EmbeddingTable needs at least one ColumnSchema")
         first = col_schemas[0]
@@ -82,9 +82,11 @@ class EmbeddingTable(Block):
         self.input_dim = None
         for col in col_schemas:
             self.add_feature(col)
-        if sequence_combiner is not None and sequence_combiner not in ("mean", "sum", "sqrtn"):
-            raise ValueError("sequence_combiner must be 'mean', 'sum' or 'sqrtn'")
+        if sequence_combiner is not None and sequence_combiner not in ("mean", "sum", "sqrtn", "max"):
+            raise ValueError("sequence_combiner must be 'mean', 'sum', 'sqrtn' (ragged) or 'max' (dense lists)")
         self.sequence_combiner = sequence_combiner
+        # embedding.py:463-464: every lookup adds factor * sum(out^2) over the batch to the loss
+        self.l2_batch_regularization_factor = float(l2_batch_regularization_factor or 0.0)
         self.device = torch.device(device) if device is not None else default_device()
         w = _init_table(embeddings_initializer, self.input_dim, self.dim, self.device, seed)
         self.table = Parameter(w, name=f"{self.name}/embeddings", trainable=trainable, sparse=True)
@@ -130,7 +132,9 @@ class EmbeddingTable(Block):
             x = x.squeeze(-1)
         if x.dim() == 2 and x.shape[1] > 1:
             if not self.sequence_combiner:
-                raise ValueError("dense list inputs need a sequence_combiner ('mean' or 'sum')")
+                raise ValueError("dense list inputs need a sequence_combiner ('mean', 'sum' or 'max')")
+            if self.sequence_combiner == "sqrtn":
+                raise ValueError("Only 'mean', 'sum', and 'max' str combiners is implemented for dense list/multi-hot embedded features.")
             return ops.embedding_dense_list(w, x, self.sequence_combiner, out=out)
         res = ops.embedding_gather([w], [x], out=None if out is None else out.unsqueeze(1))
         return res[:, 0]
@@ -173,6 +177,18 @@ class EmbeddingsBlock(ParallelBlock):
             if n not in onehot:
                 self.feature_table[n]._lookup(inputs[n], out=out[:, slots[n]])
         self._last = {n: inputs[n] for n in names}
+        for n in names:  # forward outputs the l2 batch regularisation needs in the backward
+            if self.feature_table[n].l2_batch_regularization_factor > 0:
+                self._fwd_out = getattr(self, "_fwd_out", {})
+                self._fwd_out[n] = out[:, slots[n]]
+
+    @property
+    def has_batch_regularization(self) -> bool:
+        return any(t.l2_batch_regularization_factor > 0 for t in self.parallel_layers.values())
+
+    def regularization_loss(self) -> Optional[torch.Tensor]:
+        """Sum of the tables' factor * sum(out^2) terms of the LAST train step (device scalar), or None."""
+        return getattr(self, "_reg_loss", None) if self.has_batch_regularization else None
 
     def forward(self, inputs: TabularData):
         names = [n for n in self.feature_names if n in inputs]
@@ -246,8 +262,17 @@ class EmbeddingsBlock(ParallelBlock):
                 return t.state["m"], t.state["v"]
             return None, None
 
-        # ragged / dense-list features: gradient rows scale with the combiner, one fused launch chain each
         g2 = grad.reshape(grad.shape[0], -1)
+        if self.has_batch_regularization:  # d (factor * sum out^2) / d out = 2 factor out, added to the incoming gradient
+            if getattr(self, "_reg_loss", None) is None:
+                self._reg_loss = torch.zeros(1, dtype=torch.float32, device=grad.device)
+            self._reg_loss.zero_()
+            for n in offsets:
+                ft = self.feature_table[n]
+                if n in self._last and ft.l2_batch_regularization_factor > 0:
+                    ops.l2_batch_reg(self._fwd_out[n], g2[:, offsets[n]:offsets[n] + ft.dim],
+                                     ft.l2_batch_regularization_factor, self._reg_loss)
+        # ragged / dense-list features: gradient rows scale with the combiner, one fused launch chain each
         for n in lists:
             ft = self.feature_table[n]
             x = self._last[n]
@@ -282,7 +307,8 @@ def Embeddings(schema: Schema, dim: Optional[Union[Dict[str, int], int]] = None,
                infer_dim_fn: Callable[[ColumnSchema], int] = infer_embedding_dim,
                sequence_combiner: Optional[Union[str, Dict[str, str]]] = "mean",
                embeddings_initializer=None, trainable: Optional[Union[bool, Dict[str, bool]]] = None,
-               aggregation=None, block_name: str = "embeddings", device=None, seed: int = 0) -> EmbeddingsBlock:
+               aggregation=None, block_name: str = "embeddings", device=None, seed: int = 0,
+               l2_batch_regularization_factor: Optional[Union[float, Dict[str, float]]] = 0.0) -> EmbeddingsBlock:
     """embedding.py:585-683: one EmbeddingTable per categorical column; columns whose
     ``int_domain.name`` coincide share one table; ``dim=None`` -> ``infer_dim_fn(col)``."""
     schema = schema.select_by_tag(Tags.CATEGORICAL) if any(Tags.CATEGORICAL in c.tags for c in schema) else schema
@@ -306,6 +332,7 @@ def Embeddings(schema: Schema, dim: Optional[Union[Dict[str, int], int]] = None,
         if tr is not None:
             kw["trainable"] = tr
         init = pick(embeddings_initializer, col)
+        kw["l2_batch_regularization_factor"] = pick(l2_batch_regularization_factor, col) or 0.0
         tables[tname] = EmbeddingTable(d, col, sequence_combiner=pick(sequence_combiner, col),
                                        embeddings_initializer=init if init is not None else "uniform",
                                        name=tname, device=device, seed=seed + i, **kw)

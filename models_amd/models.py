@@ -16,7 +16,7 @@ import torch
 from . import ops, optim
 from .blocks import CrossBlock, DLRMBlock, MLPBlock, TwoTowerBlock, _Dense
 from .core import Block, ConcatFeatures, ParallelBlock, SequentialBlock, TabularData, call_layer
-from .inputs import InputBlockV2, Ragged
+from .inputs import EmbeddingsBlock, InputBlockV2, Ragged
 from .outputs import BinaryOutput, BruteForce, ContrastiveOutput, Prediction, TopKOutput
 from .schema import ColumnSchema, Schema, Tags
 
@@ -181,10 +181,20 @@ class RankingModel(Model):
             else:
                 self.body.backward(dh)
             self.optimizer.apply(self)
-        return loss
+        return _with_regularization(self, loss)
 
     def evaluate(self, batches, **kwargs) -> Dict[str, float]:
         return _ranking_evaluate(self, batches)
+
+
+def _with_regularization(model, loss: torch.Tensor) -> torch.Tensor:
+    """Keras adds the layers' ``add_loss`` terms to the training loss (models/base.py:1137-1151): here the
+    l2_batch_regularization terms of the embedding tables (inputs/embedding.py:463-464)."""
+    for blk in model.blocks_of_type(EmbeddingsBlock):
+        r = blk.regularization_loss()
+        if r is not None:
+            loss = loss + r[0]
+    return loss
 
 
 def _ranking_evaluate(model, batches) -> Dict[str, float]:
@@ -332,7 +342,7 @@ class RetrievalModel(Model):
             self.body.parallel_layers["query"].backward(dq)
             self.body.parallel_layers["item"].backward(ditem)
             self.optimizer.apply(self)
-        return res.loss.mean()
+        return _with_regularization(self, res.loss.mean())
 
     def evaluate(self, batches, k: int = 10, **kwargs) -> Dict[str, float]:
         """In-batch evaluation as the reference runs it under ``testing=True`` (outputs/contrastive.py:223-344): every

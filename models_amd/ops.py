@@ -272,8 +272,8 @@ def embedding_bag(
     idt = _ids_dtype(values, "values")
     if offsets.dtype != values.dtype:
         raise TypeError("offsets and values must share one integer dtype")
-    if combiner not in COMBINER:
-        raise ValueError(f"combiner must be one of {sorted(COMBINER)}, got {combiner!r}")
+    if combiner not in COMBINER or combiner == "max":
+        raise ValueError(f"ragged combiner must be one of ['mean', 'sqrtn', 'sum'], got {combiner!r}")
     B = offsets.shape[0] - 1
     D = table.shape[1]
     values = values.reshape(-1).contiguous()
@@ -298,8 +298,8 @@ def embedding_dense_list(
     _dev(table, "table", torch.float32)
     _dev(ids, "ids")
     idt = _ids_dtype(ids, "ids")
-    if combiner not in ("mean", "sum"):
-        raise ValueError("Only 'mean' and 'sum' str combiners are implemented on the HIP path")
+    if combiner not in ("mean", "sum", "max"):
+        raise ValueError("Only 'mean', 'sum', and 'max' str combiners is implemented for dense list/multi-hot embedded features.")
     if ids.dim() == 3 and ids.shape[-1] == 1:
         ids = ids.squeeze(-1)
     if ids.dim() != 2:
@@ -576,6 +576,19 @@ def embedding_bag_backward(table: torch.Tensor, state: Optional[torch.Tensor], v
                                      _stream()),
             "mh_embedding_bag_bwd",
         )
+
+
+def l2_batch_reg(out: torch.Tensor, grad: Optional[torch.Tensor], factor: float, loss_accum: torch.Tensor) -> None:
+    """``loss_accum += factor * sum(out^2)`` and ``grad += 2 * factor * out`` for [B, D] views with unit inner stride
+    (``mh_l2_batch_reg``: the l2_batch_regularization term of an embedding lookup)."""
+    lib = _lib.load()
+    _dev(out, "out", torch.float32)
+    _dev(loss_accum, "loss_accum", torch.float32)
+    if out.dim() != 2 or out.stride(1) != 1 or (grad is not None and (grad.shape != out.shape or grad.stride(1) != 1)):
+        raise ValueError("l2_batch_reg: out / grad must be [B, D] views with unit inner stride")
+    ws = _workspace(1024, out.device, "l2_batch_reg")
+    check(lib.mh_l2_batch_reg(_ptr(out), out.stride(0), _ptr(grad), 0 if grad is None else grad.stride(0), out.shape[0],
+                              out.shape[1], float(factor), _ptr(loss_accum), _ptr(ws), _stream()), "mh_l2_batch_reg")
 
 
 def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):

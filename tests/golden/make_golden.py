@@ -143,6 +143,21 @@ def main():
     corr = torch.cat([probs[pos_id].unsqueeze(1), probs[neg_id].unsqueeze(0).expand(B, Nn)], 1)
     out.update(pc_probs=probs, pc_reg=np.array(reg), pc_logits=logits - reg * torch.log(corr + 1e-16))
 
+    # --- ragged lookup: the reference's torch backend combines a bag with F.embedding_bag(inputs, weight, offsets,
+    # mode=seq_combiner) (torch/inputs/embedding.py:291-293) -- sum / mean bags incl. empty ones (offsets WITHOUT the end)
+    embedding_bag = load("merlin/models/torch/inputs/embedding.py", "forward_bag", "EmbeddingTable",
+                         {"nn": torch.nn})
+    V, D_, nb = 29, 12, 17
+    Wb = torch.randn(V, D_, generator=g)
+    lens = torch.randint(0, 6, (nb,), generator=g)
+    lens[4] = 0
+    offs = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(lens, 0)])
+    vals = torch.randint(0, V, (int(offs[-1]),), generator=g)
+    out.update(bag_W=Wb, bag_values=vals, bag_offsets=offs)
+    for mode in ("sum", "mean"):
+        me7 = types.SimpleNamespace(table=types.SimpleNamespace(weight=Wb), seq_combiner=mode)
+        out[f"bag_{mode}"] = embedding_bag(me7, vals, offs[:-1])
+
     np.savez_compressed(OUT / "reference_vectors.npz",
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     print("wrote", OUT / "reference_vectors.npz", len(out), "arrays")

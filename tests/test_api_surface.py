@@ -77,9 +77,14 @@ def test_two_tower_requires_user_and_item_tags():
         mm.TwoTowerModel(sch, mm.MLPBlock([8], device=CPU), device=CPU)
 
 
-def test_contrastive_output_rejects_other_samplers():
-    with pytest.raises(NotImplementedError):
-        mm.ContrastiveOutput(S.categorical("item_id", 10, [S.Tags.ITEM_ID]), negative_samplers="popularity")
+def test_contrastive_output_samplers():
+    col = S.categorical("item_id", 10, [S.Tags.ITEM_ID])
+    with pytest.raises(ValueError):  # unregistered sampler name
+        mm.ContrastiveOutput(col, negative_samplers="popularity")
+    out = mm.ContrastiveOutput(col, negative_samplers=["in-batch", mm.PopularityBasedSamplerV2(max_id=9, max_num_samples=3)])
+    assert [type(s).__name__ for s in out.negative_samplers] == ["InBatchSamplerV2", "PopularityBasedSamplerV2"]
+    with pytest.raises(NotImplementedError):  # only the popularity logQ block is a supported `post`
+        mm.ContrastiveOutput(col, post=mm.MLPBlock([4]))
 
 
 def test_prepare_features_ragged_contract():
@@ -107,7 +112,7 @@ def test_encoder_and_two_tower_v2_signature():
     assert model.output.logits_temperature == 0.5 and model.body.parallel_layers["item"] is c
     with pytest.raises(ValueError):
         mm.TwoTowerModelV2(mm.MLPBlock([8], device="cpu"), c)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # not a registered sampler name
         mm.TwoTowerModelV2(q, c, negative_samplers=["popularity"])
 
 

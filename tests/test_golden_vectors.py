@@ -85,3 +85,18 @@ def test_hip_cross_matches_reference_vectors(device):
         h = ops.linear(x, t(G[f"crl_U{i}"]), None, None)
         x = ops.cross_layer_lowrank(x0, x, h, t(G[f"crl_V{i}"]), t(G[f"crl_b{i}"]))
     np.testing.assert_allclose(x.cpu().numpy(), G["crl_y"], atol=ATOL, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_bag_lookup_matches_reference_embedding_bag(device):
+    """HIP ragged lookup (mh_embedding_bag_fwd) against the reference torch backend's F.embedding_bag outputs."""
+    import torch
+
+    from models_amd import ops
+
+    W = torch.from_numpy(G["bag_W"]).to(device)
+    vals = torch.from_numpy(G["bag_values"]).to(device)
+    offs = torch.from_numpy(G["bag_offsets"]).to(device)
+    for mode in ("sum", "mean"):
+        got = ops.embedding_bag(W, vals, offs, mode)
+        np.testing.assert_allclose(got.cpu().numpy(), G[f"bag_{mode}"], atol=1e-6)

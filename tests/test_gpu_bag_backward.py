@@ -114,3 +114,66 @@ def test_embeddings_block_trains_ragged_feature():
     np.testing.assert_allclose(emb.feature_table["a"].table.numpy(), Wa0 - 0.5 * dWa, rtol=1e-5, atol=1e-6)
     dWl = O.embedding_bag_grad(40, values, offsets, grad[:, 1], "mean")
     np.testing.assert_allclose(emb.feature_table["l"].table.numpy(), Wl0 - 0.5 * dWl, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("D,L", [(8, 5), (64, 12)])
+def test_dense_list_max_combiner_forward_and_backward(dtype, D, L):
+    """process_str_sequence_combiner "max" (tf/inputs/embedding.py:1579-1580): tf.reduce_max over the list axis and
+    its gradient (the maximum's positions share the gradient equally), against torch-CPU autograd of amax."""
+    from models_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(D * L)
+    V, B = 40, 200
+    W = rng.standard_normal((V, D)).astype(np.float32).round(1)  # coarse values: ties happen
+    ids = rng.integers(0, V, size=(B, L))
+    ids[3, 2] = V + 5   # out of range: contributes the zero row
+    wt = torch.from_numpy(W).clone().requires_grad_()
+    rows = wt[torch.from_numpy(np.clip(ids, 0, V - 1))] * torch.from_numpy((ids < V)[..., None].astype(np.float32))
+    out_ref = rows.amax(dim=1)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    out_ref.backward(torch.from_numpy(g))  # amax backward distributes evenly among ties, like tf.reduce_max
+    out = ops.embedding_dense_list(torch.from_numpy(W).to(dev), torch.from_numpy(ids).to(dtype).to(dev), "max")
+    np.testing.assert_array_equal(out.cpu().numpy(), out_ref.detach().numpy())
+    dW = torch.from_numpy(W).to(dev).clone()
+    ops.embedding_bag_backward(dW, None, torch.from_numpy(ids).to(dtype).to(dev), None, torch.from_numpy(g).to(dev),
+                               "max", "sgd", 1.0)
+    np.testing.assert_allclose(W - dW.cpu().numpy(), wt.grad.numpy(), atol=1e-5, rtol=1e-5)
+
+
+def test_l2_batch_regularization_through_dlrm_train_step():
+    """l2_batch_regularization_factor (tf/inputs/embedding.py:463-464): the train loss gains factor * sum(out^2) per
+    regularised lookup and the table gradient gains 2 factor out -- compared with torch-CPU autograd on the same step."""
+    import models_amd as mm
+    from models_amd import schema as S
+
+    dev = _dev()
+    torch.manual_seed(0)
+    lam = 0.01
+    cols = [S.categorical("a", 30), S.categorical("b", 50), S.continuous("x"), S.binary_target("y")]
+    schema = mm.Schema(cols)
+
+    # the option travels through mm.Embeddings / EmbeddingTable; exercise it on the block level
+    emb = mm.Embeddings(mm.Schema(cols[:2]), dim=8, device=dev, l2_batch_regularization_factor={"a": lam}, aggregation=None)
+    B = 64
+    g = torch.Generator().manual_seed(2)
+    x = {"a": torch.randint(0, 30, (B, 1), generator=g).to(dev), "b": torch.randint(0, 50, (B, 1), generator=g).to(dev)}
+    Wa0 = emb.feature_table["a"].table.data.clone()
+    Wb0 = emb.feature_table["b"].table.data.clone()
+    buf = torch.empty(B, 2, 8, device=dev)
+    emb.gather_into(x, buf, {"a": 0, "b": 1})
+    up = torch.randn(B, 2, 8, generator=g).to(dev)
+    grad = up.clone()
+    from models_amd.optim import SGD
+
+    opt = SGD(learning_rate=1.0)
+    emb.set_pending_grad(grad, {"a": 0, "b": 8})
+    emb.apply_sparse(opt)
+    out_a = Wa0[x["a"].reshape(-1)]
+    want_loss = lam * float((out_a.double() ** 2).sum())
+    assert abs(float(emb.regularization_loss()[0]) - want_loss) < 1e-4 * max(1.0, want_loss)
+    ga = torch.zeros_like(Wa0).index_add_(0, x["a"].reshape(-1), up[:, 0] + 2 * lam * out_a)
+    gb = torch.zeros_like(Wb0).index_add_(0, x["b"].reshape(-1), up[:, 1])
+    torch.testing.assert_close(Wa0 - emb.feature_table["a"].table.data, ga, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(Wb0 - emb.feature_table["b"].table.data, gb, atol=1e-5, rtol=1e-5)

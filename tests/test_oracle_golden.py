@@ -145,3 +145,18 @@ def test_topk_metrics_known_answers():
 
     ref = ndcg_score(labels, preds, k=4, ignore_ties=True)  # the reference cross-checks against sklearn too
     np.testing.assert_allclose(O.ndcg_at(y, cnt, 4).mean(), ref, atol=1e-6)
+
+
+def test_bag_sum_mean_match_the_reference_torch_embedding_bag():
+    """Ragged lookup with sum / mean combiners pinned to the outputs of the reference torch backend's own
+    EmbeddingTable.forward_bag (F.embedding_bag, torch/inputs/embedding.py:264-293; vectors by make_golden.py)."""
+    from pathlib import Path
+
+    import numpy as np
+
+    from oracle import oracle as O
+
+    G = np.load(Path(__file__).parent / "golden" / "reference_vectors.npz")
+    for mode in ("sum", "mean"):
+        got = O.embedding_bag(G["bag_W"], G["bag_values"], G["bag_offsets"], mode)
+        np.testing.assert_allclose(got, G[f"bag_{mode}"], atol=1e-6)
