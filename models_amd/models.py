@@ -132,23 +132,69 @@ class Model(Block):
             if self.optimizer.lr_device is None:
                 self.optimizer.lr_device = torch.zeros(1, dtype=torch.float32, device=dev)
 
-    def fit(self, batches: Iterable[Tuple[TabularData, torch.Tensor]], epochs: int = 1, steps_per_epoch: Optional[int] = None):
+    @property
+    def graph_capturable(self) -> bool:
+        """Whether a train step is a fixed launch sequence (no host-side state that changes per step)."""
+        return True
+
+    @staticmethod
+    def _batch_size(x: TabularData) -> int:
+        v = next(iter(x.values()))
+        return (v.offsets.shape[0] - 1) if isinstance(v, Ragged) else v.shape[0]
+
+    def fit(self, batches: Iterable, epochs: int = 1, steps_per_epoch: Optional[int] = None, graph: Optional[bool] = None):
         """Minimal fit loop; samples/sec follows ExamplesPerSecondCallback
-        (tf/logging/callbacks.py:174-189): batch_size * steps / elapsed, first step discarded."""
+        (tf/logging/callbacks.py:174-189): batch_size * steps / elapsed, first step discarded.
+        Batches are ``inputs`` or ``(inputs, targets)`` (what ``models_amd.Loader`` yields; retrieval models take no
+        targets).  ``graph=None``: when the step is a fixed launch sequence (dense inputs of one static shape, stateless
+        samplers) it is captured ONCE into a hipGraph and replayed with each batch copied into the static inputs --
+        eager Python dispatch costs ~3x the kernel time of a DLRM step; batches of another shape (the last partial
+        one) run eagerly."""
+        from .graph import GraphedStep, PackedBatch
+
         if self.optimizer is None:
             self.compile()
         history = {"loss": [], "examples_per_sec": []}
+        graphed, sig = None, None
+
+        def pack(x, y):
+            d = dict(x)
+            if y is not None:
+                d["__targets__"] = y
+            return d
+
+        def eager(d):
+            d = dict(d)
+            y = d.pop("__targets__", None)
+            return self.train_step(d, y)
+
+        def can_graph(x, y):
+            ok = all(isinstance(v, torch.Tensor) and v.is_cuda for v in x.values())
+            return ok and (y is None or isinstance(y, torch.Tensor)) and self.graph_capturable
+
         for _ in range(epochs):
             t0, n, steps, last = None, 0, 0, None
-            for step, (x, y) in enumerate(batches):
+            for step, batch in enumerate(batches):
                 if steps_per_epoch is not None and step >= steps_per_epoch:
                     break
-                last = self.train_step(x, y)
+                x, y = self._split(batch)
+                use_graph = (graph is not False) and can_graph(x, y)
+                if use_graph:
+                    d = pack(x, y)
+                    this_sig = tuple((k, tuple(v.shape), v.dtype) for k, v in d.items())
+                    if graphed is None and (graph or step >= 1):  # step 0 runs eagerly: builds lazily-shaped layers
+                        graphed, sig = GraphedStep(eager, PackedBatch(d)), this_sig
+                    if graphed is not None and this_sig == sig:
+                        last = graphed.replay(PackedBatch(d))
+                    else:
+                        last = eager(d)
+                else:
+                    last = self.train_step(x, y)
                 if step == 0:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                 else:
-                    n += y.shape[0]
+                    n += self._batch_size(x)
                     steps += 1
             torch.cuda.synchronize()
             if last is not None:
@@ -304,6 +350,12 @@ class RetrievalModel(Model):
         emb = self.body(x)
         return self.output.forward({"query": emb["query"], "candidate": emb["item"]}, features=x,
                                    training=training, testing=testing)
+
+    @property
+    def graph_capturable(self) -> bool:
+        from .sampling import InBatchSamplerV2
+
+        return all(isinstance(s, InBatchSamplerV2) for s in self.output.negative_samplers)
 
     def train_step(self, inputs: TabularData, targets=None) -> torch.Tensor:
         """fwd (fused scorer: no [B, B] logits in HBM) -> bwd -> fused updates."""

@@ -594,3 +594,44 @@ def test_contrastive_output_over_candidate_table_with_popularity_sampler(device)
     want, _ = O.contrastive_outputs(q.cpu().numpy(), W[t], W[nid], t, nid, positive_sampling_prob=dist[t],
                                     negative_sampling_prob=dist[nid])
     np.testing.assert_allclose(pred.outputs.cpu().numpy(), want, atol=1e-4)
+
+
+def test_fit_auto_graph_and_targetless_batches(device):
+    """Model.fit: (inputs, targets) batches for ranking, inputs-only batches for retrieval (no AttributeError on a
+    missing target); the static-shape steps replay a captured hipGraph and give the same weights as eager steps; a
+    trailing partial batch falls back to eager."""
+    torch.manual_seed(0)
+    schema = mm.Schema([S.categorical("a", 40), S.categorical("b", 17), S.continuous("x"), S.binary_target("y")])
+
+    def build():
+        torch.manual_seed(3)
+        m = mm.DLRMModel(schema, embedding_dim=8, bottom_block=mm.MLPBlock([8], device=device, seed=1),
+                         top_block=mm.MLPBlock([8], device=device, seed=2), device=device)
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    def batches(sizes):
+        g = torch.Generator().manual_seed(9)
+        out = []
+        for B in sizes:
+            x = {"a": torch.randint(0, 40, (B, 1), generator=g).to(device), "b": torch.randint(0, 17, (B, 1), generator=g).to(device),
+                 "x": torch.rand(B, 1, generator=g).to(device)}
+            out.append((x, torch.randint(0, 2, (B, 1), generator=g).float().to(device)))
+        return out
+
+    data = batches([64, 64, 64, 64, 20])
+    m1, m2 = build(), build()
+    h1 = m1.fit(data, graph=None)
+    h2 = m2.fit(data, graph=False)
+    assert len(h1["loss"]) == 1 and h1["examples_per_sec"][0] > 0
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(p1.data, p2.data, atol=1e-6, rtol=1e-5)
+    assert abs(h1["loss"][0] - h2["loss"][0]) < 1e-5
+    tt = mm.TwoTowerModel(_tt_schema(), mm.MLPBlock([16], device=device), embedding_dim=8, device=device)
+    tt.compile(optimizer="adagrad", learning_rate=0.05)
+    hist = tt.fit([_tt_batch(device, 96, i) for i in range(4)])  # inputs only
+    assert np.isfinite(hist["loss"][0]) and tt.graph_capturable
+    tt2 = mm.TwoTowerModel(_tt_schema(), mm.MLPBlock([16], device=device), embedding_dim=8,
+                           samplers=["in-batch", mm.CachedCrossBatchSampler(64)], device=device)
+    assert not tt2.graph_capturable
+    assert np.isfinite(tt2.fit([_tt_batch(device, 96, i) for i in range(3)])["loss"][0])
