@@ -270,8 +270,11 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain):
     """BASELINE configs[2] train step (two towers + in-batch sampled softmax, B = 32 768 per GPU)."""
     from models_amd.graph import PackedBatch
 
+    from models_amd.distributed import sharded_tables
+
     B = args.tt_batch
-    model, schema = build_twotower(device)
+    with sharded_tables(args.shard_threshold):
+        model, schema = build_twotower(device)
     model.compile(optimizer=args.optimizer, learning_rate=0.01)
     rank = int(os.environ.get("RANK", 0))
     batches = [PackedBatch(make_twotower_batch(device, B, rank * 1000 + i)) for i in range(args.batches)]
@@ -283,6 +286,9 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain):
         runner = DistributedTwoTower(model, shard_threshold=args.shard_threshold)
     train = args.mode == "train"
     eager = (lambda inp: runner.train_step(inp)) if train else (lambda inp: runner(inp, training=True))
+    if tm.world > 1:
+        for i in range(3):  # calibration of the fixed-capacity exchange
+            eager(batches[i % len(batches)].tensors)
     graphed = None
     if not args.eager and tm.world == 1:
         try:
@@ -386,7 +392,10 @@ def run_dcn(args, device, tm: Timing):
     """BASELINE configs[4]: DCN-v2 depth 3 (d = 3341), emb_dim=128, deep [512, 256], B = 64 K per GPU, data-parallel."""
     from models_amd.graph import PackedBatch
 
-    model, schema = build_model(device, emb_dim=128, dcn=True)
+    from models_amd.distributed import sharded_tables
+
+    with sharded_tables(args.shard_threshold):
+        model, schema = build_model(device, emb_dim=128, dcn=True)
     model.compile(optimizer=args.optimizer, learning_rate=0.01)
     rank = int(os.environ.get("RANK", 0))
     batches = [PackedBatch(make_batch(device, args.batch, rank * 1000 + i, args.ids)) for i in range(args.batches)]
@@ -396,7 +405,7 @@ def run_dcn(args, device, tm: Timing):
     if tm.world > 1:
         from models_amd.distributed import DataParallel
 
-        runner = DataParallel(model)
+        runner = DataParallel(model, shard_threshold=args.shard_threshold)
     train = args.mode == "train"
 
     def eager(inp):
@@ -484,7 +493,10 @@ def main():
 
     force = os.environ.get("MH_FORCE_DISTRIBUTED") == "1"  # exercise the sharded code path on one GPU
     sharded = world > 1 or force
-    model, schema = build_model(device, extra_rows=args.extra_table_rows)
+    from models_amd.distributed import sharded_tables
+
+    with sharded_tables(args.shard_threshold, force=force):  # N > 1: large tables are ALLOCATED as row shards
+        model, schema = build_model(device, extra_rows=args.extra_table_rows)
     model.compile(optimizer=args.optimizer, learning_rate=0.01)
     batches = [PackedBatch(make_batch(device, args.batch, rank * 1000 + i, args.ids, args.extra_table_rows))
                for i in range(max(args.batches, 1))]
@@ -503,11 +515,16 @@ def main():
         return runner(x) if args.mode == "fwd" else runner.train_step(x, y)
 
     graphed = None
+    if sharded:  # calibration steps of the row-sharded exchange (dense mode, host-side counts), then fixed windows
+        for i in range(3):
+            eager(batches[i % nb].tensors)
     if not args.eager and getattr(runner, "graph_capturable", not sharded):
         graphed = graph_or_eager(eager, batches[0], True)  # whole step captured once into a hipGraph
     step = (lambda i: graphed.replay(batches[i % nb])) if graphed else (lambda i: eager(batches[i % nb].tensors))
     dt, sustained, step_stats = run_steps(step, args, tm)
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
+    if hasattr(runner, "check_overflow"):
+        runner.check_overflow()  # one host read, outside the timed regions: no request of the run was dropped
     if rank != 0:
         return finish({})
 

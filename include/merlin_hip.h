@@ -370,13 +370,19 @@ int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, f
  *   stack that request p back-propagates into);  counts[w] = requests for owner w (int64, device).
  * ids: HOST array of F device pointers; slots: HOST array. */
 int64_t mh_route_workspace_bytes(int64_t n, int32_t W);
+/* capacity == 0: dense send order (owner w's requests start at the sum of the counts before it; the exchange then needs
+ * the host-side counts).  capacity > 0: FIXED windows -- owner w's requests occupy send_keys[w*capacity ..), padded with
+ * key -1 / source row -1, so the all-to-all has equal, host-known splits: no host sync, the step replays from a hipGraph.
+ * A request beyond its owner's window is dropped (pos_of = -1) and overflow[0] |= 1 (device flag, may be NULL). */
 int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int64_t B, int32_t W,
-                       const int32_t* slots, int32_t F_total, int64_t* send_keys, int64_t* pos_of,
-                       int64_t* src_row, int64_t* counts, void* workspace, int64_t workspace_bytes,
+                       const int32_t* slots, int32_t F_total, int64_t capacity, int64_t* send_keys, int64_t* pos_of,
+                       int64_t* src_row, int64_t* counts, int32_t* overflow, void* workspace, int64_t workspace_bytes,
                        mh_stream_t stream);
-/* Owner side: rows[i] = base[key >> 40] + (key & (2^40 - 1)): row of the rank's concatenated local shards. */
-int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, int32_t F, int64_t* rows,
-                            mh_stream_t stream);
+/* Owner side: rows[i] = base[key >> 40] + (key & (2^40 - 1)): row of the rank's concatenated local shards; -1 (read as a
+ * zero row by the gather, skipped by the fused update) for padding keys (< 0) and for local rows >= shard_rows[f]
+ * (an id beyond the table's cardinality; shard_rows may be NULL = unchecked). */
+int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, const int64_t* shard_rows,
+                            int32_t F, int64_t* rows, mh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -45,8 +45,8 @@ SIGNATURES = {
     "mh_dense_optimizer_step_multi": (_i32, [_p, _p, _p, _p, _i32, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_eltwise": (_i32, [_i32, _p, _p, _p, _p, _i64, _p]),
     "mh_route_workspace_bytes": (_i64, [_i64, _i32]),
-    "mh_route_build": (_i32, [_p, _i32, _i32, _i64, _i32, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
-    "mh_route_local_rows": (_i32, [_p, _i64, _p, _i32, _p, _p]),
+    "mh_route_build": (_i32, [_p, _i32, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "mh_route_local_rows": (_i32, [_p, _i64, _p, _p, _i32, _p, _p]),
     "mh_dense_optimizer_step": (_i32, [_p, _p, _p, _i64, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_adam_tick": (_i32, [_p, _f32, _f32, _f32, _p, _p]),
     "mh_dlrm_interaction_fused_fwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),

@@ -73,11 +73,16 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const RouteArgs a, i
                                                             const int* __restrict__ scan,
                                                             int64_t* __restrict__ send_keys,
                                                             int64_t* __restrict__ pos_of,
-                                                            int64_t* __restrict__ src_row) {
+                                                            int64_t* __restrict__ src_row, int64_t cap,
+                                                            int* __restrict__ overflow) {
     __shared__ int run[MAX_W];         // slots of this tile already handed out, per owner
     __shared__ int wave_cnt[2][4][MAX_W];  // per-wave counts, double-buffered by iteration parity
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((int)threadIdx.x < W) run[threadIdx.x] = scan[(int64_t)threadIdx.x * ntiles + blockIdx.x];
+    // dense mode (cap == 0): owner w's requests start at the exclusive prefix scan[w][0]; fixed-capacity mode: at w * cap
+    if ((int)threadIdx.x < W) {
+        const int64_t first = scan[(int64_t)threadIdx.x * ntiles];
+        run[threadIdx.x] = scan[(int64_t)threadIdx.x * ntiles + blockIdx.x] - (cap > 0 ? (int)first : 0);
+    }
     const int64_t e0 = (int64_t)blockIdx.x * TILE;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int it = 0; it < TILE_IT; ++it) {
@@ -96,11 +101,22 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const RouteArgs a, i
         }
         __syncthreads();  // wave_cnt complete; run[] of the previous iteration visible
         if (owner >= 0) {
-            int p = run[owner] + rank;
+            int64_t p = run[owner] + rank;
             for (int wv = 0; wv < wave; ++wv) p += wave_cnt[it & 1][wv][owner];
-            send_keys[p] = ((int64_t)f << 40) | (id / W);
-            pos_of[e] = p;
-            src_row[p] = b * F_total + a.slot[f];
+            if (cap > 0) {
+                if (p >= cap) {  // this owner's fixed window is full: the request is dropped (zero row, no update)
+                    pos_of[e] = -1;
+                    if (overflow) atomicOr(overflow, 1);
+                    p = -1;
+                } else {
+                    p += (int64_t)owner * cap;
+                }
+            }
+            if (p >= 0) {
+                send_keys[p] = ((int64_t)f << 40) | (id / W);
+                pos_of[e] = p;
+                src_row[p] = b * F_total + a.slot[f];
+            }
         }
         __syncthreads();
         if ((int)threadIdx.x < W)
@@ -109,19 +125,19 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const RouteArgs a, i
     }
 }
 
+// rows[i] = base[f] + local row, or -1 (a row the gather reads as zeros and the fused update skips) for the padding
+// keys of the fixed-capacity exchange (key < 0) and for local rows outside feature f's shard (an id >= the table's
+// cardinality must not reach the NEXT feature's shard of the concatenated buffer)
 __global__ void route_local_rows_kernel(const int64_t* __restrict__ keys, int64_t n,
-                                        const int64_t* __restrict__ base, int F, int64_t* __restrict__ rows,
-                                        int* __restrict__ bad) {
+                                        const int64_t* __restrict__ base, const int64_t* __restrict__ shard_rows,
+                                        int F, int64_t* __restrict__ rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t k = keys[i];
     const int f = (int)(k >> 40);
-    if (f < 0 || f >= F) {
-        rows[i] = 0;
-        if (bad) *bad = 1;
-        return;
-    }
-    rows[i] = base[f] + (k & ((1ll << 40) - 1));
+    const int64_t r = k & ((1ll << 40) - 1);
+    const bool ok = k >= 0 && f < F && (!shard_rows || r < shard_rows[f]);
+    rows[i] = ok ? base[f] + r : -1;
 }
 
 // exclusive prefix of the (owner, tile) histogram, one workgroup (the sequence is W * ntiles ints: a few thousand)
@@ -179,8 +195,8 @@ int64_t mh_route_workspace_bytes(int64_t n, int32_t W) {
 }
 
 int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int64_t B, int32_t W,
-                       const int32_t* slots, int32_t F_total, int64_t* send_keys, int64_t* pos_of,
-                       int64_t* src_row, int64_t* counts, void* workspace, int64_t workspace_bytes,
+                       const int32_t* slots, int32_t F_total, int64_t capacity, int64_t* send_keys, int64_t* pos_of,
+                       int64_t* src_row, int64_t* counts, int32_t* overflow, void* workspace, int64_t workspace_bytes,
                        mh_stream_t stream) {
     MH_REQUIRE(ids && slots && counts, "mh_route_build: null argument");
     MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_route_build: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
@@ -196,7 +212,15 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
         return MH_OK;
     }
     MH_REQUIRE(send_keys && pos_of && src_row && workspace, "mh_route_build: null output");
+    MH_REQUIRE(capacity >= 0, "mh_route_build: negative capacity");
     const int64_t n = B * F;
+    if (capacity > 0) {  // padding slots: key -1 (no row), source row -1 (zero gradient)
+        if (hipMemsetAsync(send_keys, 0xff, sizeof(int64_t) * (size_t)W * capacity, s) != hipSuccess ||
+            hipMemsetAsync(src_row, 0xff, sizeof(int64_t) * (size_t)W * capacity, s) != hipSuccess) {
+            mh_set_error("mh_route_build: memset failed");
+            return MH_ERR_LAUNCH;
+        }
+    }
     MH_REQUIRE(n < (1ll << 31), "mh_route_build: F*B must be < 2^31");
     RouteWs L;
     route_ws(n, W, &L);
@@ -222,21 +246,21 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
     hipLaunchKernelGGL(route_counts_kernel, dim3(1), dim3(64), 0, s, scan, L.ntiles, W, n, counts);
     if (ids_dtype == MH_I32)
         hipLaunchKernelGGL(route_scatter_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
-                           send_keys, pos_of, src_row);
+                           send_keys, pos_of, src_row, capacity, overflow);
     else
         hipLaunchKernelGGL(route_scatter_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
-                           send_keys, pos_of, src_row);
+                           send_keys, pos_of, src_row, capacity, overflow);
     MH_CHECK_LAUNCH("mh_route_build");
     return MH_OK;
 }
 
-int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, int32_t F, int64_t* rows,
-                            mh_stream_t stream) {
+int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, const int64_t* shard_rows,
+                            int32_t F, int64_t* rows, mh_stream_t stream) {
     if (n <= 0) return MH_OK;
     MH_REQUIRE(recv_keys && base && rows, "mh_route_local_rows: null argument");
     MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_route_local_rows: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
     hipLaunchKernelGGL(route_local_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream),
-                       recv_keys, n, base, F, rows, (int*)nullptr);
+                       recv_keys, n, base, shard_rows, F, rows);
     MH_CHECK_LAUNCH("mh_route_local_rows");
     return MH_OK;
 }

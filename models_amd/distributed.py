@@ -49,6 +49,29 @@ def shard_table(full: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
     return full[rank::world_size].contiguous()
 
 
+class sharded_tables:
+    """``with distributed.sharded_tables(threshold): model = mm.DLRMModel(...)``: every EmbeddingTable with at least
+    ``threshold`` rows is allocated as this rank's row shard only (rows ``rank, rank + W, ...``; same values as the
+    unsharded table would hold).  Wrap the model in ``DistributedDLRM`` / ``DistributedModel`` afterwards."""
+
+    def __init__(self, threshold: int = 200_000, force: bool = False):
+        self.threshold, self.force = int(threshold), force
+
+    def __enter__(self):
+        from . import inputs
+
+        rank, W = world()
+        self._prev = inputs._SHARD_CTX
+        inputs._SHARD_CTX = (rank, W, self.threshold) if (W > 1 or self.force) else None
+        return self
+
+    def __exit__(self, *exc):
+        from . import inputs
+
+        inputs._SHARD_CTX = self._prev
+        return False
+
+
 class Route:
     """Send ``payload[i]`` (int64) to rank ``owner[i]``: permutation into owner order + per-peer counts.
     ONE host sync per route (RCCL needs host-side split sizes): send and receive counts travel together."""
@@ -129,60 +152,129 @@ class ShardedEmbeddingTable:
         self.update_fn(self.table, self.state, self._route.recv_rows, g)
 
 
-def route_build_torch(ids: Sequence[torch.Tensor], world_size: int, slots: Sequence[int], n_slots: int):
+def route_build_torch(ids: Sequence[torch.Tensor], world_size: int, slots: Sequence[int], n_slots: int,
+                      capacity: int = 0, overflow: Optional[torch.Tensor] = None):
     """Framework-op statement of ``mh_route_build`` (same contract, any device): what the gloo tests inject and
-    what the HIP kernel is checked against.  Entry e = f*B + b; stable order within an owner."""
+    what the HIP kernel is checked against.  Entry e = f*B + b; stable order within an owner.  ``capacity`` > 0:
+    fixed windows of that many slots per owner, padding -1, dropped requests ``pos_of`` = -1 (``overflow`` |= 1)."""
     idm = torch.stack([i.reshape(-1).to(torch.int64) for i in ids])  # [F, B]
     F, B = idm.shape
     owner = torch.remainder(idm, world_size).reshape(-1)
     order = torch.argsort(owner, stable=True)
     feat = torch.arange(F, device=idm.device, dtype=torch.int64).unsqueeze(1)
     key = ((feat << 40) | torch.div(idm, world_size, rounding_mode="floor")).reshape(-1)
-    pos_of = torch.empty_like(order)
-    pos_of[order] = torch.arange(order.numel(), device=order.device, dtype=order.dtype)
     b = torch.arange(B, device=idm.device, dtype=torch.int64).unsqueeze(0)
     src = (b * n_slots + torch.tensor(list(slots), device=idm.device, dtype=torch.int64).unsqueeze(1)).reshape(-1)
-    return key[order], pos_of.reshape(F, B), src[order], torch.bincount(owner, minlength=world_size)
+    counts = torch.bincount(owner, minlength=world_size)
+    n = order.numel()
+    if not capacity:
+        pos_of = torch.empty_like(order)
+        pos_of[order] = torch.arange(n, device=order.device, dtype=order.dtype)
+        return key[order], pos_of.reshape(F, B), src[order], counts
+    first = torch.cumsum(counts, 0) - counts                       # first dense slot of every owner
+    so = owner[order]
+    rank_in = torch.arange(n, device=order.device, dtype=torch.int64) - first[so]
+    keep = rank_in < capacity
+    p = so * capacity + rank_in
+    send_keys = torch.full((world_size * capacity,), -1, dtype=torch.int64, device=idm.device)
+    src_row = torch.full((world_size * capacity,), -1, dtype=torch.int64, device=idm.device)
+    send_keys[p[keep]] = key[order][keep]
+    src_row[p[keep]] = src[order][keep]
+    pos_of = torch.empty_like(order)
+    pos_of[order] = torch.where(keep, p, torch.full_like(p, -1))
+    if overflow is not None and n:
+        overflow |= (~keep).any().to(overflow.dtype)
+    return send_keys, pos_of.reshape(F, B), src_row, counts
 
 
-def route_local_rows_torch(recv_keys: torch.Tensor, base: torch.Tensor) -> torch.Tensor:
-    return base[recv_keys >> 40] + (recv_keys & ((1 << 40) - 1))
+def route_local_rows_torch(recv_keys: torch.Tensor, base: torch.Tensor, shard_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    f = (recv_keys >> 40).clamp(0, base.numel() - 1)
+    r = recv_keys & ((1 << 40) - 1)
+    ok = (recv_keys >= 0) & ((recv_keys >> 40) < base.numel())
+    if shard_rows is not None:
+        ok = ok & (r < shard_rows[f])
+    return torch.where(ok, base[f] + r, torch.full_like(r, -1))
 
 
 class ShardedEmbeddingGroup:
-    """ALL row-sharded features of a model behind ONE route per step: the local shards live back to back in
-    one [sum V_local, D] buffer, a request is the int64 key (feature << 40 | local_row), the owner turns it
-    into a row of the concatenated buffer -> one gather launch, one fused update launch, three all-to-alls
-    (ids, rows, row-gradients) and one host sync per step regardless of the number of sharded tables.
+    """ALL row-sharded features of a model behind ONE route per step: the local shards of the DISTINCT tables live
+    back to back in one [sum V_local, D] buffer, a request is the int64 key (feature << 40 | local_row), the owner
+    turns it into a row of the concatenated buffer -> one gather launch, one fused update launch and three
+    all-to-alls (ids, rows, row-gradients) per step regardless of the number of sharded tables.
 
-    ``route_fn`` / ``rows_fn`` build the send order and the owner-side rows: ``ops.route_build`` /
-    ``ops.route_local_rows`` (HIP) in production, the framework-op statements above in the gloo tests."""
+    Two exchange modes:
+      * dense (``capacity`` None): every rank sends exactly its requests; RCCL needs the per-peer counts on the host:
+        ONE host sync per step.  Used for the first ``calibration`` steps, which record the largest per-owner count;
+      * fixed capacity (after ``freeze_capacity``): every (sender, owner) window has ``capacity`` slots, padded with
+        key -1 -> equal, host-known splits: no host sync, the whole step is a fixed launch sequence (hipGraph replay).
+        A request beyond its window is dropped and sets the device flag ``overflow`` (``check_overflow()`` raises).
 
-    def __init__(self, full_tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None,
-                 route_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None):
+    ``tables``: the distinct tables, full (``presharded=False``: sliced here) or already the local shards;
+    ``feature_table[f]``: index into ``tables`` of feature f (features sharing a table share its shard).
+    ``route_fn`` / ``rows_fn``: ``ops.route_build`` / ``ops.route_local_rows`` (HIP) in production, the framework-op
+    statements above in the gloo tests."""
+
+    def __init__(self, tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None,
+                 route_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None,
+                 feature_table: Optional[Sequence[int]] = None, presharded: bool = False,
+                 global_rows: Optional[Sequence[int]] = None, capacity_factor: float = 1.25, calibration: int = 2):
         self.rank, self.world_size = world()
         self.group = group
         self.gather_fn, self.update_fn = gather_fn, update_fn
         self.route_fn = route_fn or route_build_torch
         self.rows_fn = rows_fn or route_local_rows_torch
-        shards = [shard_table(t, self.rank, self.world_size) for t in full_tables]
-        self.global_rows = [t.shape[0] for t in full_tables]
+        W = self.world_size
+        shards = list(tables) if presharded else [shard_table(t, self.rank, W) for t in tables]
+        self.global_rows = list(global_rows) if global_rows is not None else [t.shape[0] for t in tables]
         sizes = [sh.shape[0] for sh in shards]
-        D = full_tables[0].shape[1]
-        self.local = torch.empty((max(sum(sizes), 1), D), dtype=torch.float32, device=full_tables[0].device)
-        base, o = [], 0
+        D = tables[0].shape[1]
+        dev = tables[0].device
+        self.local = torch.empty((max(sum(sizes), 1), D), dtype=torch.float32, device=dev)
+        tbase, o = [], 0
         self.views: List[torch.Tensor] = []
         for sh, n in zip(shards, sizes):
             self.local[o:o + n] = sh
             self.views.append(self.local[o:o + n])
-            base.append(o)
+            tbase.append(o)
             o += n
-        self.base = torch.tensor(base, dtype=torch.int64, device=self.local.device)
+        ft = list(range(len(tables))) if feature_table is None else list(feature_table)
+        self.feature_table = ft
+        self.base = torch.tensor([tbase[t] for t in ft], dtype=torch.int64, device=dev)          # per FEATURE
+        self.shard_rows = torch.tensor([sizes[t] for t in ft], dtype=torch.int64, device=dev)    # per FEATURE
         self.state: Optional[torch.Tensor] = None
         self.state2: Optional[torch.Tensor] = None
         self._rows: Optional[torch.Tensor] = None
+        self.capacity_factor = float(capacity_factor)
+        self.calibration = int(calibration)
+        self.capacity: Optional[int] = None          # slots per (sender, owner) window once frozen
+        self._steps, self._max_count = 0, 0
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def _a2a(self, out, inp, out_splits, in_splits, async_op: bool = False):
+    # ---- capacity management ------------------------------------------------------------------------------------
+    def freeze_capacity(self, n_requests: int, capacity: Optional[int] = None) -> int:
+        """Switch to the fixed-capacity exchange.  Default window: the largest per-owner count seen during calibration
+        (maximum over the ranks) x ``capacity_factor``; one rank needs no slack (its window holds every request)."""
+        W = self.world_size
+        if capacity is None:
+            if W == 1:
+                capacity = n_requests
+            else:
+                seen = self._max_count if self._max_count else (n_requests + W - 1) // W
+                capacity = min(n_requests, int(seen * self.capacity_factor) + 1)
+        self.capacity = (max(int(capacity), 1) + 63) // 64 * 64
+        return self.capacity
+
+    def check_overflow(self) -> None:
+        """One host read of the overflow flag (call it outside timed regions / at epoch ends)."""
+        if int(self.overflow.item()) != 0:
+            raise RuntimeError(f"row-sharded exchange: a per-owner window of {self.capacity} requests overflowed "
+                               "(requests were dropped); raise capacity_factor or recalibrate")
+
+    @property
+    def graph_capturable(self) -> bool:
+        return self.capacity is not None
+
+    def _a2a(self, out, inp, out_splits=None, in_splits=None, async_op: bool = False):
         """Returns a work handle (``.wait()`` orders the CURRENT stream after the exchange) or None."""
         if self.world_size > 1:
             return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
@@ -198,39 +290,63 @@ class ShardedEmbeddingGroup:
         ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``."""
         W = self.world_size
         F_sh, B = len(ids), ids[0].numel()
+        n = F_sh * B
         if scatter_into is not None:
             stacked, slots, scatter_fn = scatter_into
             n_slots = stacked.shape[1]
         else:
             slots, n_slots = list(range(F_sh)), F_sh
-        send_keys, pos_of, src_row, send_counts = self.route_fn(ids, W, slots, n_slots)
-        recv_counts = torch.empty_like(send_counts)
-        if W > 1:
-            dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        else:
-            recv_counts.copy_(send_counts)
-        both = torch.stack([send_counts, recv_counts]).tolist()  # the one host sync of the step
-        self._send_counts, self._recv_counts = both[0], both[1]
-        self._pos_of, self._src_row, self._n = pos_of, src_row, F_sh * B
-        recv_keys = torch.empty(sum(self._recv_counts), dtype=torch.int64, device=send_keys.device)
+        if self.capacity is None and self.calibration <= 0:
+            self.freeze_capacity(n)
+        if self.capacity is not None:   # ---- fixed windows: no host sync ----
+            cap = self.capacity
+            send_keys, pos_of, src_row, _ = self.route_fn(ids, W, slots, n_slots, cap, self.overflow)
+            self._send_counts = self._recv_counts = None
+            n_recv = W * cap
+        else:                           # ---- dense: per-peer counts on the host (calibration steps) ----
+            send_keys, pos_of, src_row, send_counts = self.route_fn(ids, W, slots, n_slots)
+            recv_counts = torch.empty_like(send_counts)
+            if W > 1:
+                dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+            else:
+                recv_counts.copy_(send_counts)
+            both = torch.stack([send_counts, recv_counts]).tolist()  # the one host sync of a calibration step
+            self._send_counts, self._recv_counts = both[0], both[1]
+            n_recv = sum(self._recv_counts)
+            self._max_count = max(self._max_count, max(self._send_counts), max(self._recv_counts))
+            self._steps += 1
+            if self._steps >= self.calibration:
+                if W > 1:  # every rank must choose the same window
+                    m = torch.tensor([self._max_count], dtype=torch.int64, device=send_keys.device)
+                    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+                    self._max_count = int(m.item())
+                self._freeze_after = n
+        self._pos_of, self._src_row, self._n_send = pos_of, src_row, send_keys.numel()
+        self._fwd_layout = (list(slots), int(n_slots))
+        recv_keys = torch.empty(n_recv, dtype=torch.int64, device=send_keys.device)
         self._a2a(recv_keys, send_keys, self._recv_counts, self._send_counts)
-        self._rows = self.rows_fn(recv_keys, self.base)  # rows of the concatenated local buffer
+        self._rows = self.rows_fn(recv_keys, self.base, self.shard_rows)  # rows of the concatenated local buffer (-1: none)
         rows = self.gather_fn(self.local, self._rows)
         D = rows.shape[1]
-        back = torch.empty((self._n, D), dtype=rows.dtype, device=rows.device)
+        back = torch.empty((self._n_send, D), dtype=rows.dtype, device=rows.device)
         rows = rows.contiguous()
         # the row exchange runs on RCCL's stream: whatever the caller enqueues before lookup_end() overlaps it
         work = self._a2a(back, rows, self._send_counts, self._recv_counts, async_op=True)
         self._pending_lookup = (work, back, rows, scatter_into, F_sh, B)
 
-    def lookup_end(self) -> Optional[torch.Tensor]:
+    def lookup_end(self, scatter: Optional[Callable] = None) -> Optional[torch.Tensor]:
+        """``scatter(back, [pos_of[f] ...])``: the caller places the returned rows itself (e.g. into a concat buffer)."""
         work, back, _rows_alive, scatter_into, F_sh, B = self._pending_lookup
         self._pending_lookup = None
         if work is not None:
             work.wait()
         pos_of, D = self._pos_of, back.shape[1]
+        if scatter is not None:
+            scatter(back, [pos_of[f] for f in range(F_sh)])
+            return None
         if scatter_into is None:
-            return back[pos_of.reshape(-1)].reshape(F_sh, B, D)
+            out = self.gather_fn(back, pos_of.reshape(-1))  # dropped requests (pos_of -1) read as zero rows
+            return out.reshape(F_sh, B, D)
         stacked, slots, scatter_fn = scatter_into
         # returned rows arrive in owner order; request (f, b) sits at pos_of[f, b]: ONE multi-"table" gather
         # writes them straight into their stack slots (no un-permute pass, no index_put)
@@ -244,16 +360,31 @@ class ShardedEmbeddingGroup:
     def backward_begin(self, grad: torch.Tensor, from_stacked=None) -> None:
         """``grad`` [F_sh, B, D] in the order of ``lookup``; or ``from_stacked = (dstack [B, F, D], slots,
         gather_fn)``: the gradient rows are pulled out of dstack already in owner order by one gather launch
-        (``src_row`` of the route).  Starts the gradient exchange; ``backward_end`` applies the fused update."""
+        (``src_row`` of the route; padding slots read a zero row).  Starts the gradient exchange; ``backward_end``
+        applies the fused update."""
         if from_stacked is None:
             D = grad.shape[-1]
-            send = torch.empty((self._n, D), dtype=grad.dtype, device=grad.device)
-            send[self._pos_of.reshape(-1)] = grad.reshape(-1, D)
+            flat = grad.reshape(-1, D)
+            send = torch.zeros((self._n_send, D), dtype=grad.dtype, device=grad.device)
+            pos = self._pos_of.reshape(-1)
+            keep = pos >= 0
+            send[pos[keep]] = flat[keep]
         else:
             dstack, slots, gather_fn = from_stacked
             B, F, D = dstack.shape
-            send = gather_fn(dstack.reshape(B * F, D), self._src_row)  # [n, D] in owner order
-        g = torch.empty((sum(self._recv_counts), D), dtype=send.dtype, device=send.device)
+            src = self._src_row
+            fslots, fn = self._fwd_layout
+            if list(slots) != fslots or F != fn:
+                # the gradient stack is laid out differently from the forward stack the route was built for:
+                # src = b * fn + forward slot  ->  b * F + backward slot (padding stays -1)
+                remap = torch.full((fn,), -1, dtype=torch.int64, device=src.device)
+                remap[torch.tensor(fslots, dtype=torch.int64, device=src.device)] = torch.tensor(
+                    list(slots), dtype=torch.int64, device=src.device)
+                safe = src.clamp(min=0)
+                src = torch.where(src >= 0, torch.div(safe, fn, rounding_mode="floor") * F + remap[safe % fn], src)
+            send = gather_fn(dstack.reshape(B * F, D), src)  # [n_send, D] in owner order
+        n_recv = self._rows.numel()
+        g = torch.empty((n_recv, D), dtype=send.dtype, device=send.device)
         work = self._a2a(g, send, self._recv_counts, self._send_counts, async_op=True)
         self._pending_bwd = (work, g, send)
 
@@ -263,6 +394,10 @@ class ShardedEmbeddingGroup:
         if work is not None:
             work.wait()
         self.update_fn(self.local, self.state, self._rows, g)
+        fa = getattr(self, "_freeze_after", None)
+        if fa is not None:  # calibration done: the next step runs on fixed windows
+            self._freeze_after = None
+            self.freeze_capacity(fa)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -311,48 +446,148 @@ def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group=Non
 # ------------------------------------------------------------------------------------------------
 # DLRM data-parallel / model-parallel hybrid step
 # ------------------------------------------------------------------------------------------------
+def _hip_group_fns(owner):
+    """gather / fused-update callables over the concatenated local shards (HIP ops); ``owner.model.optimizer`` and
+    ``owner.group_sh`` are read at call time."""
+    from . import ops
+
+    def gather_fn(table, rows):
+        return ops.embedding_gather([table], [rows])[:, 0]
+
+    def update_fn(table, state, rows, grads):
+        opt = owner.model.optimizer
+        D = table.shape[1]
+        g3 = grads.reshape(grads.shape[0], 1, D).contiguous()
+        st2 = owner.group_sh.state2  # LazyAdam second moment of the local shards
+        ops.embedding_gather_backward([table], None if state is None else [state], [rows], g3, [0], opt.name,
+                                      opt.learning_rate, opt.epsilon, None if st2 is None else [st2],
+                                      opt.beta_1, opt.beta_2, opt.lr_device)
+
+    return gather_fn, update_fn
+
+
+def _build_group(owner, emb, names, group, capacity_factor, calibration):
+    """One ShardedEmbeddingGroup over the DISTINCT tables of the sharded features ``names`` of an EmbeddingsBlock
+    (features sharing a table -- same Parameter -- share one shard); rebinds every table to a view of its shard."""
+    from . import ops
+
+    tabs, index, ft = [], {}, []
+    for n in names:
+        t = emb.feature_table[n]
+        if id(t) not in index:
+            index[id(t)] = len(tabs)
+            tabs.append(t)
+        ft.append(index[id(t)])
+    gather_fn, update_fn = _hip_group_fns(owner)
+    pre = [getattr(t, "shard", None) is not None for t in tabs]
+    if any(pre) and not all(pre):
+        raise ValueError("either every sharded table is built as a shard (distributed.sharded_tables) or none is")
+    grp = ShardedEmbeddingGroup([t.table.data for t in tabs], gather_fn, update_fn, group, route_fn=ops.route_build,
+                                rows_fn=ops.route_local_rows, feature_table=ft, presharded=all(pre) and len(pre) > 0,
+                                global_rows=[t.input_dim for t in tabs], capacity_factor=capacity_factor,
+                                calibration=calibration)
+    for t, view in zip(tabs, grp.views):
+        t.table.data = view  # drop the replicated copy; keep a view of the local shard
+        t.shard = (grp.rank, grp.world_size)
+    return grp, tabs
+
+
 class DistributedDLRM:
     """Wraps an ``mm.DLRMModel`` built on every rank: tables with >= ``shard_threshold`` rows keep only
-    their local row shard (all-to-all lookup), the rest stay replicated."""
+    their local row shard (all-to-all lookup), the rest stay replicated.  Build the model under
+    ``distributed.sharded_tables(threshold)`` and the large tables are ALLOCATED as shards (a 100M-row table is never
+    materialised on one GPU).  After ``calibration`` steps the exchange runs on fixed windows with no host sync
+    (``graph_capturable``); one rank (``force_shard``) uses them from the first step."""
 
-    def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False):
-        from . import ops
-
+    def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False,
+                 capacity_factor: float = 1.25, calibration: int = 2):
         self.model = model
         self.body = model.body
         self.group = group
         self.rank, self.world_size = world()
         emb = self.body.embeddings
-        self.sharded: Dict[str, ShardedEmbeddingTable] = {}
-        D = self.body.dim
-
-        def gather_fn(table, rows):
-            return ops.embedding_gather([table], [rows])[:, 0]
-
-        def update_fn(table, state, rows, grads, _self=self):
-            opt = _self.model.optimizer
-            g3 = grads.reshape(grads.shape[0], 1, D).contiguous()
-            st2 = _self.group_sh.state2  # LazyAdam second moment of the local shards
-            ops.embedding_gather_backward([table], None if state is None else [state], [rows], g3, [0], opt.name,
-                                          opt.learning_rate, opt.epsilon, None if st2 is None else [st2],
-                                          opt.beta_1, opt.beta_2, opt.lr_device)
-
-        names = [n for n in self.body.cat_names
-                 if (self.world_size > 1 or force_shard) and emb.feature_table[n].input_dim >= shard_threshold]
-        self.sharded: Dict[str, torch.Tensor] = {}
+        active = self.world_size > 1 or force_shard
+        names = [n for n in self.body.cat_names if active and (emb.feature_table[n].input_dim >= shard_threshold
+                                                               or getattr(emb.feature_table[n], "shard", None) is not None)]
         self.group_sh: Optional[ShardedEmbeddingGroup] = None
+        self.sharded_tables: List = []
         if names:
-            self.group_sh = ShardedEmbeddingGroup([emb.feature_table[n].table.data for n in names], gather_fn, update_fn, group,
-                                                  route_fn=ops.route_build, rows_fn=ops.route_local_rows)
-            for n, view in zip(names, self.group_sh.views):
-                emb.feature_table[n].table.data = view  # drop the replicated copy; keep a view of the local shard
-                self.sharded[n] = view
+            self.group_sh, self.sharded_tables = _build_group(self, emb, names, group, capacity_factor,
+                                                              0 if self.world_size == 1 else calibration)
         self.sharded_names = names
         self._bucket: Optional[torch.Tensor] = None
-        self.replicated = [n for n in self.body.cat_names if n not in self.sharded]
+        self.replicated = [n for n in self.body.cat_names if n not in names]
+        rep_tabs, seen = [], set()
+        for n in self.replicated:  # distinct replicated tables (shared tables appear once)
+            t = emb.feature_table[n].table
+            if id(t) not in seen:
+                seen.add(id(t))
+                rep_tabs.append(t)
+        self.rep_tabs = rep_tabs
         dense = [p.data for p in model.parameters() if not p.sparse]
-        rep = [emb.feature_table[n].table.data for n in self.replicated]
-        broadcast_parameters(dense + rep, 0, group)
+        broadcast_parameters(dense + [t.data for t in rep_tabs], 0, group)
+
+    @property
+    def sharded(self) -> Dict[str, torch.Tensor]:
+        """name -> local shard of every sharded feature's table."""
+        emb = self.body.embeddings
+        return {n: emb.feature_table[n].table.data for n in self.sharded_names}
+
+    @property
+    def graph_capturable(self) -> bool:
+        """True once every per-step collective has host-known sizes (fixed windows).  At more than one rank the capture
+        of RCCL collectives into a hipGraph is opt-in (MERLIN_HIP_GRAPH_DISTRIBUTED=1)."""
+        import os
+
+        ok = self.group_sh is None or self.group_sh.graph_capturable
+        return ok and (self.world_size == 1 or os.environ.get("MERLIN_HIP_GRAPH_DISTRIBUTED") == "1")
+
+    def check_overflow(self) -> None:
+        if self.group_sh is not None:
+            self.group_sh.check_overflow()
+
+    # ---- checkpoint / resume: the row shards and their optimizer state are per rank -----------------------------------
+    def save_weights(self, path) -> None:
+        """Rank 0 writes the replicated part (``Model.save_weights`` layout, sharded tables left out) to ``path``; every
+        rank writes its shards and their optimizer state to ``path.shard<rank>of<W>.npz``."""
+        import numpy as np
+
+        path = str(path)
+        shard_ids = {id(t.table) for t in self.sharded_tables}
+        if self.rank == 0:
+            self.model.save_weights(path, skip=shard_ids)
+        arrays = {}
+        gs = self.group_sh
+        if gs is not None:
+            arrays["local"] = gs.local.detach().cpu().numpy()
+            if gs.state is not None:
+                arrays["state"] = gs.state.detach().cpu().numpy()
+            if gs.state2 is not None:
+                arrays["state2"] = gs.state2.detach().cpu().numpy()
+        np.savez(f"{path}.shard{self.rank}of{self.world_size}.npz", **arrays)
+        if self.world_size > 1:
+            dist.barrier(group=self.group)
+
+    def load_weights(self, path) -> None:
+        """Inverse of ``save_weights`` at the SAME world size; values are copied INTO the live tensors, so a captured
+        hipGraph keeps replaying on the restored state."""
+        import numpy as np
+
+        path = str(path)
+        shard_ids = {id(t.table) for t in self.sharded_tables}
+        self.model.load_weights(path if path.endswith(".npz") else path + ".npz", skip=shard_ids)
+        z = np.load(f"{path}.shard{self.rank}of{self.world_size}.npz")
+        gs = self.group_sh
+        if gs is not None:
+            gs.local.copy_(torch.from_numpy(z["local"]).to(gs.local.device))
+            for key in ("state", "state2"):
+                if key in z.files:
+                    cur = getattr(gs, key)
+                    val = torch.from_numpy(z[key]).to(gs.local.device)
+                    if cur is None:
+                        setattr(gs, key, val)
+                    else:
+                        cur.copy_(val)
 
     # forward of the DLRM body with sharded lookups
     def forward_body(self, inputs):
@@ -442,7 +677,7 @@ class DistributedDLRM:
             # 2 + 3. ONE persistent flat bucket [MLP / head gradients | dense [V, D] gradients of the replicated
             #    tables]: the table part is zeroed by one fill and accumulated by the fused backward (SGD, lr = -1),
             #    the MLP part is packed by one cat; after the in-place reduction the gradients are VIEWS of the bucket
-            rep_tabs = [emb.feature_table[n].table for n in self.replicated]
+            rep_tabs = self.rep_tabs  # DISTINCT replicated tables: a shared table has one gradient and one update
             dense = [q for q in model.parameters() if not q.sparse and q.grad is not None]
             n_dense = sum(q.grad.numel() for q in dense)
             n_rep = sum(t.data.numel() for t in rep_tabs)
@@ -451,13 +686,16 @@ class DistributedDLRM:
             if self._bucket is None or self._bucket.numel() != total:
                 self._bucket = torch.zeros(total, dtype=torch.float32, device=dstack.device)
             bucket = self._bucket
-            rep_grads, o = [], n_head
+            rep_grads, o, grad_of = [], n_head, {}
             for t in rep_tabs:
                 rep_grads.append(bucket[o:o + t.data.numel()].view_as(t.data))
+                grad_of[id(t)] = rep_grads[-1]
                 o += t.data.numel()
             if rep_tabs:
                 bucket[n_head:n_head + n_rep].zero_()
-                ops.embedding_gather_backward(rep_grads, None, [x[n] for n in self.replicated], dstack,
+                # per FEATURE: features sharing a table pass the same gradient buffer and are summed into it
+                ops.embedding_gather_backward([grad_of[id(emb.feature_table[n].table)] for n in self.replicated], None,
+                                              [x[n] for n in self.replicated], dstack,
                                               [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
             ops.SIDE.join()  # the dW / db GEMMs ran on their side stream: the bucket below reads them
         # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
@@ -476,3 +714,301 @@ class DistributedDLRM:
             t.grad = g
         ops.dense_optimizer_step_multi(opt, dense + rep_tabs)  # one launch per 64 tensors
         return loss
+
+
+# ------------------------------------------------------------------------------------------------
+# generic data-parallel wrapper: any RankingModel / RetrievalModel over EmbeddingsBlocks (TwoTower C3, DCN-v2 C5)
+# ------------------------------------------------------------------------------------------------
+class _ShardedEmbeddings:
+    """Installs the row-sharded exchange on ONE EmbeddingsBlock by replacing two of its methods on the instance:
+    ``gather_into`` (forward: sharded features arrive through the group's all-to-all, the rest by the local gather)
+    and ``_apply_sparse_now`` (backward: sharded gradient rows go to their owners; gradients of replicated tables are
+    accumulated as dense [V, D] buffers inside the owner's flat bucket)."""
+
+    def __init__(self, owner, emb, names, group, capacity_factor, calibration):
+        from .inputs import EmbeddingsBlock
+
+        self.owner, self.emb = owner, emb
+        self.groups: Dict[int, Tuple[ShardedEmbeddingGroup, List[str]]] = {}
+        by_dim: Dict[int, List[str]] = {}
+        for n in names:
+            by_dim.setdefault(emb.feature_table[n].dim, []).append(n)
+        self.sharded_tables = []
+        for d, ns in by_dim.items():
+            holder = type("_G", (), {})()  # update_fn reads .model / .group_sh of its owner: one holder per group
+            holder.model = owner.model
+            grp, tabs = _build_group(holder, emb, ns, group, capacity_factor, calibration)
+            holder.group_sh = grp
+            self.groups[d] = (grp, ns)
+            self.sharded_tables += tabs
+        self.sharded_names = set(names)
+        self.replicated = [n for n in emb.feature_table if n not in self.sharded_names]
+        self._orig_gather_into = EmbeddingsBlock.gather_into
+        self._orig_gather_concat = EmbeddingsBlock.gather_concat
+        emb.gather_into = self.gather_into
+        emb.gather_concat = self.gather_concat
+        emb._apply_sparse_now = self.apply_sparse_now
+        self._active: List[ShardedEmbeddingGroup] = []
+
+    def gather_into(self, inputs, out, slots) -> None:
+        from . import ops
+
+        emb = self.emb
+        names = [n for n in emb.feature_names if n in inputs]
+        D = out.shape[2]
+        grp, gnames = self.groups.get(D, (None, []))
+        mine = [n for n in gnames if n in names]  # the GROUP's feature order: request keys carry the feature index
+        if mine and len(mine) != len(gnames):
+            raise ValueError(f"row-sharded features {gnames} must be looked up together (got {mine})")
+        if mine:
+            for n in mine:
+                if not emb._is_onehot(inputs[n]):
+                    raise NotImplementedError(f"row-sharded table of {n!r}: list / ragged inputs need a replicated table")
+
+            def scatter_fn(tabs, idx, o, sl):
+                ops.embedding_gather(tabs, idx, out=o, out_slot=sl)
+
+            grp.lookup_begin([inputs[n].reshape(-1) for n in mine], scatter_into=(out, [slots[n] for n in mine], scatter_fn))
+        rest = {n: inputs[n] for n in names if n not in mine}
+        if rest:
+            self._orig_gather_into(emb, rest, out, slots)  # the replicated-table gather overlaps the row all-to-all
+        if mine:
+            grp.lookup_end()
+        last = dict(getattr(emb, "_last_all", {})) if getattr(emb, "_last_step", None) is self.owner._step_token else {}
+        last.update({n: inputs[n] for n in names})
+        emb._last_all, emb._last_step = last, self.owner._step_token
+        emb._last = last
+
+    def gather_concat(self, inputs, names, buf, offsets) -> None:
+        """Concat layout (InputBlockV2): sharded features through their groups, the rest by the local gather."""
+        from . import ops
+
+        emb = self.emb
+        begun = []
+        for d, (grp, gnames) in self.groups.items():
+            mine = [n for n in gnames if n in names]  # the GROUP's feature order
+            if mine and len(mine) != len(gnames):
+                raise ValueError(f"row-sharded features {gnames} must be looked up together (got {mine})")
+            if mine:
+                grp.lookup_begin([inputs[n].reshape(-1) for n in mine])
+                begun.append((grp, mine))
+        taken = {n for _, mine in begun for n in mine}
+        rest = [n for n in names if n not in taken]
+        if rest:
+            self._orig_gather_concat(emb, inputs, rest, buf, offsets)
+        for grp, mine in begun:
+            grp.lookup_end(scatter=lambda back, pos, mine=mine: ops.embedding_gather(
+                [back] * len(mine), pos, out=buf, out_offset=[offsets[n] for n in mine]))
+        emb._last = {n: inputs[n] for n in names}
+
+    def apply_sparse_now(self, opt, grad, offsets) -> None:
+        from . import ops
+
+        emb = self.emb
+        g2 = grad.reshape(grad.shape[0], -1)
+        emb._apply_batch_regularization(g2, offsets)
+        B, stride = g2.shape
+        present = [n for n in offsets if n in emb._last and emb.feature_table[n].table.trainable]
+        for d, (grp, gnames) in self.groups.items():
+            mine = [n for n in gnames if n in present]  # same order as the lookup
+            if not mine:
+                continue
+            if opt.name == "adagrad" and grp.state is None:
+                grp.state = torch.full_like(grp.local, opt.initial_accumulator_value)
+            if opt.name == "adam" and grp.state is None:
+                grp.state, grp.state2 = torch.zeros_like(grp.local), torch.zeros_like(grp.local)
+            pull = lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]
+            if stride % d == 0 and all(offsets[n] % d == 0 for n in mine):
+                # gradient rows sit at multiples of d: the buffer IS a [B, stride / d, d] stack, rows pulled in owner order
+                grp.backward_begin(None, from_stacked=(g2.reshape(B, stride // d, d), [offsets[n] // d for n in mine], pull))
+            else:  # e.g. a concat row of 26 x 128 + 13 floats: compact the sharded features' columns first (one copy)
+                compact = torch.stack([g2[:, offsets[n]:offsets[n] + d] for n in mine], dim=1).contiguous()
+                grp.backward_begin(None, from_stacked=(compact, list(range(len(mine))), pull))
+            self._active.append(grp)
+        rep = [n for n in present if n not in self.sharded_names]
+        onehot = [n for n in rep if emb._is_onehot(emb._last[n])]
+        grad_of = self.owner._rep_grad
+        for d in sorted({emb.feature_table[n].dim for n in onehot}):
+            grp_n = [n for n in onehot if emb.feature_table[n].dim == d]
+            ops.embedding_gather_backward([grad_of[id(emb.feature_table[n].table)] for n in grp_n], None,
+                                          [emb._last[n] for n in grp_n], grad, [offsets[n] for n in grp_n], "sgd", -1.0, 0.0)
+        for n in rep:
+            if n in onehot:
+                continue
+            from .inputs import Ragged
+
+            ft, x = emb.feature_table[n], emb._last[n]
+            vals, offs = (x.values, x.offsets) if isinstance(x, Ragged) else (x, None)
+            ops.embedding_bag_backward(grad_of[id(ft.table)], None, vals, offs, g2[:, offsets[n]:offsets[n] + ft.dim],
+                                       ft.sequence_combiner, "sgd", -1.0, 0.0)
+
+    def finish(self) -> None:
+        for grp in self._active:
+            grp.backward_end()
+        self._active = []
+
+
+class DistributedModel:
+    """Data-parallel execution of ANY ``mm`` ranking / retrieval model whose categorical inputs go through
+    EmbeddingsBlocks -- ``mm.TwoTowerModel`` (BASELINE configs[2]) and ``mm.DCNModel`` (configs[4]) in the bench --
+    the role of ``hvd.DistributedOptimizer`` around the model's optimizer in the reference (tf/models/base.py:476-508,
+    1472-1476):
+      * the batch is sharded by rank; in-batch negatives stay rank-local (tf/blocks/retrieval/base.py:329-375);
+      * tables with >= ``shard_threshold`` rows are row-sharded (``ShardedEmbeddingGroup``: all-to-all lookup, fused
+        update on the owner; never all-reduced), the rest are replicated;
+      * every dense gradient (MLP / cross / head tensors and the dense [V, D] gradients of the replicated tables) lives
+        in ONE flat bucket, summed in place by reduce-scatter + all-gather while the owners apply the sharded updates;
+      * the loss gradient is scaled by 1/W at the source, so every reduction is a plain SUM; parameters are broadcast
+        from rank 0 at construction.
+    Replicated tables take the DENSE optimizer step on their summed gradient (Adam: every row's moments decay; the
+    single-GPU path steps touched rows only, LazyAdam) -- identical for SGD / Adagrad."""
+
+    def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False,
+                 capacity_factor: float = 1.25, calibration: int = 2):
+        from .inputs import EmbeddingsBlock
+
+        self.model = model
+        self.group = group
+        self.rank, self.world_size = world()
+        W = self.world_size
+        active = W > 1 or force_shard
+        self._step_token = object()
+        self.shards: List[_ShardedEmbeddings] = []
+        rep_tabs, seen, shard_ids = [], set(), set()
+        for emb in model.blocks_of_type(EmbeddingsBlock):
+            names = [n for n, t in emb.feature_table.items()
+                     if active and (t.input_dim >= shard_threshold or getattr(t, "shard", None) is not None)]
+            sh = _ShardedEmbeddings(self, emb, names, group, capacity_factor, 0 if W == 1 else calibration)
+            self.shards.append(sh)
+            shard_ids |= {id(t.table) for t in sh.sharded_tables}
+        for emb in model.blocks_of_type(EmbeddingsBlock):
+            for t in emb.feature_table.values():
+                if id(t.table) not in shard_ids and id(t.table) not in seen and t.table.trainable:
+                    seen.add(id(t.table))
+                    rep_tabs.append(t.table)
+        self.rep_tabs = rep_tabs
+        self._shard_param_ids = shard_ids
+        self._rep_grad: Dict[int, torch.Tensor] = {}
+        self._bucket: Optional[torch.Tensor] = None
+        model.loss_grad_divisor = W
+        if model.optimizer is None:
+            model.compile()
+        model.optimizer.apply = self._apply  # the DistributedOptimizer: same call site, reductions inside
+        dense = [p.data for p in model.parameters() if not p.sparse]
+        broadcast_parameters(dense + [t.data for t in rep_tabs], 0, group)
+
+    @property
+    def graph_capturable(self) -> bool:
+        import os
+
+        ok = all(g.graph_capturable for sh in self.shards for g, _ in sh.groups.values())
+        return ok and getattr(self.model, "graph_capturable", True) and (
+            self.world_size == 1 or os.environ.get("MERLIN_HIP_GRAPH_DISTRIBUTED") == "1")
+
+    def check_overflow(self) -> None:
+        for sh in self.shards:
+            for g, _ in sh.groups.values():
+                g.check_overflow()
+
+    def __call__(self, inputs, **kwargs):
+        self._step_token = object()
+        return self.model(inputs, **kwargs)
+
+    def _apply(self, model=None) -> None:
+        from . import ops
+        from .inputs import EmbeddingsBlock
+
+        model, opt = self.model, self.model.optimizer
+        params = model.parameters()
+        if params:
+            opt.ensure_begun(params[0].data.device)
+        dense = [q for q in params if not q.sparse and q.trainable and q.grad is not None]
+        n_dense = sum(q.grad.numel() for q in dense)
+        n_rep = sum(t.data.numel() for t in self.rep_tabs)
+        n_head = (n_dense + 63) // 64 * 64  # table gradients start 256-byte aligned
+        W = self.world_size
+        total = (n_head + n_rep + 64 * W - 1) // (64 * W) * (64 * W)
+        dev = params[0].data.device
+        if self._bucket is None or self._bucket.numel() != total:
+            self._bucket = torch.zeros(total, dtype=torch.float32, device=dev)
+        bucket = self._bucket
+        o = n_head
+        for t in self.rep_tabs:
+            self._rep_grad[id(t)] = bucket[o:o + t.data.numel()].view_as(t.data)
+            o += t.data.numel()
+        with ops.SIDE.deferred():
+            if self.rep_tabs:
+                bucket[n_head:n_head + n_rep].zero_()
+            for emb in model.blocks_of_type(EmbeddingsBlock):
+                pending = getattr(emb, "_pending", None)
+                if pending is None:
+                    continue
+                emb._pending, emb._pending_event = None, None
+                emb._apply_sparse_now(opt, *pending)  # sharded: gradient all-to-all started; replicated: into the bucket
+            ops.SIDE.join()  # dW / db GEMMs ran on their side stream: the bucket reads them
+        if dense:
+            torch.cat([q.grad.reshape(-1) for q in dense], out=bucket[:n_dense])
+        works = allreduce_flat_(bucket, self.group, async_op=True)
+        for sh in self.shards:
+            sh.finish()  # fused updates of the local shards overlap the bucket reduction
+        for w in works:
+            w.wait()
+        o = 0
+        for q in dense:
+            q.grad = bucket[o:o + q.data.numel()].view_as(q.data)
+            o += q.data.numel()
+        for t in self.rep_tabs:
+            t.grad = self._rep_grad[id(t)]
+        ops.dense_optimizer_step_multi(opt, dense + self.rep_tabs)
+        opt._begun = False
+
+    def train_step(self, inputs, targets=None):
+        self._step_token = object()
+        loss = self.model.train_step(inputs, targets)
+        if self.world_size > 1:  # mean of the ranks' batch-mean losses = the global-batch mean (equal shards)
+            loss = loss.detach().clone()
+            dist.all_reduce(loss, group=self.group)
+            loss = loss / self.world_size
+        return loss
+
+    # checkpoint / resume: replicated part by rank 0, row shards + their optimizer state per rank
+    def save_weights(self, path) -> None:
+        import numpy as np
+
+        path = str(path)
+        if self.rank == 0:
+            self.model.save_weights(path, skip=self._shard_param_ids)
+        arrays = {}
+        for i, sh in enumerate(self.shards):
+            for d, (g, _) in sh.groups.items():
+                arrays[f"local_{i}_{d}"] = g.local.detach().cpu().numpy()
+                if g.state is not None:
+                    arrays[f"state_{i}_{d}"] = g.state.detach().cpu().numpy()
+                if g.state2 is not None:
+                    arrays[f"state2_{i}_{d}"] = g.state2.detach().cpu().numpy()
+        np.savez(f"{path}.shard{self.rank}of{self.world_size}.npz", **arrays)
+        if self.world_size > 1:
+            dist.barrier(group=self.group)
+
+    def load_weights(self, path) -> None:
+        import numpy as np
+
+        path = str(path)
+        self.model.load_weights(path, skip=self._shard_param_ids)
+        z = np.load(f"{path}.shard{self.rank}of{self.world_size}.npz")
+        for i, sh in enumerate(self.shards):
+            for d, (g, _) in sh.groups.items():
+                g.local.copy_(torch.from_numpy(z[f"local_{i}_{d}"]).to(g.local.device))
+                for key in ("state", "state2"):
+                    name = f"{key}_{i}_{d}"
+                    if name in z.files:
+                        val = torch.from_numpy(z[name]).to(g.local.device)
+                        cur = getattr(g, key)
+                        if cur is None:
+                            setattr(g, key, val)
+                        else:
+                            cur.copy_(val)
+
+
+DistributedTwoTower = DistributedModel  # BASELINE configs[2]: row-sharded user / item id tables, rank-local negatives
+DataParallel = DistributedModel         # BASELINE configs[4]: DCN-v2, replicated cross / deep weights in one bucket

@@ -34,17 +34,40 @@ def infer_embedding_dim(col_schema: ColumnSchema, multiplier: float = 2.0, ensur
     return _infer_dim_from_cardinality(int(col_schema.int_domain.max) + 1, multiplier, ensure_multiple_of_8)
 
 
-def _init_table(initializer, rows: int, dim: int, device, seed: Optional[int]) -> torch.Tensor:
+# Row sharding at construction (models_amd.distributed.sharded_tables): (rank, world, threshold) or None
+_SHARD_CTX = None
+_INIT_CHUNK = 1 << 20  # rows per init chunk of a large table
+
+
+def _init_table(initializer, rows: int, dim: int, device, seed: Optional[int], shard=None) -> torch.Tensor:
     """keras Embedding default "uniform" = U(-0.05, 0.05) (embedding.py:205); V1 EmbeddingFeatures
-    default TruncatedNormal(0, 0.05) (:1051) is available as "truncated_normal"."""
+    default TruncatedNormal(0, 0.05) (:1051) is available as "truncated_normal".
+    Large uniform tables are drawn in chunks of 2^20 rows, each from its own generator seeded by (seed, chunk): the
+    values of row r do not depend on how the table is partitioned, so ``shard = (rank, W)`` draws the rows
+    ``rank, rank + W, ...`` of exactly the table an unsharded build would hold without ever materialising it."""
     if initializer is None or (isinstance(initializer, str) and initializer == "uniform"):
-        g = torch.Generator(device="cpu")
-        g.manual_seed(0 if seed is None else seed)
-        if rows * dim > (1 << 24) and device.type == "cuda":
+        base = 0 if seed is None else seed
+        if rows * dim > (1 << 24) and device.type == "cuda" or shard is not None:
+            rank, W = shard if shard is not None else (0, 1)
+            n_local = (rows - rank + W - 1) // W if rows > rank else 0
+            out = torch.empty((n_local, dim), dtype=torch.float32, device=device)
             gd = torch.Generator(device=device)
-            gd.manual_seed(0 if seed is None else seed)
-            return (torch.rand((rows, dim), generator=gd, device=device) - 0.5) * 0.1
+            o = 0
+            for c0 in range(0, rows, _INIT_CHUNK):
+                c1 = min(rows, c0 + _INIT_CHUNK)
+                gd.manual_seed((base * 1_000_003 + c0 // _INIT_CHUNK) & 0x7FFFFFFFFFFFFFFF)
+                chunk = (torch.rand((c1 - c0, dim), generator=gd, device=device) - 0.5) * 0.1
+                first = (rank - c0) % W  # first row of this chunk owned by `rank`
+                part = chunk[first::W]
+                out[o:o + part.shape[0]] = part
+                o += part.shape[0]
+            return out
+        g = torch.Generator(device="cpu")
+        g.manual_seed(base)
         return ((torch.rand((rows, dim), generator=g) - 0.5) * 0.1).to(device)
+    if shard is not None:
+        raise NotImplementedError("sharded construction supports the 'uniform' initializer only (pretrained / custom "
+                                  "tables: build the full table and let the distributed wrapper slice it)")
     if isinstance(initializer, str) and initializer == "truncated_normal":
         g = torch.Generator(device="cpu")
         g.manual_seed(0 if seed is None else seed)
@@ -88,7 +111,11 @@ class EmbeddingTable(Block):
         # embedding.py:463-464: every lookup adds factor * sum(out^2) over the batch to the loss
         self.l2_batch_regularization_factor = float(l2_batch_regularization_factor or 0.0)
         self.device = torch.device(device) if device is not None else default_device()
-        w = _init_table(embeddings_initializer, self.input_dim, self.dim, self.device, seed)
+        # under distributed.sharded_tables(): a large table is ALLOCATED as this rank's row shard (rows rank, rank + W, ...)
+        self.shard = None
+        if _SHARD_CTX is not None and self.input_dim >= _SHARD_CTX[2]:
+            self.shard = (_SHARD_CTX[0], _SHARD_CTX[1])
+        w = _init_table(embeddings_initializer, self.input_dim, self.dim, self.device, seed, shard=self.shard)
         self.table = Parameter(w, name=f"{self.name}/embeddings", trainable=trainable, sparse=True)
 
     # embedding.py:111-128
@@ -182,6 +209,13 @@ class EmbeddingsBlock(ParallelBlock):
                 self._fwd_out = getattr(self, "_fwd_out", {})
                 self._fwd_out[n] = out[:, slots[n]]
 
+    def gather_concat(self, inputs: TabularData, names: Sequence[str], buf: torch.Tensor, offsets: Dict[str, int]) -> None:
+        """One-hot feature ``n`` -> ``buf[:, offsets[n] : offsets[n] + dim]`` of a [B, W] concat buffer (the
+        ConcatFeatures layout, core/aggregation.py:54-66) for all ``names`` in ONE multi-table launch."""
+        ops.embedding_gather([self.feature_table[n].table.data for n in names], [inputs[n] for n in names], out=buf,
+                             out_offset=[offsets[n] for n in names])
+        self._last = {n: inputs[n] for n in names}
+
     @property
     def has_batch_regularization(self) -> bool:
         return any(t.l2_batch_regularization_factor > 0 for t in self.parallel_layers.values())
@@ -246,6 +280,19 @@ class EmbeddingsBlock(ParallelBlock):
             return
         self._apply_sparse_now(opt, grad, offsets)
 
+    def _apply_batch_regularization(self, g2: torch.Tensor, offsets) -> None:
+        """d (factor * sum out^2) / d out = 2 factor out, added to the incoming gradient (embedding.py:463-464)."""
+        if not self.has_batch_regularization:
+            return
+        if getattr(self, "_reg_loss", None) is None:
+            self._reg_loss = torch.zeros(1, dtype=torch.float32, device=g2.device)
+        self._reg_loss.zero_()
+        for n in offsets:
+            ft = self.feature_table[n]
+            if n in self._last and ft.l2_batch_regularization_factor > 0:
+                ops.l2_batch_reg(self._fwd_out[n], g2[:, offsets[n]:offsets[n] + ft.dim],
+                                 ft.l2_batch_regularization_factor, self._reg_loss)
+
     def _apply_sparse_now(self, opt, grad, offsets) -> None:
         names = [n for n in offsets if n in self._last and self.feature_table[n].table.trainable]
         lists = [n for n in names if not self._is_onehot(self._last[n])]
@@ -263,15 +310,7 @@ class EmbeddingsBlock(ParallelBlock):
             return None, None
 
         g2 = grad.reshape(grad.shape[0], -1)
-        if self.has_batch_regularization:  # d (factor * sum out^2) / d out = 2 factor out, added to the incoming gradient
-            if getattr(self, "_reg_loss", None) is None:
-                self._reg_loss = torch.zeros(1, dtype=torch.float32, device=grad.device)
-            self._reg_loss.zero_()
-            for n in offsets:
-                ft = self.feature_table[n]
-                if n in self._last and ft.l2_batch_regularization_factor > 0:
-                    ops.l2_batch_reg(self._fwd_out[n], g2[:, offsets[n]:offsets[n] + ft.dim],
-                                     ft.l2_batch_regularization_factor, self._reg_loss)
+        self._apply_batch_regularization(g2, offsets)
         # ragged / dense-list features: gradient rows scale with the combiner, one fused launch chain each
         for n in lists:
             ft = self.feature_table[n]
@@ -427,9 +466,7 @@ class InputBlockV2(Block):
             self.categorical._is_onehot(inputs[n]) for n in cat_names)
         if cat_names:
             if self._fused:
-                ops.embedding_gather([self.categorical.feature_table[n].table.data for n in cat_names],
-                                     [inputs[n] for n in cat_names], out=buf, out_offset=[offsets[n] for n in cat_names])
-                self.categorical._last = {n: inputs[n] for n in cat_names}
+                self.categorical.gather_concat(inputs, cat_names, buf, offsets)
             else:
                 emb = self.categorical({n: inputs[n] for n in cat_names})
                 for n in cat_names:

@@ -93,13 +93,16 @@ class Model(Block):
         raise NotImplementedError
 
     # --- checkpoint / resume (the reference relies on Keras `model.save_weights` / `load_weights`) ---
-    def save_weights(self, path) -> None:
+    def save_weights(self, path, skip=()) -> None:
         """Parameters (by position and name), their optimizer state (Adagrad accumulators, Adam moments) and the
-        optimizer's step counter into one ``.npz``.  The model must have been built (called once)."""
+        optimizer's step counter into one ``.npz``.  The model must have been built (called once).  ``skip``: ids of
+        Parameters stored elsewhere (the row shards of a distributed model, written per rank)."""
         arrays: Dict[str, np.ndarray] = {}
         names = []
         for i, p in enumerate(self.parameters()):
             names.append(p.name)
+            if id(p) in skip:
+                continue
             arrays[f"p{i}"] = p.data.detach().cpu().numpy()
             for k, v in p.state.items():
                 arrays[f"s{i}:{k}"] = v.detach().cpu().numpy()
@@ -109,26 +112,40 @@ class Model(Block):
             arrays["__adam_step__"] = opt._step_dev.detach().cpu().numpy()
         np.savez(path, **arrays)
 
-    def load_weights(self, path) -> None:
-        """Inverse of ``save_weights`` for an identically constructed (and built) model."""
+    def load_weights(self, path, skip=()) -> None:
+        """Inverse of ``save_weights`` for an identically constructed (and built) model.  Values are copied INTO the
+        existing tensors (parameters, optimizer state, the on-device Adam step) wherever they exist, so a captured
+        hipGraph keeps updating the restored buffers."""
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
         params = self.parameters()
         names = [str(n) for n in z["__names__"]]
         if len(names) != len(params):
             raise ValueError(f"checkpoint has {len(names)} parameters, the model has {len(params)}")
         for i, p in enumerate(params):
+            if id(p) in skip:
+                continue
             w = z[f"p{i}"]
             if tuple(w.shape) != tuple(p.data.shape):
                 raise ValueError(f"parameter {i} ({p.name}): checkpoint shape {w.shape} != model shape {tuple(p.data.shape)}")
             p.data.copy_(torch.from_numpy(w))
-            p.state = {}
             prefix = f"s{i}:"
-            for key in z.files:
-                if key.startswith(prefix):
-                    p.state[key[len(prefix):]] = torch.from_numpy(z[key]).to(p.data.device)
+            keys = {key[len(prefix):] for key in z.files if key.startswith(prefix)}
+            for k in list(p.state):
+                if k not in keys:
+                    del p.state[k]
+            for k in keys:
+                val = torch.from_numpy(z[prefix + k]).to(p.data.device)
+                if k in p.state and p.state[k].shape == val.shape:
+                    p.state[k].copy_(val)
+                else:
+                    p.state[k] = val
         if "__adam_step__" in z.files and self.optimizer is not None and getattr(self.optimizer, "name", "") == "adam":
             dev = params[0].data.device
-            self.optimizer._step_dev = torch.from_numpy(z["__adam_step__"]).to(dev)  # next tick recomputes lr_device
+            step = torch.from_numpy(z["__adam_step__"]).to(dev)  # the next tick recomputes lr_device from it
+            if getattr(self.optimizer, "_step_dev", None) is not None:
+                self.optimizer._step_dev.copy_(step)
+            else:
+                self.optimizer._step_dev = step
             if self.optimizer.lr_device is None:
                 self.optimizer.lr_device = torch.zeros(1, dtype=torch.float32, device=dev)
 
@@ -219,6 +236,9 @@ class RankingModel(Model):
         p = self.output(h)
         self.optimizer.ensure_begun(p.device)
         loss, dlogit = self.output.loss_and_grad(p, targets)
+        div = getattr(self, "loss_grad_divisor", 1)
+        if div != 1:  # data parallel: gradients are partial sums of the GLOBAL-mean loss, every reduction a plain SUM
+            dlogit = dlogit / div
         xa = getattr(self.body, "output_activation", None)
         with ops.SIDE.deferred():  # dW GEMMs and the sparse update run on side streams, joined after the update
             dh = self.output.backward(dlogit, x_activation=xa)
@@ -373,7 +393,8 @@ class RetrievalModel(Model):
         if neg.n_inbatch not in (0, B):
             raise ValueError("in-batch negatives must cover the whole batch")
         pid, nid = (ids, neg.ids) if out.downscore_false_negatives else (None, None)
-        kw = dict(pos_logq=neg.pos_logq, neg_logq=neg.neg_logq, logq_after_mask=neg.logq_after_mask)
+        kw = dict(pos_logq=neg.pos_logq, neg_logq=neg.neg_logq, logq_after_mask=neg.logq_after_mask,
+                  grad_scale=1.0 / (B * getattr(self, "loss_grad_divisor", 1)))
         # one pass over the score tiles gives loss, lse AND dq (flash-style); the column pass then gives dneg
         fused = ops.inbatch_softmax_train(q, it, neg.embedding, pid, nid, out.logits_temperature, out.false_negative_score, **kw)
         if fused is not None:
@@ -382,7 +403,7 @@ class RetrievalModel(Model):
                                                       out.false_negative_score, need_dq=False, **kw)
         else:  # E > 128: tiled kernels
             res = ops.inbatch_softmax(q, it, neg.embedding, pid, nid, out.logits_temperature, out.false_negative_score,
-                                      materialize=False, **kw)
+                                      materialize=False, **{k: v for k, v in kw.items() if k != "grad_scale"})
             dq, ditem, dneg = ops.inbatch_softmax_backward(q, it, neg.embedding, res.lse, pid, nid, out.logits_temperature,
                                                            out.false_negative_score, **kw)
         if neg.n_inbatch:  # rows 0..B of the negatives ARE this batch's items; cached / sampled rows are constants here

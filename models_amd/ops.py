@@ -999,10 +999,12 @@ def topk_metrics(labels_sorted: torch.Tensor, k: int, relevant_counts: Optional[
 
 # --- multi-GPU: row-sharded embedding exchange --------------------------------------------------
 def route_build(ids: Sequence[torch.Tensor], world_size: int, slots: Optional[Sequence[int]] = None,
-                n_slots: Optional[int] = None):
+                n_slots: Optional[int] = None, capacity: int = 0, overflow: Optional[torch.Tensor] = None):
     """Send order of the row-sharded lookup (``mh_route_build``): stable counting sort of the F*B requests
-    by owner = id % W.  Returns ``(send_keys [n] int64, pos_of [F, B] int64, src_row [n] int64,
-    counts [W] int64)``; see include/merlin_hip.h for the meaning of each."""
+    by owner = id % W.  Returns ``(send_keys int64, pos_of [F, B] int64, src_row int64, counts [W] int64)``; see
+    include/merlin_hip.h for the meaning of each.  ``capacity`` > 0: fixed windows of that many slots per owner
+    (``send_keys`` / ``src_row`` have ``W * capacity`` entries, padding = -1; dropped requests have ``pos_of`` -1 and
+    set the int32 device flag ``overflow``) -- equal splits, so the exchange needs no host sync."""
     lib = _lib.load()
     F = len(ids)
     if F == 0:
@@ -1022,27 +1024,33 @@ def route_build(ids: Sequence[torch.Tensor], world_size: int, slots: Optional[Se
     n_slots = (max(slots) + 1) if n_slots is None else int(n_slots)
     dev = flat[0].device
     n = F * B
-    send_keys = torch.empty(n, dtype=torch.int64, device=dev)
+    n_send = world_size * int(capacity) if capacity else n
+    send_keys = torch.empty(n_send, dtype=torch.int64, device=dev)
     pos_of = torch.empty((F, B), dtype=torch.int64, device=dev)
-    src_row = torch.empty(n, dtype=torch.int64, device=dev)
+    src_row = torch.empty(n_send, dtype=torch.int64, device=dev)
     counts = torch.empty(world_size, dtype=torch.int64, device=dev)
+    if overflow is not None:
+        _dev(overflow, "overflow", torch.int32)
     nbytes = lib.mh_route_workspace_bytes(n, world_size)
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_route_workspace_bytes failed")
     ws = _workspace(nbytes, dev, "route")
     check(lib.mh_route_build(_host_ptr_array([i.data_ptr() for i in flat]), idt, F, B, world_size,
-                             (C.c_int32 * F)(*slots), n_slots, _ptr(send_keys), _ptr(pos_of), _ptr(src_row),
-                             _ptr(counts), _ptr(ws), ws.numel(), _stream()), "mh_route_build")
+                             (C.c_int32 * F)(*slots), n_slots, int(capacity), _ptr(send_keys), _ptr(pos_of), _ptr(src_row),
+                             _ptr(counts), _ptr(overflow), _ptr(ws), ws.numel(), _stream()), "mh_route_build")
     return send_keys, pos_of, src_row, counts
 
 
-def route_local_rows(recv_keys: torch.Tensor, base: torch.Tensor) -> torch.Tensor:
-    """rows[i] = base[key >> 40] + (key & (2^40 - 1)) (``mh_route_local_rows``)."""
+def route_local_rows(recv_keys: torch.Tensor, base: torch.Tensor, shard_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """rows[i] = base[key >> 40] + (key & (2^40 - 1)), or -1 for padding keys and rows outside the feature's shard
+    (``mh_route_local_rows``)."""
     lib = _lib.load()
     _dev(recv_keys, "recv_keys", torch.int64)
     _dev(base, "base", torch.int64)
+    if shard_rows is not None:
+        _dev(shard_rows, "shard_rows", torch.int64)
     rows = torch.empty_like(recv_keys)
     if recv_keys.numel():
-        check(lib.mh_route_local_rows(_ptr(recv_keys), recv_keys.numel(), _ptr(base), base.numel(), _ptr(rows),
-                                      _stream()), "mh_route_local_rows")
+        check(lib.mh_route_local_rows(_ptr(recv_keys), recv_keys.numel(), _ptr(base), _ptr(shard_rows), base.numel(),
+                                      _ptr(rows), _stream()), "mh_route_local_rows")
     return rows

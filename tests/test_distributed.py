@@ -257,3 +257,176 @@ def test_distributed_dlrm_step_world2_matches_full_batch_model():
         for n, t in st["shard"].items():
             full_t = model.body.embeddings.feature_table[n].table.data
             np.testing.assert_allclose(t, D.shard_table(full_t, rank, world).numpy(), atol=2e-5, rtol=1e-4)
+
+
+# ---- generic DistributedModel: TwoTower (configs[2]) and DCN-v2 (configs[4]) at world size 2 -----------------------
+def _tt_parts():
+    import models_amd as mm
+    from models_amd import schema as S
+
+    dev = torch.device("cpu")
+    schema = mm.Schema([S.categorical("user_id", 3001, [S.Tags.USER, S.Tags.USER_ID]), S.categorical("user_age", 9, [S.Tags.USER]),
+                        S.categorical("item_id", 2003, [S.Tags.ITEM, S.Tags.ITEM_ID]), S.categorical("item_cat", 17, [S.Tags.ITEM])])
+    m = mm.TwoTowerModel(schema, mm.MLPBlock([16, 8], device=dev, seed=3), embedding_dim=8, device=dev)
+    m.compile(optimizer="adagrad", learning_rate=0.05)
+    cards = {"user_id": 3001, "user_age": 9, "item_id": 2003, "item_cat": 17}
+    return m, cards
+
+
+def _dcn_parts():
+    import models_amd as mm
+    from models_amd import schema as S
+
+    dev = torch.device("cpu")
+    cards = {"C1": 4001, "C2": 7, "C3": 2500}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous("I1"), S.continuous("I2"), S.binary_target("label")]
+    m = mm.DCNModel(mm.Schema(cols), depth=2, deep_block=mm.MLPBlock([16, 8], device=dev, seed=5), embedding_dim=8, device=dev)
+    m.compile(optimizer="adagrad", learning_rate=0.05)
+    return m, cards
+
+
+def _reseed(model):
+    """Identical dense weights in every process (some blocks draw their seeds from a construction counter)."""
+    for i, p in enumerate(q for q in model.parameters() if not q.sparse):
+        g = torch.Generator().manual_seed(1000 + i)
+        p.data.copy_(torch.randn(p.data.shape, generator=g) * (0.0 if p.data.dim() == 1 else 0.15))
+
+
+def _generic_batches(cards, world, B, steps, conts=(), seed=23, same_on_all_ranks=False):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        x = {n: torch.randint(0, v, (world, B, 1), generator=g) for n, v in cards.items()}
+        x.update({c: torch.rand(world, B, 1, generator=g) for c in conts})
+        y = torch.randint(0, 2, (world, B, 1), generator=g).float()
+        if same_on_all_ranks:
+            x = {k: v[:1].expand(world, *v.shape[1:]).contiguous() for k, v in x.items()}
+        out.append((x, y))
+    return out
+
+
+def _generic_worker(rank, world, port, q, kind):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import ops_shim
+
+        ops_shim.install()
+        B, steps = 48, 4
+        if kind == "twotower":
+            model, cards = _tt_parts()
+            batches = _generic_batches(cards, world, B, steps, same_on_all_ranks=True)
+        else:
+            model, cards = _dcn_parts()
+            batches = _generic_batches(cards, world, B, steps, conts=("I1", "I2"))
+        model({k: v[rank] for k, v in batches[0][0].items()})  # build lazily-shaped layers
+        _reseed(model)
+        dm = D.DistributedModel(model, shard_threshold=1000)
+        n_sharded = sum(len(ns) for sh in dm.shards for _, ns in sh.groups.values())
+        losses = []
+        for x, y in batches:
+            xi = {k: v[rank] for k, v in x.items()}
+            losses.append(float(dm.train_step(xi, None if kind == "twotower" else y[rank])))
+        dm.check_overflow()
+        frozen = all(g.capacity is not None for sh in dm.shards for g, _ in sh.groups.values())
+        from models_amd.inputs import EmbeddingsBlock
+
+        tabs = {}
+        for emb in model.blocks_of_type(EmbeddingsBlock):
+            for n, t in emb.feature_table.items():
+                tabs[n] = (t.table.data.numpy().copy(), getattr(t, "shard", None))
+        q.put((rank, "ok", {"loss": losses, "n_sharded": n_sharded, "frozen": frozen, "tabs": tabs,
+                            "dense": [p.data.numpy().copy() for p in model.parameters() if not p.sparse]}))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["twotower", "dcn"])
+def test_distributed_model_world2(kind):
+    """DistributedModel at world size 2 over gloo (kernels replaced by tests/ops_shim.py):
+    * dcn: two ranks with half a batch each end with the parameters (dense, replicated tables, row shards) of ONE model
+      trained on the concatenated batch -- BCE is a mean over the global batch;
+    * twotower: in-batch negatives are rank-local (tf/blocks/retrieval/base.py:329-375), so the global-batch model is
+      not the reference; with the SAME batch on both ranks the summed, 1/W-scaled gradients must reproduce the
+      single-process model trained on that batch -- which exercises the sharded exchange, the bucket and the scaling.
+    Steps 3-4 run on the fixed-capacity windows (no host sync)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ops_shim
+    from models_amd import ops
+
+    world, B, steps = 2, 48, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_generic_worker, args=(r, world, port, q, kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+    assert all(m == "ok" for _, m, _ in res), [m for _, m, _ in res]
+    saved = {n: getattr(ops, n) for n in dir(ops)}
+    try:
+        ops_shim.install()
+        if kind == "twotower":
+            model, cards = _tt_parts()
+            batches = _generic_batches(cards, world, B, steps, same_on_all_ranks=True)
+        else:
+            model, cards = _dcn_parts()
+            batches = _generic_batches(cards, world, B, steps, conts=("I1", "I2"))
+        model({k: v[0] for k, v in batches[0][0].items()})
+        _reseed(model)
+        ref_losses = []
+        for x, y in batches:
+            if kind == "twotower":
+                ref_losses.append(float(model.train_step({k: v[0] for k, v in x.items()})))
+            else:
+                full = {k: v.reshape(world * B, 1) for k, v in x.items()}
+                ref_losses.append(float(model.train_step(full, y.reshape(world * B, 1))))
+    finally:
+        for n, v in saved.items():
+            setattr(ops, n, v)
+    from models_amd.inputs import EmbeddingsBlock
+
+    ref_tabs = {n: t.table.data.numpy() for emb in model.blocks_of_type(EmbeddingsBlock) for n, t in emb.feature_table.items()}
+    ref_dense = [p.data.numpy() for p in model.parameters() if not p.sparse]
+    for rank, _, st in res:
+        assert st["n_sharded"] == 2 and st["frozen"]
+        np.testing.assert_allclose(st["loss"], ref_losses, rtol=2e-5, atol=2e-6)
+        for a, b in zip(st["dense"], ref_dense):
+            np.testing.assert_allclose(a, b, atol=3e-5, rtol=2e-4)
+        for n, (t, shard) in st["tabs"].items():
+            want = ref_tabs[n] if shard is None else ref_tabs[n][rank::world]
+            np.testing.assert_allclose(t, want, atol=3e-5, rtol=2e-4, err_msg=n)
+
+
+def test_sharded_table_construction_matches_slices_of_the_full_table():
+    """distributed.sharded_tables: a large table allocated as a row shard holds exactly the rows rank, rank + W, ... the
+    unsharded build would hold (chunked, partition-independent initialisation) -- on CPU the chunked path is taken by the
+    shard request itself."""
+    import models_amd as mm
+    from models_amd import inputs, schema as S
+
+    col = S.categorical("big", 5000)
+    old = inputs._INIT_CHUNK
+    inputs._INIT_CHUNK = 1024  # several chunks, none a multiple of W
+    try:
+        full = inputs._init_table("uniform", 5000, 8, torch.device("cpu"), seed=7, shard=(0, 1))
+        for W in (2, 3):
+            for rank in range(W):
+                part = inputs._init_table("uniform", 5000, 8, torch.device("cpu"), seed=7, shard=(rank, W))
+                assert torch.equal(part, full[rank::W])
+        inputs._SHARD_CTX = (1, 3, 1000)
+        t = mm.EmbeddingTable(8, col, device=torch.device("cpu"), seed=7)
+        assert t.shard == (1, 3) and torch.equal(t.table.data, full[1::3]) and t.input_dim == 5000
+        small = mm.EmbeddingTable(8, S.categorical("small", 50), device=torch.device("cpu"))
+        assert small.shard is None and small.table.data.shape[0] == 50
+    finally:
+        inputs._SHARD_CTX = None
+        inputs._INIT_CHUNK = old
