@@ -384,6 +384,40 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
 int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* base, const int64_t* shard_rows,
                             int32_t F, int64_t* rows, mh_stream_t stream);
 
+/* ---- collectives behind the C ABI: RCCL over xGMI, one communicator per process ---------------
+ * Reference role: SparseOperationKit's distributed lookup behind `tf/distributed/embedding.py:117-149` and Horovod's
+ * gradient all-reduce (`tf/models/base.py:476-508`).  Every call is asynchronous on `stream` and has host-known sizes
+ * only: a step built from them is a fixed launch sequence (hipGraph-capturable).  RCCL is resolved with dlopen at the
+ * first call (the copy PyTorch already loaded wins: one RCCL per process).
+ *   mh_comm_unique_id: rank 0 obtains the 128-byte id; the caller broadcasts it over its own channel (MPI, a TCP store,
+ *                      torch.distributed's store) and every rank calls mh_comm_init (world == 1 needs no id). */
+typedef void* mh_comm_t;
+int32_t mh_comm_unique_id(void* id128);
+int32_t mh_comm_init(int32_t rank, int32_t world, const void* unique_id128, mh_comm_t* comm_out);
+int32_t mh_comm_destroy(mh_comm_t comm);
+/* equal windows: bytes_per_peer bytes to / from every rank (send / recv hold world * bytes_per_peer bytes) */
+int32_t mh_comm_alltoall(mh_comm_t comm, const void* send, void* recv, int64_t bytes_per_peer, mh_stream_t stream);
+/* in-place SUM of n floats across the ranks: reduce-scatter + all-gather when n % world == 0 (every xGMI link carries
+ * 1/world of the bucket per phase), plain all-reduce otherwise */
+int32_t mh_allreduce_dense(mh_comm_t comm, float* buf, int64_t n, mh_stream_t stream);
+/* Row-sharded lookup of F one-hot features in ONE call: route (fixed windows of `capacity` requests per owner, see
+ * mh_route_build) -> all-to-all(keys) -> local rows -> gather of the rank's concatenated shards -> all-to-all(rows) ->
+ * feature f of sample b lands at out[b * out_row_stride + out_offset[f] ..+D] (HOST offsets, like
+ * mh_embedding_gather_fwd).  base / shard_rows: device [F] (first row / row count of feature f's shard in
+ * local_shards).  The workspace (mh_sharded_lookup_workspace_bytes) keeps the route for the matching _bwd call.
+ * _bwd: grad_stack[B, F, D] = d loss / d (looked-up rows); the rows travel back to their owners, which apply the fused
+ * dedup + optimizer update (mh_embedding_gather_bwd semantics) to local_shards (+ state, state2 of the same shape). */
+int64_t mh_sharded_lookup_workspace_bytes(int64_t B, int32_t F, int32_t W, int64_t capacity, int32_t D);
+int32_t mh_sharded_lookup_fwd(mh_comm_t comm, const void* const* ids /*HOST [F]*/, int32_t ids_dtype, int32_t F, int64_t B,
+                              int64_t capacity, const float* local_shards, const int64_t* base,
+                              const int64_t* shard_rows, int32_t D, float* out, int64_t out_row_stride,
+                              const int64_t* out_offset /*HOST [F]*/, int32_t* overflow, void* workspace,
+                              int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_sharded_lookup_bwd(mh_comm_t comm, int32_t F, int64_t B, int64_t capacity, int32_t D, const float* grad_stack,
+                              float* local_shards, float* state, float* state2, int64_t local_rows_total,
+                              int32_t optimizer, float lr, float eps, float beta1, float beta2, const float* lr_device,
+                              void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,14 @@ SIGNATURES = {
     "mh_route_workspace_bytes": (_i64, [_i64, _i32]),
     "mh_route_build": (_i32, [_p, _i32, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "mh_route_local_rows": (_i32, [_p, _i64, _p, _p, _i32, _p, _p]),
+    "mh_comm_unique_id": (_i32, [_p]),
+    "mh_comm_init": (_i32, [_i32, _i32, _p, C.POINTER(_p)]),
+    "mh_comm_destroy": (_i32, [_p]),
+    "mh_comm_alltoall": (_i32, [_p, _p, _p, _i64, _p]),
+    "mh_allreduce_dense": (_i32, [_p, _p, _i64, _p]),
+    "mh_sharded_lookup_workspace_bytes": (_i64, [_i64, _i32, _i32, _i64, _i32]),
+    "mh_sharded_lookup_fwd": (_i32, [_p, _p, _i32, _i32, _i64, _i64, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_sharded_lookup_bwd": (_i32, [_p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _i32, _f32, _f32, _f32, _f32, _p, _p, _i64, _p]),
     "mh_dense_optimizer_step": (_i32, [_p, _p, _p, _i64, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_adam_tick": (_i32, [_p, _f32, _f32, _f32, _p, _p]),
     "mh_dlrm_interaction_fused_fwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),

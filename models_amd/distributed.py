@@ -274,12 +274,14 @@ class ShardedEmbeddingGroup:
     def graph_capturable(self) -> bool:
         return self.capacity is not None
 
-    def _a2a(self, out, inp, out_splits=None, in_splits=None, async_op: bool = False):
-        """Returns a work handle (``.wait()`` orders the CURRENT stream after the exchange) or None."""
-        if self.world_size > 1:
-            return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
-        out.copy_(inp)
-        return None
+    def _exchange(self, inp: torch.Tensor, n_out: int, out_splits=None, in_splits=None, async_op: bool = False):
+        """all-to-all of the leading dimension; returns (received tensor, work handle or None).  One rank: the exchange
+        is the identity -- the input is returned as is (no copy of the 134 MB row / gradient buffers)."""
+        if self.world_size == 1:
+            return inp, None
+        out = torch.empty((n_out,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+        work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
+        return out, work
 
     def lookup(self, ids: Sequence[torch.Tensor], scatter_into=None) -> Optional[torch.Tensor]:
         self.lookup_begin(ids, scatter_into)
@@ -323,15 +325,11 @@ class ShardedEmbeddingGroup:
                 self._freeze_after = n
         self._pos_of, self._src_row, self._n_send = pos_of, src_row, send_keys.numel()
         self._fwd_layout = (list(slots), int(n_slots))
-        recv_keys = torch.empty(n_recv, dtype=torch.int64, device=send_keys.device)
-        self._a2a(recv_keys, send_keys, self._recv_counts, self._send_counts)
+        recv_keys, _ = self._exchange(send_keys, n_recv, self._recv_counts, self._send_counts)
         self._rows = self.rows_fn(recv_keys, self.base, self.shard_rows)  # rows of the concatenated local buffer (-1: none)
-        rows = self.gather_fn(self.local, self._rows)
-        D = rows.shape[1]
-        back = torch.empty((self._n_send, D), dtype=rows.dtype, device=rows.device)
-        rows = rows.contiguous()
+        rows = self.gather_fn(self.local, self._rows).contiguous()
         # the row exchange runs on RCCL's stream: whatever the caller enqueues before lookup_end() overlaps it
-        work = self._a2a(back, rows, self._send_counts, self._recv_counts, async_op=True)
+        back, work = self._exchange(rows, self._n_send, self._send_counts, self._recv_counts, async_op=True)
         self._pending_lookup = (work, back, rows, scatter_into, F_sh, B)
 
     def lookup_end(self, scatter: Optional[Callable] = None) -> Optional[torch.Tensor]:
@@ -383,9 +381,7 @@ class ShardedEmbeddingGroup:
                 safe = src.clamp(min=0)
                 src = torch.where(src >= 0, torch.div(safe, fn, rounding_mode="floor") * F + remap[safe % fn], src)
             send = gather_fn(dstack.reshape(B * F, D), src)  # [n_send, D] in owner order
-        n_recv = self._rows.numel()
-        g = torch.empty((n_recv, D), dtype=send.dtype, device=send.device)
-        work = self._a2a(g, send, self._recv_counts, self._send_counts, async_op=True)
+        g, work = self._exchange(send.contiguous(), self._rows.numel(), self._recv_counts, self._send_counts, async_op=True)
         self._pending_bwd = (work, g, send)
 
     def backward_end(self) -> None:

@@ -200,7 +200,9 @@ class Model(Block):
                     d = pack(x, y)
                     this_sig = tuple((k, tuple(v.shape), v.dtype) for k, v in d.items())
                     if graphed is None and (graph or step >= 1):  # step 0 runs eagerly: builds lazily-shaped layers
-                        graphed, sig = GraphedStep(eager, PackedBatch(d)), this_sig
+                        # warmup=0: step 0 already ran eagerly (layers built, kernels' LDS attributes set); a warm-up
+                        # replay here would TRAIN on this batch several times
+                        graphed, sig = GraphedStep(eager, PackedBatch(d), warmup=0), this_sig
                     if graphed is not None and this_sig == sig:
                         last = graphed.replay(PackedBatch(d))
                     else:

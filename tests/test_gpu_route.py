@@ -56,3 +56,83 @@ def test_route_build_empty_and_errors():
         ops.route_build([torch.zeros(4, dtype=torch.int64, device=dev)], 65)
     with pytest.raises(MerlinHipError):
         ops.route_build([torch.zeros(4, dtype=torch.int64)], 2)  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("W,cap", [(2, 4096), (8, 600), (8, 64)])
+def test_route_build_fixed_capacity_matches_statement(W, cap):
+    """Fixed windows (capacity > 0): padding keys / source rows are -1, requests beyond a window are dropped
+    (pos_of -1) and raise the overflow flag -- bit-exact against the framework-op statement."""
+    from models_amd import ops
+    from models_amd.distributed import route_build_torch, route_local_rows_torch
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(W * 7 + cap)
+    F, B = 5, 1000
+    ids = [torch.randint(0, 1 << 18, (B,), generator=g).to(torch.int32).to(dev) for _ in range(F)]
+    slots = [4, 0, 2, 6, 1]
+    of_hip = torch.zeros(1, dtype=torch.int32, device=dev)
+    of_ref = torch.zeros(1, dtype=torch.int32, device=dev)
+    got = ops.route_build(ids, W, slots, 7, capacity=cap, overflow=of_hip)
+    want = route_build_torch(ids, W, slots, 7, cap, of_ref)
+    for a, b, name in zip(got, want, ("send_keys", "pos_of", "src_row", "counts")):
+        assert torch.equal(a, b), name
+    assert int(of_hip.item()) == int(of_ref.item()) == int(F * B / W > cap)
+    base = torch.tensor([0, 1 << 15, 1 << 16, 3 << 15, 1 << 17], dtype=torch.int64, device=dev)
+    shard_rows = torch.tensor([20000, 1 << 15, 100, 5, 1 << 15], dtype=torch.int64, device=dev)  # some rows out of range
+    r_hip = ops.route_local_rows(got[0], base, shard_rows)
+    r_ref = route_local_rows_torch(got[0], base, shard_rows)
+    assert torch.equal(r_hip, r_ref) and bool((r_hip[got[0] < 0] == -1).all()) and bool((r_hip == -1).any())
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad"])
+def test_comm_sharded_lookup_single_rank_matches_direct_path(opt):
+    """mh_comm_* / mh_sharded_lookup_fwd / _bwd with a world of one: the exchange degenerates to device copies, so the
+    result must equal the unsharded gather and the unsharded fused update bit for bit (same kernels, same order of the
+    duplicate rows: the route keeps request order within an owner)."""
+    from models_amd import comm as mc
+    from models_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    rows, D, B = [5000, 300, 70000], 16, 3000
+    tabs = [torch.randn(r, D, generator=g).to(dev) for r in rows]
+    ids = [torch.randint(0, r, (B,), generator=g).to(torch.int32).to(dev) for r in rows]
+    ids[1][:50] = 7  # duplicates
+    F = len(rows)
+    c = mc.Comm.create()
+    assert (c.rank, c.world) == (0, 1)
+    local = torch.cat(tabs).contiguous()
+    base = torch.tensor([0, rows[0], rows[0] + rows[1]], dtype=torch.int64, device=dev)
+    srows = torch.tensor(rows, dtype=torch.int64, device=dev)
+    look = mc.ShardedLookup(c, local.clone(), base, srows, capacity=F * B)
+    out = torch.zeros(B, F * D + 8, device=dev)
+    look.forward(ids, out, [0, D, 2 * D])
+    want = torch.cat([t[i.long()] for t, i in zip(tabs, ids)], dim=1)
+    assert torch.equal(out[:, : F * D], want) and int(look.overflow.item()) == 0 and bool((out[:, F * D:] == 0).all())
+
+    grad = torch.randn(B, F, D, generator=g).to(dev)
+    state = torch.full_like(local, 0.1) if opt == "adagrad" else None
+    look.backward(grad, optimizer=opt, lr=0.05, state=state)
+    ref_t = [t.clone() for t in tabs]
+    ref_s = [torch.full_like(t, 0.1) for t in tabs] if opt == "adagrad" else None
+    gflat = grad.reshape(B, F * D)
+    ops.embedding_gather_backward(ref_t, ref_s, ids, gflat, [0, D, 2 * D], optimizer=opt, lr=0.05)
+    got = torch.split(look.local, rows)
+    for a, b in zip(got, ref_t):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)  # summation order of duplicates may differ between the two sorts
+    if opt == "adagrad":
+        for a, b in zip(torch.split(state, rows), ref_s):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+    # a too-small window drops requests and raises the flag instead of faulting
+    small = mc.ShardedLookup(c, local.clone(), base, srows, capacity=B)
+    small.forward(ids, torch.zeros(B, F * D, device=dev), [0, D, 2 * D])
+    assert int(small.overflow.item()) == 1
+
+    flat = torch.randn(1000, device=dev)
+    keep = flat.clone()
+    assert torch.equal(c.allreduce_(flat), keep)  # world of one: identity
+    a, b = torch.arange(64, device=dev, dtype=torch.float32), torch.empty(64, device=dev)
+    c.alltoall(a, b)
+    assert torch.equal(a, b)
+    c.destroy()
