@@ -44,6 +44,14 @@ def _next_seed() -> int:
     return _seed_counter[0]
 
 
+def set_seed(seed: int) -> None:
+    """Reproducible construction (the role of ``tf.keras.utils.set_random_seed`` in the reference's tests): layers built
+    without an explicit ``seed=`` draw theirs from a counter; resetting it makes two models built by the same code
+    identical -- in one process or in the ranks of a job."""
+    _seed_counter[0] = 1000 + 7919 * int(seed)
+    torch.manual_seed(int(seed))
+
+
 class _Dense(Block):
     """A Dense layer that concat-aggregates dict inputs before projecting (mlp.py:210-300).
     ``kernel`` is [in, out] (Keras layout); built lazily on the first call."""

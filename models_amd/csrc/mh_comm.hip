@@ -88,7 +88,8 @@ struct MhComm {
         }                                                                                                \
     } while (0)
 
-// equal windows of `bytes` per peer; W == 1 is a device copy
+// equal windows of `bytes` per peer; W == 1 is a device copy (never part of a captured multi-GPU step: the product
+// path at W == 1 aliases instead, see models_amd/distributed.py)
 int32_t alltoall_bytes(RcclApi* R, MhComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s, const char* what) {
     if (bytes <= 0) return MH_OK;
     if (c->world == 1) {

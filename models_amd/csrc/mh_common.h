@@ -32,6 +32,12 @@ static inline hipStream_t mh_stream(mh_stream_t s) { return reinterpret_cast<hip
 
 static inline int64_t mh_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Fill of `words` 32-bit words as a KERNEL on the stream (mh_misc.hip).  hipMemsetAsync is not used anywhere in the library:
+// captured into a hipGraph it becomes a memset node, and ROCm 7 does not keep such a node ordered with the kernel
+// nodes around it on every replay (measured: a replayed train step whose sort counters are cleared by a memset node
+// sporadically sees them cleared late -- garbage piece counts, inf accumulators; a kernel node in the chain is ordered).
+int32_t mh_fill_words(void* dst, uint32_t value, int64_t words, hipStream_t s);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -574,9 +574,9 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->off_vals_a = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_vals_b = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_carry = o; o = align_up(o + (size_t)L->nchunks * D * 4, 256);
+    L->off_counter = o; o = align_up(o + 4, 256);  // right behind the carry rows: ONE fill kernel clears both
     L->off_pieces = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 16, 256);  // <= one cut per run + per chunk
     L->off_home = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 4, 256);
-    L->off_counter = o; o = align_up(o + 4, 256);
     L->off_cnt = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << RBITS_MAX) * 4, 256);
     L->total = o;
     return true;
@@ -615,8 +615,11 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     const uint32_t* vals = vbuf[1];
 
     // ---- 2. piece list, 3. segmented reduce + fused optimizer, 4. carried runs -------------------------------------------
-    (void)hipMemsetAsync(counter, 0, sizeof(unsigned int), s);
-    if (!det) (void)hipMemsetAsync(carry, 0, (size_t)L.nchunks * D * sizeof(float), s);
+    {  // a kernel, not a memset node (see mh_fill_words); deterministic mode does not accumulate into `carry`
+        const int32_t st = det ? mh_fill_words(counter, 0u, 1, s)
+                               : mh_fill_words(carry, 0u, (int64_t)(L.off_counter + 4 - L.off_carry) / 4, s);
+        if (st != MH_OK) return st;
+    }
     const int LPR = D / 4;
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,

@@ -245,6 +245,21 @@ __global__ __launch_bounds__(64) void l2_batch_reg_finish_kernel(const float* __
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+int32_t mh_fill_words(void* dst, uint32_t value, int64_t words, hipStream_t s) {
+    if (words <= 0) return MH_OK;
+    int64_t nb = mh_ceil_div(words, 256 * 4);
+    const int64_t cap = (int64_t)mh_num_cus() * 8;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)nb), dim3(256), 0, s, static_cast<uint32_t*>(dst), value, words);
+    MH_CHECK_LAUNCH("mh_fill_words");
+    return MH_OK;
+}
+
 extern "C" {
 
 int32_t mh_l2_batch_reg(const float* out, int64_t ld_out, float* grad, int64_t ld_grad, int64_t B, int32_t D, float factor,

@@ -205,21 +205,15 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
     MH_REQUIRE(F_total >= 1, "mh_route_build: F_total must be >= 1");
     hipStream_t s = mh_stream(stream);
     if (B <= 0) {
-        if (hipMemsetAsync(counts, 0, sizeof(int64_t) * W, s) != hipSuccess) {
-            mh_set_error("mh_route_build: memset failed");
-            return MH_ERR_LAUNCH;
-        }
-        return MH_OK;
+        return mh_fill_words(counts, 0u, 2 * (int64_t)W, s);
     }
     MH_REQUIRE(send_keys && pos_of && src_row && workspace, "mh_route_build: null output");
     MH_REQUIRE(capacity >= 0, "mh_route_build: negative capacity");
     const int64_t n = B * F;
     if (capacity > 0) {  // padding slots: key -1 (no row), source row -1 (zero gradient)
-        if (hipMemsetAsync(send_keys, 0xff, sizeof(int64_t) * (size_t)W * capacity, s) != hipSuccess ||
-            hipMemsetAsync(src_row, 0xff, sizeof(int64_t) * (size_t)W * capacity, s) != hipSuccess) {
-            mh_set_error("mh_route_build: memset failed");
-            return MH_ERR_LAUNCH;
-        }
+        int32_t st = mh_fill_words(send_keys, 0xffffffffu, 2 * (int64_t)W * capacity, s);
+        if (st == MH_OK) st = mh_fill_words(src_row, 0xffffffffu, 2 * (int64_t)W * capacity, s);
+        if (st != MH_OK) return st;
     }
     MH_REQUIRE(n < (1ll << 31), "mh_route_build: F*B must be < 2^31");
     RouteWs L;

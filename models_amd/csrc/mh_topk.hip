@@ -213,6 +213,15 @@ __global__ __launch_bounds__(FWM * FWN * 64, 2) void topk_filter_gemm_kernel(
 
 // Merge a compact (score, index) list into the running sorted top-k of each row; order = (score desc,
 // index asc) -- the total order of tf.math.top_k -- so survivors may arrive in any order.
+__global__ __launch_bounds__(256) void topk_stage_init_kernel(const float* __restrict__ out_scores, int k, int64_t Bq,
+                                                              float* __restrict__ tau, int* __restrict__ cnt) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= Bq) return;
+    tau[r] = out_scores[r * k + (k - 1)];
+    cnt[r] = 0;
+    cnt[Bq + r] = 0;
+}
+
 __global__ __launch_bounds__(256) void topk_merge_compact_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
                                                                 int* __restrict__ cnt, int cap, int64_t Bq, int k,
                                                                 float* __restrict__ best_s, int32_t* __restrict__ best_i,
@@ -444,10 +453,9 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         int* overflow = cnt + Bq;  // [Bq] per-row dirty flags
         float* cs = reinterpret_cast<float*>(ws + p.off_cs);
         int32_t* ci = reinterpret_cast<int32_t*>(ws + p.off_ci);
-        (void)hipMemsetAsync(cnt, 0, (size_t)(2 * Bq) * sizeof(int), s);
-        // tau[row] = current k-th best (strided copy out of the running list)
-        (void)hipMemcpy2DAsync(tau, sizeof(float), out_scores + (k - 1), (size_t)k * sizeof(float), sizeof(float), (size_t)Bq,
-                               hipMemcpyDeviceToDevice, s);
+        // tau[row] = current k-th best (strided read of the running list); survivor counts and dirty flags cleared.
+        // One kernel node, not memset / memcpy nodes: see mh_fill_words in mh_common.h
+        hipLaunchKernelGGL(topk_stage_init_kernel, dim3((unsigned)mh_ceil_div(Bq, 256)), dim3(256), 0, s, out_scores, k, Bq, tau, cnt);
         const int vec_q = ((reinterpret_cast<uintptr_t>(q) & 15) == 0) && (E % 4 == 0);
         const int vec_c = ((reinterpret_cast<uintptr_t>(cand) & 15) == 0) && (E % 4 == 0);
         const int row_tiles = (int)mh_ceil_div(Bq, FBM);

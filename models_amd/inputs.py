@@ -253,7 +253,7 @@ class EmbeddingsBlock(ParallelBlock):
         side stream while the caller keeps enqueueing independent work)."""
         self._pending = (grad, offsets)
         self._pending_event = None
-        if ready and grad.is_cuda and ops.SIDE.active():
+        if ready and grad.is_cuda and ops.SIDE.active("sparse"):
             self._pending_event = torch.cuda.Event()
             self._pending_event.record()
 
@@ -270,7 +270,7 @@ class EmbeddingsBlock(ParallelBlock):
         self._pending = None
         ev = getattr(self, "_pending_event", None)
         self._pending_event = None
-        if ev is not None and ops.SIDE.active():
+        if ev is not None and ops.SIDE.active("sparse"):
             side = ops.SIDE.fork_after("sparse", ev, keep=(grad,) + tuple(self._last.values()))
             if getattr(opt, "_wait_event", None) is not None:
                 side.wait_event(opt._wait_event)

@@ -89,17 +89,19 @@ class _SideStreams:
     def __init__(self):
         import os
 
-        self.enabled = os.environ.get("MERLIN_HIP_SIDE_STREAMS", "1") != "0"
+        mode = os.environ.get("MERLIN_HIP_SIDE_STREAMS", "1")  # "0" | "1" | "dw" | "sparse" (one kind only: debugging)
+        self.enabled = mode != "0"
+        self.kinds = {"dw", "sparse"} if mode in ("0", "1") else {mode}
         self._streams = {}
         self._pending = set()
         self._keep = []
         self._defer = 0
 
-    def active(self) -> bool:
+    def active(self, kind: str = None) -> bool:
         # not under hipGraph capture: ROCm 7 replays a captured graph on ONE hardware queue (measured: the kernel
         # trace of a replayed multi-branch step shows no overlap and the event nodes cost ~2 %), so side streams only
         # pay in eager steps (the sharded multi-GPU step: 2.13 -> 2.01 ms at W = 1)
-        return (self.enabled and not TIMER.enabled and torch.cuda.is_available()
+        return (self.enabled and (kind is None or kind in self.kinds) and not TIMER.enabled and torch.cuda.is_available()
                 and not torch.cuda.is_current_stream_capturing())
 
     def stream(self, name: str):
@@ -433,7 +435,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
     nbytes = lib.mh_linear_bwd_workspace_bytes(M, K, N)
     yp, ldy = (_ptr(y), y.stride(0)) if act != 0 else (None, 0)
-    if SIDE.active():
+    if SIDE.active("dw"):
         # dz first (in place), then dX on this stream while dW / db run on the "dw" side stream
         if act != 0:
             check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,

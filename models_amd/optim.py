@@ -43,7 +43,7 @@ class Optimizer:
             self.ensure_begun(params[0].data.device)
         # prologue ran only now: a sparse update forked from an earlier event must also wait for it
         self._wait_event = None
-        if late and self.lr_device is not None and ops.SIDE.active():
+        if late and self.lr_device is not None and ops.SIDE.active("sparse"):
             self._wait_event = torch.cuda.Event()
             self._wait_event.record()
         with ops.SIDE.deferred():
