@@ -561,6 +561,8 @@ def main():
         "sustained": None if not sustained else dict(sustained, value=world * B * sustained["steps"] / sustained["seconds"]),
         "roofline": hbm_roofline(km, dominant, kernels[dominant], *traffic(dominant)) if dominant else None,
         "roofline_gather": hbm_roofline(km, "embedding_gather", kernels["embedding_gather"], *traffic("embedding_gather")),
+        "roofline_fused_fwd": hbm_roofline(km, "dlrm_fused_fwd", kernels["dlrm_fused_fwd"], *traffic("dlrm_fused_fwd")),
+        "roofline_fused_bwd": hbm_roofline(km, "dlrm_fused_bwd", kernels["dlrm_fused_bwd"], *traffic("dlrm_fused_bwd")),
         "mfma": mfma_rates(km, [k for k in km if k.startswith("linear_")]),
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()},
         "step_ms": step_stats,

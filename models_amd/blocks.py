@@ -254,17 +254,25 @@ class DLRMBlock(Block):
         return len(self.stack_order)
 
     def _fusable(self, inputs) -> bool:
-        # The fused gather->interaction kernels are correct (tests/test_gpu_dense.py) but, in round 1, slower
-        # than gather + interaction back to back (281 vs 259 us forward at C2: one sample per wavefront does not
-        # keep enough row loads in flight) -- opt in with MERLIN_HIP_FUSED_DLRM=1.
+        # gather -> interaction in one kernel (forward 123 us instead of 283 us for gather + interaction at C2; the backward
+        # re-gathers the rows instead of reading a saved stack: 230 us vs 216 us) -- on whenever the geometry fits, every
+        # categorical input is one-hot and the rows are local (a sharded lookup delivers rows through an exchange, the
+        # l2 batch regulariser needs the gathered rows); MERLIN_HIP_FUSED_DLRM=0 forces the unfused pair.
         import os
 
-        if os.environ.get("MERLIN_HIP_FUSED_DLRM") != "1":
+        if os.environ.get("MERLIN_HIP_FUSED_DLRM", "1") == "0":
             return False
         D, F = self.dim, self.num_features
-        if D % 16 != 0 or F * D > 2048 or F > 32 or D not in (16, 32, 64, 128):
+        if F < 2 or F * D > 2048 or F > 32 or D not in (16, 32, 64, 128):
             return False
-        return all(self.embeddings._is_onehot(inputs[n]) for n in self.cat_names)
+        emb = self.embeddings
+        if "gather_into" in emb.__dict__ or "gather_concat" in emb.__dict__ or emb.has_batch_regularization:
+            return False
+        if any(emb.feature_table[n].dim != D for n in self.cat_names):
+            return False
+        if not all(emb._is_onehot(inputs[n]) for n in self.cat_names):
+            return False
+        return len({inputs[n].dtype for n in self.cat_names}) == 1
 
     def forward(self, inputs: TabularData):
         first = inputs[self.cat_names[0]]

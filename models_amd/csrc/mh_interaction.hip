@@ -441,90 +441,100 @@ struct FusedArgs {
     int64_t rows[IMAXF];
 };
 
-template <typename IdT, int NV>
-struct RowGather {
-    const float* tptr[NV];
-    const IdT* iptr[NV];
-    int64_t nrows[NV];
-    int lds_off[NV];
-    int c4off[NV];
-    int64_t idn[NV];  // ids of the sample whose rows are fetched next
-    f32x4 xr[NV];
+// Lane f (< F) of every wavefront owns stack slot f: its table, id column and row count live in 6 VGPRs.  Per sample it
+// turns its id into the ADDRESS of the row (0 = out of range / no slot: the row reads as zeros) and the lanes that load
+// the row fetch that address with two ds_bpermute -- no per-load pointer / bound arrays (the first version of this
+// kernel kept those per lane: 215 VGPRs, 2 waves per SIMD, slower than the unfused pair).
+template <typename IdT>
+struct SlotLane {
+    const float* tab;
+    const IdT* ids;
+    int64_t rows;
+    bool mine, dense;
 
-    __device__ __forceinline__ void init(const FusedArgs& a, int lane, int F, int D, int LD) {
-        const int vpr = D / 4, nvec = F * vpr;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = lane + 64 * i;
-            const int r = idx / vpr, c4 = idx - r * vpr;
-            const bool ok = idx < nvec;
-            lds_off[i] = ok ? r * LD + c4 * 4 : -1;
-            c4off[i] = c4 * 4;
-            tptr[i] = ok ? a.table[r] : nullptr;
-            iptr[i] = ok ? static_cast<const IdT*>(a.ids[r]) : nullptr;
-            nrows[i] = ok ? a.rows[r] : 0;
-        }
+    __device__ __forceinline__ void init(const FusedArgs& a, int lane, int F) {
+        mine = lane < F;
+        const int f = mine ? lane : 0;
+        tab = a.table[f];
+        ids = static_cast<const IdT*>(a.ids[f]);
+        rows = a.rows[f];
+        dense = mine && tab == nullptr;
     }
-    __device__ __forceinline__ void load_ids(int64_t b) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) idn[i] = (lds_off[i] >= 0 && tptr[i]) ? (int64_t)iptr[i][b] : 0;
-    }
-    __device__ __forceinline__ void load_rows(int64_t b, const float* __restrict__ dense, int64_t ld_dense, int D) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (lds_off[i] < 0) continue;
-            if (tptr[i]) {
-                const int64_t id = idn[i];
-                xr[i] = (id >= 0 && id < nrows[i])
-                            ? *reinterpret_cast<const f32x4*>(tptr[i] + id * D + c4off[i])
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                xr[i] = *reinterpret_cast<const f32x4*>(dense + b * ld_dense + c4off[i]);
-            }
-        }
-    }
-    __device__ __forceinline__ void to_lds(float* Xs) const {
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(Xs + lds_off[i]) = xr[i];
+    __device__ __forceinline__ int64_t load_id(int64_t b) const { return (mine && !dense) ? (int64_t)ids[b] : 0; }
+    __device__ __forceinline__ uint64_t address(int64_t b, int64_t id, const float* __restrict__ dense_src, int64_t ld_dense,
+                                                int D) const {
+        if (!mine) return 0;
+        if (dense) return dense_src ? reinterpret_cast<uint64_t>(dense_src + b * ld_dense) : 0;
+        return (id >= 0 && id < rows) ? reinterpret_cast<uint64_t>(tab + id * D) : 0;
     }
 };
 
-template <typename IdT, int NV>
+// rows i*RP + sub (sub = lane / vpr) of the sample whose slot addresses are in `addr` (lane f = slot f)
+template <int D, int NV>
+__device__ __forceinline__ void fetch_rows(uint64_t addr, int F, int lane, f32x4 (&xr)[NV]) {
+    constexpr int vpr = D / 4, RP = 64 / vpr;
+    const int sub = lane / vpr, c4 = lane - sub * vpr;
+    const int alo = (int)(uint32_t)addr, ahi = (int)(uint32_t)(addr >> 32);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i * RP >= F) break;  // uniform
+        const int src = i * RP + sub;  // < 64: NV * RP <= 32 + RP
+        const uint32_t lo = (uint32_t)__shfl(alo, src), hi = (uint32_t)__shfl(ahi, src);
+        const uint64_t a = ((uint64_t)hi << 32) | lo;
+        xr[i] = a ? *reinterpret_cast<const f32x4*>(a + (uint64_t)c4 * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// contiguous samples per wavefront (the 4-byte id loads of consecutive samples share cache lines)
+__device__ __forceinline__ void wave_chunk(int64_t B, int64_t* b0, int64_t* b1) {
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t per = (B + nw - 1) / nw;
+    *b0 = w * per < B ? w * per : B;
+    *b1 = *b0 + per < B ? *b0 + per : B;
+}
+
+template <typename IdT, int DT, int NV>
 __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, const float* __restrict__ dense,
                                                             int64_t ld_dense, int dense_slot, int64_t B, int F,
-                                                            int D, int append_dense, float* __restrict__ out,
-                                                            int64_t ldo) {
+                                                            int append_dense, float* __restrict__ out, int64_t ldo) {
+    constexpr int D = DT * 16;
+    constexpr int LD = D + 4;
+    constexpr int vpr = D / 4, RP = 64 / vpr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LD = D + 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* Xs = smem + wave * IMAXF * LD;
     const int i16 = lane & 15, q = lane >> 4;
     const int P = F * (F - 1) / 2;
     const int qoff = q * (D / 4);
-    const int steps = D / 4;
-    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
-    RowGather<IdT, NV> g;
-    g.init(a, lane, F, D, LD);
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t b = (int64_t)blockIdx.x * 4 + wave;
-    if (b < B) {
-        g.load_ids(b);
-        g.load_rows(b, dense, ld_dense, D);
-        if (b + stride < B) g.load_ids(b + stride);
+    constexpr int steps = D / 4;
+    for (int idx = lane; idx < IMAXF * LD; idx += 64) Xs[idx] = 0.f;  // rows >= F stay zero (never written again)
+    const int sub = lane / vpr, c4 = lane - sub * vpr;
+    float* xdst = Xs + sub * LD + c4 * 4;  // row i*RP + sub lands at xdst + i*RP*LD
+    SlotLane<IdT> sl;
+    sl.init(a, lane, F);
+    int64_t b, b1;
+    wave_chunk(B, &b, &b1);
+    f32x4 xr[NV];
+    int64_t idn = 0;
+    if (b < b1) {
+        fetch_rows<D, NV>(sl.address(b, sl.load_id(b), dense, ld_dense, D), F, lane, xr);
+        if (b + 1 < b1) idn = sl.load_id(b + 1);
     }
     const bool two = F > 16;
-    while (b < B) {
-        g.to_lds(Xs);
+    while (b < b1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i * RP < F && i * RP + sub < IMAXF) *reinterpret_cast<f32x4*>(xdst + i * RP * LD) = xr[i];
         __builtin_amdgcn_wave_barrier();
-        const int64_t bn = b + stride;
-        if (bn < B) {
-            g.load_rows(bn, dense, ld_dense, D);          // ids of bn were fetched one iteration ago
-            if (bn + stride < B) g.load_ids(bn + stride);  // two samples ahead
+        if (b + 1 < b1) {
+            fetch_rows<D, NV>(sl.address(b + 1, idn, dense, ld_dense, D), F, lane, xr);  // ids of b+1 came in one iteration ago
+            if (b + 2 < b1) idn = sl.load_id(b + 2);
         }
         f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
         const float* r0 = Xs + i16 * LD + qoff;
         const float* r1 = Xs + (16 + i16) * LD + qoff;
+#pragma unroll
         for (int s = 0; s < steps; s += 4) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0 + s);
             if (two) {
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
         if (append_dense && dense_slot >= 0)
             for (int t = lane; t < D; t += 64) orow[P + t] = Xs[dense_slot * LD + t];
         __builtin_amdgcn_wave_barrier();
-        b = bn;
+        ++b;
     }
 }
 
@@ -561,6 +571,7 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
     constexpr int D = DT * 16;
     constexpr int LD = D + 16;
     constexpr int NP = 8;
+    constexpr int vpr = D / 4, RP = 64 / vpr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = F * (F - 1) / 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -580,48 +591,46 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
         pair_j[p] = (unsigned char)(i + 1 + (p - start));
     }
     for (int idx = lane; idx < IMAXF * LDS_S; idx += 64) Ss[idx] = 0.f;
-    for (int idx = lane; idx < (IMAXF - F) * LD; idx += 64) Xs[F * LD + idx] = 0.f;
+    for (int idx = lane; idx < IMAXF * LD; idx += 64) Xs[idx] = 0.f;
     __syncthreads();
-    RowGather<IdT, NV> g;
-    g.init(a, lane, F, D, LD);
-    int s_off0[NP], s_off1[NP];
+    const int sub = lane / vpr, c4 = lane - sub * vpr;
+    float* xdst = Xs + sub * LD + c4 * 4;
+    SlotLane<IdT> sl;
+    sl.init(a, lane, F);
+    int s_off[NP];  // both scatter offsets of pair p = lane + 64 k, 16 bits each (-1: no pair)
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int p = lane + 64 * k;
-        if (p < P) {
-            s_off0[k] = pair_i[p] * LDS_S + pair_j[p];
-            s_off1[k] = pair_j[p] * LDS_S + pair_i[p];
-        } else {
-            s_off0[k] = s_off1[k] = -1;
-        }
+        s_off[k] = (p < P) ? ((pair_i[p] * LDS_S + pair_j[p]) | ((pair_j[p] * LDS_S + pair_i[p]) << 16)) : -1;
     }
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    int64_t b, b1;
+    wave_chunk(B, &b, &b1);
+    f32x4 xr[NV];
     float gr[NP];
+    int64_t idn = 0;
     auto load_g = [&](int64_t bb) {
         const float* gp = dout + bb * ldo;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
-            if (s_off0[k] >= 0) gr[k] = gp[lane + 64 * k];
+            if (s_off[k] >= 0) gr[k] = gp[lane + 64 * k];
     };
-    if (b < B) {
-        g.load_ids(b);
-        g.load_rows(b, dense, ld_dense, D);
+    if (b < b1) {
+        fetch_rows<D, NV>(sl.address(b, sl.load_id(b), dense, ld_dense, D), F, lane, xr);
         load_g(b);
-        if (b + stride < B) g.load_ids(b + stride);
+        if (b + 1 < b1) idn = sl.load_id(b + 1);
     }
     const int nti = F > 16 ? 2 : 1;
-    const int vpr = D / 4;
-    while (b < B) {
-        g.to_lds(Xs);
+    while (b < b1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i * RP < F && i * RP + sub < IMAXF) *reinterpret_cast<f32x4*>(xdst + i * RP * LD) = xr[i];
 #pragma unroll
         for (int k = 0; k < NP; ++k)
-            if (s_off0[k] >= 0) {
-                Ss[s_off0[k]] = gr[k];
-                Ss[s_off1[k]] = gr[k];
+            if (s_off[k] >= 0) {
+                Ss[s_off[k] & 0xffff] = gr[k];
+                Ss[s_off[k] >> 16] = gr[k];
             }
         __builtin_amdgcn_wave_barrier();
-        const int64_t bn = b + stride;
         const float* gcur = dout + b * ldo;
         float tgv[DT];
 #pragma unroll
@@ -629,10 +638,10 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
             const int d = 16 * tn + i16;
             tgv[tn] = (tail_slot >= 0 && d < T) ? gcur[P + d] : 0.f;
         }
-        if (bn < B) {
-            g.load_rows(bn, dense, ld_dense, D);
-            load_g(bn);
-            if (bn + stride < B) g.load_ids(bn + stride);
+        if (b + 1 < b1) {
+            fetch_rows<D, NV>(sl.address(b + 1, idn, dense, ld_dense, D), F, lane, xr);
+            load_g(b + 1);
+            if (b + 2 < b1) idn = sl.load_id(b + 2);
         }
         float a0[8], a1[8];
 #pragma unroll
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
                 if (nti == 2) acc1[tn] = mfma16(a1[st], bv, acc1[tn]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();  // all reads of X done: the slab is reused for dX
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) {
             const int d = 16 * tn + i16;
@@ -664,13 +673,12 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
             }
         }
         __builtin_amdgcn_wave_barrier();
-        f32x4* dst = reinterpret_cast<f32x4*>(dx + b * (int64_t)F * D);
+        f32x4* dst = reinterpret_cast<f32x4*>(dx + b * (int64_t)F * D) + c4;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (g.lds_off[i] >= 0) dst[lane + 64 * i] = *reinterpret_cast<const f32x4*>(Xs + g.lds_off[i]);
+            if (i * RP + sub < F) dst[(i * RP + sub) * vpr] = *reinterpret_cast<const f32x4*>(xdst + i * RP * LD);
         __builtin_amdgcn_wave_barrier();
-        b = bn;
-        (void)vpr;
+        ++b;
     }
 }
 
@@ -784,37 +792,57 @@ static int32_t fill_fused_args(FusedArgs* a, const float* const* slot_tables, co
     return MH_OK;
 }
 
+// one resident set of workgroups (every wavefront walks one contiguous run of samples): CUs x what LDS and a <= 128 VGPR
+// budget allow
+static dim3 fused_grid(int64_t B, size_t lds) {
+    int occ = (int)((160 * 1024) / lds);
+    if (occ > 4) occ = 4;
+    if (occ < 1) occ = 1;
+    const int64_t want = mh_ceil_div(B, 4);
+    const int64_t cap = (int64_t)mh_num_cus() * occ;
+    return dim3((unsigned)(want < cap ? want : cap));
+}
+
 int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int64_t* slot_rows,
                                       const void* const* slot_ids, int32_t ids_dtype, const float* dense,
                                       int64_t ld_dense, int64_t B, int32_t F, int32_t D, int32_t append_dense,
                                       float* out, int64_t ldo, mh_stream_t stream) {
     MH_REQUIRE(slot_tables && slot_rows && slot_ids && out, "mh_dlrm_interaction_fused_fwd: null argument");
     MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dlrm_interaction_fused_fwd: F=%d outside [2,%d]", F, IMAXF);
-    MH_REQUIRE(D >= 16 && D % 16 == 0 && F * (D / 4) <= 64 * 8, "mh_dlrm_interaction_fused_fwd: needs D %% 16 == 0 and F*D <= 2048 (got F=%d D=%d)", F, D);
+    MH_REQUIRE((D == 16 || D == 32 || D == 64 || D == 128) && F * (D / 4) <= 64 * 8,
+               "mh_dlrm_interaction_fused_fwd: needs D in {16,32,64,128} and F*D <= 2048 (got F=%d D=%d)", F, D);
     MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_dlrm_interaction_fused_fwd: bad ids_dtype");
     FusedArgs a;
     int32_t dense_slot;
     int32_t st = fill_fused_args(&a, slot_tables, slot_rows, slot_ids, F, &dense_slot, "mh_dlrm_interaction_fused_fwd");
     if (st != MH_OK) return st;
-    MH_REQUIRE(dense_slot < 0 || (dense && ld_dense >= D && ld_dense % 4 == 0), "mh_dlrm_interaction_fused_fwd: dense slot needs a 16-byte aligned [B, D] source");
+    MH_REQUIRE(dense_slot < 0 || (dense && ld_dense >= D && ld_dense % 4 == 0 && (reinterpret_cast<uintptr_t>(dense) & 15) == 0),
+               "mh_dlrm_interaction_fused_fwd: dense slot needs a 16-byte aligned [B, D] source");
     const int P = F * (F - 1) / 2;
     const int T = (append_dense && dense_slot >= 0) ? D : 0;
     MH_REQUIRE(ldo >= P + T, "mh_dlrm_interaction_fused_fwd: ldo too small");
     if (B <= 0) return MH_OK;
     const size_t lds = (size_t)4 * IMAXF * (D + 4) * sizeof(float);
-    const int64_t want = mh_ceil_div(B, 4);
-    const int64_t cap = (int64_t)mh_num_cus() * 8;
-    dim3 grid((unsigned)(want < cap ? want : cap));
+    const dim3 grid = fused_grid(B, lds);
     hipStream_t s_ = mh_stream(stream);
-    if (ids_dtype == MH_I32) {
-        auto kern = dlrm_fused_fwd_kernel<int32_t, 8>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, D, append_dense, out, ldo);
-    } else {
-        auto kern = dlrm_fused_fwd_kernel<int64_t, 8>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, D, append_dense, out, ldo);
+#define MH_LAUNCH_FUSED_FWD(IDT, DT)                                                                             \
+    {                                                                                                            \
+        auto kern = dlrm_fused_fwd_kernel<IDT, DT, 8>;                                                           \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, append_dense, out, ldo); \
     }
+    if (ids_dtype == MH_I32) {
+        if (D == 16) MH_LAUNCH_FUSED_FWD(int32_t, 1)
+        else if (D == 32) MH_LAUNCH_FUSED_FWD(int32_t, 2)
+        else if (D == 64) MH_LAUNCH_FUSED_FWD(int32_t, 4)
+        else MH_LAUNCH_FUSED_FWD(int32_t, 8)
+    } else {
+        if (D == 16) MH_LAUNCH_FUSED_FWD(int64_t, 1)
+        else if (D == 32) MH_LAUNCH_FUSED_FWD(int64_t, 2)
+        else if (D == 64) MH_LAUNCH_FUSED_FWD(int64_t, 4)
+        else MH_LAUNCH_FUSED_FWD(int64_t, 8)
+    }
+#undef MH_LAUNCH_FUSED_FWD
     MH_CHECK_LAUNCH("mh_dlrm_interaction_fused_fwd");
     return MH_OK;
 }
@@ -828,20 +856,20 @@ int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int
     MH_REQUIRE((D == 16 || D == 32 || D == 64 || D == 128) && F * (D / 4) <= 64 * 8,
                "mh_dlrm_interaction_fused_bwd: needs D in {16,32,64,128} and F*D <= 2048 (got F=%d D=%d)", F, D);
     MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_dlrm_interaction_fused_bwd: bad ids_dtype");
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, "mh_dlrm_interaction_fused_bwd: dx must be 16-byte aligned");
     FusedArgs a;
     int32_t dense_slot;
     int32_t st = fill_fused_args(&a, slot_tables, slot_rows, slot_ids, F, &dense_slot, "mh_dlrm_interaction_fused_bwd");
     if (st != MH_OK) return st;
-    MH_REQUIRE(dense_slot < 0 || (dense && ld_dense >= D && ld_dense % 4 == 0), "mh_dlrm_interaction_fused_bwd: dense slot needs a 16-byte aligned [B, D] source");
+    MH_REQUIRE(dense_slot < 0 || (dense && ld_dense >= D && ld_dense % 4 == 0 && (reinterpret_cast<uintptr_t>(dense) & 15) == 0),
+               "mh_dlrm_interaction_fused_bwd: dense slot needs a 16-byte aligned [B, D] source");
     const int P = F * (F - 1) / 2;
     const int tail_slot = (tail_to_dense && dense_slot >= 0) ? dense_slot : -1;
     const int T = tail_slot >= 0 ? D : 0;
     MH_REQUIRE(ldo >= P + T, "mh_dlrm_interaction_fused_bwd: ldo too small");
     if (B <= 0) return MH_OK;
     const size_t lds = 1024 + (size_t)4 * (IMAXF * (D + 16) + IMAXF * LDS_S) * sizeof(float);
-    const int64_t want = mh_ceil_div(B, 4);
-    const int64_t cap = (int64_t)mh_num_cus() * 8;
-    dim3 grid((unsigned)(want < cap ? want : cap));
+    const dim3 grid = fused_grid(B, lds);
     hipStream_t s_ = mh_stream(stream);
 #define MH_LAUNCH_FUSED_BWD(IDT, DT)                                                                             \
     {                                                                                                            \

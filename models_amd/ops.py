@@ -928,7 +928,8 @@ def dlrm_interaction_fused(slot_tables, slot_ids, dense: Optional[torch.Tensor],
     T = D if (append_dense and dense is not None) else 0
     if out is None:
         out = torch.empty((B, P + T), dtype=torch.float32, device=first.device)
-    with _timed("dlrm_fused_fwd"):
+    with _timed("dlrm_fused_fwd", nbytes=B * ((F - 1) * (D * 4 + 4) + (D * 4 if dense is not None else 0) + (P + T) * 4),
+                flops=2 * B * D * F * (F - 1) // 2):
         check(lib.mh_dlrm_interaction_fused_fwd(tab, rows, idp, idt, _ptr(dense), 0 if dense is None else dense.stride(0),
                                                 B, F, D, int(bool(append_dense)), _ptr(out), out.stride(0), _stream()),
               "mh_dlrm_interaction_fused_fwd")
@@ -945,7 +946,8 @@ def dlrm_interaction_fused_backward(slot_tables, slot_ids, dense: Optional[torch
     _rowmajor_2d(dout, "dout")
     B = dout.shape[0]
     dx = torch.empty((B, F, D), dtype=torch.float32, device=first.device)
-    with _timed("dlrm_fused_bwd"):
+    with _timed("dlrm_fused_bwd", nbytes=B * ((F - 1) * (D * 4 + 4) + (D * 4 if dense is not None else 0) + dout.shape[1] * 4 + F * D * 4),
+                flops=2 * B * D * F * (F - 1)):
         check(lib.mh_dlrm_interaction_fused_bwd(tab, rows, idp, idt, _ptr(dense), 0 if dense is None else dense.stride(0),
                                                 _ptr(dout), dout.stride(0), B, F, D, int(bool(tail_to_dense)), _ptr(dx),
                                                 _stream()),

@@ -119,3 +119,34 @@ def test_fused_gather_interaction_fwd_bwd(device, F, D, dense_pos, idt):
     dx_ref = ops.dot_interaction_backward(_t(X, device), _t(dout, device), -1 if dense_pos is None else dense_pos,
                                           0 if dense_pos is None else D)
     torch.testing.assert_close(dx, dx_ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_fused_segment_equals_unfused_pair_bitwise_long_runs(device, idt):
+    """BASELINE configs[1] geometry (26 tables + bottom-MLP row, D = 64) at a batch where every wavefront walks a run of
+    several samples (id prefetch two ahead, row prefetch one ahead): the fused kernels issue the same MFMA chains as
+    gather + interaction, so forward and backward are bit-identical to the unfused pair."""
+    g = torch.Generator().manual_seed(5)
+    B, F, D = 20011, 27, 64
+    rows = [3, 17, 1000, 250000] * 6 + [7, 90000]
+    order = list(range(26))
+    dense_slot = 11
+    tabs = [torch.randn(r, D, generator=g).to(device) for r in rows]
+    ids = [torch.randint(0, r, (B,), generator=g).to(idt).to(device) for r in rows]
+    ids[3][5] = -1
+    ids[0][B - 1] = 3  # out of range: zero rows
+    dense = torch.randn(B, D, generator=g).to(device)
+    slot_tabs = tabs[:dense_slot] + [None] + tabs[dense_slot:]
+    slot_ids = ids[:dense_slot] + [None] + ids[dense_slot:]
+    stack = torch.empty(B, F, D, device=device)
+    ops.embedding_gather(tabs, ids, out=stack, out_slot=[s for s in range(F) if s != dense_slot])
+    stack[:, dense_slot] = dense
+    P = F * (F - 1) // 2
+    ref = torch.empty(B, P + D, device=device)
+    ops.dot_interaction(stack, dense, out=ref)
+    out = ops.dlrm_interaction_fused(slot_tabs, slot_ids, dense)
+    assert torch.equal(out, ref)
+    dout = torch.randn(B, P + D, generator=g).to(device)
+    dx_ref = ops.dot_interaction_backward(stack, dout, dense_slot, D)
+    dx = ops.dlrm_interaction_fused_backward(slot_tabs, slot_ids, dense, dout)
+    assert torch.equal(dx, dx_ref)

@@ -68,6 +68,24 @@ if not which or "embbwd" in which:
     idb = [torch.randint(0, 50_000_000, (B * 8,), dtype=torch.int32, device=dev)]
     outl = torch.empty(B * 8, 1, D, device=dev)
     timeit("gather fwd, one 12.8 GB table, 512K ids", lambda: ops.embedding_gather([big], idb, out=outl), nbytes=B * 8 * (2 * D * 4 + 4))
+if "fused" in which:
+    from models_amd.synthetic import CRITEO_CARDINALITIES
+
+    tabs = [torch.rand(v, D, device=dev) for v in CRITEO_CARDINALITIES]
+    ids = [torch.randint(0, v, (B,), dtype=torch.int32, device=dev) for v in CRITEO_CARDINALITIES]
+    dense = torch.randn(B, D, device=dev)
+    stack = torch.empty(B, F, D, device=dev)
+    out = torch.empty(B, 416, device=dev)
+    dout = torch.randn(B, 415, device=dev)
+    alg_f = B * (26 * (D * 4 + 4) + D * 4 + 415 * 4)
+    def unfused_fwd():
+        ops.embedding_gather(tabs, ids, out=stack)
+        ops.dot_interaction(stack, dense, out=out[:, :415])
+    timeit("gather + interaction fwd (unfused pair)", unfused_fwd, nbytes=alg_f)
+    slot_t, slot_i = tabs + [None], ids + [None]
+    timeit("fused gather->interaction fwd", lambda: ops.dlrm_interaction_fused(slot_t, slot_i, dense, out=out[:, :415]), nbytes=alg_f)
+    timeit("interaction bwd (unfused, reads the stack)", lambda: ops.dot_interaction_backward(stack, dout, 26, D), nbytes=alg_f + B * F * D * 4)
+    timeit("fused gather->interaction bwd", lambda: ops.dlrm_interaction_fused_backward(slot_t, slot_i, dense, dout), nbytes=alg_f + B * F * D * 4)
 if "embbig" in which:
     tabs = [torch.rand(1_000_000, D, device=dev) for _ in range(26)]
     ids = [torch.randint(0, 1_000_000, (B,), dtype=torch.int32, device=dev) for _ in range(26)]
