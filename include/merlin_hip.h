@@ -177,6 +177,34 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
                                float* dW, float* db, void* workspace, int64_t workspace_bytes,
                                mh_stream_t stream);
 
+/* ---- a6 (chains): consecutive SMALL Dense layers in one launch ---------------------------
+ * Replaces a run of _Dense.call (blocks/mlp.py:275-280) inside an MLPBlock (blocks/mlp.py:35-139) -- e.g. the DLRM
+ * bottom MLP 13 -> 128 -> 64 and the tail of the top MLP with the BinaryOutput head 128 -> 64 -> 32 -> 1
+ * (outputs/classification.py:114) -- when every width is <= 128:  y_l = act_l(y_{l-1} W_l + b_l), l = 1..L, y_0 = x.
+ * dims[L+1] = {K_0, N_1, .., N_L}; W[l] is [dims[l], dims[l+1]] row-major (Keras kernel layout), b[l] is [dims[l+1]]
+ * or NULL (b itself may be NULL); act[l] in MH_ACT_*; y[l] ([M, dims[l+1]], leading dim ldy[l]) receives every layer's
+ * output (the backward needs them).  W / b / act / y / ldy / dims are HOST arrays of L entries.  Every output is one
+ * k-ascending fmaf chain, bit-identical to mh_linear_bias_act_fwd layer by layer (which uses 16 partial chains for
+ * N <= 4 heads: there the chain differs in the last bits).
+ * mh_mlp_chain_supported: 1 when a fused kernel covers (L, dims) (L = 2 or 3, widths <= 128 within the compiled
+ * signatures), else 0 -- _fwd / _bwd then return MH_ERR_UNSUPPORTED and the caller goes layer by layer. */
+int32_t mh_mlp_chain_supported(int32_t L, const int32_t* dims);
+int32_t mh_mlp_chain_fwd(const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
+                         const float* const* W, const float* const* b, const int32_t* act, float* const* y,
+                         const int64_t* ldy, mh_stream_t stream);
+/* Backward of the chain (GradientTape through the same layers, models/base.py:1121-1174): g[M, dims[L]] (leading dim
+ * ldg) is the gradient w.r.t. y_L, or already dz_L when pre_masked != 0 (e.g. the BCE-with-sigmoid gradient).  Per
+ * layer, last to first: dz_l = g * act_l'(y_l), dW[l] = y_{l-1}^T dz_l, db[l] = colsum(dz_l) (db or db[l] may be NULL),
+ * g = dz_l W_l^T.  dx (NULL = not needed) receives (dz_1 W_1^T) * x_act'(x) where x_act names the activation that
+ * produced x (as in mh_linear_bias_act_bwd).  dz never touches HBM; dW / db are reduced in a fixed order
+ * (deterministic).  dx is bit-identical to the layer-by-layer path; dW / db sum the batch in a different order. */
+int64_t mh_mlp_chain_bwd_workspace_bytes(int64_t M, int32_t L, const int32_t* dims);
+int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
+                         const float* const* W, const int32_t* act, const float* const* y, const int64_t* ldy,
+                         const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
+                         float* const* dW, float* const* db, void* workspace, int64_t workspace_bytes,
+                         mh_stream_t stream);
+
 /* ---- a7: DLRM pairwise dot interaction --------------------------------------------------
  * Replaces tf.matmul(x, x, transpose_b=True) + strict-upper-triangle boolean_mask in
  * DotProductInteraction.call (blocks/interaction.py:86-116): x[B, F, D] ->

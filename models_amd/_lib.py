@@ -39,6 +39,10 @@ SIGNATURES = {
     "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_linear_bias_act_bwd": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_mlp_chain_supported": (_i32, [_i32, _p]),
+    "mh_mlp_chain_fwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "mh_mlp_chain_bwd_workspace_bytes": (_i64, [_i64, _i32, _p]),
+    "mh_mlp_chain_bwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
     "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
     "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p]),
     "mh_rowwise_dot": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p]),
@@ -124,7 +128,7 @@ class _Traced:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if name in ("mh_last_error", "mh_version") or name.endswith("_workspace_bytes"):
+        if name in ("mh_last_error", "mh_version", "mh_mlp_chain_supported") or name.endswith("_workspace_bytes"):
             return fn
 
         def call(*a):

@@ -119,13 +119,81 @@ class _Dense(Block):
         return dx
 
 
+_CHAIN_OK: dict = {}
+
+
+def _chain_supported(dims) -> bool:
+    import os
+
+    if os.environ.get("MERLIN_HIP_MLP_CHAIN", "1") == "0":  # debugging / A-B switch: every layer goes through ops.linear
+        return False
+    key = tuple(int(d) for d in dims)
+    ok = _CHAIN_OK.get(key)
+    if ok is None:
+        ok = _CHAIN_OK[key] = ops.mlp_chain_supported(key)
+    return ok
+
+
+def mlp_forward(layers, x, out_last: Optional[torch.Tensor] = None):
+    """Forward through consecutive _Dense layers.  Runs of 2-3 SMALL layers (every width <= 128: the DLRM bottom MLP,
+    the tail of the top MLP with the head) go through ONE fused launch (``ops.mlp_chain``); the partition is remembered
+    on the first layer so that ``mlp_backward`` mirrors it.  ``out_last``: destination of the last layer's output."""
+    if isinstance(x, dict):
+        x = layers[0].pre_aggregation(x)
+    d = x.shape[-1]
+    for l in layers:
+        if l.kernel is None:
+            l.build(d)
+        d = l.units
+    dims = [x.shape[-1]] + [l.units for l in layers]
+    n, i, plan = len(layers), 0, []
+    while i < n:
+        run = 1
+        if x.is_cuda:
+            for r in (3, 2):
+                if i + r <= n and _chain_supported(dims[i:i + r + 1]):
+                    run = r
+                    break
+        plan.append((i, run))
+        i += run
+    layers[0]._chain_plan = plan
+    for i, r in plan:
+        seg = layers[i:i + r]
+        last = out_last if i + r == n else None
+        if r == 1:
+            x = seg[0].forward(x, out=last)
+            continue
+        ys = ops.mlp_chain(x, [l.kernel.data for l in seg], [None if l.bias is None else l.bias.data for l in seg],
+                           [l.activation for l in seg], [None] * (r - 1) + [last])
+        for l, xin, y in zip(seg, [x] + ys[:-1], ys):
+            l._x, l._y = xin, y
+        x = ys[-1]
+    return x
+
+
 def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False):
     """Backward through consecutive _Dense layers, chaining the activation derivative of layer i-1
-    into the dX epilogue of layer i (no separate elementwise pass between layers)."""
+    into the dX epilogue of layer i (no separate elementwise pass between layers); the fused runs of
+    ``mlp_forward`` go back through one ``ops.mlp_chain_backward`` launch each."""
+    plan = getattr(layers[0], "_chain_plan", None) if layers else None
+    if not plan or sum(r for _, r in plan) != len(layers):
+        plan = [(i, 1) for i in range(len(layers))]
     with ops.SIDE.deferred():  # the dW GEMMs of all layers overlap the dX chain; joined at the outermost exit
-        for i in range(len(layers) - 1, -1, -1):
+        for i, r in reversed(plan):
             prev_act = layers[i - 1].activation if i > 0 else None
-            grad = layers[i].backward(grad, need_dx=(i > 0) or need_dx, pre_masked=pre_masked, x_activation=prev_act)
+            want_dx = (i > 0) or need_dx
+            if r == 1:
+                grad = layers[i].backward(grad, need_dx=want_dx, pre_masked=pre_masked, x_activation=prev_act)
+            else:
+                seg = layers[i:i + r]
+                grad, dWs, dbs = ops.mlp_chain_backward(seg[0]._x, [l.kernel.data for l in seg], [l._y for l in seg],
+                                                        [l.activation for l in seg], grad, pre_masked=pre_masked,
+                                                        need_dx=want_dx, need_db=[l.bias is not None for l in seg],
+                                                        x_activation=prev_act)
+                for l, dW, db in zip(seg, dWs, dbs):
+                    l.kernel.grad = dW
+                    if l.bias is not None:
+                        l.bias.grad = db
             pre_masked = prev_act is not None
     return grad
 
@@ -274,7 +342,20 @@ class DLRMBlock(Block):
             return False
         return len({inputs[n].dtype for n in self.cat_names}) == 1
 
-    def forward(self, inputs: TabularData):
+    @property
+    def accepts_head(self) -> bool:
+        """The model's Dense head can ride at the end of the top MLP's fused chain (``forward(inputs, head=...)``)."""
+        return self.top_block is not None and _dense_layers(self.top_block) is not None
+
+    def _top(self, top_in: torch.Tensor, head: Optional[_Dense]):
+        self._head = head
+        tl = _dense_layers(self.top_block)
+        if tl is None:
+            out = self.top_block(top_in)
+            return out if head is None else head(out)
+        return mlp_forward(tl + ([head] if head is not None else []), top_in)
+
+    def forward(self, inputs: TabularData, head: Optional[_Dense] = None):
         first = inputs[self.cat_names[0]]
         B = first.shape[0] if isinstance(first, torch.Tensor) else first.offsets.shape[0] - 1
         dev = self.embeddings.feature_table[self.cat_names[0]].table.data.device
@@ -300,16 +381,19 @@ class DLRMBlock(Block):
             top_in = buf[:, :width]
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
             self._top_in = top_in
-            return self.top_block(top_in)
+            return self._top(top_in, head)
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
         tail = None
         if self.bottom_block is not None:
             x = self.continuous(inputs)
             layers = self.bottom_block.layers if isinstance(self.bottom_block, SequentialBlock) else [self.bottom_block]
-            for layer in layers[:-1]:
-                x = layer(x)
             tail = stacked[:, self.slots["bottom_block"]]
-            layers[-1].forward(x, out=tail)  # last bottom layer writes its slot of the stack
+            if all(isinstance(l, _Dense) for l in layers):
+                mlp_forward(layers, x, out_last=tail)  # last bottom layer writes its slot of the stack
+            else:
+                for layer in layers[:-1]:
+                    x = layer(x)
+                layers[-1].forward(x, out=tail)
         self.embeddings.gather_into(inputs, stacked, self.slots)
         self._stacked = stacked
         if self.top_block is None:
@@ -320,7 +404,7 @@ class DLRMBlock(Block):
         top_in = buf[:, :width]
         self.interaction.forward(stacked, tail, out=top_in)
         self._top_in = top_in
-        return self.top_block(top_in)
+        return self._top(top_in, head)
 
     @property
     def output_activation(self):
@@ -330,9 +414,15 @@ class DLRMBlock(Block):
 
     def backward(self, grad, pre_masked: bool = False):
         D = self.dim
+        head = getattr(self, "_head", None)
         if self.top_block is not None:
             tl = _dense_layers(self.top_block)
-            grad = mlp_backward(tl, grad, True, pre_masked) if tl else self.top_block.backward(grad)
+            if head is not None and tl:  # grad is the head's dz (the loss gradient w.r.t. its pre-activation)
+                grad = mlp_backward(tl + [head], grad, True, pre_masked=True)
+            else:
+                if head is not None:
+                    grad = head.backward(grad, pre_masked=True)
+                grad = mlp_backward(tl, grad, True, pre_masked) if tl else self.top_block.backward(grad)
         has_tail = self.bottom_block is not None and self.top_block is not None
         slot = self.slots["bottom_block"] if self.bottom_block is not None else -1
         if getattr(self, "_fused", False):

@@ -61,15 +61,32 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every ``csrc/*.hip`` for gfx950 and link ``libmerlin_hip.so``."""
     if not force and not needs_build():
         return LIB
+    # one builder at a time: concurrent ranks (torchrun) finding a stale library would otherwise write the same
+    # .o / .so files at once; the losers of the lock find the library fresh and return
+    import fcntl
+
+    with open(CSRC / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> Path:
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
+    tmp = LIB.with_suffix(".so.tmp")
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, LIB)  # atomic: a process loading the library never sees a half-written file
     return LIB
 
 

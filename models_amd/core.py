@@ -161,8 +161,19 @@ class SequentialBlock(Block):
         x = inputs
         if self.filter is not None and isinstance(x, dict):
             x = self.filter(x)
-        for layer in self.layers:
-            x = call_layer(layer, x, **kwargs)
+        from .blocks import _Dense, mlp_forward  # local import: blocks imports core
+
+        layers, i, n = self.layers, 0, len(self.layers)
+        while i < n:
+            j = i
+            while j < n and isinstance(layers[j], _Dense):
+                j += 1
+            if j - i >= 2:  # a run of Dense layers: small ones are fused into one launch (blocks.mlp_forward)
+                x = mlp_forward(layers[i:j], x)
+                i = j
+                continue
+            x = call_layer(layers[i], x, **kwargs)
+            i += 1
         return x
 
     def backward(self, grad):

@@ -586,7 +586,7 @@ class DistributedDLRM:
                         cur.copy_(val)
 
     # forward of the DLRM body with sharded lookups
-    def forward_body(self, inputs):
+    def forward_body(self, inputs, head=None):
         from . import ops
 
         body = self.body
@@ -603,11 +603,10 @@ class DistributedDLRM:
             self.group_sh.lookup_begin([inputs[n] for n in self.sharded_names],
                                        scatter_into=(stacked, [body.slots[n] for n in self.sharded_names], scatter_fn))
         x = body.continuous(inputs)
-        layers = body.bottom_block.layers
-        for layer in layers[:-1]:
-            x = layer(x)
+        from .blocks import mlp_forward
+
         tail = stacked[:, body.slots["bottom_block"]]
-        layers[-1].forward(x, out=tail)
+        mlp_forward(body.bottom_block.layers, x, out_last=tail)  # small Dense runs fused; the last layer writes its stack slot
         emb = body.embeddings
         if self.replicated:
             ops.embedding_gather([emb.feature_table[n].table.data for n in self.replicated],
@@ -627,12 +626,12 @@ class DistributedDLRM:
         top_in = buf[:, :width]
         body.interaction.forward(stacked, tail, out=top_in)
         body._top_in = top_in
-        return body.top_block(top_in)
+        return body._top(top_in, head)  # the Dense(1, sigmoid) head rides on the top MLP's fused chain
 
     def __call__(self, inputs):
         from .models import prepare_features
 
-        return self.model.output(self.forward_body(prepare_features(inputs)))
+        return self.forward_body(prepare_features(inputs), head=self.model.output.to_call)
 
     def train_step(self, inputs, targets):
         """Gradients are partial sums of the GLOBAL-mean loss (scale 1/(B*W) at the loss), so every
@@ -645,16 +644,13 @@ class DistributedDLRM:
             model.compile()
         opt = model.optimizer
         x = prepare_features(inputs)
-        h = self.forward_body(x)
-        p = model.output(h)
+        p = self.forward_body(x, head=model.output.to_call)
         B = p.shape[0]
         loss, dlogit = ops.bce(p, targets, need_grad=True)
         if self.world_size > 1:
             dlogit = dlogit / self.world_size
-        xa = body.output_activation
         with ops.SIDE.deferred():  # side work (dW GEMMs) is joined below, right before the bucket reads the gradients
-            dh = model.output.backward(dlogit, x_activation=xa)
-            body.backward(dh, pre_masked=xa is not None)  # leaves (dstack, offsets) pending on the embeddings block
+            body.backward(dlogit)  # head + top MLP + interaction; leaves (dstack, offsets) pending on the embeddings block
             dstack, offsets = body.embeddings._pending
             body.embeddings._pending = None
             D = body.dim

@@ -230,12 +230,20 @@ class RankingModel(Model):
         super().__init__(body, output, schema=schema, name=name)
         self.body, self.output = body, output
 
+    def _predict(self, x: TabularData) -> torch.Tensor:
+        if getattr(self.body, "accepts_head", False):  # DLRM: the Dense(1, sigmoid) head rides on the top-MLP chain
+            return self.body(x, head=self.output.to_call)
+        return self.output(self.body(x))
+
+    def forward(self, inputs: TabularData, targets=None, training: bool = False, testing: bool = False):
+        return self._predict(prepare_features(inputs))
+
     def train_step(self, inputs: TabularData, targets: torch.Tensor) -> torch.Tensor:
         if self.optimizer is None:
             self.compile()
         x = prepare_features(inputs)
-        h = self.body(x)
-        p = self.output(h)
+        fused_head = bool(getattr(self.body, "accepts_head", False))
+        p = self._predict(x)
         self.optimizer.ensure_begun(p.device)
         loss, dlogit = self.output.loss_and_grad(p, targets)
         div = getattr(self, "loss_grad_divisor", 1)
@@ -243,11 +251,14 @@ class RankingModel(Model):
             dlogit = dlogit / div
         xa = getattr(self.body, "output_activation", None)
         with ops.SIDE.deferred():  # dW GEMMs and the sparse update run on side streams, joined after the update
-            dh = self.output.backward(dlogit, x_activation=xa)
-            if xa is not None:
-                self.body.backward(dh, pre_masked=True)
+            if fused_head:  # the head went forward at the end of the body's top-MLP chain: it goes back the same way
+                self.body.backward(dlogit)
             else:
-                self.body.backward(dh)
+                dh = self.output.backward(dlogit, x_activation=xa)
+                if xa is not None:
+                    self.body.backward(dh, pre_masked=True)
+                else:
+                    self.body.backward(dh)
             self.optimizer.apply(self)
         return _with_regularization(self, loss)
 

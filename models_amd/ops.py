@@ -127,6 +127,11 @@ class _SideStreams:
         self._keep.extend(keep)
         return st
 
+    def retire(self, buf) -> None:
+        """A workspace being replaced: keep it alive until the next join if any side stream has work in flight."""
+        if self._pending:
+            self._keep.append(buf)
+
     def join(self) -> None:
         if self._pending:
             cur = torch.cuda.current_stream()
@@ -362,6 +367,97 @@ def linear(
     return out
 
 
+def _chain_dims(x: torch.Tensor, Ws: Sequence[torch.Tensor]):
+    dims = [int(x.shape[1])] + [int(W.shape[1]) for W in Ws]
+    for i, W in enumerate(Ws):
+        _dev(W, f"W[{i}]", torch.float32)
+        if W.dim() != 2 or W.shape[0] != dims[i] or not W.is_contiguous():
+            raise ValueError(f"W[{i}] must be contiguous [{dims[i]}, N]")
+    return dims, (C.c_int32 * len(dims))(*dims)
+
+
+def mlp_chain_supported(dims: Sequence[int]) -> bool:
+    """True when one fused launch covers the Dense chain ``dims[0] -> dims[1] -> ...``."""
+    if not 3 <= len(dims) <= 4:
+        return False
+    arr = (C.c_int32 * len(dims))(*[int(d) for d in dims])
+    return bool(_lib.load().mh_mlp_chain_supported(len(dims) - 1, arr))
+
+
+def mlp_chain(x: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[Optional[torch.Tensor]],
+              activations: Sequence[Optional[str]], outs: Optional[Sequence[Optional[torch.Tensor]]] = None):
+    """``y_l = act_l(y_{l-1} @ W_l + b_l)`` for a run of small Dense layers in ONE launch; returns every layer's
+    output (the backward needs them).  ``outs[l]`` may name a destination (e.g. a slot of a stacked buffer)."""
+    lib = _lib.load()
+    _rowmajor_2d(x, "x")
+    L = len(Ws)
+    dims, cdims = _chain_dims(x, Ws)
+    M = x.shape[0]
+    ys = []
+    for l in range(L):
+        o = outs[l] if outs is not None and outs[l] is not None else torch.empty((M, dims[l + 1]), dtype=torch.float32, device=x.device)
+        _rowmajor_2d(o, f"outs[{l}]")
+        if bs[l] is not None:
+            _dev(bs[l], f"b[{l}]", torch.float32)
+        if activations[l] not in ACT:
+            raise ValueError(f"unsupported activation {activations[l]!r}")
+        ys.append(o)
+    if M == 0:
+        return ys
+    cW = _host_ptr_array([W.data_ptr() for W in Ws])
+    cb = _host_ptr_array([0 if b is None else b.data_ptr() for b in bs])
+    cact = (C.c_int32 * L)(*[ACT[a] for a in activations])
+    cy = _host_ptr_array([y.data_ptr() for y in ys])
+    cld = (C.c_int64 * L)(*[y.stride(0) for y in ys])
+    name = "mlp_chain_" + "x".join(str(d) for d in dims)
+    nbytes = 4 * (M * sum(dims) + sum(dims[i] * dims[i + 1] for i in range(L)))
+    with _timed(name, nbytes=nbytes, flops=2 * M * sum(dims[i] * dims[i + 1] for i in range(L))):
+        check(lib.mh_mlp_chain_fwd(_ptr(x), x.stride(0), M, L, cdims, cW, cb, cact, cy, cld, _stream()), "mh_mlp_chain_fwd")
+    return ys
+
+
+def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence[torch.Tensor],
+                       activations: Sequence[Optional[str]], grad: torch.Tensor, pre_masked: bool = False,
+                       need_dx: bool = True, need_db: Optional[Sequence[bool]] = None, x_activation: Optional[str] = None):
+    """Backward of ``mlp_chain``: returns ``(dx | None, [dW_l], [db_l | None])``.  ``grad`` is d/dy_L (or dz_L when
+    ``pre_masked``); dx has the producer's activation derivative (``x_activation``) folded in, like ``linear_backward``."""
+    lib = _lib.load()
+    _rowmajor_2d(x, "x")
+    _rowmajor_2d(grad, "grad")
+    L = len(Ws)
+    dims, cdims = _chain_dims(x, Ws)
+    M = x.shape[0]
+    if grad.shape != (M, dims[-1]):
+        raise ValueError(f"grad must be [{M}, {dims[-1]}]")
+    need_db = [True] * L if need_db is None else list(need_db)
+    dx, lddx = None, dims[0]
+    if need_dx:
+        lddx = (dims[0] + 3) // 4 * 4
+        buf = torch.empty((M, lddx), dtype=torch.float32, device=x.device)
+        if lddx != dims[0]:
+            buf[:, dims[0]:].zero_()
+        dx = buf[:, :dims[0]]
+    dWs = [torch.empty((dims[l], dims[l + 1]), dtype=torch.float32, device=x.device) for l in range(L)]
+    dbs = [torch.empty((dims[l + 1],), dtype=torch.float32, device=x.device) if need_db[l] else None for l in range(L)]
+    nbytes = lib.mh_mlp_chain_bwd_workspace_bytes(M, L, cdims)
+    if nbytes < 0:
+        raise _lib.MerlinHipError("mh_mlp_chain_bwd_workspace_bytes: unsupported chain")
+    ws = _workspace(nbytes, x.device, "mlp_chain_bwd")
+    cW = _host_ptr_array([W.data_ptr() for W in Ws])
+    cact = (C.c_int32 * L)(*[ACT[a] for a in activations])
+    cy = _host_ptr_array([_rowmajor_2d(y, "y").data_ptr() for y in ys])
+    cld = (C.c_int64 * L)(*[y.stride(0) for y in ys])
+    cdW = _host_ptr_array([t.data_ptr() for t in dWs])
+    cdb = _host_ptr_array([0 if t is None else t.data_ptr() for t in dbs])
+    name = "mlp_chain_bwd_" + "x".join(str(d) for d in dims)
+    with _timed(name, nbytes=4 * M * (sum(dims) + (dims[0] if need_dx else 0) + dims[-1]),
+                flops=(4 * M * sum(dims[i] * dims[i + 1] for i in range(L)))):
+        check(lib.mh_mlp_chain_bwd(_ptr(x), x.stride(0), M, L, cdims, cW, cact, cy, cld, _ptr(grad), grad.stride(0),
+                                   1 if pre_masked else 0, ACT[x_activation], _ptr(dx), lddx, cdW, cdb, _ptr(ws), ws.numel(),
+                                   _stream()), "mh_mlp_chain_bwd")
+    return dx, dWs, dbs
+
+
 def dot_interaction(
     x: torch.Tensor, tail: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
 ) -> torch.Tensor:
@@ -403,6 +499,10 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     key = (str(device), tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # a kernel queued on a side stream may still be using the old block: it must not go back to the caching
+            # allocator (which would hand it to a launch-stream allocation) before the side streams are joined
+            SIDE.retire(buf)
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
