@@ -1,0 +1,278 @@
+// fp32 MFMA GEMM core, second generation (gfx950, v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak).
+//
+//   C[M, N] = A[M, K] * B        B_NT = false: B = W[K, N] row-major (Dense forward, cross layer)
+//                                B_NT = true : B = W[N, K] row-major, C = A W^T (dX of a Dense layer, scorer-style products)
+//
+// What changed against mh_gemm_core.h (global -> registers -> ds_write staging, 2 LDS stages, 32x64 per wavefront):
+//   * tiles travel global -> LDS by DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, no wait of
+//     the issuing wavefront; the LDS image is chunk-swizzled by permuting the per-lane SOURCE address;
+//   * a STAGES-deep ring of 16-wide k-tiles with ONE barrier per k-tile: the loads of tile t + STAGES - 1 are issued
+//     right after the barrier that publishes tile t, so STAGES - 1 tiles (24 KB each at 256 x 128) are in flight per
+//     workgroup -- the HBM-streamed operand of the skinny layers needs that depth;
+//   * 64 x 64 outputs per wavefront (2 x 2 accumulators): every A / B fragment feeds two MFMAs, half the LDS reads.
+// Numerics are unchanged: every output is ONE k-ascending fp32 fmaf chain from zero (k = 2 s + h inside a step, steps and
+// tiles ascending), bit-identical to mh_gemm_core.h and to oracle/oracle_c.c.
+//
+// Requirements (the launchers in mh_linear*.hip fall back to the first-generation kernels otherwise): K % 4 == 0 (the
+// 16-byte chunks at or past K of the last k-tile are fetched from a zero buffer for BOTH operands), 16-byte aligned rows
+// (lda % 4 == 0, and ldb % 4 == 0 / N % 4 == 0 for the n-contiguous B), K >= 4, N >= 4.
+#pragma once
+#include "mh_common.h"
+
+namespace mhgemm2 {
+
+constexpr int BK = 16;
+
+struct Epilogue {
+    const float* bias;  // [N] or NULL
+    int act;            // MH_ACT_*
+    const float* x0;    // DCN-v2 cross epilogue (blocks/cross.py:188-202): out = x0 * (.) + xres, both [M, ld_x0]
+    const float* xres;
+    int64_t ld_x0;
+    const float* maskx;  // dX: the producer's activation derivative folded in (x_act of mh_linear_bias_act_bwd)
+    int64_t ldm;
+    int x_act;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void dma16(const float* g, float* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// source of the 16-byte chunks past K in the last k-tile (K % 16 != 0, K % 4 == 0): both operands read zeros there
+static __device__ __attribute__((aligned(16))) float g_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    // "memory": nothing that touches LDS or global memory moves across (the compiler does not know that the DMA
+    // instructions issued earlier write the LDS tile read below)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == MH_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MH_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// k-major LDS tile [ROWS][16 k]: 16-byte chunk c (k = 4c .. 4c+3) of row r sits at chunk position 4 r + (c ^ ((r >> 2) & 3)):
+// the 16 lanes of a quarter wavefront (consecutive rows) then hit 16 distinct 4-bank groups on ds_read_b128.
+__device__ __forceinline__ int kmajor_src_chunk(int p) {  // chunk position -> source chunk c of row p >> 2
+    const int r = p >> 2;
+    return (p & 3) ^ ((r >> 2) & 3);
+}
+
+template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true>
+__global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb, int64_t M, int N, int K,
+                                                          float* __restrict__ C, int64_t ldc, const Epilogue ep,
+                                                          int ncol_tiles) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;
+    constexpr int NIA = BM / 16 / NW, NIB = BN / 16 / NW;  // DMA wave-instructions (1 KiB each) per wavefront per tile
+    static_assert(NIA >= 1 && NIB >= 1 && (BM / 16) % NW == 0 && (BN / 16) % NW == 0, "tile / wavefront mismatch");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int NI = NIA + NIB;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    // column tiles fastest: the workgroups resident at one time share few A row panels (read once from HBM) and sweep
+    // all of B (L2 / Infinity Cache resident)
+    const int64_t row0 = (int64_t)(blockIdx.x / ncol_tiles) * BM;
+    const int n0 = (int)(blockIdx.x % ncol_tiles) * BN;
+
+    // ---- per-lane DMA source pointers (tile 0) ------------------------------------------------------------------------
+    const float* pa[NIA];
+    const float* pb[NIB];
+#pragma unroll
+    for (int j = 0; j < NIA; ++j) {
+        const int p = (wave + j * NW) * 64 + lane;
+        int64_t row = row0 + (p >> 2);
+        if (row > M - 1) row = M - 1;
+        pa[j] = A + row * lda + 4 * kmajor_src_chunk(p);
+    }
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+        const int p = (wave + j * NW) * 64 + lane;
+        if (B_NT) {
+            int n = n0 + (p >> 2);
+            if (n > N - 1) n = N - 1;
+            pb[j] = B + (int64_t)n * ldb + 4 * kmajor_src_chunk(p);
+        } else {
+            // n-major tile [16 k][BN]: chunk position p = k * (BN/4) + pc holds source chunk pc ^ (8 (k & 1)): the two
+            // k-slots of an MFMA step (rows k, k+1) read 32 consecutive floats each, 32 banks apart
+            constexpr int CPR = BN / 4;
+            const int k = p / CPR, pc = p % CPR;
+            int n = n0 + 4 * (pc ^ (8 * (k & 1)));
+            const int nlast = ((N - 4) / 4) * 4;
+            if (n > nlast) n = nlast;
+            pb[j] = B + (int64_t)k * ldb + n;
+        }
+    }
+    const int nk = (K + BK - 1) / BK;
+    // k offset (inside a tile) of the chunk each DMA lane fetches: chunks at or past K read g_zero_chunk (last tile only)
+    int ka[NIA], kb[NIB];
+#pragma unroll
+    for (int j = 0; j < NIA; ++j) ka[j] = 4 * kmajor_src_chunk((wave + j * NW) * 64 + lane);
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+        const int p = (wave + j * NW) * 64 + lane;
+        kb[j] = B_NT ? 4 * kmajor_src_chunk(p) : p / (BN / 4);
+    }
+    auto issue = [&](int kt) {
+        float* st = smem + (kt % STAGES) * ST_FL;
+        const int k0 = kt * BK;
+        const bool tail = k0 + BK > K;  // uniform
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const float* g = pa[j] + k0;
+            if (tail && k0 + ka[j] >= K) g = g_zero_chunk;
+            dma16(g, st + (wave + j * NW) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const float* g = B_NT ? pb[j] + k0 : pb[j] + (int64_t)k0 * ldb;
+            if (tail && k0 + kb[j] >= K) g = g_zero_chunk;
+            dma16(g, st + A_FL + (wave + j * NW) * 256);
+        }
+    };
+
+    // ---- fragment addresses (floats, relative to the stage base) -------------------------------------------------------
+    int fa[TM], fb[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int r = wm * TM * 32 + tm * 32 + l31;
+        fa[tm] = r * 16 + (((r >> 2) & 3) << 2);  // chunk c of this row: fa ^ (c << 2)
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = wn * TN * 32 + tn * 32 + l31;
+        if (B_NT)
+            fb[tn] = A_FL + n * 16 + (((n >> 2) & 3) << 2);
+        else
+            fb[tn] = A_FL + h * BN + ((((n >> 2) ^ (8 * h)) << 2) | (n & 3));  // step s: + 2 s BN
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    // ---- prologue: STAGES - 1 tiles in flight -------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+
+    // fragments of chunk c (MFMA steps 2c, 2c + 1): [0] = step 2c, [1] = step 2c + 1
+    auto load_frags = [&](const float* st, int c, float (&a)[2][TM], float (&b)[2][TN]) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + (fa[tm] ^ (c << 2)));
+            a[0][tm] = h ? v.y : v.x;  // k = 4c + h
+            a[1][tm] = h ? v.w : v.z;  // k = 4c + 2 + h
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            if (B_NT) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(st + (fb[tn] ^ (c << 2)));
+                b[0][tn] = h ? v.y : v.x;
+                b[1][tn] = h ? v.w : v.z;
+            } else {
+                b[0][tn] = st[fb[tn] + (4 * c) * BN];
+                b[1][tn] = st[fb[tn] + (4 * c + 2) * BN];
+            }
+        }
+    };
+    auto compute = [&](const float* st) {
+        float a[2][2][TM], b[2][2][TN];  // [buffer][step][tile]
+        load_frags(st, 0, a[0], b[0]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // the reads of chunk c + 1 are issued BEFORE the MFMAs of chunk c (a wavefront issues in order: reads placed
+            // after the MFMAs only leave once the matrix pipe has accepted all of them, and their latency is then exposed)
+            if (c + 1 < 4) load_frags(st, c + 1, a[(c + 1) & 1], b[(c + 1) & 1]);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(a[c & 1][j][tm], b[c & 1][j][tn], acc[tm][tn]);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- main loop, unrolled by the ring depth so that stage bases are immediates ---------------------------------------
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+            const int kt = kt0 + s;
+            if (kt < nk) {
+                // tile kt has landed when at most the loads of the STAGES - 2 tiles issued after it are outstanding
+                if (kt + STAGES - 2 <= nk - 1)
+                    wait_vm_and_barrier<(STAGES - 2) * NI>();
+                else
+                    wait_vm_and_barrier<0>();
+                // every wavefront is past tile kt - 1: its stage is free for tile kt + STAGES - 1
+                if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+                compute(smem + s * ST_FL);
+            }
+        }
+    }
+
+    // ---- epilogue: bias / activation / cross / folded activation derivative ---------------------------------------------
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + l31;
+        if (col >= N) continue;
+        const float bv = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float v = acc[tm][tn][r] + bv;
+                    if (ep.x0) v = ep.x0[row * ep.ld_x0 + col] * v + ep.xres[row * ep.ld_x0 + col];
+                    v = act_apply(v, ep.act);
+                    if (ep.x_act == MH_ACT_RELU) {
+                        v = (ep.maskx[row * ep.ldm + col] > 0.f) ? v : 0.f;
+                    } else if (ep.x_act == MH_ACT_SIGMOID) {
+                        const float xx = ep.maskx[row * ep.ldm + col];
+                        v *= xx * (1.f - xx);
+                    }
+                    C[row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true>
+inline hipError_t launch(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int N, int K, float* C,
+                         int64_t ldc, const Epilogue& ep, hipStream_t s) {
+    auto kern = gemm2_kernel<BM, BN, WM, WN, B_NT, STAGES, PIPE>;
+    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(float);
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int ncol = (int)((N + BN - 1) / BN);
+    const int64_t nrow = (M + BM - 1) / BM;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrow * ncol)), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, M, N, K, C, ldc, ep, ncol);
+    return hipGetLastError();
+}
+
+}  // namespace mhgemm2

@@ -6,7 +6,10 @@
 // (it is L2-resident: <= 212 KB on the DLRM config), x is read exactly once, y written once.
 // Roofline: bytes = 4(MK + KN + MN), flops = 2MKN; layers with K,N >= 128 sit above the fp32
 // ridge (157 TF / 8 TB/s ~ 20 flop/B), K = 13 / N <= 64 layers are HBM-bound.
+#include <stdlib.h>
+
 #include "mh_gemm_core.h"
+#include "mh_gemm2.h"
 
 using namespace mhgemm;
 
@@ -169,6 +172,24 @@ int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const fl
                            int act, float* y, int64_t ldy, const float* x0, const float* xres, hipStream_t s) {
     const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
     const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
+    // Second-generation core (mh_gemm2.h: DMA tiles, 3-deep ring, 64x64 per wavefront, column tiles fastest) for the wide
+    // layers: DCN cross 3344 x 3344 112 -> 131 TF, 3344 -> 512 105 -> 116 TF, 512 -> 256 91 -> 95 TF (tools/exp/gemm_lab).
+    // One column tile (N <= 128) gains nothing: those layers are bound per workgroup, not by the loop (profiles/r2_notes.md).
+    static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
+    if (!no_v2 && vec_x && vec_w && N >= 256 && K >= 64 && K % 4 == 0) {
+        mhgemm2::Epilogue ep{};
+        ep.bias = b;
+        ep.act = act;
+        ep.x0 = x0;
+        ep.xres = xres;
+        ep.ld_x0 = N;
+        const hipError_t e = mhgemm2::launch<256, 128, 4, 2, false, 3>(x, ldx, W, N, M, N, K, y, ldy, ep, s);
+        if (e != hipSuccess) {
+            mh_set_error("mh_linear_bias_act_fwd: launch failed: %s", hipGetErrorString(e));
+            return MH_ERR_LAUNCH;
+        }
+        return MH_OK;
+    }
     if (N > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(N, 128));
         hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);

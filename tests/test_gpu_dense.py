@@ -150,3 +150,42 @@ def test_fused_segment_equals_unfused_pair_bitwise_long_runs(device, idt):
     dx_ref = ops.dot_interaction_backward(stack, dout, dense_slot, D)
     dx = ops.dlrm_interaction_fused_backward(slot_tabs, slot_ids, dense, dout)
     assert torch.equal(dx, dx_ref)
+
+
+# ---- second-generation GEMM core (mh_gemm2.h: DMA tiles, 3-deep ring) -- taken for N >= 256, K % 4 == 0 -----------------
+@pytest.mark.parametrize("M,K,N", [(300, 100, 256), (130, 132, 260), (1000, 64, 512), (257, 416, 384), (513, 3344, 256)])
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_wide_linear_matches_oracle_and_first_generation_core(device, M, K, N, act, monkeypatch):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    W = O.glorot_uniform(rng, K, N)
+    b = rng.normal(size=N).astype(np.float32) * 0.1
+    y = ops.linear(_t(x, device), _t(W, device), _t(b, device), act).cpu().numpy()
+    np.testing.assert_allclose(y, O.dense(x, W, b, act), atol=ATOL, rtol=1e-5)
+    # same k-ascending fmaf chain as the C oracle: identical bits (K tail through the zero chunks, M / N tails clamped)
+    y0 = ops.linear(_t(x, device), _t(W, device), None, None).cpu().numpy()
+    np.testing.assert_array_equal(y0, cbind.gemm_nn_fmaf(x, W))
+
+
+def test_wide_linear_strided_operands(device):
+    rng = np.random.default_rng(7)
+    M, K, N = 260, 128, 256
+    big = rng.normal(size=(M, 200)).astype(np.float32)
+    W = O.glorot_uniform(rng, K, N)
+    outb = torch.full((M, 300), -3.0, device=device)
+    ops.linear(_t(big, device)[:, 8:8 + K], _t(W, device), None, "relu", out=outb[:, 12:12 + N])
+    ref = O.dense(big[:, 8:8 + K], W, None, "relu")
+    np.testing.assert_allclose(outb[:, 12:12 + N].cpu().numpy(), ref, atol=ATOL)
+    assert float(outb[:, :12].max()) == -3.0 and float(outb[:, 12 + N:].max()) == -3.0
+
+
+@pytest.mark.parametrize("d", [256, 260, 388])
+def test_wide_cross_layer_matches_oracle(device, d):
+    rng = np.random.default_rng(d)
+    M = 333
+    x0 = rng.normal(size=(M, d)).astype(np.float32)
+    x = rng.normal(size=(M, d)).astype(np.float32)
+    W = O.glorot_uniform(rng, d, d)
+    b = rng.normal(size=d).astype(np.float32) * 0.1
+    y = ops.cross_layer(_t(x0, device), _t(x, device), _t(W, device), _t(b, device)).cpu().numpy()
+    np.testing.assert_allclose(y, O.cross_layer(x0, x, W, b), atol=ATOL, rtol=1e-5)
