@@ -275,4 +275,174 @@ inline hipError_t launch(const float* A, int64_t lda, const float* B, int64_t ld
     return hipGetLastError();
 }
 
+// ---- split-M "TN" product: part[s][K, N] = X[m in slice s][K]^T Z[m in slice s][N]  (dW of a Dense layer) ---------------
+// Both operands are n-major tiles [16 contraction rows][cols] (the B-operand layout of the NN product: odd rows rotated by
+// 8 chunks, fragments are conflict-free ds_read_b32); rows at or past the end of the slice read the zero chunk.  The
+// contraction runs over the batch in ascending row order inside a slice (deterministic); the slices are summed by
+// reduce_partials_kernel.  db_part (optional): column sums of Z per slice, accumulated by the blockIdx.x == 0 workgroups.
+template <int BMO, int BNO, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void gemm2_tn_kernel(const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ Z, int64_t ldz, int64_t M, int K,
+                                                             int N, int64_t rows_per_split, float* __restrict__ part,
+                                                             float* __restrict__ db_part) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BMO / WM / 32, TN = BNO / WN / 32;
+    constexpr int A_FL = BMO * BK, B_FL = BNO * BK, ST_FL = A_FL + B_FL;
+    constexpr int NIA = BMO / 16 / NW, NIB = BNO / 16 / NW;
+    static_assert(NIA >= 1 && NIB >= 1 && (BMO / 16) % NW == 0 && (BNO / 16) % NW == 0, "tile / wavefront mismatch");
+    constexpr int NI = NIA + NIB;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int k0 = blockIdx.x * BMO;  // output row tile (over K)
+    const int n0 = blockIdx.y * BNO;  // output column tile (over N)
+    const int sl = blockIdx.z;
+    const int64_t m_beg = (int64_t)sl * rows_per_split;
+    const int64_t m_end = (m_beg + rows_per_split < M) ? m_beg + rows_per_split : M;
+    const int nk = (int)((m_end - m_beg + BK - 1) / BK);
+
+    // per-lane DMA sources: row (inside a tile) and clamped, rotated column chunk
+    const float* pa[NIA];
+    const float* pb[NIB];
+    int ra[NIA], rb[NIB];
+#pragma unroll
+    for (int j = 0; j < NIA; ++j) {
+        constexpr int CPR = BMO / 4;
+        const int p = (wave + j * NW) * 64 + lane;
+        const int r = p / CPR, pc = p % CPR;
+        int c = k0 + 4 * (pc ^ (8 * (r & 1)));
+        const int clast = (int)((ldx - 4) / 4) * 4;  // chunks past K read the row's padding / next columns: never stored
+        if (c > clast) c = clast;
+        ra[j] = r;
+        pa[j] = X + (m_beg + r) * ldx + c;
+    }
+#pragma unroll
+    for (int j = 0; j < NIB; ++j) {
+        constexpr int CPR = BNO / 4;
+        const int p = (wave + j * NW) * 64 + lane;
+        const int r = p / CPR, pc = p % CPR;
+        int c = n0 + 4 * (pc ^ (8 * (r & 1)));
+        const int clast = (int)((ldz - 4) / 4) * 4;
+        if (c > clast) c = clast;
+        rb[j] = r;
+        pb[j] = Z + (m_beg + r) * ldz + c;
+    }
+    const int64_t nrows = m_end - m_beg;
+    auto issue = [&](int kt) {
+        float* st = smem + (kt % STAGES) * ST_FL;
+        const int64_t r0 = (int64_t)kt * BK;
+#pragma unroll
+        for (int j = 0; j < NIA; ++j) {
+            const float* g = pa[j] + r0 * ldx;
+            if (r0 + ra[j] >= nrows) g = g_zero_chunk;
+            dma16(g, st + (wave + j * NW) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < NIB; ++j) {
+            const float* g = pb[j] + r0 * ldz;
+            if (r0 + rb[j] >= nrows) g = g_zero_chunk;
+            dma16(g, st + A_FL + (wave + j * NW) * 256);
+        }
+    };
+
+    int fa[TM], fb[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int c = wm * TM * 32 + tm * 32 + l31;
+        fa[tm] = h * BMO + ((((c >> 2) ^ (8 * h)) << 2) | (c & 3));  // step s: + 2 s BMO
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int c = wn * TN * 32 + tn * 32 + l31;
+        fb[tn] = A_FL + h * BNO + ((((c >> 2) ^ (8 * h)) << 2) | (c & 3));
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    float dbacc = 0.f;
+    const bool do_db = db_part != nullptr && blockIdx.x == 0 && (int)threadIdx.x < BNO;
+    const int dbc = threadIdx.x;  // column of the Z tile this thread sums
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue(s);
+
+    auto compute = [&](const float* st) {
+        if (do_db) {
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < BK; ++r) cs += st[A_FL + r * BNO + ((((dbc >> 2) ^ (8 * (r & 1))) << 2) | (dbc & 3))];
+            dbacc += cs;
+        }
+#pragma unroll
+        for (int sp = 0; sp < BK / 2; sp += 2) {  // two MFMA steps per round: reads of the round are issued together
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) a[u][tm] = st[fa[tm] + 2 * (sp + u) * BMO];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) b[u][tn] = st[fb[tn] + 2 * (sp + u) * BNO];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(a[u][tm], b[u][tn], acc[tm][tn]);
+        }
+    };
+
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+            const int kt = kt0 + s;
+            if (kt < nk) {
+                if (kt + STAGES - 2 <= nk - 1)
+                    wait_vm_and_barrier<(STAGES - 2) * NI>();
+                else
+                    wait_vm_and_barrier<0>();
+                if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+                compute(smem + s * ST_FL);
+            }
+        }
+    }
+    if (do_db && n0 + dbc < N) db_part[(int64_t)sl * N + n0 + dbc] = dbacc;
+    float* P = part + (int64_t)sl * K * N;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + wn * TN * 32 + tn * 32 + l31;
+        if (col >= N) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = k0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < K) P[(int64_t)row * N + col] = acc[tm][tn][r];
+            }
+    }
+}
+
+template <int BMO, int BNO, int WM, int WN, int STAGES>
+inline hipError_t launch_tn(const float* X, int64_t ldx, const float* Z, int64_t ldz, int64_t M, int K, int N,
+                            int64_t rows_per_split, int splits, float* part, float* db_part, hipStream_t s) {
+    auto kern = gemm2_tn_kernel<BMO, BNO, WM, WN, STAGES>;
+    const size_t lds = (size_t)STAGES * (BMO + BNO) * BK * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((K + BMO - 1) / BMO), (unsigned)((N + BNO - 1) / BNO), (unsigned)splits);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, X, ldx, Z, ldz, M, K, N, rows_per_split, part, db_part);
+    return hipGetLastError();
+}
+
 }  // namespace mhgemm2

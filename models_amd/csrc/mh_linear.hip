@@ -176,7 +176,9 @@ int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const fl
     // layers: DCN cross 3344 x 3344 112 -> 131 TF, 3344 -> 512 105 -> 116 TF, 512 -> 256 91 -> 95 TF (tools/exp/gemm_lab).
     // One column tile (N <= 128) gains nothing: those layers are bound per workgroup, not by the loop (profiles/r2_notes.md).
     static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
-    if (!no_v2 && vec_x && vec_w && N >= 256 && K >= 64 && K % 4 == 0) {
+    // ... and only when the 256 x 128 tiles still give every CU two workgroups (M = 32 K x N = 256 does not: first generation)
+    const bool fills = mh_ceil_div(M, 256) * mh_ceil_div(N, 128) >= 2 * (int64_t)mh_num_cus();
+    if (!no_v2 && fills && vec_x && vec_w && N >= 256 && K >= 64 && K % 4 == 0) {
         mhgemm2::Epilogue ep{};
         ep.bias = b;
         ep.act = act;

@@ -7,7 +7,10 @@
 //   dW[K,N] = x[M,K]^T dz[M,N]             "TN" GEMM, contraction over the batch: split over M
 //                                          into S slices, partial [S,K,N] slabs, fixed-order reduce
 // Every reduction has a fixed order (no float atomics): results are run-to-run deterministic.
+#include <stdlib.h>
+
 #include "mh_gemm_core.h"
+#include "mh_gemm2.h"
 
 using namespace mhgemm;
 
@@ -321,6 +324,20 @@ int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, i
                                  hipStream_t s) {
     const int vec_a = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     const int vec_b = ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0) && (ldb % 4 == 0);
+    static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
+    const bool fills = mh_ceil_div(M, 256) * mh_ceil_div(Nout, 128) >= 2 * (int64_t)mh_num_cus();
+    if (!no_v2 && fills && vec_a && vec_b && Nout >= 256 && Kc >= 256 && Kc % 4 == 0) {  // wide layers: second-generation core
+        mhgemm2::Epilogue ep{};
+        ep.maskx = maskx;
+        ep.ldm = ldm;
+        ep.x_act = maskx ? x_act : MH_ACT_NONE;
+        const hipError_t e = mhgemm2::launch<256, 128, 4, 2, true, 3>(A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, ep, s);
+        if (e != hipSuccess) {
+            mh_set_error("gemm_nt: launch failed: %s", hipGetErrorString(e));
+            return MH_ERR_LAUNCH;
+        }
+        return MH_OK;
+    }
     if (Nout > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(Nout, 128));
         hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
@@ -393,7 +410,17 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
     if (dW) {
         const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
         const int vec_dy = ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (lddy % 4 == 0);
-        if (big_tiles(K, N)) {
+        static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
+        // second-generation core (DMA tiles, 3-deep ring): 415 x 128 211 -> 199 us with dX, 3344 x 3344 27.0 -> 23.7 ms; the
+        // 256 x 128 layer of the two-tower config is faster on the first generation (measured, profiles/r2_notes.md)
+        if (!no_v2 && vec_x && vec_dy && K >= 256 && N >= 128 && (int64_t)K * N >= 49152) {
+            const hipError_t e = mhgemm2::launch_tn<256, 128, 4, 2, 3>(x, ldx, dy, lddy, M, K, N, p.rows_per_split, p.splits,
+                                                                       ws_dw, db ? ws_db : nullptr, s);
+            if (e != hipSuccess) {
+                mh_set_error("mh_linear_bias_act_bwd: launch failed: %s", hipGetErrorString(e));
+                return MH_ERR_LAUNCH;
+            }
+        } else if (big_tiles(K, N)) {
             dim3 grid((unsigned)mh_ceil_div(K, 128), (unsigned)mh_ceil_div(N, 128), (unsigned)p.splits);
             hipLaunchKernelGGL((gemm_tn_splitm_kernel<128, 128>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
                                p.rows_per_split, ws_dw, vec_x, vec_dy, db ? ws_db : nullptr);

@@ -272,3 +272,62 @@ def test_lazy_adam_reproduces_the_reference_known_answers(device):
                                       torch.full((1, 1, D), 0.2, device=device), [0], "adam", o2.learning_rate, o2.epsilon,
                                       [st[3]], o2.beta_1, o2.beta_2, o2.lr_device)
         np.testing.assert_allclose(agg.cpu().numpy(), rep.cpu().numpy(), rtol=1e-6)
+
+
+# ---- second-generation GEMM core in the backward: dX (NT) for K, N >= 256 and dW (split-M TN) for K >= 256, N >= 128 --------
+@pytest.mark.parametrize("M,K,N,ldx", [(513, 300, 260, 300), (700, 415, 128, 416), (1030, 512, 256, 512), (2500, 260, 388, 264)])
+@pytest.mark.parametrize("act,x_act", [(None, None), ("relu", "relu"), ("sigmoid", "sigmoid")])
+def test_wide_linear_backward(device, M, K, N, ldx, act, x_act):
+    g = torch.Generator().manual_seed(M + N + K)
+    x0 = torch.randn(M, K, generator=g)
+    x = R.act(x0, x_act).detach().requires_grad_()  # x is the output of a layer with activation x_act
+    W = (torch.randn(K, N, generator=g) * 0.1).requires_grad_()
+    b = (torch.randn(N, generator=g) * 0.1).requires_grad_()
+    dy = torch.randn(M, N, generator=g)
+    y = R.act(x @ W + b, act)
+    y.backward(dy)
+    buf = torch.zeros(M, ldx)
+    buf[:, :K] = x.detach()
+    xd = buf.to(device)[:, :K]  # ld-padded operand (the interaction output feeding the top MLP has ld 416 for K = 415)
+    yd = ops.linear(xd, W.detach().to(device), b.detach().to(device), act)
+    dx, dW, db = ops.linear_backward(xd, W.detach().to(device), yd, dy.clone().to(device), act, x_activation=x_act)
+    # reference dx folds the producer's derivative: d/dz_prev = (dz W^T) * x_act'(x)
+    gx = x.grad
+    if x_act == "relu":
+        gx = gx * (x.detach() > 0)
+    elif x_act == "sigmoid":
+        gx = gx * x.detach() * (1 - x.detach())
+    tol = dict(atol=3e-4 * max(1.0, M / 256) ** 0.5, rtol=1e-4)
+    torch.testing.assert_close(dx.cpu(), gx, atol=2e-4, rtol=1e-4)
+    torch.testing.assert_close(dW.cpu(), W.grad, **tol)
+    torch.testing.assert_close(db.cpu(), b.grad, **tol)
+
+
+def test_wide_backward_equals_first_generation_core(device):
+    """y and dX are bit-identical between the two GEMM cores (one k-ascending chain per output); dW sums the same slices
+    of the batch in the same row order -> identical too; db groups its partial sums differently."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import torch, sys
+        from models_amd import ops
+        g = torch.Generator().manual_seed(5)
+        M, K, N = 1500, 512, 384
+        x = torch.randn(M, K, generator=g).cuda(); W = (torch.randn(K, N, generator=g) * 0.1).cuda()
+        dy = torch.randn(M, N, generator=g).cuda()
+        y = ops.linear(x, W, None, "relu")
+        dx, dW, db = ops.linear_backward(x, W, y, dy, "relu")
+        torch.save([y.cpu(), dx.cpu(), dW.cpu(), db.cpu()], sys.argv[1])
+    ''')
+    import os, tempfile
+    outs = []
+    for v1 in (False, True):
+        env = dict(os.environ)
+        env.pop("MERLIN_HIP_GEMM_V1", None)
+        if v1:
+            env["MERLIN_HIP_GEMM_V1"] = "1"
+        with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+            outs.append(torch.load(f.name))
+    (y0, dx0, dW0, db0), (y1, dx1, dW1, db1) = outs
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dW0, dW1)
+    torch.testing.assert_close(db0, db1, atol=1e-4, rtol=1e-5)  # column sums: 16- vs 32-row partial sums per k-tile
