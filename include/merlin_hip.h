@@ -247,6 +247,12 @@ int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int
  * (DenseMaybeLowRank, blocks/mlp.py:304-396, low_rank_dim=None). x0, x, out: [M, d]. */
 int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, const float* b,
                            int64_t M, int32_t d, float* out, mh_stream_t stream);
+/* The same layer under a gradient tape (BaseModel.train_step, models/base.py:1121-1174): additionally stores
+ * p = x W + b into p_out [M, d]; the backward needs it (d loss / d x0 = dout * p) and would otherwise recompute the
+ * whole d x d product (11 ms per layer at d = 3344, B = 64 K). */
+int32_t mh_cross_layer_fwd_save(const float* x0, const float* x, const float* W, const float* b, int64_t M, int32_t d,
+                                float* out, float* p_out, mh_stream_t stream);
+
 /* Low-rank form W = U V (DCN-v2 Eq. 2; DenseMaybeLowRank with low_rank_dim = r, blocks/mlp.py:365-396):
  * h[M, r] = x U comes from mh_linear_bias_act_fwd (no bias, no activation); this call finishes the layer,
  * out = x0 * (h V + b) + x with V[r, d].  All matrices contiguous. */

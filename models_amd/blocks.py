@@ -120,6 +120,22 @@ class _Dense(Block):
 
 
 _CHAIN_OK: dict = {}
+_TAPE = [0]
+
+
+class tape:
+    """``with tape():`` -- the forward inside runs for a backward (the role of ``tf.GradientTape`` in
+    BaseModel.train_step, models/base.py:1121-1174): layers keep what their backward would otherwise recompute
+    (the cross layer's p = x W + b: one extra [B, d] store instead of a second d x d product)."""
+
+    def __enter__(self):
+        _TAPE[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _TAPE[0] -= 1
+        return False
+
 
 
 def _chain_supported(dims) -> bool:
@@ -507,7 +523,11 @@ class Cross(Block):
         d, d4 = self.d, self.d4
         x0w, xw = _widen(x0, d4), _widen(x, d4)
         self._x0, self._x = x0w, xw
+        self._p = None
         if self.kernel_u is None:
+            if _TAPE[0] > 0:
+                out, self._p = ops.cross_layer(x0w, xw, self.kernel.data, self.bias.data, save_p=True)
+                return out[:, :d]
             return ops.cross_layer(x0w, xw, self.kernel.data, self.bias.data)[:, :d]
         self._h = ops.linear(xw, self.kernel_u.data, None, None)  # [B, r4], pad columns exactly zero
         return ops.cross_layer_lowrank(x0w, xw, self._h, self.kernel.data, self.bias.data)[:, :d]
@@ -518,7 +538,10 @@ class Cross(Block):
         d, d4 = self.d, self.d4
         dout = _widen(dout, d4)
         src = x if self.kernel_u is None else self._h
-        p = ops.linear(src, self.kernel.data, self.bias.data, None)  # recomputed, not stored
+        p = getattr(self, "_p", None)  # stored by the forward under blocks.tape() ...
+        if p is None:
+            p = ops.linear(src, self.kernel.data, self.bias.data, None)  # ... recomputed otherwise
+        self._p = None
         dx0 = ops.eltwise("mul", dout, p)
         g = ops.eltwise("mul", dout, x0)                             # d loss / d p
         dsrc, dW, db = ops.linear_backward(src, self.kernel.data, None, g, None, need_dx=True, need_db=True)

@@ -29,6 +29,8 @@ struct Epilogue {
     const float* x0;    // DCN-v2 cross epilogue (blocks/cross.py:188-202): out = x0 * (.) + xres, both [M, ld_x0]
     const float* xres;
     int64_t ld_x0;
+    float* p_out;  // cross layer under a gradient tape: also store p = x W + b ([M, ldp]) -- the backward needs it (dx0 = dout * p)
+    int64_t ldp;
     const float* maskx;  // dX: the producer's activation derivative folded in (x_act of mh_linear_bias_act_bwd)
     int64_t ldm;
     int x_act;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
                 const int64_t row = row0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row < M) {
                     float v = acc[tm][tn][r] + bv;
+                    if (ep.p_out) ep.p_out[row * ep.ldp + col] = v;
                     if (ep.x0) v = ep.x0[row * ep.ld_x0 + col] * v + ep.xres[row * ep.ld_x0 + col];
                     v = act_apply(v, ep.act);
                     if (ep.x_act == MH_ACT_RELU) {

@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256) void linear_small_n_kernel(const float* __rest
 
 }  // namespace
 
+bool mh_internal_linear_v2(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N, int act,
+                           float* y, int64_t ldy, const float* x0, const float* xres, float* p_out, hipStream_t s);
+
 extern "C" {
 
 int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, const float* b,
@@ -158,6 +161,19 @@ int32_t mh_cross_layer_fwd(const float* x0, const float* x, const float* W, cons
     return mh_internal_linear(x, d, W, b, M, d, d, MH_ACT_NONE, out, d, x0, x, mh_stream(stream));
 }
 
+int32_t mh_cross_layer_fwd_save(const float* x0, const float* x, const float* W, const float* b, int64_t M, int32_t d,
+                                float* out, float* p_out, mh_stream_t stream) {
+    MH_REQUIRE(x0 && x && W && out && p_out, "mh_cross_layer_fwd_save: null argument");
+    MH_REQUIRE(M >= 0 && d >= 5, "mh_cross_layer_fwd_save: bad shape M=%lld d=%d (d must be > 4)", (long long)M, d);
+    if (M == 0) return MH_OK;
+    hipStream_t s = mh_stream(stream);
+    if (mh_internal_linear_v2(x, d, W, b, M, d, d, MH_ACT_NONE, out, d, x0, x, p_out, s)) return MH_OK;
+    // first-generation core: p = x W + b as a plain product, then the cross as one elementwise pass
+    const int32_t st = mh_internal_linear(x, d, W, b, M, d, d, MH_ACT_NONE, p_out, d, nullptr, nullptr, s);
+    if (st != MH_OK) return st;
+    return mh_eltwise(2, x0, p_out, x, out, M * (int64_t)d, stream);
+}
+
 int32_t mh_cross_layer_lowrank_fwd(const float* x0, const float* x, const float* h, const float* V, const float* b,
                                    int64_t M, int32_t d, int32_t r, float* out, mh_stream_t stream) {
     MH_REQUIRE(x0 && x && h && V && out, "mh_cross_layer_lowrank_fwd: null argument");
@@ -168,30 +184,34 @@ int32_t mh_cross_layer_lowrank_fwd(const float* x0, const float* x, const float*
 
 }  // extern "C"
 
+// Second-generation core (mh_gemm2.h: DMA tiles, 3-deep ring, 64x64 per wavefront, column tiles fastest) for the wide
+// layers: DCN cross 3344 x 3344 112 -> 131 TF, 3344 -> 512 105 -> 116 TF, 512 -> 256 91 -> 95 TF (tools/exp/gemm_lab).
+// One column tile (N <= 128) gains nothing: those layers are bound per workgroup, not by the loop (profiles/r2_notes.md);
+// and the 256 x 128 tiles must still give every CU two workgroups (M = 32 K x N = 256 does not: first generation).
+// Returns false when the shape / alignment is not eligible (the caller then takes the first-generation kernels).
+bool mh_internal_linear_v2(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N, int act,
+                           float* y, int64_t ldy, const float* x0, const float* xres, float* p_out, hipStream_t s) {
+    static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
+    const bool vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
+    const bool vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
+    const bool fills = mh_ceil_div(M, 256) * mh_ceil_div(N, 128) >= 2 * (int64_t)mh_num_cus();
+    if (no_v2 || !fills || !vec_x || !vec_w || N < 256 || K < 64 || K % 4 != 0) return false;
+    mhgemm2::Epilogue ep{};
+    ep.bias = b;
+    ep.act = act;
+    ep.x0 = x0;
+    ep.xres = xres;
+    ep.ld_x0 = N;
+    ep.p_out = p_out;
+    ep.ldp = N;
+    return mhgemm2::launch<256, 128, 4, 2, false, 3>(x, ldx, W, N, M, N, K, y, ldy, ep, s) == hipSuccess;
+}
+
 int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int K, int N,
                            int act, float* y, int64_t ldy, const float* x0, const float* xres, hipStream_t s) {
     const int vec_x = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (ldx % 4 == 0);
     const int vec_w = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (N % 4 == 0);
-    // Second-generation core (mh_gemm2.h: DMA tiles, 3-deep ring, 64x64 per wavefront, column tiles fastest) for the wide
-    // layers: DCN cross 3344 x 3344 112 -> 131 TF, 3344 -> 512 105 -> 116 TF, 512 -> 256 91 -> 95 TF (tools/exp/gemm_lab).
-    // One column tile (N <= 128) gains nothing: those layers are bound per workgroup, not by the loop (profiles/r2_notes.md).
-    static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
-    // ... and only when the 256 x 128 tiles still give every CU two workgroups (M = 32 K x N = 256 does not: first generation)
-    const bool fills = mh_ceil_div(M, 256) * mh_ceil_div(N, 128) >= 2 * (int64_t)mh_num_cus();
-    if (!no_v2 && fills && vec_x && vec_w && N >= 256 && K >= 64 && K % 4 == 0) {
-        mhgemm2::Epilogue ep{};
-        ep.bias = b;
-        ep.act = act;
-        ep.x0 = x0;
-        ep.xres = xres;
-        ep.ld_x0 = N;
-        const hipError_t e = mhgemm2::launch<256, 128, 4, 2, false, 3>(x, ldx, W, N, M, N, K, y, ldy, ep, s);
-        if (e != hipSuccess) {
-            mh_set_error("mh_linear_bias_act_fwd: launch failed: %s", hipGetErrorString(e));
-            return MH_ERR_LAUNCH;
-        }
-        return MH_OK;
-    }
+    if (mh_internal_linear_v2(x, ldx, W, b, M, K, N, act, y, ldy, x0, xres, nullptr, s)) return MH_OK;
     if (N > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(N, 128));
         hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);

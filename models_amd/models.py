@@ -13,6 +13,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from .blocks import tape as blocks_tape
 from . import ops, optim
 from .blocks import CrossBlock, DLRMBlock, MLPBlock, TwoTowerBlock, _Dense
 from .core import Block, ConcatFeatures, ParallelBlock, SequentialBlock, TabularData, call_layer
@@ -243,7 +244,8 @@ class RankingModel(Model):
             self.compile()
         x = prepare_features(inputs)
         fused_head = bool(getattr(self.body, "accepts_head", False))
-        p = self._predict(x)
+        with blocks_tape():
+            p = self._predict(x)
         self.optimizer.ensure_begun(p.device)
         loss, dlogit = self.output.loss_and_grad(p, targets)
         div = getattr(self, "loss_grad_divisor", 1)

@@ -941,8 +941,9 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
     return scores, ids, idx
 
 
-def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    """DCN-v2 cross layer ``x0 * (x @ W + b) + x`` (full-rank W [d, d])."""
+def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], save_p: bool = False):
+    """DCN-v2 cross layer ``x0 * (x @ W + b) + x`` (full-rank W [d, d]).  ``save_p``: also return ``p = x @ W + b``
+    (what the backward multiplies the incoming gradient with), stored by the same kernel."""
     lib = _lib.load()
     for n_, t in (("x0", x0), ("x", x), ("W", W)):
         _dev(t, n_, torch.float32)
@@ -950,6 +951,12 @@ def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[
             raise ValueError(f"{n_} must be contiguous 2-D")
     M, d = x.shape
     out = torch.empty_like(x)
+    if save_p:
+        p = torch.empty_like(x)
+        with _timed(f"cross_{d}", nbytes=4 * (5 * M * d + d * d), flops=2 * M * d * d):
+            check(lib.mh_cross_layer_fwd_save(_ptr(x0), _ptr(x), _ptr(W), _ptr(b), M, d, _ptr(out), _ptr(p), _stream()),
+                  "mh_cross_layer_fwd_save")
+        return out, p
     with _timed(f"cross_{d}", nbytes=4 * (4 * M * d + d * d), flops=2 * M * d * d):
         check(lib.mh_cross_layer_fwd(_ptr(x0), _ptr(x), _ptr(W), _ptr(b), M, d, _ptr(out), _stream()), "mh_cross_layer_fwd")
     return out

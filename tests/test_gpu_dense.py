@@ -189,3 +189,16 @@ def test_wide_cross_layer_matches_oracle(device, d):
     b = rng.normal(size=d).astype(np.float32) * 0.1
     y = ops.cross_layer(_t(x0, device), _t(x, device), _t(W, device), _t(b, device)).cpu().numpy()
     np.testing.assert_allclose(y, O.cross_layer(x0, x, W, b), atol=ATOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,d", [(333, 260), (44032, 260)])  # small: first-generation fallback; large: fused store of p
+def test_cross_layer_with_saved_preactivation(device, M, d):
+    rng = np.random.default_rng(d + M)
+    x0 = _t(rng.normal(size=(M, d)).astype(np.float32), device)
+    x = _t(rng.normal(size=(M, d)).astype(np.float32), device)
+    W = _t(O.glorot_uniform(rng, d, d), device)
+    b = _t(rng.normal(size=d).astype(np.float32) * 0.1, device)
+    out, p = ops.cross_layer(x0, x, W, b, save_p=True)
+    assert torch.equal(p, ops.linear(x, W, b, None))           # p = x W + b, the same fmaf chains
+    torch.testing.assert_close(out, ops.cross_layer(x0, x, W, b), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(out, x0 * p + x, atol=1e-5, rtol=1e-5)
