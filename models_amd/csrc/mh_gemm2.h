@@ -17,24 +17,13 @@
 // 16-byte chunks at or past K of the last k-tile are fetched from a zero buffer for BOTH operands), 16-byte aligned rows
 // (lda % 4 == 0, and ldb % 4 == 0 / N % 4 == 0 for the n-contiguous B), K >= 4, N >= 4.
 #pragma once
-#include "mh_common.h"
+#include "mh_gemm_core.h"
 
 namespace mhgemm2 {
 
-constexpr int BK = 16;
+constexpr int BK = 16;  // default k-tile (the split-M TN kernel); gemm2_kernel takes it as a template parameter
 
-struct Epilogue {
-    const float* bias;  // [N] or NULL
-    int act;            // MH_ACT_*
-    const float* x0;    // DCN-v2 cross epilogue (blocks/cross.py:188-202): out = x0 * (.) + xres, both [M, ld_x0]
-    const float* xres;
-    int64_t ld_x0;
-    float* p_out;  // cross layer under a gradient tape: also store p = x W + b ([M, ldp]) -- the backward needs it (dx0 = dout * p)
-    int64_t ldp;
-    const float* maskx;  // dX: the producer's activation derivative folded in (x_act of mh_linear_bias_act_bwd)
-    int64_t ldm;
-    int x_act;
-};
+using Epilogue = mhgemm::EpiArgs;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -55,29 +44,31 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == MH_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == MH_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    return v;
+
+// k-major LDS tile [ROWS][BKT k], CH = BKT / 4 chunks of 16 bytes per row: chunk c (k = 4c .. 4c+3) of row r sits at chunk
+// position CH r + (c ^ swz(r)) with swz(r) = (r >> 2) & 3 (CH = 4) or (r >> 1) & 7 (CH = 8): the 16 lanes of a quarter
+// wavefront (consecutive rows) then hit 16 distinct 4-bank groups on ds_read_b128.
+template <int CH>
+__device__ __forceinline__ int kmajor_swz(int r) {
+    return CH == 4 ? ((r >> 2) & 3) : ((r >> 1) & 7);
+}
+template <int CH>
+__device__ __forceinline__ int kmajor_src_chunk(int p) {  // chunk position -> source chunk c of row p / CH
+    return (p % CH) ^ kmajor_swz<CH>(p / CH);
 }
 
-// k-major LDS tile [ROWS][16 k]: 16-byte chunk c (k = 4c .. 4c+3) of row r sits at chunk position 4 r + (c ^ ((r >> 2) & 3)):
-// the 16 lanes of a quarter wavefront (consecutive rows) then hit 16 distinct 4-bank groups on ds_read_b128.
-__device__ __forceinline__ int kmajor_src_chunk(int p) {  // chunk position -> source chunk c of row p >> 2
-    const int r = p >> 2;
-    return (p & 3) ^ ((r >> 2) & 3);
-}
-
-template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true>
+template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb, int64_t M, int N, int K,
                                                           float* __restrict__ C, int64_t ldc, const Epilogue ep,
                                                           int ncol_tiles) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int BK = BKT, CH = BKT / 4;
+    static_assert(BKT == 16 || BKT == 32, "k-tile");
     constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;
-    constexpr int NIA = BM / 16 / NW, NIB = BN / 16 / NW;  // DMA wave-instructions (1 KiB each) per wavefront per tile
-    static_assert(NIA >= 1 && NIB >= 1 && (BM / 16) % NW == 0 && (BN / 16) % NW == 0, "tile / wavefront mismatch");
+    constexpr int NIA = BM * CH / 64 / NW, NIB = BN * CH / 64 / NW;  // DMA wave-instructions (1 KiB each) per wavefront per tile
+    static_assert(NIA >= 1 && NIB >= 1 && (BM * CH / 64) % NW == 0 && (BN * CH / 64) % NW == 0, "tile / wavefront mismatch");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int NI = NIA + NIB;
     extern __shared__ __attribute__((aligned(1024))) float smem[];
@@ -97,17 +88,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < NIA; ++j) {
         const int p = (wave + j * NW) * 64 + lane;
-        int64_t row = row0 + (p >> 2);
+        int64_t row = row0 + p / CH;
         if (row > M - 1) row = M - 1;
-        pa[j] = A + row * lda + 4 * kmajor_src_chunk(p);
+        pa[j] = A + row * lda + 4 * kmajor_src_chunk<CH>(p);
     }
 #pragma unroll
     for (int j = 0; j < NIB; ++j) {
         const int p = (wave + j * NW) * 64 + lane;
         if (B_NT) {
-            int n = n0 + (p >> 2);
+            int n = n0 + p / CH;
             if (n > N - 1) n = N - 1;
-            pb[j] = B + (int64_t)n * ldb + 4 * kmajor_src_chunk(p);
+            pb[j] = B + (int64_t)n * ldb + 4 * kmajor_src_chunk<CH>(p);
         } else {
             // n-major tile [16 k][BN]: chunk position p = k * (BN/4) + pc holds source chunk pc ^ (8 (k & 1)): the two
             // k-slots of an MFMA step (rows k, k+1) read 32 consecutive floats each, 32 banks apart
@@ -123,11 +114,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
     // k offset (inside a tile) of the chunk each DMA lane fetches: chunks at or past K read g_zero_chunk (last tile only)
     int ka[NIA], kb[NIB];
 #pragma unroll
-    for (int j = 0; j < NIA; ++j) ka[j] = 4 * kmajor_src_chunk((wave + j * NW) * 64 + lane);
+    for (int j = 0; j < NIA; ++j) ka[j] = 4 * kmajor_src_chunk<CH>((wave + j * NW) * 64 + lane);
 #pragma unroll
     for (int j = 0; j < NIB; ++j) {
         const int p = (wave + j * NW) * 64 + lane;
-        kb[j] = B_NT ? 4 * kmajor_src_chunk(p) : p / (BN / 4);
+        kb[j] = B_NT ? 4 * kmajor_src_chunk<CH>(p) : p / (BN / 4);
     }
     auto issue = [&](int kt) {
         float* st = smem + (kt % STAGES) * ST_FL;
@@ -152,13 +143,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int r = wm * TM * 32 + tm * 32 + l31;
-        fa[tm] = r * 16 + (((r >> 2) & 3) << 2);  // chunk c of this row: fa ^ (c << 2)
+        fa[tm] = r * BK + (kmajor_swz<CH>(r) << 2);  // chunk c of this row: fa ^ (c << 2)
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = wn * TN * 32 + tn * 32 + l31;
         if (B_NT)
-            fb[tn] = A_FL + n * 16 + (((n >> 2) & 3) << 2);
+            fb[tn] = A_FL + n * BK + (kmajor_swz<CH>(n) << 2);
         else
             fb[tn] = A_FL + h * BN + ((((n >> 2) ^ (8 * h)) << 2) | (n & 3));  // step s: + 2 s BN
     }
@@ -200,10 +191,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
         float a[2][2][TM], b[2][2][TN];  // [buffer][step][tile]
         load_frags(st, 0, a[0], b[0]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CH; ++c) {
             // the reads of chunk c + 1 are issued BEFORE the MFMAs of chunk c (a wavefront issues in order: reads placed
             // after the MFMAs only leave once the matrix pipe has accepted all of them, and their latency is then exposed)
-            if (c + 1 < 4) load_frags(st, c + 1, a[(c + 1) & 1], b[(c + 1) & 1]);
+            if (c + 1 < CH) load_frags(st, c + 1, a[(c + 1) & 1], b[(c + 1) & 1]);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -227,46 +218,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
                 else
                     wait_vm_and_barrier<0>();
                 // every wavefront is past tile kt - 1: its stage is free for tile kt + STAGES - 1
-                if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
-                compute(smem + s * ST_FL);
+                // ABLATE (tools/exp/gemm_lab only): 1 = no tile loads after the prologue, 2 = no MFMAs -- which side bounds the loop
+                if (ABLATE != 1 && kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+                if (ABLATE != 2) compute(smem + s * ST_FL);
             }
         }
     }
 
-    // ---- epilogue: bias / activation / cross / folded activation derivative ---------------------------------------------
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + wn * TN * 32 + tn * 32 + l31;
-        if (col >= N) continue;
-        const float bv = ep.bias ? ep.bias[col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M) {
-                    float v = acc[tm][tn][r] + bv;
-                    if (ep.p_out) ep.p_out[row * ep.ldp + col] = v;
-                    if (ep.x0) v = ep.x0[row * ep.ld_x0 + col] * v + ep.xres[row * ep.ld_x0 + col];
-                    v = act_apply(v, ep.act);
-                    if (ep.x_act == MH_ACT_RELU) {
-                        v = (ep.maskx[row * ep.ldm + col] > 0.f) ? v : 0.f;
-                    } else if (ep.x_act == MH_ACT_SIGMOID) {
-                        const float xx = ep.maskx[row * ep.ldm + col];
-                        v *= xx * (1.f - xx);
-                    }
-                    C[row * ldc + col] = v;
-                }
-            }
-        }
-    }
+    // ---- epilogue: bias / activation / cross / folded activation derivative (mh_gemm_core.h) -------------------------------
+    mhgemm::store_tile<TM, TN>(acc, C, ldc, row0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane, ep);
 }
 
-template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true>
+template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>
 inline hipError_t launch(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int N, int K, float* C,
                          int64_t ldc, const Epilogue& ep, hipStream_t s) {
-    auto kern = gemm2_kernel<BM, BN, WM, WN, B_NT, STAGES, PIPE>;
-    const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(float);
+    auto kern = gemm2_kernel<BM, BN, WM, WN, B_NT, STAGES, PIPE, BKT, ABLATE>;
+    const size_t lds = (size_t)STAGES * (BM + BN) * BKT * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -212,6 +212,117 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 }
 
+// ---- epilogue shared by every GEMM kernel (both cores) ----------------------------------------------------------------
+// out = x_act'(maskx) * act( [x0 * (acc + bias) + xres]  or  (acc + bias) ),  optionally p_out = acc + bias.
+struct EpiArgs {
+    const float* bias;  // [N] or NULL
+    int act;            // MH_ACT_*
+    const float* x0;    // DCN-v2 cross epilogue (blocks/cross.py:188-202): out = x0 * (.) + xres, both [M, ld_x0]
+    const float* xres;
+    int64_t ld_x0;
+    float* p_out;  // cross layer under a gradient tape: also store p = x W + b ([M, ldp]) -- the backward needs it (dx0 = dout * p)
+    int64_t ldp;
+    const float* maskx;  // dX: the producer's activation derivative folded in (x_act of mh_linear_bias_act_bwd)
+    int64_t ldm;
+    int x_act;
+};
+
+template <int A>
+struct EpiTag {
+    static constexpr int value = A;
+};
+template <bool B>
+struct EpiFlag {
+    static constexpr bool value = B;
+};
+
+__device__ __forceinline__ float epi_act(float v, int act) {
+    if (act == MH_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MH_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+// A wavefront's TM x TN grid of 32x32 accumulators -> C.  The common cases (Dense forward: bias + activation; dX: optional
+// relu mask) on a tile without ragged edges run a loop body specialised on the activation with row pointers advanced by
+// additions and the column tiles as immediate offsets: the generic body costs ~25 scalar / vector instructions per element
+// (runtime activation tests, 64-bit row * ld products, bounds tests) -- with one workgroup generation per CU and all of
+// them in lockstep that was ~10 us of an 80 us skinny-layer GEMM during which no MFMA issues.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restrict__ C, int64_t ldc, int64_t row_base,
+                                           int col_base, int64_t M, int N, int lane, const EpiArgs& ep) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const bool full = row_base + TM * 32 <= M && col_base + TN * 32 <= N;  // uniform per wavefront
+    const bool plain = !ep.x0 && !ep.p_out && (ep.x_act == MH_ACT_NONE || (ep.x_act == MH_ACT_RELU && !ep.bias && ep.act == MH_ACT_NONE));
+    if (full && plain) {
+        float bv[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bv[tn] = ep.bias ? ep.bias[col_base + tn * 32 + l31] : 0.f;
+        float* p0 = C + (row_base + 4 * h) * ldc + col_base + l31;
+        const int64_t ld8 = 8 * ldc;
+        auto body = [&](auto act_tag, auto mask_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool MASK = decltype(mask_tag)::value;
+            const float* m0 = MASK ? ep.maskx + (row_base + 4 * h) * ep.ldm + col_base + l31 : nullptr;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                float* pg = p0 + (int64_t)tm * 32 * ldc;
+                const float* mg = MASK ? m0 + (int64_t)tm * 32 * ep.ldm : nullptr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float* pr = pg;
+                    const float* mr = mg;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) {
+                            float v = acc[tm][tn][4 * g + q] + bv[tn];
+                            if (ACT == MH_ACT_RELU) v = v > 0.f ? v : 0.f;
+                            if (ACT == MH_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                            if (MASK) v = (mr[32 * tn] > 0.f) ? v : 0.f;
+                            pr[32 * tn] = v;
+                        }
+                        pr += ldc;
+                        if (MASK) mr += ep.ldm;
+                    }
+                    pg += ld8;
+                    if (MASK) mg += 8 * ep.ldm;
+                }
+            }
+        };
+        if (ep.x_act == MH_ACT_RELU) body(EpiTag<MH_ACT_NONE>{}, EpiFlag<true>{});
+        else if (ep.act == MH_ACT_RELU) body(EpiTag<MH_ACT_RELU>{}, EpiFlag<false>{});
+        else if (ep.act == MH_ACT_SIGMOID) body(EpiTag<MH_ACT_SIGMOID>{}, EpiFlag<false>{});
+        else body(EpiTag<MH_ACT_NONE>{}, EpiFlag<false>{});
+        return;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = col_base + tn * 32 + l31;
+        if (col >= N) continue;
+        const float bv = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) {
+                    float v = acc[tm][tn][r] + bv;
+                    if (ep.p_out) ep.p_out[row * ep.ldp + col] = v;
+                    if (ep.x0) v = ep.x0[row * ep.ld_x0 + col] * v + ep.xres[row * ep.ld_x0 + col];
+                    v = epi_act(v, ep.act);
+                    if (ep.x_act == MH_ACT_RELU) {
+                        v = (ep.maskx[row * ep.ldm + col] > 0.f) ? v : 0.f;
+                    } else if (ep.x_act == MH_ACT_SIGMOID) {
+                        const float xx = ep.maskx[row * ep.ldm + col];
+                        v *= xx * (1.f - xx);
+                    }
+                    C[row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 __device__ __forceinline__ int acc_col(int lane) { return lane & 31; }

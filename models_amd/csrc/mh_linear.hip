@@ -72,25 +72,13 @@ __global__ __launch_bounds__(WM * WN * 64) void linear_fwd_kernel(const float* _
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + wn * TN * 32 + tn * 32 + acc_col(lane);
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
-                if (row < M) {
-                    float v = acc[tm][tn][r] + bv;
-                    // DCN-v2 cross epilogue (blocks/cross.py:188-202): x0 * (x W + b) + x
-                    if (x0) v = x0[row * (int64_t)N + col] * v + xres[row * (int64_t)N + col];
-                    y[row * ldy + col] = apply_act(v, act);
-                }
-            }
-        }
-    }
+    EpiArgs ep{};
+    ep.bias = bias;
+    ep.act = act;
+    ep.x0 = x0;
+    ep.xres = xres;
+    ep.ld_x0 = N;
+    store_tile<TM, TN>(acc, y, ldy, row0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane, ep);
 }
 
 // N <= 4 heads (e.g. BinaryOutput's Dense(1, sigmoid), outputs/classification.py:114):

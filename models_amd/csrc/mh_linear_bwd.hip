@@ -163,28 +163,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const float* __re
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int col = n0 + wn * TN * 32 + tn * 32 + acc_col(lane);
-        if (col >= Nout) continue;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + wm * TM * 32 + tm * 32 + acc_row(r, lane);
-                if (row < M) {
-                    float v = acc[tm][tn][r];
-                    // fold the producer's activation derivative into dX: x = act(z_prev) is at hand
-                    if (x_act == MH_ACT_RELU) {
-                        v = (maskx[row * ldm + col] > 0.f) ? v : 0.f;
-                    } else if (x_act == MH_ACT_SIGMOID) {
-                        const float xx = maskx[row * ldm + col];
-                        v *= xx * (1.f - xx);
-                    }
-                    Cm[row * ldc + col] = v;
-                }
-            }
-    }
+    // the producer's activation derivative is folded into dX: x = act(z_prev) is at hand (store_tile, mh_gemm_core.h)
+    EpiArgs ep{};
+    ep.maskx = maskx;
+    ep.ldm = ldm;
+    ep.x_act = maskx ? x_act : MH_ACT_NONE;
+    store_tile<TM, TN>(acc, Cm, ldc, row0 + wm * TM * 32, n0 + wn * TN * 32, M, Nout, lane, ep);
 }
 
 // Split-M "TN" GEMM: part[s][K, N] = x[m in slice s][K]^T dz[m in slice s][N].

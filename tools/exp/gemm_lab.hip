@@ -63,11 +63,11 @@ static size_t mismatches(const float* d0, const float* d1, int64_t M, int N, int
     return bad;
 }
 
-template <int BM, int BN, int WM, int WN, bool NT, int STAGES, bool PIPE = true>
+template <int BM, int BN, int WM, int WN, bool NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>
 static void run_variant(const char* name, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int N, int K,
                         float* C, int64_t ldc, const float* ref, int iters) {
     mhgemm2::Epilogue ep{};
-    auto launch = [&]() { mhgemm2::launch<BM, BN, WM, WN, NT, STAGES, PIPE>(A, lda, B, ldb, M, N, K, C, ldc, ep, 0); };
+    auto launch = [&]() { mhgemm2::launch<BM, BN, WM, WN, NT, STAGES, PIPE, BKT, ABLATE>(A, lda, B, ldb, M, N, K, C, ldc, ep, 0); };
     CK(hipMemset(C, 0xff, (size_t)M * ldc * 4));
     launch();
     CK(hipDeviceSynchronize());
@@ -122,14 +122,24 @@ int main(int argc, char** argv) {
         const int64_t lda = K, ldb = sh.nt ? K : N;
         if (sh.nt) {
             run_variant<256, 128, 4, 2, true, 3>("256x128 8w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
-            run_variant<256, 128, 4, 2, true, 3, false>("256x128 8w 3-stage nopipe", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<256, 128, 4, 2, true, 3, true, 32>("256x128 8w 3-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<256, 128, 4, 2, true, 2, true, 32>("256x128 8w 2-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<128, 128, 2, 2, true, 3, true, 32>("128x128 4w 3-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<128, 128, 4, 2, true, 3, true, 32>("128x128 8w 3-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<256, 128, 4, 2, true, 2>("256x128 8w 2-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 128, 2, 2, true, 3>("128x128 4w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 128, 2, 2, true, 4>("128x128 4w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 64, 2, 1, true, 4>("128x64  2w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
         } else {
             run_variant<256, 128, 4, 2, false, 3>("256x128 8w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
-            run_variant<256, 128, 4, 2, false, 3, false>("256x128 8w 3-stage nopipe", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<256, 128, 4, 2, false, 3, true, 16, 1>("256x128 8w 3-stage NO LOADS", A, lda, B, ldb, M, N, K, C1, ldc, nullptr, sh.iters);
+            run_variant<256, 128, 4, 2, false, 3, true, 16, 2>("256x128 8w 3-stage NO MFMA", A, lda, B, ldb, M, N, K, C1, ldc, nullptr, sh.iters);
+            run_variant<128, 128, 2, 2, false, 3, true, 16, 1>("128x128 4w 3-stage NO LOADS", A, lda, B, ldb, M, N, K, C1, ldc, nullptr, sh.iters);
+            run_variant<128, 128, 2, 2, false, 3, true, 16, 2>("128x128 4w 3-stage NO MFMA", A, lda, B, ldb, M, N, K, C1, ldc, nullptr, sh.iters);
+            run_variant<256, 128, 4, 2, false, 3, true, 32>("256x128 8w 3-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<256, 128, 4, 2, false, 2, true, 32>("256x128 8w 2-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<128, 128, 2, 2, false, 3, true, 32>("128x128 4w 3-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            run_variant<128, 128, 4, 2, false, 3, true, 32>("128x128 8w 3-stage BK32", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<256, 128, 4, 2, false, 2>("256x128 8w 2-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 128, 2, 2, false, 3>("128x128 4w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 128, 2, 2, false, 4>("128x128 4w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
