@@ -106,13 +106,14 @@ class _Dense(Block):
                              self.activation, out=out)
         return self._y
 
-    def backward(self, grad, need_dx: bool = True, pre_masked: bool = False, x_activation=None):
+    def backward(self, grad, need_dx: bool = True, pre_masked: bool = False, x_activation=None, zero_pad: bool = True):
         """``pre_masked``: ``grad`` is already dz (the consumer folded this layer's activation
         derivative into its dX epilogue).  ``x_activation``: activation that produced this layer's
-        input; its derivative is folded into the returned dx."""
+        input; its derivative is folded into the returned dx.  ``zero_pad=False``: the consumer of dx never reads the
+        alignment columns beyond K (saves a fill launch)."""
         dx, dW, db = ops.linear_backward(self._x, self.kernel.data, self._y, grad,
                                          None if pre_masked else self.activation, need_dx=need_dx,
-                                         need_db=self.bias is not None, x_activation=x_activation)
+                                         need_db=self.bias is not None, x_activation=x_activation, zero_pad=zero_pad)
         self.kernel.grad = dW
         if self.bias is not None:
             self.bias.grad = db
@@ -187,7 +188,7 @@ def mlp_forward(layers, x, out_last: Optional[torch.Tensor] = None):
     return x
 
 
-def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False):
+def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False, zero_pad: bool = True):
     """Backward through consecutive _Dense layers, chaining the activation derivative of layer i-1
     into the dX epilogue of layer i (no separate elementwise pass between layers); the fused runs of
     ``mlp_forward`` go back through one ``ops.mlp_chain_backward`` launch each."""
@@ -199,7 +200,8 @@ def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False):
             prev_act = layers[i - 1].activation if i > 0 else None
             want_dx = (i > 0) or need_dx
             if r == 1:
-                grad = layers[i].backward(grad, need_dx=want_dx, pre_masked=pre_masked, x_activation=prev_act)
+                grad = layers[i].backward(grad, need_dx=want_dx, pre_masked=pre_masked, x_activation=prev_act,
+                                          zero_pad=zero_pad or i > 0)
             else:
                 seg = layers[i:i + r]
                 grad, dWs, dbs = ops.mlp_chain_backward(seg[0]._x, [l.kernel.data for l in seg], [l._y for l in seg],

@@ -588,26 +588,29 @@ struct ReduceArgs {
     float* db[MAXL];
 };
 
-// out[p] = sum_g slabs[g][p] in a fixed order: 4 groups of a workgroup take every 4th slab, 4 independent chains each
-__global__ __launch_bounds__(256) void chain_reduce_kernel(const ReduceArgs a) {
-    __shared__ float red[256];
+// out[p] = sum_g slabs[g][p] in a fixed order: a workgroup owns 64 parameters, its 16 wavefronts take every 16th slab
+// (4 independent chains each: 4 dependent load rounds for 256 slabs instead of 16), then a fixed-order tree through LDS
+__global__ __launch_bounds__(1024) void chain_reduce_kernel(const ReduceArgs a) {
+    __shared__ float red[1024];
     const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + o;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (p < a.ptotal) {
         int k = grp;
-        for (; k + 12 < a.G; k += 16) {
+        for (; k + 48 < a.G; k += 64) {
             s0 += a.slabs[(int64_t)k * a.ptotal + p];
-            s1 += a.slabs[(int64_t)(k + 4) * a.ptotal + p];
-            s2 += a.slabs[(int64_t)(k + 8) * a.ptotal + p];
-            s3 += a.slabs[(int64_t)(k + 12) * a.ptotal + p];
+            s1 += a.slabs[(int64_t)(k + 16) * a.ptotal + p];
+            s2 += a.slabs[(int64_t)(k + 32) * a.ptotal + p];
+            s3 += a.slabs[(int64_t)(k + 48) * a.ptotal + p];
         }
-        for (; k < a.G; k += 4) s0 += a.slabs[(int64_t)k * a.ptotal + p];
+        for (; k < a.G; k += 16) s0 += a.slabs[(int64_t)k * a.ptotal + p];
     }
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp != 0 || p >= a.ptotal) return;
-    const float v = (red[o] + red[64 + o]) + (red[128 + o] + red[192 + o]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) v += (red[g * 64 + o] + red[(g + 1) * 64 + o]) + (red[(g + 2) * 64 + o] + red[(g + 3) * 64 + o]);
     for (int l = 0; l < a.L; ++l) {
         if (p >= a.poff_w[l] && p < a.poff_w[l] + a.nw[l]) {
             a.dW[l][p - a.poff_w[l]] = v;
@@ -798,7 +801,7 @@ int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
         r.poff_w[l] = a.poff_w[l];
         r.poff_b[l] = a.poff_b[l];
     }
-    hipLaunchKernelGGL(chain_reduce_kernel, dim3((unsigned)mh_ceil_div(a.ptotal, 64)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(chain_reduce_kernel, dim3((unsigned)mh_ceil_div(a.ptotal, 64)), dim3(1024), 0, s, r);
     MH_CHECK_LAUNCH("mh_mlp_chain_bwd(reduce)");
     return MH_OK;
 }

@@ -508,7 +508,8 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     return buf
 
 
-def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True, x_activation=None):
+def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True, x_activation=None,
+                    zero_pad: bool = True):
     """Backward of ``linear``: returns (dx | None, dW, db | None).  ``dy`` is overwritten with
     dz = dy * act'(y) when an activation is given.  ``x_activation`` names the activation that
     produced ``x``: its derivative is folded into dx, which is then the producer's dz."""
@@ -528,7 +529,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
     if need_dx:
         lddx = (K + 3) // 4 * 4  # 16-byte aligned rows for whoever consumes dx next
         buf = torch.empty((M, lddx), dtype=torch.float32, device=x.device)
-        if lddx != K:
+        if lddx != K and zero_pad:  # consumers that widen dx to its leading dimension expect zeros there (blocks._widen)
             buf[:, K:].zero_()
         dx = buf[:, :K]
     dW = torch.empty((K, N), dtype=torch.float32, device=x.device)

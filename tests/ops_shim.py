@@ -82,7 +82,7 @@ def dot_interaction_backward(x, dout, tail_slot=-1, tail_width=0):
     return dx
 
 
-def linear_backward(x, W, y, dy, activation=None, need_dx=True, need_db=True, x_activation=None):
+def linear_backward(x, W, y, dy, activation=None, need_dx=True, need_db=True, x_activation=None, zero_pad=True):
     if activation not in (None, "linear"):
         dy.copy_(_act_grad(y, dy, activation))  # in place, like the kernel
     dx = None
@@ -153,8 +153,9 @@ def rowwise_dot(a, b):
     return (a * b).sum(-1, keepdim=True)
 
 
-def cross_layer(x0, x, W, b):
-    return x0 * (x @ W + (0 if b is None else b)) + x
+def cross_layer(x0, x, W, b, save_p=False):
+    p = x @ W + (0 if b is None else b)
+    return (x0 * p + x, p) if save_p else x0 * p + x
 
 
 def _scorer_terms(q, item, neg, pos_ids, neg_ids, T, fns, pos_logq, neg_logq, after):
