@@ -103,6 +103,14 @@ int32_t mh_embedding_bag_fwd(const float* table, int64_t rows, const void* value
  * offsets == NULL selects the dense list of length L (nnz must equal B*L).  nnz < 2^26.
  * MAX (dense lists only): the gradient of tf.reduce_max -- grad[b, d] goes to the positions whose row attains the maximum
  * of component d, split equally among ties (the rows are re-gathered from the not-yet-updated table). */
+/* The expansion half on its own: gexp[nnz, D] (row j = the gradient row of value j: grad[bag(j)] / div(bag(j)), or the
+ * max-combiner split; `table` is only read by MAX).  Callers that must fold SEVERAL lookups of one table into a single
+ * dedup + optimizer step -- a one-hot feature and a list feature that share a table (item_id / item_id_history), the
+ * IndexedSlices of which Keras sums before ONE apply (models/base.py:1121-1174) -- expand every list, concatenate values
+ * and rows with the one-hot ids / gradient rows, and call mh_embedding_gather_bwd once.  scale_ws: B floats (unused by MAX). */
+int32_t mh_embedding_bag_expand(const float* table, int64_t rows, const void* values, int64_t nnz, const void* offsets,
+                                int64_t L, int32_t ids_dtype, int64_t B, int32_t D, int32_t combiner, const float* grad,
+                                int64_t grad_row_stride, float* gexp, float* scale_ws, mh_stream_t stream);
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D);
 int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t rows, const void* values,
                              int64_t nnz, const void* offsets, int64_t L, int32_t ids_dtype, int64_t B, int32_t D,

@@ -859,6 +859,56 @@ int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D) 
     return (int64_t)align_up((size_t)B * sizeof(float), 256) + (int64_t)align_up((size_t)nnz * D * sizeof(float), 256) + inner;
 }
 
+// Expansion half of the list backward on its own: gexp[j] = the gradient row of value j (grad[bag(j)] / div(bag(j)), or
+// the max-combiner split).  mh_embedding_bag_bwd = this + mh_embedding_gather_bwd over the nnz values; callers that must
+// merge several lookups of ONE table into a single dedup + optimizer step (a one-hot feature and a list feature sharing a
+// table) expand first, concatenate, and call mh_embedding_gather_bwd once.  scale_ws: B floats.
+int32_t mh_embedding_bag_expand(const float* table, int64_t rows, const void* values, int64_t nnz, const void* offsets,
+                                int64_t L, int32_t ids_dtype, int64_t B, int32_t D, int32_t combiner, const float* grad,
+                                int64_t grad_row_stride, float* gexp, float* scale_ws, mh_stream_t stream) {
+    MH_REQUIRE(grad && gexp, "mh_embedding_bag_expand: null argument");
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_bag_expand: bad ids_dtype");
+    MH_REQUIRE(combiner >= MH_COMBINER_SUM && combiner <= MH_COMBINER_MAX, "mh_embedding_bag_expand: bad combiner %d", combiner);
+    MH_REQUIRE(combiner != MH_COMBINER_MAX || (!offsets && table),
+               "mh_embedding_bag_expand: the max combiner is defined for dense lists only (and needs the table)");
+    MH_REQUIRE(combiner == MH_COMBINER_MAX || scale_ws, "mh_embedding_bag_expand: scale workspace (B floats) required");
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_bag_expand: D=%d must be a multiple of 4 in [4,1024]", D);
+    MH_REQUIRE(grad_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0,
+               "mh_embedding_bag_expand: grad must be 16-byte aligned with grad_row_stride %% 4 == 0");
+    MH_REQUIRE(offsets || L >= 1, "mh_embedding_bag_expand: need CSR offsets or a list length L >= 1");
+    if (B <= 0 || nnz <= 0) return MH_OK;
+    MH_REQUIRE(values, "mh_embedding_bag_expand: null values");
+    MH_REQUIRE(offsets || nnz == B * L, "mh_embedding_bag_expand: dense list needs nnz == B*L");
+    hipStream_t s = mh_stream(stream);
+    const int LPR = D / 4;
+    const int groups = 256 / LPR;
+    const dim3 gs((unsigned)mh_ceil_div(B, 4));
+    int64_t nb = mh_ceil_div(nnz, groups);
+    const int64_t cap = (int64_t)mh_num_cus() * 16;
+    if (nb > cap) nb = cap;
+    float* scale = scale_ws;
+    if (combiner == MH_COMBINER_MAX) {
+        if (ids_dtype == MH_I32)
+            hipLaunchKernelGGL((bag_expand_max_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
+                               (const int32_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
+        else
+            hipLaunchKernelGGL((bag_expand_max_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
+                               (const int64_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
+    } else if (ids_dtype == MH_I32) {
+        hipLaunchKernelGGL((bag_scale_kernel<int32_t>), gs, dim3(256), 0, s, (const int32_t*)values,
+                           (const int32_t*)offsets, L, B, combiner, scale);
+        hipLaunchKernelGGL((bag_expand_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int32_t*)offsets, L,
+                           B, nnz, LPR, scale, grad, grad_row_stride, gexp);
+    } else {
+        hipLaunchKernelGGL((bag_scale_kernel<int64_t>), gs, dim3(256), 0, s, (const int64_t*)values,
+                           (const int64_t*)offsets, L, B, combiner, scale);
+        hipLaunchKernelGGL((bag_expand_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int64_t*)offsets, L,
+                           B, nnz, LPR, scale, grad, grad_row_stride, gexp);
+    }
+    MH_CHECK_LAUNCH("mh_embedding_bag_expand");
+    return MH_OK;
+}
+
 int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t rows, const void* values,
                              int64_t nnz, const void* offsets, int64_t L, int32_t ids_dtype, int64_t B, int32_t D,
                              int32_t combiner, const float* grad, int64_t grad_row_stride, int32_t optimizer, float lr,
@@ -885,31 +935,11 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
     ws += align_up((size_t)B * sizeof(float), 256);
     float* gexp = reinterpret_cast<float*>(ws);
     ws += align_up((size_t)nnz * D * sizeof(float), 256);
-    const int LPR = D / 4;
-    const int groups = 256 / LPR;
-    const dim3 gs((unsigned)mh_ceil_div(B, 4));
-    int64_t nb = mh_ceil_div(nnz, groups);
-    const int64_t cap = (int64_t)mh_num_cus() * 16;
-    if (nb > cap) nb = cap;
-    if (combiner == MH_COMBINER_MAX) {
-        if (ids_dtype == MH_I32)
-            hipLaunchKernelGGL((bag_expand_max_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
-                               (const int32_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
-        else
-            hipLaunchKernelGGL((bag_expand_max_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
-                               (const int64_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
-    } else if (ids_dtype == MH_I32) {
-        hipLaunchKernelGGL((bag_scale_kernel<int32_t>), gs, dim3(256), 0, s, (const int32_t*)values,
-                           (const int32_t*)offsets, L, B, combiner, scale);
-        hipLaunchKernelGGL((bag_expand_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int32_t*)offsets, L,
-                           B, nnz, LPR, scale, grad, grad_row_stride, gexp);
-    } else {
-        hipLaunchKernelGGL((bag_scale_kernel<int64_t>), gs, dim3(256), 0, s, (const int64_t*)values,
-                           (const int64_t*)offsets, L, B, combiner, scale);
-        hipLaunchKernelGGL((bag_expand_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int64_t*)offsets, L,
-                           B, nnz, LPR, scale, grad, grad_row_stride, gexp);
+    {
+        const int32_t st = mh_embedding_bag_expand(table, rows, values, nnz, offsets, L, ids_dtype, B, D, combiner, grad,
+                                                   grad_row_stride, gexp, scale, stream);
+        if (st != MH_OK) return st;
     }
-    MH_CHECK_LAUNCH("mh_embedding_bag_bwd");
     float* tabs[1] = {table};
     float* st1[1] = {state};
     float* st2[1] = {state2};

@@ -311,6 +311,36 @@ class EmbeddingsBlock(ParallelBlock):
 
         g2 = grad.reshape(grad.shape[0], -1)
         self._apply_batch_regularization(g2, offsets)
+        # A table looked up through a list feature AND any other feature (item_id + item_id_history is the common case):
+        # Keras sums the IndexedSlices of all lookups of a variable before ONE optimizer apply, so Adagrad / Adam must see
+        # the summed row gradient once -- two fused launches would step the shared rows twice.  Those tables go through
+        # ONE dedup + update over the concatenation of every lookup's (id, gradient row) pairs.
+        by_table: Dict[int, list] = {}
+        for n in lists + names:
+            by_table.setdefault(id(self.feature_table[n].table), []).append(n)
+        merged = [grp for grp in by_table.values() if len(grp) > 1 and any(n in lists for n in grp)]
+        for grp in merged:
+            ft0 = self.feature_table[grp[0]]
+            st, st2 = _states(ft0.table)
+            ids_all, rows_all = [], []
+            for n in grp:
+                ft, x = self.feature_table[n], self._last[n]
+                gcol = g2[:, offsets[n]:offsets[n] + ft.dim]
+                if n in lists:
+                    vals, offs = (x.values, x.offsets) if isinstance(x, Ragged) else (x, None)
+                    v, gexp = ops.embedding_bag_expand(ft.table.data, vals, offs, gcol, ft.sequence_combiner)
+                else:
+                    v, gexp = x.reshape(-1), gcol
+                ids_all.append(v.to(torch.int64) if v.dtype != torch.int64 else v)
+                rows_all.append(gexp)
+            ids_cat = torch.cat(ids_all)
+            rows_cat = torch.cat(rows_all, dim=0)  # contiguous [sum nnz, D]
+            ops.embedding_gather_backward([ft0.table.data], None if st is None else [st], [ids_cat], rows_cat, [0], opt.name,
+                                          opt.learning_rate, opt.epsilon, None if st2 is None else [st2], opt.beta_1,
+                                          opt.beta_2, opt.lr_device)
+        done = {n for grp in merged for n in grp}
+        lists = [n for n in lists if n not in done]
+        names = [n for n in names if n not in done]
         # ragged / dense-list features: gradient rows scale with the combiner, one fused launch chain each
         for n in lists:
             ft = self.feature_table[n]

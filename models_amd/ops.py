@@ -8,7 +8,7 @@ test infrastructure only).
 from __future__ import annotations
 
 import ctypes as C
-from typing import NamedTuple, Optional, Sequence
+from typing import NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -624,6 +624,44 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
                                         _stream()),
             "mh_embedding_gather_bwd",
         )
+
+
+def embedding_bag_expand(table: torch.Tensor, values: torch.Tensor, offsets: Optional[torch.Tensor], grad: torch.Tensor,
+                         combiner: str = "mean") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-value gradient rows of a list lookup: returns ``(values [nnz], gexp [nnz, D])`` with
+    ``gexp[j] = grad[bag(j)] / div(bag(j))`` (the IndexedSlices of the lookup's table gradient, before any dedup)."""
+    lib = _lib.load()
+    _dev(table, "table", torch.float32)
+    _dev(values, "values")
+    _dev(grad, "grad", torch.float32)
+    idt = _ids_dtype(values, "values")
+    if combiner not in COMBINER:
+        raise ValueError(f"combiner must be one of {sorted(COMBINER)}, got {combiner!r}")
+    D = table.shape[1]
+    if grad.dim() != 2 or grad.shape[1] != D or grad.stride(1) != 1:
+        raise ValueError(f"grad must be [B, {D}] with unit inner stride")
+    B, L = grad.shape[0], 0
+    if offsets is None:
+        if values.dim() == 3 and values.shape[-1] == 1:
+            values = values.squeeze(-1)
+        if values.dim() != 2 or values.shape[0] != B:
+            raise ValueError("dense list values must be [B, L]")
+        L = values.shape[1]
+    else:
+        _dev(offsets, "offsets")
+        if offsets.dtype != values.dtype:
+            raise TypeError("offsets and values must share one integer dtype")
+        offsets = offsets.reshape(-1).contiguous()
+    values = values.reshape(-1).contiguous()
+    nnz = values.shape[0]
+    gexp = torch.empty((nnz, D), dtype=torch.float32, device=grad.device)
+    if B == 0 or nnz == 0:
+        return values, gexp
+    scale = torch.empty((B,), dtype=torch.float32, device=grad.device)
+    check(lib.mh_embedding_bag_expand(_ptr(table), table.shape[0], _ptr(values), nnz, _ptr(offsets), L, idt, B, D,
+                                      COMBINER[combiner], _ptr(grad), grad.stride(0), _ptr(gexp), _ptr(scale), _stream()),
+          "mh_embedding_bag_expand")
+    return values, gexp
 
 
 def embedding_bag_backward(table: torch.Tensor, state: Optional[torch.Tensor], values: torch.Tensor,

@@ -177,3 +177,58 @@ def test_l2_batch_regularization_through_dlrm_train_step():
     gb = torch.zeros_like(Wb0).index_add_(0, x["b"].reshape(-1), up[:, 1])
     torch.testing.assert_close(Wa0 - emb.feature_table["a"].table.data, ga, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(Wb0 - emb.feature_table["b"].table.data, gb, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("optimizer", ["adagrad", "adam"])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_shared_table_onehot_and_list_take_one_optimizer_step(optimizer, idt):
+    """item_id (one-hot) and item_id_history (ragged list) share one table (same int_domain.name).  Keras sums the
+    IndexedSlices of both lookups before ONE optimizer apply: Adagrad must add (g_onehot + g_list)^2 to the accumulator
+    once, not g_onehot^2 and g_list^2 in two steps (round-1 advisor finding)."""
+    import models_amd as mm
+    from models_amd import optim
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(21)
+    B, D, V = 257, 16, 60
+    schema = mm.Schema([mm.schema.categorical("item_id", V, domain_name="item"),
+                        mm.schema.categorical("item_id_history", V, domain_name="item", is_list=True, is_ragged=True),
+                        mm.schema.categorical("other", 30)])
+    emb = mm.Embeddings(schema, dim=D, sequence_combiner="mean", device=dev)
+    assert emb.feature_table["item_id"].table is emb.feature_table["item_id_history"].table
+    values, offsets = _csr(rng, B, V, 6, neg_frac=0.03, oob_frac=0.0)
+    ids = rng.integers(0, V, size=B)
+    oth = rng.integers(0, 30, size=B)
+    inputs = {"item_id": torch.from_numpy(ids).to(idt).to(dev), "other": torch.from_numpy(oth).to(idt).to(dev),
+              "item_id_history": mm.Ragged(torch.from_numpy(values).to(idt).to(dev), torch.from_numpy(offsets).to(idt).to(dev))}
+    emb(inputs)
+    W0 = emb.feature_table["item_id"].table.numpy().copy()
+    Wo0 = emb.feature_table["other"].table.numpy().copy()
+    names = emb.feature_names
+    grad = rng.standard_normal((B, len(names), D)).astype(np.float32)
+    emb.set_pending_grad(torch.from_numpy(grad).to(dev), {n: i * D for i, n in enumerate(names)})
+    lr = 0.1
+    opt = optim.get(optimizer, learning_rate=lr)
+    opt.ensure_begun(dev)  # Adam: advances the on-device step / bias-corrected lr once
+    emb.apply_sparse(opt)
+    torch.cuda.synchronize()
+    # reference: ONE update with the summed gradient of both lookups
+    g1 = np.zeros_like(W0)
+    np.add.at(g1, ids, grad[:, names.index("item_id")])
+    g = g1 + O.embedding_bag_grad(V, values, offsets, grad[:, names.index("item_id_history")], "mean")
+    touched = np.abs(g).sum(1) > 0
+    if optimizer == "adagrad":
+        acc = np.full_like(W0, opt.initial_accumulator_value) + g * g
+        ref = W0 - lr * g / (np.sqrt(acc) + opt.epsilon)
+    else:  # LazyAdam, first step: m = (1-b1) g, v = (1-b2) g^2, bias-corrected lr
+        b1, b2 = opt.beta_1, opt.beta_2
+        m, v = (1 - b1) * g, (1 - b2) * g * g
+        lr_t = lr * np.sqrt(1 - b2) / (1 - b1)
+        ref = np.where(touched[:, None], W0 - lr_t * m / (np.sqrt(v) + opt.epsilon), W0)
+    got = emb.feature_table["item_id"].table.numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+    # the unshared table still takes its own step
+    go = np.zeros_like(Wo0)
+    np.add.at(go, oth, grad[:, names.index("other")])
+    assert not np.allclose(emb.feature_table["other"].table.numpy(), Wo0)
