@@ -165,6 +165,35 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ W, int K
     }
 }
 
+// acc[t] += sum_s A[s] * B[s][t] with the LDS operands of step s + DIST already on their way while the MFMAs of step s
+// issue: a wavefront issues in order, so reads placed right before their MFMAs (what hipcc schedules when left alone) expose
+// the LDS latency once per step -- with one or two wavefronts per SIMD nothing else fills that gap (measured: MFMA busy
+// 0.41 / 0.31 of the SIMD cycles in the first version of these kernels).  The scheduling barriers pin the order.
+template <int STEPS, int TT>
+__device__ __forceinline__ void chain_mfma_loop(const float* __restrict__ ap, const float* __restrict__ bp, f32x4 (&acc)[TT]) {
+    constexpr int DIST = STEPS >= 2 ? 2 : 1;  // prefetch distance in steps
+    float a[DIST + 1];
+    float b[DIST + 1][TT];
+#pragma unroll
+    for (int s = 0; s < DIST && s < STEPS; ++s) {
+        a[s] = ap[4 * s];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) b[s][t] = bp[(s * TT + t) * 64];
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + DIST < STEPS) {
+            a[(s + DIST) % (DIST + 1)] = ap[4 * (s + DIST)];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) b[(s + DIST) % (DIST + 1)][t] = bp[((s + DIST) * TT + t) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = mfma16(a[s % (DIST + 1)], b[s % (DIST + 1)][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- one forward layer on a wave-private strip -------------------------------------------------------------------
 template <int PIN, int POUT>
 __device__ __forceinline__ void fwd_layer(float* __restrict__ slab, const float* __restrict__ frag,
@@ -175,14 +204,7 @@ __device__ __forceinline__ void fwd_layer(float* __restrict__ slab, const float*
     f32x4 acc[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = slab + l15 * SA + q;
-    const float* bp = frag + lane;
-#pragma unroll
-    for (int s = 0; s < PIN / 4; ++s) {
-        const float a = ap[4 * s];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tn] = mfma16(a, bp[(s * TN + tn) * 64], acc[tn]);
-    }
+    chain_mfma_loop<PIN / 4, TN>(slab + l15 * SA + q, frag + lane, acc);
     float bv[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -379,14 +401,7 @@ __device__ __forceinline__ void bwd_dx(const CTiles<POUT>& dz, float* __restrict
         for (int r = 0; r < 4; ++r) slab[(4 * q + r) * SA + 16 * tn + l15] = dz.t[tn][r];
 #pragma unroll
     for (int tj = 0; tj < TJ; ++tj) gin.t[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = slab + l15 * SA + q;
-    const float* bp = fragT + lane;
-#pragma unroll 4
-    for (int s = 0; s < POUT / 4; ++s) {
-        const float av = ap[4 * s];
-#pragma unroll
-        for (int tj = 0; tj < TJ; ++tj) gin.t[tj] = mfma16(av, bp[(s * TJ + tj) * 64], gin.t[tj]);
-    }
+    chain_mfma_loop<POUT / 4, TJ>(slab + l15 * SA + q, fragT + lane, gin.t);
 }
 
 // dW[ti][tn] += y^T dz over the strip's 16 rows, from registers; db[tn] += column sums (per-lane partial over its 4 rows)
