@@ -287,15 +287,19 @@ class ShardedEmbeddingGroup:
         self.lookup_begin(ids, scatter_into)
         return self.lookup_end()
 
-    def lookup_begin(self, ids: Sequence[torch.Tensor], scatter_into=None) -> None:
+    def lookup_begin(self, ids: Sequence[torch.Tensor], scatter_into=None, layout=None) -> None:
         """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D], or, with
-        ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``."""
+        ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``.
+        ``layout = (slots, n_slots)``: the [B, n_slots, D] stack the GRADIENT will arrive in (``backward_begin(...,
+        from_stacked=...)``) when the forward places the rows itself (``lookup_end(scatter=...)``)."""
         W = self.world_size
         F_sh, B = len(ids), ids[0].numel()
         n = F_sh * B
         if scatter_into is not None:
             stacked, slots, scatter_fn = scatter_into
             n_slots = stacked.shape[1]
+        elif layout is not None:
+            slots, n_slots = list(layout[0]), int(layout[1])
         else:
             slots, n_slots = list(range(F_sh)), F_sh
         if self.capacity is None and self.calibration <= 0:
@@ -593,6 +597,8 @@ class DistributedDLRM:
         B = inputs[body.cat_names[0]].shape[0]
         dev = inputs[body.cat_names[0]].device
         F, D = body.num_features, body.dim
+        if dev.type == "cuda" and body._fusable(inputs):
+            return self._forward_body_fused(inputs, head)
         # 1. route FIRST: its one host sync then waits only for the tiny bucketing kernels, and everything
         #    below is enqueued back to back; the row all-to-all overlaps the bottom MLP / replicated gather
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
@@ -627,6 +633,54 @@ class DistributedDLRM:
         body.interaction.forward(stacked, tail, out=top_in)
         body._top_in = top_in
         return body._top(top_in, head)  # the Dense(1, sigmoid) head rides on the top MLP's fused chain
+
+    def _forward_body_fused(self, inputs, head=None):
+        """The fused gather -> interaction kernel on the sharded path: a sharded feature's slot is the buffer of rows that
+        came back from the owners, indexed by the position of request (f, b) in it (``pos_of``; a dropped request is -1 and
+        reads as a zero row) -- no stacked [B, F, D] tensor, no scatter of the returned rows, and the backward re-gathers
+        from the same buffer.  Replicated features are ordinary (table, ids) slots."""
+        from . import ops
+        from .blocks import mlp_forward
+
+        body = self.body
+        emb = body.embeddings
+        B = inputs[body.cat_names[0]].shape[0]
+        dev = inputs[body.cat_names[0]].device
+        F, D = body.num_features, body.dim
+        gs = self.group_sh
+        if gs is not None:  # route first: the row all-to-all overlaps the bottom MLP
+            gs.lookup_begin([inputs[n] for n in self.sharded_names],
+                            layout=([body.slots[n] for n in self.sharded_names], F))
+        dense = mlp_forward(body.bottom_block.layers, body.continuous(inputs))
+        got = {}
+        if gs is not None:
+            gs.lookup_end(scatter=lambda back, pos: got.update(back=back, pos=pos))
+        idt = inputs[body.cat_names[0]].dtype
+        sh_index = {n: i for i, n in enumerate(self.sharded_names)}
+        slot_tables, slot_ids = [], []
+        for k in body.stack_order:
+            if k == "bottom_block":
+                slot_tables.append(None)
+                slot_ids.append(None)
+            elif k in sh_index:
+                slot_tables.append(got["back"])
+                slot_ids.append(got["pos"][sh_index[k]].to(idt))
+            else:
+                slot_tables.append(emb.feature_table[k].table.data)
+                slot_ids.append(inputs[k])
+        emb._last = {n: inputs[n] for n in body.cat_names}
+        P = F * (F - 1) // 2
+        width = P + D
+        ld = (width + 3) // 4 * 4
+        buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        if ld != width:
+            buf[:, width:].zero_()
+        top_in = buf[:, :width]
+        ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
+        body._fused = True
+        body._slots_ctx = (slot_tables, slot_ids, dense)  # keeps the returned rows alive for the backward's re-gather
+        body._top_in = top_in
+        return body._top(top_in, head)
 
     def __call__(self, inputs):
         from .models import prepare_features

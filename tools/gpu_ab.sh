@@ -1,6 +1,5 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_backward.py tests/test_gpu_fullsize.py tests/test_gpu_route.py tests/test_gpu_embedding.py tests/test_gpu_hygiene.py -x -q 2>&1 | tail -3
-show() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['ms_per_step'],4), d['kernels_ms'].get('embedding_bwd'))"; }
+timeout 600 python -m pytest tests/test_gpu_models.py tests/test_gpu_route.py -x -q 2>&1 | tail -3
+show() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['ms_per_step'],4), d['kernels_ms'])"; }
 MH_FORCE_DISTRIBUTED=1 python bench.py --steps 50 --warmup 8 --no-cpu-baseline 2>/dev/null | show forced_dist
-python bench.py --steps 100 --no-cpu-baseline --no-secondary 2>/dev/null | show graph
