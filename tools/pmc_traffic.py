@@ -16,14 +16,16 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / "gpurun_out" / "pmc_traffic"
 N = 5
-SEGMENTS = {"calib": None, "embbwd": ("radix_", "piece_", "carry_apply", "fill_words"), "gather": ("gather_fwd",), "cold": ("gather_fwd",)}
+SEGMENTS = {"calib": None, "embbwd": ("radix_", "piece_", "carry_apply", "fill_words"), "gather": ("gather_fwd",), "cold": ("gather_fwd",),
+            "fused_fwd": ("dlrm_fused_fwd",), "fused_bwd": ("dlrm_fused_bwd",)}
+WORKLOAD = {"fused_fwd": "fused", "fused_bwd": "fused"}  # segment -> pmc_workload.py argument (default: the segment name)
 
 
 def run_pass(seg, counter):
     d = OUT / f"{seg}_{counter}"
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", str(d), "-o", "p", "--",
-                    sys.executable, str(ROOT / "tools" / "pmc_workload.py"), seg], cwd="/tmp", env=env,
+                    sys.executable, str(ROOT / "tools" / "pmc_workload.py"), WORKLOAD.get(seg, seg)], cwd="/tmp", env=env,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
     f = glob.glob(str(d / "**" / "*counter_collection.csv"), recursive=True)
     rows = []
@@ -67,10 +69,11 @@ def main():
             entry[counter + "_bytes_per_launch"] = tot_units * unit if unit else None
         if entry.get("FETCH_SIZE_bytes_per_launch") is not None and entry.get("WRITE_SIZE_bytes_per_launch") is not None:
             entry["traffic_bytes"] = entry["FETCH_SIZE_bytes_per_launch"] + entry["WRITE_SIZE_bytes_per_launch"]
-        name = {"embbwd": "embedding_bwd", "gather": "embedding_gather", "cold": "gather_cold"}[seg]
+        name = {"embbwd": "embedding_bwd", "gather": "embedding_gather", "cold": "gather_cold", "fused_fwd": "dlrm_fused_fwd",
+                "fused_bwd": "dlrm_fused_bwd"}[seg]
         res[name] = entry
     json.dump(res, open(ROOT / "gpurun_out" / "pmc_traffic.json", "w"), indent=1)
-    for k in ("calibration", "embedding_bwd", "embedding_gather", "gather_cold"):
+    for k in ("calibration", "embedding_bwd", "embedding_gather", "gather_cold", "dlrm_fused_fwd", "dlrm_fused_bwd"):
         v = res.get(k, {})
         print(k, {a: b for a, b in v.items() if not isinstance(b, dict) or a == "calibration"} if k != "calibration" else v)
 
