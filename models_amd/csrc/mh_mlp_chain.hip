@@ -305,16 +305,18 @@ __global__ __launch_bounds__(CW * 64) void chain_fwd_kernel(const ChainArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* const slab = slabs + wave * 16 * SA;
 
-    stage_weights<P0, P1, false>(a.W[0], a.dims[0], a.dims[1], w1);
-    if constexpr (S::L >= 2) stage_weights<P1, P2, false>(a.W[1], a.dims[1], a.dims[2], w2);
-    if constexpr (S::L >= 3) stage_weights<P2, P3, false>(a.W[2], a.dims[2], a.dims[3], w3);
-    __syncthreads();
-
+    // the first strip's loads (HBM) are in flight while the weights (L2) are staged
     const int64_t nstrips = (a.M + 15) / 16;
     const int64_t stride = (int64_t)gridDim.x * CW;
     int64_t strip = (int64_t)blockIdx.x * CW + wave;
     XStrip<P0, VEC> xs;
     if (strip < nstrips) xs.load(a.x, a.ldx, a.dims[0], strip * 16, a.M, lane);
+
+    stage_weights<P0, P1, false>(a.W[0], a.dims[0], a.dims[1], w1);
+    if constexpr (S::L >= 2) stage_weights<P1, P2, false>(a.W[1], a.dims[1], a.dims[2], w2);
+    if constexpr (S::L >= 3) stage_weights<P2, P3, false>(a.W[2], a.dims[2], a.dims[3], w3);
+    __syncthreads();
+
     for (; strip < nstrips; strip += stride) {
         const int64_t row0 = strip * 16;
         xs.store(slab, lane);
@@ -487,6 +489,40 @@ __device__ __forceinline__ void wg_reduce_tiles(f32x4* __restrict__ v, float* __
     }
 }
 
+// dW tiles of one layer: summed over the CW wavefronts (fixed order) and written to the workgroup's slab by ALL wavefronts --
+// every wavefront parks its tiles in LDS (PART at a time), then each sums and stores a quarter of them.  (Summing on wave 0
+// alone, eight tiles a round, was ~6 us of a 55 us kernel.)
+template <int PIN, int POUT>
+__device__ __forceinline__ void wg_reduce_store_dw(const f32x4* __restrict__ dw, float* __restrict__ scratch,
+                                                   float* __restrict__ out, int K, int N, int wave, int lane) {
+    constexpr int TN_ = POUT / 16, NT = (PIN / 16) * TN_;
+    constexpr int PART = 16;
+    const int l15 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += PART) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PART; ++j)
+            if (t0 + j < NT) *reinterpret_cast<f32x4*>(scratch + ((wave * PART + j) * 64 + lane) * 4) = dw[t0 + j];
+        __syncthreads();
+        for (int j = wave; j < PART && t0 + j < NT; j += CW) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(scratch + ((0 * PART + j) * 64 + lane) * 4);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(scratch + ((1 * PART + j) * 64 + lane) * 4);
+            const f32x4 s2 = *reinterpret_cast<const f32x4*>(scratch + ((2 * PART + j) * 64 + lane) * 4);
+            const f32x4 s3 = *reinterpret_cast<const f32x4*>(scratch + ((3 * PART + j) * 64 + lane) * 4);
+            const f32x4 v = (s0 + s1) + (s2 + s3);
+            const int t = t0 + j, ti = t / TN_, tn = t % TN_;
+            const int n = 16 * tn + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * ti + 4 * q + r;
+                if (kk < K && n < N) out[kk * N + n] = v[r];
+            }
+        }
+    }
+}
+static_assert(CW == 4, "wg_reduce_store_dw sums four wavefronts");
+
 // wave 0 writes the workgroup's dW tile array of one layer to its slab (real entries only)
 template <int PIN, int POUT>
 __device__ __forceinline__ void store_dw(const f32x4* __restrict__ dw, float* __restrict__ out, int K, int N, int lane) {
@@ -521,6 +557,12 @@ __global__ __launch_bounds__(CW * 64) void chain_bwd_kernel(const ChainArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* const slab = slabs + wave * 16 * SA;
 
+    const int64_t nstrips = (a.M + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * CW;
+    int64_t strip = (int64_t)blockIdx.x * CW + wave;
+    StripIn<P0, P1, P2, P3> nxt;
+    if (strip < nstrips) nxt.load(a, strip * 16, lane);  // in flight while the weights are staged
+
     if constexpr (NEED_DX) stage_weights<P0, P1, true>(a.W[0], a.dims[0], a.dims[1], w1);
     if constexpr (S::L >= 2) stage_weights<P1, P2, true>(a.W[1], a.dims[1], a.dims[2], w2);
     if constexpr (S::L >= 3) stage_weights<P2, P3, true>(a.W[2], a.dims[2], a.dims[3], w3);
@@ -533,11 +575,6 @@ __global__ __launch_bounds__(CW * 64) void chain_bwd_kernel(const ChainArgs a) {
 #pragma unroll
     for (int i = 0; i < NB1 + NB2 + NB3; ++i) db[i] = 0.f;
 
-    const int64_t nstrips = (a.M + 15) / 16;
-    const int64_t stride = (int64_t)gridDim.x * CW;
-    int64_t strip = (int64_t)blockIdx.x * CW + wave;
-    StripIn<P0, P1, P2, P3> nxt;
-    if (strip < nstrips) nxt.load(a, strip * 16, lane);
     for (; strip < nstrips; strip += stride) {
         const int64_t row0 = strip * 16;
         StripIn<P0, P1, P2, P3> cur = nxt;
@@ -570,7 +607,10 @@ __global__ __launch_bounds__(CW * 64) void chain_bwd_kernel(const ChainArgs a) {
     }
 
     // ---- workgroup reduction (fixed wave order) and the partial slab ------------------------------------------------
-    wg_reduce_tiles<NTW>(dw, smem, wave, lane);
+    float* const out = a.slabs + (int64_t)blockIdx.x * a.ptotal;
+    wg_reduce_store_dw<P0, P1>(dw, smem, out + a.poff_w[0], a.dims[0], a.dims[1], wave, lane);
+    if constexpr (S::L >= 2) wg_reduce_store_dw<P1, P2>(dw + NT1, smem, out + a.poff_w[1], a.dims[1], a.dims[2], wave, lane);
+    if constexpr (S::L >= 3) wg_reduce_store_dw<P2, P3>(dw + NT1 + NT2, smem, out + a.poff_w[2], a.dims[2], a.dims[3], wave, lane);
     f32x4 dbt[NTB];
 #pragma unroll
     for (int i = 0; i < NTB; ++i)
@@ -578,10 +618,6 @@ __global__ __launch_bounds__(CW * 64) void chain_bwd_kernel(const ChainArgs a) {
         for (int r = 0; r < 4; ++r) dbt[i][r] = (4 * i + r < NB1 + NB2 + NB3) ? db[4 * i + r] : 0.f;
     wg_reduce_tiles<NTB>(dbt, smem, wave, lane);
     if (wave != 0) return;
-    float* const out = a.slabs + (int64_t)blockIdx.x * a.ptotal;
-    store_dw<P0, P1>(dw, out + a.poff_w[0], a.dims[0], a.dims[1], lane);
-    if constexpr (S::L >= 2) store_dw<P1, P2>(dw + NT1, out + a.poff_w[1], a.dims[1], a.dims[2], lane);
-    if constexpr (S::L >= 3) store_dw<P2, P3>(dw + NT1 + NT2, out + a.poff_w[2], a.dims[2], a.dims[3], lane);
     // db: sum the four k-slot partials of every column (lanes l15, l15+16, l15+32, l15+48)
 #pragma unroll
     for (int i = 0; i < NB1 + NB2 + NB3; ++i) {
@@ -800,7 +836,7 @@ int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
     const int* p = sig->p;
     const int wf = (dx ? p[0] * p[1] : 0) + p[1] * p[2] + p[2] * p[3];
     size_t lds = (size_t)(wf + CW * 16 * SA) * sizeof(float);
-    const size_t scratch = (size_t)(CW - 1) * 8 * 64 * 4 * sizeof(float);  // wg_reduce_tiles
+    const size_t scratch = (size_t)CW * 16 * 64 * 4 * sizeof(float);  // wg_reduce_store_dw: 16 tiles of every wavefront
     if (lds < scratch) lds = scratch;
     hipStream_t s = mh_stream(stream);
     auto kern = dx ? sig->bwd_dx : sig->bwd_nodx;

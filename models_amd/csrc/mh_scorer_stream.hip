@@ -335,17 +335,22 @@ __global__ __launch_bounds__(SW * 64, 2) void stream_kernel(const StreamArgs a) 
                     } else {
                         v2 = ((masked ? a.fns : acc[r]) - post[r]) * scale2;
                     }
-                    if (jl >= nvalid) v2 = -INFINITY;  // only the last tile of Y can be partial
+                    if (nvalid < bn && jl >= nvalid) v2 = -INFINITY;  // only the last tile of Y can be partial (uniform test first)
                     t2[r] = v2;
                 }
                 if (MODE == SM_FWD) {
                     const float tmax = fmaxf(fmaxf(t2[0], t2[1]), fmaxf(t2[2], t2[3]));
-                    const float m_new = fmaxf(m_run[q], tmax);
-                    float s_new = s_run[q] * fast_exp2(m_run[q] - m_new);
+                    // the running maximum settles after the first tiles: the rescale (a quarter-rate exp2 + a multiply per
+                    // unit) runs only when some lane's maximum moves; exp2(0) = 1 makes skipping it exact
+                    if (__any(tmax > m_run[q])) {
+                        const float m_new = fmaxf(m_run[q], tmax);
+                        s_run[q] *= fast_exp2(m_run[q] - m_new);
+                        m_run[q] = m_new;
+                    }
+                    float s_new = s_run[q];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s_new += fast_exp2(t2[r] - m_new);
+                    for (int r = 0; r < 4; ++r) s_new += fast_exp2(t2[r] - m_run[q]);
                     s_run[q] = s_new;
-                    m_run[q] = m_new;
                 } else if (MODE == SM_GRAD) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
