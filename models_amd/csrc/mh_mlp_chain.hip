@@ -205,13 +205,11 @@ __device__ __forceinline__ void fwd_layer(float* __restrict__ slab, const float*
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
     chain_mfma_loop<PIN / 4, TN>(slab + l15 * SA + q, frag + lane, acc);
+    // the bias sits in LDS next to the weights (zero where there is none / past N): read from global memory here, each
+    // tile's value was its own dependent L2 round trip per strip (8 + 4 serialized waits: most of a strip's time)
     float bv[TN];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = 16 * tn + l15;
-        const float t = bias ? bias[n < N ? n : 0] : 0.f;
-        bv[tn] = (bias && n < N) ? t : 0.f;
-    }
+    for (int tn = 0; tn < TN; ++tn) bv[tn] = bias[16 * tn + l15];
     const bool full = row0 + 16 <= M && N == POUT;  // uniform: no bounds tests, no pad columns
     dispatch_act(act, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
@@ -302,8 +300,16 @@ __global__ __launch_bounds__(CW * 64) void chain_fwd_kernel(const ChainArgs a) {
     float* const w2 = w1 + P0 * P1;
     float* const w3 = w2 + P1 * P2;
     float* const slabs = smem + S::wfloats;
+    float* const b1 = slabs + CW * 16 * SA;  // biases, zero-padded to the tile widths
+    float* const b2 = b1 + P1;
+    float* const b3 = b2 + P2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* const slab = slabs + wave * 16 * SA;
+    for (int i = threadIdx.x; i < P1 + P2 + P3; i += CW * 64) {
+        const int l = i < P1 ? 0 : (i < P1 + P2 ? 1 : 2);
+        const int n = i - (l == 0 ? 0 : (l == 1 ? P1 : P1 + P2));
+        b1[i] = (a.b[l] && n < a.dims[l + 1]) ? a.b[l][n] : 0.f;
+    }
 
     // the first strip's loads (HBM) are in flight while the weights (L2) are staged
     const int64_t nstrips = (a.M + 15) / 16;
@@ -321,9 +327,9 @@ __global__ __launch_bounds__(CW * 64) void chain_fwd_kernel(const ChainArgs a) {
         const int64_t row0 = strip * 16;
         xs.store(slab, lane);
         if (strip + stride < nstrips) xs.load(a.x, a.ldx, a.dims[0], (strip + stride) * 16, a.M, lane);
-        fwd_layer<P0, P1>(slab, w1, a.b[0], a.dims[1], a.act[0], a.y[0], a.ldy[0], row0, a.M, lane);
-        if constexpr (S::L >= 2) fwd_layer<P1, P2>(slab, w2, a.b[1], a.dims[2], a.act[1], a.y[1], a.ldy[1], row0, a.M, lane);
-        if constexpr (S::L >= 3) fwd_layer<P2, P3>(slab, w3, a.b[2], a.dims[3], a.act[2], a.y[2], a.ldy[2], row0, a.M, lane);
+        fwd_layer<P0, P1>(slab, w1, b1, a.dims[1], a.act[0], a.y[0], a.ldy[0], row0, a.M, lane);
+        if constexpr (S::L >= 2) fwd_layer<P1, P2>(slab, w2, b2, a.dims[2], a.act[1], a.y[1], a.ldy[1], row0, a.M, lane);
+        if constexpr (S::L >= 3) fwd_layer<P2, P3>(slab, w3, b3, a.dims[3], a.act[2], a.y[2], a.ldy[2], row0, a.M, lane);
     }
 }
 
@@ -774,7 +780,7 @@ int32_t mh_mlp_chain_fwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
     }
     if (M == 0) return MH_OK;
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ldx % 4 == 0 && dims[0] % 4 == 0;
-    const size_t lds = (size_t)(wfloats(sig->p) + CW * 16 * SA) * sizeof(float);
+    const size_t lds = (size_t)(wfloats(sig->p) + CW * 16 * SA + sig->p[1] + sig->p[2] + sig->p[3]) * sizeof(float);
     // two workgroups per CU when the LDS allows it: the strips of a workgroup's four wavefronts are independent
     const int64_t tiles = mh_ceil_div(mh_ceil_div(M, 16), CW);
     const int64_t cap = (int64_t)mh_num_cus() * (lds <= 80 * 1024 ? 2 : 1);
