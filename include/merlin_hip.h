@@ -151,6 +151,21 @@ int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const*
                                 float beta1, float beta2, const float* lr_device, void* workspace,
                                 int64_t workspace_bytes, mh_stream_t stream);
 
+/* The two halves of mh_embedding_gather_bwd as separate calls.  _prepare needs the ids only (segmented sort + piece list,
+ * left in the workspace): a caller issues it at the START of the step on a second stream, beside the forward pass, and the
+ * sort leaves the critical path (142 us of the 430 us launch at the C2 shapes).  _apply -- same tables / table_rows / ids /
+ * B / F / D and the SAME, untouched workspace, after the gradient exists -- does the segmented reduce + fused optimizer and
+ * the carried runs.  mh_embedding_gather_bwd == _prepare followed by _apply. */
+int32_t mh_embedding_gather_bwd_prepare(float* const* tables /*HOST [F]: identity of shared tables only*/,
+                                        const int64_t* table_rows, const void* const* ids, int32_t ids_dtype, int64_t B,
+                                        int32_t F, int32_t D, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_embedding_gather_bwd_apply(float* const* tables, float* const* state, const int64_t* table_rows,
+                                      const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
+                                      const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
+                                      int32_t optimizer, float lr, float eps, float* const* state2, float beta1,
+                                      float beta2, const float* lr_device, void* workspace, int64_t workspace_bytes,
+                                      mh_stream_t stream);
+
 /* l2_batch_regularization_factor of EmbeddingTable (inputs/embedding.py:463-464): the layer adds
  * factor * sum(out^2) over the batch of looked-up rows to the loss.  out[B, D] / grad[B, D] are views with row strides
  * ld_out / ld_grad (e.g. one slot of the stacked [B, F, D] buffers): grad += 2 factor out (skipped if grad == NULL),

@@ -36,6 +36,8 @@ SIGNATURES = {
     "mh_embedding_bag_bwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "mh_embedding_bag_bwd": (_i32, [_p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _p, _i64, _i32, _f32, _f32, _f32, _f32, _p, _p, _i64, _p]),
     "mh_embedding_gather_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _f32, _f32, _p, _p, _i64, _p]),
+    "mh_embedding_gather_bwd_prepare": (_i32, [_p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p]),
+    "mh_embedding_gather_bwd_apply": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _f32, _f32, _p, _p, _i64, _p]),
     "mh_l2_batch_reg": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _f32, _p, _p, _p]),
     "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),

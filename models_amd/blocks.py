@@ -389,6 +389,8 @@ class DLRMBlock(Block):
             slot_ids = [None if k == "bottom_block" else inputs[k] for k in self.stack_order]
             self._slots_ctx = (slot_tables, slot_ids, dense)
             self.embeddings._last = {n: inputs[n] for n in self.cat_names}
+            if _TAPE[0] > 0:  # training: the sort of the sparse update starts now, beside the forward (eager steps)
+                self.embeddings.prepare_sparse(inputs, self.cat_names)
             if self.top_block is None:
                 return ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=False)
             width = P + (D if dense is not None else 0)

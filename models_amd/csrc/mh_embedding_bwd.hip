@@ -609,6 +609,10 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     return true;
 }
 
+// phases of one launch: PREPARE = everything that depends on the ids only (sort, cleared carry rows, piece list -- left in the
+// workspace); APPLY = the gradient-dependent part (segmented reduce + fused optimizer, carried runs)
+enum { PH_PREPARE = 1, PH_APPLY = 2, PH_ALL = 3 };
+
 bool deterministic_mode() {
     const char* v = getenv("MERLIN_HIP_DETERMINISTIC");
     return v && v[0] == '1';
@@ -617,7 +621,7 @@ bool deterministic_mode() {
 template <typename IdT, typename KeyT>
 int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbits, const WsLayout& L, char* ws, int64_t B, int F,
                        int D, const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp,
-                       hipStream_t s) {
+                       hipStream_t s, int phases) {
     void* kbuf[2] = {ws + L.off_keys_a, ws + L.off_keys_b};
     uint32_t* vbuf[2] = {reinterpret_cast<uint32_t*>(ws + L.off_vals_a), reinterpret_cast<uint32_t*>(ws + L.off_vals_b)};
     float* carry = reinterpret_cast<float*>(ws + L.off_carry);
@@ -630,7 +634,7 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     // ---- 1. segmented stable LSD radix sort: digit width rbits per pass; a segment runs only the passes its own
     //         key bits need (sa.npass) and alternates buffers so that its last pass lands in buffer 1 ---------------------
     const int ntiles = sa.tile0[sa.nseg];
-    for (int p = 0; p < npass; ++p) {
+    for (int p = 0; (phases & PH_PREPARE) && p < npass; ++p) {
         const int shift = p * rbits;
         hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
                            (const void*)kbuf[1], p, shift, rbits, cnt);
@@ -642,15 +646,20 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     const uint32_t* vals = vbuf[1];
 
     // ---- 2. piece list, 3. segmented reduce + fused optimizer, 4. carried runs -------------------------------------------
-    {  // a kernel, not a memset node (see mh_fill_words); deterministic mode does not accumulate into `carry`
+    if (phases & PH_PREPARE) {  // a kernel, not a memset node (see mh_fill_words); deterministic mode does not accumulate into `carry`
         const int32_t st = det ? mh_fill_words(counter, 0u, 1, s)
                                : mh_fill_words(carry, 0u, (int64_t)(L.off_counter + 4 - L.off_carry) / 4, s);
         if (st != MH_OK) return st;
     }
     const int LPR = D / 4;
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
-    hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
-                       keys, vals, L.n, pieces, home, counter);
+    if (phases & PH_PREPARE)
+        hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
+                           keys, vals, L.n, pieces, home, counter);
+    if (!(phases & PH_APPLY)) {
+        MH_CHECK_LAUNCH("mh_embedding_gather_bwd_prepare");
+        return MH_OK;
+    }
     {
         int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
         static int resident = 0;  // workgroups per CU the kernel's register budget allows: exactly one resident wave
@@ -780,12 +789,21 @@ int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D) {
     return (int64_t)L.total;
 }
 
-int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const int64_t* table_rows,
-                                const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
-                                const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
-                                int32_t optimizer, float lr, float eps, float* const* state2, float beta1, float beta2,
-                                const float* lr_device, void* workspace, int64_t workspace_bytes,
-                                mh_stream_t stream) {
+static int32_t gather_bwd_impl(float* const* tables, float* const* state, const int64_t* table_rows,
+                               const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
+                               const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
+                               int32_t optimizer, float lr, float eps, float* const* state2, float beta1, float beta2,
+                               const float* lr_device, void* workspace, int64_t workspace_bytes,
+                               mh_stream_t stream, int phases) {
+    if (phases == PH_PREPARE) {  // ids only: no gradient, no optimizer state yet
+        static const int64_t zero_off[MH_MAX_FEATURES] = {0};
+        MH_REQUIRE(tables && table_rows && ids, "mh_embedding_gather_bwd_prepare: null argument");
+        grad = reinterpret_cast<const float*>(tables[0]);  // any 16-byte aligned address: never dereferenced by this phase
+        grad_row_stride = D;
+        grad_offset = zero_off;
+        optimizer = MH_OPT_SGD;
+        state = state2 = nullptr;
+    }
     MH_REQUIRE(tables && table_rows && ids && grad && grad_offset, "mh_embedding_gather_bwd: null argument");
     MH_REQUIRE(F >= 1 && F < MH_MAX_FEATURES, "mh_embedding_gather_bwd: F=%d outside [1,%d]", F, MH_MAX_FEATURES - 1);
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_bwd: D=%d must be a multiple of 4 in [4,1024]", D);
@@ -872,11 +890,41 @@ int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const
     }
     const bool wide = (uint64_t)total_rows >= 0xffffffffull;
     if (ids_dtype == MH_I32) {
-        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
-        return run_pipeline_t<int32_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
+        return run_pipeline_t<int32_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
     }
-    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
-    return run_pipeline_t<int64_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s);
+    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
+    return run_pipeline_t<int64_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
+}
+
+int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const int64_t* table_rows,
+                                const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
+                                const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
+                                int32_t optimizer, float lr, float eps, float* const* state2, float beta1, float beta2,
+                                const float* lr_device, void* workspace, int64_t workspace_bytes,
+                                mh_stream_t stream) {
+    return gather_bwd_impl(tables, state, table_rows, ids, ids_dtype, B, F, D, grad, grad_row_stride, grad_offset, optimizer, lr,
+                           eps, state2, beta1, beta2, lr_device, workspace, workspace_bytes, stream, PH_ALL);
+}
+
+// The two halves of mh_embedding_gather_bwd as separate calls: _prepare needs the ids only (sort + piece list, left in the
+// workspace), so a caller can issue it at the START of the step on a second stream, beside the forward pass; _apply (same
+// tables / ids / shapes / workspace, after the gradient exists) does the segmented reduce + fused optimizer.
+int32_t mh_embedding_gather_bwd_prepare(float* const* tables, const int64_t* table_rows, const void* const* ids,
+                                        int32_t ids_dtype, int64_t B, int32_t F, int32_t D, void* workspace,
+                                        int64_t workspace_bytes, mh_stream_t stream) {
+    return gather_bwd_impl(tables, nullptr, table_rows, ids, ids_dtype, B, F, D, nullptr, 0, nullptr, MH_OPT_SGD, 0.f, 0.f,
+                           nullptr, 0.f, 0.f, nullptr, workspace, workspace_bytes, stream, PH_PREPARE);
+}
+
+int32_t mh_embedding_gather_bwd_apply(float* const* tables, float* const* state, const int64_t* table_rows,
+                                      const void* const* ids, int32_t ids_dtype, int64_t B, int32_t F, int32_t D,
+                                      const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
+                                      int32_t optimizer, float lr, float eps, float* const* state2, float beta1,
+                                      float beta2, const float* lr_device, void* workspace, int64_t workspace_bytes,
+                                      mh_stream_t stream) {
+    return gather_bwd_impl(tables, state, table_rows, ids, ids_dtype, B, F, D, grad, grad_row_stride, grad_offset, optimizer, lr,
+                           eps, state2, beta1, beta2, lr_device, workspace, workspace_bytes, stream, PH_APPLY);
 }
 
 int64_t mh_embedding_bag_bwd_workspace_bytes(int64_t B, int64_t nnz, int32_t D) {

@@ -216,6 +216,24 @@ class EmbeddingsBlock(ParallelBlock):
                              out_offset=[offsets[n] for n in names])
         self._last = {n: inputs[n] for n in names}
 
+    def prepare_sparse(self, inputs: TabularData, names: Sequence[str]) -> None:
+        """Start the id-only half of the fused sparse update (segmented sort + piece list) NOW, on the "sort" side stream,
+        so that it runs beside the forward pass instead of on the step's critical path (eager steps under ``blocks.tape``
+        only: a replayed hipGraph is one hardware queue).  Only the plain case is prepared: every feature one-hot, one
+        embedding dim, one launch; ``_apply_sparse_now`` falls back to the single call for anything else."""
+        self._prepared = None
+        if not names or len(names) > 63 or not ops.SIDE.active("sort"):
+            return
+        fts = [self.feature_table[n] for n in names]
+        if len({ft.dim for ft in fts}) != 1 or not all(ft.table.trainable for ft in fts):
+            return
+        if not all(self._is_onehot(inputs[n]) for n in names) or self.has_batch_regularization:
+            return
+        side = ops.SIDE.fork("sort", keep=tuple(inputs[n] for n in names))
+        with torch.cuda.stream(side):
+            h = ops.embedding_gather_backward_prepare([ft.table.data for ft in fts], [inputs[n] for n in names])
+        self._prepared = (tuple(names), h) if h is not None else None
+
     @property
     def has_batch_regularization(self) -> bool:
         return any(t.l2_batch_regularization_factor > 0 for t in self.parallel_layers.values())
@@ -364,12 +382,16 @@ class EmbeddingsBlock(ParallelBlock):
                     if "m" not in t.state:
                         t.state["m"], t.state["v"] = torch.zeros_like(t.data), torch.zeros_like(t.data)
                 states, states2 = [t.state["m"] for t in tabs], [t.state["v"] for t in tabs]
+            prep = getattr(self, "_prepared", None)
+            self._prepared = None
             for start in range(0, len(grp), 63):
                 sl = slice(start, start + 63)
+                handle = prep[1] if prep is not None and prep[0] == tuple(grp[sl]) else None
                 ops.embedding_gather_backward([t.data for t in tabs[sl]], None if states is None else states[sl],
                                               [self._last[n] for n in grp[sl]], grad, [offsets[n] for n in grp[sl]],
                                               opt.name, opt.learning_rate, opt.epsilon,
-                                              None if states2 is None else states2[sl], opt.beta_1, opt.beta_2, opt.lr_device)
+                                              None if states2 is None else states2[sl], opt.beta_1, opt.beta_2, opt.lr_device,
+                                              prepared=handle)
 
 
 def Embeddings(schema: Schema, dim: Optional[Union[Dict[str, int], int]] = None,

@@ -91,7 +91,7 @@ class _SideStreams:
 
         mode = os.environ.get("MERLIN_HIP_SIDE_STREAMS", "1")  # "0" | "1" | "dw" | "sparse" (one kind only: debugging)
         self.enabled = mode != "0"
-        self.kinds = {"dw", "sparse"} if mode in ("0", "1") else {mode}
+        self.kinds = {"dw", "sparse", "sort"} if mode in ("0", "1") else {mode}
         self._streams = {}
         self._pending = set()
         self._keep = []
@@ -579,13 +579,53 @@ def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int
     return dx
 
 
+class PreparedSparseUpdate:
+    """Handle of ``embedding_gather_backward_prepare``: the sorted ids / piece list live in ``ws`` until the matching
+    ``embedding_gather_backward(..., prepared=handle)``; ``event`` marks the end of the preparation on its stream."""
+
+    def __init__(self, ws, key, event):
+        self.ws, self.key, self.event = ws, key, event
+
+
+def _sparse_key(tables, ids, B, D):
+    return (tuple(t.data_ptr() for t in tables), tuple(i.data_ptr() for i in ids), int(B), int(D))
+
+
+def embedding_gather_backward_prepare(tables: Sequence[torch.Tensor], ids: Sequence[torch.Tensor]) -> Optional[PreparedSparseUpdate]:
+    """The id-only half of ``embedding_gather_backward`` (segmented sort + piece list) on the CURRENT stream -- call it on a
+    side stream at the start of the step so that it runs beside the forward pass.  The handle owns a dedicated workspace."""
+    lib = _lib.load()
+    F = len(tables)
+    if F == 0 or F > _lib.MAX_FEATURES - 1:
+        return None
+    flat = [i.reshape(-1) for i in ids]
+    B, D = flat[0].shape[0], tables[0].shape[1]
+    if B == 0 or any(i.shape[0] != B or not i.is_contiguous() or i.dtype != flat[0].dtype for i in flat):
+        return None
+    idt = _ids_dtype(flat[0], "ids[0]")
+    nbytes = lib.mh_embedding_bwd_workspace_bytes(B, F, D)
+    if nbytes < 0:
+        return None
+    ws = _workspace(nbytes, tables[0].device, "embedding_bwd_prepared")
+    tab = _host_ptr_array([w.data_ptr() for w in tables])
+    idp = _host_ptr_array([i.data_ptr() for i in flat])
+    rows = (C.c_int64 * F)(*[w.shape[0] for w in tables])
+    check(lib.mh_embedding_gather_bwd_prepare(tab, rows, idp, idt, B, F, D, _ptr(ws), ws.numel(), _stream()),
+          "mh_embedding_gather_bwd_prepare")
+    ev = torch.cuda.Event()
+    ev.record()
+    return PreparedSparseUpdate(ws, _sparse_key(tables, flat, B, D), ev)
+
+
 def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[Sequence[Optional[torch.Tensor]]],
                               ids: Sequence[torch.Tensor], grad: torch.Tensor, grad_offset: Sequence[int],
                               optimizer: str = "sgd", lr: float = 0.01, eps: float = 1e-7,
                               states2: Optional[Sequence[torch.Tensor]] = None, beta1: float = 0.9, beta2: float = 0.999,
-                              lr_device: Optional[torch.Tensor] = None) -> None:
+                              lr_device: Optional[torch.Tensor] = None, prepared: Optional[PreparedSparseUpdate] = None) -> None:
     """Fused backward + sparse optimizer step for the one-hot lookup.  ``grad`` is a contiguous
-    ``[B, ...]`` buffer; feature f's gradient row starts ``grad_offset[f]`` floats into row b."""
+    ``[B, ...]`` buffer; feature f's gradient row starts ``grad_offset[f]`` floats into row b.
+    ``prepared``: handle of ``embedding_gather_backward_prepare`` for the SAME tables / ids (checked): only the
+    gradient-dependent half runs, after waiting for the preparation's event."""
     lib = _lib.load()
     F = len(tables)
     if F == 0:
@@ -616,6 +656,17 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     nbytes = lib.mh_embedding_bwd_workspace_bytes(B, F, D)
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_embedding_bwd_workspace_bytes failed")
+    if prepared is not None and prepared.key == _sparse_key(tables, flat, B, D) and prepared.ws.numel() >= nbytes:
+        torch.cuda.current_stream().wait_event(prepared.event)
+        ws = prepared.ws
+        with _timed("embedding_bwd_apply", nbytes=B * F * (_OPT_ROW_PASSES[optimizer] * D * 4 + flat[0].element_size())):
+            check(
+                lib.mh_embedding_gather_bwd_apply(tab, st, rows, idp, idt, B, F, D, _ptr(grad), row_stride, slot,
+                                                  _lib.OPT[optimizer], lr, eps, st2, beta1, beta2, _ptr(lr_device), _ptr(ws),
+                                                  ws.numel(), _stream()),
+                "mh_embedding_gather_bwd_apply",
+            )
+        return
     ws = _workspace(nbytes, grad.device, "embedding_bwd")
     with _timed("embedding_bwd", nbytes=B * F * (_OPT_ROW_PASSES[optimizer] * D * 4 + flat[0].element_size())):
         check(

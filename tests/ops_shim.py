@@ -92,7 +92,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx=True, need_db=True, x_
 
 
 def embedding_gather_backward(tables, states, ids, grad, grad_offset, optimizer="sgd", lr=0.01, eps=1e-7,
-                              states2=None, beta1=0.9, beta2=0.999, lr_device=None):
+                              states2=None, beta1=0.9, beta2=0.999, lr_device=None, prepared=None):
     if optimizer not in ("sgd", "adagrad"):
         raise NotImplementedError("shim: sgd / adagrad only")
     B = grad.shape[0]
