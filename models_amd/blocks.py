@@ -6,6 +6,8 @@ DLRMBlock (dlrm.py:32-170), CrossBlock / Cross (cross.py:29-202), TwoTowerBlock
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional, Sequence, Union
 
@@ -389,7 +391,8 @@ class DLRMBlock(Block):
             slot_ids = [None if k == "bottom_block" else inputs[k] for k in self.stack_order]
             self._slots_ctx = (slot_tables, slot_ids, dense)
             self.embeddings._last = {n: inputs[n] for n in self.cat_names}
-            if _TAPE[0] > 0:  # training: the sort of the sparse update starts now, beside the forward (eager steps)
+            sort_late = os.environ.get("MERLIN_HIP_SORT_AFTER_GATHER", "1") != "0"
+            if _TAPE[0] > 0 and not sort_late:
                 self.embeddings.prepare_sparse(inputs, self.cat_names)
             if self.top_block is None:
                 return ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=False)
@@ -400,6 +403,11 @@ class DLRMBlock(Block):
                 buf[:, width:].zero_()
             top_in = buf[:, :width]
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
+            if _TAPE[0] > 0 and sort_late:
+                # training, eager step: the id-only sort of the sparse update is forked HERE, behind the HBM-bound gather ->
+                # interaction kernel, so that it runs beside the MFMA-bound top MLP (a light, latency-bound partner for it)
+                # rather than competing with the gather for memory
+                self.embeddings.prepare_sparse(inputs, self.cat_names)
             self._top_in = top_in
             return self._top(top_in, head)
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)

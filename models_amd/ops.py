@@ -492,6 +492,7 @@ def dot_interaction(
 # backward / training ops
 # --------------------------------------------------------------------------------------------
 _WS = {}
+_DW_AFTER_DX = __import__("os").environ.get("MERLIN_HIP_DW_AFTER_DX", "1") != "0"
 
 
 def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
@@ -541,15 +542,23 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         if act != 0:
             check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
                                              0, None, 0, None, None, None, 0, _stream()), "mh_linear_bias_act_bwd")
-        side = SIDE.fork("dw", keep=(x, dy))
+        # dX first, on the launch stream; dW / db start on the "dw" stream only when dX is done, so that the MFMA-bound dW
+        # runs beside whatever FOLLOWS dX on the launch stream (for the top-MLP layer of a DLRM: the HBM-bound interaction
+        # backward) instead of competing with dX for the matrix pipe
+        if need_dx:
+            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
+                                             ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
+                  "mh_linear_bias_act_bwd")
+        if _DW_AFTER_DX:
+            ev = torch.cuda.Event()
+            ev.record()
+            side = SIDE.fork_after("dw", ev, keep=(x, dy))
+        else:
+            side = SIDE.fork("dw", keep=(x, dy))
         ws = _workspace(nbytes, x.device, "linear_bwd_side")
         with torch.cuda.stream(side):
             check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
                                              None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
-                  "mh_linear_bias_act_bwd")
-        if need_dx:
-            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
-                                             ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
                   "mh_linear_bias_act_bwd")
         SIDE.maybe_join()
         return dx, dW, db

@@ -186,3 +186,42 @@ def test_route_full_size_is_a_stable_partition(device):
     want_src = torch.empty(n, dtype=torch.int64, device=device)
     want_src[flat_pos] = torch.arange(B, device=device).repeat(F) * NS + torch.tensor(slots, device=device).repeat_interleave(B)
     assert torch.equal(src_row, want_src)
+
+
+def test_fused_chains_equal_layer_by_layer_at_the_baseline_batch(device):
+    """The two fused chains of the C2 DLRM (bottom MLP 13 -> 128 -> 64, top tail + head 128 -> 64 -> 32 -> 1) at B = 65 536:
+    forward and dX bit-identical to the layer-by-layer kernels (same k-ascending fmaf chains), dW / db equal to
+    reassociation error, and the column-sum identity db == sum_rows(dz) holds for the last layer."""
+    from models_amd import ops
+
+    M = 65536
+    g = torch.Generator().manual_seed(7)
+    for dims, acts, x_act in [([13, 128, 64], ["relu", "relu"], None), ([128, 64, 32, 1], ["relu", "relu", "sigmoid"], "relu")]:
+        x = torch.rand(M, dims[0], generator=g).to(device)
+        Ws = [((torch.rand(dims[i], dims[i + 1], generator=g) - 0.5) * (2.0 / dims[i] ** 0.5)).to(device) for i in range(len(dims) - 1)]
+        bs = [(torch.rand(dims[i + 1], generator=g) * 0.1).to(device) for i in range(len(dims) - 1)]
+        ys = ops.mlp_chain(x, Ws, bs, acts)
+        h = x
+        for l, (W, b, a) in enumerate(zip(Ws, bs, acts)):
+            h = ops.linear(h, W, b, a)
+            if W.shape[1] > 4:
+                assert torch.equal(ys[l], h)
+            else:
+                torch.testing.assert_close(ys[l], h, atol=2e-6, rtol=1e-5)
+            h = ys[l]
+        pre = dims[-1] == 1  # the head receives the BCE gradient w.r.t. its pre-activation
+        dy = (torch.rand(M, dims[-1], generator=g) - 0.5).to(device) / M
+        dx, dWs, dbs = ops.mlp_chain_backward(x, Ws, ys, acts, dy, pre_masked=pre, need_dx=x_act is not None, x_activation=x_act)
+        grad, pm = dy.clone(), pre
+        xs = [x] + ys[:-1]
+        for l in range(len(Ws) - 1, -1, -1):
+            prev = acts[l - 1] if l > 0 else x_act
+            grad, rW, rb = ops.linear_backward(xs[l], Ws[l], ys[l], grad, None if pm else acts[l],
+                                               need_dx=(l > 0) or x_act is not None, x_activation=prev)
+            pm = prev is not None
+            torch.testing.assert_close(dWs[l], rW, atol=1e-6, rtol=5e-4)
+            torch.testing.assert_close(dbs[l], rb, atol=1e-6, rtol=5e-4)
+        if x_act is not None:
+            assert torch.equal(dx, grad)
+        if pre:
+            torch.testing.assert_close(dbs[-1], dy.sum(0), atol=1e-7, rtol=1e-4)

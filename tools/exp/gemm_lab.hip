@@ -94,7 +94,8 @@ int main(int argc, char** argv) {
                             {"dX   128->416   (NT, K=128)", 128, 416, true, 30},
                             {"tower 512x256   (NN)", 512, 256, false, 30},
                             {"deep 3344x512   (NN)", 3344, 512, false, 5},
-                            {"cross 3344x3344 (NN)", 3344, 3344, false, 2}};
+                            {"cross 3344x3344 (NN)", 3344, 3344, false, 2},
+                            {"dXcross 3344x3344 (NT)", 3344, 3344, true, 2}};
     const char* only = argc > 1 ? argv[1] : nullptr;
     for (const Shape& sh : shapes) {
         if (only && !strstr(sh.name, only)) continue;
