@@ -336,6 +336,18 @@ class ShardedEmbeddingGroup:
         back, work = self._exchange(rows, self._n_send, self._send_counts, self._recv_counts, async_op=True)
         self._pending_lookup = (work, back, rows, scatter_into, F_sh, B)
 
+    def prepare_update(self) -> None:
+        """Training step, HIP path: the owner-side rows of this step's requests are known since ``lookup_begin`` -- start the
+        id-only half of their fused update (sort + piece list) on the "sort" side stream now, beside the rest of the forward."""
+        from . import ops
+
+        self._prepared_update = None
+        if self._rows is None or not self._rows.is_cuda or not ops.SIDE.active("sort"):
+            return
+        side = ops.SIDE.fork("sort_sharded", keep=(self._rows,))
+        with torch.cuda.stream(side):
+            self._prepared_update = ops.embedding_gather_backward_prepare([self.local], [self._rows], tag=":sharded")
+
     def lookup_end(self, scatter: Optional[Callable] = None) -> Optional[torch.Tensor]:
         """``scatter(back, [pos_of[f] ...])``: the caller places the returned rows itself (e.g. into a concat buffer)."""
         work, back, _rows_alive, scatter_into, F_sh, B = self._pending_lookup
@@ -459,9 +471,11 @@ def _hip_group_fns(owner):
         D = table.shape[1]
         g3 = grads.reshape(grads.shape[0], 1, D).contiguous()
         st2 = owner.group_sh.state2  # LazyAdam second moment of the local shards
+        prep = getattr(owner.group_sh, "_prepared_update", None)  # id-only half already done beside the forward
+        owner.group_sh._prepared_update = None
         ops.embedding_gather_backward([table], None if state is None else [state], [rows], g3, [0], opt.name,
                                       opt.learning_rate, opt.epsilon, None if st2 is None else [st2],
-                                      opt.beta_1, opt.beta_2, opt.lr_device)
+                                      opt.beta_1, opt.beta_2, opt.lr_device, prepared=prep)
 
     return gather_fn, update_fn
 
@@ -590,7 +604,7 @@ class DistributedDLRM:
                         cur.copy_(val)
 
     # forward of the DLRM body with sharded lookups
-    def forward_body(self, inputs, head=None):
+    def forward_body(self, inputs, head=None, training: bool = False):
         from . import ops
 
         body = self.body
@@ -598,7 +612,7 @@ class DistributedDLRM:
         dev = inputs[body.cat_names[0]].device
         F, D = body.num_features, body.dim
         if dev.type == "cuda" and body._fusable(inputs):
-            return self._forward_body_fused(inputs, head)
+            return self._forward_body_fused(inputs, head, training)
         # 1. route FIRST: its one host sync then waits only for the tiny bucketing kernels, and everything
         #    below is enqueued back to back; the row all-to-all overlaps the bottom MLP / replicated gather
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
@@ -634,7 +648,7 @@ class DistributedDLRM:
         body._top_in = top_in
         return body._top(top_in, head)  # the Dense(1, sigmoid) head rides on the top MLP's fused chain
 
-    def _forward_body_fused(self, inputs, head=None):
+    def _forward_body_fused(self, inputs, head=None, training: bool = False):
         """The fused gather -> interaction kernel on the sharded path: a sharded feature's slot is the buffer of rows that
         came back from the owners, indexed by the position of request (f, b) in it (``pos_of``; a dropped request is -1 and
         reads as a zero row) -- no stacked [B, F, D] tensor, no scatter of the returned rows, and the backward re-gathers
@@ -677,6 +691,17 @@ class DistributedDLRM:
             buf[:, width:].zero_()
         top_in = buf[:, :width]
         ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
+        self._prep_rep = None
+        if training and ops.SIDE.active("sort"):
+            # the id-only halves (sort + piece list) of BOTH sparse updates of the step start here, behind the HBM-bound
+            # gather -> interaction kernel, beside the MFMA-bound top MLP (same placement as the one-GPU step)
+            if gs is not None:
+                gs.prepare_update()
+            if self.replicated:
+                side = ops.SIDE.fork("sort", keep=tuple(inputs[n] for n in self.replicated))
+                with torch.cuda.stream(side):
+                    self._prep_rep = ops.embedding_gather_backward_prepare(
+                        [emb.feature_table[n].table.data for n in self.replicated], [inputs[n] for n in self.replicated], tag=":rep")
         body._fused = True
         body._slots_ctx = (slot_tables, slot_ids, dense)  # keeps the returned rows alive for the backward's re-gather
         body._top_in = top_in
@@ -698,7 +723,7 @@ class DistributedDLRM:
             model.compile()
         opt = model.optimizer
         x = prepare_features(inputs)
-        p = self.forward_body(x, head=model.output.to_call)
+        p = self.forward_body(x, head=model.output.to_call, training=True)
         B = p.shape[0]
         loss, dlogit = ops.bce(p, targets, need_grad=True)
         if self.world_size > 1:
@@ -740,9 +765,10 @@ class DistributedDLRM:
             if rep_tabs:
                 bucket[n_head:n_head + n_rep].zero_()
                 # per FEATURE: features sharing a table pass the same gradient buffer and are summed into it
+                prep, self._prep_rep = getattr(self, "_prep_rep", None), None
                 ops.embedding_gather_backward([grad_of[id(emb.feature_table[n].table)] for n in self.replicated], None,
                                               [x[n] for n in self.replicated], dstack,
-                                              [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0)
+                                              [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0, prepared=prep)
             ops.SIDE.join()  # the dW / db GEMMs ran on their side stream: the bucket below reads them
         # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
         torch.cat([q.grad.reshape(-1) for q in dense] + [loss.detach().reshape(1)], out=bucket[:n_dense + 1])

@@ -597,12 +597,19 @@ class PreparedSparseUpdate:
 
 
 def _sparse_key(tables, ids, B, D):
-    return (tuple(t.data_ptr() for t in tables), tuple(i.data_ptr() for i in ids), int(B), int(D))
+    """What the prepared half depends on: the id buffers, the row counts and WHICH features share a table (the segments of
+    the sort) -- not the table addresses themselves: the apply may target other buffers of the same shapes (the dense
+    gradient accumulators of replicated tables in the data-parallel step)."""
+    ptrs = [t.data_ptr() for t in tables]
+    share = tuple(ptrs.index(p) for p in ptrs)
+    return (share, tuple(int(t.shape[0]) for t in tables), tuple(i.data_ptr() for i in ids), int(B), int(D))
 
 
-def embedding_gather_backward_prepare(tables: Sequence[torch.Tensor], ids: Sequence[torch.Tensor]) -> Optional[PreparedSparseUpdate]:
+def embedding_gather_backward_prepare(tables: Sequence[torch.Tensor], ids: Sequence[torch.Tensor],
+                                      tag: str = "") -> Optional[PreparedSparseUpdate]:
     """The id-only half of ``embedding_gather_backward`` (segmented sort + piece list) on the CURRENT stream -- call it on a
-    side stream at the start of the step so that it runs beside the forward pass.  The handle owns a dedicated workspace."""
+    side stream at the start of the step so that it runs beside the forward pass.  The handle owns the workspace named by
+    ``tag`` (two updates prepared in the same step need two tags)."""
     lib = _lib.load()
     F = len(tables)
     if F == 0 or F > _lib.MAX_FEATURES - 1:
@@ -615,7 +622,7 @@ def embedding_gather_backward_prepare(tables: Sequence[torch.Tensor], ids: Seque
     nbytes = lib.mh_embedding_bwd_workspace_bytes(B, F, D)
     if nbytes < 0:
         return None
-    ws = _workspace(nbytes, tables[0].device, "embedding_bwd_prepared")
+    ws = _workspace(nbytes, tables[0].device, "embedding_bwd_prepared" + tag)
     tab = _host_ptr_array([w.data_ptr() for w in tables])
     idp = _host_ptr_array([i.data_ptr() for i in flat])
     rows = (C.c_int64 * F)(*[w.shape[0] for w in tables])
