@@ -16,8 +16,10 @@
 //             from REGISTERS (the C layout of a [16 x 16] tile is both the A operand of y^T and the B operand of dz when
 //             the contraction index is numbered (step r, k-slot q) <-> row 4 q + r); db_l += colsum; g = dz_l W_l^T
 //             through the slab (k-ascending over n: bit-identical to gemm_nt_kernel).  dz never goes to HBM; dW / db
-//             accumulate in registers over all strips of a wavefront, are summed across the workgroup through LDS and
-//             leave as ONE partial slab per workgroup; a second small kernel sums the slabs in a fixed order.
+//             accumulate in registers over all strips of a wavefront, are summed across the workgroup through LDS (every
+//             wavefront sums and stores a quarter of the tiles) and leave as ONE partial slab per workgroup; a second small
+//             kernel sums the slabs in a fixed order.  LDS operands run two MFMA steps ahead of their use (chain_mfma_loop);
+//             loop bodies are specialised on the activation; full strips take pointer-increment load / store paths.
 //
 // Widths are padded to multiples of 16 at compile time (template signature <P0, P1, P2, P3>); the host picks the
 // cheapest signature that covers a chain and falls back to the layer-by-layer kernels when none does.
@@ -528,21 +530,6 @@ __device__ __forceinline__ void wg_reduce_store_dw(const f32x4* __restrict__ dw,
     }
 }
 static_assert(CW == 4, "wg_reduce_store_dw sums four wavefronts");
-
-// wave 0 writes the workgroup's dW tile array of one layer to its slab (real entries only)
-template <int PIN, int POUT>
-__device__ __forceinline__ void store_dw(const f32x4* __restrict__ dw, float* __restrict__ out, int K, int N, int lane) {
-    const int l15 = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int ti = 0; ti < PIN / 16; ++ti)
-#pragma unroll
-        for (int tn = 0; tn < POUT / 16; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = 16 * ti + 4 * q + r, n = 16 * tn + l15;
-                if (kk < K && n < N) out[kk * N + n] = dw[ti * (POUT / 16) + tn][r];
-            }
-}
 
 template <int P0, int P1, int P2, int P3, bool NEED_DX>
 __global__ __launch_bounds__(CW * 64) void chain_bwd_kernel(const ChainArgs a) {

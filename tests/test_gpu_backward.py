@@ -331,3 +331,24 @@ def test_wide_backward_equals_first_generation_core(device):
     (y0, dx0, dW0, db0), (y1, dx1, dW1, db1) = outs
     assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dW0, dW1)
     torch.testing.assert_close(db0, db1, atol=1e-4, rtol=1e-5)  # column sums: 16- vs 32-row partial sums per k-tile
+
+
+def test_dense_adam_reproduces_the_reference_known_answers(device):
+    """The DENSE scenario of the reference's optimizer suite (tests/unit/tf/blocks/test_optimizer.py:448-487: var0 = [1, 2]
+    with grads [0.1, 0.1], var1 = [3, 4] with grads [0.01, 0.01], three steps against `adam_update_numpy`) through
+    mh_dense_optimizer_step -- the Keras Adam that the dense tensors of a model take (tf/models/base.py:476-508)."""
+    from models_amd import optim
+    from models_amd.core import Parameter
+
+    opt = optim.Adam(learning_rate=0.001)
+    scen = [(np.array([1.0, 2.0], np.float32), np.array([0.1, 0.1], np.float32)),
+            (np.array([3.0, 4.0], np.float32), np.array([0.01, 0.01], np.float32))]
+    params = [Parameter(torch.from_numpy(v.copy()).to(device), name=f"var{i}") for i, (v, _) in enumerate(scen)]
+    ref = [(v.astype(np.float64).copy(), np.zeros(2), np.zeros(2)) for v, _ in scen]
+    for t in range(3):
+        opt.begin_step(device)
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(scen[i][1]).to(device)
+            ops.dense_optimizer_step(opt, p)
+            ref[i] = O.adam_update(ref[i][0], scen[i][1].astype(np.float64), t, ref[i][1], ref[i][2])
+            np.testing.assert_allclose(p.data.cpu().numpy(), ref[i][0], rtol=1e-6, atol=1e-6)
