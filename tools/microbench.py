@@ -123,8 +123,20 @@ if "topk" in which:
     c = torch.randn(N, E, device=dev)
     qq = torch.randn(Bq, E, device=dev)
     timeit("topk 4096 x 1M x 128, k=100", lambda: ops.topk_dot(qq, c, None, k), flops=2 * Bq * N * E, iters=3)
+if "chain" in which:
+    for dims, acts, need_dx, pre in [([13, 128, 64], ["relu", "relu"], False, False), ([128, 64, 32, 1], ["relu", "relu", "sigmoid"], True, True)]:
+        xc = torch.rand(B, dims[0], device=dev)
+        Ws = [(torch.rand(dims[i], dims[i + 1], device=dev) - 0.5) * 0.2 for i in range(len(dims) - 1)]
+        bs = [torch.zeros(dims[i + 1], device=dev) for i in range(len(dims) - 1)]
+        ys = ops.mlp_chain(xc, Ws, bs, acts)
+        gr = torch.rand(B, dims[-1], device=dev)
+        tag = "x".join(map(str, dims))
+        timeit(f"mlp_chain fwd {tag}", lambda: ops.mlp_chain(xc, Ws, bs, acts, ys), flops=2 * B * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)))
+        timeit(f"mlp_chain bwd {tag}", lambda: ops.mlp_chain_backward(xc, Ws, ys, acts, gr, pre_masked=pre, need_dx=need_dx,
+                                                                      x_activation="relu" if need_dx else None),
+               flops=4 * B * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)))
 if "cross" in which:
-    for d in (3341, 3344):
+    for d in (3344,):
         x0 = torch.randn(B, d, device=dev)
         W = torch.randn(d, d, device=dev) * 0.02
         bb = torch.zeros(d, device=dev)

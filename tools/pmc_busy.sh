@@ -24,7 +24,7 @@ def ratio(v, a, b):
     return f"{v[a] / v[b]:.2f}" if v.get(b) else "-"
 print(f"{'kernel':58s} {'n':>4s} mfma/busy wait_any/wave wait_inst/wave lds_wait/wave lds_conf/lds_act valu/busy vmem/busy")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0)):
-    if not any(s in k for s in os.environ.get("PMC_FILTER", "gemm,linear_fwd,scorer,interaction,piece,gather_fwd").split(",")):
+    if not any(s in k for s in os.environ.get("PMC_FILTER", "gemm,linear_fwd,stream_kernel,chain_,interaction,fused,piece,gather_fwd").split(",")):
         continue
     print(f"{k:58s} {n[k]:4d} {ratio(v,'SQ_VALU_MFMA_BUSY_CYCLES','SQ_BUSY_CYCLES'):>9s} {ratio(v,'SQ_WAIT_ANY','SQ_WAVE_CYCLES'):>13s} "
           f"{ratio(v,'SQ_WAIT_INST_ANY','SQ_WAVE_CYCLES'):>14s} {ratio(v,'SQ_WAIT_INST_LDS','SQ_WAVE_CYCLES'):>13s} "
