@@ -557,10 +557,13 @@ def main():
             for i in range(10):
                 fn(i)
             return tm.timed(fn, n, 0) / n * 1e3
-        pg, pe = probe(step), probe(eager_step)
-        launch_probe = {"hipGraph_replay_ms": pg, "eager_side_streams_ms": pe}
-        if pe < pg * 0.99:
-            step, graphed = eager_step, None
+        try:
+            pg, pe = probe(step), probe(eager_step)
+            launch_probe = {"hipGraph_replay_ms": pg, "eager_side_streams_ms": pe}
+            if pe < pg * 0.99:
+                step, graphed = eager_step, None
+        except Exception as e:  # noqa: BLE001 -- the replayed graph stays the timed mode
+            launch_probe = {"error": f"{type(e).__name__}: {e}"}
     dt, sustained, step_stats = run_steps(step, args, tm)
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
     if hasattr(runner, "check_overflow"):
