@@ -284,7 +284,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_tn_kernel(const float* __re
         const int p = (wave + j * NW) * 64 + lane;
         const int r = p / CPR, pc = p % CPR;
         int c = k0 + 4 * (pc ^ (8 * (r & 1)));
-        const int clast = (int)((ldx - 4) / 4) * 4;  // chunks past K read the row's padding / next columns: never stored
+        // chunks past K only feed outputs that are never stored: clamp them to the chunk that holds column K - 1 (an
+        // ld-padded operand owns it: ldx % 4 == 0), never beyond -- a column-offset view must not be read past its rows
+        int clast = (K + 3) / 4 * 4 - 4;
+        if (clast > (int)((ldx - 4) / 4) * 4) clast = (int)((ldx - 4) / 4) * 4;
         if (c > clast) c = clast;
         ra[j] = r;
         pa[j] = X + (m_beg + r) * ldx + c;
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_tn_kernel(const float* __re
         const int p = (wave + j * NW) * 64 + lane;
         const int r = p / CPR, pc = p % CPR;
         int c = n0 + 4 * (pc ^ (8 * (r & 1)));
-        const int clast = (int)((ldz - 4) / 4) * 4;
+        int clast = (N + 3) / 4 * 4 - 4;
+        if (clast > (int)((ldz - 4) / 4) * 4) clast = (int)((ldz - 4) / 4) * 4;
         if (c > clast) c = clast;
         rb[j] = r;
         pb[j] = Z + (m_beg + r) * ldz + c;

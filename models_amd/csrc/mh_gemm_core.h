@@ -102,10 +102,10 @@ struct NMajorTile {
     const float* ptr[NV];  // W + r*ldw + clamped column
     int col[NV];
 
-    // Column groups are clamped to the leading dimension, not to N: in vector mode (16-byte aligned rows,
-    // ldw % 4 == 0) the group straddling N reads the row's padding (it only feeds outputs that are never
-    // stored), so an ld-padded operand such as x[M, 415] with ld 416 takes the 16-byte path for every group.
-    // Every row -- the last included -- must therefore own ldw floats.
+    // Column groups are clamped to the group that holds column N - 1 (rounded up to the 16-byte group, within the leading
+    // dimension): in vector mode (16-byte aligned rows, ldw % 4 == 0) the group straddling N reads the row's padding (it
+    // only feeds outputs that are never stored), so an ld-padded operand such as x[M, 415] with ld 416 takes the 16-byte
+    // path for every group.  Every row -- the last included -- must therefore own ceil(N / 4) * 4 floats.
     __device__ __forceinline__ void init(const float* __restrict__ W, int64_t ldw, int n0, int N) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -113,7 +113,9 @@ struct NMajorTile {
             const int r = idx / VPR, c4 = idx - r * VPR;
             int n = n0 + c4 * 4;
             col[i] = n;
-            const int last = (ldw >= 4) ? (int)((ldw - 4) / 4) * 4 : 0;
+            int last = (ldw >= 4) ? (int)((ldw - 4) / 4) * 4 : 0;
+            const int need = (N + 3) / 4 * 4 - 4;  // the group that holds column N - 1: nothing beyond it is ever needed
+            if (need >= 0 && need < last) last = need;  // (a column-offset view must not be read past its rows)
             if (n > last) n = last;
             ptr[i] = W + (int64_t)r * ldw + n;
         }
