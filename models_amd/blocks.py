@@ -9,13 +9,13 @@ from __future__ import annotations
 import os
 
 import math
-from typing import Dict, List, Optional, Sequence, Union
+from typing import List, Optional, Sequence, Union
 
 import numpy as np
 import torch
 
 from . import ops
-from .core import Block, ConcatFeatures, Filter, ParallelBlock, Parameter, SequentialBlock, TabularData
+from .core import Block, ConcatFeatures, ParallelBlock, Parameter, SequentialBlock, TabularData
 from .inputs import ContinuousFeatures, Embeddings, EmbeddingsBlock, default_device
 from .schema import Schema, Tags
 

@@ -7,7 +7,7 @@ plumbing) and replayed; new batches are copied into the static input buffers.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict
 
 import torch
 

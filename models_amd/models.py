@@ -8,17 +8,17 @@
 from __future__ import annotations
 
 import time
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+from typing import Dict, Iterable, List, Optional, Union
 
 import numpy as np
 import torch
 
 from .blocks import tape as blocks_tape
 from . import ops, optim
-from .blocks import CrossBlock, DLRMBlock, MLPBlock, TwoTowerBlock, _Dense
-from .core import Block, ConcatFeatures, ParallelBlock, SequentialBlock, TabularData, call_layer
+from .blocks import CrossBlock, DLRMBlock, MLPBlock, TwoTowerBlock
+from .core import Block, SequentialBlock, TabularData, call_layer
 from .inputs import EmbeddingsBlock, InputBlockV2, Ragged
-from .outputs import BinaryOutput, BruteForce, ContrastiveOutput, Prediction, TopKOutput
+from .outputs import BinaryOutput, ContrastiveOutput, Prediction, TopKOutput
 from .schema import ColumnSchema, Schema, Tags
 
 

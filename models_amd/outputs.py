@@ -5,7 +5,7 @@ BinaryOutput (classification.py:72-123), DotProduct (base.py:291-322), Contrasti
 """
 from __future__ import annotations
 
-from typing import NamedTuple, Optional, Sequence, Union
+from typing import NamedTuple, Optional, Union
 
 import numpy as np
 import torch
