@@ -463,6 +463,12 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
 // (home from the scanned chunk flags).  Every piece is independent, so the random 256-byte read-modify-writes
 // of different rows overlap freely -- tools/exp/rmw_bench.hip measures the same traffic pattern at ~5 TB/s,
 // which the earlier one-group-per-chunk serial walk (2.3 TB/s) could not reach.
+// VMODE 1 (D / 4 in {16, 32, 64}: a group is an aligned part of ONE wavefront at least as wide as a chunk): the dependent
+// chain record -> sample indices -> gradient rows is cut to its last link.  The record is fetched TWO iterations ahead
+// and the piece's <= 16 sample indices ONE iteration ahead, by the group's first 16 lanes in one coalesced load; the
+// gradient-row loop takes them from those lanes with wavefront shuffles.  The LDS partials are double-buffered, so an
+// iteration has one barrier instead of two.  Sums are formed in the same order: results are bit-identical to VMODE 0.
+template <int VMODE>
 __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a, const uint32_t* __restrict__ vals,
                                                                 int D, int LPR, const float* __restrict__ grad,
                                                                 int64_t grad_row_stride, float* __restrict__ carry,
@@ -470,11 +476,13 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
                                                                 const ulonglong2* __restrict__ pieces,
                                                                 const unsigned int* __restrict__ counter, int opt,
                                                                 const OptHyper hp, int deterministic) {
-    __shared__ f32x4 part_s[256];      // partial sum of every group (one f32x4 per thread)
-    __shared__ uint64_t part_key[64];  // key of a group's partial-run piece, ~0 if it has none
+    constexpr int NBUF = VMODE ? 2 : 1;
+    __shared__ f32x4 part_s[NBUF][256];      // partial sum of every group (one f32x4 per thread)
+    __shared__ uint64_t part_key[NBUF][64];  // key of a group's partial-run piece, ~0 if it has none
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
+    const int glane0 = (int)(threadIdx.x & 63) - c4;  // VMODE 1: first lane of the group inside its wavefront
     const int64_t np = (int64_t)*counter;
     const int64_t stride = (int64_t)gridDim.x * groups;
     auto row = [&](uint32_t v) -> f32x4 {
@@ -482,15 +490,45 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         return *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + a.offset[f] +
                                                c4 * 4);
     };
+    // records as scalar pairs (rec, key); a record of length 0 stands for "no piece"
     int64_t base = (int64_t)blockIdx.x * groups;  // block-uniform: the loop carries barriers
-    ulonglong2 next = make_ulonglong2(0ull, ~0ull);
-    if (gi < groups && base + gi < np) next = pieces[base + gi];
+    uint64_t next_rec = 0, next_key = ~0ull, next2_rec = 0, next2_key = ~0ull;
+    uint32_t myv = 0;  // VMODE 1: lane c4 < len holds the sample index of entry c4 of the CURRENT piece
+    if (gi < groups && base + gi < np) {
+        const ulonglong2 r = pieces[base + gi];
+        next_rec = r.x;
+        next_key = r.y;
+    }
+    if (VMODE) {
+        if (gi < groups && base + gi + stride < np) {
+            const ulonglong2 r = pieces[base + gi + stride];
+            next2_rec = r.x;
+            next2_key = r.y;
+        }
+        if (c4 < (int)((next_rec >> 32) & 31)) myv = vals[(int64_t)(next_rec & 0xffffffffull) + c4];
+    }
+    int buf = 0;
     for (; base < np; base += stride) {
         const int64_t p = base + gi;
         const bool active = gi < groups && p < np;
-        const ulonglong2 cur = next;
-        if (gi < groups && p + stride < np) next = pieces[p + stride];  // next record in flight during this piece
-        const uint64_t rec = cur.x, key = cur.y;
+        const uint64_t rec = next_rec, key = next_key;
+        uint32_t nv = 0;
+        if (VMODE) {
+            next_rec = next2_rec;
+            next_key = next2_key;
+            if (c4 < (int)((next_rec >> 32) & 31)) nv = vals[(int64_t)(next_rec & 0xffffffffull) + c4];  // indices of the next piece
+            next2_rec = 0;
+            next2_key = ~0ull;
+            if (gi < groups && p + 2 * stride < np) {
+                const ulonglong2 r = pieces[p + 2 * stride];
+                next2_rec = r.x;
+                next2_key = r.y;
+            }
+        } else if (gi < groups && p + stride < np) {  // next record in flight during this piece
+            const ulonglong2 r = pieces[p + stride];
+            next_rec = r.x;
+            next_key = r.y;
+        }
         const int64_t s0 = (int64_t)(rec & 0xffffffffull);
         const int len = active ? (int)((rec >> 32) & 31) : 0;
         const bool starts = (rec >> 37) & 1, ends = (rec >> 38) & 1;
@@ -500,10 +538,13 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         RowRmw rr;
         if (whole) load_row(a, fk, (int64_t)key, D, c4, opt, rr);  // independent of the gradient rows: overlaps them
         const uint32_t* vv = vals + s0;
+        // entry i of the piece: VMODE 1 reads it from lane i of the group (every lane of a group runs the same trip count, so
+        // the source lanes are active), VMODE 0 from memory
+        auto idx = [&](int i) -> uint32_t { return VMODE ? (uint32_t)__shfl((int)myv, glane0 + i) : vv[i]; };
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         int i = 0;
         for (; i + 4 <= len; i += 4) {
-            const uint32_t v0 = vv[i], v1 = vv[i + 1], v2 = vv[i + 2], v3 = vv[i + 3];
+            const uint32_t v0 = idx(i), v1 = idx(i + 1), v2 = idx(i + 2), v3 = idx(i + 3);
             const f32x4 r0 = row(v0), r1 = row(v1), r2 = row(v2), r3 = row(v3);
             acc += r0;
             acc += r1;
@@ -511,31 +552,34 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
             acc += r3;
         }
         if (i + 2 <= len) {
-            const uint32_t v0 = vv[i], v1 = vv[i + 1];
+            const uint32_t v0 = idx(i), v1 = idx(i + 1);
             const f32x4 r0 = row(v0), r1 = row(v1);
             acc += r0;
             acc += r1;
             i += 2;
         }
-        if (i < len) acc += row(vv[i]);
+        if (i < len) acc += row(idx(i));
         if (whole) finish_row(rr, acc, opt, hp);
+        if (VMODE) myv = nv;
         // Pieces of ONE long run sit next to each other in the list, i.e. in neighbouring groups of this block:
         // they are summed through LDS first and the leader issues a single set of atomics.  Without this a hot
         // row (a 3-row table takes 21K gradients of a 64K batch) serialises ~1400 same-line atomics in L2 and
         // the whole kernel waits for it (measured: ~330 us floor independent of everything else).
-        part_s[threadIdx.x] = acc;
-        if (c4 == 0 && gi < 64) part_key[gi] = partial ? key : ~0ull;
+        part_s[buf][threadIdx.x] = acc;
+        if (c4 == 0 && gi < 64) part_key[buf][gi] = partial ? key : ~0ull;
         __syncthreads();
-        if (partial && (gi == 0 || part_key[gi - 1] != key)) {
+        if (partial && (gi == 0 || part_key[buf][gi - 1] != key)) {
             f32x4 sum = acc;
-            for (int g2 = gi + 1; g2 < groups && part_key[g2] == key; ++g2) sum += part_s[g2 * LPR + c4];
+            for (int g2 = gi + 1; g2 < groups && part_key[buf][g2] == key; ++g2) sum += part_s[buf][g2 * LPR + c4];
             float* cr = carry + (int64_t)home[p] * D + c4 * 4;
             atomicAdd(cr + 0, sum.x);
             atomicAdd(cr + 1, sum.y);
             atomicAdd(cr + 2, sum.z);
             atomicAdd(cr + 3, sum.w);
         }
-        __syncthreads();
+        // two buffers: the next iteration writes the other one, and the one after that is separated from the reads above by
+        // the next iteration's barrier
+        if (VMODE) buf ^= 1; else __syncthreads();
     }
 }
 
@@ -661,17 +705,25 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         return MH_OK;
     }
     {
+        // the group's lanes fetch and hand out a piece's sample indices (kernel comment) where a group is an aligned 16- / 32- /
+        // 64-lane part of a wavefront; MERLIN_HIP_PIECE_MODE=0 keeps the per-piece loads everywhere
+        static const bool piece_mode_on = [] {
+            const char* v = getenv("MERLIN_HIP_PIECE_MODE");
+            return !(v && v[0] == '0');
+        }();
+        const bool vmode = piece_mode_on && (LPR == 16 || LPR == 32 || LPR == 64);
+        auto kern = vmode ? piece_reduce_apply_kernel<1> : piece_reduce_apply_kernel<0>;
         int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
-        static int resident = 0;  // workgroups per CU the kernel's register budget allows: exactly one resident wave
-        if (resident == 0) {
+        static int resident[2] = {0, 0};  // workgroups per CU the kernel's register budget allows: exactly one resident wave
+        if (resident[vmode] == 0) {
             int r = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, piece_reduce_apply_kernel, 256, 0) != hipSuccess || r < 1) r = 4;
-            resident = r;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, kern, 256, 0) != hipSuccess || r < 1) r = 4;
+            resident[vmode] = r;
         }
-        const int64_t cap = (int64_t)mh_num_cus() * resident;
+        const int64_t cap = (int64_t)mh_num_cus() * resident[vmode];
         if (nb > cap) nb = cap;
-        hipLaunchKernelGGL(piece_reduce_apply_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad,
-                           grad_row_stride, carry, home, pieces, counter, optimizer, hp, det);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad, grad_row_stride, carry, home,
+                           pieces, counter, optimizer, hp, det);
     }
     hipLaunchKernelGGL((carry_apply_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, groups)), dim3(256), 0, s, a, keys,
                        vals, L.n, D, LPR, carry, optimizer, hp, grad, grad_row_stride, det);
