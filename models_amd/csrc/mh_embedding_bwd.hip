@@ -93,11 +93,51 @@ __device__ __forceinline__ uint32_t id_to_local_key(const SortArgs& a, int s, in
     return (id >= 0 && id < a.rows[s]) ? (uint32_t)id : (uint32_t)a.rows[s];
 }
 
+// Pass 0 reads the id columns themselves.  The RTILE / 4 consecutive entries of a wavefront almost always lie inside ONE
+// feature (always when B is a multiple of RTILE / 4): then the column pointer and the first sample are wave-uniform and an
+// entry is one coalesced load from a scalar base.  Otherwise (a wavefront that straddles two features of a shared table, or
+// the switch MERLIN_HIP_SORT_FASTLOAD=0) every lane walks its own (feature, sample) position.
+template <typename IdT>
+struct Pass0 {
+    bool one;          // wave-uniform: fast path
+    const IdT* col;    // fast path: column of the wavefront's feature, at its first sample
+    int64_t b0;        // fast path: first sample
+    int feat;          // fast path: feature index (position in SortArgs::ids)
+    EntryPos pos;      // slow path
+    __device__ __forceinline__ void init(const SortArgs& a, int s, int64_t e0, int64_t n_s, int lane, int fast) {
+        int64_t last = e0 + RTILE / 4;
+        if (last > n_s) last = n_s;
+        const int64_t fo0 = e0 / a.B;
+        b0 = e0 - fo0 * a.B;
+        one = fast && e0 < n_s && b0 + (last - e0) <= a.B;
+        feat = a.seg_f0[s] + (int)fo0;
+        if (one)
+            col = static_cast<const IdT*>(a.ids[feat]) + b0;
+        else
+            pos.init(e0 + lane, a.B);
+    }
+    // entry e0 + it * 64 + lane (the caller checked e < n_s): local key and, for the scatter, the packed (feature, sample)
+    __device__ __forceinline__ uint32_t key(const SortArgs& a, int s, int it, int lane) const {
+        if (one) {
+            const int64_t id = (int64_t)col[it * 64 + lane];
+            return (id >= 0 && id < a.rows[s]) ? (uint32_t)id : (uint32_t)a.rows[s];
+        }
+        return id_to_local_key<IdT>(a, s, pos.fo, pos.b);
+    }
+    __device__ __forceinline__ uint32_t val(const SortArgs& a, int s, int it, int lane) const {
+        if (one) return ((uint32_t)feat << 26) | (uint32_t)(b0 + it * 64 + lane);
+        return ((uint32_t)(a.seg_f0[s] + pos.fo) << 26) | (uint32_t)pos.b;
+    }
+    __device__ __forceinline__ void next(const SortArgs& a) {
+        if (!one) pos.advance(64, a.B);
+    }
+};
+
 // cnt[(tile0[s] + t) * 2^RBITS_MAX + d] = number of entries of tile t of segment s whose digit is d (tile-major: a
 // tile's counters are one contiguous, coalesced block for the histogram, the scan and the scatter alike)
 template <typename IdT>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const void* keys0, const void* keys1, int pass,
-                                                        int shift, int rbits, int* __restrict__ cnt) {
+                                                        int shift, int rbits, int* __restrict__ cnt, int fast) {
     __shared__ int hist[1 << RBITS_MAX];
     const int s = seg_of_tile(a, blockIdx.x);
     if (pass >= a.npass[s]) return;  // this segment is already sorted
@@ -108,17 +148,17 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const
     const int t = blockIdx.x - a.tile0[s];
     const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
     const int64_t n_s = (int64_t)(a.seg_f0[s + 1] - a.seg_f0[s]) * a.B;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t e0 = (int64_t)t * RTILE + wave * (RTILE / 4);
     uint32_t k[RITEMS];
-    EntryPos pos;
-    if (pass == 0) pos.init(e0 + lane, a.B);
+    Pass0<IdT> p0;
+    if (pass == 0) p0.init(a, s, e0, n_s, lane, fast);
 #pragma unroll
     for (int it = 0; it < RITEMS; ++it) {  // all loads of the tile in flight before the first LDS atomic
         const int64_t e = e0 + it * 64 + lane;
         k[it] = 0xffffffffu;
-        if (e < n_s) k[it] = (pass == 0) ? id_to_local_key<IdT>(a, s, pos.fo, pos.b) : keys_in[2 * (seg_base + e)];  // (key, val) pairs
-        if (pass == 0) pos.advance(64, a.B);
+        if (e < n_s) k[it] = (pass == 0) ? p0.key(a, s, it, lane) : keys_in[2 * (seg_base + e)];  // (key, val) pairs
+        if (pass == 0) p0.next(a);
     }
     __syncthreads();
     // plain LDS atomics: peeling hot digits with ballots (one aggregated atomic per distinct digit) was measured SLOWER
@@ -208,7 +248,7 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int 
 template <typename IdT, typename KeyT>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, int pass, int shift, int rbits,
                                                            const int* __restrict__ cnt, void* keys0, uint32_t* vals0,
-                                                           void* keys1, uint32_t* vals1) {
+                                                           void* keys1, uint32_t* vals1, int fast) {
     __shared__ int wcnt[4][1 << RBITS_MAX];
     const int s = seg_of_tile(a, blockIdx.x);
     const int np = a.npass[s];
@@ -223,13 +263,13 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, in
     const int t = blockIdx.x - a.tile0[s];
     const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
     const int64_t n_s = (int64_t)(a.seg_f0[s + 1] - a.seg_f0[s]) * a.B;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t e0 = (int64_t)t * RTILE + wave * (RTILE / 4);
     uint32_t key[RITEMS], val[RITEMS];
     int off[RITEMS];  // digit | rank-inside-(wave, digit) << 11
-    EntryPos pos;
-    if (pass == 0) pos.init(e0 + lane, a.B);
+    Pass0<IdT> p0;
+    if (pass == 0) p0.init(a, s, e0, n_s, lane, fast);
 #pragma unroll
     for (int it = 0; it < RITEMS; ++it) {  // every load of the tile in flight before the ranking starts
         const int64_t e = e0 + it * 64 + lane;
@@ -237,15 +277,15 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, in
         val[it] = 0;
         if (e < n_s) {
             if (pass == 0) {
-                key[it] = id_to_local_key<IdT>(a, s, pos.fo, pos.b);
-                val[it] = ((uint32_t)(a.seg_f0[s] + pos.fo) << 26) | (uint32_t)pos.b;
+                key[it] = p0.key(a, s, it, lane);
+                val[it] = p0.val(a, s, it, lane);
             } else {
                 const uint2 kv = reinterpret_cast<const uint2*>(keys_in)[seg_base + e];  // pairs from the previous pass
                 key[it] = kv.x;
                 val[it] = kv.y;
             }
         }
-        if (pass == 0) pos.advance(64, a.B);
+        if (pass == 0) p0.next(a);
     }
     __syncthreads();
 #pragma unroll
@@ -377,6 +417,7 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
     __shared__ int64_t wave_last_start[LIST_TILES][4];  // last run start inside (tile, wave), -1 if none
     __shared__ int64_t start_before[LIST_TILES][4];     // latest run start before (tile, wave): in-window or searched
     __shared__ unsigned int block_base;
+    __shared__ int64_t pre_start;  // start of the run that reaches into this window from before it, -1 if none
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const uint64_t le_mask = lt_mask | (1ull << lane);
@@ -385,6 +426,37 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
     unsigned int rank[LIST_TILES];
     int64_t my_start[LIST_TILES];  // run start of this entry if it lies in the same wave, else -1
     const int64_t w0 = (int64_t)blockIdx.x * LIST_TILES * 256;
+    if (wave == 3) {
+        // The run that reaches into this window from before it (if any): lower bound of its key inside the segment, found
+        // by a 64-ary search of this wavefront (a 64 K-entry segment takes 3 dependent probes; the binary search of one
+        // thread took 16, and the windows of a tiny table -- runs of thousands -- all need it).
+        int64_t pre = -1;
+        if (w0 > 0 && w0 < n) {
+            const KeyT k0 = keys[w0];
+            if (k0 != SENT && keys[w0 - 1] == k0) {
+                int sg = 0;
+                while (sg + 1 < sa.nseg && (int64_t)sa.seg_f0[sg + 1] * sa.B <= w0) ++sg;
+                // invariant: the answer lies in [lo, hi] and keys[hi] == k0 (valid keys are sorted inside a segment, and
+                // everything before a valid entry of a segment is valid)
+                int64_t lo = (int64_t)sa.seg_f0[sg] * sa.B, hi = w0 - 1;
+                while (lo < hi) {
+                    const int64_t step = (hi - lo) / 64 + 1;
+                    int64_t q = lo + lane * step;
+                    if (q > hi) q = hi;
+                    const int c = __popcll(__ballot(keys[q] < k0));  // sorted: the probes below k0 are the first c
+                    if (c == 0) {
+                        hi = lo;
+                    } else {
+                        const int64_t nhi = lo + c * step;  // c == 64: past hi (64 step > hi - lo)
+                        lo = lo + (c - 1) * step + 1;
+                        if (nhi < hi) hi = nhi;
+                    }
+                }
+                pre = lo;
+            }
+        }
+        if (lane == 0) pre_start = pre;
+    }
 #pragma unroll
     for (int t = 0; t < LIST_TILES; ++t) {
         const int64_t i = w0 + t * 256 + threadIdx.x;
@@ -419,22 +491,7 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
         unsigned int tot = 0;
         for (int t = 0; t < LIST_TILES; ++t) tot += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
         block_base = tot ? atomicAdd(counter, tot) : 0u;
-        // the run that reaches into this window from before it (if any): lower bound of its key inside the segment
-        int64_t pre = -1;
-        if (w0 > 0 && w0 < n) {
-            const KeyT k0 = keys[w0];
-            if (k0 != SENT && keys[w0 - 1] == k0) {
-                int sg = 0;
-                while (sg + 1 < sa.nseg && (int64_t)sa.seg_f0[sg + 1] * sa.B <= w0) ++sg;
-                int64_t lo = (int64_t)sa.seg_f0[sg] * sa.B, hi = w0 - 1;  // keys[hi] == k0; find the first index with k0
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (keys[mid] < k0) lo = mid + 1; else hi = mid;
-                }
-                pre = lo;
-            }
-        }
-        int64_t run = pre;
+        int64_t run = pre_start;
         for (int t = 0; t < LIST_TILES; ++t)
             for (int w = 0; w < 4; ++w) {
                 start_before[t][w] = run;
@@ -601,18 +658,19 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
     if (c1 >= n) return;  // the last chunk cannot be crossed
     const KeyT key = keys[c1 - 1];
     if (key == KeyTraits<KeyT>::sentinel || keys[c1] != key) return;  // last run ends here
-    int64_t st = c0;  // first entry of that run inside the chunk
-    if (keys[c0] == key) {  // sorted: the whole chunk is this run
-        if (c0 > 0 && keys[c0 - 1] == key) return;  // ... and it began in an earlier chunk: that one is its home
-    } else {
-        st = c1 - 1;
-        while (keys[st - 1] == key) --st;  // stops inside the chunk: keys[c0] differs
-    }
-    f32x4 g;
-    if (!deterministic) {
-        g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
-    } else {
-        g = f32x4{0.f, 0.f, 0.f, 0.f};
+    // everything else that depends on the chunk index alone is fetched together (one round trip, not a chain of four)
+    const KeyT kfirst = keys[c0];
+    const KeyT kbefore = (c0 > 0) ? keys[c0 - 1] : KeyTraits<KeyT>::sentinel;  // the sentinel differs from `key`
+    const uint32_t vlast = vals[c1 - 1];
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (!deterministic) g = *reinterpret_cast<const f32x4*>(carry + chunk * D + c4 * 4);
+    if (kfirst == key && kbefore == key) return;  // sorted: the whole chunk is this run, which began in an earlier chunk (its home)
+    if (deterministic) {
+        int64_t st = c0;  // first entry of that run inside the chunk
+        if (kfirst != key) {
+            st = c1 - 1;
+            while (keys[st - 1] == key) --st;  // stops inside the chunk: keys[c0] differs
+        }
         for (int64_t i = st; i < n && keys[i] == key; ++i) {
             const uint32_t v = vals[i];
             g += *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
@@ -620,7 +678,7 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
         }
     }
     RowRmw rr;
-    load_row(a, (int)(vals[c1 - 1] >> 26), (int64_t)key, D, c4, opt, rr);
+    load_row(a, (int)(vlast >> 26), (int64_t)key, D, c4, opt, rr);
     finish_row(rr, g, opt, hp);
 }
 
@@ -678,13 +736,17 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     // ---- 1. segmented stable LSD radix sort: digit width rbits per pass; a segment runs only the passes its own
     //         key bits need (sa.npass) and alternates buffers so that its last pass lands in buffer 1 ---------------------
     const int ntiles = sa.tile0[sa.nseg];
+    static const int fast = [] {
+        const char* v = getenv("MERLIN_HIP_SORT_FASTLOAD");
+        return (v && v[0] == '0') ? 0 : 1;
+    }();
     for (int p = 0; (phases & PH_PREPARE) && p < npass; ++p) {
         const int shift = p * rbits;
         hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
-                           (const void*)kbuf[1], p, shift, rbits, cnt);
+                           (const void*)kbuf[1], p, shift, rbits, cnt, fast);
         hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt);
         hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, p, shift, rbits, cnt,
-                           kbuf[0], vbuf[0], kbuf[1], vbuf[1]);
+                           kbuf[0], vbuf[0], kbuf[1], vbuf[1], fast);
     }
     const KeyT* keys = static_cast<const KeyT*>(kbuf[1]);
     const uint32_t* vals = vbuf[1];
