@@ -137,9 +137,21 @@ struct Pass0 {
 // tile's counters are one contiguous, coalesced block for the histogram, the scan and the scatter alike)
 template <typename IdT>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const void* keys0, const void* keys1, int pass,
-                                                        int shift, int rbits, int* __restrict__ cnt, int fast) {
+                                                        int shift, int rbits, int* __restrict__ cnt, int fast,
+                                                        uint4* __restrict__ clear, int64_t clear_vec,
+                                                        unsigned int* __restrict__ clear_word) {
     __shared__ int hist[1 << RBITS_MAX];
     const int s = seg_of_tile(a, blockIdx.x);
+    // Pass 0 (every workgroup runs it) also zeroes what the later stages accumulate into -- the carried rows and the piece
+    // counter: each workgroup clears its slice with fire-and-forget 16-byte stores before its own loads (a separate fill
+    // kernel was 7 us of the launch; a kernel, not a memset node -- see mh_fill_words)
+    if (clear_vec > 0) {
+        const int64_t per = (clear_vec + gridDim.x - 1) / gridDim.x;
+        const int64_t beg = (int64_t)blockIdx.x * per;
+        const int64_t end = beg + per < clear_vec ? beg + per : clear_vec;
+        for (int64_t i = beg + threadIdx.x; i < end; i += 256) clear[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
     if (pass >= a.npass[s]) return;  // this segment is already sorted
     // input of pass p = output of pass p - 1 (see radix_scatter_kernel for the buffer parity)
     const uint32_t* keys_in = static_cast<const uint32_t*>(((a.npass[s] - pass) & 1) ? keys0 : keys1);
@@ -174,7 +186,8 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const
 // one workgroup per segment: cnt[t][d] := first output slot of (digit d, tile t) inside the segment, i.e. the exclusive
 // prefix in digit-major order.  A thread owns 2 digits: tile totals (coalesced loop over the tiles), block scan over the
 // digits, then the running prefix over the tiles.
-__global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int pass, int rbits, int* __restrict__ cnt) {
+__global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int pass, int rbits, int* __restrict__ cnt,
+                                                         int keep_regs) {
     constexpr int RS = 1 << RBITS_MAX;
     __shared__ int wsum[16];
     const int s = blockIdx.x;
@@ -188,7 +201,18 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int 
     // both tile loops run 8 loads ahead: one dependent load per iteration made a 128-tile segment (the single segment of
     // the row-sharded update: 524 K requests) cost 35 us per pass; the per-table segments of the one-GPU path have 16 tiles
     int t0 = 0, t1 = 0;
-    if (on) {
+    constexpr int NREG = 16;  // a one-hot feature of a 64 K batch: 16 tiles -- ONE round of loads, the counts stay in registers
+    int2 keep[NREG];
+    const bool small = keep_regs && nt <= NREG;  // block-uniform
+    if (on && small) {
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) keep[u] = (u < nt) ? *reinterpret_cast<const int2*>(c + (int64_t)u * RS + d0) : make_int2(0, 0);
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) {
+            t0 += keep[u].x;
+            t1 += keep[u].y;
+        }
+    } else if (on) {
         int t = 0;
         for (; t + 8 <= nt; t += 8) {
             int2 v[8];
@@ -218,7 +242,15 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int 
     int run0 = x - tot;
     for (int w = 0; w < wave; ++w) run0 += wsum[w];
     int run1 = run0 + t0;
-    if (on) {
+    if (on && small) {
+#pragma unroll
+        for (int u = 0; u < NREG; ++u)
+            if (u < nt) {
+                *reinterpret_cast<int2*>(c + (int64_t)u * RS + d0) = make_int2(run0, run1);
+                run0 += keep[u].x;
+                run1 += keep[u].y;
+            }
+    } else if (on) {
         int t = 0;
         for (; t + 8 <= nt; t += 8) {
             int2 v[8];
@@ -740,11 +772,19 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         const char* v = getenv("MERLIN_HIP_SORT_FASTLOAD");
         return (v && v[0] == '0') ? 0 : 1;
     }();
+    static const int lean = [] {  // 0: separate clear kernel, scan re-reads the tile counts (A/B switch)
+        const char* v = getenv("MERLIN_HIP_SORT_LEAN");
+        return (v && v[0] == '0') ? 0 : 1;
+    }();
     for (int p = 0; (phases & PH_PREPARE) && p < npass; ++p) {
         const int shift = p * rbits;
+        // pass 0 clears the carried rows (not accumulated into in deterministic mode) and the piece counter on the way
+        const bool clr = (p == 0) && lean;
         hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
-                           (const void*)kbuf[1], p, shift, rbits, cnt, fast);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt);
+                           (const void*)kbuf[1], p, shift, rbits, cnt, fast, reinterpret_cast<uint4*>(carry),
+                           (clr && !det) ? (int64_t)((L.off_counter - L.off_carry) / 16) : (int64_t)0,
+                           clr ? counter : (unsigned int*)nullptr);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt, lean);
         hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, p, shift, rbits, cnt,
                            kbuf[0], vbuf[0], kbuf[1], vbuf[1], fast);
     }
@@ -752,7 +792,7 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     const uint32_t* vals = vbuf[1];
 
     // ---- 2. piece list, 3. segmented reduce + fused optimizer, 4. carried runs -------------------------------------------
-    if (phases & PH_PREPARE) {  // a kernel, not a memset node (see mh_fill_words); deterministic mode does not accumulate into `carry`
+    if ((phases & PH_PREPARE) && !lean) {  // a kernel, not a memset node (see mh_fill_words)
         const int32_t st = det ? mh_fill_words(counter, 0u, 1, s)
                                : mh_fill_words(carry, 0u, (int64_t)(L.off_counter + 4 - L.off_carry) / 4, s);
         if (st != MH_OK) return st;

@@ -1,6 +1,4 @@
 #!/bin/bash
-# sparse-update timing (tools/microbench.py embbwd), its tests, and an isolated kernel trace of the all-big / all-tiny table cases
+# A/B of MERLIN_HIP_SORT_LEAN on one box (tools/microbench.py embbwd), alternating
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 120 python tools/microbench.py embbwd 2>&1 | grep "embedding bwd"
-timeout 300 python -m pytest tests/test_gpu_backward.py tests/test_gpu_bag_backward.py tests/test_gpu_fullsize.py tests/test_gpu_hygiene.py -x -q 2>&1 | tail -3
-MB_ARGS="embbwd embbig" bash tools/gpu_embbwd_trace.sh
+for m in 0 1 0 1 0 1; do echo -n "lean $m: "; MERLIN_HIP_SORT_LEAN=$m timeout 25 python tools/microbench.py embbwd 2>&1 | grep "embedding bwd" | awk '{printf "%s ", $(NF-1)}'; echo; done
