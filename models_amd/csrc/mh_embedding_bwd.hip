@@ -11,11 +11,13 @@
 //      total row count.  Pass 1 reads the ids directly (no key-build pass); the last pass emits COMPACT keys
 //      first_row[table] + id (the row number in the concatenation of the distinct tables; sentinel = all ones).
 //      Per pass: per-tile digit histograms -> per-segment exclusive scan -> stable scatter (wave-private digit
-//      counters in LDS, ranks from a ballot match);
+//      counters in LDS, ranks from a ballot match).  Pass 0 of the histogram kernel also clears what the later
+//      stages accumulate into (carried rows, piece counter): no separate fill launch;
 //   2. PIECES (a run cut at every 16th sorted index) enumerated into a compact list, each with the chunk its run
 //      starts in (found inside the workgroup's window, or by one binary search per workgroup for a run that began
 //      before it);
-//   3. segmented reduce over the pieces: one D/4-lane group per piece sums its gradient rows in registers; a
+//   3. segmented reduce over the pieces: one D/4-lane group per piece sums its gradient rows in registers (record
+//      and sample indices prefetched two / one iteration ahead: only the gradient-row loads are a dependent chain); a
 //      piece that is a whole run is applied to the table row directly (exclusive owner, no atomics); the pieces of
 //      a run crossing a chunk boundary add to carry[home chunk] -- long runs of hot ids are pre-summed 16:1 in
 //      registers and 16:1 again through LDS;
