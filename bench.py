@@ -388,6 +388,25 @@ def run_gather_cold(device, D=64, rows=50_000_000, n_ids=524_288, iters=20):
             "GBps": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS}
 
 
+def run_hbm_copy_peak(device, nbytes=1 << 30, iters=10):
+    """the box's own streaming rate beside the 8 TB/s spec peak -- a device-to-device copy of 1 GiB (torch's copy
+    kernel, read + write counted), hipEvent-timed.  Context for every `frac` of the line; not a kernel of this library."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).fill_(1)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    gbps = 2 * nbytes / (ms * 1e-3) / 1e9
+    return {"shape": f"device-to-device copy of {nbytes >> 20} MiB, read + write", "ms": ms, "GBps": gbps,
+            "frac_of_peak": gbps / HBM_PEAK_GBS}
+
+
 def run_cross_gemm(device, M=65536, d=3344, iters=4):
     """The DCN-v2 cross layer of BASELINE configs[4] (d = 3341 padded to 3344, B = 64 K): x0 * (x W + b) + x, the one
     dense-contraction-dominated layer of the path, on the second-generation GEMM core."""
@@ -461,7 +480,7 @@ def main():
                     help="dlrm = BASELINE configs[1] (the headline metric); the others are secondary configs")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--tt-batch", type=int, default=32768, help="TwoTower batch per GPU (BASELINE configs[2])")
     ap.add_argument("--batches", type=int, default=8, help="distinct pre-generated batches rotated through the timed loop")
@@ -644,6 +663,10 @@ def main():
     }
     if world == 1 and not args.no_secondary and not args.extra_table_rows and not force:
         sec = {}
+        try:
+            sec["hbm_copy_peak"] = run_hbm_copy_peak(device)
+        except Exception as e:  # noqa: BLE001 -- context only
+            sec["hbm_copy_peak"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             sec["gather_cold"] = run_gather_cold(device)
             sec["scorer_fwd"] = run_scorer_fwd(device)
