@@ -809,13 +809,13 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         return MH_OK;
     }
     {
-        // the group's lanes fetch and hand out a piece's sample indices (kernel comment) where a group is an aligned 16- / 32- /
-        // 64-lane part of a wavefront; MERLIN_HIP_PIECE_MODE=0 keeps the per-piece loads everywhere
+        // the group's lanes fetch and hand out a piece's sample indices (kernel comment) where a group is an aligned 16- / 32-lane
+        // part of a wavefront; MERLIN_HIP_PIECE_MODE=0 keeps the per-piece loads everywhere
         static const bool piece_mode_on = [] {
             const char* v = getenv("MERLIN_HIP_PIECE_MODE");
             return !(v && v[0] == '0');
         }();
-        const bool vmode = piece_mode_on && (LPR == 16 || LPR == 32 || LPR == 64);
+        const bool vmode = piece_mode_on && (LPR == 16 || LPR == 32);  // D = 64 / 128 (GPU-tested); 64-lane groups (D = 256) keep mode 0 until a test covers them
         auto kern = vmode ? piece_reduce_apply_kernel<1> : piece_reduce_apply_kernel<0>;
         int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
         static int resident[2] = {0, 0};  // workgroups per CU the kernel's register budget allows: exactly one resident wave
