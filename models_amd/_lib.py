@@ -90,7 +90,10 @@ class MerlinHipError(RuntimeError):
 
 
 def lib_path() -> Path:
-    return _build.LIB
+    """The in-tree library, or the file named by MERLIN_HIP_LIB (a prebuilt libmerlin_hip.so elsewhere: deployment
+    override, also how two builds are compared on one box).  An override is never rebuilt."""
+    override = os.environ.get("MERLIN_HIP_LIB")
+    return Path(override) if override else _build.LIB
 
 
 def load() -> C.CDLL:
@@ -104,7 +107,10 @@ def load() -> C.CDLL:
     import torch  # noqa: F401  (buffer carrier + the process-wide HIP runtime)
 
     path = lib_path()
-    if _build.needs_build():
+    if path != _build.LIB:
+        if not path.exists():
+            raise MerlinHipError(f"MERLIN_HIP_LIB={path} does not exist")
+    elif _build.needs_build():
         if shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists():
             _build.build()
         elif not path.exists():

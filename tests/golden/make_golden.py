@@ -11,6 +11,9 @@ the reference SOURCE at run time with ``ast`` and executed with torch-CPU:
   * merlin/models/torch/blocks/dlrm.py: DLRMInteraction.forward       (interaction, a7)
   * merlin/models/torch/blocks/cross.py: CrossBlock.forward loop      (cross, a9)
   * merlin/models/utils/schema_utils.py: get_embedding_size_from_cardinality (a2)
+  * merlin/models/torch/outputs/classification.py: BinaryOutput.DEFAULT_LOSS_CLS (nn.BCELoss) and
+    merlin/models/torch/outputs/contrastive.py: ContrastiveOutput.__init__'s default `loss` (nn.CrossEntropyLoss()): the
+    loss classes the reference's torch backend instantiates, evaluated on fixed inputs (BCE, softmax-CE a13)
 
 Nothing is copied into this repository: only inputs/outputs land in tests/golden/*.npz.
 """
@@ -48,6 +51,24 @@ def load(path, name, cls=None, extra=None):
     ns.update(extra or {})
     exec(extract(REF / path, name, cls), ns)
     return ns[name]
+
+
+def class_attr(path, cls: str, attr: str, ns):
+    """Evaluate the class attribute `cls.attr` of the reference source file `path` (e.g. DEFAULT_LOSS_CLS)."""
+    tree = ast.parse((REF / path).read_text())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    asg = next(n for n in node.body if isinstance(n, ast.Assign) and any(getattr(t, "id", None) == attr for t in n.targets))
+    return eval(compile(ast.Expression(asg.value), str(path), "eval"), ns)
+
+
+def init_default(path, cls: str, arg: str, ns):
+    """Evaluate the default value of `cls.__init__`'s argument `arg` in the reference source file `path`."""
+    tree = ast.parse((REF / path).read_text())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    init = next(n for n in node.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    names = [a.arg for a in init.args.args]
+    dflt = init.args.defaults[names.index(arg) - (len(names) - len(init.args.defaults))]
+    return eval(compile(ast.Expression(dflt), str(path), "eval"), ns)
 
 
 def main():
@@ -157,6 +178,22 @@ def main():
     for mode in ("sum", "mean"):
         me7 = types.SimpleNamespace(table=types.SimpleNamespace(weight=Wb), seq_combiner=mode)
         out[f"bag_{mode}"] = embedding_bag(me7, vals, offs[:-1])
+
+    # --- losses: the classes the reference's torch backend instantiates (appended: earlier draws are unchanged) ----
+    # BinaryOutput: nn.Sigmoid() then DEFAULT_LOSS_CLS() = nn.BCELoss (torch/outputs/classification.py:44,58-62);
+    # ContrastiveOutput: default loss = nn.CrossEntropyLoss() (:59) on [B, 1 + Nn] logits with the positive in column 0
+    # (torch/outputs/contrastive.py: target built by contrastive_outputs).  Probabilities stay inside [1e-6, 1 - 1e-6]:
+    # Keras clips at 1e-7, torch clamps log at -100 -- the two statements agree on that range.
+    bce_cls = class_attr("merlin/models/torch/outputs/classification.py", "BinaryOutput", "DEFAULT_LOSS_CLS", {"nn": torch.nn})
+    ce = init_default("merlin/models/torch/outputs/contrastive.py", "ContrastiveOutput", "loss", {"nn": torch.nn})
+    z = torch.randn(257, 1, generator=g) * 3.0
+    prob = torch.sigmoid(z).clamp(1e-6, 1 - 1e-6)
+    lab = (torch.rand(257, 1, generator=g) < 0.4).float()
+    out.update(bce_p=prob, bce_y=lab, bce_loss=bce_cls()(prob, lab), bce_cls=np.array(bce_cls.__name__))
+    ce_logits = contrastive(me2, q, pos, pos, ids.unsqueeze(0), ids.unsqueeze(0))  # the in-batch logits above
+    # class-index target 0 == the one-hot-on-column-0 target the reference builds
+    out.update(ce_loss=ce(ce_logits, torch.zeros(B, dtype=torch.long)), ce_cls=np.array(type(ce).__name__),
+               ce_loss_onehot=ce(ce_logits, me2.target))
 
     np.savez_compressed(OUT / "reference_vectors.npz",
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})

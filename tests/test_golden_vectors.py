@@ -42,6 +42,16 @@ def test_inferred_embedding_dims_match_reference():
     np.testing.assert_array_equal(got, G["emb_dim_raw"])
 
 
+def test_oracle_losses_match_the_reference_loss_classes():
+    """BCE and softmax-CE pinned to the loss modules the reference's torch backend instantiates (BinaryOutput.DEFAULT_LOSS_CLS,
+    torch/outputs/classification.py:44; ContrastiveOutput's default loss, torch/outputs/contrastive.py:59)."""
+    assert str(G["bce_cls"]) == "BCELoss" and str(G["ce_cls"]) == "CrossEntropyLoss"
+    np.testing.assert_allclose(O.binary_crossentropy(G["bce_p"], G["bce_y"]).mean(), G["bce_loss"], atol=1e-6, rtol=1e-6)
+    loss, _ = O.softmax_ce_first_column(G["ib_logits"])
+    np.testing.assert_allclose(loss.mean(), G["ce_loss"], atol=1e-5, rtol=1e-6)
+    np.testing.assert_allclose(G["ce_loss_onehot"], G["ce_loss"], atol=1e-6)  # one-hot column 0 == class index 0
+
+
 # ---- the same vectors through the HIP path ------------------------------------------------------
 @pytest.mark.gpu
 def test_hip_scorer_matches_reference_vectors(device):
@@ -100,3 +110,22 @@ def test_bag_lookup_matches_reference_embedding_bag(device):
     for mode in ("sum", "mean"):
         got = ops.embedding_bag(W, vals, offs, mode)
         np.testing.assert_allclose(got.cpu().numpy(), G[f"bag_{mode}"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_losses_match_the_reference_loss_classes(device):
+    """mh_bce_mean_fwd_bwd and the scorer's fused softmax-CE against nn.BCELoss / nn.CrossEntropyLoss outputs."""
+    import torch
+
+    from models_amd import ops
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    mean, dlogit = ops.bce(t(G["bce_p"]), t(G["bce_y"]))
+    np.testing.assert_allclose(float(mean), G["bce_loss"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(ops.bce_per_sample(t(G["bce_p"]), t(G["bce_y"])).mean().item(), G["bce_loss"], atol=1e-6, rtol=1e-5)
+    # d mean / d logit of sigmoid + BCE = (p - y) / M
+    np.testing.assert_allclose(dlogit.cpu().numpy(), (G["bce_p"] - G["bce_y"]) / G["bce_p"].shape[0], atol=1e-8, rtol=1e-5)
+    ids = t(G["ib_ids"])
+    for mat in (True, False):
+        r = ops.inbatch_softmax(t(G["sc_q"]), t(G["sc_pos"]), t(G["sc_pos"]), ids, ids, materialize=mat)
+        np.testing.assert_allclose(r.loss.mean().item(), G["ce_loss"], atol=1e-5, rtol=1e-5)
