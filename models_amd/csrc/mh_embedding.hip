@@ -39,11 +39,19 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const GatherArgs args, 
     const int64_t b0 = (int64_t)blockIdx.x * (rows_per_pass * R) + r_in;
     float* __restrict__ obase = out + args.offset[f] + c * 4;
 
+    // ids first, RAW and branch-free (sample index clamped): a predicated load with its sign extension right behind it was
+    // followed by s_waitcnt vmcnt(0) -- the R id loads were R sequential round trips (seen in the ISA)
+    IdT raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t b = b0 + (int64_t)r * rows_per_pass;
+        raw[r] = ids[b < B ? b : B - 1];
+    }
     int64_t id[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t b = b0 + (int64_t)r * rows_per_pass;
-        id[r] = (b < B) ? (int64_t)ids[b] : -1;
+        id[r] = (b < B) ? (int64_t)raw[r] : -1;
     }
     f32x4 v[R];
 #pragma unroll

@@ -126,6 +126,19 @@ struct Pass0 {
         }
         return id_to_local_key<IdT>(a, s, pos.fo, pos.b);
     }
+    // The two halves of key() for the fast path, so that a tile's loads can ALL be issued before the first of them is used:
+    // a load whose value is compared right behind it, inside a per-entry `if (e < n_s)`, is followed by s_waitcnt vmcnt(0) --
+    // the 16 loads of a thread were 16 sequential round trips (seen in the ISA).  raw(): branch-free, the entry index is
+    // clamped into the wavefront's range (n >= 1 entries); finish(): the bounds test.
+    __device__ __forceinline__ IdT raw(int it, int lane, int n) const {
+        int i = it * 64 + lane;
+        if (i > n - 1) i = n - 1;
+        return col[i];
+    }
+    __device__ __forceinline__ uint32_t finish(const SortArgs& a, int s, IdT r) const {
+        const int64_t id = (int64_t)r;
+        return (id >= 0 && id < a.rows[s]) ? (uint32_t)id : (uint32_t)a.rows[s];
+    }
     __device__ __forceinline__ uint32_t val(const SortArgs& a, int s, int it, int lane) const {
         if (one) return ((uint32_t)feat << 26) | (uint32_t)(b0 + it * 64 + lane);
         return ((uint32_t)(a.seg_f0[s] + pos.fo) << 26) | (uint32_t)pos.b;
@@ -167,12 +180,31 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const
     uint32_t k[RITEMS];
     Pass0<IdT> p0;
     if (pass == 0) p0.init(a, s, e0, n_s, lane, fast);
+    const int64_t nw = n_s - e0;  // entries of this wavefront (<= 0: none)
+    if (pass == 0 && p0.one) {  // wave-uniform
+        IdT r[RITEMS];
 #pragma unroll
-    for (int it = 0; it < RITEMS; ++it) {  // all loads of the tile in flight before the first LDS atomic
-        const int64_t e = e0 + it * 64 + lane;
-        k[it] = 0xffffffffu;
-        if (e < n_s) k[it] = (pass == 0) ? p0.key(a, s, it, lane) : keys_in[2 * (seg_base + e)];  // (key, val) pairs
-        if (pass == 0) p0.next(a);
+        for (int it = 0; it < RITEMS; ++it) r[it] = p0.raw(it, lane, (int)(nw < RTILE / 4 ? nw : RTILE / 4));
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) k[it] = (it * 64 + lane < nw) ? p0.finish(a, s, r[it]) : 0xffffffffu;
+    } else if (pass > 0 && nw > 0) {  // wave-uniform
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) {
+            int64_t i = it * 64 + lane;
+            if (i > nw - 1) i = nw - 1;
+            k[it] = keys_in[2 * (seg_base + e0 + i)];  // (key, val) pairs
+        }
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it)
+            if (it * 64 + lane >= nw) k[it] = 0xffffffffu;
+    } else {
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) {  // a wavefront that straddles two features of a shared table (or has no entries)
+            const int64_t e = e0 + it * 64 + lane;
+            k[it] = 0xffffffffu;
+            if (e < n_s && pass == 0) k[it] = p0.key(a, s, it, lane);
+            if (pass == 0) p0.next(a);
+        }
     }
     __syncthreads();
     // plain LDS atomics: peeling hot digits with ballots (one aggregated atomic per distinct digit) was measured SLOWER
@@ -304,22 +336,43 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, in
     int off[RITEMS];  // digit | rank-inside-(wave, digit) << 11
     Pass0<IdT> p0;
     if (pass == 0) p0.init(a, s, e0, n_s, lane, fast);
+    const int64_t nw = n_s - e0;  // entries of this wavefront (<= 0: none)
+    if (pass == 0 && p0.one) {  // wave-uniform; loads first, branch-free (see Pass0::raw)
+        IdT r[RITEMS];
 #pragma unroll
-    for (int it = 0; it < RITEMS; ++it) {  // every load of the tile in flight before the ranking starts
-        const int64_t e = e0 + it * 64 + lane;
-        key[it] = 0;
-        val[it] = 0;
-        if (e < n_s) {
-            if (pass == 0) {
+        for (int it = 0; it < RITEMS; ++it) r[it] = p0.raw(it, lane, (int)(nw < RTILE / 4 ? nw : RTILE / 4));
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) {
+            const bool live = it * 64 + lane < nw;
+            key[it] = live ? p0.finish(a, s, r[it]) : 0u;
+            val[it] = live ? p0.val(a, s, it, lane) : 0u;
+        }
+    } else if (pass > 0 && nw > 0) {  // wave-uniform
+        uint2 kv[RITEMS];
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) {
+            int64_t i = it * 64 + lane;
+            if (i > nw - 1) i = nw - 1;
+            kv[it] = reinterpret_cast<const uint2*>(keys_in)[seg_base + e0 + i];  // pairs from the previous pass
+        }
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) {
+            const bool live = it * 64 + lane < nw;
+            key[it] = live ? kv[it].x : 0u;
+            val[it] = live ? kv[it].y : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < RITEMS; ++it) {  // a wavefront that straddles two features of a shared table (or has no entries)
+            const int64_t e = e0 + it * 64 + lane;
+            key[it] = 0;
+            val[it] = 0;
+            if (e < n_s && pass == 0) {
                 key[it] = p0.key(a, s, it, lane);
                 val[it] = p0.val(a, s, it, lane);
-            } else {
-                const uint2 kv = reinterpret_cast<const uint2*>(keys_in)[seg_base + e];  // pairs from the previous pass
-                key[it] = kv.x;
-                val[it] = kv.y;
             }
+            if (pass == 0) p0.next(a);
         }
-        if (pass == 0) p0.next(a);
     }
     __syncthreads();
 #pragma unroll
@@ -379,25 +432,55 @@ struct OptHyper {
 
 // A table row update in two halves, so that the row (+ optimizer state) loads can be issued BEFORE the gradient
 // rows they do not depend on: load_row() fetches, finish_row() applies the optimizer and stores.
+// pointers into the tables carry the GLOBAL address space explicitly: a pointer that went through LDS (FeatRow below) is
+// generic to the compiler, and its accesses would be flat_load / flat_store
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
 struct RowRmw {
-    float* w;
-    float* s1;
-    float* s2;
+    gfloat* w;
+    gfloat* s1;
+    gfloat* s2;
     f32x4 wv, m, v;
 };
 
 // f: any feature of the run (features sharing a table share pointers and key range); key: compact key.
 __device__ __forceinline__ void load_row(const BwdArgs& a, int f, int64_t key, int D, int c4, int opt, RowRmw& r) {
     const int64_t off = (key - a.first[f]) * D + c4 * 4;
-    r.w = a.table[f] + off;
-    r.wv = *reinterpret_cast<const f32x4*>(r.w);
+    r.w = (gfloat*)(a.table[f] + off);
+    r.wv = *reinterpret_cast<const gf32x4*>(r.w);
     if (opt != MH_OPT_SGD) {
-        r.s1 = a.state[f] + off;
-        r.m = *reinterpret_cast<const f32x4*>(r.s1);
+        r.s1 = (gfloat*)(a.state[f] + off);
+        r.m = *reinterpret_cast<const gf32x4*>(r.s1);
     }
     if (opt == MH_OPT_ADAM) {
-        r.s2 = a.state2[f] + off;
-        r.v = *reinterpret_cast<const f32x4*>(r.s2);
+        r.s2 = (gfloat*)(a.state2[f] + off);
+        r.v = *reinterpret_cast<const gf32x4*>(r.s2);
+    }
+}
+
+// What a row update needs of one feature.  The piece kernel copies the BwdArgs columns into LDS once per workgroup: indexing
+// the kernel-argument arrays with a per-lane feature number compiles to GLOBAL loads from the argument segment, and every
+// row address then hangs behind such a load -- measured in the ISA of the first version: pointer fetch -> wait -> weight row
+// -> pointer fetch -> wait for everything -> state row -> offset fetch -> wait -> gradient rows, three to four memory round
+// trips per piece.  From LDS the pointers arrive in ~100 cycles and all rows of a piece are fetched in ONE round trip.
+struct FeatRow {
+    float* table;
+    float* state;
+    float* state2;
+    int64_t first, offset;
+};
+
+__device__ __forceinline__ void load_row(const FeatRow& ft, int64_t key, int D, int c4, int opt, RowRmw& r) {
+    const int64_t off = (key - ft.first) * D + c4 * 4;
+    r.w = (gfloat*)(ft.table + off);
+    r.wv = *reinterpret_cast<const gf32x4*>(r.w);
+    if (opt != MH_OPT_SGD) {
+        r.s1 = (gfloat*)(ft.state + off);
+        r.m = *reinterpret_cast<const gf32x4*>(r.s1);
+    }
+    if (opt == MH_OPT_ADAM) {
+        r.s2 = (gfloat*)(ft.state2 + off);
+        r.v = *reinterpret_cast<const gf32x4*>(r.s2);
     }
 }
 
@@ -407,7 +490,7 @@ __device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const Op
     f32x4 wv = r.wv;
     if (opt == MH_OPT_ADAGRAD) {
         const f32x4 sv = r.m + g * g;
-        *reinterpret_cast<f32x4*>(r.s1) = sv;
+        *reinterpret_cast<gf32x4*>(r.s1) = sv;
         wv.x -= lr * g.x / (sqrtf(sv.x) + eps);
         wv.y -= lr * g.y / (sqrtf(sv.y) + eps);
         wv.z -= lr * g.z / (sqrtf(sv.z) + eps);
@@ -416,8 +499,8 @@ __device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const Op
         // LazyAdam._resource_apply_sparse (blocks/optimizer.py:412-437): only the touched rows' moments move
         const f32x4 m = r.m * hp.beta1 + g * (1.f - hp.beta1);
         const f32x4 v = r.v * hp.beta2 + (g * g) * (1.f - hp.beta2);
-        *reinterpret_cast<f32x4*>(r.s1) = m;
-        *reinterpret_cast<f32x4*>(r.s2) = v;
+        *reinterpret_cast<gf32x4*>(r.s1) = m;
+        *reinterpret_cast<gf32x4*>(r.s2) = v;
         wv.x -= lr * m.x / (sqrtf(v.x) + eps);
         wv.y -= lr * m.y / (sqrtf(v.y) + eps);
         wv.z -= lr * m.z / (sqrtf(v.z) + eps);
@@ -425,7 +508,7 @@ __device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const Op
     } else {
         wv -= g * lr;
     }
-    *reinterpret_cast<f32x4*>(r.w) = wv;
+    *reinterpret_cast<gf32x4*>(r.w) = wv;
 }
 
 
@@ -491,12 +574,27 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
         }
         if (lane == 0) pre_start = pre;
     }
+    // Loads in two rounds, each branch-free and issued for all LIST_TILES tiles before any of them is used (one load per
+    // `if`, used right behind it, compiled to a load + s_waitcnt vmcnt(0) each: 4 x LIST_TILES sequential round trips per
+    // thread in the first version).  Round 1: the entry's key and its predecessor's; round 2: the key behind the piece and
+    // the entry's value.  Indices are clamped into [0, n - 1]; what a clamped load returns is never used.
+    KeyT k1[LIST_TILES], kp[LIST_TILES];
 #pragma unroll
     for (int t = 0; t < LIST_TILES; ++t) {
         const int64_t i = w0 + t * 256 + threadIdx.x;
-        const KeyT k = (i < n) ? keys[i] : SENT;
+        const int64_t ic = i < n ? i : n - 1;
+        k1[t] = keys[ic];
+        kp[t] = keys[ic > 0 ? ic - 1 : 0];
+    }
+    int64_t pe[LIST_TILES];  // first index behind the piece that starts at this entry (if one does)
+    int plen[LIST_TILES];
+    bool pcut[LIST_TILES], pstart[LIST_TILES];
+#pragma unroll
+    for (int t = 0; t < LIST_TILES; ++t) {
+        const int64_t i = w0 + t * 256 + threadIdx.x;
+        const KeyT k = (i < n) ? k1[t] : SENT;
         const bool valid = k != SENT;
-        const bool run_start = valid && (i == 0 || keys[i - 1] != k);
+        const bool run_start = valid && (i == 0 || kp[t] != k);
         const bool cut = valid && (run_start || (i & (CHUNK - 1)) == 0);
         const uint64_t cuts = __ballot(cut);
         const uint64_t stops = cuts | ~__ballot(valid);  // a piece ends before the next cut or the next invalid entry
@@ -504,13 +602,13 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
         rec[t] = 0;
         kk[t] = k;
         my_start[t] = -1;
+        const uint64_t later = (lane == 63) ? 0ull : (stops >> (lane + 1));
+        const int len = later ? (__ffsll((unsigned long long)later)) : (64 - lane);  // 64 | chunk: a wave end is a cut
+        plen[t] = len;
+        pcut[t] = cut;
+        pstart[t] = run_start;
+        pe[t] = cut ? i + len : i;
         if (cut) {
-            const uint64_t later = (lane == 63) ? 0ull : (stops >> (lane + 1));
-            const int len = later ? (__ffsll((unsigned long long)later)) : (64 - lane);  // 64 | chunk: a wave end is a cut
-            const int64_t e = i + len;
-            const bool ends = (e >= n) || (keys[e] != k);
-            rec[t] = (uint64_t)i | ((uint64_t)len << 32) | ((uint64_t)(run_start ? 1 : 0) << 37) |
-                     ((uint64_t)(ends ? 1 : 0) << 38) | ((uint64_t)(vals[i] >> 26) << 39) | (1ull << 63);
             const uint64_t sb = starts & le_mask;
             if (sb) my_start[t] = i - lane + (63 - __clzll((unsigned long long)sb));
         }
@@ -518,6 +616,23 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
         if (lane == 0) {
             wave_cnt[t][wave] = __popcll(cuts);
             wave_last_start[t][wave] = starts ? (i + (63 - __clzll((unsigned long long)starts))) : -1;
+        }
+    }
+    KeyT ke[LIST_TILES];
+    uint32_t pv[LIST_TILES];
+#pragma unroll
+    for (int t = 0; t < LIST_TILES; ++t) {
+        const int64_t i = w0 + t * 256 + threadIdx.x;
+        ke[t] = keys[pe[t] < n ? pe[t] : n - 1];
+        pv[t] = vals[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int t = 0; t < LIST_TILES; ++t) {
+        if (pcut[t]) {
+            const int64_t i = w0 + t * 256 + threadIdx.x;
+            const bool ends = (pe[t] >= n) || (ke[t] != kk[t]);
+            rec[t] = (uint64_t)i | ((uint64_t)plen[t] << 32) | ((uint64_t)(pstart[t] ? 1 : 0) << 37) |
+                     ((uint64_t)(ends ? 1 : 0) << 38) | ((uint64_t)(pv[t] >> 26) << 39) | (1ull << 63);
         }
     }
     __syncthreads();
@@ -574,11 +689,21 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
     const int glane0 = (int)(threadIdx.x & 63) - c4;  // VMODE 1: first lane of the group inside its wavefront
+    __shared__ FeatRow feat[MH_MAX_FEATURES];
+    if (threadIdx.x < MH_MAX_FEATURES) {
+        const int f = threadIdx.x;
+        feat[f].table = a.table[f];
+        feat[f].state = a.state[f];
+        feat[f].state2 = a.state2[f];
+        feat[f].first = a.first[f];
+        feat[f].offset = a.offset[f];
+    }
+    __syncthreads();
     const int64_t np = (int64_t)*counter;
     const int64_t stride = (int64_t)gridDim.x * groups;
     auto row = [&](uint32_t v) -> f32x4 {
         const int f = (int)(v >> 26);
-        return *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + a.offset[f] +
+        return *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + feat[f].offset +
                                                c4 * 4);
     };
     // records as scalar pairs (rec, key); a record of length 0 stands for "no piece"
@@ -627,7 +752,7 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         const bool whole = active && starts && ends;
         const bool partial = active && !whole && !deterministic;  // deterministic: carry_apply walks crossing runs itself
         RowRmw rr;
-        if (whole) load_row(a, fk, (int64_t)key, D, c4, opt, rr);  // independent of the gradient rows: overlaps them
+        if (whole) load_row(feat[fk], (int64_t)key, D, c4, opt, rr);  // independent of the gradient rows: overlaps them
         const uint32_t* vv = vals + s0;
         // entry i of the piece: VMODE 1 reads it from lane i of the group (every lane of a group runs the same trip count, so
         // the source lanes are active), VMODE 0 from memory
@@ -690,8 +815,8 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
     const int64_t c0 = chunk * CHUNK;
     const int64_t c1 = c0 + CHUNK;
     if (c1 >= n) return;  // the last chunk cannot be crossed
-    const KeyT key = keys[c1 - 1];
-    if (key == KeyTraits<KeyT>::sentinel || keys[c1] != key) return;  // last run ends here
+    const KeyT key = keys[c1 - 1], after = keys[c1];  // both before the test: `a || keys[c1] != key` would load the second behind a wait for the first
+    if ((key == KeyTraits<KeyT>::sentinel) | (after != key)) return;  // last run ends here (`|`: no short circuit, see above)
     // everything else that depends on the chunk index alone is fetched together (one round trip, not a chain of four)
     const KeyT kfirst = keys[c0];
     const KeyT kbefore = (c0 > 0) ? keys[c0 - 1] : KeyTraits<KeyT>::sentinel;  // the sentinel differs from `key`

@@ -57,11 +57,14 @@ __device__ __forceinline__ int kmajor_src_chunk(int p) {  // chunk position -> s
     return (p % CH) ^ kmajor_swz<CH>(p / CH);
 }
 
-template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restrict__ A, int64_t lda,
-                                                          const float* __restrict__ B, int64_t ldb, int64_t M, int N, int K,
-                                                          float* __restrict__ C, int64_t ldc, const Epilogue ep,
-                                                          int ncol_tiles) {
+// The product of one output tile, accumulators left in registers: acc[tm][tn] is the 32 x 32 block at rows
+// row0 + wm * TM * 32 + tm * 32, columns n0 + wn * TN * 32 + tn * 32 of C in the MFMA C layout (lane: column l31, rows
+// (r & 3) + 8 (r >> 2) + 4 h).  gemm2_kernel stores them through mhgemm::store_tile; a kernel with its own epilogue (row
+// reductions instead of a store: tools/exp/scorer_lab.hip) calls this directly.
+template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE, int BKT, int ABLATE>
+__device__ __forceinline__ void gemm2_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                           int64_t M, int N, int K, int64_t row0, int n0, float* smem,
+                                           f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int BK = BKT, CH = BKT / 4;
@@ -71,16 +74,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
     static_assert(NIA >= 1 && NIB >= 1 && (BM * CH / 64) % NW == 0 && (BN * CH / 64) % NW == 0, "tile / wavefront mismatch");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int NI = NIA + NIB;
-    extern __shared__ __attribute__((aligned(1024))) float smem[];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    // column tiles fastest: the workgroups resident at one time share few A row panels (read once from HBM) and sweep
-    // all of B (L2 / Infinity Cache resident)
-    const int64_t row0 = (int64_t)(blockIdx.x / ncol_tiles) * BM;
-    const int n0 = (int)(blockIdx.x % ncol_tiles) * BN;
 
     // ---- per-lane DMA source pointers (tile 0) ------------------------------------------------------------------------
     const float* pa[NIA];
@@ -154,7 +152,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
             fb[tn] = A_FL + h * BN + ((((n >> 2) ^ (8 * h)) << 2) | (n & 3));  // step s: + 2 s BN
     }
 
-    f32x16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -225,8 +222,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restr
         }
     }
 
+}
+
+template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb, int64_t M, int N, int K,
+                                                          float* __restrict__ C, int64_t ldc, const Epilogue ep,
+                                                          int ncol_tiles) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    // column tiles fastest: the workgroups resident at one time share few A row panels (read once from HBM) and sweep
+    // all of B (L2 / Infinity Cache resident)
+    const int64_t row0 = (int64_t)(blockIdx.x / ncol_tiles) * BM;
+    const int n0 = (int)(blockIdx.x % ncol_tiles) * BN;
+    f32x16 acc[TM][TN];
+    gemm2_tile<BM, BN, WM, WN, B_NT, STAGES, PIPE, BKT, ABLATE>(A, lda, B, ldb, M, N, K, row0, n0, smem, acc);
     // ---- epilogue: bias / activation / cross / folded activation derivative (mh_gemm_core.h) -------------------------------
-    mhgemm::store_tile<TM, TN>(acc, C, ldc, row0 + wm * TM * 32, n0 + wn * TN * 32, M, N, lane, ep);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    mhgemm::store_tile<TM, TN>(acc, C, ldc, row0 + (wave / WN) * TM * 32, n0 + (wave % WN) * TN * 32, M, N, (int)(threadIdx.x & 63), ep);
 }
 
 template <int BM, int BN, int WM, int WN, bool B_NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>

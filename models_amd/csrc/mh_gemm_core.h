@@ -273,6 +273,16 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
                 for (int g = 0; g < 4; ++g) {
                     float* pr = pg;
                     const float* mr = mg;
+                    // the mask values of the group's 4 rows are fetched BEFORE its first store: nothing tells the compiler that
+                    // C and the mask do not overlap, so a mask load behind a store stayed behind it -- load, wait, store per
+                    // element (seen in the ISA)
+                    float mk[4][TN];
+                    if (MASK) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) mk[q][tn] = mr[q * ep.ldm + 32 * tn];
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -280,11 +290,10 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
                             float v = acc[tm][tn][4 * g + q] + bv[tn];
                             if (ACT == MH_ACT_RELU) v = v > 0.f ? v : 0.f;
                             if (ACT == MH_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                            if (MASK) v = (mr[32 * tn] > 0.f) ? v : 0.f;
+                            if (MASK) v = (mk[q][tn] > 0.f) ? v : 0.f;
                             pr[32 * tn] = v;
                         }
                         pr += ldc;
-                        if (MASK) mr += ep.ldm;
                     }
                     pg += ld8;
                     if (MASK) mg += 8 * ep.ldm;
@@ -295,6 +304,43 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
         else if (ep.act == MH_ACT_RELU) body(EpiTag<MH_ACT_RELU>{}, EpiFlag<false>{});
         else if (ep.act == MH_ACT_SIGMOID) body(EpiTag<MH_ACT_SIGMOID>{}, EpiFlag<false>{});
         else body(EpiTag<MH_ACT_NONE>{}, EpiFlag<false>{});
+        return;
+    }
+    if (full && ep.x0 && ep.act == MH_ACT_NONE && ep.x_act == MH_ACT_NONE) {
+        // Cross layer (optionally storing the pre-activation p): out = x0 * (acc + b) + x.  The x0 / x values of four rows x TN
+        // column blocks are fetched together, then used: in the element-wise fallback below every element's two loads sit
+        // inside `if (row < M)` with their use right behind them, and each compiled to a load + s_waitcnt vmcnt(0) -- 128
+        // sequential round trips per wavefront at the end of every 256 x 128 tile (seen in the ISA).
+        float bv[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bv[tn] = ep.bias ? ep.bias[col_base + tn * 32 + l31] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t r0 = row_base + tm * 32 + 8 * g + 4 * h;
+                const float* px0 = ep.x0 + r0 * ep.ld_x0 + col_base + l31;
+                const float* pxr = ep.xres + r0 * ep.ld_x0 + col_base + l31;
+                float a0[4][TN], ar[4][TN];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        a0[q][tn] = px0[q * ep.ld_x0 + 32 * tn];
+                        ar[q][tn] = pxr[q * ep.ld_x0 + 32 * tn];
+                    }
+                float* pc = C + r0 * ldc + col_base + l31;
+                float* pp = ep.p_out ? ep.p_out + r0 * ep.ldp + col_base + l31 : nullptr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        float v = acc[tm][tn][4 * g + q] + bv[tn];
+                        if (pp) pp[q * ep.ldp + 32 * tn] = v;
+                        v = a0[q][tn] * v + ar[q][tn];
+                        pc[q * ldc + 32 * tn] = v;
+                    }
+            }
         return;
     }
 #pragma unroll

@@ -460,11 +460,20 @@ struct SlotLane {
         rows = a.rows[f];
         dense = mine && tab == nullptr;
     }
-    __device__ __forceinline__ int64_t load_id(int64_t b) const { return (mine && !dense) ? (int64_t)ids[b] : 0; }
-    __device__ __forceinline__ uint64_t address(int64_t b, int64_t id, const float* __restrict__ dense_src, int64_t ld_dense,
+    // The id is kept RAW (as loaded) until address() of the next iteration uses it: any arithmetic on it right after the
+    // load -- the sign extension of `(int64_t)ids[b]` was enough -- makes the compiler wait for the load at once, and with
+    // the in-order vmcnt counter that wait also covered the row loads issued just before it: the "prefetch" of the first
+    // version was synchronous (s_waitcnt vmcnt(0) in front of the MFMA section, seen in the ISA).
+    __device__ __forceinline__ IdT load_id(int64_t b) const {
+        IdT v = 0;
+        if (mine && !dense) v = ids[b];
+        return v;
+    }
+    __device__ __forceinline__ uint64_t address(int64_t b, IdT raw_id, const float* __restrict__ dense_src, int64_t ld_dense,
                                                 int D) const {
         if (!mine) return 0;
         if (dense) return dense_src ? reinterpret_cast<uint64_t>(dense_src + b * ld_dense) : 0;
+        const int64_t id = (int64_t)raw_id;
         return (id >= 0 && id < rows) ? reinterpret_cast<uint64_t>(tab + id * D) : 0;
     }
 };
@@ -481,7 +490,10 @@ __device__ __forceinline__ void fetch_rows(uint64_t addr, int F, int lane, f32x4
         const int src = i * RP + sub;  // < 64: NV * RP <= 32 + RP
         const uint32_t lo = (uint32_t)__shfl(alo, src), hi = (uint32_t)__shfl(ahi, src);
         const uint64_t a = ((uint64_t)hi << 32) | lo;
-        xr[i] = a ? *reinterpret_cast<const f32x4*>(a + (uint64_t)c4 * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // the address was rebuilt from two shuffled halves: without the explicit GLOBAL address space the access is a
+        // flat_load, which also counts in lgkmcnt -- every LDS wait of the MFMA section then waited for the row loads too
+        xr[i] = a ? *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(a + (uint64_t)c4 * 16)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -516,21 +528,47 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
     int64_t b, b1;
     wave_chunk(B, &b, &b1);
     f32x4 xr[NV];
-    int64_t idn = 0;
+    IdT idn = 0;
     if (b < b1) {
         fetch_rows<D, NV>(sl.address(b, sl.load_id(b), dense, ld_dense, D), F, lane, xr);
         if (b + 1 < b1) idn = sl.load_id(b + 1);
     }
     const bool two = F > 16;
+    // The outputs of sample b are stored one iteration LATE, right behind the prefetch loads of iteration b + 1: gfx9-family
+    // stores count in vmcnt like loads, so the s_waitcnt vmcnt(0) in front of the LDS writes at the top of an iteration also
+    // waited for the stores the previous iteration had issued at its very end; issued together with the loads they have a
+    // whole MFMA phase to complete.
+    f32x4 o00 = {0.f, 0.f, 0.f, 0.f}, o01 = o00, o11 = o00;
+    float odense = 0.f;
+    float* oprev = nullptr;
+    auto flush = [&]() {
+        if (!oprev) return;  // wave-uniform
+        store_tile(o00, 0, 0, lane, F, oprev);
+        if (two) {
+            store_tile(o01, 0, 1, lane, F, oprev);
+            store_tile(o11, 1, 1, lane, F, oprev);
+        }
+        if (append_dense && dense_slot >= 0 && lane < D) oprev[P + lane] = odense;
+    };
     while (b < b1) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (i * RP < F && i * RP + sub < IMAXF) *reinterpret_cast<f32x4*>(xdst + i * RP * LD) = xr[i];
         __builtin_amdgcn_wave_barrier();
         if (b + 1 < b1) {
-            fetch_rows<D, NV>(sl.address(b + 1, idn, dense, ld_dense, D), F, lane, xr);  // ids of b+1 came in one iteration ago
+            // order matters for the waits the compiler inserts: the id of b + 1 (loaded one iteration ago) is consumed, the id
+            // load of b + 2 is issued into the same register, THEN the row loads -- nothing touches a loaded register between
+            // the issue of this sample's loads and the MFMA section
+            const uint64_t addr = sl.address(b + 1, idn, dense, ld_dense, D);
             if (b + 2 < b1) idn = sl.load_id(b + 2);
+            fetch_rows<D, NV>(addr, F, lane, xr);
         }
+        // the stores stay HERE: without the two fences the optimizer moves them (nothing aliases `out`) to the top of the
+        // loop and, after rotation, back to the end of the previous iteration -- exactly the placement this avoids
+        asm volatile("" ::: "memory");
+        flush();  // sample b - 1
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc11 = acc00;
         const float* r0 = Xs + i16 * LD + qoff;
         const float* r1 = Xs + (16 + i16) * LD + qoff;
@@ -550,17 +588,23 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
                 for (int j = 0; j < 4; ++j) acc00 = mfma16(a0[j], a0[j], acc00);
             }
         }
-        float* orow = out + b * ldo;
-        store_tile(acc00, 0, 0, lane, F, orow);
-        if (two) {
-            store_tile(acc01, 0, 1, lane, F, orow);
-            store_tile(acc11, 1, 1, lane, F, orow);
+        oprev = out + b * ldo;
+        o00 = acc00;
+        o01 = acc01;
+        o11 = acc11;
+        if (append_dense && dense_slot >= 0) {
+            static_assert(D <= 128, "dense copy: two values per lane at most");
+            if (D <= 64) {
+                if (lane < D) odense = Xs[dense_slot * LD + lane];
+            } else {  // D = 128: the second half goes out at once (rare configuration)
+                odense = Xs[dense_slot * LD + lane];
+                oprev[P + 64 + lane] = Xs[dense_slot * LD + 64 + lane];
+            }
         }
-        if (append_dense && dense_slot >= 0)
-            for (int t = lane; t < D; t += 64) orow[P + t] = Xs[dense_slot * LD + t];
         __builtin_amdgcn_wave_barrier();
         ++b;
     }
+    flush();
 }
 
 template <typename IdT, int DT, int NV>
@@ -578,8 +622,14 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
     unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);
     unsigned char* pair_j = pair_i + 512;
     float* base = smem + 256;
-    float* Xs = base + wave * (IMAXF * LD + IMAXF * LDS_S);
-    float* Ss = Xs + IMAXF * LD;
+    // The slab of a wavefront holds F + 1 rows of X and of the gradient matrix S, not IMAXF: rows F .. 31 of the 32-row MFMA
+    // operands are all zero, so every read of a row >= F is redirected to ONE zero row (row F, never written).  The LDS saved
+    // decides how many workgroups a CU holds: 27 features, D = 64: 52 instead of 59 KB -> 3 instead of 2 (130 + 20 registers
+    // allow 3 wavefronts per SIMD).
+    const int R = F + 1;
+    const int slab = R * LD + ((R * LDS_S + 3) & ~3);  // multiple of 4 floats: the next wavefront's rows stay 16-byte aligned
+    float* Xs = base + wave * slab;
+    float* Ss = Xs + R * LD;
     const int i16 = lane & 15, q = lane >> 4;
     for (int p = threadIdx.x; p < P; p += 256) {
         int i = 0, start = 0;
@@ -590,8 +640,8 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
         pair_i[p] = (unsigned char)i;
         pair_j[p] = (unsigned char)(i + 1 + (p - start));
     }
-    for (int idx = lane; idx < IMAXF * LDS_S; idx += 64) Ss[idx] = 0.f;
-    for (int idx = lane; idx < IMAXF * LD; idx += 64) Xs[idx] = 0.f;
+    for (int idx = lane; idx < R * LDS_S; idx += 64) Ss[idx] = 0.f;
+    for (int idx = lane; idx < R * LD; idx += 64) Xs[idx] = 0.f;
     __syncthreads();
     const int sub = lane / vpr, c4 = lane - sub * vpr;
     float* xdst = Xs + sub * LD + c4 * 4;
@@ -607,12 +657,20 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
     wave_chunk(B, &b, &b1);
     f32x4 xr[NV];
     float gr[NP];
-    int64_t idn = 0;
+    IdT idn = 0;
+    float tgn[DT];  // tail gradient (the appended dense copy) of the NEXT sample: fetched with the rest of its prefetch
+#pragma unroll
+    for (int tn = 0; tn < DT; ++tn) tgn[tn] = 0.f;
     auto load_g = [&](int64_t bb) {
         const float* gp = dout + bb * ldo;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if (s_off[k] >= 0) gr[k] = gp[lane + 64 * k];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) {
+            const int d = 16 * tn + i16;
+            if (tail_slot >= 0 && d < T) tgn[tn] = gp[P + d];
+        }
     };
     if (b < b1) {
         fetch_rows<D, NV>(sl.address(b, sl.load_id(b), dense, ld_dense, D), F, lane, xr);
@@ -620,10 +678,14 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
         if (b + 1 < b1) idn = sl.load_id(b + 1);
     }
     const int nti = F > 16 ? 2 : 1;
+    const int srow0 = (i16 < F ? i16 : F) * LDS_S, srow1 = (16 + i16 < F ? 16 + i16 : F) * LDS_S;
+    int xrow[8];  // operand row 4 st + q of X (the zero row for rows >= F)
+#pragma unroll
+    for (int st = 0; st < 8; ++st) xrow[st] = (4 * st + q < F ? 4 * st + q : F) * LD;
     while (b < b1) {
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (i * RP < F && i * RP + sub < IMAXF) *reinterpret_cast<f32x4*>(xdst + i * RP * LD) = xr[i];
+            if (i * RP + sub < F) *reinterpret_cast<f32x4*>(xdst + i * RP * LD) = xr[i];
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if (s_off[k] >= 0) {
@@ -631,23 +693,20 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
                 Ss[s_off[k] >> 16] = gr[k];
             }
         __builtin_amdgcn_wave_barrier();
-        const float* gcur = dout + b * ldo;
         float tgv[DT];
 #pragma unroll
-        for (int tn = 0; tn < DT; ++tn) {
-            const int d = 16 * tn + i16;
-            tgv[tn] = (tail_slot >= 0 && d < T) ? gcur[P + d] : 0.f;
-        }
+        for (int tn = 0; tn < DT; ++tn) tgv[tn] = tgn[tn];
         if (b + 1 < b1) {
-            fetch_rows<D, NV>(sl.address(b + 1, idn, dense, ld_dense, D), F, lane, xr);
-            load_g(b + 1);
+            const uint64_t addr = sl.address(b + 1, idn, dense, ld_dense, D);  // same order as in the forward kernel
             if (b + 2 < b1) idn = sl.load_id(b + 2);
+            fetch_rows<D, NV>(addr, F, lane, xr);
+            load_g(b + 1);
         }
         float a0[8], a1[8];
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-            a0[st] = Ss[i16 * LDS_S + 4 * st + q];
-            a1[st] = (nti == 2) ? Ss[(16 + i16) * LDS_S + 4 * st + q] : 0.f;
+            a0[st] = Ss[srow0 + 4 * st + q];
+            a1[st] = (nti == 2) ? Ss[srow1 + 4 * st + q] : 0.f;
         }
         f32x4 acc0[DT], acc1[DT];
 #pragma unroll
@@ -656,7 +715,7 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
             acc1[tn] = acc0[tn];
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                const float bv = Xs[(4 * st + q) * LD + 16 * tn + i16];
+                const float bv = Xs[xrow[st] + 16 * tn + i16];
                 acc0[tn] = mfma16(a0[st], bv, acc0[tn]);
                 if (nti == 2) acc1[tn] = mfma16(a1[st], bv, acc1[tn]);
             }
@@ -668,8 +727,8 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f0 = q * 4 + r, f1 = 16 + f0;
-                Xs[f0 * LD + d] = acc0[tn][r] + (f0 == tail_slot ? tgv[tn] : 0.f);
-                if (nti == 2) Xs[f1 * LD + d] = acc1[tn][r] + (f1 == tail_slot ? tgv[tn] : 0.f);
+                if (f0 < F) Xs[f0 * LD + d] = acc0[tn][r] + (f0 == tail_slot ? tgv[tn] : 0.f);
+                if (nti == 2 && f1 < F) Xs[f1 * LD + d] = acc1[tn][r] + (f1 == tail_slot ? tgv[tn] : 0.f);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -794,9 +853,9 @@ static int32_t fill_fused_args(FusedArgs* a, const float* const* slot_tables, co
 
 // one resident set of workgroups (every wavefront walks one contiguous run of samples): CUs x what LDS and a <= 128 VGPR
 // budget allow
-static dim3 fused_grid(int64_t B, size_t lds) {
+static dim3 fused_grid(int64_t B, size_t lds, int max_occ = 4) {
     int occ = (int)((160 * 1024) / lds);
-    if (occ > 4) occ = 4;
+    if (occ > max_occ) occ = max_occ;
     if (occ < 1) occ = 1;
     const int64_t want = mh_ceil_div(B, 4);
     const int64_t cap = (int64_t)mh_num_cus() * occ;
@@ -868,8 +927,8 @@ int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int
     const int T = tail_slot >= 0 ? D : 0;
     MH_REQUIRE(ldo >= P + T, "mh_dlrm_interaction_fused_bwd: ldo too small");
     if (B <= 0) return MH_OK;
-    const size_t lds = 1024 + (size_t)4 * (IMAXF * (D + 16) + IMAXF * LDS_S) * sizeof(float);
-    const dim3 grid = fused_grid(B, lds);
+    const size_t lds = 1024 + (size_t)4 * ((F + 1) * (D + 16) + (((F + 1) * LDS_S + 3) & ~3)) * sizeof(float);
+    const dim3 grid = fused_grid(B, lds, D == 16 ? 4 : (D == 128 ? 2 : 3));  // what the register count of each instantiation allows
     hipStream_t s_ = mh_stream(stream);
 #define MH_LAUNCH_FUSED_BWD(IDT, DT)                                                                             \
     {                                                                                                            \

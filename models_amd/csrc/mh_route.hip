@@ -36,6 +36,44 @@ __device__ __forceinline__ int64_t load_id(const RouteArgs& a, int64_t e, int64_
     return (int64_t) reinterpret_cast<const IdT*>(a.ids[f])[b];
 }
 
+// The TILE entries of a workgroup lie inside ONE feature whenever B is a multiple of TILE (and almost always otherwise): the
+// id column and the first sample are then workgroup-uniform, and a thread's TILE_IT ids are TILE_IT independent loads from a
+// scalar base, issued together (index clamped, validity applied by the caller).  Entry by entry -- a 64-bit division, a
+// pointer fetched from the kernel-argument table with a per-lane index, then the id, each behind a wait -- the loop was
+// 2 x TILE_IT sequential memory round trips per thread (seen in the ISA).
+template <typename IdT>
+struct TileIds {
+    bool one;   // workgroup-uniform
+    int f0;
+    int64_t b0;
+    IdT raw[TILE_IT];
+    __device__ __forceinline__ void load(const RouteArgs& a, int64_t e0, int64_t n, int64_t B) {
+        const int64_t last = (e0 + TILE < n ? e0 + TILE : n) - 1;  // >= e0: a launched tile has entries
+        f0 = (int)(e0 / B);
+        b0 = e0 - (int64_t)f0 * B;
+        one = last / B == f0;
+        if (one) {
+            const IdT* col = reinterpret_cast<const IdT*>(a.ids[f0]) + b0;
+            const int64_t nt = last - e0 + 1;
+#pragma unroll
+            for (int it = 0; it < TILE_IT; ++it) {
+                int64_t i = it * 256 + threadIdx.x;
+                if (i > nt - 1) i = nt - 1;
+                raw[it] = col[i];
+            }
+        }
+    }
+    // entry e = e0 + it * 256 + threadIdx.x < n
+    __device__ __forceinline__ int64_t get(const RouteArgs& a, int it, int64_t e, int64_t B, int& f, int64_t& b) const {
+        if (one) {
+            f = f0;
+            b = b0 + it * 256 + threadIdx.x;
+            return (int64_t)raw[it];
+        }
+        return load_id<IdT>(a, e, B, f, b);
+    }
+};
+
 template <typename IdT>
 __global__ __launch_bounds__(256) void route_count_kernel(const RouteArgs a, int64_t n, int64_t B, int W,
                                                           int64_t ntiles, int* __restrict__ hist) {
@@ -43,13 +81,15 @@ __global__ __launch_bounds__(256) void route_count_kernel(const RouteArgs a, int
     if (threadIdx.x < MAX_W) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t e0 = (int64_t)blockIdx.x * TILE;
+    TileIds<IdT> t;
+    t.load(a, e0, n, B);
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
         const int64_t e = e0 + it * 256 + threadIdx.x;
         if (e < n) {
             int f;
             int64_t b;
-            const int64_t id = load_id<IdT>(a, e, B, f, b);
+            const int64_t id = t.get(a, it, e, B, f, b);
             atomicAdd(&h[owner_of(id, W)], 1);
         }
     }
@@ -85,12 +125,15 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(const RouteArgs a, i
     }
     const int64_t e0 = (int64_t)blockIdx.x * TILE;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    TileIds<IdT> t;
+    t.load(a, e0, n, B);
+#pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
         const int64_t e = e0 + it * 256 + threadIdx.x;
         int owner = -1, f = 0;
         int64_t b = 0, id = 0;
         if (e < n) {
-            id = load_id<IdT>(a, e, B, f, b);
+            id = t.get(a, it, e, B, f, b);
             owner = owner_of(id, W);
         }
         int rank = 0;

@@ -63,6 +63,52 @@ static size_t mismatches(const float* d0, const float* d1, int64_t M, int N, int
     return bad;
 }
 
+// Staggered co-resident workgroups (UNMEASURED lead of round 2): with one column tile (N = 128) every CU runs ONE generation of
+// workgroups in lock step -- their barrier gaps, LDS-read latencies, prologues and store phases coincide.  Odd workgroups sleep
+// `units` x 1024 cycles (~0.43 us each at 2.4 GHz) before their first tile load, so that two workgroups sharing a CU (128-row
+// tiles, 4 waves each: one wave per SIMD per workgroup) run out of phase and fill each other's gaps.
+template <int BM, int BN, int WM, int WN, bool NT, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void staggered_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb, int64_t M, int N, int K,
+                                                              float* __restrict__ C, int64_t ldc, const mhgemm2::Epilogue ep,
+                                                              int ncol_tiles, int units) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    if (blockIdx.x & 1)
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+    const int64_t row0 = (int64_t)(blockIdx.x / ncol_tiles) * BM;
+    const int n0 = (int)(blockIdx.x % ncol_tiles) * BN;
+    f32x16 acc[TM][TN];
+    mhgemm2::gemm2_tile<BM, BN, WM, WN, NT, STAGES, true, 16, 0>(A, lda, B, ldb, M, N, K, row0, n0, smem, acc);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    mhgemm::store_tile<TM, TN>(acc, C, ldc, row0 + (wave / WN) * TM * 32, n0 + (wave % WN) * TN * 32, M, N,
+                               (int)(threadIdx.x & 63), ep);
+}
+
+template <int BM, int BN, int WM, int WN, bool NT, int STAGES>
+static void run_staggered(const char* name, int units, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int N,
+                          int K, float* C, int64_t ldc, const float* ref, int iters) {
+    mhgemm2::Epilogue ep{};
+    auto kern = staggered_kernel<BM, BN, WM, WN, NT, STAGES>;
+    const size_t lds = (size_t)STAGES * (BM + BN) * 16 * sizeof(float);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ncol = (N + BN - 1) / BN;
+    const int64_t nrow = (M + BM - 1) / BM;
+    auto launch = [&]() {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nrow * ncol)), dim3(WM * WN * 64), lds, 0, A, lda, B, ldb, M, N, K, C, ldc, ep, ncol,
+                           units);
+    };
+    CK(hipMemset(C, 0xff, (size_t)M * ldc * 4));
+    launch();
+    CK(hipDeviceSynchronize());
+    const size_t bad = ref ? mismatches(C, ref, M, N, ldc) : 0;
+    const float ms = time_ms(launch, iters);
+    char label[96];
+    snprintf(label, sizeof label, "%s stagger %d", name, units);
+    printf("  %-34s %8.1f us  %6.1f TF  mismatches %zu\n", label, ms * 1e3, 2.0 * M * N * K / ms * 1e-9, bad);
+    fflush(stdout);
+}
+
 template <int BM, int BN, int WM, int WN, bool NT, int STAGES, bool PIPE = true, int BKT = 16, int ABLATE = 0>
 static void run_variant(const char* name, const float* A, int64_t lda, const float* B, int64_t ldb, int64_t M, int N, int K,
                         float* C, int64_t ldc, const float* ref, int iters) {
@@ -131,6 +177,8 @@ int main(int argc, char** argv) {
             run_variant<128, 128, 2, 2, true, 3>("128x128 4w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 128, 2, 2, true, 4>("128x128 4w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 64, 2, 1, true, 4>("128x64  2w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            for (int u : {0, 1, 2, 4, 8}) run_staggered<128, 128, 2, 2, true, 3>("128x128 4w", u, A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            for (int u : {0, 2, 4, 8}) run_staggered<256, 128, 4, 2, true, 3>("256x128 8w", u, A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
         } else {
             run_variant<256, 128, 4, 2, false, 3>("256x128 8w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<256, 128, 4, 2, false, 3, true, 16, 1>("256x128 8w 3-stage NO LOADS", A, lda, B, ldb, M, N, K, C1, ldc, nullptr, sh.iters);
@@ -145,6 +193,8 @@ int main(int argc, char** argv) {
             run_variant<128, 128, 2, 2, false, 3>("128x128 4w 3-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 128, 2, 2, false, 4>("128x128 4w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
             run_variant<128, 64, 2, 1, false, 4>("128x64  2w 4-stage", A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            for (int u : {0, 1, 2, 4, 8}) run_staggered<128, 128, 2, 2, false, 3>("128x128 4w", u, A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
+            for (int u : {0, 2, 4, 8}) run_staggered<256, 128, 4, 2, false, 3>("256x128 8w", u, A, lda, B, ldb, M, N, K, C1, ldc, C0, sh.iters);
         }
         CK(hipFree(A));
         CK(hipFree(B));

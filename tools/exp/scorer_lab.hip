@@ -1,0 +1,259 @@
+// Lab (UNMEASURED when written -- round 2 ended without GPU minutes): the in-batch scorer forward as a TILED kernel on the
+// second-generation GEMM core, to be compared with the shipped stream kernel (mh_scorer_stream.hip: 0.66-0.69 of the fp32
+// MFMA peak in forward-only mode, 0.655 as the top-k filter).
+//
+//   z[i, j] = (q_i . n_j) / T   (false negatives: pos_id[i] == neg_id[j] -> fns / T),   lse_i = log(exp(z_pos_i) + sum_j exp(z[i, j]))
+//
+// The product is computed TRANSPOSED: the 256-row operand of a workgroup tile is the candidate block n[256, E], the 128-column
+// (NT) operand the query block q[128, E].  In the MFMA C layout a lane then holds 16 CANDIDATES of ONE query per 32 x 32 block:
+// the online (max, sum exp) of a query over the 64 candidates of its wavefront is a register loop (no cross-lane butterflies --
+// the untransposed layout needs 5 shuffle steps per row, twice, 32 rows per lane), then one shuffle joins the two half-waves
+// and LDS joins the four wavefronts that share the query columns.  Partials go to part[candidate tile][query] (float2), a
+// finalize kernel merges them with the positive logit.
+//
+// Build / run (GPU box):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/exp/scorer_lab.hip -Imodels_amd/csrc -o tools/exp/scorer_lab && tools/exp/scorer_lab
+// Prints: correctness against a naive kernel at a small size, then us / TF/s at 32768 x 32768 x 128 with and without the mask.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "../../models_amd/csrc/mh_gemm2.h"
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                               \
+        }                                                                          \
+    } while (0)
+
+namespace {
+
+constexpr int BM = 256, BN = 128, WM = 4, WN = 2, STAGES = 3;
+constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+
+// (m, s) <- merge of two online-softmax partials
+__device__ __forceinline__ void merge(float& m, float& s, float m2, float s2) {
+    const float mm = fmaxf(m, m2);
+    if (mm == -INFINITY) {  // both empty (a lane whose candidates are all padding): exp(-inf - -inf) would be NaN
+        s = 0.f;
+        return;
+    }
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(WM* WN * 64) void scorer_tiled_kernel(const float* __restrict__ neg, const float* __restrict__ q,
+                                                                 int64_t Nn, int B, int E, float inv_T, float fns,
+                                                                 const int* __restrict__ pos_ids,
+                                                                 const int* __restrict__ neg_ids,
+                                                                 float2* __restrict__ part, int ncol_tiles) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    __shared__ float2 wpart[WM][BN];
+    __shared__ int ids_s[BM];
+    const int64_t row0 = (int64_t)(blockIdx.x / ncol_tiles) * BM;  // candidates
+    const int n0 = (int)(blockIdx.x % ncol_tiles) * BN;            // queries
+    if (MASK) {
+        const int64_t r = row0 + threadIdx.x;
+        if (threadIdx.x < BM) ids_s[threadIdx.x] = (r < Nn) ? neg_ids[r] : -1;
+    }
+    f32x16 acc[TM][TN];
+    mhgemm2::gemm2_tile<BM, BN, WM, WN, true, STAGES, true, 16, 0>(neg, E, q, E, Nn, B, E, row0, n0, smem, acc);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    if (MASK) __syncthreads();  // ids_s (the main loop's barriers already ordered it for nk >= 1; explicit for clarity)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = wn * TN * 32 + tn * 32 + l31;  // query inside the tile
+        const int qi = n0 + col;
+        const int pid = (MASK && qi < B) ? pos_ids[qi] : -2;
+        float m = -INFINITY, s = 0.f;
+        float z[TM][16];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;  // candidate inside the tile
+                float v = acc[tm][tn][r];
+                if (MASK && ids_s[rl] == pid) v = fns;
+                v *= inv_T;
+                if (row0 + rl >= Nn) v = -INFINITY;
+                z[tm][r] = v;
+                m = fmaxf(m, v);
+            }
+        const float mref = (m == -INFINITY) ? 0.f : m;  // all 32 candidates of this lane are padding: s stays 0
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += __expf(z[tm][r] - mref);  // exp(-inf - mref) = 0 for the padded candidates
+        merge(m, s, __shfl_xor(m, 32), __shfl_xor(s, 32));
+        if (h == 0) wpart[wm][col] = make_float2(m, s);
+    }
+    __syncthreads();
+    if (threadIdx.x < BN && n0 + (int)threadIdx.x < B) {
+        float2 p = wpart[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < WM; ++w) merge(p.x, p.y, wpart[w][threadIdx.x].x, wpart[w][threadIdx.x].y);
+        part[(int64_t)(blockIdx.x / ncol_tiles) * B + n0 + threadIdx.x] = p;
+    }
+}
+
+__global__ void finalize_kernel(const float2* __restrict__ part, int nrow_tiles, int B, const float* __restrict__ q,
+                                const float* __restrict__ item, int E, float inv_T, float* __restrict__ lse) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float zp = 0.f;
+    for (int k = 0; k < E; ++k) zp = fmaf(q[(int64_t)i * E + k], item[(int64_t)i * E + k], zp);
+    float m = zp * inv_T, s = 1.f;
+    for (int t = 0; t < nrow_tiles; ++t) {
+        const float2 p = part[(int64_t)t * B + i];
+        merge(m, s, p.x, p.y);
+    }
+    lse[i] = m + logf(s);
+}
+
+// naive reference: one thread per query, fp32 fmaf chains (the product's numerics), double accumulation of the softmax
+__global__ void naive_kernel(const float* __restrict__ q, const float* __restrict__ item, const float* __restrict__ neg,
+                             int B, int64_t Nn, int E, float inv_T, float fns, const int* pos_ids, const int* neg_ids,
+                             float* __restrict__ lse) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float zp = 0.f;
+    for (int k = 0; k < E; ++k) zp = fmaf(q[(int64_t)i * E + k], item[(int64_t)i * E + k], zp);
+    double m = zp * inv_T, s = 1.0;
+    for (int64_t j = 0; j < Nn; ++j) {
+        float d = 0.f;
+        for (int k = 0; k < E; ++k) d = fmaf(neg[j * E + k], q[(int64_t)i * E + k], d);  // operand order of the transposed product
+        if (pos_ids && pos_ids[i] == neg_ids[j]) d = fns;
+        const double z = (double)(d * inv_T);
+        if (z > m) {
+            s = s * exp(m - z) + 1.0;
+            m = z;
+        } else {
+            s += exp(z - m);
+        }
+    }
+    lse[i] = (float)(m + log(s));
+}
+
+float* dev_rand(size_t n, uint32_t seed, float scale) {
+    std::vector<float> h(n);
+    uint32_t s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        h[i] = ((int32_t)(s >> 8) % 2001 - 1000) * 0.001f * scale;
+    }
+    float* d;
+    CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+int* dev_ids(size_t n, uint32_t seed, int mod) {
+    std::vector<int> h(n);
+    uint32_t s = seed * 747796405u + 2891336453u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        h[i] = (int)((s >> 8) % (uint32_t)mod);
+    }
+    int* d;
+    CK(hipMalloc(&d, n * sizeof(int)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    return d;
+}
+
+template <bool MASK>
+void run_tiled(const float* neg, const float* q, const float* item, int64_t Nn, int B, int E, float inv_T, float fns,
+               const int* pos_ids, const int* neg_ids, float2* part, float* lse) {
+    auto kern = scorer_tiled_kernel<MASK>;
+    const size_t lds = (size_t)STAGES * (BM + BN) * 16 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const int ncol = (B + BN - 1) / BN;
+    const int nrow = (int)((Nn + BM - 1) / BM);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrow * ncol)), dim3(WM * WN * 64), lds, 0, neg, q, Nn, B, E, inv_T, fns, pos_ids,
+                       neg_ids, part, ncol);
+    hipLaunchKernelGGL(finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, 0, part, nrow, B, q, item, E, inv_T, lse);
+}
+
+}  // namespace
+
+int main() {
+    const int E = 128;
+    const float inv_T = 1.f / 0.05f, fns = -655.04f;
+    {  // ---- correctness at a small, ragged size -------------------------------------------------------------------------
+        const int B = 1000;
+        const int64_t Nn = 2100;
+        float* q = dev_rand((size_t)B * E, 1, 0.09f);
+        float* item = dev_rand((size_t)B * E, 2, 0.09f);
+        float* neg = dev_rand((size_t)Nn * E, 3, 0.09f);
+        int* pid = dev_ids(B, 4, 500);
+        int* nid = dev_ids(Nn, 5, 500);
+        float2* part;
+        float *l0, *l1;
+        CK(hipMalloc(&part, (size_t)((Nn + BM - 1) / BM) * B * sizeof(float2)));
+        CK(hipMalloc(&l0, B * 4));
+        CK(hipMalloc(&l1, B * 4));
+        for (int mask = 0; mask < 2; ++mask) {
+            hipLaunchKernelGGL(naive_kernel, dim3((B + 63) / 64), dim3(64), 0, 0, q, item, neg, B, Nn, E, inv_T, fns,
+                               mask ? pid : nullptr, mask ? nid : nullptr, l0);
+            if (mask) run_tiled<true>(neg, q, item, Nn, B, E, inv_T, fns, pid, nid, part, l1);
+            else run_tiled<false>(neg, q, item, Nn, B, E, inv_T, fns, nullptr, nullptr, part, l1);
+            CK(hipDeviceSynchronize());
+            std::vector<float> a(B), b(B);
+            CK(hipMemcpy(a.data(), l0, B * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), l1, B * 4, hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (int i = 0; i < B; ++i) worst = fmax(worst, fabs((double)a[i] - b[i]));
+            printf("check B=%d Nn=%lld mask=%d: max |lse - naive| = %.3g (%s)\n", B, (long long)Nn, mask, worst,
+                   worst < 1e-4 ? "ok" : "MISMATCH");
+        }
+    }
+    {  // ---- the headline shape ---------------------------------------------------------------------------------------------
+        const int B = 32768;
+        const int64_t Nn = 32768;
+        float* q = dev_rand((size_t)B * E, 11, 0.09f);
+        float* item = dev_rand((size_t)B * E, 12, 0.09f);
+        float* neg = dev_rand((size_t)Nn * E, 13, 0.09f);
+        int* pid = dev_ids(B, 14, 1000000);
+        int* nid = dev_ids(Nn, 15, 1000000);
+        float2* part;
+        float* lse;
+        CK(hipMalloc(&part, (size_t)((Nn + BM - 1) / BM) * B * sizeof(float2)));
+        CK(hipMalloc(&lse, B * 4));
+        for (int mask = 0; mask < 2; ++mask) {
+            auto f = [&]() {
+                if (mask) run_tiled<true>(neg, q, item, Nn, B, E, inv_T, fns, pid, nid, part, lse);
+                else run_tiled<false>(neg, q, item, Nn, B, E, inv_T, fns, nullptr, nullptr, part, lse);
+            };
+            hipEvent_t a, b;
+            CK(hipEventCreate(&a));
+            CK(hipEventCreate(&b));
+            for (int i = 0; i < 3; ++i) f();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(a));
+            const int iters = 10;
+            for (int i = 0; i < iters; ++i) f();
+            CK(hipEventRecord(b));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            ms /= iters;
+            const double tf = 2.0 * B * Nn * E / ms * 1e-9;
+            printf("tiled scorer forward %d x %lld x %d mask=%d: %8.1f us  %6.1f TF  (%.3f of 157.3)\n", B, (long long)Nn, E, mask,
+                   ms * 1e3, tf, tf / 157.3);
+        }
+    }
+    return 0;
+}
