@@ -68,6 +68,24 @@ if not which or "embbwd" in which:
     idb = [torch.randint(0, 50_000_000, (B * 8,), dtype=torch.int32, device=dev)]
     outl = torch.empty(B * 8, 1, D, device=dev)
     timeit("gather fwd, one 12.8 GB table, 512K ids", lambda: ops.embedding_gather([big], idb, out=outl), nbytes=B * 8 * (2 * D * 4 + 4))
+if "embada" in which or "embsgd" in which:  # ONE optimizer, C2 shapes: the selection the isolated rocprofv3 traces are taken on
+    from models_amd.synthetic import CRITEO_CARDINALITIES
+
+    tabs = [torch.rand(v, D, device=dev) for v in CRITEO_CARDINALITIES]
+    st = [torch.full_like(t, 0.1) for t in tabs]
+    ids = [torch.randint(0, v, (B,), dtype=torch.int32, device=dev) for v in CRITEO_CARDINALITIES]
+    grad = torch.randn(B, F, D, device=dev)
+    offs = [i * D for i in range(26)]
+    if "embada" in which:
+        timeit("embedding bwd adagrad (26 tables)", lambda: ops.embedding_gather_backward(tabs, st, ids, grad, offs, "adagrad", 0.01, 1e-7))
+    else:
+        timeit("embedding bwd sgd (26 tables)", lambda: ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", 0.01, 1e-7))
+if "emb1m" in which:
+    tabs = [torch.rand(1_000_000, D, device=dev) for _ in range(26)]
+    ids = [torch.randint(0, 1_000_000, (B,), dtype=torch.int32, device=dev) for _ in range(26)]
+    grad = torch.randn(B, F, D, device=dev)
+    offs = [i * D for i in range(26)]
+    timeit("embedding bwd sgd, 26 x 1M-row tables", lambda: ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", 0.01, 1e-7))
 if "fused" in which:
     from models_amd.synthetic import CRITEO_CARDINALITIES
 
