@@ -384,6 +384,17 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
 int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* relevant_counts, int64_t B,
                         int32_t k, float* out, mh_stream_t stream);
 
+/* ---- log-uniform (Zipfian) candidate sampler (outputs/sampling/popularity.py:118-137 ->
+ * tf.random.log_uniform_candidate_sampler(range_max, num_sampled, unique)) -------------------------------------
+ * out_ids[i] = min_id + k_i with P(k) = (log(k + 2) - log(k + 1)) / log(range_max + 1), k in [0, range_max).
+ * Draw j of call c is a pure function of (seed, c, j) (Philox4x32-10; u = 53 bits; k = floor(exp(u log(range_max + 1))) - 1):
+ * unique = 0: out_ids[i] = draw i; unique != 0: the first n DISTINCT draws in draw order (what the rejection loop of the
+ * TF sampler returns; needs n <= range_max).  rng_state: DEVICE uint64[2] = {seed, calls}; the kernel bumps `calls`, so a
+ * replayed hipGraph samples anew each time.  Asynchronous, no host synchronisation. */
+int64_t mh_log_uniform_sample_workspace_bytes(int64_t n, int32_t unique);
+int32_t mh_log_uniform_sample(int64_t range_max, int64_t min_id, int64_t n, int32_t unique, uint64_t* rng_state,
+                              int64_t* out_ids, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+
 /* ---- BinaryOutput head loss (outputs/classification.py:72-123): BCE on probabilities ----
  * p[M] = sigmoid output of the head, label[M] in {0,1}: loss[m] = keras binary_crossentropy
  * (clip p to [1e-7, 1-1e-7]); dlogit[m] = (p - label) * grad_scale (gradient w.r.t. the

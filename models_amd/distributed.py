@@ -247,8 +247,11 @@ class ShardedEmbeddingGroup:
         self.capacity_factor = float(capacity_factor)
         self.calibration = int(calibration)
         self.capacity: Optional[int] = None          # slots per (sender, owner) window once frozen
+        self._capacity_n = 0                         # request count the window was derived from
         self._steps, self._max_count = 0, 0
         self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.check_every = 64                        # fixed-window calls between two automatic overflow checks (0: never)
+        self._since_check = 0
 
     # ---- capacity management ------------------------------------------------------------------------------------
     def freeze_capacity(self, n_requests: int, capacity: Optional[int] = None) -> int:
@@ -262,6 +265,7 @@ class ShardedEmbeddingGroup:
                 seen = self._max_count if self._max_count else (n_requests + W - 1) // W
                 capacity = min(n_requests, int(seen * self.capacity_factor) + 1)
         self.capacity = (max(int(capacity), 1) + 63) // 64 * 64
+        self._capacity_n = int(n_requests)
         return self.capacity
 
     def check_overflow(self) -> None:
@@ -304,7 +308,18 @@ class ShardedEmbeddingGroup:
             slots, n_slots = list(range(F_sh)), F_sh
         if self.capacity is None and self.calibration <= 0:
             self.freeze_capacity(n)
-        if self.capacity is not None:   # ---- fixed windows: no host sync ----
+        # The window was sized for _capacity_n requests.  A call with MORE requests (evaluate / predict with a larger batch,
+        # a bigger train batch) would overflow it and silently drop requests: such a call takes the dense exchange (host-side
+        # counts, exact).  n is the same on every rank (equal per-rank batches -- the fixed all-to-all needs that anyway), so
+        # all ranks take the same branch.
+        fixed = self.capacity is not None and n <= self._capacity_n
+        if fixed and self.check_every > 0:
+            self._since_check += 1
+            capturing = send_capturing()
+            if self._since_check >= self.check_every and not capturing:
+                self._since_check = 0
+                self.check_overflow()  # one host read every check_every steps: a dropped request never goes unnoticed for long
+        if fixed:                       # ---- fixed windows: no host sync ----
             cap = self.capacity
             send_keys, pos_of, src_row, _ = self.route_fn(ids, W, slots, n_slots, cap, self.overflow)
             self._send_counts = self._recv_counts = None
@@ -321,7 +336,7 @@ class ShardedEmbeddingGroup:
             n_recv = sum(self._recv_counts)
             self._max_count = max(self._max_count, max(self._send_counts), max(self._recv_counts))
             self._steps += 1
-            if self._steps >= self.calibration:
+            if self.capacity is None and self._steps >= self.calibration:
                 if W > 1:  # every rank must choose the same window
                     m = torch.tensor([self._max_count], dtype=torch.int64, device=send_keys.device)
                     dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
@@ -415,6 +430,11 @@ class ShardedEmbeddingGroup:
 # ------------------------------------------------------------------------------------------------
 # dense gradients
 # ------------------------------------------------------------------------------------------------
+def send_capturing() -> bool:
+    """True while the current HIP stream is being captured into a graph (no host reads allowed then)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def allreduce_flat_(flat: torch.Tensor, group=None, async_op: bool = False):
     """In-place SUM of one flat fp32 bucket across ranks.  On RCCL: reduce-scatter + all-gather, so every xGMI
     link carries 1/W of the bucket per phase (needs ``numel % W == 0``; callers pad the bucket).
@@ -850,6 +870,7 @@ class _ShardedEmbeddings:
         last.update({n: inputs[n] for n in names})
         emb._last_all, emb._last_step = last, self.owner._step_token
         emb._last = last
+        emb._record_fwd_out(names, lambda n: out[:, slots[n]])
 
     def gather_concat(self, inputs, names, buf, offsets) -> None:
         """Concat layout (InputBlockV2): sharded features through their groups, the rest by the local gather."""
@@ -872,6 +893,7 @@ class _ShardedEmbeddings:
             grp.lookup_end(scatter=lambda back, pos, mine=mine: ops.embedding_gather(
                 [back] * len(mine), pos, out=buf, out_offset=[offsets[n] for n in mine]))
         emb._last = {n: inputs[n] for n in names}
+        emb._record_fwd_out(names, lambda n: buf[:, offsets[n]:offsets[n] + emb.feature_table[n].dim])
 
     def apply_sparse_now(self, opt, grad, offsets) -> None:
         from . import ops

@@ -204,10 +204,18 @@ class EmbeddingsBlock(ParallelBlock):
             if n not in onehot:
                 self.feature_table[n]._lookup(inputs[n], out=out[:, slots[n]])
         self._last = {n: inputs[n] for n in names}
-        for n in names:  # forward outputs the l2 batch regularisation needs in the backward
+        self._record_fwd_out(names, lambda n: out[:, slots[n]])
+
+    def _record_fwd_out(self, names, view) -> None:
+        """Forward output views of the features whose table carries an l2 batch regulariser (the backward adds
+        2 factor out to their gradient, embedding.py:463-464); ``view(n)`` = where feature n was written."""
+        if not self.has_batch_regularization:
+            return
+        kept = getattr(self, "_fwd_out", {})
+        for n in names:
             if self.feature_table[n].l2_batch_regularization_factor > 0:
-                self._fwd_out = getattr(self, "_fwd_out", {})
-                self._fwd_out[n] = out[:, slots[n]]
+                kept[n] = view(n)
+        self._fwd_out = kept
 
     def gather_concat(self, inputs: TabularData, names: Sequence[str], buf: torch.Tensor, offsets: Dict[str, int]) -> None:
         """One-hot feature ``n`` -> ``buf[:, offsets[n] : offsets[n] + dim]`` of a [B, W] concat buffer (the
@@ -215,6 +223,7 @@ class EmbeddingsBlock(ParallelBlock):
         ops.embedding_gather([self.feature_table[n].table.data for n in names], [inputs[n] for n in names], out=buf,
                              out_offset=[offsets[n] for n in names])
         self._last = {n: inputs[n] for n in names}
+        self._record_fwd_out(names, lambda n: buf[:, offsets[n]:offsets[n] + self.feature_table[n].dim])
 
     def prepare_sparse(self, inputs: TabularData, names: Sequence[str]) -> None:
         """Start the id-only half of the fused sparse update (segmented sort + piece list) NOW, on the "sort" side stream,

@@ -1198,6 +1198,20 @@ def dense_optimizer_step_multi(opt, params) -> None:
 TOPK_METRIC_NAMES = ("recall", "precision", "map", "dcg", "ndcg", "mrr")
 
 
+def log_uniform_sample(range_max: int, n: int, unique: bool, rng_state: torch.Tensor, min_id: int = 0) -> torch.Tensor:
+    """``n`` classes of the log-uniform (Zipfian) candidate sampler over ``[min_id, min_id + range_max)`` as int64 ``[n]``.
+    ``rng_state``: device int64 ``[2]`` = (seed, calls); the kernel advances ``calls`` (no host state, no host sync)."""
+    lib = _lib.load()
+    _dev(rng_state, "rng_state", torch.int64)
+    if rng_state.numel() != 2 or not rng_state.is_contiguous():
+        raise ValueError("rng_state must be a contiguous int64 tensor with 2 entries (seed, calls)")
+    out = torch.empty((int(n),), dtype=torch.int64, device=rng_state.device)
+    ws = _workspace(lib.mh_log_uniform_sample_workspace_bytes(int(n), int(bool(unique))), rng_state.device, "log_uniform")
+    check(lib.mh_log_uniform_sample(int(range_max), int(min_id), int(n), int(bool(unique)), _ptr(rng_state), _ptr(out), _ptr(ws),
+                                    ws.numel(), _stream()), "mh_log_uniform_sample")
+    return out
+
+
 def topk_metrics(labels_sorted: torch.Tensor, k: int, relevant_counts: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-query ranking metrics @k on pre-sorted labels -> [B, 6] (TOPK_METRIC_NAMES order)."""
     lib = _lib.load()

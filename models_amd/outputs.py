@@ -151,12 +151,12 @@ class ContrastiveOutput(Block):
         if self.logq_sampling_correction and len(self.negative_samplers) > 1:
             raise ValueError("It is only possible to apply logQ sampling correction "
                              "(logq_sampling_correction=True) when only one negative sampler is provided.")
-        candidates = []
+        candidates = []  # (sampler, its candidates): a sampler that returned nothing (an empty cache) is skipped WITH its slot
         for sampler in self.negative_samplers:
             neg = sampler(positive, features=features, training=training, testing=testing)
             positive = sampler.with_sampling_probs(positive)
             if neg is not None and neg.id is not None and neg.id.numel() > 0:
-                candidates.append(sampler.with_sampling_probs(neg))
+                candidates.append((sampler, sampler.with_sampling_probs(neg)))
         if not candidates:
             raise Exception(f"No negative items where sampled from samplers {self.negative_samplers}")
         return candidates, positive
@@ -173,7 +173,7 @@ class ContrastiveOutput(Block):
         positive = Candidate(positive_id.reshape(-1), dict(features or {})).with_embedding(positive_embedding)
         cands, positive = self.sample_negatives(positive, features, training=training, testing=testing)
         embs, ids, probs, n_in = [], [], [], 0
-        for sampler, c in zip(self.negative_samplers, cands):
+        for sampler, c in cands:
             if isinstance(sampler, InBatchSamplerV2):
                 if embs:
                     raise ValueError("the in-batch sampler must come first in negative_samplers")

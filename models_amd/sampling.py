@@ -10,7 +10,6 @@ sampling probabilities; scoring, the correction itself and the loss run in the f
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Sequence, Union
 
 import torch
@@ -105,7 +104,10 @@ class PopularityBasedSamplerV2(CandidateSampler):
     """Log-uniform (Zipfian) sampling of ``max_num_samples`` ids from ``[min_id, max_id)`` -- ids are assumed to be
     sorted by decreasing frequency -- with the sampling probabilities the logQ correction needs
     (outputs/sampling/popularity.py:24-199; the sampler is TensorFlow's ``log_uniform_candidate_sampler``:
-    P(k) = (log(k + 2) - log(k + 1)) / log(range_max + 1), drawn as floor(exp(u log(range_max + 1))) - 1)."""
+    P(k) = (log(k + 2) - log(k + 1)) / log(range_max + 1), drawn as floor(exp(u log(range_max + 1))) - 1).
+
+    The draw runs on the device (``mh_log_uniform_sample``: counter-based Philox draws, first-appearance dedup in a hash
+    set; the call counter is device state): no host loop, no host synchronisation, replayable from a hipGraph."""
 
     def __init__(self, max_id: int, min_id: int = 0, max_num_samples: int = 10, unique: bool = True,
                  seed: Optional[int] = None, name: Optional[str] = None):
@@ -113,9 +115,13 @@ class PopularityBasedSamplerV2(CandidateSampler):
         self.max_id, self.min_id, self.seed, self.unique = int(max_id), int(min_id), seed, bool(unique)
         assert self.max_num_samples <= self.max_id, (
             f"Number of items to sample `{self.max_num_samples}` should be less than total number of ids `{self.max_id}`")
-        self._gen = torch.Generator()
-        if seed is not None:
-            self._gen.manual_seed(int(seed))
+        if self.unique and self.max_num_samples > self.max_id - self.min_id:
+            raise ValueError(f"cannot draw {self.max_num_samples} unique ids from the {self.max_id - self.min_id} ids of "
+                             f"[{self.min_id}, {self.max_id})")
+        if seed is None:  # like an unseeded TF op: a fresh stream per sampler
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._seed = int(seed)
+        self._rng_state: Dict[torch.device, torch.Tensor] = {}  # device int64 [2] = (seed, calls so far)
         self.sampling_dist = self.get_sampling_distribution()
 
     def add(self, items: Candidate) -> None:
@@ -125,30 +131,18 @@ class PopularityBasedSamplerV2(CandidateSampler):
                 testing: bool = False) -> Candidate:
         return self.sample(device=None if positive_items is None else positive_items.id.device)
 
-    def _draw(self, n: int) -> torch.Tensor:
-        range_max = self.max_id - self.min_id
-        u = torch.rand(n, generator=self._gen, dtype=torch.float64)
-        k = torch.floor(torch.exp(u * math.log(range_max + 1.0))).to(torch.int64) - 1
-        return k.clamp_(0, range_max - 1)
-
     def sample(self, device=None) -> Candidate:
-        n = self.max_num_samples
-        if not self.unique:
-            ids = self._draw(n)
-        else:  # rejection until n distinct ids, in first-appearance order (what the TF sampler returns)
-            seen, out = set(), []
-            while len(out) < n:
-                for v in self._draw(max(2 * (n - len(out)), 16)).tolist():
-                    if v not in seen:
-                        seen.add(v)
-                        out.append(v)
-                        if len(out) == n:
-                            break
-            ids = torch.tensor(out, dtype=torch.int64)
-        ids = (ids + self.min_id).reshape(-1, 1)
-        if device is not None:
-            ids = ids.to(device)
-        return Candidate(ids, {})
+        from . import ops
+        from .inputs import default_device
+
+        device = torch.device(device) if device is not None else default_device()
+        if device.type != "cuda":
+            raise RuntimeError("PopularityBasedSamplerV2 draws on the GPU (mh_log_uniform_sample); there is no CPU path")
+        st = self._rng_state.get(device)
+        if st is None:
+            st = self._rng_state[device] = torch.tensor([self._seed, 0], dtype=torch.int64, device=device)
+        ids = ops.log_uniform_sample(self.max_id - self.min_id, self.max_num_samples, self.unique, st, self.min_id)
+        return Candidate(ids.reshape(-1, 1), {})
 
     def get_sampling_distribution(self) -> torch.Tensor:
         """Probability of every id under the sampler (popularity.py:139-166); with ``unique`` the probability of being
@@ -169,119 +163,105 @@ class PopularityBasedSamplerV2(CandidateSampler):
 
 
 class FIFOQueue(Block):
-    """Fixed-capacity FIFO storage over a ring buffer (blocks/sampling/queue.py:22-360): caches tensors (item
-    embeddings, item ids) across batches; when full, the oldest examples are overwritten."""
+    """Fixed-capacity first-in-first-out store of tensors across batches (the role of blocks/sampling/queue.py:22-360:
+    cached item embeddings / ids for cross-batch negatives; when full, the oldest entries are overwritten).
+
+    Design: ``storage`` is a device-resident ring.  Its state is two host integers -- ``_head`` (slot of the oldest
+    entry) and ``_size`` -- which move by amounts known on the host (the row count of what is enqueued / dequeued), so no
+    operation reads anything back from the device.  Every data movement is ONE indexed copy through modular slot numbers
+    ``(start + arange(n)) % capacity``; wrap-around is arithmetic, not a case distinction."""
 
     def __init__(self, capacity: int, dtype: torch.dtype, dims: Sequence[int] = (), queue_name: str = "",
                  initialize_tensor: Optional[torch.Tensor] = None, device=None, name: Optional[str] = None):
         assert capacity > 0
         super().__init__(name)
         self.capacity, self.queue_dtype, self.dims, self.queue_name = int(capacity), dtype, list(dims), queue_name
-        self.first_pointer = 0
-        self.next_available_pointer = 0
-        self.at_full_capacity = False
-        if initialize_tensor is None:  # -1: never a valid categorical value, so index_of() cannot match empty slots
-            initialize_tensor = torch.zeros([self.capacity] + self.dims, dtype=dtype, device=device) - 1
+        if initialize_tensor is None:
+            # -1 is never a valid categorical value: index_of() cannot match a slot that was never written
+            initialize_tensor = torch.full([self.capacity] + self.dims, -1, dtype=dtype, device=device)
         self.storage = initialize_tensor.clone()
+        self._head = 0
+        self._size = 0
+        self._lane = torch.arange(self.capacity, device=self.storage.device)  # 0 .. capacity - 1, reused by every slot range
 
-    def _check_input_values(self, values: torch.Tensor) -> None:
+    def _slots(self, start: int, n: int) -> torch.Tensor:
+        """Ring slots start, start + 1, ... (n of them, n <= capacity), wrapped."""
+        return (self._lane[:n] + start) % self.capacity
+
+    @property
+    def _tail(self) -> int:
+        return (self._head + self._size) % self.capacity
+
+    def _check_rows(self, values: torch.Tensor) -> None:
         assert values.dim() == len(self.dims) + 1, (
             "The rank of values (ignoring the first dim which is the number of examples) and self.dims should match")
         assert list(values.shape[1:]) == self.dims, (
             "The shape of values (ignoring the first dim which is the number of examples) and self.dims should match")
 
+    def _push(self, rows: torch.Tensor) -> None:
+        n = int(rows.shape[0])
+        if n > self.capacity:  # only the newest `capacity` rows can survive
+            rows, n = rows[n - self.capacity:], self.capacity
+        self.storage.index_copy_(0, self._slots(self._tail, n), rows.to(self.storage.dtype))
+        grown = self._size + n
+        self._head = (self._head + max(0, grown - self.capacity)) % self.capacity  # overwritten entries were the oldest
+        self._size = min(self.capacity, grown)
+
+    def _pop(self, n: int) -> torch.Tensor:
+        rows = self.storage.index_select(0, self._slots(self._head, n))
+        self._head = (self._head + n) % self.capacity
+        self._size -= n
+        return rows
+
     def enqueue(self, val: torch.Tensor) -> None:
         assert val.dim() == len(self.dims), "The rank of val and self.dims should match"
         assert list(val.shape) == self.dims, "The shape of val and self.dims should match"
-        self.storage[self.next_available_pointer] = val
-        self.next_available_pointer += 1
-        if self.next_available_pointer >= self.capacity:
-            self.next_available_pointer = 0
-        if self.at_full_capacity or self.next_available_pointer == self.first_pointer:
-            self.first_pointer = self.next_available_pointer
-            self.at_full_capacity = True
+        self._push(val.unsqueeze(0))
 
     def enqueue_many(self, vals: torch.Tensor) -> None:
-        self._check_input_values(vals)
-        vals = vals[-self.capacity:]
-        n = int(vals.shape[0])
-        start = self.next_available_pointer
-        end = start + n
-        if end < self.capacity:
-            self.storage[start:end] = vals
-            if self.at_full_capacity or (start < self.first_pointer and end >= self.first_pointer):
-                self.first_pointer = end
-                self.at_full_capacity = True
-        else:
-            over = end - self.capacity
-            self.storage[start:self.capacity] = vals[: n - over]
-            self.storage[0:over] = vals[n - over:]
-            end = over
-            if self.at_full_capacity or end >= self.first_pointer:
-                self.first_pointer = end
-                self.at_full_capacity = True
-        self.next_available_pointer = end
+        self._check_rows(vals)
+        self._push(vals)
 
     def dequeue(self) -> torch.Tensor:
-        if self.first_pointer == self.next_available_pointer and not self.at_full_capacity:
+        if self._size == 0:
             raise IndexError("The queue is empty")
-        self.at_full_capacity = False
-        val = self.storage[self.first_pointer].clone()
-        self.first_pointer += 1
-        if self.first_pointer >= self.capacity:
-            self.first_pointer = 0
-        return val
+        return self._pop(1)[0]
 
     def dequeue_many(self, n: int) -> torch.Tensor:
-        if self.first_pointer == self.next_available_pointer and not self.at_full_capacity:
+        if self._size == 0:
             raise IndexError("The queue is empty")
         if n <= 0:
             raise ValueError("The number of elements to dequeue must be greater than 0.")
-        n = min(n, self.count())
-        self.at_full_capacity = False
-        start, end = self.first_pointer, self.first_pointer + n
-        if end < self.capacity:
-            vals = self.storage[start:end].clone()
-        else:
-            missing = end - self.capacity
-            vals = torch.cat([self.storage[start:], self.storage[:missing]], 0)
-            end = missing
-        self.first_pointer = end
-        return vals
+        return self._pop(min(int(n), self._size))
 
     def list_all(self) -> torch.Tensor:
-        if self.first_pointer < self.next_available_pointer:
-            return self.storage[self.first_pointer:self.next_available_pointer]
-        if self.first_pointer == self.next_available_pointer and not self.at_full_capacity:
-            return self.storage[0:0]
-        return torch.cat([self.storage[self.first_pointer:], self.storage[:self.next_available_pointer]], 0)
+        """Every queued entry, oldest first."""
+        return self.storage.index_select(0, self._slots(self._head, self._size))
 
     def count(self) -> int:
-        if self.first_pointer < self.next_available_pointer:
-            return self.next_available_pointer - self.first_pointer
-        if self.at_full_capacity:
-            return self.capacity
-        if self.first_pointer == self.next_available_pointer:
-            return 0
-        return self.capacity - self.first_pointer + self.next_available_pointer
+        return self._size
+
+    @property
+    def at_full_capacity(self) -> bool:
+        return self._size == self.capacity
 
     def clear(self) -> None:
-        self.first_pointer, self.next_available_pointer, self.at_full_capacity = 0, 0, False
+        self._head = self._size = 0
 
     def index_of(self, ids: torch.Tensor) -> torch.Tensor:
-        """Index in the STORAGE of every id (first match), -1 if absent; integer queues of scalars only."""
+        """Slot in the STORAGE of every id (first match), -1 if absent; integer queues of scalars only."""
         assert not self.queue_dtype.is_floating_point, "The index_of method is only available for queues with an int dtype"
         assert self.dims == [], "The index_of method is only available for queues of scalars (dims=[])"
-        eq = (self.storage.reshape(1, -1) == ids.reshape(-1, 1)).to(torch.int32)
-        ext = torch.cat([torch.zeros((eq.shape[0], 1), dtype=torch.int32, device=eq.device), eq], 1)
-        return torch.argmax(ext, dim=1) - 1
+        hit = self.storage.reshape(1, -1) == ids.reshape(-1, 1).to(self.storage.dtype)
+        slot = torch.where(hit, self._lane.reshape(1, -1), self.capacity).amin(dim=1)  # smallest matching slot
+        return torch.where(slot < self.capacity, slot, -1)
 
     def get_values_by_indices(self, indices: torch.Tensor) -> torch.Tensor:
-        return self.storage[indices.long()]
+        return self.storage.index_select(0, indices.reshape(-1).long())
 
     def update_by_indices(self, indices: torch.Tensor, values: torch.Tensor) -> None:
-        self._check_input_values(values)
-        self.storage[indices.long()] = values
+        self._check_rows(values)
+        self.storage.index_copy_(0, indices.reshape(-1).long(), values.to(self.storage.dtype))
 
 
 class CachedCrossBatchSampler(CandidateSampler):
@@ -317,7 +297,8 @@ class CachedCrossBatchSampler(CandidateSampler):
             self._pending = None
         if training:
             if self.ignore_last_batch_on_sample:
-                self._pending = Candidate(items.id, {EMBEDDING_KEY: items.embedding})
+                # a snapshot: the caller's buffers are reused by the next step, and no gradient flows into the cache
+                self._pending = Candidate(items.id.detach().clone(), {EMBEDDING_KEY: items.embedding.detach().clone()})
             else:
                 self.add(items)
         return self.sample()

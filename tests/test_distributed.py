@@ -430,3 +430,39 @@ def test_sharded_table_construction_matches_slices_of_the_full_table():
     finally:
         inputs._SHARD_CTX = None
         inputs._INIT_CHUNK = old
+
+
+def test_fixed_windows_do_not_drop_requests_of_a_larger_batch():
+    """Round-2 advisor finding: the per-owner window is frozen for the request count of the calibration steps; a later call
+    with MORE requests (evaluate / predict with a larger batch) must not lose any -- it takes the dense exchange."""
+    g = torch.Generator().manual_seed(3)
+    fulls = [torch.randn(v, 8, generator=g) for v in (301, 57)]
+
+    def gather_fn(table, rows):  # rows -1 (window padding) read as zero rows, like the HIP gather
+        out = table[rows.clamp(min=0)]
+        out[rows < 0] = 0
+        return out
+
+    grp = D.ShardedEmbeddingGroup(fulls, gather_fn, _update_fn, calibration=0)
+    B = 64
+    ids = [torch.randint(0, t.shape[0], (B,), generator=g) for t in fulls]
+    rows = grp.lookup(ids)
+    assert grp.capacity is not None and grp._capacity_n == 2 * B  # frozen by the first call (one rank: no calibration)
+    for f in range(2):
+        torch.testing.assert_close(rows[f], fulls[f][ids[f]])
+    big = [torch.randint(0, t.shape[0], (5 * B,), generator=g) for t in fulls]
+    rows = grp.lookup(big)                                          # 5x the requests the window was sized for
+    for f in range(2):
+        torch.testing.assert_close(rows[f], fulls[f][big[f]])       # every request answered, none zeroed
+    grp.check_overflow()
+    small = [i[:10] for i in ids]
+    rows = grp.lookup(small)                                        # a smaller batch still fits the fixed window
+    for f in range(2):
+        torch.testing.assert_close(rows[f], fulls[f][small[f]])
+    grp.check_every = 2                                             # the periodic check reads the flag by itself
+    grp.overflow.fill_(1)
+    import pytest
+
+    with pytest.raises(RuntimeError, match="overflowed"):
+        for _ in range(3):
+            grp.lookup(small)

@@ -179,6 +179,40 @@ def test_l2_batch_regularization_through_dlrm_train_step():
     torch.testing.assert_close(Wb0 - emb.feature_table["b"].table.data, gb, atol=1e-5, rtol=1e-5)
 
 
+def test_l2_batch_regularization_through_the_concat_layout():
+    """The same regulariser on the InputBlockV2 route (DCN / MLP / two-tower inputs): one-hot features gathered straight into
+    the [B, W] concat buffer (gather_concat) -- round-2 advisor finding: that path did not record the forward views."""
+    import models_amd as mm
+    from models_amd import schema as S
+    from models_amd.optim import SGD
+
+    dev = _dev()
+    torch.manual_seed(1)
+    lam = 0.02
+    cols = [S.categorical("a", 30), S.categorical("b", 50)]
+    emb = mm.Embeddings(mm.Schema(cols), dim=8, device=dev, l2_batch_regularization_factor={"b": lam}, aggregation=None)
+    B = 96
+    g = torch.Generator().manual_seed(4)
+    for _ in range(2):  # twice: the second step must use THIS step's forward views, not the first one's
+        x = {"a": torch.randint(0, 30, (B,), generator=g).to(dev), "b": torch.randint(0, 50, (B,), generator=g).to(dev)}
+        Wa0 = emb.feature_table["a"].table.data.clone()
+        Wb0 = emb.feature_table["b"].table.data.clone()
+        buf = torch.empty(B, 20, device=dev)  # [a | 4 floats of something else | b]
+        offs = {"a": 0, "b": 12}
+        emb.gather_concat(x, ["a", "b"], buf, offs)
+        torch.testing.assert_close(buf[:, 12:20], Wb0[x["b"]])
+        up = torch.randn(B, 20, generator=g).to(dev)
+        emb.set_pending_grad(up.clone(), offs)
+        emb.apply_sparse(SGD(learning_rate=1.0))
+        out_b = Wb0[x["b"]]
+        want_loss = lam * float((out_b.double() ** 2).sum())
+        assert abs(float(emb.regularization_loss()[0]) - want_loss) < 1e-4 * max(1.0, want_loss)
+        ga = torch.zeros_like(Wa0).index_add_(0, x["a"], up[:, 0:8])
+        gb = torch.zeros_like(Wb0).index_add_(0, x["b"], up[:, 12:20] + 2 * lam * out_b)
+        torch.testing.assert_close(Wa0 - emb.feature_table["a"].table.data, ga, atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(Wb0 - emb.feature_table["b"].table.data, gb, atol=1e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("optimizer", ["adagrad", "adam"])
 @pytest.mark.parametrize("idt", [torch.int32, torch.int64])
 def test_shared_table_onehot_and_list_take_one_optimizer_step(optimizer, idt):
