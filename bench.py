@@ -148,18 +148,23 @@ class Timing:
         return self.max_over_ranks(time.perf_counter() - t0)
 
 
-def run_steps(step, args, tm: Timing):
-    """warmup, the K timed steps of the contract, a sustained region of >= --sustain seconds, and the per-step
-    hipEvent distribution (median, p10 / p90)."""
+def run_sustained(step, seconds, per_step_s, tm: Timing, min_steps=1):
+    """The same step repeated for >= `seconds` (barrier + synchronize on both sides, MAX over ranks)."""
+    if seconds <= 0:
+        return None
+    n_s = int(min(max(min_steps, math.ceil(seconds / max(per_step_s, 1e-6))), 200_000))
+    ds = tm.timed(step, n_s, 0)
+    return {"steps": n_s, "seconds": ds, "ms_per_step": ds / n_s * 1e3}
+
+
+def run_steps(step, args, tm: Timing, sustain_now=True):
+    """warmup, the K timed steps of the contract, (unless deferred to the end of the run) a sustained region of
+    >= --sustain seconds, and the per-step hipEvent distribution (median, p10 / p90)."""
     for i in range(args.warmup):
         step(i)
     dt = tm.timed(step, args.steps, args.warmup)
     per = dt / max(args.steps, 1)
-    n_s = int(min(max(args.steps, math.ceil(args.sustain / max(per, 1e-6))), 200_000)) if args.sustain > 0 else 0
-    sustained = None
-    if n_s:
-        ds = tm.timed(step, n_s, args.warmup + args.steps)
-        sustained = {"steps": n_s, "seconds": ds, "ms_per_step": ds / n_s * 1e3}
+    sustained = run_sustained(step, args.sustain, per, tm, args.steps) if sustain_now else None
     n_ev = min(max(args.steps, 1), 100)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for i, (a_ev, b_ev) in enumerate(evs):
@@ -389,22 +394,30 @@ def run_gather_cold(device, D=64, rows=50_000_000, n_ids=524_288, iters=20):
 
 
 def run_hbm_copy_peak(device, nbytes=1 << 30, iters=10):
-    """the box's own streaming rate beside the 8 TB/s spec peak -- a device-to-device copy of 1 GiB (torch's copy
-    kernel, read + write counted), hipEvent-timed.  Context for every `frac` of the line; not a kernel of this library."""
+    """the box's own streaming rates beside the 8 TB/s spec peak, hipEvent-timed, read + write counted:
+    the library's float4 copy kernel (mh_stream_copy; the guide measures 6.29 TB/s with such a kernel) and, for reference,
+    torch's device-to-device copy.  Context for every `frac` of the line."""
+    from models_amd import ops
+
     src = torch.empty(nbytes, dtype=torch.uint8, device=device).fill_(1)
     dst = torch.empty_like(src)
-    for _ in range(2):
-        dst.copy_(src)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        dst.copy_(src)
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / iters
-    gbps = 2 * nbytes / (ms * 1e-3) / 1e9
-    return {"shape": f"device-to-device copy of {nbytes >> 20} MiB, read + write", "ms": ms, "GBps": gbps,
-            "frac_of_peak": gbps / HBM_PEAK_GBS}
+
+    def rate(fn):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+        return ms, 2 * nbytes / (ms * 1e-3) / 1e9
+
+    ms_k, gb_k = rate(lambda: ops.stream_copy(src, dst))
+    ms_t, gb_t = rate(lambda: dst.copy_(src))
+    return {"shape": f"{nbytes >> 20} MiB copied, read + write counted", "kernel": "stream_copy_kernel (mh_misc.hip): float4, 4 loads in flight",
+            "ms": ms_k, "GBps": gb_k, "frac_of_peak": gb_k / HBM_PEAK_GBS, "torch_d2d_copy_GBps": gb_t, "spec_peak_GBps": HBM_PEAK_GBS}
 
 
 def run_cross_gemm(device, M=65536, d=3344, iters=4):
@@ -484,7 +497,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--tt-batch", type=int, default=32768, help="TwoTower batch per GPU (BASELINE configs[2])")
     ap.add_argument("--batches", type=int, default=8, help="distinct pre-generated batches rotated through the timed loop")
-    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of the additional sustained region (0 = off)")
+    ap.add_argument("--sustain", type=float, default=5.0,
+                    help="seconds of the additional sustained region, the LAST thing the run does (0 = off)")
     ap.add_argument("--mode", choices=["fwd", "train"], default="train",
                     help="train = fwd + loss + bwd + optimizer update (the reference's fit() throughput)")
     ap.add_argument("--optimizer", choices=["sgd", "adagrad", "adam"], default="adagrad")
@@ -583,19 +597,33 @@ def main():
                 step, graphed = eager_step, None
         except Exception as e:  # noqa: BLE001 -- the replayed graph stays the timed mode
             launch_probe = {"error": f"{type(e).__name__}: {e}"}
-    dt, sustained, step_stats = run_steps(step, args, tm)
+    dt, _, step_stats = run_steps(step, args, tm, sustain_now=False)  # the sustained region runs LAST (below)
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
     if hasattr(runner, "check_overflow"):
         runner.check_overflow()  # one host read, outside the timed regions: no request of the run was dropped
+    def sustained_last():
+        # the long steady region is the last GPU work of the run (every rank takes part), >= --sustain seconds: what the
+        # driver's utilisation sampler sees, and a second reading of the step time
+        for i in range(5):
+            step(i)
+        sd = run_sustained(step, args.sustain, dt / max(args.steps, 1), tm, args.steps)
+        return None if not sd else dict(sd, value=world * args.batch * sd["steps"] / sd["seconds"])
+
     if rank != 0:
+        sustained_last()
         return finish({})
 
     B = args.batch
-    try:  # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.sh; not re-measured live)
+    # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py: rocprofv3 cannot run inside this process).
+    # The file is stamped with the hash of the kernel sources it was taken with: figures of other kernels are refused.
+    from models_amd.build import source_hash
+
+    try:
         pmc = json.load(open(ROOT / "profiles" / "pmc_traffic.json"))
     except Exception:  # noqa: BLE001
         pmc = {}
-    pmc_ok = B == 65536 and args.ids == "uniform" and not args.extra_table_rows and not sharded
+    pmc_fresh = pmc.get("source_hash") == source_hash()
+    pmc_ok = pmc_fresh and B == 65536 and args.ids == "uniform" and not args.extra_table_rows and not sharded
 
     def dedup_aware(rl):
         """SURVEY 8d prices the embedding backward at 5 row passes per LOOKED-UP row (duplicates counted as if unique).
@@ -628,8 +656,10 @@ def main():
 
     def traffic(name):
         t = pmc.get(name, {}).get("traffic_bytes") if pmc_ok else None
-        return t, ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 per the "
-                   "guide's gfx950 correction)" if t else None)
+        if t:
+            return t, ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 per the "
+                       f"guide's gfx950 correction), taken with these kernel sources (hash {source_hash()[:12]})")
+        return None, (None if pmc_fresh or not pmc else "profiles/pmc_traffic.json is stale (taken with other kernel sources): not used")
 
     kernels = {"embedding_gather": "gather_fwd_kernel (mh_embedding.hip)",
                "embedding_bwd": "mh_embedding_gather_bwd: key build + radix sort + piece list + piece_reduce_apply_kernel (dominant): ONE C-ABI launch",
@@ -652,7 +682,7 @@ def main():
                    "launch_probe": launch_probe, "distinct_batches": nb,
                    "input_staging": "next batch copied into the static inputs inside the timed step (2 device copies)",
                    "parallelism": f"dp{world}" + (" + row-sharded tables (all-to-all)" if sharded else "")},
-        "sustained": None if not sustained else dict(sustained, value=world * B * sustained["steps"] / sustained["seconds"]),
+        "sustained": None,
         "roofline": dedup_aware(hbm_roofline(km, dominant, kernels[dominant], *traffic(dominant))) if dominant else None,
         "roofline_gather": hbm_roofline(km, "embedding_gather", kernels["embedding_gather"], *traffic("embedding_gather")),
         "roofline_fused_fwd": hbm_roofline(km, "dlrm_fused_fwd", kernels["dlrm_fused_fwd"], *traffic("dlrm_fused_fwd")),
@@ -687,6 +717,7 @@ def main():
         got = model({k: v[:ns] for k, v in split(b0)[0].items()}).cpu().numpy()
         res["cpu_baseline"] = base
         res["max_abs_err_vs_oracle"] = float(np.abs(got - ref["prob"]).max())
+    res["sustained"] = sustained_last()
     finish(res)
 
 

@@ -384,6 +384,11 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
 int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* relevant_counts, int64_t B,
                         int32_t k, float* out, mh_stream_t stream);
 
+/* ---- measurement probe ("record a stream-copy peak on the box") -----------------------------------
+ * dst[0 .. bytes) = src[0 .. bytes) with a float4 grid-stride kernel (16-byte aligned, bytes % 16 == 0): the streaming
+ * rate a hand-written kernel reaches on this GPU, reported by bench.py beside the 8 TB/s spec peak. */
+int32_t mh_stream_copy(const void* src, void* dst, int64_t bytes, mh_stream_t stream);
+
 /* ---- log-uniform (Zipfian) candidate sampler (outputs/sampling/popularity.py:118-137 ->
  * tf.random.log_uniform_candidate_sampler(range_max, num_sampled, unique)) -------------------------------------
  * out_ids[i] = min_id + k_i with P(k) = (log(k + 2) - log(k + 1)) / log(range_max + 1), k in [0, range_max).

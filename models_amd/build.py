@@ -34,6 +34,18 @@ def _deps() -> list[Path]:
     return sources() + sorted(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "merlin_hip.h"]
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, the C-ABI header): stamps measurement files (profiles/pmc_traffic.json)
+    so that a figure taken with other kernels is recognised as stale."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in _deps():
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not LIB.exists():
         return True

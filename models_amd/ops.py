@@ -1198,6 +1198,17 @@ def dense_optimizer_step_multi(opt, params) -> None:
 TOPK_METRIC_NAMES = ("recall", "precision", "map", "dcg", "ndcg", "mrr")
 
 
+def stream_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """``dst[:] = src`` with the library's float4 copy kernel (measurement probe: the box's achievable streaming rate)."""
+    lib = _lib.load()
+    _dev(src, "src")
+    _dev(dst, "dst")
+    nbytes = src.numel() * src.element_size()
+    if not (src.is_contiguous() and dst.is_contiguous()) or dst.numel() * dst.element_size() != nbytes:
+        raise ValueError("stream_copy: contiguous tensors of equal byte size required")
+    check(lib.mh_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream()), "mh_stream_copy")
+
+
 def log_uniform_sample(range_max: int, n: int, unique: bool, rng_state: torch.Tensor, min_id: int = 0) -> torch.Tensor:
     """``n`` classes of the log-uniform (Zipfian) candidate sampler over ``[min_id, min_id + range_max)`` as int64 ``[n]``.
     ``rng_state``: device int64 ``[2]`` = (seed, calls); the kernel advances ``calls`` (no host state, no host sync)."""

@@ -38,7 +38,10 @@ def run_pass(seg, counter):
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
-    res = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, one counter per pass, one process per segment "
+    sys.path.insert(0, str(ROOT))
+    from models_amd.build import source_hash
+
+    res = {"source_hash": source_hash(), "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, one counter per pass, one process per segment "
                      "(tools/pmc_workload.py); counter units calibrated on a 1 GiB fill / 1 GiB sum", "launches_per_segment": N}
     raw = {}
     for seg in SEGMENTS:
