@@ -359,8 +359,7 @@ class ShardedEmbeddingGroup:
         self._prepared_update = None
         if self._rows is None or not self._rows.is_cuda or not ops.SIDE.active("sort"):
             return
-        side = ops.SIDE.fork("sort_sharded", keep=(self._rows,))
-        with torch.cuda.stream(side):
+        with ops.SIDE.on("sort_sharded", keep=(self._rows,)):
             self._prepared_update = ops.embedding_gather_backward_prepare([self.local], [self._rows], tag=":sharded")
 
     def lookup_end(self, scatter: Optional[Callable] = None) -> Optional[torch.Tensor]:
@@ -718,8 +717,7 @@ class DistributedDLRM:
             if gs is not None:
                 gs.prepare_update()
             if self.replicated:
-                side = ops.SIDE.fork("sort", keep=tuple(inputs[n] for n in self.replicated))
-                with torch.cuda.stream(side):
+                with ops.SIDE.on("sort", keep=tuple(inputs[n] for n in self.replicated)):
                     self._prep_rep = ops.embedding_gather_backward_prepare(
                         [emb.feature_table[n].table.data for n in self.replicated], [inputs[n] for n in self.replicated], tag=":rep")
         body._fused = True

@@ -1,4 +1,5 @@
-"""hipGraph capture of a whole hot-path step.
+"""hipGraph capture of a whole hot-path step: as ONE graph (``GraphedStep``) or as per-stream graph SEGMENTS replayed on
+several streams (``SegmentedStep``: the zero-host-work replay that keeps the eager step's side-stream overlap).
 
 The DLRM forward at batch 64 K is ~15 kernel launches of 10-150 us each: launched eagerly from
 Python the step is host-bound by an order of magnitude.  The step is a fixed launch sequence
@@ -75,5 +76,94 @@ class GraphedStep:
                     self.inputs[k].copy_(v, non_blocking=True)
         self.graph.replay()
         return self.output
+
+    __call__ = replay
+
+
+class SegmentedStep:
+    """``fn(static_inputs)`` recorded ONCE as a list of per-stream hipGraph segments (``ops.StepRecorder``: every
+    ``SIDE.on / mark / wait / join`` of the step cuts a segment and notes a dependency edge) and replayed by launching the
+    segments on real streams with events on the edges.
+
+    One graph of the whole step replays on ONE hardware queue (ROCm 7.2): no host work, no overlap.  Eager launches overlap
+    (sort beside the top MLP, dW beside dX, sparse apply beside the bottom-MLP backward) but need ~0.75 ms of Python per step.
+    A segmented step has both: ~10 graph launches + a few event operations of host work per step, the eager step's overlap.
+    Same interface as ``GraphedStep``."""
+
+    def __init__(self, fn: Callable, inputs, warmup: int = 3):
+        from . import ops
+
+        self.packed = None
+        if isinstance(inputs, PackedBatch):
+            self.packed = PackedBatch(inputs.tensors)
+            self.inputs = self.packed.tensors
+        else:
+            self.inputs = {k: v.clone() for k, v in inputs.items()}
+        self.fn = fn
+        for _ in range(warmup):  # eager, with the real side streams: builds lazy layers, sizes every workspace
+            fn(self.inputs)
+        torch.cuda.synchronize()
+        if ops.SIDE.recorder is not None:
+            raise RuntimeError("a step is already being recorded")
+        rec = ops.StepRecorder()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        ops.SIDE.recorder = rec
+        try:
+            with torch.cuda.stream(cap):
+                rec.begin()
+                try:
+                    self.output = fn(self.inputs)
+                finally:
+                    rec.finish()
+        finally:
+            ops.SIDE.recorder = None
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        self.segments = rec.segments
+        needed = {d for sg in self.segments for d in sg["deps"]}
+        self._events = {i: torch.cuda.Event() for i in needed}
+        self._side = {sg["stream"]: ops.SIDE.stream(sg["stream"]) for sg in self.segments if sg["stream"] != "main"}
+        self._skip = {i for i, sg in enumerate(self.segments) if sg.get("empty")}  # nothing captured: only their edges matter
+        self._first = True
+
+    @property
+    def n_segments(self) -> int:
+        return len(self.segments) - len(self._skip)
+
+    def replay(self, new_inputs=None):
+        if new_inputs is not None:
+            if self.packed is not None:
+                self.packed.copy_from(new_inputs)
+            else:
+                for k, v in new_inputs.items():
+                    self.inputs[k].copy_(v, non_blocking=True)
+        cur = torch.cuda.current_stream()
+        evs = self._events
+        for i, sg in enumerate(self.segments):
+            st = cur if sg["stream"] == "main" else self._side[sg["stream"]]
+            for d in sg["deps"]:
+                st.wait_event(evs[d])
+            if i not in self._skip:
+                if st is cur:
+                    self._launch(i, sg)
+                else:
+                    with torch.cuda.stream(st):
+                        self._launch(i, sg)
+            if i in evs:
+                evs[i].record(st)
+        self._first = False
+        # every side segment was joined by a later main segment of the step (SIDE.deferred() exits join): the launch stream
+        # is ordered after the whole step
+        return self.output
+
+    def _launch(self, i, sg) -> None:
+        if not self._first:
+            sg["graph"].replay()
+            return
+        try:  # first replay: a segment that captured nothing (two cuts in a row) may refuse to launch -- drop it
+            sg["graph"].replay()
+        except RuntimeError:
+            self._skip.add(i)
 
     __call__ = replay

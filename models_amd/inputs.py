@@ -238,8 +238,7 @@ class EmbeddingsBlock(ParallelBlock):
             return
         if not all(self._is_onehot(inputs[n]) for n in names) or self.has_batch_regularization:
             return
-        side = ops.SIDE.fork("sort", keep=tuple(inputs[n] for n in names))
-        with torch.cuda.stream(side):
+        with ops.SIDE.on("sort", keep=tuple(inputs[n] for n in names)):
             h = ops.embedding_gather_backward_prepare([ft.table.data for ft in fts], [inputs[n] for n in names])
         self._prepared = (tuple(names), h) if h is not None else None
 
@@ -281,8 +280,7 @@ class EmbeddingsBlock(ParallelBlock):
         self._pending = (grad, offsets)
         self._pending_event = None
         if ready and grad.is_cuda and ops.SIDE.active("sparse"):
-            self._pending_event = torch.cuda.Event()
-            self._pending_event.record()
+            self._pending_event = ops.SIDE.mark()
 
     def backward(self, grad):
         if isinstance(grad, dict):
@@ -298,10 +296,7 @@ class EmbeddingsBlock(ParallelBlock):
         ev = getattr(self, "_pending_event", None)
         self._pending_event = None
         if ev is not None and ops.SIDE.active("sparse"):
-            side = ops.SIDE.fork_after("sparse", ev, keep=(grad,) + tuple(self._last.values()))
-            if getattr(opt, "_wait_event", None) is not None:
-                side.wait_event(opt._wait_event)
-            with torch.cuda.stream(side):
+            with ops.SIDE.on("sparse", after=[ev, getattr(opt, "_wait_event", None)], keep=(grad,) + tuple(self._last.values())):
                 self._apply_sparse_now(opt, grad, offsets)
             ops.SIDE.maybe_join()
             return

@@ -165,11 +165,15 @@ class Model(Block):
         (tf/logging/callbacks.py:174-189): batch_size * steps / elapsed, first step discarded.
         Batches are ``inputs`` or ``(inputs, targets)`` (what ``models_amd.Loader`` yields; retrieval models take no
         targets).  ``graph=None``: when the step is a fixed launch sequence (dense inputs of one static shape, stateless
-        samplers) it is captured ONCE into a hipGraph and replayed with each batch copied into the static inputs --
+        samplers) it is captured ONCE (``graph.SegmentedStep``: per-stream hipGraph segments) and replayed with each batch copied
+        into the static inputs --
         eager Python dispatch costs ~3x the kernel time of a DLRM step; batches of another shape (the last partial
         one) run eagerly."""
-        from .graph import GraphedStep, PackedBatch
+        from .graph import GraphedStep, PackedBatch, SegmentedStep
 
+        # the fastest replay mode: per-stream graph segments keep the side-stream overlap of the eager step (one graph of the
+        # whole step replays on one hardware queue); without side streams the single graph is the same thing with fewer launches
+        Step = SegmentedStep if ops.SIDE.enabled else GraphedStep
         if self.optimizer is None:
             self.compile()
         history = {"loss": [], "examples_per_sec": []}
@@ -203,7 +207,7 @@ class Model(Block):
                     if graphed is None and (graph or step >= 1):  # step 0 runs eagerly: builds lazily-shaped layers
                         # warmup=0: step 0 already ran eagerly (layers built, kernels' LDS attributes set); a warm-up
                         # replay here would TRAIN on this batch several times
-                        graphed, sig = GraphedStep(eager, PackedBatch(d), warmup=0), this_sig
+                        graphed, sig = Step(eager, PackedBatch(d), warmup=0), this_sig
                     if graphed is not None and this_sig == sig:
                         last = graphed.replay(PackedBatch(d))
                     else:

@@ -78,13 +78,103 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _Marker:
+    """Record mode: the END of segment ``seg`` of a step being recorded (the role an event plays in an eager step)."""
+
+    __slots__ = ("seg",)
+
+    def __init__(self, seg: int):
+        self.seg = seg
+
+
+class StepRecorder:
+    """Records ONE step as a list of SEGMENTS -- maximal runs of launches on one logical stream -- each captured into its own
+    hipGraph, with the dependency edges between them; ``graph.SegmentedStep`` replays the list on real streams.
+
+    Why: a whole step captured into one hipGraph replays on ONE hardware queue (ROCm 7.2): no host work, but none of the overlap
+    the eager step gets from its side streams.  Launching ~10 small graphs on 3-4 streams with events between them keeps both:
+    host cost = a handful of graph launches, GPU overlap = the eager step's.  While recording, everything executes (is captured)
+    sequentially on the capture stream; ``SIDE.on / mark / wait / join`` cut segments and note edges instead of touching streams."""
+
+    def __init__(self):
+        self.segments = []      # [{"stream": name, "graph": CUDAGraph, "deps": [segment ids]}]
+        self._cur = None        # index of the segment being captured
+        self._stack = []        # logical stream names: "main" at the bottom, a side name while inside SIDE.on(...)
+        self._pending = {}      # side stream name -> its last segment (not yet joined by main)
+        self._last_on = {}      # logical stream -> last segment captured for it
+
+    # -- segment control ------------------------------------------------------------------------------------------------
+    def begin(self) -> None:
+        self._stack = ["main"]
+        self._open("main", [])
+
+    def finish(self) -> None:
+        self._close()
+
+    def _open(self, stream: str, deps) -> None:
+        g = torch.cuda.CUDAGraph()
+        deps = sorted({d for d in deps if d is not None and self.segments[d]["stream"] != stream})
+        self.segments.append({"stream": stream, "graph": g, "deps": deps})
+        self._cur = len(self.segments) - 1
+        self._last_on[stream] = self._cur
+        g.capture_begin()
+
+    def _close(self) -> int:
+        import warnings
+
+        i = self._cur
+        with warnings.catch_warnings(record=True) as caught:  # torch warns when a capture holds no node: two cuts in a row
+            warnings.simplefilter("always")
+            self.segments[i]["graph"].capture_end()
+        self.segments[i]["empty"] = any("Graph is empty" in str(w.message) for w in caught)
+        self._cur = None
+        return i
+
+    def _cut(self, extra_deps=()) -> int:
+        """End the current segment and continue on the same logical stream; returns the index of the ended segment."""
+        ended = self._close()
+        self._open(self._stack[-1], list(extra_deps))
+        return ended
+
+    # -- what SIDE forwards to ------------------------------------------------------------------------------------------
+    def mark(self) -> _Marker:
+        return _Marker(self._cut())
+
+    def wait(self, marker: _Marker) -> None:
+        self._cut([marker.seg])
+
+    def enter(self, name: str, after) -> None:
+        prev = self._close()
+        deps = [m.seg for m in after] if after else [prev]
+        self._stack.append(name)
+        self._open(name, deps)
+
+    def leave(self) -> None:
+        ended = self._close()
+        name = self._stack.pop()
+        self._pending[name] = ended
+        self._open(self._stack[-1], [])
+
+    def join(self, names=None) -> None:
+        names = list(self._pending) if names is None else [n for n in names if n in self._pending]
+        if not names:
+            return
+        deps = [self._pending.pop(n) for n in names]
+        self._cut(deps)
+
+
 class _SideStreams:
     """Independent work of one train step on extra HIP streams: the dW / db GEMMs of an MLP backward (stream
-    "dw") run beside the dX chain, the fused embedding backward (stream "sparse") beside the bottom-MLP backward.
-    Fork = the side stream waits for an event on the launch stream; join = the launch stream waits for the side
-    streams.  Tensors a side stream reads are kept alive until the join (the caching allocator would otherwise
-    hand their memory to later launch-stream kernels).  Used by eager steps only (see ``active``);
-    ``MERLIN_HIP_SIDE_STREAMS=0`` turns it off; the per-op timer of bench.py runs single-stream."""
+    "dw") run beside the dX chain, the fused embedding backward (stream "sparse") beside the bottom-MLP backward, the id-only
+    half of the sparse update (stream "sort") beside the top MLP.
+
+    ``with SIDE.on(name, after=..., keep=...):`` runs a block on side stream ``name`` -- ordered after everything enqueued so
+    far on the current stream, or after the given ``mark()``s; ``join`` makes the launch stream wait for the side streams.
+    Tensors a side stream reads are kept alive until the join (the caching allocator would otherwise hand their memory to
+    later launch-stream kernels).  Two modes: EAGER (real streams and events) and RECORD (a ``StepRecorder`` is installed:
+    the same calls cut the step into per-stream graph segments, replayed by ``graph.SegmentedStep``).  A step captured into
+    ONE graph gets neither (see ``active``).  ``MERLIN_HIP_SIDE_STREAMS=0`` turns it off; the per-op timer of bench.py runs
+    single-stream."""
 
     def __init__(self):
         import os
@@ -96,13 +186,15 @@ class _SideStreams:
         self._pending = set()
         self._keep = []
         self._defer = 0
+        self.recorder: Optional[StepRecorder] = None
 
     def active(self, kind: str = None) -> bool:
-        # not under hipGraph capture: ROCm 7 replays a captured graph on ONE hardware queue (measured: the kernel
+        # not under a plain hipGraph capture: ROCm 7 replays a captured graph on ONE hardware queue (measured: the kernel
         # trace of a replayed multi-branch step shows no overlap and the event nodes cost ~2 %), so side streams only
-        # pay in eager steps (the sharded multi-GPU step: 2.13 -> 2.01 ms at W = 1)
-        return (self.enabled and (kind is None or kind in self.kinds) and not TIMER.enabled and torch.cuda.is_available()
-                and not torch.cuda.is_current_stream_capturing())
+        # pay in eager steps and in recorded (segmented) steps
+        if not (self.enabled and (kind is None or kind in self.kinds) and not TIMER.enabled and torch.cuda.is_available()):
+            return False
+        return self.recorder is not None or not torch.cuda.is_current_stream_capturing()
 
     def stream(self, name: str):
         dev = torch.cuda.current_device()
@@ -112,20 +204,56 @@ class _SideStreams:
             self._streams[(dev, name)] = st
         return st
 
-    def fork(self, name: str, keep=()):
-        """Returns the side stream, ordered after everything enqueued so far on the current stream."""
-        st = self.stream(name)
-        st.wait_stream(torch.cuda.current_stream())
-        self._pending.add(st)
-        self._keep.extend(keep)
-        return st
+    # -- events ---------------------------------------------------------------------------------------------------------
+    def mark(self):
+        """An ordering point on the current stream: pass it to ``on(after=[...])`` or ``wait``."""
+        if self.recorder is not None:
+            return self.recorder.mark()
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
 
-    def fork_after(self, name: str, event, keep=()):
-        st = self.stream(name)
-        st.wait_event(event)
-        self._pending.add(st)
-        self._keep.extend(keep)
-        return st
+    def wait(self, marker) -> None:
+        """The current stream waits for ``marker``."""
+        if isinstance(marker, _Marker):
+            if self.recorder is None:
+                raise RuntimeError("a marker of a recorded step used outside its recording")
+            self.recorder.wait(marker)
+        else:
+            torch.cuda.current_stream().wait_event(marker)
+
+    class _On:
+        def __init__(self, owner, name, after, keep):
+            self.owner, self.name, self.after, self.keep = owner, name, after, keep
+            self._ctx = None
+
+        def __enter__(self):
+            o = self.owner
+            if o.recorder is not None:
+                o.recorder.enter(self.name, self.after)
+                return self
+            st = o.stream(self.name)
+            if self.after:
+                for ev in self.after:
+                    st.wait_event(ev)
+            else:
+                st.wait_stream(torch.cuda.current_stream())
+            o._pending.add(st)
+            o._keep.extend(self.keep)
+            self._ctx = torch.cuda.stream(st)
+            self._ctx.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self._ctx is not None:
+                return self._ctx.__exit__(*exc)
+            self.owner.recorder.leave()
+            return False
+
+    def on(self, name: str, after=None, keep=()):
+        """Context: the block's launches go to side stream ``name``, ordered after ``after`` (a list of ``mark()``s) or,
+        by default, after everything enqueued so far on the current stream."""
+        return _SideStreams._On(self, name, [a for a in (after or []) if a is not None], keep)
 
     def retire(self, buf) -> None:
         """A workspace being replaced: keep it alive until the next join if any side stream has work in flight."""
@@ -133,6 +261,9 @@ class _SideStreams:
             self._keep.append(buf)
 
     def join(self) -> None:
+        if self.recorder is not None:
+            self.recorder.join()
+            return
         if self._pending:
             cur = torch.cuda.current_stream()
             for st in self._pending:
@@ -142,6 +273,9 @@ class _SideStreams:
 
     def join_stream(self, name: str) -> None:
         """The current stream waits for ONE side stream (its kept tensors stay alive until the full join)."""
+        if self.recorder is not None:
+            self.recorder.join([name])
+            return
         st = self._streams.get((torch.cuda.current_device(), name)) if torch.cuda.is_available() else None
         if st is not None and st in self._pending:
             torch.cuda.current_stream().wait_stream(st)
@@ -492,7 +626,6 @@ def dot_interaction(
 # backward / training ops
 # --------------------------------------------------------------------------------------------
 _WS = {}
-_DW_AFTER_DX = __import__("os").environ.get("MERLIN_HIP_DW_AFTER_DX", "1") != "0"
 
 
 def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
@@ -549,14 +682,8 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
             check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
                                              ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
                   "mh_linear_bias_act_bwd")
-        if _DW_AFTER_DX:
-            ev = torch.cuda.Event()
-            ev.record()
-            side = SIDE.fork_after("dw", ev, keep=(x, dy))
-        else:
-            side = SIDE.fork("dw", keep=(x, dy))
         ws = _workspace(nbytes, x.device, "linear_bwd_side")
-        with torch.cuda.stream(side):
+        with SIDE.on("dw", keep=(x, dy)):
             check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
                                              None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
                   "mh_linear_bias_act_bwd")
@@ -628,9 +755,7 @@ def embedding_gather_backward_prepare(tables: Sequence[torch.Tensor], ids: Seque
     rows = (C.c_int64 * F)(*[w.shape[0] for w in tables])
     check(lib.mh_embedding_gather_bwd_prepare(tab, rows, idp, idt, B, F, D, _ptr(ws), ws.numel(), _stream()),
           "mh_embedding_gather_bwd_prepare")
-    ev = torch.cuda.Event()
-    ev.record()
-    return PreparedSparseUpdate(ws, _sparse_key(tables, flat, B, D), ev)
+    return PreparedSparseUpdate(ws, _sparse_key(tables, flat, B, D), SIDE.mark())
 
 
 def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[Sequence[Optional[torch.Tensor]]],
@@ -673,7 +798,7 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_embedding_bwd_workspace_bytes failed")
     if prepared is not None and prepared.key == _sparse_key(tables, flat, B, D) and prepared.ws.numel() >= nbytes:
-        torch.cuda.current_stream().wait_event(prepared.event)
+        SIDE.wait(prepared.event)
         ws = prepared.ws
         with _timed("embedding_bwd_apply", nbytes=B * F * (_OPT_ROW_PASSES[optimizer] * D * 4 + flat[0].element_size())):
             check(

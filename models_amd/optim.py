@@ -44,8 +44,7 @@ class Optimizer:
         # prologue ran only now: a sparse update forked from an earlier event must also wait for it
         self._wait_event = None
         if late and self.lr_device is not None and ops.SIDE.active("sparse"):
-            self._wait_event = torch.cuda.Event()
-            self._wait_event.record()
+            self._wait_event = ops.SIDE.mark()
         with ops.SIDE.deferred():
             # sparse first: it leaves for its side stream (if the gradients were announced ready) and runs beside
             # the tail of the backward and the dense update below

@@ -479,10 +479,12 @@ def test_two_tower_v2_encoders_equal_v1_model(device):
     np.testing.assert_allclose(emb, v2.query_embeddings(batches[0]).cpu().numpy(), atol=1e-6)
 
 
-def test_graph_replayed_train_steps_equal_eager_steps(device):
-    """The headline number of bench.py is a hipGraph replay of the whole train step: replaying it on a sequence of
-    NEW batches must leave the model exactly where eager steps on the same batches leave it."""
-    from models_amd.graph import GraphedStep
+@pytest.mark.parametrize("mode", ["one_graph", "segmented"])
+def test_graph_replayed_train_steps_equal_eager_steps(device, mode):
+    """The headline number of bench.py is a replay of the captured train step -- ONE hipGraph, or the per-stream graph
+    segments of graph.SegmentedStep (what Model.fit uses): replaying it on a sequence of NEW batches must leave the model
+    exactly where eager steps on the same batches leave it."""
+    from models_amd.graph import GraphedStep, SegmentedStep
 
     cards = {"C1": 5000, "C2": 7, "C3": 300, "C4": 50}
     cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
@@ -512,7 +514,11 @@ def test_graph_replayed_train_steps_equal_eager_steps(device):
 
     static = dict(batches[0][0])
     static["__label__"] = batches[0][1]
-    gs = GraphedStep(step, static, warmup=2)  # warm-up steps DO train b: put it back to the initial state in place
+    gs = (GraphedStep if mode == "one_graph" else SegmentedStep)(step, static, warmup=2)  # warm-up steps DO train b: put it back to the initial state in place
+    if mode == "segmented":
+        streams = {sg["stream"] for sg in gs.segments}
+        assert {"main", "sort", "sparse"} <= streams and len(gs.segments) >= 5  # the step really was cut along its side streams
+        assert all(d < i for i, sg in enumerate(gs.segments) for d in sg["deps"])  # edges point backwards in launch order
     for pb, w in zip(b.parameters(), init):
         pb.data.copy_(w)
         for v in pb.state.values():
