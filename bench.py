@@ -443,6 +443,39 @@ def run_cross_gemm(device, M=65536, d=3344, iters=4):
             "tflops": tf, "frac_of_peak": tf / MFMA_F32_PEAK_TF}
 
 
+def run_c4_one_gpu(args, device, tm: Timing, rows=100_000_000, steps=20, warmup=5):
+    """BASELINE configs[3] on ONE GPU: configs[1] + one 100 M-row x 64 table (25.6 GB fp32 + 25.6 GB Adagrad accumulator; at
+    N = 8 it is row-sharded, 3.2 GB per GPU) -- fits the 288 GB of one MI355X, so the lookup / update of a table far beyond
+    every cache is measured here too.  Eager launches with side streams; the embedding backward's roofline of exactly this
+    configuration (27 lookups per sample)."""
+    from models_amd.graph import PackedBatch
+
+    model, _ = build_model(device, extra_rows=rows)
+    model.compile(optimizer=args.optimizer, learning_rate=0.01)
+    B = args.batch
+    batches = [PackedBatch(make_batch(device, B, 500 + i, "uniform", rows)) for i in range(4)]
+    split = lambda t: ({k: v for k, v in t.items() if k != "__label__"}, t["__label__"])
+    model(split(batches[0].tensors)[0])
+    step = lambda i: model.train_step(*split(batches[i % 4].tensors))
+    for i in range(warmup):
+        step(i)
+    dt = tm.timed(step, steps, warmup)
+    km = kernel_times(step, 4)
+    out = {"workload": f"BASELINE configs[3] on one GPU: DLRM configs[1] + one {rows}-row x 64 table, train ({args.optimizer}), B={B}",
+           "ms_per_step": dt / steps * 1e3, "value": B * steps / dt, "unit": "samples/s", "steps": steps,
+           "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
+    rl = hbm_roofline(km, "embedding_bwd", "mh_embedding_gather_bwd (27 tables incl. the 100 M-row one: three sort passes)")
+    if rl:
+        out["roofline"] = {k: rl[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "avg_launch_ms")}
+    for k in ("dlrm_fused_fwd", "dlrm_fused_bwd"):
+        r2 = hbm_roofline(km, k, k)
+        if r2:
+            out[f"roofline_{k}"] = {"achieved": r2["achieved"], "frac": r2["frac"], "avg_launch_ms": r2["avg_launch_ms"]}
+    del model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_dcn(args, device, tm: Timing):
     """BASELINE configs[4]: DCN-v2 depth 3 (d = 3341), emb_dim=128, deep [512, 256], B = 64 K per GPU, data-parallel."""
     from models_amd.graph import PackedBatch
@@ -560,6 +593,7 @@ def main():
                for i in range(max(args.batches, 1))]
     nb = len(batches)
     split = lambda t: ({k: v for k, v in t.items() if k != "__label__"}, t["__label__"])
+    split_xy = split
     model(split(batches[0].tensors)[0])  # builds the lazily-shaped dense layers
     runner = model
     if sharded:
@@ -616,6 +650,64 @@ def main():
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
     if hasattr(runner, "check_overflow"):
         runner.check_overflow()  # one host read, outside the timed regions: no request of the run was dropped
+    def sharded_report():
+        """N > 1 (and the forced one-rank run of the same code): the time split of the step with the phases serialised
+        (models_amd.distributed.PHASES), the bytes each rank sends per step against the xGMI peak, and a W = N forward against
+        the W = 1 numpy oracle on rank 0's first rows -- the rows fetched from their owners by plain indexing + all-reduce,
+        an independent path from the route kernels.  All outside the timed regions."""
+        import torch.distributed as dist
+
+        from models_amd.distributed import PHASES
+        from oracle import oracle as O
+
+        PHASES.start()
+        for i in range(5):
+            eager_step(i)
+        split = PHASES.stop()
+        xb = runner.exchange_bytes_per_step(args.batch)
+        rep = {"time_split_ms_serialised": {k: round(v, 4) for k, v in split.items()}, "bytes_sent_per_rank_per_step": xb,
+               "xgmi_peak_GBps_per_gpu": 7 * 153.0}
+        t_lookup = split.get("a2a_ids_route_owner_gather", 0.0) + split.get("a2a_rows_wait", 0.0)
+        if t_lookup > 0 and xb["a2a_rows"]:
+            rep["lookup_exchange_GBps_lower_bound"] = (xb["a2a_ids"] + xb["a2a_rows"]) / (t_lookup * 1e-3) / 1e9
+        t_ar = split.get("allreduce_issue", 0.0) + split.get("allreduce_wait", 0.0)
+        if t_ar > 0 and xb["allreduce"]:
+            rep["allreduce_GBps_lower_bound"] = xb["allreduce"] / (t_ar * 1e-3) / 1e9
+        # ---- W = N forward == W = 1 oracle ----
+        n = 256
+        b0 = batches[0].tensors
+        x0 = split_xy(b0)[0]
+        p = runner(x0)[:n]
+        body = model.body
+        W_, r_ = world, rank
+        compact, remap = {}, {}
+        for name in body.cat_names:
+            ids = x0[name][:n].reshape(-1).long().clone()
+            if W_ > 1:
+                dist.broadcast(ids, 0)
+            tab = body.embeddings.feature_table[name].table.data
+            if name in getattr(runner, "sharded_names", []):
+                mine = (ids % W_) == r_
+                rows = torch.zeros((n, tab.shape[1]), device=device)
+                rows[mine] = tab[(ids[mine] // W_)]
+                if W_ > 1:
+                    dist.all_reduce(rows)
+            else:
+                rows = tab[ids]
+            u, inv = np.unique(ids.cpu().numpy(), return_inverse=True)
+            first = np.zeros(len(u), dtype=np.int64)
+            first[inv] = np.arange(n)
+            compact[name] = rows.cpu().numpy()[first]
+            remap[name] = inv.reshape(-1, 1)
+        if rank == 0:
+            lay = lambda blk: [(l.kernel.numpy(), l.bias.numpy(), l.activation) for l in blk.layers]
+            hd = model.output.to_call
+            ref = O.dlrm_forward(remap, {k: x0[k][:n].cpu().numpy() for k in body.continuous.features}, compact,
+                                 lay(body.bottom_block), lay(body.top_block), (hd.kernel.numpy(), hd.bias.numpy()))
+            rep["max_abs_err_vs_w1_oracle"] = float(np.abs(p.cpu().numpy() - ref["prob"]).max())
+            rep["oracle_rows_checked"] = n
+        return rep
+
     def sustained_last():
         # the long steady region is the last GPU work of the run (every rank takes part), >= --sustain seconds: what the
         # driver's utilisation sampler sees, and a second reading of the step time
@@ -624,6 +716,12 @@ def main():
         sd = run_sustained(step, args.sustain, dt / max(args.steps, 1), tm, args.steps)
         return None if not sd else dict(sd, value=world * args.batch * sd["steps"] / sd["seconds"])
 
+    shard_rep = None
+    if sharded and args.mode == "train":
+        try:
+            shard_rep = sharded_report()  # collective: every rank runs it
+        except Exception as e:  # noqa: BLE001 -- a reporting extra must not cost the line
+            shard_rep = {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
         sustained_last()
         return finish({})
@@ -703,6 +801,7 @@ def main():
         "mfma": mfma_rates(km, [k for k in km if k.startswith("linear_")]),
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()},
         "step_ms": step_stats,
+        "sharded": shard_rep,
     }
     if world == 1 and not args.no_secondary and not args.extra_table_rows and not force:
         sec = {}
@@ -718,6 +817,8 @@ def main():
             sec["twotower_train"] = {k: tt[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline") if k in tt}
             tk = run_topk(args, device, steps=3, warmup=1)
             sec["topk"] = {k: tk[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline")}
+            if args.mode == "train":
+                sec["c4_one_gpu"] = run_c4_one_gpu(args, device, tm)
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             sec["error"] = f"{type(e).__name__}: {e}"
         res["secondary"] = sec

@@ -3,8 +3,13 @@ RCCL driven from ``libmerlin_hip.so`` itself, with host-known sizes only (hipGra
 
 ``Comm.create()`` builds the communicator of this process: the 128-byte RCCL id is made on rank 0 and travels over
 ``torch.distributed`` (any initialised backend; only used as the bootstrap channel) -- a host without torch would
-broadcast it over MPI or a TCP store, see INTEGRATION.md.  ``models_amd.distributed`` uses ``torch.distributed`` for the
-same exchange by default; ``MERLIN_HIP_COMM=rccl`` switches the row-sharded lookup to this path.
+broadcast it over MPI or a TCP store, see INTEGRATION.md.
+
+``default()`` is what ``models_amd.distributed`` uses on GPUs: the fixed-window all-to-alls of the row-sharded lookup and the
+dense-gradient bucket reduction go through this communicator (``Comm.alltoall_async`` / ``Comm.allreduce_async`` on a
+dedicated HIP stream, so that they overlap the caller's kernels like torch's async collectives do).  The communicator is
+verified once against ``torch.distributed`` on a small buffer when it is created; ``MERLIN_HIP_COMM=torch`` keeps the
+``torch.distributed`` calls instead (debugging).  CPU / gloo runs (the world-size-2 tests) never come here.
 """
 from __future__ import annotations
 
@@ -18,9 +23,91 @@ from ._lib import check
 from .ops import _dev, _host_ptr_array, _ids_dtype, _ptr, _stream, _workspace
 
 
+class _Work:
+    """Handle of a collective issued on the communicator's side stream: ``wait()`` orders the CURRENT stream behind it."""
+
+    def __init__(self, event, keep):
+        self.event, self.keep = event, keep
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+        self.keep = None
+
+
+_DEFAULT: Optional["Comm"] = None
+_DEFAULT_TRIED = False
+
+
+def default() -> Optional["Comm"]:
+    """The process-wide communicator for GPU runs under an initialised NCCL (= RCCL) process group, created and verified on
+    first use; None when the collectives should stay on ``torch.distributed`` (CPU / gloo, one rank, MERLIN_HIP_COMM=torch,
+    or a failed self-check -- reported once on stderr)."""
+    global _DEFAULT, _DEFAULT_TRIED
+    if _DEFAULT_TRIED:
+        return _DEFAULT
+    _DEFAULT_TRIED = True
+    import os
+    import sys
+
+    import torch.distributed as dist
+
+    if os.environ.get("MERLIN_HIP_COMM", "rccl") == "torch" or not torch.cuda.is_available():
+        return None
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or dist.get_backend() != "nccl":
+        return None
+    try:
+        c = Comm.create()
+        c.self_check()
+        _DEFAULT = c
+    except Exception as e:  # noqa: BLE001 -- the torch.distributed path is always available
+        print(f"[models_amd.comm] C-ABI communicator disabled ({type(e).__name__}: {e}); using torch.distributed", file=sys.stderr)
+        _DEFAULT = None
+    return _DEFAULT
+
+
 class Comm:
     def __init__(self, handle: C.c_void_p, rank: int, world: int):
         self.handle, self.rank, self.world = handle, rank, world
+        self._stream: Optional[torch.cuda.Stream] = None
+
+    def side_stream(self) -> torch.cuda.Stream:
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        return self._stream
+
+    def _async(self, fn, keep) -> _Work:
+        st = self.side_stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            fn()
+            ev = torch.cuda.Event()
+            ev.record()
+        return _Work(ev, keep)
+
+    def alltoall_async(self, send: torch.Tensor, recv: torch.Tensor) -> _Work:
+        """Equal-window all-to-all on the communicator's stream, ordered after the current stream's work so far."""
+        return self._async(lambda: self.alltoall(send, recv), (send, recv))
+
+    def allreduce_async(self, flat: torch.Tensor) -> _Work:
+        return self._async(lambda: self.allreduce_(flat), (flat,))
+
+    def self_check(self) -> None:
+        """One all-to-all and one all-reduce of a small buffer against torch.distributed (same RCCL underneath): a
+        communicator that disagrees must not carry gradients."""
+        import torch.distributed as dist
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        W, r = self.world, self.rank
+        send = (torch.arange(W * 64, device=dev, dtype=torch.float32) + 1000.0 * r).contiguous()
+        got, want = torch.empty_like(send), torch.empty_like(send)
+        self.alltoall(send, got)
+        dist.all_to_all_single(want, send)
+        red, red_t = send.clone(), send.clone()
+        self.allreduce_(red)
+        dist.all_reduce(red_t)
+        torch.cuda.synchronize()
+        if not (torch.equal(got, want) and torch.allclose(red, red_t, rtol=1e-6, atol=0)):
+            raise RuntimeError("self-check against torch.distributed failed")
 
     @classmethod
     def create(cls) -> "Comm":

@@ -284,6 +284,17 @@ class ShardedEmbeddingGroup:
         if self.world_size == 1:
             return inp, None
         out = torch.empty((n_out,) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
+        if out_splits is None and inp.is_cuda and self.group is None:
+            # fixed windows on GPUs: the collective behind the C ABI (mh_comm_alltoall: grouped ncclSend / ncclRecv)
+            from . import comm as _comm
+
+            c = _comm.default()
+            if c is not None:
+                work = c.alltoall_async(inp.contiguous(), out)
+                if not async_op:
+                    work.wait()
+                    work = None
+                return out, work
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
         return out, work
 
@@ -429,6 +440,61 @@ class ShardedEmbeddingGroup:
 # ------------------------------------------------------------------------------------------------
 # dense gradients
 # ------------------------------------------------------------------------------------------------
+class _Phases:
+    """Time split of a sharded step (SURVEY 8e "Reported": gather, a2a, MLP, interaction, allreduce).  Off by default
+    (``with phase(...)`` is then a no-op); ``PHASES.start()`` makes every phase synchronise the device on entry and exit
+    and accumulate its wall time -- phases then run one after the other, so the split shows what each part COSTS, not the
+    overlapped step time.  bench.py runs a few profiled steps after the timed region at N > 1."""
+
+    def __init__(self):
+        self.acc = None
+        self.steps = 0
+
+    def start(self) -> None:
+        self.acc, self.steps = {}, 0
+
+    def stop(self) -> Dict[str, float]:
+        acc, n = self.acc or {}, max(self.steps, 1)
+        self.acc = None
+        return {k: v / n * 1e3 for k, v in acc.items()}  # ms per step
+
+    class _Ctx:
+        def __init__(self, owner, name):
+            self.owner, self.name = owner, name
+
+        def __enter__(self):
+            import time
+
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+        def __exit__(self, *exc):
+            import time
+
+            torch.cuda.synchronize()
+            a = self.owner.acc
+            a[self.name] = a.get(self.name, 0.0) + time.perf_counter() - self.t0
+            return False
+
+    class _Null:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *exc):
+            return False
+
+    _NULL = _Null()
+
+    def __call__(self, name: str):
+        if self.acc is None or not torch.cuda.is_available():
+            return self._NULL
+        return _Phases._Ctx(self, name)
+
+
+PHASES = _Phases()
+phase = PHASES
+
+
 def send_capturing() -> bool:
     """True while the current HIP stream is being captured into a graph (no host reads allowed then)."""
     return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
@@ -442,6 +508,16 @@ def allreduce_flat_(flat: torch.Tensor, group=None, async_op: bool = False):
     if W == 1 or flat.numel() == 0:
         return []
     n = flat.numel()
+    if flat.is_cuda and group is None:  # GPUs: mh_allreduce_dense behind the C ABI (reduce-scatter + all-gather over RCCL)
+        from . import comm as _comm
+
+        c = _comm.default()
+        if c is not None:
+            work = c.allreduce_async(flat)
+            if async_op:
+                return [work]
+            work.wait()
+            return []
     if dist.get_backend(group) == "nccl" and n % W == 0:
         shard = torch.empty(n // W, dtype=flat.dtype, device=flat.device)
         works = [dist.reduce_scatter_tensor(shard, flat, group=group, async_op=async_op),
@@ -682,12 +758,15 @@ class DistributedDLRM:
         F, D = body.num_features, body.dim
         gs = self.group_sh
         if gs is not None:  # route first: the row all-to-all overlaps the bottom MLP
-            gs.lookup_begin([inputs[n] for n in self.sharded_names],
-                            layout=([body.slots[n] for n in self.sharded_names], F))
-        dense = mlp_forward(body.bottom_block.layers, body.continuous(inputs))
+            with phase("a2a_ids_route_owner_gather"):  # route build, ids all-to-all, owner-side gather, rows all-to-all issued
+                gs.lookup_begin([inputs[n] for n in self.sharded_names],
+                                layout=([body.slots[n] for n in self.sharded_names], F))
+        with phase("mlp_bottom_fwd"):
+            dense = mlp_forward(body.bottom_block.layers, body.continuous(inputs))
         got = {}
         if gs is not None:
-            gs.lookup_end(scatter=lambda back, pos: got.update(back=back, pos=pos))
+            with phase("a2a_rows_wait"):
+                gs.lookup_end(scatter=lambda back, pos: got.update(back=back, pos=pos))
         idt = inputs[body.cat_names[0]].dtype
         sh_index = {n: i for i, n in enumerate(self.sharded_names)}
         slot_tables, slot_ids = [], []
@@ -709,7 +788,8 @@ class DistributedDLRM:
         if ld != width:
             buf[:, width:].zero_()
         top_in = buf[:, :width]
-        ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
+        with phase("gather_interaction_fwd"):
+            ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
         self._prep_rep = None
         if training and ops.SIDE.active("sort"):
             # the id-only halves (sort + piece list) of BOTH sparse updates of the step start here, behind the HBM-bound
@@ -723,7 +803,8 @@ class DistributedDLRM:
         body._fused = True
         body._slots_ctx = (slot_tables, slot_ids, dense)  # keeps the returned rows alive for the backward's re-gather
         body._top_in = top_in
-        return body._top(top_in, head)
+        with phase("mlp_top_fwd"):
+            return body._top(top_in, head)
 
     def __call__(self, inputs):
         from .models import prepare_features
@@ -746,8 +827,11 @@ class DistributedDLRM:
         loss, dlogit = ops.bce(p, targets, need_grad=True)
         if self.world_size > 1:
             dlogit = dlogit / self.world_size
+        if PHASES.acc is not None:
+            PHASES.steps += 1
         with ops.SIDE.deferred():  # side work (dW GEMMs) is joined below, right before the bucket reads the gradients
-            body.backward(dlogit)  # head + top MLP + interaction; leaves (dstack, offsets) pending on the embeddings block
+            with phase("mlp_interaction_bwd"):
+                body.backward(dlogit)  # head + top MLP + interaction; leaves (dstack, offsets) pending on the embeddings block
             dstack, offsets = body.embeddings._pending
             body.embeddings._pending = None
             D = body.dim
@@ -761,8 +845,9 @@ class DistributedDLRM:
                 if opt.name == "adam" and gs.state is None:
                     gs.state, gs.state2 = torch.zeros_like(gs.local), torch.zeros_like(gs.local)
                 # starts the gradient all-to-all; it overlaps the replicated-table gradient pass below
-                gs.backward_begin(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
-                                                      lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
+                with phase("a2a_grads"):
+                    gs.backward_begin(None, from_stacked=(dstack, [body.slots[n] for n in self.sharded_names],
+                                                          lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]))
             # 2 + 3. ONE persistent flat bucket [MLP / head gradients | dense [V, D] gradients of the replicated
             #    tables]: the table part is zeroed by one fill and accumulated by the fused backward (SGD, lr = -1),
             #    the MLP part is packed by one cat; after the in-place reduction the gradients are VIEWS of the bucket
@@ -784,17 +869,21 @@ class DistributedDLRM:
                 bucket[n_head:n_head + n_rep].zero_()
                 # per FEATURE: features sharing a table pass the same gradient buffer and are summed into it
                 prep, self._prep_rep = getattr(self, "_prep_rep", None), None
-                ops.embedding_gather_backward([grad_of[id(emb.feature_table[n].table)] for n in self.replicated], None,
-                                              [x[n] for n in self.replicated], dstack,
-                                              [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0, prepared=prep)
+                with phase("replicated_table_grads"):
+                    ops.embedding_gather_backward([grad_of[id(emb.feature_table[n].table)] for n in self.replicated], None,
+                                                  [x[n] for n in self.replicated], dstack,
+                                                  [offsets[n] for n in self.replicated], "sgd", -1.0, 0.0, prepared=prep)
             ops.SIDE.join()  # the dW / db GEMMs ran on their side stream: the bucket below reads them
         # (packed at every world size, so that the single-GPU parity test walks the same code as an 8-GPU job)
         torch.cat([q.grad.reshape(-1) for q in dense] + [loss.detach().reshape(1)], out=bucket[:n_dense + 1])
-        works = allreduce_flat_(bucket, self.group, async_op=True)
+        with phase("allreduce_issue"):
+            works = allreduce_flat_(bucket, self.group, async_op=True)
         if self.group_sh is not None:
-            self.group_sh.backward_end()  # fused update of the local shards overlaps the bucket reduction
-        for w in works:
-            w.wait()
+            with phase("a2a_grads_wait_sharded_update"):
+                self.group_sh.backward_end()  # fused update of the local shards overlaps the bucket reduction
+        with phase("allreduce_wait"):
+            for w in works:
+                w.wait()
         loss = bucket[n_dense] / self.world_size
         o = 0
         for q in dense:
@@ -802,8 +891,23 @@ class DistributedDLRM:
             o += q.data.numel()
         for t, g in zip(rep_tabs, rep_grads):
             t.grad = g
-        ops.dense_optimizer_step_multi(opt, dense + rep_tabs)  # one launch per 64 tensors
+        with phase("dense_optimizer"):
+            ops.dense_optimizer_step_multi(opt, dense + rep_tabs)  # one launch per 64 tensors
         return loss
+
+    def exchange_bytes_per_step(self, batch: int) -> Dict[str, int]:
+        """Bytes this rank SENDS per train step: ids all-to-all, rows all-to-all, row-gradient all-to-all over the
+        fixed windows (padding included), and the dense bucket (reduce-scatter + all-gather: 2 (W - 1) / W of it)."""
+        W, gs = self.world_size, self.group_sh
+        out = {"a2a_ids": 0, "a2a_rows": 0, "a2a_grads": 0, "allreduce": 0}
+        if gs is not None and W > 1:
+            cap = gs.capacity if gs.capacity is not None else (len(self.sharded_names) * batch + W - 1) // W
+            D = gs.local.shape[1]
+            out["a2a_ids"] = (W - 1) * cap * 8
+            out["a2a_rows"] = out["a2a_grads"] = (W - 1) * cap * D * 4
+        if self._bucket is not None and W > 1:
+            out["allreduce"] = int(2 * (W - 1) / W * self._bucket.numel() * 4)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------
