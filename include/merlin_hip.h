@@ -141,6 +141,9 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
  * workspace: mh_embedding_bwd_workspace_bytes(B, F, D) bytes.  Limits: F < 64, B < 2^26, B*F < 2^31, D % 4 == 0,
  * D <= 1024.  Runs whose gradients fit one 16-entry piece are summed in sorted (sample) order -> reproducible;
  * hot rows spanning several pieces are combined with float atomics (order-dependent in the last bits). */
+/* Deterministic mode of the fused sparse update (process-wide; initial value from MERLIN_HIP_DETERMINISTIC=1 at load time):
+ * crossing runs are walked in sample order instead of summed with float atomics -- bit-reproducible, slower on very hot rows. */
+int32_t mh_set_deterministic(int32_t on);
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
                                 const int64_t* table_rows /*HOST [F]*/,

@@ -391,9 +391,6 @@ class DLRMBlock(Block):
             slot_ids = [None if k == "bottom_block" else inputs[k] for k in self.stack_order]
             self._slots_ctx = (slot_tables, slot_ids, dense)
             self.embeddings._last = {n: inputs[n] for n in self.cat_names}
-            sort_late = os.environ.get("MERLIN_HIP_SORT_AFTER_GATHER", "1") != "0"
-            if _TAPE[0] > 0 and not sort_late:
-                self.embeddings.prepare_sparse(inputs, self.cat_names)
             if self.top_block is None:
                 return ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=False)
             width = P + (D if dense is not None else 0)
@@ -403,7 +400,7 @@ class DLRMBlock(Block):
                 buf[:, width:].zero_()
             top_in = buf[:, :width]
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
-            if _TAPE[0] > 0 and sort_late:
+            if _TAPE[0] > 0:
                 # training, eager step: the id-only sort of the sparse update is forked HERE, behind the HBM-bound gather ->
                 # interaction kernel, so that it runs beside the MFMA-bound top MLP (a light, latency-bound partner for it)
                 # rather than competing with the gather for memory

@@ -874,10 +874,12 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
 // workspace); APPLY = the gradient-dependent part (segmented reduce + fused optimizer, carried runs)
 enum { PH_PREPARE = 1, PH_APPLY = 2, PH_ALL = 3 };
 
-bool deterministic_mode() {
+// MERLIN_HIP_DETERMINISTIC=1 at load time, or mh_set_deterministic() at run time (no getenv on the launch path)
+int g_deterministic = [] {
     const char* v = getenv("MERLIN_HIP_DETERMINISTIC");
-    return v && v[0] == '1';
-}
+    return (v && v[0] == '1') ? 1 : 0;
+}();
+bool deterministic_mode() { return g_deterministic != 0; }
 
 template <typename IdT, typename KeyT>
 int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbits, const WsLayout& L, char* ws, int64_t B, int F,
@@ -895,14 +897,8 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     // ---- 1. segmented stable LSD radix sort: digit width rbits per pass; a segment runs only the passes its own
     //         key bits need (sa.npass) and alternates buffers so that its last pass lands in buffer 1 ---------------------
     const int ntiles = sa.tile0[sa.nseg];
-    static const int fast = [] {
-        const char* v = getenv("MERLIN_HIP_SORT_FASTLOAD");
-        return (v && v[0] == '0') ? 0 : 1;
-    }();
-    static const int lean = [] {  // 0: separate clear kernel, scan re-reads the tile counts (A/B switch)
-        const char* v = getenv("MERLIN_HIP_SORT_LEAN");
-        return (v && v[0] == '0') ? 0 : 1;
-    }();
+    constexpr int fast = 1;  // pass 0 reads the id columns from a wave-uniform base (decided in round 2: 396 -> 385 us)
+    constexpr int lean = 1;  // pass 0 of the histogram kernel clears the carried rows; the scan keeps tile counts in registers
     for (int p = 0; (phases & PH_PREPARE) && p < npass; ++p) {
         const int shift = p * rbits;
         // pass 0 clears the carried rows (not accumulated into in deterministic mode) and the piece counter on the way
@@ -935,12 +931,8 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     }
     {
         // the group's lanes fetch and hand out a piece's sample indices (kernel comment) where a group is an aligned 16- / 32-lane
-        // part of a wavefront; MERLIN_HIP_PIECE_MODE=0 keeps the per-piece loads everywhere
-        static const bool piece_mode_on = [] {
-            const char* v = getenv("MERLIN_HIP_PIECE_MODE");
-            return !(v && v[0] == '0');
-        }();
-        const bool vmode = piece_mode_on && (LPR == 16 || LPR == 32);  // D = 64 / 128 (GPU-tested); 64-lane groups (D = 256) keep mode 0 until a test covers them
+        // part of a wavefront
+        const bool vmode = (LPR == 16 || LPR == 32);  // D = 64 / 128 (GPU-tested); 64-lane groups (D = 256) keep mode 0 until a test covers them
         auto kern = vmode ? piece_reduce_apply_kernel<1> : piece_reduce_apply_kernel<0>;
         int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
         static int resident[2] = {0, 0};  // workgroups per CU the kernel's register budget allows: exactly one resident wave
@@ -1062,6 +1054,11 @@ __global__ __launch_bounds__(256) void bag_expand_max_kernel(const float* __rest
 }  // namespace
 
 extern "C" {
+
+int32_t mh_set_deterministic(int32_t on) {
+    g_deterministic = on ? 1 : 0;
+    return MH_OK;
+}
 
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D) {
     if (B <= 0 || F <= 0 || D <= 0) return 0;

@@ -260,19 +260,14 @@ int32_t mh_fill_words(void* dst, uint32_t value, int64_t words, hipStream_t s) {
     return MH_OK;
 }
 
-// float4 grid-stride copy, four independent 16-byte loads in flight per lane: the streaming rate a hand-written kernel
-// reaches on this box (the "achievable" figure the HBM rooflines of the library are read against, beside the 8 TB/s spec)
+// float4 copy, ONE 16-byte element per thread, nontemporal on both sides, one workgroup per 4 KB: the streaming rate a
+// hand-written kernel reaches on this box -- the "achievable" figure the HBM rooflines of the library are read against,
+// beside the 8 TB/s spec.  tools/exp/copy_lab.hip measured the alternatives on a 1 GiB copy: this form 6.6 TB/s (6.25 without
+// the nontemporal hint), a workgroup-contiguous grid-stride loop with 4 loads in flight 5.9 TB/s, a whole-grid-stride loop
+// 4.3-5.2 TB/s, hipMemcpy D2D 5.1 TB/s -- on gfx950 the hardware workgroup dispatcher beats a persistent loop for streaming.
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a;
-        dst[i + stride] = b;
-        dst[i + 2 * stride] = c;
-        dst[i + 3 * stride] = d;
-    }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 extern "C" {
@@ -282,9 +277,8 @@ int32_t mh_stream_copy(const void* src, void* dst, int64_t bytes, mh_stream_t st
     MH_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "mh_stream_copy: 16-byte alignment required");
     if (bytes == 0) return MH_OK;
     const int64_t n4 = bytes / 16;
-    int64_t nb = mh_ceil_div(n4, 256 * 4);
-    const int64_t cap = (int64_t)mh_num_cus() * 8;
-    if (nb > cap) nb = cap;
+    const int64_t nb = mh_ceil_div(n4, 256);
+    MH_REQUIRE(nb < (1ll << 31), "mh_stream_copy: at most 2^31 workgroups of 4 KB");
     hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), static_cast<const f32x4*>(src),
                        static_cast<f32x4*>(dst), n4);
     MH_CHECK_LAUNCH("mh_stream_copy");

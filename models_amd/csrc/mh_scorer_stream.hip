@@ -547,10 +547,6 @@ __global__ __launch_bounds__(256) void unpad_rows_kernel(const float* __restrict
     dst[idx] = src[row * Ep + (idx - row * E)];
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 template <int MODE, int E, bool LSE_STREAM>
 int32_t launch_mode(const StreamArgs& a, int ids_dtype, dim3 grid, size_t lds, hipStream_t s) {
@@ -588,7 +584,7 @@ MhStreamPlan mh_stream_plan(int mode, int64_t Nx, int64_t Ny, int E, int ids_byt
     // forward: 64-row tiles (64 KB of LDS -> two workgroups per CU); gradient modes hold ~200 registers -> one
     // workgroup per CU anyway, so they take 128-row tiles (half as many barriers)
     const bool light = (mode == SM_FWD || mode == SM_FILTER);  // no second GEMM: ~110 registers, two workgroups per CU
-    p.bn = env_int(light ? "MERLIN_HIP_SCORER_BN_FWD" : "MERLIN_HIP_SCORER_BN_GRAD", light ? 64 : 128);
+    p.bn = light ? 64 : 128;  // streamed rows per tile: measured best of {64, 128} per mode (tools/microbench.py scorer, round 2)
     if (p.bn != 64 && p.bn != 128) p.bn = 128;
     if (Ny <= 64) p.bn = 64;
     p.row_tiles = (int)mh_ceil_div(Nx, SX);
@@ -614,7 +610,7 @@ int32_t mh_stream_launch(int mode, int lse_stream, const MhStreamPlan& p, const 
     a.X = X; a.Y = Y; a.Nx = Nx; a.Ny = Ny; a.x_ids = x_ids; a.y_ids = y_ids; a.lse = lse; a.pos = pos;
     a.invT = invT; a.fns = fns; a.gscale = gscale; a.logits = logits; a.ld_logits = ld_logits;
     a.part_m = part_m; a.part_s = part_s; a.opart = opart; a.bn = p.bn; a.tiles_per_split = p.tps;
-    a.prio = env_int("MERLIN_HIP_SCORER_PRIO", 1);
+    a.prio = 1;  // s_setprio around the MFMA section (measured +2 % in round 2)
     a.tau = nullptr; a.cnt = nullptr; a.cs = nullptr; a.ci = nullptr; a.cap = 0; a.idx0 = 0;
     a.x_corr = x_corr; a.y_corr = y_corr; a.corr_after_mask = corr_after_mask;
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
@@ -668,7 +664,7 @@ int32_t mh_stream_filter(const float* q, int64_t Bq, const float* cand, int64_t 
     StreamArgs a;
     std::memset(&a, 0, sizeof(a));
     a.X = q; a.Y = cand; a.Nx = Bq; a.Ny = n_cand; a.invT = 1.f; a.bn = p.bn; a.tiles_per_split = p.tps;
-    a.prio = env_int("MERLIN_HIP_SCORER_PRIO", 1);
+    a.prio = 1;  // s_setprio around the MFMA section (measured +2 % in round 2)
     a.tau = tau; a.cnt = cnt; a.cs = cs; a.ci = ci; a.cap = cap; a.idx0 = idx0;
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
     if (E == 128) return launch_mode<SM_FILTER, 128, false>(a, MH_I32, grid, p.lds, s);

@@ -732,12 +732,27 @@ def _sparse_key(tables, ids, B, D):
     return (share, tuple(int(t.shape[0]) for t in tables), tuple(i.data_ptr() for i in ids), int(B), int(D))
 
 
+_DET = [None]
+
+
+def _sync_deterministic(lib) -> None:
+    """MERLIN_HIP_DETERMINISTIC is read HERE (a dict lookup per call) and handed to the library when it changes: tests flip it
+    inside one process; the library itself no longer calls getenv on its launch path."""
+    import os
+
+    want = 1 if os.environ.get("MERLIN_HIP_DETERMINISTIC") == "1" else 0
+    if _DET[0] != want:
+        lib.mh_set_deterministic(want)
+        _DET[0] = want
+
+
 def embedding_gather_backward_prepare(tables: Sequence[torch.Tensor], ids: Sequence[torch.Tensor],
                                       tag: str = "") -> Optional[PreparedSparseUpdate]:
     """The id-only half of ``embedding_gather_backward`` (segmented sort + piece list) on the CURRENT stream -- call it on a
     side stream at the start of the step so that it runs beside the forward pass.  The handle owns the workspace named by
     ``tag`` (two updates prepared in the same step need two tags)."""
     lib = _lib.load()
+    _sync_deterministic(lib)
     F = len(tables)
     if F == 0 or F > _lib.MAX_FEATURES - 1:
         return None
@@ -768,6 +783,7 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     ``prepared``: handle of ``embedding_gather_backward_prepare`` for the SAME tables / ids (checked): only the
     gradient-dependent half runs, after waiting for the preparation's event."""
     lib = _lib.load()
+    _sync_deterministic(lib)
     F = len(tables)
     if F == 0:
         return

@@ -121,19 +121,9 @@ if "scorer" in which:
     it = torch.randn(Bs, E, device=dev) * 0.1
     ids = torch.randperm(1_000_000, device=dev)[:Bs].to(torch.int32)
     r = ops.inbatch_softmax(q, it, it, ids, ids, materialize=False)
-    for prio in ("1", "0"):
-        os.environ["MERLIN_HIP_SCORER_PRIO"] = prio
-        for bn in ("64", "128"):
-            os.environ["MERLIN_HIP_SCORER_BN_FWD"] = bn
-            timeit(f"scorer fwd fused 32Kx32Kx128 prio={prio} bn={bn}",
-                   lambda: ops.inbatch_softmax(q, it, it, ids, ids, materialize=False), flops=2 * Bs * Bs * E, iters=5)
-        for bn in ("128", "64"):
-            os.environ["MERLIN_HIP_SCORER_BN_GRAD"] = bn
-            timeit(f"scorer fwd+dq 32Kx32Kx128 prio={prio} bn={bn}", lambda: ops.inbatch_softmax_train(q, it, it, ids, ids),
-                   flops=4 * Bs * Bs * E, iters=5)
-            timeit(f"scorer bwd column pass prio={prio} bn={bn}",
-                   lambda: ops.inbatch_softmax_backward(q, it, it, r.lse, ids, ids, need_dq=False), flops=4 * Bs * Bs * E, iters=5)
-    os.environ.pop("MERLIN_HIP_SCORER_BN_FWD"), os.environ.pop("MERLIN_HIP_SCORER_BN_GRAD"), os.environ.pop("MERLIN_HIP_SCORER_PRIO")
+    timeit("scorer fwd fused 32Kx32Kx128", lambda: ops.inbatch_softmax(q, it, it, ids, ids, materialize=False), flops=2 * Bs * Bs * E, iters=5)
+    timeit("scorer fwd+dq 32Kx32Kx128", lambda: ops.inbatch_softmax_train(q, it, it, ids, ids), flops=4 * Bs * Bs * E, iters=5)
+    timeit("scorer bwd column pass", lambda: ops.inbatch_softmax_backward(q, it, it, r.lse, ids, ids, need_dq=False), flops=4 * Bs * Bs * E, iters=5)
     timeit("scorer bwd (row + column passes)", lambda: ops.inbatch_softmax_backward(q, it, it, r.lse, ids, ids),
            flops=8 * Bs * Bs * E, iters=3)
 if "topk" in which:
