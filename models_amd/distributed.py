@@ -252,6 +252,25 @@ class ShardedEmbeddingGroup:
         self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
         self.check_every = 64                        # fixed-window calls between two automatic overflow checks (0: never)
         self._since_check = 0
+        self._parent: Optional["ShardedEmbeddingGroup"] = None
+        self._deferred: List = []                    # (rows, gradient rows) handed over by aliases: ONE update per step
+        self._pending_bwd = None
+
+    def alias(self) -> "ShardedEmbeddingGroup":
+        """A second route over the SAME local shards (own exchange state, own windows): list / ragged features request one row
+        per VALUE, a different request count than the one-hot features of the group.  Its gradient rows are not applied by
+        itself: ``backward_end`` hands them to this group, which applies everything that arrived for its shards in ONE fused
+        update (Keras sums all IndexedSlices of a variable before one optimizer apply)."""
+        import copy
+
+        a = copy.copy(self)
+        a._parent = self
+        a._deferred = []
+        a._pending_bwd = a._pending_lookup = None
+        a._rows = None
+        a.capacity, a._capacity_n, a._steps, a._max_count, a._since_check = None, 0, 0, 0, 0
+        a.overflow = torch.zeros_like(self.overflow)
+        return a
 
     # ---- capacity management ------------------------------------------------------------------------------------
     def freeze_capacity(self, n_requests: int, capacity: Optional[int] = None) -> int:
@@ -298,11 +317,11 @@ class ShardedEmbeddingGroup:
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
         return out, work
 
-    def lookup(self, ids: Sequence[torch.Tensor], scatter_into=None) -> Optional[torch.Tensor]:
-        self.lookup_begin(ids, scatter_into)
+    def lookup(self, ids: Sequence[torch.Tensor], scatter_into=None, features=None) -> Optional[torch.Tensor]:
+        self.lookup_begin(ids, scatter_into, features=features)
         return self.lookup_end()
 
-    def lookup_begin(self, ids: Sequence[torch.Tensor], scatter_into=None, layout=None) -> None:
+    def lookup_begin(self, ids: Sequence[torch.Tensor], scatter_into=None, layout=None, features=None) -> None:
         """``ids[f]`` is [B] for sharded feature f; returns [F_sh, B, D], or, with
         ``scatter_into = (stacked [B, F, D], slots, scatter_fn)``, writes feature f into ``stacked[:, slots[f]]``.
         ``layout = (slots, n_slots)``: the [B, n_slots, D] stack the GRADIENT will arrive in (``backward_begin(...,
@@ -353,6 +372,11 @@ class ShardedEmbeddingGroup:
                     dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
                     self._max_count = int(m.item())
                 self._freeze_after = n
+        if features is not None and list(features) != list(range(F_sh)):
+            # the route numbers the id columns 0 .. F_sh - 1; ``features`` says which features of the GROUP they are
+            fmap = torch.tensor(list(features), dtype=torch.int64, device=send_keys.device)
+            low = (1 << 40) - 1
+            send_keys = torch.where(send_keys >= 0, (fmap[(send_keys >> 40).clamp(min=0)] << 40) | (send_keys & low), send_keys)
         self._pos_of, self._src_row, self._n_send = pos_of, src_row, send_keys.numel()
         self._fwd_layout = (list(slots), int(n_slots))
         recv_keys, _ = self._exchange(send_keys, n_recv, self._recv_counts, self._send_counts)
@@ -426,11 +450,23 @@ class ShardedEmbeddingGroup:
         self._pending_bwd = (work, g, send)
 
     def backward_end(self) -> None:
-        work, g, _send_alive = self._pending_bwd
-        self._pending_bwd = None
-        if work is not None:
-            work.wait()
-        self.update_fn(self.local, self.state, self._rows, g)
+        parts = []
+        if self._pending_bwd is not None:
+            work, g, _send_alive = self._pending_bwd
+            self._pending_bwd = None
+            if work is not None:
+                work.wait()
+            parts.append((self._rows, g))
+        if self._parent is not None:      # an alias: the owner group applies everything in one update
+            self._parent._deferred.extend(parts)
+            parts = []
+        else:
+            parts += self._deferred
+            self._deferred = []
+        if len(parts) == 1:
+            self.update_fn(self.local, self.state, parts[0][0], parts[0][1])
+        elif parts:
+            self.update_fn(self.local, self.state, torch.cat([r for r, _ in parts]), torch.cat([g for _, g in parts]))
         fa = getattr(self, "_freeze_after", None)
         if fa is not None:  # calibration done: the next step runs on fixed windows
             self._freeze_after = None
@@ -943,6 +979,50 @@ class _ShardedEmbeddings:
         emb.gather_concat = self.gather_concat
         emb._apply_sparse_now = self.apply_sparse_now
         self._active: List[ShardedEmbeddingGroup] = []
+        self._aliases: Dict[str, ShardedEmbeddingGroup] = {}  # list feature -> its own route over the group's shards
+        self._list_ctx: Dict[str, tuple] = {}
+
+    # ---- list / ragged features of a row-sharded table (SOK's lookup takes sparse ids with a combiner,
+    #      tf/distributed/embedding.py:144-148): one request per VALUE through an alias route, combined on the requesting rank
+    def _list_lookup(self, grp, gnames, n, x, out_view) -> None:
+        from . import ops
+        from .inputs import Ragged
+
+        ft = self.emb.feature_table[n]
+        comb = ft.sequence_combiner
+        if not comb:
+            raise ValueError("list inputs need a str sequence_combiner")
+        if isinstance(x, Ragged):
+            vals, offs, shape = x.values.reshape(-1), x.offsets, None
+            # pruned ids (< 0, safe_embedding_lookup_sparse) are requested as row `input_dim`: beyond the table, so the owner
+            # answers with a zero row and its update skips the request -- exactly "not looked up"
+            req = torch.where(vals >= 0, vals, torch.full_like(vals, ft.input_dim))
+        else:
+            if x.dim() == 3 and x.shape[-1] == 1:
+                x = x.squeeze(-1)
+            if comb == "sqrtn":
+                raise ValueError("Only 'mean', 'sum', and 'max' str combiners is implemented for dense list/multi-hot embedded features.")
+            vals, offs, shape = x.reshape(-1), None, tuple(x.shape)
+            req = vals
+        alias = self._aliases.get(n)
+        if alias is None:
+            alias = self._aliases[n] = grp.alias()
+        rows = alias.lookup([req], features=[gnames.index(n)])[0]            # [nnz, D] in value order
+        local = torch.arange(vals.numel(), dtype=vals.dtype, device=vals.device)
+        if offs is not None:
+            local = torch.where(vals >= 0, local, torch.full_like(local, -1))
+            ops.embedding_bag(rows, local, offs, comb, out=out_view)
+        else:
+            ops.embedding_dense_list(rows, local.reshape(shape), comb, out=out_view)
+        self._list_ctx[n] = (alias, rows, local if offs is not None else local.reshape(shape), offs)
+
+    def _list_backward(self, n, gcols, comb) -> None:
+        from . import ops
+
+        alias, rows, local, offs = self._list_ctx.pop(n)
+        _, gexp = ops.embedding_bag_expand(rows, local, offs, gcols, comb)   # one gradient row per value
+        alias.backward_begin(gexp.reshape(1, gexp.shape[0], gexp.shape[1]))
+        self._active.insert(0, alias)  # aliases hand their rows over BEFORE the owner groups apply
 
     def gather_into(self, inputs, out, slots) -> None:
         from . import ops
@@ -951,23 +1031,22 @@ class _ShardedEmbeddings:
         names = [n for n in emb.feature_names if n in inputs]
         D = out.shape[2]
         grp, gnames = self.groups.get(D, (None, []))
-        mine = [n for n in gnames if n in names]  # the GROUP's feature order: request keys carry the feature index
-        if mine and len(mine) != len(gnames):
-            raise ValueError(f"row-sharded features {gnames} must be looked up together (got {mine})")
+        sharded_here = [n for n in gnames if n in names]
+        mine = [n for n in sharded_here if emb._is_onehot(inputs[n])]  # the GROUP's feature order (keys carry the feature index)
+        lists = [n for n in sharded_here if n not in mine]
         if mine:
-            for n in mine:
-                if not emb._is_onehot(inputs[n]):
-                    raise NotImplementedError(f"row-sharded table of {n!r}: list / ragged inputs need a replicated table")
-
             def scatter_fn(tabs, idx, o, sl):
                 ops.embedding_gather(tabs, idx, out=o, out_slot=sl)
 
-            grp.lookup_begin([inputs[n].reshape(-1) for n in mine], scatter_into=(out, [slots[n] for n in mine], scatter_fn))
-        rest = {n: inputs[n] for n in names if n not in mine}
+            grp.lookup_begin([inputs[n].reshape(-1) for n in mine], scatter_into=(out, [slots[n] for n in mine], scatter_fn),
+                             features=[gnames.index(n) for n in mine])
+        rest = {n: inputs[n] for n in names if n not in sharded_here}
         if rest:
             self._orig_gather_into(emb, rest, out, slots)  # the replicated-table gather overlaps the row all-to-all
         if mine:
             grp.lookup_end()
+        for n in lists:
+            self._list_lookup(grp, gnames, n, inputs[n], out[:, slots[n]])
         last = dict(getattr(emb, "_last_all", {})) if getattr(emb, "_last_step", None) is self.owner._step_token else {}
         last.update({n: inputs[n] for n in names})
         emb._last_all, emb._last_step = last, self.owner._step_token
@@ -981,11 +1060,9 @@ class _ShardedEmbeddings:
         emb = self.emb
         begun = []
         for d, (grp, gnames) in self.groups.items():
-            mine = [n for n in gnames if n in names]  # the GROUP's feature order
-            if mine and len(mine) != len(gnames):
-                raise ValueError(f"row-sharded features {gnames} must be looked up together (got {mine})")
+            mine = [n for n in gnames if n in names]  # the GROUP's feature order (gather_concat takes one-hot features only)
             if mine:
-                grp.lookup_begin([inputs[n].reshape(-1) for n in mine])
+                grp.lookup_begin([inputs[n].reshape(-1) for n in mine], features=[gnames.index(n) for n in mine])
                 begun.append((grp, mine))
         taken = {n for _, mine in begun for n in mine}
         rest = [n for n in names if n not in taken]
@@ -1006,13 +1083,21 @@ class _ShardedEmbeddings:
         B, stride = g2.shape
         present = [n for n in offsets if n in emb._last and emb.feature_table[n].table.trainable]
         for d, (grp, gnames) in self.groups.items():
-            mine = [n for n in gnames if n in present]  # same order as the lookup
-            if not mine:
+            here = [n for n in gnames if n in present]
+            if not here:
                 continue
             if opt.name == "adagrad" and grp.state is None:
                 grp.state = torch.full_like(grp.local, opt.initial_accumulator_value)
             if opt.name == "adam" and grp.state is None:
                 grp.state, grp.state2 = torch.zeros_like(grp.local), torch.zeros_like(grp.local)
+            mine = [n for n in here if n not in self._list_ctx]  # one-hot lookups, same order as the lookup
+            for n in here:
+                if n in self._list_ctx:
+                    self._list_backward(n, g2[:, offsets[n]:offsets[n] + d], emb.feature_table[n].sequence_combiner)
+            if grp not in self._active:
+                self._active.append(grp)  # applies what its aliases hand over even when it has no one-hot lookups itself
+            if not mine:
+                continue
             pull = lambda tab, idx: ops.embedding_gather([tab], [idx])[:, 0]
             if stride % d == 0 and all(offsets[n] % d == 0 for n in mine):
                 # gradient rows sit at multiples of d: the buffer IS a [B, stride / d, d] stack, rows pulled in owner order
@@ -1020,7 +1105,6 @@ class _ShardedEmbeddings:
             else:  # e.g. a concat row of 26 x 128 + 13 floats: compact the sharded features' columns first (one copy)
                 compact = torch.stack([g2[:, offsets[n]:offsets[n] + d] for n in mine], dim=1).contiguous()
                 grp.backward_begin(None, from_stacked=(compact, list(range(len(mine))), pull))
-            self._active.append(grp)
         rep = [n for n in present if n not in self.sharded_names]
         onehot = [n for n in rep if emb._is_onehot(emb._last[n])]
         grad_of = self.owner._rep_grad

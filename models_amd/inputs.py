@@ -41,46 +41,52 @@ _INIT_CHUNK = 1 << 20  # rows per init chunk of a large table
 
 def _init_table(initializer, rows: int, dim: int, device, seed: Optional[int], shard=None) -> torch.Tensor:
     """keras Embedding default "uniform" = U(-0.05, 0.05) (embedding.py:205); V1 EmbeddingFeatures
-    default TruncatedNormal(0, 0.05) (:1051) is available as "truncated_normal".
-    Large uniform tables are drawn in chunks of 2^20 rows, each from its own generator seeded by (seed, chunk): the
-    values of row r do not depend on how the table is partitioned, so ``shard = (rank, W)`` draws the rows
-    ``rank, rank + W, ...`` of exactly the table an unsharded build would hold without ever materialising it."""
-    if initializer is None or (isinstance(initializer, str) and initializer == "uniform"):
-        base = 0 if seed is None else seed
-        if rows * dim > (1 << 24) and device.type == "cuda" or shard is not None:
-            rank, W = shard if shard is not None else (0, 1)
-            n_local = (rows - rank + W - 1) // W if rows > rank else 0
-            out = torch.empty((n_local, dim), dtype=torch.float32, device=device)
-            gd = torch.Generator(device=device)
-            o = 0
-            for c0 in range(0, rows, _INIT_CHUNK):
-                c1 = min(rows, c0 + _INIT_CHUNK)
-                gd.manual_seed((base * 1_000_003 + c0 // _INIT_CHUNK) & 0x7FFFFFFFFFFFFFFF)
-                chunk = (torch.rand((c1 - c0, dim), generator=gd, device=device) - 0.5) * 0.1
-                first = (rank - c0) % W  # first row of this chunk owned by `rank`
-                part = chunk[first::W]
-                out[o:o + part.shape[0]] = part
-                o += part.shape[0]
-            return out
-        g = torch.Generator(device="cpu")
-        g.manual_seed(base)
-        return ((torch.rand((rows, dim), generator=g) - 0.5) * 0.1).to(device)
-    if shard is not None:
-        raise NotImplementedError("sharded construction supports the 'uniform' initializer only (pretrained / custom "
-                                  "tables: build the full table and let the distributed wrapper slice it)")
-    if isinstance(initializer, str) and initializer == "truncated_normal":
-        g = torch.Generator(device="cpu")
-        g.manual_seed(0 if seed is None else seed)
-        t = torch.empty((rows, dim))
-        torch.nn.init.trunc_normal_(t, mean=0.0, std=0.05, a=-0.1, b=0.1, generator=g)
-        return t.to(device)
+    default TruncatedNormal(0, 0.05) (:1051) is available as "truncated_normal"; an array / tensor / callable gives the
+    values themselves (pretrained tables, embedding.py:283).
+
+    ``shard = (rank, W)`` returns the rows ``rank, rank + W, ...`` of EXACTLY the table an unsharded build on the same device
+    would hold, without materialising that table on the device:
+      * up to 2^24 elements the table is drawn from one CPU generator (as ever) and sliced on the host;
+      * larger tables are drawn on the device in chunks of 2^20 rows, each from its own generator seeded by (seed, chunk) --
+        the values of row r do not depend on the partition -- whether sharded or not;
+      * given values are sliced on the host."""
+    rank, W = shard if shard is not None else (0, 1)
+    base = 0 if seed is None else seed
+    kind = "uniform" if initializer is None else initializer
+    if isinstance(kind, str) and kind in ("uniform", "truncated_normal"):
+        def draw(shape, gen, dev):
+            if kind == "uniform":
+                return (torch.rand(shape, generator=gen, device=dev) - 0.5) * 0.1
+            t = torch.empty(shape, device=dev)
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=0.05, a=-0.1, b=0.1, generator=gen)
+            return t
+
+        if rows * dim <= (1 << 24):
+            g = torch.Generator(device="cpu")
+            g.manual_seed(base)
+            return draw((rows, dim), g, "cpu")[rank::W].contiguous().to(device)
+        n_local = (rows - rank + W - 1) // W if rows > rank else 0
+        out = torch.empty((n_local, dim), dtype=torch.float32, device=device)
+        gd = torch.Generator(device=device)
+        o = 0
+        for c0 in range(0, rows, _INIT_CHUNK):
+            c1 = min(rows, c0 + _INIT_CHUNK)
+            gd.manual_seed((base * 1_000_003 + c0 // _INIT_CHUNK) & 0x7FFFFFFFFFFFFFFF)
+            chunk = draw((c1 - c0, dim), gd, device)
+            first = (rank - c0) % W  # first row of this chunk owned by `rank`
+            part = chunk[first::W]
+            out[o:o + part.shape[0]] = part
+            o += part.shape[0]
+        return out
+    if isinstance(initializer, str):
+        raise ValueError(f"unknown embeddings_initializer {initializer!r} ('uniform', 'truncated_normal', values or a callable)")
     if callable(initializer):
         initializer = initializer((rows, dim))
     w = torch.as_tensor(np.asarray(initializer.cpu() if isinstance(initializer, torch.Tensor) else initializer),
                         dtype=torch.float32)
     if tuple(w.shape) != (rows, dim):
         raise ValueError(f"initializer gave shape {tuple(w.shape)}, expected {(rows, dim)}")
-    return w.contiguous().to(device)
+    return w[rank::W].contiguous().to(device)
 
 
 class EmbeddingTable(Block):
@@ -535,9 +541,20 @@ class InputBlockV2(Block):
     def backward(self, grad):
         if grad is None or not self._cat_names:
             return None
-        if not self._fused:
-            raise NotImplementedError("backward needs 16-byte aligned one-hot embedding columns (fused layout)")
         B = grad.shape[0]
+        if not self._fused:
+            # list / ragged features, mixed embedding widths or columns that do not start on a 16-byte boundary: the embedding
+            # columns are compacted into one aligned buffer (every width is a multiple of 4 floats); the fused sparse update
+            # takes the one-hot features from it, list features go through the bag backward (EmbeddingsBlock._apply_sparse_now)
+            dims = [self.categorical.feature_table[n].dim for n in self._cat_names]
+            g = torch.empty((B, sum(dims)), dtype=torch.float32, device=grad.device)
+            offs, o = {}, 0
+            for n, d in zip(self._cat_names, dims):
+                g[:, o:o + d] = grad[:, self._offsets[n]:self._offsets[n] + d]
+                offs[n] = o
+                o += d
+            self.categorical.set_pending_grad(g, offs)
+            return None
         if grad.is_contiguous() and grad.shape[1] == self._W and self._W % 4 == 0 and grad.data_ptr() % 16 == 0:
             g = grad
         else:  # re-pitch to the 16-byte aligned row stride the fused backward needs

@@ -114,6 +114,78 @@ def embedding_gather_backward(tables, states, ids, grad, grad_offset, optimizer=
             t -= lr * g
 
 
+def _bag_ids(values, offsets, B):
+    lens = (offsets[1:] - offsets[:-1]).long()
+    return torch.repeat_interleave(torch.arange(B, device=values.device), lens)
+
+
+def _bag_div(combiner, n):
+    n = n.to(torch.float32)
+    one = torch.ones_like(n)
+    if combiner == "mean":
+        return torch.where(n > 0, n, one)
+    if combiner == "sqrtn":
+        return torch.where(n > 0, n.sqrt(), one)
+    return one
+
+
+def embedding_bag(table, values, offsets, combiner="mean", out=None):
+    B, V = offsets.shape[0] - 1, table.shape[0]
+    values = values.reshape(-1).long()
+    bag = _bag_ids(values, offsets.reshape(-1), B)
+    kept = values >= 0
+    valid = kept & (values < V)
+    acc = torch.zeros((B, table.shape[1]), dtype=torch.float32, device=table.device)
+    acc.index_add_(0, bag[valid], table[values[valid]])
+    acc = acc / _bag_div(combiner, torch.bincount(bag[kept], minlength=B)).unsqueeze(1)
+    if out is None:
+        return acc
+    out.copy_(acc)
+    return out
+
+
+def embedding_dense_list(table, ids, combiner="mean", out=None):
+    if ids.dim() == 3:
+        ids = ids.squeeze(-1)
+    B, L = ids.shape
+    idx = ids.reshape(-1).long()
+    ok = (idx >= 0) & (idx < table.shape[0])
+    g = (table[idx.clamp(0, table.shape[0] - 1)] * ok.unsqueeze(1).to(table.dtype)).reshape(B, L, -1)
+    res = {"mean": lambda: g.mean(1), "sum": lambda: g.sum(1), "max": lambda: g.max(1).values}[combiner]()
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
+def embedding_bag_expand(table, values, offsets, grad, combiner="mean"):
+    B = grad.shape[0]
+    if offsets is None:
+        if values.dim() == 3:
+            values = values.squeeze(-1)
+        L = values.shape[1]
+        flat = values.reshape(-1)
+        bag = torch.arange(B, device=grad.device).repeat_interleave(L)
+        if combiner == "max":
+            idx = flat.long()
+            ok = (idx >= 0) & (idx < table.shape[0])
+            rows = (table[idx.clamp(0, table.shape[0] - 1)] * ok.unsqueeze(1).to(table.dtype)).reshape(B, L, -1)
+            sel = (rows == rows.max(1, keepdim=True).values).to(grad.dtype)
+            return flat, (sel / sel.sum(1, keepdim=True) * grad.unsqueeze(1)).reshape(B * L, -1)
+        div = torch.full((B,), float(L) if combiner == "mean" else 1.0, device=grad.device)
+    else:
+        flat = values.reshape(-1)
+        bag = _bag_ids(flat, offsets.reshape(-1), B)
+        div = _bag_div(combiner, torch.bincount(bag[flat >= 0], minlength=B))
+    return flat, grad[bag] / div[bag].unsqueeze(1)
+
+
+def embedding_bag_backward(table, state, values, offsets, grad, combiner="mean", optimizer="sgd", lr=0.01, eps=1e-7,
+                           state2=None, beta1=0.9, beta2=0.999, lr_device=None):
+    flat, gexp = embedding_bag_expand(table, values, offsets, grad, combiner)
+    embedding_gather_backward([table], None if state is None else [state], [flat], gexp.unsqueeze(1), [0], optimizer, lr, eps)
+
+
 def bce(p, label, need_grad=True):
     p, label = p.reshape(-1), label.reshape(-1)
     pc = p.clamp(1e-7, 1 - 1e-7)
@@ -217,6 +289,7 @@ def install():
 
     for name in ("embedding_gather", "linear", "dot_interaction", "dot_interaction_backward", "linear_backward",
                  "embedding_gather_backward", "bce", "dense_optimizer_step_multi", "route_build", "eltwise", "rowwise_dot",
-                 "cross_layer", "inbatch_softmax", "inbatch_softmax_train", "inbatch_softmax_backward", "l2norm"):
+                 "cross_layer", "inbatch_softmax", "inbatch_softmax_train", "inbatch_softmax_backward", "l2norm", "embedding_bag",
+                 "embedding_dense_list", "embedding_bag_expand", "embedding_bag_backward"):
         setattr(ops, name, globals()[name])
     ops.route_local_rows = D.route_local_rows_torch

@@ -163,3 +163,28 @@ def test_embedding_initializer_statistics():
     a = mm.EmbeddingTable(16, col, device="cpu", seed=5).table.numpy()
     b = mm.EmbeddingTable(16, col, device="cpu", seed=5).table.numpy()
     assert np.array_equal(a, b)  # seeded
+
+
+def test_sharded_construction_draws_the_rows_of_the_unsharded_table():
+    """distributed.sharded_tables: a table built as a row shard holds rows rank, rank + W, ... of EXACTLY the table an unsharded
+    build holds -- for both drawn initializers, below and above the chunked-draw threshold, and for given (pretrained) values
+    (round-2 advisor finding: the promise did not hold for tables under 2^24 elements; only 'uniform' could be sharded)."""
+    import numpy as np
+    import torch
+
+    from models_amd import inputs as I
+
+    dev = torch.device("cpu")
+    for init in ("uniform", "truncated_normal"):
+        for rows, dim in ((1000, 8), (300_001, 64)):  # 19.2 M elements: drawn in 2^20-row chunks
+            full = I._init_table(init, rows, dim, dev, seed=5)
+            assert full.shape == (rows, dim) and float(full.abs().max()) <= 0.1 + 1e-6
+            for W in (2, 3):
+                for rank in range(W):
+                    part = I._init_table(init, rows, dim, dev, seed=5, shard=(rank, W))
+                    assert torch.equal(part, full[rank::W]), (init, rows, W, rank)
+    vals = np.arange(7 * 4, dtype=np.float32).reshape(7, 4)
+    assert torch.equal(I._init_table(vals, 7, 4, dev, None, shard=(1, 3)), torch.from_numpy(vals)[1::3])
+    assert torch.equal(I._init_table(lambda shape: torch.ones(shape), 7, 4, dev, None, shard=(2, 3)), torch.ones(2, 4))
+    with pytest.raises(ValueError):
+        I._init_table("orthogonal", 7, 4, dev, None)

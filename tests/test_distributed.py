@@ -466,3 +466,131 @@ def test_fixed_windows_do_not_drop_requests_of_a_larger_batch():
     with pytest.raises(RuntimeError, match="overflowed"):
         for _ in range(3):
             grp.lookup(small)
+
+
+# ---- list / ragged features of ROW-SHARDED tables (SOK's lookup takes sparse ids with a combiner, tf/distributed/embedding.py:144-148)
+def _list_parts():
+    import models_amd as mm
+    from models_amd import schema as S
+
+    dev = torch.device("cpu")
+    cols = [S.categorical("item_id", 2003, domain_name="item"),
+            S.categorical("item_hist", 2003, domain_name="item", is_list=True, is_ragged=True),  # shares item_id's table
+            S.categorical("tags", 1500, is_list=True), S.categorical("small", 7),
+            S.continuous("I1"), S.binary_target("label")]
+    m = mm.DCNModel(mm.Schema(cols), depth=1, deep_block=mm.MLPBlock([16, 8], device=dev, seed=5), embedding_dim=8, device=dev)
+    m.compile(optimizer="adagrad", learning_rate=0.05)
+    return m
+
+
+def _list_batches(world, B, steps, seed=31):
+    """per step: (per-rank inputs, labels [world, B, 1]); ragged histories with empty bags and pruned (-1) ids."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        ranks = []
+        for _r in range(world):
+            lens = torch.randint(0, 5, (B,), generator=g)
+            lens[3] = 0
+            offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+            vals = torch.randint(0, 2003, (int(offs[-1]),), generator=g)
+            vals[torch.rand(vals.shape, generator=g) < 0.05] = -1
+            ranks.append({"item_id": torch.randint(0, 2003, (B, 1), generator=g), "item_hist": (vals, offs),
+                          "tags": torch.randint(0, 1500, (B, 3), generator=g), "small": torch.randint(0, 7, (B, 1), generator=g),
+                          "I1": torch.rand(B, 1, generator=g)})
+        out.append((ranks, torch.randint(0, 2, (world, B, 1), generator=g).float()))
+    return out
+
+
+def _list_inputs(r):
+    import models_amd as mm
+
+    x = dict(r)
+    x["item_hist"] = mm.Ragged(*r["item_hist"])
+    return x
+
+
+def _list_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import ops_shim
+
+        ops_shim.install()
+        B, steps = 40, 4
+        model = _list_parts()
+        batches = _list_batches(world, B, steps)
+        model(_list_inputs(batches[0][0][rank]))
+        _reseed(model)
+        dm = D.DistributedModel(model, shard_threshold=1000)
+        losses = [float(dm.train_step(_list_inputs(ranks[rank]), y[rank])) for ranks, y in batches]
+        dm.check_overflow()
+        from models_amd.inputs import EmbeddingsBlock
+
+        tabs = {n: (t.table.data.numpy().copy(), getattr(t, "shard", None))
+                for emb in model.blocks_of_type(EmbeddingsBlock) for n, t in emb.feature_table.items()}
+        q.put((rank, "ok", {"loss": losses, "tabs": tabs, "dense": [p.data.numpy().copy() for p in model.parameters() if not p.sparse]}))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_model_world2_list_features_on_sharded_tables():
+    """A ragged history that SHARES the row-sharded item table with the one-hot item id, and a dense list over another sharded
+    table: two ranks with half a batch each end where ONE model trained on the concatenated batch ends -- rows fetched per
+    value through the alias route, combined on the requesting rank, gradient rows expanded per value and applied by the owner
+    together with the one-hot lookups' rows in ONE Adagrad step per table."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ops_shim
+    from models_amd import ops
+
+    world, B, steps = 2, 40, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_list_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+    assert all(m == "ok" for _, m, _ in res), [m for _, m, _ in res]
+    saved = {n: getattr(ops, n) for n in dir(ops)}
+    try:
+        ops_shim.install()
+        import models_amd as mm
+
+        model = _list_parts()
+        batches = _list_batches(world, B, steps)
+        model(_list_inputs(batches[0][0][0]))
+        _reseed(model)
+        ref_losses = []
+        for ranks, y in batches:
+            full = {k: torch.cat([r[k] for r in ranks], 0) for k in ("item_id", "tags", "small", "I1")}
+            vals = torch.cat([r["item_hist"][0] for r in ranks])
+            offs, base = [torch.zeros(1, dtype=torch.int64)], 0
+            for r in ranks:
+                offs.append(r["item_hist"][1][1:] + base)
+                base += int(r["item_hist"][1][-1])
+            full["item_hist"] = mm.Ragged(vals, torch.cat(offs))
+            ref_losses.append(float(model.train_step(full, y.reshape(world * B, 1))))
+    finally:
+        for n, v in saved.items():
+            setattr(ops, n, v)
+    from models_amd.inputs import EmbeddingsBlock
+
+    ref_tabs = {n: t.table.data.numpy() for emb in model.blocks_of_type(EmbeddingsBlock) for n, t in emb.feature_table.items()}
+    ref_dense = [p.data.numpy() for p in model.parameters() if not p.sparse]
+    for rank, _, st in res:
+        np.testing.assert_allclose(st["loss"], ref_losses, rtol=1e-5, atol=1e-6)
+        for a, b in zip(st["dense"], ref_dense):
+            np.testing.assert_allclose(a, b, atol=2e-5, rtol=1e-4)
+        assert st["tabs"]["item_hist"][1] is not None and st["tabs"]["tags"][1] is not None  # really row-sharded
+        for n, (t, shard) in st["tabs"].items():
+            want = ref_tabs[n] if shard is None else ref_tabs[n][shard[0]::shard[1]]
+            np.testing.assert_allclose(t, want, atol=2e-5, rtol=1e-4, err_msg=n)

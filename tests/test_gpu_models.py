@@ -641,3 +641,48 @@ def test_fit_auto_graph_and_targetless_batches(device):
                            samplers=["in-batch", mm.CachedCrossBatchSampler(64)], device=device)
     assert not tt2.graph_capturable
     assert np.isfinite(tt2.fit([_tt_batch(device, 96, i) for i in range(3)])["loss"][0])
+
+
+def test_sharded_list_features_equal_the_plain_model_on_the_hip_kernels(device):
+    """The row-sharded route with list features on the HIP kernels (forced sharding on one GPU: the code an N-GPU job runs,
+    exchange = identity): a ragged history sharing the item table with the one-hot item id + a dense list over another table,
+    DCN-v2 body, Adagrad -- equal to the plain model step for step (tf/distributed/embedding.py:144-148)."""
+    from models_amd import distributed as D
+
+    cols = [S.categorical("item_id", 2003, domain_name="item"),
+            S.categorical("item_hist", 2003, domain_name="item", is_list=True, is_ragged=True),
+            S.categorical("tags", 1500, is_list=True), S.categorical("small", 7), S.continuous("I1"), S.binary_target("label")]
+    schema = mm.Schema(cols)
+
+    def build():
+        m = mm.DCNModel(schema, depth=1, deep_block=mm.MLPBlock([16, 8], device=device, seed=5), embedding_dim=8, device=device)
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    g = torch.Generator().manual_seed(8)
+    B = 300
+
+    def batch():
+        lens = torch.randint(0, 6, (B,), generator=g)
+        lens[5] = 0
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+        vals = torch.randint(0, 2003, (int(offs[-1]),), generator=g)
+        vals[torch.rand(vals.shape, generator=g) < 0.05] = -1
+        x = {"item_id": torch.randint(0, 2003, (B, 1), generator=g).to(device), "item_hist": mm.Ragged(vals.to(device), offs.to(device)),
+             "tags": torch.randint(0, 1500, (B, 3), generator=g).to(device), "small": torch.randint(0, 7, (B, 1), generator=g).to(device),
+             "I1": torch.rand(B, 1, generator=g).to(device)}
+        return x, torch.randint(0, 2, (B, 1), generator=g).float().to(device)
+
+    batches = [batch() for _ in range(3)]
+    a, b = build(), build()
+    a(batches[0][0]), b(batches[0][0])
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        pb.data.copy_(pa.data)
+    dm = D.DistributedModel(b, shard_threshold=1000, force_shard=True)
+    assert sum(len(ns) for sh in dm.shards for _, ns in sh.groups.values()) == 3  # item_id, item_hist, tags
+    for x, y in batches:
+        la, lb = a.train_step(x, y), dm.train_step(x, y)
+        assert abs(float(la) - float(lb)) < 1e-5
+    dm.check_overflow()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pb.data, pa.data, atol=2e-6, rtol=2e-5)
