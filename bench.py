@@ -324,6 +324,70 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain, batch=None):
     return res
 
 
+def run_negatives(args, device, tm: Timing, kinds, steps=20, warmup=6):
+    """SURVEY 8f-4 negative samplers on the device.
+      queue      : TwoTower configs[2] train step with in-batch + cached cross-batch negatives (FIFO ring of B rows: 2 B
+                   negatives per row once full), eager and replayed from the captured step;
+      popularity : sampled softmax over the 1 M-row item table with `n_neg` log-uniform UNIQUE negatives + logQ correction
+                   (ContrastiveOutput over an EmbeddingTable): sampler kernel + gather + fused scorer, forward."""
+    import models_amd as mm
+    from models_amd import ops
+    from models_amd import schema as S
+    from models_amd.graph import PackedBatch, SegmentedStep
+
+    out = {}
+    B = args.tt_batch
+    if "queue" in kinds:
+        tags = {"USER_ID": [S.Tags.USER, S.Tags.USER_ID], "USER": [S.Tags.USER], "ITEM_ID": [S.Tags.ITEM, S.Tags.ITEM_ID], "ITEM": [S.Tags.ITEM]}
+        schema = mm.Schema([S.categorical(n, v, tags[t]) for n, v, t in TWOTOWER_COLS])
+        model = mm.TwoTowerModel(schema, mm.MLPBlock([256, 128], device=device), embedding_dim=128,
+                                 samplers=["in-batch", mm.CachedCrossBatchSampler(B)], device=device)
+        model.compile(optimizer=args.optimizer, learning_rate=0.01)
+        batches = [PackedBatch(make_twotower_batch(device, B, 900 + i)) for i in range(4)]
+        for i in range(warmup):  # fills the queue
+            model.train_step(batches[i % 4].tensors)
+        eager = lambda i: model.train_step(batches[i % 4].tensors)
+        dt_e = tm.timed(eager, steps, 0)
+        res = {"negatives_per_row": 2 * B, "eager_ms_per_step": dt_e / steps * 1e3, "graph_capturable": bool(model.graph_capturable)}
+        if model.graph_capturable:
+            seg = SegmentedStep(lambda t: model.train_step(t), batches[0], warmup=0)
+            rep = lambda i: seg.replay(batches[i % 4])
+            for i in range(3):
+                rep(i)
+            dt_g = tm.timed(rep, steps, 0)
+            res["replayed_ms_per_step"] = dt_g / steps * 1e3
+        best = min(res["eager_ms_per_step"], res.get("replayed_ms_per_step", 1e9))
+        res.update(value=B / (best * 1e-3), unit="samples/s",
+                   workload=f"TwoTower configs[2] train step, in-batch + cross-batch queue negatives, B={B}")
+        out["queue"] = res
+        del model
+    if "popularity" in kinds:
+        n_neg, V, E = 8192, 1_000_000, 128
+        col = S.categorical("item_id", V, [S.Tags.ITEM, S.Tags.ITEM_ID])
+        table = mm.EmbeddingTable(E, col, device=device)
+        sampler = mm.PopularityBasedSamplerV2(max_id=V - 1, max_num_samples=n_neg, seed=7)
+        head = mm.ContrastiveOutput(table, negative_samplers=sampler, logq_sampling_correction=True)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        q = (torch.randn(B, E, generator=g) * 0.1).to(device)
+        tgt = torch.randint(0, V - 1, (B, 1), generator=g).to(device)
+        fwd = lambda i: head({"query": q}, features={}, targets=tgt, training=True, materialize=False)
+        for i in range(3):
+            fwd(i)
+        dt = tm.timed(fwd, steps, 0)
+        st = torch.tensor([7, 0], dtype=torch.int64, device=device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            ops.log_uniform_sample(V - 1, n_neg, True, st)
+        b.record()
+        torch.cuda.synchronize()
+        out["popularity"] = {"workload": f"sampled softmax over a {V}-row x {E} item table, {n_neg} unique log-uniform negatives + logQ, "
+                                         f"B={B}, forward (sampler + gather + fused scorer)", "ms_per_step": dt / steps * 1e3,
+                             "value": B / (dt / steps), "unit": "samples/s", "sampler_kernel_ms": a.elapsed_time(b) / 20,
+                             "host_synchronisations_per_step": 0}
+    return out
+
+
 def run_scorer_fwd(device, B=32768, E=128, iters=5):
     """The scorer forward alone (fused loss, nothing B x B written) at configs[2] shapes."""
     from models_amd import ops
@@ -544,6 +608,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--launch", choices=["auto", "graph"], default="auto",
                     help="auto: probe hipGraph replay and eager launches with side streams, time the faster (DLRM train)")
+    ap.add_argument("--negatives", default="", help="with --workload twotower: comma list of 'queue', 'popularity' -- the negative-sampler "
+                                                      "variants of SURVEY 8f-4 as the line's `negatives` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / cache-busting extras of the default line")
     args = ap.parse_args()
@@ -574,7 +640,10 @@ def main():
             dist.destroy_process_group()
 
     if args.workload == "twotower":
-        return finish(run_twotower(args, device, tm, args.steps, args.warmup, args.sustain))
+        res = run_twotower(args, device, tm, args.steps, args.warmup, args.sustain)
+        if args.negatives and world == 1:
+            res["negatives"] = run_negatives(args, device, tm, [k.strip() for k in args.negatives.split(",") if k.strip()])
+        return finish(res)
     if args.workload == "dcn":
         return finish(run_dcn(args, device, tm))
     if args.workload == "topk":
@@ -822,6 +891,7 @@ def main():
             sec["topk"] = {k: tk[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline")}
             if args.mode == "train":
                 sec["c4_one_gpu"] = run_c4_one_gpu(args, device, tm)
+                sec["negatives"] = run_negatives(args, device, tm, ["queue", "popularity"], steps=10)
         except Exception as e:  # noqa: BLE001 -- the headline line must still be printed
             sec["error"] = f"{type(e).__name__}: {e}"
         res["secondary"] = sec

@@ -392,9 +392,7 @@ class RetrievalModel(Model):
 
     @property
     def graph_capturable(self) -> bool:
-        from .sampling import InBatchSamplerV2
-
-        return all(isinstance(s, InBatchSamplerV2) for s in self.output.negative_samplers)
+        return all(s.graph_capturable for s in self.output.negative_samplers)
 
     def train_step(self, inputs: TabularData, targets=None) -> torch.Tensor:
         """fwd (fused scorer: no [B, B] logits in HBM) -> bwd -> fused updates."""

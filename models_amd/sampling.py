@@ -75,6 +75,12 @@ class CandidateSampler(Block):
     def with_sampling_probs(self, items: Candidate) -> Candidate:
         return items
 
+    @property
+    def graph_capturable(self) -> bool:
+        """True when a step using this sampler is a fixed launch sequence with fixed shapes (no host-side state that a
+        replayed hipGraph would miss)."""
+        return False
+
     def add(self, items: Candidate) -> None:
         raise NotImplementedError()
 
@@ -88,6 +94,8 @@ class InBatchSamplerV2(CandidateSampler):
     def __init__(self, batch_size: Optional[int] = None, name: Optional[str] = None):
         super().__init__(batch_size, name)
         self._last_batch: Optional[Candidate] = None
+
+    graph_capturable = True
 
     def add(self, items: Candidate) -> None:
         self._last_batch = items
@@ -123,6 +131,8 @@ class PopularityBasedSamplerV2(CandidateSampler):
         self._seed = int(seed)
         self._rng_state: Dict[torch.device, torch.Tensor] = {}  # device int64 [2] = (seed, calls so far)
         self.sampling_dist = self.get_sampling_distribution()
+
+    graph_capturable = True  # the draw is one kernel, its call counter is device state
 
     def add(self, items: Candidate) -> None:
         pass
@@ -166,10 +176,12 @@ class FIFOQueue(Block):
     """Fixed-capacity first-in-first-out store of tensors across batches (the role of blocks/sampling/queue.py:22-360:
     cached item embeddings / ids for cross-batch negatives; when full, the oldest entries are overwritten).
 
-    Design: ``storage`` is a device-resident ring.  Its state is two host integers -- ``_head`` (slot of the oldest
-    entry) and ``_size`` -- which move by amounts known on the host (the row count of what is enqueued / dequeued), so no
-    operation reads anything back from the device.  Every data movement is ONE indexed copy through modular slot numbers
-    ``(start + arange(n)) % capacity``; wrap-around is arithmetic, not a case distinction."""
+    Design: ``storage`` is a device-resident ring.  The slot of the oldest entry lives ON THE DEVICE (``_head``, an int64
+    scalar tensor) and every data movement is ONE indexed copy through slot numbers computed on the device,
+    ``(head + offset + arange(n)) % capacity`` -- wrap-around is arithmetic, not a case distinction.  The host keeps only the
+    entry COUNT, which moves by amounts it knows (the row count of what is enqueued / dequeued): no operation reads anything
+    back from the device, and once the queue is full every operation is a fixed launch sequence with fixed shapes -- a train
+    step that feeds the queue replays from a hipGraph (the head advances on the device with every replay)."""
 
     def __init__(self, capacity: int, dtype: torch.dtype, dims: Sequence[int] = (), queue_name: str = "",
                  initialize_tensor: Optional[torch.Tensor] = None, device=None, name: Optional[str] = None):
@@ -180,17 +192,14 @@ class FIFOQueue(Block):
             # -1 is never a valid categorical value: index_of() cannot match a slot that was never written
             initialize_tensor = torch.full([self.capacity] + self.dims, -1, dtype=dtype, device=device)
         self.storage = initialize_tensor.clone()
-        self._head = 0
-        self._size = 0
-        self._lane = torch.arange(self.capacity, device=self.storage.device)  # 0 .. capacity - 1, reused by every slot range
+        dev = self.storage.device
+        self._head = torch.zeros((), dtype=torch.int64, device=dev)   # slot of the oldest entry (device state)
+        self._size = 0                                                # entries queued (host: moves by host-known amounts)
+        self._lane = torch.arange(self.capacity, device=dev)          # 0 .. capacity - 1, reused by every slot range
 
-    def _slots(self, start: int, n: int) -> torch.Tensor:
-        """Ring slots start, start + 1, ... (n of them, n <= capacity), wrapped."""
-        return (self._lane[:n] + start) % self.capacity
-
-    @property
-    def _tail(self) -> int:
-        return (self._head + self._size) % self.capacity
+    def _slots(self, offset: int, n: int) -> torch.Tensor:
+        """Ring slots of the entries offset, offset + 1, ... (n of them) counted from the oldest, wrapped."""
+        return (self._lane[:n] + (self._head + offset)) % self.capacity
 
     def _check_rows(self, values: torch.Tensor) -> None:
         assert values.dim() == len(self.dims) + 1, (
@@ -202,14 +211,15 @@ class FIFOQueue(Block):
         n = int(rows.shape[0])
         if n > self.capacity:  # only the newest `capacity` rows can survive
             rows, n = rows[n - self.capacity:], self.capacity
-        self.storage.index_copy_(0, self._slots(self._tail, n), rows.to(self.storage.dtype))
-        grown = self._size + n
-        self._head = (self._head + max(0, grown - self.capacity)) % self.capacity  # overwritten entries were the oldest
-        self._size = min(self.capacity, grown)
+        self.storage.index_copy_(0, self._slots(self._size, n), rows.to(self.storage.dtype))
+        lost = max(0, self._size + n - self.capacity)  # overwritten entries were the oldest: the head moves past them
+        if lost:
+            self._head.add_(lost).remainder_(self.capacity)
+        self._size = min(self.capacity, self._size + n)
 
     def _pop(self, n: int) -> torch.Tensor:
-        rows = self.storage.index_select(0, self._slots(self._head, n))
-        self._head = (self._head + n) % self.capacity
+        rows = self.storage.index_select(0, self._slots(0, n))
+        self._head.add_(n).remainder_(self.capacity)
         self._size -= n
         return rows
 
@@ -236,7 +246,7 @@ class FIFOQueue(Block):
 
     def list_all(self) -> torch.Tensor:
         """Every queued entry, oldest first."""
-        return self.storage.index_select(0, self._slots(self._head, self._size))
+        return self.storage.index_select(0, self._slots(0, self._size))
 
     def count(self) -> int:
         return self._size
@@ -246,7 +256,8 @@ class FIFOQueue(Block):
         return self._size == self.capacity
 
     def clear(self) -> None:
-        self._head = self._size = 0
+        self._head.zero_()
+        self._size = 0
 
     def index_of(self, ids: torch.Tensor) -> torch.Tensor:
         """Slot in the STORAGE of every id (first match), -1 if absent; integer queues of scalars only."""
@@ -279,6 +290,13 @@ class CachedCrossBatchSampler(CandidateSampler):
         self._emb: Optional[FIFOQueue] = None
         self._pending: Optional[Candidate] = None
 
+    @property
+    def graph_capturable(self) -> bool:
+        """Once the queues are full (and a batch is pending) every step enqueues and lists the same number of rows: fixed
+        shapes, the ring head advances on the device."""
+        return (self._emb is not None and self._emb.at_full_capacity and self._ids.at_full_capacity
+                and (self._pending is not None or not self.ignore_last_batch_on_sample))
+
     def _ensure(self, items: Candidate) -> None:
         if self._emb is None:
             dev = items.embedding.device
@@ -297,8 +315,15 @@ class CachedCrossBatchSampler(CandidateSampler):
             self._pending = None
         if training:
             if self.ignore_last_batch_on_sample:
-                # a snapshot: the caller's buffers are reused by the next step, and no gradient flows into the cache
-                self._pending = Candidate(items.id.detach().clone(), {EMBEDDING_KEY: items.embedding.detach().clone()})
+                # a snapshot (the caller's buffers are reused by the next step, no gradient flows into the cache) written IN
+                # PLACE into persistent buffers: the batch pending from one step is consumed by the next, and a step replayed
+                # from a hipGraph can only hand a tensor to its next replay through an address that does not change
+                hold = getattr(self, "_hold", None)
+                if hold is None or hold.id.shape != items.id.shape or hold.embedding.shape != items.embedding.shape:
+                    hold = Candidate(torch.empty_like(items.id), {EMBEDDING_KEY: torch.empty_like(items.embedding.detach())})
+                hold.id.copy_(items.id.detach())
+                hold.embedding.copy_(items.embedding.detach())
+                self._hold = self._pending = hold
             else:
                 self.add(items)
         return self.sample()

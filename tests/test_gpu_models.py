@@ -686,3 +686,27 @@ def test_sharded_list_features_equal_the_plain_model_on_the_hip_kernels(device):
     dm.check_overflow()
     for pa, pb in zip(a.parameters(), b.parameters()):
         torch.testing.assert_close(pb.data, pa.data, atol=2e-6, rtol=2e-5)
+
+
+def test_cross_batch_queue_step_replays_from_a_graph_once_the_queue_is_full(device):
+    """in-batch + cached cross-batch negatives (blocks/sampling/queue.py): the FIFO ring's head is device state, so once the
+    queue is full the train step is a fixed launch sequence -- Model.fit captures it and the replayed steps leave the model
+    where eager steps leave it (the queue contents included)."""
+    def build():
+        mm.set_seed(11)
+        m = mm.TwoTowerModel(_tt_schema(), mm.MLPBlock([16], device=device, seed=4), embedding_dim=8,
+                             samplers=["in-batch", mm.CachedCrossBatchSampler(128)], device=device)
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    data = [_tt_batch(device, 64, 100 + i) for i in range(9)]
+    m1, m2 = build(), build()
+    assert not m1.graph_capturable
+    h1 = m1.fit(data, graph=None)   # eager until the queue is full (step 3), captured and replayed from then on
+    h2 = m2.fit(data, graph=False)
+    assert m1.graph_capturable and abs(h1["loss"][0] - h2["loss"][0]) < 1e-5
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(p1.data, p2.data, atol=1e-6, rtol=1e-5)
+    s1, s2 = m1.output.negative_samplers[1], m2.output.negative_samplers[1]
+    assert torch.equal(s1._ids.list_all(), s2._ids.list_all())
+    torch.testing.assert_close(s1._emb.list_all(), s2._emb.list_all(), atol=1e-6, rtol=1e-5)
