@@ -387,6 +387,26 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
 int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* relevant_counts, int64_t B,
                         int32_t k, float* out, mh_stream_t stream);
 
+/* ---- optional layers of MLPBlock (blocks/mlp.py:108-137): tf.keras.layers.Dropout and BatchNormalization behind a Dense layer ----
+ * mh_dropout: y[i] = keep(i) ? x[i] / (1 - rate) : 0 (tf.nn.dropout).  keep(i) of call c is a pure function of (seed, c, i):
+ *   word (i % 4) of Philox4x32-10(counter = (i / 4, c), key = seed) >= rate * 2^32.  rng_state: DEVICE uint64[3] =
+ *   {seed, calls, last}.  backward == 0: call = calls; afterwards last = calls, calls += 1 (on the stream).  backward != 0:
+ *   the same mask as the last forward (call = last) applied to the gradient -- no mask is stored.  x == y is allowed.
+ * mh_batchnorm_fwd (axis -1, Keras non-fused 2-D semantics): training != 0: batch mean / biased variance per column ->
+ *   save_mean, save_invstd = 1 / sqrt(var + eps); y = (x - mean) invstd gamma + beta; moving = moving * momentum +
+ *   batch * (1 - momentum) for mean and (biased) variance.  training == 0: the moving statistics normalise
+ *   (save_invstd receives 1 / sqrt(moving_var + eps)).  gamma / beta may be NULL (scale / center off).
+ * mh_batchnorm_bwd: dbeta = sum dy, dgamma = sum dy xhat; training: dx = gamma invstd (dy - dbeta / M - xhat dgamma / M);
+ *   inference statistics: dx = dy gamma invstd.  Column sums are two-stage with a fixed order (deterministic). */
+int32_t mh_dropout(const float* x, float* y, int64_t n, float rate, uint64_t* rng_state, int32_t backward, mh_stream_t stream);
+int64_t mh_batchnorm_workspace_bytes(int64_t M, int32_t N);
+int32_t mh_batchnorm_fwd(const float* x, int64_t ldx, int64_t M, int32_t N, const float* gamma, const float* beta, float eps,
+                         float momentum, int32_t training, float* moving_mean, float* moving_var, float* save_mean,
+                         float* save_invstd, float* y, int64_t ldy, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_batchnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t M, int32_t N, const float* gamma,
+                         const float* save_mean, const float* save_invstd, int32_t training, float* dx, int64_t lddx,
+                         float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+
 /* ---- measurement probe ("record a stream-copy peak on the box") -----------------------------------
  * dst[0 .. bytes) = src[0 .. bytes) with a float4 grid-stride kernel (16-byte aligned, bytes % 16 == 0): the streaming
  * rate a hand-written kernel reaches on this GPU, reported by bench.py beside the 8 TB/s spec peak. */

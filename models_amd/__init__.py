@@ -12,7 +12,8 @@ from .inputs import (  # noqa: F401
     InputBlock, InputBlockV2, Ragged, infer_embedding_dim,
 )
 from .blocks import (  # noqa: F401
-    Cross, CrossBlock, DLRMBlock, DotProductInteraction, DotProductInteractionBlock, MLPBlock, TwoTowerBlock, set_seed,
+    BatchNormalization, Cross, CrossBlock, DLRMBlock, DotProductInteraction, DotProductInteractionBlock, Dropout, MLPBlock,
+    TwoTowerBlock, set_seed,
 )
 from .outputs import (  # noqa: F401
     MIN_FLOAT, BinaryOutput, BruteForce, ContrastiveOutput, DotProduct, Prediction, TopKOutput, TopKPrediction,

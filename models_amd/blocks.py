@@ -218,6 +218,80 @@ def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False, z
     return grad
 
 
+class Dropout(Block):
+    """tf.keras.layers.Dropout(rate) behind a Dense layer of an MLPBlock (mlp.py:108-114, 126-127): active under
+    ``blocks.tape()`` (the training forward), identity otherwise.  The mask is counter-based (``mh_dropout``): nothing is kept
+    for the backward, a replayed graph draws a new mask every step."""
+
+    def __init__(self, rate: float, seed: Optional[int] = None, name: Optional[str] = None, device=None):
+        super().__init__(name)
+        if not 0.0 <= float(rate) < 1.0:
+            raise ValueError(f"dropout rate must be in [0, 1), got {rate}")
+        self.rate = float(rate)
+        self.seed = _next_seed() if seed is None else int(seed)
+        self._state: Optional[torch.Tensor] = None
+        self._active = False
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._active = _TAPE[0] > 0 and self.rate > 0.0
+        if not self._active:
+            return x
+        if self._state is None or self._state.device != x.device:
+            self._state = torch.tensor([self.seed, 0, 0], dtype=torch.int64, device=x.device)
+        return ops.dropout(x.contiguous(), self.rate, self._state)
+
+    def backward(self, grad: torch.Tensor) -> torch.Tensor:
+        if not self._active:
+            return grad
+        return ops.dropout(grad.contiguous(), self.rate, self._state, backward=True)
+
+
+class BatchNormalization(Block):
+    """tf.keras.layers.BatchNormalization() over the last axis (mlp.py:129-131; Keras defaults momentum 0.99, epsilon 1e-3,
+    gamma 1, beta 0, moving mean 0 / variance 1): batch statistics under ``blocks.tape()`` (moving statistics updated), the
+    moving statistics otherwise."""
+
+    def __init__(self, momentum: float = 0.99, epsilon: float = 1e-3, center: bool = True, scale: bool = True,
+                 name: Optional[str] = None, device=None):
+        super().__init__(name)
+        self.momentum, self.epsilon, self.center, self.scale = float(momentum), float(epsilon), center, scale
+        self.device = torch.device(device) if device is not None else default_device()
+        self.gamma: Optional[Parameter] = None
+        self.beta: Optional[Parameter] = None
+        self.moving_mean: Optional[torch.Tensor] = None
+        self.moving_variance: Optional[torch.Tensor] = None
+
+    def build(self, n: int) -> None:
+        if self.scale:
+            self.gamma = Parameter(torch.ones(n, device=self.device), name=f"{self.name}/gamma")
+        if self.center:
+            self.beta = Parameter(torch.zeros(n, device=self.device), name=f"{self.name}/beta")
+        self.moving_mean = torch.zeros(n, device=self.device)
+        self.moving_variance = torch.ones(n, device=self.device)
+
+    def own_parameters(self):
+        return [p for p in (self.gamma, self.beta) if p is not None]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.moving_mean is None:
+            self.build(x.shape[-1])
+        self._training = _TAPE[0] > 0
+        self._x = x
+        y, self._mean, self._invstd = ops.batchnorm(x, None if self.gamma is None else self.gamma.data,
+                                                    None if self.beta is None else self.beta.data, self.moving_mean,
+                                                    self.moving_variance, self.epsilon, self.momentum, self._training)
+        return y
+
+    def backward(self, grad: torch.Tensor) -> torch.Tensor:
+        dx, dgamma, dbeta = ops.batchnorm_backward(self._x, grad, None if self.gamma is None else self.gamma.data,
+                                                   self._mean, self._invstd, self._training)
+        if self.gamma is not None:
+            self.gamma.grad = dgamma
+        if self.beta is not None:
+            self.beta.grad = dbeta
+        return dx
+
+
 def _dense_layers(block):
     layers = block.layers if isinstance(block, SequentialBlock) else [block]
     return layers if all(isinstance(l, _Dense) for l in layers) else None
@@ -227,22 +301,32 @@ def MLPBlock(dimensions: Sequence[int], activation: Union[str, List[str]] = "rel
              kernel_initializer="glorot_uniform", bias_initializer="zeros", dropout: Optional[float] = None,
              normalization=None, filter=None, no_activation_last_layer: bool = False,
              block_name: str = "MLPBlock", device=None, seed: Optional[int] = None, **kwargs) -> SequentialBlock:
-    """mlp.py:35-139.  Dropout / BatchNorm are Keras machinery outside the hot path."""
+    """mlp.py:35-139: Dense layers, each optionally followed by Dropout(dropout) (not behind a last layer without activation,
+    :104-114) and by BatchNormalization (``normalization="batch_norm"`` or a layer instance, :129-135)."""
     if isinstance(activation, list) and len(activation) != len(dimensions):
         raise ValueError(
             f"Activation and Dimensions length mismatch. "
             f"Activation length: {len(activation)}, Dimensions length: {len(dimensions)}"
         )
-    if dropout or normalization:
-        raise NotImplementedError("dropout / normalization layers are outside the HIP hot path")
+    if normalization is not None and normalization != "batch_norm" and not isinstance(normalization, Block):
+        raise ValueError("Normalization needs to be an instance `Layer` or " "`batch_norm`")
     layers = []
     for idx, dim in enumerate(dimensions):
         act = (activation or "linear") if not isinstance(activation, list) else activation[idx]
+        drop = None
         if no_activation_last_layer and idx == len(dimensions) - 1:
             act = "linear"
+        elif dropout:
+            drop = Dropout(dropout, seed=None if seed is None else seed + 100 + idx, device=device)
         layers.append(_Dense(dim, activation=act, use_bias=use_bias, kernel_initializer=kernel_initializer,
                              bias_initializer=bias_initializer, device=device,
                              seed=None if seed is None else seed + idx))
+        if drop is not None:
+            layers.append(drop)
+        if normalization == "batch_norm":
+            layers.append(BatchNormalization(device=device))
+        elif normalization is not None:
+            layers.append(normalization)
     return SequentialBlock(layers, name=block_name, filter=filter)
 
 
@@ -415,10 +499,8 @@ class DLRMBlock(Block):
             tail = stacked[:, self.slots["bottom_block"]]
             if all(isinstance(l, _Dense) for l in layers):
                 mlp_forward(layers, x, out_last=tail)  # last bottom layer writes its slot of the stack
-            else:
-                for layer in layers[:-1]:
-                    x = layer(x)
-                layers[-1].forward(x, out=tail)
+            else:  # Dropout / BatchNormalization layers in the bottom MLP: generic path, the result is copied into its slot
+                tail.copy_(self.bottom_block(x))
         self.embeddings.gather_into(inputs, stacked, self.slots)
         self._stacked = stacked
         if self.top_block is None:
@@ -463,8 +545,7 @@ class DLRMBlock(Block):
             if all(isinstance(l, _Dense) for l in layers):
                 mlp_backward(layers, g, need_dx=False)
             else:
-                for i in range(len(layers) - 1, -1, -1):
-                    g = layers[i].backward(g, need_dx=i > 0)
+                self.bottom_block.backward(g.contiguous())
         return None
 
 

@@ -1339,6 +1339,53 @@ def dense_optimizer_step_multi(opt, params) -> None:
 TOPK_METRIC_NAMES = ("recall", "precision", "map", "dcg", "ndcg", "mrr")
 
 
+def dropout(x: torch.Tensor, rate: float, rng_state: torch.Tensor, backward: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``tf.nn.dropout(x, rate)`` with a counter-based mask (``rng_state``: device int64 ``[3]`` = seed, calls, last).
+    ``backward=True`` applies the mask of the LAST forward to ``x`` (a gradient)."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    _dev(rng_state, "rng_state", torch.int64)
+    if not x.is_contiguous() or rng_state.numel() != 3:
+        raise ValueError("dropout: contiguous input and a 3-entry int64 rng_state required")
+    out = torch.empty_like(x) if out is None else out
+    check(lib.mh_dropout(_ptr(x), _ptr(out), x.numel(), float(rate), _ptr(rng_state), int(bool(backward)), _stream()), "mh_dropout")
+    return out
+
+
+def batchnorm(x: torch.Tensor, gamma, beta, moving_mean: torch.Tensor, moving_var: torch.Tensor, eps: float = 1e-3,
+              momentum: float = 0.99, training: bool = False):
+    """Keras BatchNormalization over the last axis of ``[M, N]``: returns ``(y, save_mean, save_invstd)``; ``training``
+    normalises with the batch statistics and updates the moving ones in place."""
+    lib = _lib.load()
+    _rowmajor_2d(x, "x")
+    M, N = x.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    save_mean = torch.empty(N, dtype=torch.float32, device=x.device)
+    save_invstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.mh_batchnorm_workspace_bytes(M, N), x.device, "batchnorm")
+    check(lib.mh_batchnorm_fwd(_ptr(x), x.stride(0), M, N, _ptr(gamma), _ptr(beta), float(eps), float(momentum), int(bool(training)),
+                               _ptr(moving_mean), _ptr(moving_var), _ptr(save_mean), _ptr(save_invstd), _ptr(y), N, _ptr(ws),
+                               ws.numel(), _stream()), "mh_batchnorm_fwd")
+    return y, save_mean, save_invstd
+
+
+def batchnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma, save_mean: torch.Tensor, save_invstd: torch.Tensor,
+                       training: bool = True):
+    """``(dx, dgamma, dbeta)`` of ``batchnorm``."""
+    lib = _lib.load()
+    _rowmajor_2d(x, "x")
+    _rowmajor_2d(dy, "dy")
+    M, N = x.shape
+    dx = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(N, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.mh_batchnorm_workspace_bytes(M, N), x.device, "batchnorm")
+    check(lib.mh_batchnorm_bwd(_ptr(x), x.stride(0), _ptr(dy), dy.stride(0), M, N, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                               int(bool(training)), _ptr(dx), N, _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
+          "mh_batchnorm_bwd")
+    return dx, dgamma, dbeta
+
+
 def stream_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
     """``dst[:] = src`` with the library's float4 copy kernel (measurement probe: the box's achievable streaming rate)."""
     lib = _lib.load()

@@ -80,3 +80,25 @@ def test_bce_and_softmax_ce_match_torch(B, seed):
     want = torch.nn.functional.cross_entropy(torch.from_numpy(logits), torch.zeros(B, dtype=torch.long), reduction="none")
     np.testing.assert_allclose(loss, want.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(lse, torch.logsumexp(torch.from_numpy(logits), 1).numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_dropout_and_batchnorm_statements():
+    """Counter-based dropout: keep fraction 1 - rate, kept values scaled by 1 / (1 - rate), another call another mask;
+    batch norm (Keras non-fused 2-D semantics) against torch's functional batch_norm incl. the moving statistics."""
+    import torch
+
+    x = np.random.default_rng(0).normal(size=(4000, 16)).astype(np.float32)
+    y0, y1 = O.dropout(x, 0.3, seed=9, call=0), O.dropout(x, 0.3, seed=9, call=1)
+    assert abs((y0 != 0).mean() - 0.7) < 0.01 and not np.array_equal(y0 != 0, y1 != 0)
+    np.testing.assert_allclose(y0[y0 != 0], (x * O.dropout_scale(0.3))[y0 != 0], rtol=1e-7)
+    g, b = np.linspace(0.5, 1.5, 16).astype(np.float32), np.linspace(-0.1, 0.1, 16).astype(np.float32)
+    y, mm_, mv_ = O.batchnorm_train(x, g, b, np.zeros(16, np.float32), np.ones(16, np.float32))
+    rm, rv = torch.zeros(16), torch.ones(16)
+    yt = torch.nn.functional.batch_norm(torch.from_numpy(x), rm, rv, torch.from_numpy(g), torch.from_numpy(b), True, 0.01, 1e-3)
+    np.testing.assert_allclose(y, yt.numpy(), atol=2e-5)
+    np.testing.assert_allclose(mm_, rm.numpy(), atol=1e-6)
+    # torch's running variance is the UNBIASED batch variance, Keras' non-fused layer keeps the biased one
+    np.testing.assert_allclose(mv_, 0.99 + 0.01 * x.astype(np.float64).var(0), atol=1e-6)
+    np.testing.assert_allclose(O.batchnorm_infer(x, g, b, mm_, mv_),
+                               torch.nn.functional.batch_norm(torch.from_numpy(x), torch.from_numpy(mm_), torch.from_numpy(mv_),
+                                                              torch.from_numpy(g), torch.from_numpy(b), False, 0.0, 1e-3).numpy(), atol=2e-5)
