@@ -407,6 +407,10 @@ int32_t mh_batchnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
                          const float* save_mean, const float* save_invstd, int32_t training, float* dx, int64_t lddx,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
 
+/* ---- input staging of a replayed step: `count` small buffers (the columns of a batch: HOST arrays of device pointers and
+ * byte counts, whole 4-byte words, 4-byte aligned) copied by ONE launch into the static inputs a captured graph reads. */
+int32_t mh_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t count, mh_stream_t stream);
+
 /* ---- measurement probe ("record a stream-copy peak on the box") -----------------------------------
  * dst[0 .. bytes) = src[0 .. bytes) with a float4 grid-stride kernel (16-byte aligned, bytes % 16 == 0): the streaming
  * rate a hand-written kernel reaches on this GPU, reported by bench.py beside the 8 TB/s spec peak. */

@@ -178,6 +178,35 @@ class Model(Block):
             self.compile()
         history = {"loss": [], "examples_per_sec": []}
         graphed, sig = None, None
+        # graph=None: the captured step and the eager step are BOTH timed over PROBE steps each (one device synchronisation per
+        # window) and the faster one runs the rest -- on a fast host eager launches with side streams can beat the replay by a
+        # few percent, on a slow or busy host the replay wins by a lot.  graph=True forces the replay, graph=False eager.
+        PROBE = 12
+        probe = {"replay": None, "eager": None, "t": None, "n": 0, "mode": "replay" if graph is None else None}
+        prefer_eager = False
+
+        def probe_tick(done_mode):
+            """Called after every static-shape step while the two modes are being compared."""
+            nonlocal prefer_eager
+            if probe["mode"] is None:
+                return
+            if probe["t"] is None:
+                torch.cuda.synchronize()
+                probe["t"], probe["n"] = time.perf_counter(), 0
+                return
+            probe["n"] += 1
+            if probe["n"] < PROBE:
+                return
+            torch.cuda.synchronize()
+            probe[probe["mode"]] = (time.perf_counter() - probe["t"]) / probe["n"]
+            probe["t"] = None
+            if probe["mode"] == "replay":
+                probe["mode"] = "eager"
+            else:
+                prefer_eager = probe["eager"] < probe["replay"] * 0.98
+                probe["mode"] = None
+                history["launch_probe"] = {"replay_ms": probe["replay"] * 1e3, "eager_ms": probe["eager"] * 1e3,
+                                           "chosen": "eager" if prefer_eager else "replay"}
 
         def pack(x, y):
             d = dict(x)
@@ -207,9 +236,13 @@ class Model(Block):
                     if graphed is None and (graph or step >= 1):  # step 0 runs eagerly: builds lazily-shaped layers
                         # warmup=0: step 0 already ran eagerly (layers built, kernels' LDS attributes set); a warm-up
                         # replay here would TRAIN on this batch several times
-                        graphed, sig = Step(eager, PackedBatch(d), warmup=0), this_sig
+                        graphed, sig = Step(eager, d, warmup=0), this_sig
                     if graphed is not None and this_sig == sig:
-                        last = graphed.replay(PackedBatch(d))
+                        if prefer_eager or probe["mode"] == "eager":
+                            last = eager(d)
+                        else:
+                            last = graphed.replay(d)  # the batch's columns go into the static inputs in ONE launch
+                        probe_tick(probe["mode"])
                     else:
                         last = eager(d)
                 else:

@@ -1386,6 +1386,24 @@ def batchnorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma, save_mean: torc
     return dx, dgamma, dbeta
 
 
+def copy_many(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> None:
+    """``dsts[i][:] = srcs[i]`` for a list of small contiguous device tensors in ONE launch (the columns of a batch into the
+    static inputs of a captured step).  Pairs the kernel cannot take (other dtypes / shapes, odd byte counts) use ``copy_``."""
+    lib = _lib.load()
+    ps, pd, nb = [], [], []
+    for s_, d_ in zip(srcs, dsts):
+        n = s_.numel() * s_.element_size()
+        if (s_.is_cuda and d_.is_cuda and s_.dtype == d_.dtype and s_.shape == d_.shape and s_.is_contiguous() and d_.is_contiguous()
+                and n % 4 == 0 and s_.data_ptr() % 4 == 0 and d_.data_ptr() % 4 == 0):
+            ps.append(s_.data_ptr())
+            pd.append(d_.data_ptr())
+            nb.append(n)
+        else:
+            d_.copy_(s_, non_blocking=True)
+    if ps:
+        check(lib.mh_copy_many(_host_ptr_array(ps), _host_ptr_array(pd), (C.c_int64 * len(nb))(*nb), len(ps), _stream()), "mh_copy_many")
+
+
 def stream_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
     """``dst[:] = src`` with the library's float4 copy kernel (measurement probe: the box's achievable streaming rate)."""
     lib = _lib.load()

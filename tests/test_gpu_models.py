@@ -479,13 +479,16 @@ def test_two_tower_v2_encoders_equal_v1_model(device):
     np.testing.assert_allclose(emb, v2.query_embeddings(batches[0]).cpu().numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("mode", ["one_graph", "segmented"])
-def test_graph_replayed_train_steps_equal_eager_steps(device, mode):
+@pytest.mark.parametrize("mode", ["one_graph", "segmented", "segmented_deterministic"])
+def test_graph_replayed_train_steps_equal_eager_steps(device, mode, monkeypatch):
     """The headline number of bench.py is a replay of the captured train step -- ONE hipGraph, or the per-stream graph
     segments of graph.SegmentedStep (what Model.fit uses): replaying it on a sequence of NEW batches must leave the model
     exactly where eager steps on the same batches leave it."""
     from models_amd.graph import GraphedStep, SegmentedStep
 
+    exact = mode == "segmented_deterministic"  # no float atomics in the sparse update: replay == eager BIT FOR BIT
+    monkeypatch.setenv("MERLIN_HIP_DETERMINISTIC", "1" if exact else "0")
+    mode = "segmented" if exact else mode
     cards = {"C1": 5000, "C2": 7, "C3": 300, "C4": 50}
     cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
     cols.append(S.binary_target("label"))
@@ -530,7 +533,12 @@ def test_graph_replayed_train_steps_equal_eager_steps(device, mode):
         lb = gs.replay(new)
         assert abs(float(la) - float(lb)) < 1e-6
     for pa, pb in zip(a.parameters(), b.parameters()):
-        torch.testing.assert_close(pb.data, pa.data, atol=1e-6, rtol=1e-5)
+        if exact:
+            assert torch.equal(pb.data, pa.data)
+        else:
+            torch.testing.assert_close(pb.data, pa.data, atol=1e-6, rtol=1e-5)
+    if mode == "segmented":
+        print("segments:", [(i, sg["stream"], sg["deps"], bool(sg.get("empty"))) for i, sg in enumerate(gs.segments)])
 
 
 def _tt_schema():
