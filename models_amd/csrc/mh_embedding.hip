@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const GatherArgs args, 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t b = b0 + (int64_t)r * rows_per_pass;
-        if (b < B) *reinterpret_cast<f32x4*>(obase + b * out_row_stride) = v[r];
+        // written once, read by a later kernel after hundreds of MB more: streaming store (keeps the hot table rows in L2 / MALL)
+        if (b < B) __builtin_nontemporal_store(v[r], reinterpret_cast<f32x4*>(obase + b * out_row_stride));
     }
 }
 

@@ -476,7 +476,7 @@ __device__ __forceinline__ void load_row(const FeatRow& ft, int64_t key, int D, 
     r.wv = *reinterpret_cast<const gf32x4*>(r.w);
     if (opt != MH_OPT_SGD) {
         r.s1 = (gfloat*)(ft.state + off);
-        r.m = *reinterpret_cast<const gf32x4*>(r.s1);
+        r.m = __builtin_nontemporal_load(reinterpret_cast<const gf32x4*>(r.s1));  // optimizer state: touched by this kernel only, once per step
     }
     if (opt == MH_OPT_ADAM) {
         r.s2 = (gfloat*)(ft.state2 + off);
@@ -490,7 +490,7 @@ __device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const Op
     f32x4 wv = r.wv;
     if (opt == MH_OPT_ADAGRAD) {
         const f32x4 sv = r.m + g * g;
-        *reinterpret_cast<gf32x4*>(r.s1) = sv;
+        __builtin_nontemporal_store(sv, reinterpret_cast<gf32x4*>(r.s1));
         wv.x -= lr * g.x / (sqrtf(sv.x) + eps);
         wv.y -= lr * g.y / (sqrtf(sv.y) + eps);
         wv.z -= lr * g.z / (sqrtf(sv.z) + eps);
@@ -703,8 +703,9 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
     const int64_t stride = (int64_t)gridDim.x * groups;
     auto row = [&](uint32_t v) -> f32x4 {
         const int f = (int)(v >> 26);
-        return *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride + feat[f].offset +
-                                               c4 * 4);
+        // gradient rows are read exactly once: streaming loads (the table / state rows of hot ids stay cached)
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
+                                                                         feat[f].offset + c4 * 4));
     };
     // records as scalar pairs (rec, key); a record of length 0 stands for "no piece"
     int64_t base = (int64_t)blockIdx.x * groups;  // block-uniform: the loop carries barriers
