@@ -479,9 +479,11 @@ class DLRMBlock(Block):
                 return ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=False)
             width = P + (D if dense is not None else 0)
             ld = (width + 3) // 4 * 4
-            buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
-            if ld != width:
-                buf[:, width:].zero_()
+            # persistent per block: the alignment column behind `width` is zeroed ONCE (no kernel writes it), not by a fill launch
+            # in every step
+            buf = getattr(self, "_top_buf", None)
+            if buf is None or buf.shape != (B, ld) or buf.device != dev:
+                buf = self._top_buf = torch.zeros((B, ld), dtype=torch.float32, device=dev)
             top_in = buf[:, :width]
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
             if _TAPE[0] > 0:
@@ -524,12 +526,13 @@ class DLRMBlock(Block):
         head = getattr(self, "_head", None)
         if self.top_block is not None:
             tl = _dense_layers(self.top_block)
+            # zero_pad=False: the interaction backward reads the P + D gradient columns only, never the alignment column of dx
             if head is not None and tl:  # grad is the head's dz (the loss gradient w.r.t. its pre-activation)
-                grad = mlp_backward(tl + [head], grad, True, pre_masked=True)
+                grad = mlp_backward(tl + [head], grad, True, pre_masked=True, zero_pad=False)
             else:
                 if head is not None:
                     grad = head.backward(grad, pre_masked=True)
-                grad = mlp_backward(tl, grad, True, pre_masked) if tl else self.top_block.backward(grad)
+                grad = mlp_backward(tl, grad, True, pre_masked, zero_pad=False) if tl else self.top_block.backward(grad)
         has_tail = self.bottom_block is not None and self.top_block is not None
         slot = self.slots["bottom_block"] if self.bottom_block is not None else -1
         if getattr(self, "_fused", False):
