@@ -739,6 +739,10 @@ class DistributedDLRM:
         from . import ops
 
         body = self.body
+        for n in self.sharded_names:
+            if not body.embeddings._is_onehot(inputs[n]):
+                raise NotImplementedError(f"DistributedDLRM looks row-sharded tables up one id per sample; {n!r} is a list / ragged "
+                                          "feature: wrap the model in distributed.DistributedModel (alias routes per list feature)")
         B = inputs[body.cat_names[0]].shape[0]
         dev = inputs[body.cat_names[0]].device
         F, D = body.num_features, body.dim
