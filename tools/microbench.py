@@ -86,6 +86,15 @@ if "emb1m" in which:
     grad = torch.randn(B, F, D, device=dev)
     offs = [i * D for i in range(26)]
     timeit("embedding bwd sgd, 26 x 1M-row tables", lambda: ops.embedding_gather_backward(tabs, None, ids, grad, offs, "sgd", 0.01, 1e-7))
+if "towers" in which:  # the tower GEMMs the MFMA-utilisation target is quoted on: DLRM top layer at M = 64 K, two-tower layers at M = 32 K
+    for (M_, K, N) in [(B, 415, 128), (32768, 512, 256), (32768, 256, 256), (32768, 256, 128)]:
+        xx = torch.randn(M_, (K + 3) // 4 * 4, device=dev)[:, :K]
+        W = torch.randn(K, N, device=dev) * 0.1
+        bb = torch.zeros(N, device=dev)
+        y = ops.linear(xx, W, bb, "relu")
+        dy = torch.randn(M_, N, device=dev)
+        timeit(f"tower fwd {M_}x{K}x{N}", lambda: ops.linear(xx, W, bb, "relu", out=y), flops=2 * M_ * K * N)
+        timeit(f"tower bwd {M_}x{K}x{N}", lambda: ops.linear_backward(xx, W, y, dy, "relu"), flops=4 * M_ * K * N)
 if "fused" in which:
     from models_amd.synthetic import CRITEO_CARDINALITIES
 
