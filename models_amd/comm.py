@@ -65,6 +65,25 @@ def default() -> Optional["Comm"]:
     return _DEFAULT
 
 
+def _wait_or_die(what: str, seconds: float = 180.0) -> None:
+    """Wait for the current stream with a deadline.  A collective that never completes cannot be cancelled from here (the
+    stream is stuck behind it), so the only useful outcome is a message and a non-zero exit instead of a silent hang of
+    every rank; ``MERLIN_HIP_COMM=torch`` then runs the same job on torch.distributed."""
+    import os
+    import sys
+    import time
+
+    ev = torch.cuda.Event()
+    ev.record()
+    deadline = time.monotonic() + float(os.environ.get("MERLIN_HIP_COMM_TIMEOUT", seconds))
+    while not ev.query():
+        if time.monotonic() > deadline:
+            print(f"[models_amd.comm] {what} did not complete within the deadline: giving up "
+                  "(set MERLIN_HIP_COMM=torch to keep the collectives on torch.distributed)", file=sys.stderr, flush=True)
+            os._exit(3)
+        time.sleep(0.002)
+
+
 class Comm:
     def __init__(self, handle: C.c_void_p, rank: int, world: int):
         self.handle, self.rank, self.world = handle, rank, world
@@ -100,12 +119,13 @@ class Comm:
         W, r = self.world, self.rank
         send = (torch.arange(W * 64, device=dev, dtype=torch.float32) + 1000.0 * r).contiguous()
         got, want = torch.empty_like(send), torch.empty_like(send)
-        self.alltoall(send, got)
-        dist.all_to_all_single(want, send)
         red, red_t = send.clone(), send.clone()
-        self.allreduce_(red)
+        dist.all_to_all_single(want, send)
         dist.all_reduce(red_t)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # torch's communicator is idle: the two below are the only collectives in flight
+        self.alltoall(send, got)
+        self.allreduce_(red)
+        _wait_or_die("the first collectives of the C-ABI communicator")
         if not (torch.equal(got, want) and torch.allclose(red, red_t, rtol=1e-6, atol=0)):
             raise RuntimeError("self-check against torch.distributed failed")
 
