@@ -275,7 +275,9 @@ def test_lazy_adam_reproduces_the_reference_known_answers(device):
 
 
 # ---- second-generation GEMM core in the backward: dX (NT) for K, N >= 256 and dW (split-M TN) for K >= 256, N >= 128 --------
-@pytest.mark.parametrize("M,K,N,ldx", [(513, 300, 260, 300), (700, 415, 128, 416), (1030, 512, 256, 512), (2500, 260, 388, 264)])
+# (4100, 415, 128): the DLRM top layer's backward shape at more than 4096 rows; (4133, 200, 96): narrow odd-sized layer
+@pytest.mark.parametrize("M,K,N,ldx", [(513, 300, 260, 300), (700, 415, 128, 416), (1030, 512, 256, 512), (2500, 260, 388, 264),
+                                       (4100, 415, 128, 416), (4133, 200, 96, 200)])
 @pytest.mark.parametrize("act,x_act", [(None, None), ("relu", "relu"), ("sigmoid", "sigmoid")])
 def test_wide_linear_backward(device, M, K, N, ldx, act, x_act):
     g = torch.Generator().manual_seed(M + N + K)
@@ -311,12 +313,14 @@ def test_wide_backward_equals_first_generation_core(device):
         import torch, sys
         from models_amd import ops
         g = torch.Generator().manual_seed(5)
-        M, K, N = 1500, 512, 384
-        x = torch.randn(M, K, generator=g).cuda(); W = (torch.randn(K, N, generator=g) * 0.1).cuda()
-        dy = torch.randn(M, N, generator=g).cuda()
-        y = ops.linear(x, W, None, "relu")
-        dx, dW, db = ops.linear_backward(x, W, y, dy, "relu")
-        torch.save([y.cpu(), dx.cpu(), dW.cpu(), db.cpu()], sys.argv[1])
+        out = []
+        for M, K, N in ((1500, 512, 384), (4200, 416, 128)):  # the second shape: the DLRM top layer (K = 416, short contraction in dX)
+            x = torch.randn(M, K, generator=g).cuda(); W = (torch.randn(K, N, generator=g) * 0.1).cuda()
+            dy = torch.randn(M, N, generator=g).cuda()
+            y = ops.linear(x, W, None, "relu")
+            dx, dW, db = ops.linear_backward(x, W, y, dy, "relu", x_activation="relu" if M > 4000 else None)
+            out.append([y.cpu(), dx.cpu(), dW.cpu(), db.cpu()])
+        torch.save(out, sys.argv[1])
     ''')
     import os, tempfile
     outs = []
@@ -328,9 +332,9 @@ def test_wide_backward_equals_first_generation_core(device):
         with tempfile.NamedTemporaryFile(suffix=".pt") as f:
             subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
             outs.append(torch.load(f.name))
-    (y0, dx0, dW0, db0), (y1, dx1, dW1, db1) = outs
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dW0, dW1)
-    torch.testing.assert_close(db0, db1, atol=1e-4, rtol=1e-5)  # column sums: 16- vs 32-row partial sums per k-tile
+    for (y0, dx0, dW0, db0), (y1, dx1, dW1, db1) in zip(*outs):
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dW0, dW1)
+        torch.testing.assert_close(db0, db1, atol=1e-4, rtol=1e-5)  # column sums: 16- vs 32-row partial sums per k-tile
 
 
 def test_dense_adam_reproduces_the_reference_known_answers(device):
