@@ -506,7 +506,7 @@ __device__ __forceinline__ void wave_chunk(int64_t B, int64_t* b0, int64_t* b1) 
     *b1 = *b0 + per < B ? *b0 + per : B;
 }
 
-template <typename IdT, int DT, int NV>
+template <typename IdT, int DT, int NV, bool STAGED>
 __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, const float* __restrict__ dense,
                                                             int64_t ld_dense, int dense_slot, int64_t B, int F,
                                                             int append_dense, float* __restrict__ out, int64_t ldo) {
@@ -538,11 +538,37 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
     // stores count in vmcnt like loads, so the s_waitcnt vmcnt(0) in front of the LDS writes at the top of an iteration also
     // waited for the stores the previous iteration had issued at its very end; issued together with the loads they have a
     // whole MFMA phase to complete.
-    f32x4 o00 = {0.f, 0.f, 0.f, 0.f}, o01 = o00, o11 = o00;
+    // They go out as TWO coalesced 16-byte stores per lane (the P + T <= 416 floats of a sample are contiguous): straight from
+    // the MFMA C layout a sample took 12 scattered dword stores of four <= 64-byte runs each -- ~80 partial-line write requests
+    // at the L2 per sample, 60 % of all L2 requests of the kernel, with the wavefronts stalled on instruction issue 71 % of
+    // their cycles (SQ_WAIT_INST_ANY) and the L1 stalled on pending requests 72 % of its busy cycles.  The values pass through
+    // the first rows of the wavefront's own X slab, which is dead between the last fragment read of a sample and the row
+    // writes of the next one (LDS operations of one wavefront execute in order).
+    // STAGED is the launcher's choice: 16-byte aligned output rows of at most 512 floats.  (The staging area [0, nout) stays inside
+    // rows < F, which the next sample's row writes restore: F (F - 1) / 2 + D <= F (D + 4) for every F <= 32, D >= 16.)
+    const int nout = P + ((append_dense && dense_slot >= 0) ? D : 0);  // floats of one output row
+    constexpr bool staged = STAGED;
+    f32x4 ov0 = {0.f, 0.f, 0.f, 0.f}, ov1 = ov0;
+    f32x4 o00 = ov0, o01 = ov0, o11 = ov0;
     float odense = 0.f;
     float* oprev = nullptr;
     auto flush = [&]() {
         if (!oprev) return;  // wave-uniform
+        if (staged) {
+            // whole float4s inside the row: the tail of the last one (< 4 floats past P + T) lands in the row's ld padding or is
+            // cut to scalar stores when the row has none
+            const int n4 = nout >> 2, rem = nout & 3;
+            if (lane < n4) *reinterpret_cast<f32x4*>(oprev + lane * 4) = ov0;
+            if (64 + lane < n4) *reinterpret_cast<f32x4*>(oprev + 256 + lane * 4) = ov1;
+            if (rem) {
+                const bool lo = n4 < 64;
+                if (lane == (lo ? n4 : n4 - 64)) {
+                    const f32x4 v = lo ? ov0 : ov1;
+                    for (int r = 0; r < rem; ++r) oprev[n4 * 4 + r] = v[r];
+                }
+            }
+            return;
+        }
         store_tile(o00, 0, 0, lane, F, oprev);
         if (two) {
             store_tile(o01, 0, 1, lane, F, oprev);
@@ -589,16 +615,37 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
             }
         }
         oprev = out + b * ldo;
-        o00 = acc00;
-        o01 = acc01;
-        o11 = acc11;
-        if (append_dense && dense_slot >= 0) {
-            static_assert(D <= 128, "dense copy: two values per lane at most");
-            if (D <= 64) {
-                if (lane < D) odense = Xs[dense_slot * LD + lane];
-            } else {  // D = 128: the second half goes out at once (rare configuration)
-                odense = Xs[dense_slot * LD + lane];
-                oprev[P + 64 + lane] = Xs[dense_slot * LD + 64 + lane];
+        if (staged) {
+            float dlo = 0.f, dhi = 0.f;
+            if (append_dense && dense_slot >= 0) {
+                if (lane < D) dlo = Xs[dense_slot * LD + lane];
+                if (D > 64) dhi = Xs[dense_slot * LD + 64 + lane];
+            }
+            __builtin_amdgcn_wave_barrier();  // the dense row is in registers before the staging area is overwritten
+            store_tile(acc00, 0, 0, lane, F, Xs);
+            if (two) {
+                store_tile(acc01, 0, 1, lane, F, Xs);
+                store_tile(acc11, 1, 1, lane, F, Xs);
+            }
+            if (append_dense && dense_slot >= 0) {
+                if (lane < D) Xs[P + lane] = dlo;
+                if (D > 64) Xs[P + 64 + lane] = dhi;
+            }
+            __builtin_amdgcn_wave_barrier();
+            ov0 = *reinterpret_cast<const f32x4*>(Xs + lane * 4);
+            if (nout > 256) ov1 = *reinterpret_cast<const f32x4*>(Xs + 256 + lane * 4);  // (reads past nout: stale slab floats, never stored)
+        } else {
+            o00 = acc00;
+            o01 = acc01;
+            o11 = acc11;
+            if (append_dense && dense_slot >= 0) {
+                static_assert(D <= 128, "dense copy: two values per lane at most");
+                if (D <= 64) {
+                    if (lane < D) odense = Xs[dense_slot * LD + lane];
+                } else {  // D = 128: the second half goes out at once (rare configuration)
+                    odense = Xs[dense_slot * LD + lane];
+                    oprev[P + 64 + lane] = Xs[dense_slot * LD + 64 + lane];
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -884,9 +931,11 @@ int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int
     const size_t lds = (size_t)4 * IMAXF * (D + 4) * sizeof(float);
     const dim3 grid = fused_grid(B, lds);
     hipStream_t s_ = mh_stream(stream);
+    // coalesced 16-byte output stores through the LDS slab (see the kernel) when the rows allow them
+    const bool staged = ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && P + T <= 512;
 #define MH_LAUNCH_FUSED_FWD(IDT, DT)                                                                             \
     {                                                                                                            \
-        auto kern = dlrm_fused_fwd_kernel<IDT, DT, 8>;                                                           \
+        auto kern = staged ? dlrm_fused_fwd_kernel<IDT, DT, 8, true> : dlrm_fused_fwd_kernel<IDT, DT, 8, false>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, append_dense, out, ldo); \
     }

@@ -121,6 +121,36 @@ def test_fused_gather_interaction_fwd_bwd(device, F, D, dense_pos, idt):
     torch.testing.assert_close(dx, dx_ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("F,D,dense_pos", [(27, 64, 26), (5, 16, 2), (17, 32, 0), (9, 128, None), (32, 16, 31), (12, 128, 3), (2, 64, 0)])
+def test_fused_forward_coalesced_output_path_equals_scattered_path(device, F, D, dense_pos):
+    """Output rows that are 16-byte aligned (ld % 4 == 0) leave the fused kernel as two float4 stores per lane staged through
+    the LDS slab; any other row takes the scattered dword stores.  Same arithmetic: the two agree bit for bit, the columns
+    behind the row (the ld padding) are never written, and a chunk boundary (B not a multiple of the wavefront count) works."""
+    rng = np.random.default_rng(F + D)
+    B = 1237
+    tabs, ids = [], []
+    for s_ in range(F):
+        if s_ == dense_pos:
+            tabs.append(None)
+            ids.append(None)
+            continue
+        V = int(rng.integers(3, 400))
+        tabs.append(_t(rng.normal(size=(V, D)).astype(np.float32), device))
+        ids.append(_t(rng.integers(0, V, size=B).astype(np.int32), device))
+    dense = None if dense_pos is None else _t(rng.normal(size=(B, D)).astype(np.float32), device)
+    n = F * (F - 1) // 2 + (D if dense_pos is not None else 0)
+    ld_a = (n + 3) // 4 * 4 + 4           # aligned rows with at least 4 floats of padding
+    ld_u = ld_a + 1                       # rows that are not 16-byte aligned
+    buf_a = torch.full((B, ld_a), -7.0, device=device)
+    buf_u = torch.full((B, ld_u), -7.0, device=device)
+    ops.dlrm_interaction_fused(tabs, ids, dense, out=buf_a[:, :n])
+    ops.dlrm_interaction_fused(tabs, ids, dense, out=buf_u[:, :n])
+    assert torch.equal(buf_a[:, :n], buf_u[:, :n])
+    assert bool((buf_a[:, n:] == -7.0).all()) and bool((buf_u[:, n:] == -7.0).all())
+    ref = ops.dlrm_interaction_fused(tabs, ids, dense)
+    assert torch.equal(ref, buf_a[:, :n])
+
+
 @pytest.mark.parametrize("idt", [torch.int32, torch.int64])
 def test_fused_segment_equals_unfused_pair_bitwise_long_runs(device, idt):
     """BASELINE configs[1] geometry (26 tables + bottom-MLP row, D = 64) at a batch where every wavefront walks a run of
