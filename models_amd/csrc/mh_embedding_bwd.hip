@@ -1283,7 +1283,6 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
     const int64_t need = mh_embedding_bag_bwd_workspace_bytes(B, nnz, D);
     MH_REQUIRE(need >= 0 && workspace_bytes >= need, "mh_embedding_bag_bwd: workspace too small (%lld < %lld)",
                (long long)workspace_bytes, (long long)need);
-    hipStream_t s = mh_stream(stream);
     char* ws = static_cast<char*>(workspace);
     float* scale = reinterpret_cast<float*>(ws);
     ws += align_up((size_t)B * sizeof(float), 256);

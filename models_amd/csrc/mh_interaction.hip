@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
 // Pipelined variant (F*D <= 2048 floats, D % 16 == 0): wavefronts are fully independent (private
 // LDS slab, no workgroup barrier); the NEXT sample's rows are prefetched into registers while the
 // current one is on the matrix pipe, so HBM latency is hidden by MFMA work instead of by occupancy.
-template <int NV>
+template <int NV, bool STAGED>
 __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const float* __restrict__ x, int64_t B,
                                                                       int F, int D,
                                                                       const float* __restrict__ tail,
@@ -178,14 +178,40 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const flo
             }
         }
         float* orow = out + b * ldo;
-        store_tile(acc00, 0, 0, lane, F, orow);
-        if (two) {
-            store_tile(acc01, 0, 1, lane, F, orow);
-            store_tile(acc11, 1, 1, lane, F, orow);
-        }
-        if (tail) {
-            if (lane < T) orow[P + lane] = tv;
-            for (int t = lane + 64; t < T; t += 64) orow[P + t] = tail[b * ld_tail + t];
+        if (STAGED) {
+            // coalesced 16-byte stores staged through the first rows of the slab, as in dlrm_fused_fwd_kernel (the launcher
+            // checks: 16-byte aligned rows, P + T <= 512, T <= 64)
+            __builtin_amdgcn_wave_barrier();
+            store_tile(acc00, 0, 0, lane, F, Xs);
+            if (two) {
+                store_tile(acc01, 0, 1, lane, F, Xs);
+                store_tile(acc11, 1, 1, lane, F, Xs);
+            }
+            if (tail && lane < T) Xs[P + lane] = tv;
+            __builtin_amdgcn_wave_barrier();
+            const int nout = P + T, n4 = nout >> 2, rem = nout & 3;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(Xs + lane * 4);
+            f32x4 v1 = {0.f, 0.f, 0.f, 0.f};
+            if (nout > 256) v1 = *reinterpret_cast<const f32x4*>(Xs + 256 + lane * 4);
+            if (lane < n4) *reinterpret_cast<f32x4*>(orow + lane * 4) = v0;
+            if (64 + lane < n4) *reinterpret_cast<f32x4*>(orow + 256 + lane * 4) = v1;
+            if (rem) {
+                const bool lo = n4 < 64;
+                if (lane == (lo ? n4 : n4 - 64)) {
+                    const f32x4 v = lo ? v0 : v1;
+                    for (int r = 0; r < rem; ++r) orow[n4 * 4 + r] = v[r];
+                }
+            }
+        } else {
+            store_tile(acc00, 0, 0, lane, F, orow);
+            if (two) {
+                store_tile(acc01, 0, 1, lane, F, orow);
+                store_tile(acc11, 1, 1, lane, F, orow);
+            }
+            if (tail) {
+                if (lane < T) orow[P + lane] = tv;
+                for (int t = lane + 64; t < T; t += 64) orow[P + t] = tail[b * ld_tail + t];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         b = bn;
@@ -817,7 +843,10 @@ int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, 
         }
     }
     if (D % 16 == 0 && F * (D / 4) <= 64 * 8) {
-        auto kern = dot_interaction_fwd_pipe_kernel<8>;
+        // (staging area [0, P + T) inside rows < F of the [32][D + 4] slab: F (F - 1) / 2 + T <= F (D + 4) holds for T <= D + 4)
+        const bool staged = ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && P + T <= 512 && T <= 64 &&
+                            P + T <= F * (D + 4);
+        auto kern = staged ? dot_interaction_fwd_pipe_kernel<8, true> : dot_interaction_fwd_pipe_kernel<8, false>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, mh_stream(stream), x, B, F, D, tail, ld_tail, T, out, ldo);
     } else {

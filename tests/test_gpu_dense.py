@@ -151,6 +151,28 @@ def test_fused_forward_coalesced_output_path_equals_scattered_path(device, F, D,
     assert torch.equal(ref, buf_a[:, :n])
 
 
+@pytest.mark.parametrize("F,D,T", [(27, 64, 64), (5, 16, 16), (17, 32, 0), (32, 16, 16), (12, 128, 40), (2, 64, 64), (27, 64, 100)])
+def test_interaction_forward_coalesced_output_path_equals_scattered_path(device, F, D, T):
+    """mh_dot_interaction_fwd: aligned output rows take the staged float4 stores, other rows (and tails wider than 64) the
+    scattered ones; bit-identical, the ld padding untouched."""
+    g = torch.Generator().manual_seed(F * D + T)
+    B = 1237
+    x = torch.randn(B, F, D, generator=g).to(device)
+    tail = torch.randn(B, T, generator=g).to(device) if T else None
+    n = F * (F - 1) // 2 + T
+    ld_a = (n + 3) // 4 * 4 + 4
+    buf_a = torch.full((B, ld_a), -7.0, device=device)
+    buf_u = torch.full((B, ld_a + 1), -7.0, device=device)
+    ops.dot_interaction(x, tail, out=buf_a[:, :n])
+    ops.dot_interaction(x, tail, out=buf_u[:, :n])
+    assert torch.equal(buf_a[:, :n], buf_u[:, :n])
+    assert bool((buf_a[:, n:] == -7.0).all()) and bool((buf_u[:, n:] == -7.0).all())
+    ref = O.dot_interaction(x.cpu().numpy())
+    np.testing.assert_allclose(buf_a[:, :n - T].cpu().numpy(), ref, atol=ATOL * max(1.0, D / 64) * 4, rtol=1e-5)
+    if T:
+        assert torch.equal(buf_a[:, n - T:n], tail)
+
+
 @pytest.mark.parametrize("idt", [torch.int32, torch.int64])
 def test_fused_segment_equals_unfused_pair_bitwise_long_runs(device, idt):
     """BASELINE configs[1] geometry (26 tables + bottom-MLP row, D = 64) at a batch where every wavefront walks a run of
