@@ -411,6 +411,14 @@ int32_t mh_batchnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
  * byte counts, whole 4-byte words, 4-byte aligned) copied by ONE launch into the static inputs a captured graph reads. */
 int32_t mh_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t count, mh_stream_t stream);
 
+/* ---- ConcatFeatures of narrow fp32 columns (merlin/models/tf/core/aggregation.py:38-66 over the Continuous block's columns,
+ * tf/inputs/continuous.py:73-138): out[b, off_i + c] = src_i[b, c], off_i = width_0 + ... + width_{i-1}; `src`, `ld`, `width` are
+ * HOST arrays of `count` <= MH_MAX_FEATURES entries (device pointers of [B, width_i] row-major sources with row stride ld_i).
+ * Columns [sum width, pad_to) are written as zeros (pad_to = 0: none), so that a consumer may read 16-byte aligned rows;
+ * at most 150 output columns, ldo >= max(sum width, pad_to). */
+int32_t mh_concat_columns(const float* const* src, const int64_t* ld, const int32_t* width, int32_t count, int64_t B, float* out,
+                          int64_t ldo, int32_t pad_to, mh_stream_t stream);
+
 /* ---- measurement probe ("record a stream-copy peak on the box") -----------------------------------
  * dst[0 .. bytes) = src[0 .. bytes) with a float4 grid-stride kernel (16-byte aligned, bytes % 16 == 0): the streaming
  * rate a hand-written kernel reaches on this GPU, reported by bench.py beside the 8 TB/s spec peak. */

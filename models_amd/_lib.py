@@ -84,6 +84,7 @@ SIGNATURES = {
     "mh_batchnorm_fwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _f32, _f32, _i32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p]),
     "mh_batchnorm_bwd": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
     "mh_copy_many": (_i32, [_p, _p, _p, _i32, _p]),
+    "mh_concat_columns": (_i32, [_p, _p, _p, _i32, _i64, _p, _i64, _i32, _p]),
     "mh_stream_copy": (_i32, [_p, _p, _i64, _p]),
     "mh_log_uniform_sample_workspace_bytes": (_i64, [_i64, _i32]),
     "mh_log_uniform_sample": (_i32, [_i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),

@@ -223,13 +223,21 @@ def _as_2d(t: torch.Tensor) -> torch.Tensor:
 
 class ConcatFeatures(Block):
     """aggregation.py:38-66: concat over the last axis in sorted-key order (fp32).
-    torch.cat is buffer plumbing (one HBM copy); the fused model paths avoid it by letting the
-    producer kernels write straight into the concatenated buffer."""
+    Wide parts never come here: the fused model paths let the producer kernels write straight into the concatenated
+    buffer.  Narrow fp32 device columns (the continuous features) take ``mh_concat_columns``; anything else (CPU tensors,
+    other dtypes, very wide inputs) is a plain ``torch.cat`` (buffer plumbing)."""
 
     def forward(self, inputs: TabularData):
         self._keys = sorted(inputs)
-        self._widths = [_as_2d(inputs[k]).shape[1] for k in self._keys]
-        return torch.cat([_as_2d(inputs[k]).float() for k in self._keys], dim=-1)
+        cols = [_as_2d(inputs[k]) for k in self._keys]
+        self._widths = [c.shape[1] for c in cols]
+        if (cols and len(cols) <= 64 and sum(self._widths) <= 144
+                and all(c.is_cuda and c.dtype == torch.float32 for c in cols)):
+            # narrow device columns (the continuous features of a batch): ONE launch, rows padded to 16 bytes with zeros
+            from . import ops
+
+            return ops.concat_columns(cols, pad_to=4)
+        return torch.cat([c.float() for c in cols], dim=-1)
 
     def backward(self, grad):
         out, o = {}, 0

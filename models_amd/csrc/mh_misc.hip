@@ -295,6 +295,42 @@ __global__ __launch_bounds__(256) void copy_many_kernel(const CopyManyArgs a) {
     }
 }
 
+
+// ---- ConcatFeatures of narrow columns: out[b, off_i + c] = src_i[b, c] -------------------------------------------------------
+// (the 13 continuous features of a DLRM batch arrive as 13 [B] / [B, 1] tensors and feed the bottom MLP as one [B, 13] matrix.)
+// A workgroup takes 256 rows: every source column is read down the batch (coalesced 1 KB per wavefront for width-1 sources),
+// transposed through LDS, and the [256, W] block leaves as contiguous rows; columns [W, pad_to) are written as zeros, so a
+// consumer may treat the row as pad_to wide (16-byte aligned rows for the vector paths of the Dense kernels).
+struct ConcatArgs {
+    const float* src[MH_MAX_FEATURES];
+    int64_t ld[MH_MAX_FEATURES];
+    int32_t width[MH_MAX_FEATURES];
+    int32_t off[MH_MAX_FEATURES];
+    int32_t n, W, Wp;
+};
+
+__global__ __launch_bounds__(256) void concat_columns_kernel(const ConcatArgs a, int64_t B, float* __restrict__ out, int64_t ldo) {
+    extern __shared__ float tile[];  // [256][Wp + 1]
+    const int LT = a.Wp + 1;
+    const int64_t b0 = (int64_t)blockIdx.x * 256;
+    const int64_t b = b0 + threadIdx.x;
+    if (b < B) {
+        for (int i = 0; i < a.n; ++i) {  // uniform loop: the table reads are scalar loads
+            const float* __restrict__ s = a.src[i] + b * a.ld[i];
+            const int w = a.width[i], o = a.off[i];
+            for (int c = 0; c < w; ++c) tile[threadIdx.x * LT + o + c] = s[c];
+        }
+        for (int c = a.W; c < a.Wp; ++c) tile[threadIdx.x * LT + c] = 0.f;
+    }
+    __syncthreads();
+    const int rows = (int)((B - b0) < 256 ? (B - b0) : 256);
+    const int total = rows * a.Wp;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int r = e / a.Wp, c = e - r * a.Wp;
+        out[(b0 + r) * ldo + c] = tile[r * LT + c];
+    }
+}
+
 extern "C" {
 
 int32_t mh_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t count, mh_stream_t stream) {
@@ -325,6 +361,41 @@ int32_t mh_copy_many(const void* const* src, void* const* dst, const int64_t* by
         hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, a);
     }
     MH_CHECK_LAUNCH("mh_copy_many");
+    return MH_OK;
+}
+
+int32_t mh_concat_columns(const float* const* src, const int64_t* ld, const int32_t* width, int32_t count, int64_t B, float* out,
+                          int64_t ldo, int32_t pad_to, mh_stream_t stream) {
+    MH_REQUIRE(src && ld && width && out, "mh_concat_columns: null argument");
+    MH_REQUIRE(count >= 1 && count <= MH_MAX_FEATURES, "mh_concat_columns: count=%d outside [1,%d]", count, MH_MAX_FEATURES);
+    ConcatArgs a;
+    int W = 0;
+    for (int i = 0; i < count; ++i) {
+        MH_REQUIRE(src[i] && width[i] >= 1 && ld[i] >= width[i], "mh_concat_columns: source %d: null, empty or ld < width", i);
+        a.src[i] = src[i];
+        a.ld[i] = ld[i];
+        a.width[i] = width[i];
+        a.off[i] = W;
+        W += width[i];
+    }
+    for (int i = count; i < MH_MAX_FEATURES; ++i) {
+        a.src[i] = nullptr;
+        a.ld[i] = 0;
+        a.width[i] = 0;
+        a.off[i] = 0;
+    }
+    const int Wp = pad_to > W ? pad_to : W;
+    MH_REQUIRE(Wp <= 150, "mh_concat_columns: at most 150 output columns (got %d): wider concatenations are plain row copies", Wp);
+    MH_REQUIRE(ldo >= Wp, "mh_concat_columns: ldo=%lld < %d", (long long)ldo, Wp);
+    if (B <= 0) return MH_OK;
+    a.n = count;
+    a.W = W;
+    a.Wp = Wp;
+    const size_t lds = (size_t)256 * (Wp + 1) * sizeof(float);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(concat_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(concat_columns_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), lds, mh_stream(stream), a, B, out, ldo);
+    MH_CHECK_LAUNCH("mh_concat_columns");
     return MH_OK;
 }
 

@@ -1404,6 +1404,29 @@ def copy_many(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> Non
         check(lib.mh_copy_many(_host_ptr_array(ps), _host_ptr_array(pd), (C.c_int64 * len(nb))(*nb), len(ps), _stream()), "mh_copy_many")
 
 
+def concat_columns(cols: Sequence[torch.Tensor], pad_to: int = 0) -> torch.Tensor:
+    """``ConcatFeatures`` of narrow fp32 device columns (``[B]`` / ``[B, w]``) in ONE launch: returns the ``[B, sum w]`` view
+    of a ``[B, ld]`` buffer, ``ld`` = the width rounded up to a multiple of ``pad_to`` (0: no padding) with the padding
+    columns zeroed -- 16-byte aligned rows for the vector paths of the Dense kernels."""
+    lib = _lib.load()
+    two_d = []
+    for i, c in enumerate(cols):
+        _dev(c, f"cols[{i}]", torch.float32)
+        c2 = c.reshape(c.shape[0], -1) if c.dim() != 2 else c
+        if c2.stride(1) != 1 and c2.shape[1] > 1:
+            c2 = c2.contiguous()
+        two_d.append(c2)
+    B = two_d[0].shape[0]
+    W = sum(c.shape[1] for c in two_d)
+    ld = (W + pad_to - 1) // pad_to * pad_to if pad_to > 0 else W
+    out = torch.empty((B, ld), dtype=torch.float32, device=two_d[0].device)
+    if B:
+        n = len(two_d)
+        check(lib.mh_concat_columns(_host_ptr_array([c.data_ptr() for c in two_d]), (C.c_int64 * n)(*[int(c.stride(0)) if c.shape[0] > 1 else c.shape[1] for c in two_d]),
+                                    (C.c_int32 * n)(*[int(c.shape[1]) for c in two_d]), n, B, _ptr(out), ld, ld, _stream()), "mh_concat_columns")
+    return out[:, :W]
+
+
 def stream_copy(src: torch.Tensor, dst: torch.Tensor) -> None:
     """``dst[:] = src`` with the library's float4 copy kernel (measurement probe: the box's achievable streaming rate)."""
     lib = _lib.load()

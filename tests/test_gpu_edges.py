@@ -88,3 +88,28 @@ def test_int32_and_int64_ids_agree_in_backward(device):
     ops.embedding_gather_backward([a], None, [ids.to(torch.int32).to(device)], grad.to(device), [0], "sgd", 0.1)
     ops.embedding_gather_backward([b], None, [ids.to(torch.int64).to(device)], grad.to(device), [0], "sgd", 0.1)
     torch.testing.assert_close(a, b, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 255, 1237])
+def test_concat_columns_equals_torch_cat_and_zero_pads(device, B):
+    """mh_concat_columns (ConcatFeatures of the continuous columns, tf/core/aggregation.py:38-66): [B] / [B, w] / strided sources,
+    bit-equal to torch.cat, padding columns zero, rows 16-byte aligned."""
+    from models_amd import ops
+
+    g = torch.Generator().manual_seed(B)
+    wide = torch.randn(B, 7, generator=g).to(device)
+    cols = [torch.randn(B, generator=g).to(device), torch.randn(B, 1, generator=g).to(device), wide[:, 2:5],
+            torch.randn(B, 3, generator=g).to(device)] + [torch.randn(B, generator=g).to(device) for _ in range(9)]
+    out = ops.concat_columns(cols, pad_to=4)
+    ref = torch.cat([c.reshape(B, -1) for c in cols], dim=-1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    assert out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+    base = torch.as_strided(out, (B, out.stride(0)), (out.stride(0), 1))
+    assert bool((base[:, ref.shape[1]:] == 0).all())
+    # the block the models call
+    from models_amd.core import ConcatFeatures
+
+    agg = ConcatFeatures()
+    named = {f"c{i:02d}": c for i, c in enumerate(cols)}
+    assert torch.equal(agg(named), ref)
