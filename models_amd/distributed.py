@@ -898,6 +898,9 @@ class DistributedDLRM:
             n_head = (n_dense + 1 + 63) // 64 * 64  # + one slot for the loss; table gradients start 256-byte aligned
             total = (n_head + n_rep + 63) // 64 * 64
             if self._bucket is None or self._bucket.numel() != total:
+                from . import ops as _ops
+
+                _ops.park_replaced(self._bucket)
                 self._bucket = torch.zeros(total, dtype=torch.float32, device=dstack.device)
             bucket = self._bucket
             rep_grads, o, grad_of = [], n_head, {}
@@ -1214,6 +1217,9 @@ class DistributedModel:
         total = (n_head + n_rep + 64 * W - 1) // (64 * W) * (64 * W)
         dev = params[0].data.device
         if self._bucket is None or self._bucket.numel() != total:
+            from . import ops as _ops
+
+            _ops.park_replaced(self._bucket)
             self._bucket = torch.zeros(total, dtype=torch.float32, device=dev)
         bucket = self._bucket
         o = n_head

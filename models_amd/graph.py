@@ -75,6 +75,9 @@ class GraphedStep:
                 fn(self.inputs)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import ops
+
+        ops.CAPTURED_STEPS[0] += 1  # from here on, replaced persistent buffers are parked instead of freed (ops.park_replaced)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.output = fn(self.inputs)
@@ -116,6 +119,7 @@ class SegmentedStep:
         torch.cuda.synchronize()
         if ops.SIDE.recorder is not None:
             raise RuntimeError("a step is already being recorded")
+        ops.CAPTURED_STEPS[0] += 1  # from here on, replaced persistent buffers are parked instead of freed (ops.park_replaced)
         rec = ops.StepRecorder()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())

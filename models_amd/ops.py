@@ -628,6 +628,22 @@ def dot_interaction(
 _WS = {}
 
 
+# Persistent buffers (workspaces, a block's padded input buffer, a sampler's hold buffers) are baked BY ADDRESS into every step that
+# was captured while they were current (graph.GraphedStep / SegmentedStep).  When such a buffer is replaced later -- a call with a
+# larger batch, another model growing a shared workspace -- the old block must stay allocated: a captured step that is replayed
+# afterwards still reads and writes it (returned to the caching allocator it is handed to someone else; after
+# torch.cuda.empty_cache() it is unmapped and the replay dies with a GPU memory fault).  So: once any step has been captured in
+# this process, replaced persistent buffers are parked here for good.  Cost: one stale block per growth event.
+CAPTURED_STEPS = [0]   # incremented by graph.GraphedStep / graph.SegmentedStep
+_PARKED: list = []
+
+
+def park_replaced(buf) -> None:
+    """Call with the OLD tensor whenever a persistent buffer that kernels address directly is replaced."""
+    if buf is not None and CAPTURED_STEPS[0] > 0:
+        _PARKED.append(buf)
+
+
 def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     """Grow-only per-(device, tag) scratch buffers (caller-provided workspaces of the C ABI)."""
     key = (str(device), tag)
@@ -637,6 +653,7 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
             # a kernel queued on a side stream may still be using the old block: it must not go back to the caching
             # allocator (which would hand it to a launch-stream allocation) before the side streams are joined
             SIDE.retire(buf)
+            park_replaced(buf)  # ... and never, if a captured step may still address it
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf

@@ -320,6 +320,11 @@ class CachedCrossBatchSampler(CandidateSampler):
                 # from a hipGraph can only hand a tensor to its next replay through an address that does not change
                 hold = getattr(self, "_hold", None)
                 if hold is None or hold.id.shape != items.id.shape or hold.embedding.shape != items.embedding.shape:
+                    if hold is not None:  # a captured step may still address the old buffers
+                        from . import ops
+
+                        ops.park_replaced(hold.id)
+                        ops.park_replaced(hold.embedding)
                     hold = Candidate(torch.empty_like(items.id), {EMBEDDING_KEY: torch.empty_like(items.embedding.detach())})
                 hold.id.copy_(items.id.detach())
                 hold.embedding.copy_(items.embedding.detach())

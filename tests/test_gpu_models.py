@@ -541,6 +541,84 @@ def test_graph_replayed_train_steps_equal_eager_steps(device, mode, monkeypatch)
         print("segments:", [(i, sg["stream"], sg["deps"], bool(sg.get("empty"))) for i, sg in enumerate(gs.segments)])
 
 
+@pytest.mark.parametrize("mode", ["one_graph", "segmented"])
+def test_captured_step_survives_buffer_growth_elsewhere_and_empty_cache(device, mode):
+    """A captured step addresses its workspaces and the block's padded input buffer directly.  Other work of the process -- a
+    bigger batch through the same model, another model growing the shared workspaces -- replaces those buffers; the old blocks
+    must stay allocated (ops.park_replaced), or the next replay writes into memory the caching allocator has handed to someone
+    else, and after torch.cuda.empty_cache() dies with a GPU memory fault (bench.py's sustained region did, in segmented mode,
+    after its secondary workloads had grown the workspace of the sparse-update preparation).  Checked here: every replaced
+    workspace is still alive, blocks handed out afterwards are never written by the replay, and the replayed steps still train
+    exactly like eager steps."""
+    from models_amd import ops
+    from models_amd.graph import GraphedStep, SegmentedStep
+
+    cards = {"C1": 50000, "C2": 7, "C3": 3000, "C4": 50}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+
+    def build(seed=7):
+        m = mm.DLRMModel(schema, embedding_dim=16, bottom_block=mm.MLPBlock([32, 16], device=device, seed=seed),
+                         top_block=mm.MLPBlock([32, 8], device=device, seed=seed + 10), device=device)
+        m.output.to_call.seed = 99
+        m.compile(optimizer="adagrad", learning_rate=0.05)
+        return m
+
+    g = torch.Generator().manual_seed(21)
+    def batch(B):
+        x, xd = _batch(schema, B, g, device)
+        return xd, torch.randint(0, 2, (B, 1), generator=g).float().to(device)
+
+    ops._WS.clear()  # start from fresh workspaces whatever earlier tests grew (their captured steps are not replayed again)
+    B = 16384  # workspaces of a few MB: blocks of their own in the caching allocator
+    batches = [batch(B) for _ in range(3)]
+    a, b = build(), build()
+    a(batches[0][0]), b(batches[0][0])
+    init = [p.data.clone() for p in a.parameters()]
+    for pb, w in zip(b.parameters(), init):
+        pb.data.copy_(w)
+
+    def step(inp):
+        return b.train_step({k: v for k, v in inp.items() if k != "__label__"}, inp["__label__"])
+
+    static = dict(batches[0][0])
+    static["__label__"] = batches[0][1]
+    gs = (GraphedStep if mode == "one_graph" else SegmentedStep)(step, static, warmup=2)
+    for pb, w in zip(b.parameters(), init):
+        pb.data.copy_(w)
+        for v in pb.state.values():
+            v.fill_(0.1)
+    before = {k: (v.data_ptr(), v.numel()) for k, v in ops._WS.items()}
+    parked_before = len(ops._PARKED)
+    # --- the rest of the process: bigger batches grow the shared workspaces and replace b's padded top-MLP input buffer
+    other = build(seed=3)
+    big = batch(4 * B)
+    other(big[0])
+    other.train_step(*big)
+    with torch.no_grad():
+        b(big[0])       # same model, other batch size: its persistent input buffer is re-made
+    del other, big
+    torch.cuda.synchronize()
+    grown = [k for k, (ptr, n) in before.items() if ops._WS[k].data_ptr() != ptr]
+    assert grown, "the scenario must replace at least one workspace the captured step uses"
+    assert len(ops._PARKED) - parked_before >= len(grown) + 1  # the old workspaces and the old input buffer are kept
+    torch.cuda.empty_cache()
+    # whatever was freed is handed out again: blocks of exactly the replaced sizes, filled with a pattern the replay must not touch
+    junk = [torch.full((n,), 0xAB, dtype=torch.uint8, device=device) for k in grown for n in [before[k][1]] * 3]
+    junk.append(torch.full((B, 64), 7.0, device=device))
+    for xd, y in batches:
+        la = a.train_step(xd, y)
+        new = dict(xd)
+        new["__label__"] = y
+        lb = gs.replay(new)
+        assert abs(float(la) - float(lb)) < 1e-6
+    torch.cuda.synchronize()
+    assert all(bool((t == 0xAB).all()) for t in junk[:-1]) and bool((junk[-1] == 7.0).all())
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pb.data, pa.data, atol=1e-6, rtol=1e-5)
+
+
 def _tt_schema():
     return mm.Schema([S.categorical("user_id", 500, [S.Tags.USER, S.Tags.USER_ID]), S.categorical("user_age", 10, [S.Tags.USER]),
                       S.categorical("item_id", 300, [S.Tags.ITEM, S.Tags.ITEM_ID]), S.categorical("item_cat", 20, [S.Tags.ITEM])])
