@@ -296,6 +296,8 @@ __global__ __launch_bounds__(256) void copy_many_kernel(const CopyManyArgs a) {
 }
 
 
+namespace {
+
 // ---- ConcatFeatures of narrow columns: out[b, off_i + c] = src_i[b, c] -------------------------------------------------------
 // (the 13 continuous features of a DLRM batch arrive as 13 [B] / [B, 1] tensors and feed the bottom MLP as one [B, 13] matrix.)
 // A workgroup takes 256 rows: every source column is read down the batch (coalesced 1 KB per wavefront for width-1 sources),
@@ -306,7 +308,7 @@ struct ConcatArgs {
     int64_t ld[MH_MAX_FEATURES];
     int32_t width[MH_MAX_FEATURES];
     int32_t off[MH_MAX_FEATURES];
-    int32_t n, W, Wp;
+    int32_t n, W, Wp, all_width_one;
 };
 
 __global__ __launch_bounds__(256) void concat_columns_kernel(const ConcatArgs a, int64_t B, float* __restrict__ out, int64_t ldo) {
@@ -315,10 +317,24 @@ __global__ __launch_bounds__(256) void concat_columns_kernel(const ConcatArgs a,
     const int64_t b0 = (int64_t)blockIdx.x * 256;
     const int64_t b = b0 + threadIdx.x;
     if (b < B) {
-        for (int i = 0; i < a.n; ++i) {  // uniform loop: the table reads are scalar loads
-            const float* __restrict__ s = a.src[i] + b * a.ld[i];
-            const int w = a.width[i], o = a.off[i];
-            for (int c = 0; c < w; ++c) tile[threadIdx.x * LT + o + c] = s[c];
+        if (a.all_width_one) {
+            // the usual case ([B] / [B, 1] columns): 8 loads in flight per thread before the first LDS write (a load -> store
+            // loop pays one memory round trip per column: 9.9 us for 13 columns of 64 K rows)
+            for (int i0 = 0; i0 < a.n; i0 += 8) {  // uniform loop: the table reads are scalar loads
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + j < a.n) v[j] = a.src[i0 + j][b * a.ld[i0 + j]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (i0 + j < a.n) tile[threadIdx.x * LT + i0 + j] = v[j];
+            }
+        } else {
+            for (int i = 0; i < a.n; ++i) {
+                const float* __restrict__ s = a.src[i] + b * a.ld[i];
+                const int w = a.width[i], o = a.off[i];
+                for (int c = 0; c < w; ++c) tile[threadIdx.x * LT + o + c] = s[c];
+            }
         }
         for (int c = a.W; c < a.Wp; ++c) tile[threadIdx.x * LT + c] = 0.f;
     }
@@ -330,6 +346,8 @@ __global__ __launch_bounds__(256) void concat_columns_kernel(const ConcatArgs a,
         out[(b0 + r) * ldo + c] = tile[r * LT + c];
     }
 }
+
+}  // namespace
 
 extern "C" {
 
@@ -391,6 +409,7 @@ int32_t mh_concat_columns(const float* const* src, const int64_t* ld, const int3
     a.n = count;
     a.W = W;
     a.Wp = Wp;
+    a.all_width_one = W == count;
     const size_t lds = (size_t)256 * (Wp + 1) * sizeof(float);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(concat_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -5,6 +5,9 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
 timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# HBM traffic of the HBM-bound launches FIRST, and into profiles/ on this box: the bench lines below then carry roofline.traffic
+# measured with exactly the kernels they time (bench.py refuses a file stamped with other kernel sources)
+timeout 600 python tools/pmc_traffic.py > $O/pmc_traffic.txt 2>&1; cp gpurun_out/pmc_traffic.json $O/ 2>/dev/null && cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json; rm -rf gpurun_out/pmc_traffic
 {
 timeout 500 python bench.py
 timeout 200 python bench.py --mode fwd --no-cpu-baseline --no-secondary --sustain 1
@@ -29,5 +32,4 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/twotower -o w -- python bench.py --workload twotower --no-cpu-baseline --steps 5 --warmup 2 --sustain 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcn -o d -- python bench.py --workload dcn --no-cpu-baseline --steps 3 --warmup 1 --sustain 0 > /dev/null 2>&1
 for w in train twotower dcn; do cp $(ls $O/$w/*kernel_stats.csv | head -1) $O/bench_${w}_kernel_stats.csv; rm -rf $O/$w; done
-timeout 600 python tools/pmc_traffic.py > $O/pmc_traffic.txt 2>&1; cp gpurun_out/pmc_traffic.json $O/ 2>/dev/null; rm -rf gpurun_out/pmc_traffic
 ls -la $O
