@@ -10,6 +10,7 @@ import json
 d = json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
 k = d["kernels_ms"]; lp = d["config"]["launch_probe"]
 print("$v", "step", round(d["ms_per_step"], 4), "graph", round(lp["hipGraph_replay_ms"], 4), "seg", round(lp.get("segmented_replay_ms", 0), 4),
-      "| embbwd", k["embedding_bwd"], "ffwd", k["dlrm_fused_fwd"], "fbwd", k["dlrm_fused_bwd"], "lin", k.get("linear_415x128"), "linbwd", k.get("linear_bwd_415x128"))
+      "| embbwd", k["embedding_bwd"], "ffwd", k["dlrm_fused_fwd"], "fbwd", k["dlrm_fused_bwd"], "lin", k.get("linear_415x128"), "linbwd", k.get("linear_bwd_415x128"),
+      "chains", k.get("mlp_chain_13x128x64"), k.get("mlp_chain_128x64x32x1"), k.get("mlp_chain_bwd_128x64x32x1"), k.get("mlp_chain_bwd_13x128x64"))
 PY
 done; done
