@@ -2,7 +2,7 @@
 # A/B of prebuilt library variants on one box: gpurun -- 'bash tools/gpu_ab_libs.sh v1 v2 ...'  (v = main: the in-tree library,
 # else gpurun_in/libs/lib_<v>.so); two alternating rounds of bench.py (DLRM C2 step) per variant
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for rep in 1 2; do for v in "$@"; do
+for rep in ${REPS:-1 2}; do for v in "$@"; do
   lib=$PWD/gpurun_in/libs/lib_$v.so; [ $v = main ] && lib=$PWD/models_amd/csrc/libmerlin_hip.so
   MERLIN_HIP_LIB=$lib timeout 200 python bench.py --no-cpu-baseline --no-secondary --sustain 1 2>/dev/null | tail -1 > gpurun_out/ab_$v.json
   python - <<PY
