@@ -485,6 +485,7 @@ class DLRMBlock(Block):
             if buf is None or buf.shape != (B, ld) or buf.device != dev:
                 ops.park_replaced(buf)  # a captured step may still address the old one
                 buf = self._top_buf = torch.zeros((B, ld), dtype=torch.float32, device=dev)
+            ops.note_captured(buf)
             top_in = buf[:, :width]
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
             if _TAPE[0] > 0:

@@ -903,6 +903,10 @@ class DistributedDLRM:
                 _ops.park_replaced(self._bucket)
                 self._bucket = torch.zeros(total, dtype=torch.float32, device=dstack.device)
             bucket = self._bucket
+            if bucket.is_cuda:
+                from . import ops as _ops2
+
+                _ops2.note_captured(bucket)
             rep_grads, o, grad_of = [], n_head, {}
             for t in rep_tabs:
                 rep_grads.append(bucket[o:o + t.data.numel()].view_as(t.data))
@@ -1222,6 +1226,10 @@ class DistributedModel:
             _ops.park_replaced(self._bucket)
             self._bucket = torch.zeros(total, dtype=torch.float32, device=dev)
         bucket = self._bucket
+        if bucket.is_cuda:
+            from . import ops as _ops2
+
+            _ops2.note_captured(bucket)
         o = n_head
         for t in self.rep_tabs:
             self._rep_grad[id(t)] = bucket[o:o + t.data.numel()].view_as(t.data)

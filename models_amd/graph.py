@@ -77,10 +77,13 @@ class GraphedStep:
         torch.cuda.synchronize()
         from . import ops
 
-        ops.CAPTURED_STEPS[0] += 1  # from here on, replaced persistent buffers are parked instead of freed (ops.park_replaced)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.output = fn(self.inputs)
+        ops.CAPTURING[0] += 1  # persistent buffers touched now are addressed by this graph for good (ops.note_captured / park_replaced)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.output = fn(self.inputs)
+        finally:
+            ops.CAPTURING[0] -= 1
 
     def replay(self, new_inputs=None):
         if new_inputs is not None:
@@ -119,11 +122,11 @@ class SegmentedStep:
         torch.cuda.synchronize()
         if ops.SIDE.recorder is not None:
             raise RuntimeError("a step is already being recorded")
-        ops.CAPTURED_STEPS[0] += 1  # from here on, replaced persistent buffers are parked instead of freed (ops.park_replaced)
         rec = ops.StepRecorder()
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         ops.SIDE.recorder = rec
+        ops.CAPTURING[0] += 1  # persistent buffers touched now are addressed by the segments for good (ops.note_captured / park_replaced)
         try:
             with torch.cuda.stream(cap):
                 rec.begin()
@@ -133,6 +136,7 @@ class SegmentedStep:
                     rec.finish()
         finally:
             ops.SIDE.recorder = None
+            ops.CAPTURING[0] -= 1
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         self.segments = rec.segments

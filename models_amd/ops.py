@@ -632,15 +632,22 @@ _WS = {}
 # was captured while they were current (graph.GraphedStep / SegmentedStep).  When such a buffer is replaced later -- a call with a
 # larger batch, another model growing a shared workspace -- the old block must stay allocated: a captured step that is replayed
 # afterwards still reads and writes it (returned to the caching allocator it is handed to someone else; after
-# torch.cuda.empty_cache() it is unmapped and the replay dies with a GPU memory fault).  So: once any step has been captured in
-# this process, replaced persistent buffers are parked here for good.  Cost: one stale block per growth event.
-CAPTURED_STEPS = [0]   # incremented by graph.GraphedStep / graph.SegmentedStep
+# torch.cuda.empty_cache() it is unmapped and the replay dies with a GPU memory fault).  So every persistent buffer that is touched
+# WHILE a step is being captured is marked (note_captured), and a marked buffer that is replaced is parked here for good.
+# Unmarked buffers (eager-only use) are freed as usual: alternating batch sizes in eager mode must not accumulate memory.
+CAPTURING = [0]   # > 0 while graph.GraphedStep / graph.SegmentedStep capture (they bracket their capture with it)
 _PARKED: list = []
 
 
+def note_captured(buf) -> None:
+    """Call on every use of a persistent buffer that kernels address directly (cheap: one list read outside captures)."""
+    if CAPTURING[0] and buf is not None:
+        buf._mh_captured = True
+
+
 def park_replaced(buf) -> None:
-    """Call with the OLD tensor whenever a persistent buffer that kernels address directly is replaced."""
-    if buf is not None and CAPTURED_STEPS[0] > 0:
+    """Call with the OLD tensor whenever such a buffer is replaced."""
+    if buf is not None and getattr(buf, "_mh_captured", False):
         _PARKED.append(buf)
 
 
@@ -656,6 +663,7 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
             park_replaced(buf)  # ... and never, if a captured step may still address it
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _WS[key] = buf
+    note_captured(buf)
     return buf
 
 

@@ -326,6 +326,11 @@ class CachedCrossBatchSampler(CandidateSampler):
                         ops.park_replaced(hold.id)
                         ops.park_replaced(hold.embedding)
                     hold = Candidate(torch.empty_like(items.id), {EMBEDDING_KEY: torch.empty_like(items.embedding.detach())})
+                if hold.id.is_cuda:
+                    from . import ops as _ops
+
+                    _ops.note_captured(hold.id)
+                    _ops.note_captured(hold.embedding)
                 hold.id.copy_(items.id.detach())
                 hold.embedding.copy_(items.embedding.detach())
                 self._hold = self._pending = hold

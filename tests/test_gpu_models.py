@@ -590,6 +590,7 @@ def test_captured_step_survives_buffer_growth_elsewhere_and_empty_cache(device, 
         for v in pb.state.values():
             v.fill_(0.1)
     before = {k: (v.data_ptr(), v.numel()) for k, v in ops._WS.items()}
+    marked = {k for k, v in ops._WS.items() if getattr(v, "_mh_captured", False)}  # the workspaces the captured step addresses
     parked_before = len(ops._PARKED)
     # --- the rest of the process: bigger batches grow the shared workspaces and replace b's padded top-MLP input buffer
     other = build(seed=3)
@@ -601,8 +602,11 @@ def test_captured_step_survives_buffer_growth_elsewhere_and_empty_cache(device, 
     del other, big
     torch.cuda.synchronize()
     grown = [k for k, (ptr, n) in before.items() if ops._WS[k].data_ptr() != ptr]
-    assert grown, "the scenario must replace at least one workspace the captured step uses"
-    assert len(ops._PARKED) - parked_before >= len(grown) + 1  # the old workspaces and the old input buffer are kept
+    assert grown, "the scenario must replace at least one workspace"
+    if mode == "segmented":
+        assert marked & set(grown), "... one that the captured step addresses (the sparse-update preparation's)"
+    # kept: the old input buffer and every replaced workspace the captured step addresses; freed: the rest
+    assert len(ops._PARKED) - parked_before == len(marked & set(grown)) + 1
     torch.cuda.empty_cache()
     # whatever was freed is handed out again: blocks of exactly the replaced sizes, filled with a pattern the replay must not touch
     junk = [torch.full((n,), 0xAB, dtype=torch.uint8, device=device) for k in grown for n in [before[k][1]] * 3]
@@ -617,6 +621,14 @@ def test_captured_step_survives_buffer_growth_elsewhere_and_empty_cache(device, 
     assert all(bool((t == 0xAB).all()) for t in junk[:-1]) and bool((junk[-1] == 7.0).all())
     for pa, pb in zip(a.parameters(), b.parameters()):
         torch.testing.assert_close(pb.data, pa.data, atol=1e-6, rtol=1e-5)
+    # buffers that were never touched by a capture are freed as usual: alternating batch sizes in eager mode must not pile up
+    c = build(seed=5)
+    parked = len(ops._PARKED)
+    with torch.no_grad():
+        for _ in range(4):
+            c(batches[0][0])
+            c(batch(3000)[0])
+    assert len(ops._PARKED) == parked
 
 
 def _tt_schema():
