@@ -606,8 +606,9 @@ def main():
                     help="BASELINE configs[3] (C4): add one table of this many rows (100000000 = 25.6 GB fp32 at D=64), "
                          "row-sharded over the ranks; the default 0 is the headline config C2")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
-    ap.add_argument("--launch", choices=["auto", "graph"], default="auto",
-                    help="auto: probe hipGraph replay and eager launches with side streams, time the faster (DLRM train)")
+    ap.add_argument("--launch", choices=["auto", "graph", "segmented"], default="auto",
+                    help="auto: probe one hipGraph / eager launches with side streams / the segmented replay and time the fastest "
+                         "(DLRM train); graph, segmented: time that mode without probing")
     ap.add_argument("--negatives", default="", help="with --workload twotower: comma list of 'queue', 'popularity' -- the negative-sampler "
                                                       "variants of SURVEY 8f-4 as the line's `negatives` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -716,6 +717,11 @@ def main():
                 launch_probe["segmented_error"] = f"{type(e).__name__}: {e}"
         except Exception as e:  # noqa: BLE001 -- the replayed graph stays the timed mode
             launch_probe = {"error": f"{type(e).__name__}: {e}"}
+    elif graphed and args.launch == "segmented" and args.mode == "train":
+        from models_amd.graph import SegmentedStep
+
+        seg = SegmentedStep(eager, batches[0])
+        step, graphed, launch_mode = (lambda i: seg.replay(batches[i % nb])), None, "segmented graph replay"
     dt, _, step_stats = run_steps(step, args, tm, sustain_now=False)  # the sustained region runs LAST (below)
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
     if hasattr(runner, "check_overflow"):
