@@ -187,6 +187,13 @@ class _SideStreams:
         self._keep = []
         self._defer = 0
         self.recorder: Optional[StepRecorder] = None
+        # ONE physical side stream for all three kinds: every extra stream is one more join at the end of the step and more
+        # cross-stream hand-offs in between, and a hand-off costs of the order of 20 us here.  The side work is a chain anyway
+        # (sort -> [dW, after dX] -> sparse apply, which needs the sort).  Measured on one box, alternating runs: eager
+        # 0.966 -> 0.953 ms, segmented 1.000 -> 0.989 ms; dW alone moved onto the sort stream: +10..20 us.
+        # MERLIN_HIP_SIDE_ALIAS=none restores one stream per kind; "dw=sort" style lists are accepted for experiments.
+        spec = os.environ.get("MERLIN_HIP_SIDE_ALIAS", "dw=sort,sparse=sort")
+        self._alias = dict(kv.split("=") for kv in spec.split(",") if "=" in kv)
 
     def active(self, kind: str = None) -> bool:
         # not under a plain hipGraph capture: ROCm 7 replays a captured graph on ONE hardware queue (measured: the kernel
@@ -253,7 +260,7 @@ class _SideStreams:
     def on(self, name: str, after=None, keep=()):
         """Context: the block's launches go to side stream ``name``, ordered after ``after`` (a list of ``mark()``s) or,
         by default, after everything enqueued so far on the current stream."""
-        return _SideStreams._On(self, name, [a for a in (after or []) if a is not None], keep)
+        return _SideStreams._On(self, self._alias.get(name, name), [a for a in (after or []) if a is not None], keep)
 
     def retire(self, buf) -> None:
         """A workspace being replaced: keep it alive until the next join if any side stream has work in flight."""
@@ -273,6 +280,7 @@ class _SideStreams:
 
     def join_stream(self, name: str) -> None:
         """The current stream waits for ONE side stream (its kept tensors stay alive until the full join)."""
+        name = self._alias.get(name, name)
         if self.recorder is not None:
             self.recorder.join([name])
             return
