@@ -102,16 +102,19 @@ class Block:
         return []
 
     def parameters(self) -> List[Parameter]:
-        seen, out = set(), []
-        for p in self.own_parameters():
-            if id(p) not in seen:
-                seen.add(id(p))
-                out.append(p)
-        for c in self.children():
-            for p in c.parameters():
+        """Distinct parameters in pre-order (a block's own, then its children's, in order).  ONE iterative walk: the optimizer
+        calls this every step, and the recursive form (a list and a set rebuilt at every level of the tree) was the largest single
+        item of the host time of an eagerly launched step (tools/dbg/host_profile.py: 0.7 of 2.2 ms on the authoring host)."""
+        seen, out, stack = set(), [], [self]
+        while stack:
+            b = stack.pop()
+            for p in b.own_parameters():
                 if id(p) not in seen:
                     seen.add(id(p))
                     out.append(p)
+            ch = b.children()
+            if ch:
+                stack.extend(reversed(ch if isinstance(ch, (list, tuple)) else list(ch)))
         return out
 
     def blocks_of_type(self, cls) -> List["Block"]:

@@ -52,15 +52,20 @@ class Optimizer:
                 if hasattr(blk, "apply_sparse"):
                     blk.apply_sparse(self)
             ops.SIDE.join_stream("dw")  # the dW / db GEMMs of the MLP backward ran on their own stream
-            dense = [p for p in model.parameters() if not p.sparse and p.trainable and p.grad is not None]
+            dense = [p for p in params if not p.sparse and p.trainable and p.grad is not None]  # (one walk of the model per step)
             ops.dense_optimizer_step_multi(self, dense)  # one launch for all MLP / cross / head tensors
         self._begun = False
 
 
 def _walk(block):
-    yield block
-    for c in block.children():
-        yield from _walk(c)
+    """Pre-order walk of the block tree (iterative: called every step)."""
+    stack = [block]
+    while stack:
+        b = stack.pop()
+        yield b
+        ch = b.children()
+        if ch:
+            stack.extend(reversed(ch if isinstance(ch, (list, tuple)) else list(ch)))
 
 
 class SGD(Optimizer):

@@ -188,3 +188,43 @@ def test_sharded_construction_draws_the_rows_of_the_unsharded_table():
     assert torch.equal(I._init_table(lambda shape: torch.ones(shape), 7, 4, dev, None, shard=(2, 3)), torch.ones(2, 4))
     with pytest.raises(ValueError):
         I._init_table("orthogonal", 7, 4, dev, None)
+
+
+def test_parameters_walk_is_the_preorder_of_the_recursive_definition():
+    """Block.parameters() / optim._walk are iterative (they run every step); they must list exactly what the recursive definition
+    lists, in the same order -- optimizer state and checkpoints are keyed by that order -- including shared tables (listed once)."""
+    import models_amd as mm
+    from models_amd import optim, schema as S
+
+    def rec_params(b):
+        seen, out = set(), []
+        for p in b.own_parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        for c in b.children():
+            for p in rec_params(c):
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        return out
+
+    def rec_walk(b):
+        yield b
+        for c in b.children():
+            yield from rec_walk(c)
+
+    dev = torch.device("cpu")
+    cols = [S.categorical("user_id", 50, [S.Tags.USER, S.Tags.USER_ID]), S.categorical("item_id", 70, [S.Tags.ITEM, S.Tags.ITEM_ID]),
+            S.categorical("item_cat", 9, [S.Tags.ITEM]), S.continuous("price", [S.Tags.ITEM]), S.continuous("age", [S.Tags.USER]),
+            S.binary_target("click")]
+    schema = mm.Schema(cols)
+    models = [
+        mm.DLRMModel(schema, embedding_dim=16, bottom_block=mm.MLPBlock([32, 16], device=dev), top_block=mm.MLPBlock([32, 8], device=dev), device=dev),
+        mm.DCNModel(schema, depth=2, deep_block=mm.MLPBlock([32, 16], device=dev), embedding_dim=8, device=dev),
+        mm.TwoTowerModel(schema, mm.MLPBlock([32, 16], device=dev), embedding_dim=8, device=dev),
+    ]
+    for m in models:
+        assert [id(p) for p in m.parameters()] == [id(p) for p in rec_params(m)]
+        assert [id(b) for b in optim._walk(m)] == [id(b) for b in rec_walk(m)]
+        assert len(m.parameters()) > 0
