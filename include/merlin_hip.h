@@ -234,39 +234,49 @@ int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
 /* ---- a7: DLRM pairwise dot interaction --------------------------------------------------
  * Replaces tf.matmul(x, x, transpose_b=True) + strict-upper-triangle boolean_mask in
  * DotProductInteraction.call (blocks/interaction.py:86-116): x[B, F, D] ->
- * out[b, p(i,j)] = <x[b,i,:], x[b,j,:]> for i < j in row-major order, p = i(2F-i-1)/2 + j-i-1.
- * When tail != NULL, tail[b, 0:T] is appended after the F(F-1)/2 interaction columns
- * (the "concat" of the shortcut branch, core/combinators.py:669-693 + aggregation.py:54-66).
+ * pairs[b, p(i,j)] = <x[b,i,:], x[b,j,:]> for i < j in row-major order, p = i(2F-i-1)/2 + j-i-1.
+ * When tail != NULL, tail[b, 0:T] is the shortcut branch of the "concat" aggregation
+ * (core/combinators.py:669-693 + aggregation.py:54-66) and lands in the same output row:
+ *   tail_first != 0:  out[b] = [tail (T) | pairs (P)]   <- the reference's DLRM order: the shortcut is
+ *       Filter("bottom_block") (blocks/dlrm.py:126-130), whose dict output keeps its key "bottom_block"
+ *       (core/tabular.py:552-576); ParallelBlock.call merges dict-valued branches by `update`
+ *       (core/combinators.py:564-569), the interaction branch is keyed by its Keras name "sequential_block_<n>", and
+ *       ConcatFeatures concatenates in sorted-key order: "bottom_block" < "sequential_block...".  The torch twin agrees:
+ *       cat((continuous, interactions)) (torch/blocks/dlrm.py:102-104);
+ *   tail_first == 0:  out[b] = [pairs (P) | tail (T)]   (a shortcut whose key sorts after the block's name).
  * out has leading dimension ldo >= F(F-1)/2 + T.   F <= 32, D % 4 == 0, D <= 256. */
 int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D,
-                               const float* tail, int64_t ld_tail, int32_t T, float* out,
-                               int64_t ldo, mh_stream_t stream);
-/* Backward: dx[B,F,D] = (G + G^T) x with G the strict-upper-triangular matrix scattered from
- * dout[:, :P].  If tail_slot >= 0, the gradient of the appended shortcut copy dout[:, P:P+T]
- * (T <= D) is added to dx[:, tail_slot, :T] in the same pass. */
+                               const float* tail, int64_t ld_tail, int32_t T, int32_t tail_first,
+                               float* out, int64_t ldo, mh_stream_t stream);
+/* Backward: dx[B,F,D] = (G + G^T) x with G the strict-upper-triangular matrix scattered from the P pair
+ * columns of dout.  If tail_slot >= 0, the gradient of the shortcut copy (the T tail columns of dout, T <= D;
+ * column layout as in the forward, selected by tail_first) is added to dx[:, tail_slot, :T] in the same pass. */
 int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, int64_t B,
                                int32_t F, int32_t D, float* dx, int32_t tail_slot, int32_t T,
-                               mh_stream_t stream);
+                               int32_t tail_first, mh_stream_t stream);
 
 /* ---- a1 + a5 + a7 fused: DLRM gather -> interaction without the stacked [B, F, D] round trip ---
  * Replaces the whole `ParallelBlock{embeddings, bottom_block} -> StackFeatures -> DotProductInteraction
  * -> concat shortcut` segment of DLRMBlock (blocks/dlrm.py:110-130).  Slot s (s < F, sorted feature
  * order, core/aggregation.py:101-108) is either a categorical feature -- slot_tables[s] ([slot_rows[s], D]),
  * slot_ids[s] ([B] int32/int64) -- or the ONE dense slot (slot_tables[s] == NULL) whose row b is
- * dense[b * ld_dense .. + D] (the bottom-MLP output).  out[b] = [pairwise dots (row-major i<j) | dense row
- * if append_dense].  Needs D % 16 == 0 and F*D <= 2048.  HOST arrays as in mh_embedding_gather_fwd. */
+ * dense[b * ld_dense .. + D] (the bottom-MLP output).  With append_dense the dense row is the shortcut part of the
+ * output row: out[b] = [dense row (D) | pairwise dots (row-major i<j)] when tail_first (the reference's DLRM order,
+ * see mh_dot_interaction_fwd), [pairs | dense row] otherwise; without it out[b] = pairs.
+ * Needs D % 16 == 0 and F*D <= 2048.  HOST arrays as in mh_embedding_gather_fwd. */
 int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int64_t* slot_rows,
                                       const void* const* slot_ids, int32_t ids_dtype, const float* dense,
                                       int64_t ld_dense, int64_t B, int32_t F, int32_t D,
-                                      int32_t append_dense, float* out, int64_t ldo, mh_stream_t stream);
+                                      int32_t append_dense, int32_t tail_first, float* out, int64_t ldo,
+                                      mh_stream_t stream);
 /* Backward of the fused segment: re-gathers the rows (tables are not yet updated), dx[B, F, D] = (G+G^T) X;
- * with tail_to_dense the gradient of the appended dense copy dout[:, P:P+D] is added to the dense slot.
- * D in {16, 32, 64, 128}. */
+ * with tail_to_dense the gradient of the dense copy (the D shortcut columns of dout, placed as in the forward)
+ * is added to the dense slot.  D in {16, 32, 64, 128}. */
 int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int64_t* slot_rows,
                                       const void* const* slot_ids, int32_t ids_dtype, const float* dense,
                                       int64_t ld_dense, const float* dout, int64_t ldo, int64_t B,
-                                      int32_t F, int32_t D, int32_t tail_to_dense, float* dx,
-                                      mh_stream_t stream);
+                                      int32_t F, int32_t D, int32_t tail_to_dense, int32_t tail_first,
+                                      float* dx, mh_stream_t stream);
 
 /* ---- a9: DCN-v2 cross layer  out = x0 * (x W + b) + x ----------------------------------
  * Replaces Cross.call (blocks/cross.py:188-202) with a full-rank kernel W[d, d]

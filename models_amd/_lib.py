@@ -47,8 +47,8 @@ SIGNATURES = {
     "mh_mlp_chain_fwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "mh_mlp_chain_bwd_workspace_bytes": (_i64, [_i64, _i32, _p]),
     "mh_mlp_chain_bwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
-    "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
-    "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p]),
+    "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _p, _i64, _p]),
+    "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "mh_rowwise_dot": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p]),
     "mh_dense_optimizer_step_multi": (_i32, [_p, _p, _p, _p, _i32, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_eltwise": (_i32, [_i32, _p, _p, _p, _p, _i64, _p]),
@@ -65,8 +65,8 @@ SIGNATURES = {
     "mh_sharded_lookup_bwd": (_i32, [_p, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _i64, _i32, _f32, _f32, _f32, _f32, _p, _p, _i64, _p]),
     "mh_dense_optimizer_step": (_i32, [_p, _p, _p, _i64, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_adam_tick": (_i32, [_p, _f32, _f32, _f32, _p, _p]),
-    "mh_dlrm_interaction_fused_fwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _p, _i64, _p]),
-    "mh_dlrm_interaction_fused_bwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _p, _p]),
+    "mh_dlrm_interaction_fused_fwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "mh_dlrm_interaction_fused_bwd": (_i32, [_p, _p, _p, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "mh_cross_layer_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
     "mh_cross_layer_fwd_save": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "mh_cross_layer_lowrank_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p]),

@@ -342,8 +342,8 @@ class DotProductInteraction(Block):
         self._x, self._has_tail = inputs, tail is not None
         return ops.dot_interaction(inputs, tail, out=out)
 
-    def backward(self, grad, tail_width: int = 0):
-        return ops.dot_interaction_backward(self._x, grad, tail_width)
+    def backward(self, grad, tail_slot: int = -1, tail_width: int = 0):
+        return ops.dot_interaction_backward(self._x, grad, tail_slot, tail_width)
 
     def compute_output_shape(self, input_shape):
         return input_shape[0], input_shape[1] * (input_shape[1] - 1) // 2
@@ -368,11 +368,18 @@ class DLRMBlock(Block):
 
         continuous -> bottom MLP --(last layer writes slot "bottom_block")--+
         categorical ids -> ONE multi-table gather -> slots (sorted names) --+-> stacked [B, F, D]
-        stacked -> dot interaction (+ bottom output appended)  -> [B, F(F-1)/2 + D] -> top MLP
+        stacked -> dot interaction (behind the bottom output)  -> [B, D + F(F-1)/2] -> top MLP
 
     The stack order is ``sorted(feature names + ["bottom_block"])`` (core/aggregation.py:101-108)
-    and the concat order is [interactions | bottom output] ("sequential_block..." < "shortcut",
-    core/combinators.py:669-693).
+    and the concat order is **[bottom output | interactions]**: the shortcut branch of ``connect_with_shortcut``
+    (dlrm.py:126-130) is ``Filter("bottom_block")``, which returns the DICT ``{"bottom_block": t}``
+    (core/tabular.py:552-576); ``ParallelBlock.call`` merges dict-valued branch outputs by ``update``
+    (core/combinators.py:564-569) -- the branch key "shortcut" never appears -- while the interaction branch returns a
+    tensor and is keyed by its Keras name ``sequential_block_<n>``; ``ConcatFeatures`` then concatenates in sorted-key order
+    (core/aggregation.py:54-66) and "bottom_block" < "sequential_block...".  The reference's torch twin states the same
+    order directly: ``torch.cat((inputs["continuous"], outputs), dim=1)`` (torch/blocks/dlrm.py:102-104).  Pinned by
+    ``tests/golden/make_golden.py`` (both statements executed from the reference source).  Weights of the first top-MLP
+    layer exported from the reference therefore load unchanged: rows 0..D-1 multiply the bottom output.
     """
 
     def __init__(self, schema: Schema, *, embedding_dim: Optional[int] = None, embeddings: Optional[EmbeddingsBlock] = None,

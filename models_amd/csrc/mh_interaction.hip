@@ -2,7 +2,12 @@
 // Reference: DotProductInteraction.call (merlin/models/tf/blocks/interaction.py:86-116):
 //   Z = X X^T per sample, keep the strict upper triangle in row-major (i<j) order, then the
 //   "concat" aggregation with the shortcut branch (core/combinators.py:669-693,
-//   core/aggregation.py:54-66) -> out = [interactions | bottom_mlp_out].
+//   core/aggregation.py:54-66).  The reference's DLRM order is [bottom_mlp_out | interactions]: the shortcut branch is
+//   Filter("bottom_block"), whose dict output keeps the key "bottom_block" (core/tabular.py:552-576), ParallelBlock.call
+//   merges dict-valued branches by `update` (core/combinators.py:564-569) and "bottom_block" < "sequential_block_<n>" in
+//   ConcatFeatures' sorted-key order; torch twin: cat((continuous, interactions)) (torch/blocks/dlrm.py:102-104).
+//   Every kernel here takes the column offsets of both parts of an output row -- `pofs` (pairs) and `tofs` (the T shortcut
+//   columns): tail_first (the reference's order) = (T, 0), appended = (0, P).
 //
 // One wavefront owns one sample at a time.  X[F<=32, D] is staged in LDS ([32][D+4] fp32, rows
 // >= F zero) and Z is formed on the matrix pipe with v_mfma_f32_16x16x4_f32: only the three
@@ -35,7 +40,7 @@ __device__ __forceinline__ void store_tile(const f32x4& acc, int ti, int tj, int
 __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* __restrict__ x, int64_t B,
                                                                  int F, int D,
                                                                  const float* __restrict__ tail,
-                                                                 int64_t ld_tail, int T,
+                                                                 int64_t ld_tail, int T, int tail_first,
                                                                  float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LD = D + 4;
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
     float* Xs = smem + wave * IMAXF * LD;
     const int i16 = lane & 15, q = lane >> 4;
     const int P = F * (F - 1) / 2;
+    const int pofs = tail_first ? T : 0, tofs = tail_first ? 0 : P;
     const int vpr = D / 4;            // float4 per row
     const int nvec = F * vpr;         // float4 per sample
     const int qoff = q * (D / 4);
@@ -95,14 +101,14 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
             }
         }
         float* orow = out + b * ldo;
-        store_tile(acc00, 0, 0, lane, F, orow);
+        store_tile(acc00, 0, 0, lane, F, orow + pofs);
         if (two) {
-            store_tile(acc01, 0, 1, lane, F, orow);
-            store_tile(acc11, 1, 1, lane, F, orow);
+            store_tile(acc01, 0, 1, lane, F, orow + pofs);
+            store_tile(acc11, 1, 1, lane, F, orow + pofs);
         }
         if (tail) {
             const float* trow = tail + b * ld_tail;
-            for (int t = lane; t < T; t += 64) orow[P + t] = trow[t];
+            for (int t = lane; t < T; t += 64) orow[tofs + t] = trow[t];
         }
     }
 }
@@ -115,7 +121,7 @@ template <int NV, bool STAGED>
 __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const float* __restrict__ x, int64_t B,
                                                                       int F, int D,
                                                                       const float* __restrict__ tail,
-                                                                      int64_t ld_tail, int T,
+                                                                      int64_t ld_tail, int T, int tail_first,
                                                                       float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LD = D + 4;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const flo
     float* Xs = smem + wave * IMAXF * LD;
     const int i16 = lane & 15, q = lane >> 4;
     const int P = F * (F - 1) / 2;
+    const int pofs = tail_first ? T : 0, tofs = tail_first ? 0 : P;
     const int vpr = D / 4, nvec = F * vpr;
     const int qoff = q * (D / 4);
     const int steps = D / 4;
@@ -182,12 +189,12 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const flo
             // coalesced 16-byte stores staged through the first rows of the slab, as in dlrm_fused_fwd_kernel (the launcher
             // checks: 16-byte aligned rows, P + T <= 512, T <= 64)
             __builtin_amdgcn_wave_barrier();
-            store_tile(acc00, 0, 0, lane, F, Xs);
+            store_tile(acc00, 0, 0, lane, F, Xs + pofs);
             if (two) {
-                store_tile(acc01, 0, 1, lane, F, Xs);
-                store_tile(acc11, 1, 1, lane, F, Xs);
+                store_tile(acc01, 0, 1, lane, F, Xs + pofs);
+                store_tile(acc11, 1, 1, lane, F, Xs + pofs);
             }
-            if (tail && lane < T) Xs[P + lane] = tv;
+            if (tail && lane < T) Xs[tofs + lane] = tv;
             __builtin_amdgcn_wave_barrier();
             const int nout = P + T, n4 = nout >> 2, rem = nout & 3;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(Xs + lane * 4);
@@ -203,14 +210,14 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const flo
                 }
             }
         } else {
-            store_tile(acc00, 0, 0, lane, F, orow);
+            store_tile(acc00, 0, 0, lane, F, orow + pofs);
             if (two) {
-                store_tile(acc01, 0, 1, lane, F, orow);
-                store_tile(acc11, 1, 1, lane, F, orow);
+                store_tile(acc01, 0, 1, lane, F, orow + pofs);
+                store_tile(acc11, 1, 1, lane, F, orow + pofs);
             }
             if (tail) {
-                if (lane < T) orow[P + lane] = tv;
-                for (int t = lane + 64; t < T; t += 64) orow[P + t] = tail[b * ld_tail + t];
+                if (lane < T) orow[tofs + lane] = tv;
+                for (int t = lane + 64; t < T; t += 64) orow[tofs + t] = tail[b * ld_tail + t];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -222,17 +229,18 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_pipe_kernel(const flo
 // dX = (G + G^T) X with G the strict-upper-triangular matrix scattered from dout[:, :P].
 // One wavefront per sample: S = G + G^T ([32][34] fp32 in LDS, zero diagonal / padding) is the
 // MFMA A operand, X ([32][D+16]) the B operand; 2 x D/16 output tiles of 16x16, contraction over
-// the 32 (padded) features in 8 steps of 4.  If tail_slot >= 0 the gradient of the appended
-// shortcut copy, dout[:, P:P+T], is added to dX[:, tail_slot, :T] in the same pass.
+// the 32 (padded) features in 8 steps of 4.  If tail_slot >= 0 the gradient of the shortcut
+// copy, dout[:, tofs:tofs+T], is added to dX[:, tail_slot, :T] in the same pass (pair gradients at dout[:, pofs:pofs+P]).
 constexpr int LDS_S = 34;
 
 __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ dout, int64_t ldo,
                                                                  int64_t B, int F, int D, float* __restrict__ dx,
-                                                                 int tail_slot, int T) {
+                                                                 int tail_slot, int T, int tail_first) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LD = D + 16;
     const int P = F * (F - 1) / 2;
+    const int pofs = tail_first ? T : 0, tofs = tail_first ? 0 : P;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);        // [512]
     unsigned char* pair_j = pair_i + 512;                                  // [512]
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* _
                 const int r = idx / vpr, c4 = idx - r * vpr;
                 *reinterpret_cast<f32x4*>(Xs + r * LD + c4 * 4) = src[idx];
             }
-            const float* g = dout + b * ldo;
+            const float* g = dout + b * ldo + pofs;
             for (int p = lane; p < P; p += 64) {
                 const float v = g[p];
                 const int i = pair_i[p], j = pair_j[p];
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* _
         __syncthreads();
         if (!live) continue;
         float* drow = dx + b * (int64_t)F * D;
-        const float* g = dout + b * ldo;
+        const float* g = dout + b * ldo + tofs;  // shortcut-copy gradient
         const int nti = F > 16 ? 2 : 1;
         for (int tn = 0; tn < D / 16; ++tn) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -299,13 +307,13 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* _
                 const int f0 = q * 4 + r;
                 if (f0 < F) {
                     float v = acc0[r];
-                    if (f0 == tail_slot && d < T) v += g[P + d];
+                    if (f0 == tail_slot && d < T) v += g[d];
                     drow[f0 * D + d] = v;
                 }
                 const int f1 = 16 + f0;
                 if (nti == 2 && f1 < F) {
                     float v = acc1[r];
-                    if (f1 == tail_slot && d < T) v += g[P + d];
+                    if (f1 == tail_slot && d < T) v += g[d];
                     drow[f1 * D + d] = v;
                 }
             }
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* _
             for (int f = q; f < F; f += 4) {
                 float v = 0.f;
                 for (int kk = 0; kk < F; ++kk) v = fmaf(Ss[f * LDS_S + kk], Xs[kk * LD + d], v);
-                if (f == tail_slot && d < T) v += g[P + d];
+                if (f == tail_slot && d < T) v += g[d];
                 drow[f * D + d] = v;
             }
         }
@@ -329,12 +337,13 @@ template <int DT, int NV>
 __global__ __launch_bounds__(256) void dot_interaction_bwd_pipe_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ dout, int64_t ldo,
                                                                       int64_t B, int F, float* __restrict__ dx,
-                                                                      int tail_slot, int T) {
+                                                                      int tail_slot, int T, int tail_first) {
     constexpr int D = DT * 16;
     constexpr int LD = D + 16;
     constexpr int NP = 8;  // ceil(496 / 64) gradient values per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = F * (F - 1) / 2;
+    const int pofs = tail_first ? T : 0, tofs = tail_first ? 0 : P;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);
     unsigned char* pair_j = pair_i + 512;
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_pipe_kernel(const flo
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (lds_off[i] >= 0) xr[i] = src[lane + 64 * i];
-        const float* g = dout + bb * ldo;
+        const float* g = dout + bb * ldo + pofs;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if (s_off0[k] >= 0) gr[k] = g[lane + 64 * k];
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_pipe_kernel(const flo
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) {
             const int d = 16 * tn + i16;
-            tgv[tn] = (tail_slot >= 0 && d < T) ? gcur[P + d] : 0.f;
+            tgv[tn] = (tail_slot >= 0 && d < T) ? gcur[tofs + d] : 0.f;
         }
         if (bn < B) prefetch(bn);
         float a0[8], a1[8];
@@ -535,7 +544,8 @@ __device__ __forceinline__ void wave_chunk(int64_t B, int64_t* b0, int64_t* b1) 
 template <typename IdT, int DT, int NV, bool STAGED>
 __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, const float* __restrict__ dense,
                                                             int64_t ld_dense, int dense_slot, int64_t B, int F,
-                                                            int append_dense, float* __restrict__ out, int64_t ldo) {
+                                                            int append_dense, int tail_first, float* __restrict__ out,
+                                                            int64_t ldo) {
     constexpr int D = DT * 16;
     constexpr int LD = D + 4;
     constexpr int vpr = D / 4, RP = 64 / vpr;
@@ -572,7 +582,9 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
     // writes of the next one (LDS operations of one wavefront execute in order).
     // STAGED is the launcher's choice: 16-byte aligned output rows of at most 512 floats.  (The staging area [0, nout) stays inside
     // rows < F, which the next sample's row writes restore: F (F - 1) / 2 + D <= F (D + 4) for every F <= 32, D >= 16.)
-    const int nout = P + ((append_dense && dense_slot >= 0) ? D : 0);  // floats of one output row
+    const int Tc = (append_dense && dense_slot >= 0) ? D : 0;  // shortcut columns of one output row
+    const int nout = P + Tc;                                  // floats of one output row
+    const int pofs = tail_first ? Tc : 0, tofs = tail_first ? 0 : P;
     constexpr bool staged = STAGED;
     f32x4 ov0 = {0.f, 0.f, 0.f, 0.f}, ov1 = ov0;
     f32x4 o00 = ov0, o01 = ov0, o11 = ov0;
@@ -595,12 +607,12 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
             }
             return;
         }
-        store_tile(o00, 0, 0, lane, F, oprev);
+        store_tile(o00, 0, 0, lane, F, oprev + pofs);
         if (two) {
-            store_tile(o01, 0, 1, lane, F, oprev);
-            store_tile(o11, 1, 1, lane, F, oprev);
+            store_tile(o01, 0, 1, lane, F, oprev + pofs);
+            store_tile(o11, 1, 1, lane, F, oprev + pofs);
         }
-        if (append_dense && dense_slot >= 0 && lane < D) oprev[P + lane] = odense;
+        if (append_dense && dense_slot >= 0 && lane < D) oprev[tofs + lane] = odense;
     };
     while (b < b1) {
 #pragma unroll
@@ -648,14 +660,14 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
                 if (D > 64) dhi = Xs[dense_slot * LD + 64 + lane];
             }
             __builtin_amdgcn_wave_barrier();  // the dense row is in registers before the staging area is overwritten
-            store_tile(acc00, 0, 0, lane, F, Xs);
+            store_tile(acc00, 0, 0, lane, F, Xs + pofs);
             if (two) {
-                store_tile(acc01, 0, 1, lane, F, Xs);
-                store_tile(acc11, 1, 1, lane, F, Xs);
+                store_tile(acc01, 0, 1, lane, F, Xs + pofs);
+                store_tile(acc11, 1, 1, lane, F, Xs + pofs);
             }
             if (append_dense && dense_slot >= 0) {
-                if (lane < D) Xs[P + lane] = dlo;
-                if (D > 64) Xs[P + 64 + lane] = dhi;
+                if (lane < D) Xs[tofs + lane] = dlo;
+                if (D > 64) Xs[tofs + 64 + lane] = dhi;
             }
             __builtin_amdgcn_wave_barrier();
             ov0 = *reinterpret_cast<const f32x4*>(Xs + lane * 4);
@@ -670,7 +682,7 @@ __global__ __launch_bounds__(256) void dlrm_fused_fwd_kernel(const FusedArgs a, 
                     if (lane < D) odense = Xs[dense_slot * LD + lane];
                 } else {  // D = 128: the second half goes out at once (rare configuration)
                     odense = Xs[dense_slot * LD + lane];
-                    oprev[P + 64 + lane] = Xs[dense_slot * LD + 64 + lane];
+                    oprev[tofs + 64 + lane] = Xs[dense_slot * LD + 64 + lane];
                 }
             }
         }
@@ -684,13 +696,14 @@ template <typename IdT, int DT, int NV>
 __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, const float* __restrict__ dense,
                                                             int64_t ld_dense, const float* __restrict__ dout,
                                                             int64_t ldo, int64_t B, int F, float* __restrict__ dx,
-                                                            int tail_slot, int T) {
+                                                            int tail_slot, int T, int tail_first) {
     constexpr int D = DT * 16;
     constexpr int LD = D + 16;
     constexpr int NP = 8;
     constexpr int vpr = D / 4, RP = 64 / vpr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = F * (F - 1) / 2;
+    const int pofs = tail_first ? T : 0, tofs = tail_first ? 0 : P;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned char* pair_i = reinterpret_cast<unsigned char*>(smem);
     unsigned char* pair_j = pair_i + 512;
@@ -738,11 +751,11 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
         const float* gp = dout + bb * ldo;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
-            if (s_off[k] >= 0) gr[k] = gp[lane + 64 * k];
+            if (s_off[k] >= 0) gr[k] = gp[pofs + lane + 64 * k];
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) {
             const int d = 16 * tn + i16;
-            if (tail_slot >= 0 && d < T) tgn[tn] = gp[P + d];
+            if (tail_slot >= 0 && d < T) tgn[tn] = gp[tofs + d];
         }
     };
     if (b < b1) {
@@ -819,7 +832,7 @@ __global__ __launch_bounds__(256) void dlrm_fused_bwd_kernel(const FusedArgs a, 
 extern "C" {
 
 int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, const float* tail,
-                               int64_t ld_tail, int32_t T, float* out, int64_t ldo,
+                               int64_t ld_tail, int32_t T, int32_t tail_first, float* out, int64_t ldo,
                                mh_stream_t stream) {
     MH_REQUIRE(x && out, "mh_dot_interaction_fwd: null argument");
     MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dot_interaction_fwd: F=%d outside [2,%d]", F, IMAXF);
@@ -827,6 +840,7 @@ int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, 
     MH_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "mh_dot_interaction_fwd: x must be 16-byte aligned");
     const int P = F * (F - 1) / 2;
     if (!tail) T = 0;
+    tail_first = tail_first ? 1 : 0;
     MH_REQUIRE(T >= 0 && ldo >= P + T, "mh_dot_interaction_fwd: ldo=%lld < %d", (long long)ldo, P + T);
     MH_REQUIRE(!tail || ld_tail >= T, "mh_dot_interaction_fwd: ld_tail < T");
     if (B <= 0) return MH_OK;
@@ -848,23 +862,25 @@ int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, 
                             P + T <= F * (D + 4);
         auto kern = staged ? dot_interaction_fwd_pipe_kernel<8, true> : dot_interaction_fwd_pipe_kernel<8, false>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, mh_stream(stream), x, B, F, D, tail, ld_tail, T, out, ldo);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, mh_stream(stream), x, B, F, D, tail, ld_tail, T, tail_first, out, ldo);
     } else {
         hipLaunchKernelGGL(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
-                           tail, ld_tail, T, out, ldo);
+                           tail, ld_tail, T, tail_first, out, ldo);
     }
     MH_CHECK_LAUNCH("mh_dot_interaction_fwd");
     return MH_OK;
 }
 
 int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, int64_t B, int32_t F,
-                               int32_t D, float* dx, int32_t tail_slot, int32_t T, mh_stream_t stream) {
+                               int32_t D, float* dx, int32_t tail_slot, int32_t T, int32_t tail_first,
+                               mh_stream_t stream) {
     MH_REQUIRE(x && dout && dx, "mh_dot_interaction_bwd: null argument");
     MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dot_interaction_bwd: F=%d outside [2,%d]", F, IMAXF);
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 256, "mh_dot_interaction_bwd: D=%d must be a multiple of 4 in [4,256]", D);
     MH_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "mh_dot_interaction_bwd: x must be 16-byte aligned");
     const int P = F * (F - 1) / 2;
     if (tail_slot < 0) T = 0;
+    tail_first = tail_first ? 1 : 0;
     MH_REQUIRE(tail_slot < F && T >= 0 && T <= D && ldo >= P + T, "mh_dot_interaction_bwd: bad tail_slot/T/ldo");
     if (B <= 0) return MH_OK;
     const size_t lds = 1024 + (size_t)4 * (IMAXF * (D + 16) + IMAXF * LDS_S) * sizeof(float);
@@ -886,7 +902,7 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
     {                                                                                                            \
         auto kern = dot_interaction_bwd_pipe_kernel<DT, 8>;                                                      \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, x, dout, ldo, B, F, dx, tail_slot, T);                \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, x, dout, ldo, B, F, dx, tail_slot, T, tail_first);    \
     }
         if (D == 16) MH_LAUNCH_BWD_PIPE(1)
         else if (D == 32) MH_LAUNCH_BWD_PIPE(2)
@@ -895,7 +911,7 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
 #undef MH_LAUNCH_BWD_PIPE
     } else {
         hipLaunchKernelGGL(dot_interaction_bwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, dout, ldo, B, F, D,
-                           dx, tail_slot, T);
+                           dx, tail_slot, T, tail_first);
     }
     MH_CHECK_LAUNCH("mh_dot_interaction_bwd");
     return MH_OK;
@@ -941,7 +957,7 @@ static dim3 fused_grid(int64_t B, size_t lds, int max_occ = 4) {
 int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int64_t* slot_rows,
                                       const void* const* slot_ids, int32_t ids_dtype, const float* dense,
                                       int64_t ld_dense, int64_t B, int32_t F, int32_t D, int32_t append_dense,
-                                      float* out, int64_t ldo, mh_stream_t stream) {
+                                      int32_t tail_first, float* out, int64_t ldo, mh_stream_t stream) {
     MH_REQUIRE(slot_tables && slot_rows && slot_ids && out, "mh_dlrm_interaction_fused_fwd: null argument");
     MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dlrm_interaction_fused_fwd: F=%d outside [2,%d]", F, IMAXF);
     MH_REQUIRE((D == 16 || D == 32 || D == 64 || D == 128) && F * (D / 4) <= 64 * 8,
@@ -966,7 +982,7 @@ int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int
     {                                                                                                            \
         auto kern = staged ? dlrm_fused_fwd_kernel<IDT, DT, 8, true> : dlrm_fused_fwd_kernel<IDT, DT, 8, false>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, append_dense, out, ldo); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, append_dense, tail_first ? 1 : 0, out, ldo); \
     }
     if (ids_dtype == MH_I32) {
         if (D == 16) MH_LAUNCH_FUSED_FWD(int32_t, 1)
@@ -987,7 +1003,8 @@ int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int
 int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int64_t* slot_rows,
                                       const void* const* slot_ids, int32_t ids_dtype, const float* dense,
                                       int64_t ld_dense, const float* dout, int64_t ldo, int64_t B, int32_t F,
-                                      int32_t D, int32_t tail_to_dense, float* dx, mh_stream_t stream) {
+                                      int32_t D, int32_t tail_to_dense, int32_t tail_first, float* dx,
+                                      mh_stream_t stream) {
     MH_REQUIRE(slot_tables && slot_rows && slot_ids && dout && dx, "mh_dlrm_interaction_fused_bwd: null argument");
     MH_REQUIRE(F >= 2 && F <= IMAXF, "mh_dlrm_interaction_fused_bwd: F=%d outside [2,%d]", F, IMAXF);
     MH_REQUIRE((D == 16 || D == 32 || D == 64 || D == 128) && F * (D / 4) <= 64 * 8,
@@ -1012,7 +1029,7 @@ int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int
     {                                                                                                            \
         auto kern = dlrm_fused_bwd_kernel<IDT, DT, 8>;                                                           \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dout, ldo, B, F, dx, tail_slot, T); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dout, ldo, B, F, dx, tail_slot, T, tail_first ? 1 : 0); \
     }
     if (ids_dtype == MH_I32) {
         if (D == 16) MH_LAUNCH_FUSED_BWD(int32_t, 1)

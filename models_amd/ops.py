@@ -601,10 +601,12 @@ def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence
 
 
 def dot_interaction(
-    x: torch.Tensor, tail: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
+    x: torch.Tensor, tail: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tail_first: bool = True
 ) -> torch.Tensor:
-    """Strict-upper-triangle pairwise dots of ``x[B, F, D]`` (row-major pair order), optionally
-    followed by ``tail[B, T]`` in the same output row."""
+    """Strict-upper-triangle pairwise dots of ``x[B, F, D]`` (row-major pair order) with the shortcut
+    ``tail[B, T]`` in the same output row: ``[tail | pairs]`` (``tail_first``, the reference's DLRM order
+    ``[bottom_block | interactions]``: tf/core/combinators.py:564-569 + tf/core/aggregation.py:54-66) or
+    ``[pairs | tail]``."""
     lib = _lib.load()
     _dev(x, "x", torch.float32)
     if x.dim() != 3 or not x.is_contiguous():
@@ -624,7 +626,7 @@ def dot_interaction(
     with _timed("dot_interaction", nbytes=B * (F * D + P + T) * 4, flops=B * D * F * (F - 1)):
         check(
             lib.mh_dot_interaction_fwd(_ptr(x), B, F, D, _ptr(tail), 0 if tail is None else tail.stride(0), T,
-                                       _ptr(out), out.stride(0), _stream()),
+                                       1 if tail_first else 0, _ptr(out), out.stride(0), _stream()),
             "mh_dot_interaction_fwd",
         )
     return out
@@ -732,8 +734,9 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
     return dx, dW, db
 
 
-def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int = -1, tail_width: int = 0):
-    """dx[B,F,D] of ``dot_interaction``; the appended-tail gradient is folded into slot ``tail_slot``."""
+def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int = -1, tail_width: int = 0,
+                             tail_first: bool = True):
+    """dx[B,F,D] of ``dot_interaction``; the gradient of the shortcut columns is folded into slot ``tail_slot``."""
     lib = _lib.load()
     _dev(x, "x", torch.float32)
     _rowmajor_2d(dout, "dout")
@@ -742,7 +745,7 @@ def dot_interaction_backward(x: torch.Tensor, dout: torch.Tensor, tail_slot: int
     with _timed("dot_interaction_bwd", nbytes=B * (2 * F * D + dout.shape[1]) * 4, flops=2 * B * D * F * (F - 1)):
         check(
             lib.mh_dot_interaction_bwd(_ptr(x), _ptr(dout), dout.stride(0), B, F, D, _ptr(dx), tail_slot,
-                                       tail_width, _stream()),
+                                       tail_width, 1 if tail_first else 0, _stream()),
             "mh_dot_interaction_bwd",
         )
     return dx
@@ -1314,9 +1317,10 @@ def _fused_slot_arrays_build(slot_tables, slot_ids):
 
 
 def dlrm_interaction_fused(slot_tables, slot_ids, dense: Optional[torch.Tensor], append_dense: bool = True,
-                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           out: Optional[torch.Tensor] = None, tail_first: bool = True) -> torch.Tensor:
     """``slot_tables[s]`` / ``slot_ids[s]`` per stack slot in sorted feature order; ``None`` marks the
-    dense slot fed by ``dense[B, D]`` (the bottom-MLP output).  Returns [B, P (+ D)]."""
+    dense slot fed by ``dense[B, D]`` (the bottom-MLP output).  Returns [B, (D +) P]: ``[dense | pairs]`` with
+    ``tail_first`` (the reference's ``[bottom_block | interactions]``), ``[pairs | dense]`` without."""
     lib = _lib.load()
     F, idt, tab, rows, idp = _fused_slot_arrays(slot_tables, slot_ids)
     first = next(t for t in slot_tables if t is not None)
@@ -1331,13 +1335,14 @@ def dlrm_interaction_fused(slot_tables, slot_ids, dense: Optional[torch.Tensor],
     with _timed("dlrm_fused_fwd", nbytes=B * ((F - 1) * (D * 4 + 4) + (D * 4 if dense is not None else 0) + (P + T) * 4),
                 flops=2 * B * D * F * (F - 1) // 2):
         check(lib.mh_dlrm_interaction_fused_fwd(tab, rows, idp, idt, _ptr(dense), 0 if dense is None else dense.stride(0),
-                                                B, F, D, int(bool(append_dense)), _ptr(out), out.stride(0), _stream()),
+                                                B, F, D, int(bool(append_dense)), 1 if tail_first else 0, _ptr(out),
+                                                out.stride(0), _stream()),
               "mh_dlrm_interaction_fused_fwd")
     return out
 
 
 def dlrm_interaction_fused_backward(slot_tables, slot_ids, dense: Optional[torch.Tensor], dout: torch.Tensor,
-                                    tail_to_dense: bool = True) -> torch.Tensor:
+                                    tail_to_dense: bool = True, tail_first: bool = True) -> torch.Tensor:
     """dX [B, F, D] of the fused segment (rows re-gathered from the not-yet-updated tables)."""
     lib = _lib.load()
     F, idt, tab, rows, idp = _fused_slot_arrays(slot_tables, slot_ids)
@@ -1349,8 +1354,8 @@ def dlrm_interaction_fused_backward(slot_tables, slot_ids, dense: Optional[torch
     with _timed("dlrm_fused_bwd", nbytes=B * ((F - 1) * (D * 4 + 4) + (D * 4 if dense is not None else 0) + dout.shape[1] * 4 + F * D * 4),
                 flops=2 * B * D * F * (F - 1)):
         check(lib.mh_dlrm_interaction_fused_bwd(tab, rows, idp, idt, _ptr(dense), 0 if dense is None else dense.stride(0),
-                                                _ptr(dout), dout.stride(0), B, F, D, int(bool(tail_to_dense)), _ptr(dx),
-                                                _stream()),
+                                                _ptr(dout), dout.stride(0), B, F, D, int(bool(tail_to_dense)),
+                                                1 if tail_first else 0, _ptr(dx), _stream()),
               "mh_dlrm_interaction_fused_bwd")
     return dx
 

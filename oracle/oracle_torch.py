@@ -100,7 +100,7 @@ def _forward(state: DLRMState, cat: Dict[str, torch.Tensor], cont_x: torch.Tenso
     F = X.shape[1]
     iu = torch.triu_indices(F, F, offset=1)
     inter = torch.bmm(X, X.transpose(1, 2))[:, iu[0], iu[1]]  # strict upper triangle, row-major (interaction.py:107-112)
-    top_in = torch.cat([inter, bottom_out], dim=1)            # [interactions | bottom] (see oracle.dlrm_interaction_concat)
+    top_in = torch.cat([bottom_out, inter], dim=1)            # [bottom | interactions] (see oracle.dlrm_interaction_concat)
     p = torch.sigmoid(_mlp(top_in, state.top) @ state.head[0] + state.head[1])
     return p
 

@@ -14,6 +14,13 @@ the reference SOURCE at run time with ``ast`` and executed with torch-CPU:
   * merlin/models/torch/outputs/classification.py: BinaryOutput.DEFAULT_LOSS_CLS (nn.BCELoss) and
     merlin/models/torch/outputs/contrastive.py: ContrastiveOutput.__init__'s default `loss` (nn.CrossEntropyLoss()): the
     loss classes the reference's torch backend instantiates, evaluated on fixed inputs (BCE, softmax-CE a13)
+  * the DLRM top-MLP input layout (a5 / a8), from BOTH statements the reference holds:
+      - merlin/models/torch/blocks/dlrm.py: InteractionBlock.forward (+ torch/transforms/agg.py: Stack.forward)
+      - the TF key logic itself: WithShortcut.__init__'s branch dict, ParallelBlock.call (tf/core/combinators.py),
+        Filter.call / check_feature (tf/core/tabular.py), ConcatFeatures.call / StackFeatures.call
+        (tf/core/aggregation.py), executed over a numpy shim for tf.cast / tf.concat / tf.stack
+  * merlin/models/torch/blocks/mlp.py: MLPBlock.__init__ (the Dense -> activation sequence the reference builds), executed
+    with torch.nn modules and fixed weights (Dense a6)
 
 Nothing is copied into this repository: only inputs/outputs land in tests/golden/*.npz.
 """
@@ -69,6 +76,138 @@ def init_default(path, cls: str, arg: str, ns):
     names = [a.arg for a in init.args.args]
     dflt = init.args.defaults[names.index(arg) - (len(names) - len(init.args.defaults))]
     return eval(compile(ast.Expression(dflt), str(path), "eval"), ns)
+
+
+def assign_value(path, cls: str, fn: str, target: str, ns):
+    """Evaluate the right-hand side of `target = ...` inside `cls.fn` of the reference source file `path`."""
+    tree = ast.parse((REF / path).read_text())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    f = next(n for n in node.body if isinstance(n, ast.FunctionDef) and n.name == fn)
+    asg = next(n for n in ast.walk(f) if isinstance(n, ast.Assign) and any(getattr(t, "id", None) == target for t in n.targets))
+    return eval(compile(ast.Expression(asg.value), str(path), "eval"), ns)
+
+
+class _TFShim:
+    """The three TensorFlow calls the key logic makes, on numpy arrays."""
+    float32 = np.float32
+    SparseTensor = type("SparseTensor", (), {})
+
+    @staticmethod
+    def cast(x, dtype):
+        return np.asarray(x).astype(dtype)
+
+    @staticmethod
+    def concat(tensors, axis):
+        return np.concatenate(tensors, axis=axis)
+
+    @staticmethod
+    def stack(tensors, axis):
+        return np.stack(tensors, axis=axis)
+
+
+def dlrm_layout(out, g):
+    """What the reference feeds its top MLP: `[bottom_block | interactions]`.
+
+    TF statement (the canonical one): DLRMBlock ends in `connect_with_shortcut(DotProductInteractionBlock(),
+    shortcut_filter=Filter("bottom_block"), aggregation="concat")` (tf/blocks/dlrm.py:126-130).  Its pieces are executed here
+    FROM THE REFERENCE SOURCE: the branch dict WithShortcut.__init__ builds, ParallelBlock.call's merge loop, Filter.call,
+    ConcatFeatures.call.  What is NOT in the reference tree is Keras' automatic layer name of the interaction branch
+    (`block.name`): Keras names a layer `to_snake_case(class name)` + a uniquifying suffix -- the reference's own tests show
+    it for this class: "sequential_block", "sequential_block_1" in the model summaries of
+    tests/unit/tf/models/test_base.py:342-345.  (SequentialBlock._get_name, tf/core/combinators.py:137-138, is used by
+    __repr__ only.)  The fixture stores the order for that name and asserts that EVERY name Keras can generate for the class
+    gives the same order; the reference's torch backend states the order directly, and agrees."""
+    tfs = _TFShim()
+    comb = "merlin/models/tf/core/combinators.py"
+    B, Fc, D = 6, 5, 8
+    # upper case sorts before lower case (ASCII); every name sorts before "bottom_block" (TF) AND before "continuous" (the
+    # key the torch twin stacks the bottom output under), so both statements stack it in the last slot and agree column by column
+    names = ["C1", "C10", "C2", "I_emb", "a_cat"][:Fc]
+    emb = {n: torch.randn(B, D, generator=g).numpy() for n in names}
+    bottom = torch.randn(B, D, generator=g).numpy()
+    interaction_inputs = {**emb, "bottom_block": bottom}  # what ParallelBlock{"embeddings", "bottom_block"} hands on (dlrm.py:110-113)
+
+    # -- the interaction branch: SequentialBlock(StackFeatures(axis=1), DotProductInteraction()) (dlrm.py:169-170)
+    stack_call = load("merlin/models/tf/core/aggregation.py", "call", "StackFeatures", {"tf": tfs, "TabularData": dict})
+    stack_self = types.SimpleNamespace(axis=1, output_dtype=np.float32, _check_concat_shapes=lambda inputs: None)
+    inter_fwd = load("merlin/models/torch/blocks/dlrm.py", "forward", "DLRMInteraction")
+    Inter = type("Inter", (torch.nn.Module,), {"forward": inter_fwd})
+
+    def interaction_branch(inputs):
+        return Inter()(torch.from_numpy(stack_call(stack_self, inputs))).numpy()
+
+    # -- the shortcut branch: Filter("bottom_block")
+    filt = types.SimpleNamespace(feature_names=["bottom_block"], exclude=False, pop=False, add_to_context=False)
+    filt.check_feature = types.MethodType(load("merlin/models/tf/core/tabular.py", "check_feature", "Filter"), filt)
+    filter_call = load("merlin/models/tf/core/tabular.py", "call", "Filter", {"TabularData": dict})
+
+    # -- WithShortcut.__init__: inputs = {block_outputs_name: block, "shortcut": shortcut}, block_outputs_name = block.name
+    def run(block_name):
+        branches = assign_value(comb, "WithShortcut", "__init__", "inputs",
+                                {"block_outputs_name": block_name, "block": interaction_branch,
+                                 "shortcut": lambda inputs: filter_call(filt, inputs)})
+        me = types.SimpleNamespace(strict=False, parallel_dict=branches,
+                                   _maybe_filter_layer_inputs_using_schema=lambda name, layer, inputs: inputs)
+        par_call = load(comb, "call", "ParallelBlock", {"call_layer": lambda layer, inputs, **kw: layer(inputs)})
+        merged = par_call(me, dict(interaction_inputs))
+        concat_call = load("merlin/models/tf/core/aggregation.py", "call", "ConcatFeatures", {"tf": tfs, "TabularData": dict})
+        cself = types.SimpleNamespace(axis=-1, output_dtype=np.float32, _check_concat_shapes=lambda inputs: None)
+        return list(merged.keys()), sorted(merged.keys()), concat_call(cself, merged)
+
+    keys, order, top_in = run("sequential_block_7")
+    assert "shortcut" not in keys and sorted(keys) == ["bottom_block", "sequential_block_7"], keys
+    for nm in ["sequential_block"] + [f"sequential_block_{i}" for i in (1, 2, 9, 10, 123)]:
+        assert run(nm)[1][0] == "bottom_block" and np.array_equal(run(nm)[2], top_in), nm
+    P = (Fc + 1) * Fc // 2
+    assert top_in.shape == (B, D + P) and np.array_equal(top_in[:, :D], bottom)
+
+    # -- torch twin: InteractionBlock.forward over [Stack(dim=1), DLRMInteraction()] with the bottom output under "continuous"
+    stack_fwd = load("merlin/models/torch/transforms/agg.py", "forward", "Stack")
+    TStack = type("TStack", (torch.nn.Module,), {"forward": lambda self, inputs, batch=None: stack_fwd(self, inputs), "dim": 1})
+    TInter = type("TInter", (torch.nn.Module,), {"forward": lambda self, inputs, batch=None: inter_fwd(self, inputs)})
+    ib_fwd = load("merlin/models/torch/blocks/dlrm.py", "forward", "InteractionBlock", {"Batch": object})
+    tin = {**{k: torch.from_numpy(v) for k, v in emb.items()}, "continuous": torch.from_numpy(bottom)}
+    twin = ib_fwd(types.SimpleNamespace(values=[TStack(), TInter()]), tin).numpy()
+    assert np.array_equal(twin[:, :D], bottom), "torch twin: continuous first"
+    assert np.allclose(twin, top_in, atol=1e-5), "the two statements of the reference disagree"
+
+    out.update(dl_names=np.array(names), dl_bottom=bottom, dl_top_in=top_in, dl_key_order=np.array(order),
+               dl_merged_keys=np.array(keys), dl_twin_top_in=twin,
+               **{f"dl_emb_{n}": v for n, v in emb.items()})
+
+
+def dense_mlp(out, g):
+    """Dense (a6) through the reference's torch MLPBlock: its __init__ (torch/blocks/mlp.py) is executed from source and
+    builds `Linear -> activation` per layer; the resulting modules run with fixed weights.  Keras' Dense is
+    act(x @ kernel + bias) with kernel [in, out] = Linear.weight.T."""
+    tree = ast.parse((REF / "merlin/models/torch/blocks/mlp.py").read_text())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "MLPBlock")
+    init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    init.decorator_list = []
+    for a in init.args.args + init.args.kwonlyargs:
+        a.annotation = None
+    # the body's `super().__init__(*modules)` hands the module list to the container: capture it
+    captured = {}
+    src = ast.unparse(init).replace("super().__init__", "_capture")
+    ns = {"nn": torch.nn, "_capture": lambda *m, **kw: captured.__setitem__("modules", list(m))}
+    exec(src, ns)
+    units, din = [24, 16, 8], 19
+    ns["__init__"](types.SimpleNamespace(), units, pre_agg=torch.nn.Identity())  # default activation: the reference's (nn.ReLU)
+    mods = captured["modules"]
+    x = torch.randn(13, din, generator=g)
+    h, li = x, 0
+    for m in mods:
+        if isinstance(m, torch.nn.LazyLinear):
+            lin = torch.nn.Linear(h.shape[1], m.out_features)
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(m.out_features, h.shape[1], generator=g) * 0.3)
+                lin.bias.copy_(torch.randn(m.out_features, generator=g) * 0.1)
+            out[f"mlp_W{li}"] = lin.weight.detach().T.contiguous()
+            out[f"mlp_b{li}"] = lin.bias.detach()
+            li += 1
+            m = lin
+        h = m(h)
+    out.update(mlp_x=x, mlp_y=h.detach(), mlp_layers=np.array([type(m).__name__ for m in mods]))
 
 
 def main():
@@ -194,6 +333,10 @@ def main():
     # class-index target 0 == the one-hot-on-column-0 target the reference builds
     out.update(ce_loss=ce(ce_logits, torch.zeros(B, dtype=torch.long)), ce_cls=np.array(type(ce).__name__),
                ce_loss_onehot=ce(ce_logits, me2.target))
+
+    # --- DLRM top-MLP input layout (appended: earlier draws are unchanged) ----------------------------------------
+    dlrm_layout(out, g)
+    dense_mlp(out, g)
 
     np.savez_compressed(OUT / "reference_vectors.npz",
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})

@@ -59,26 +59,28 @@ def linear(x, W, b=None, activation=None, out=None):
     return out
 
 
-def dot_interaction(x, tail=None, out=None):
+def dot_interaction(x, tail=None, out=None, tail_first=True):
     B, F, _ = x.shape
     iu = torch.triu_indices(F, F, offset=1)
     inter = torch.bmm(x, x.transpose(1, 2))[:, iu[0], iu[1]]
-    res = inter if tail is None else torch.cat([inter, tail], dim=1)
+    res = inter if tail is None else torch.cat([tail, inter] if tail_first else [inter, tail], dim=1)
     if out is None:
         return res
     out.copy_(res)
     return out
 
 
-def dot_interaction_backward(x, dout, tail_slot=-1, tail_width=0):
+def dot_interaction_backward(x, dout, tail_slot=-1, tail_width=0, tail_first=True):
     B, F, D = x.shape
     P = F * (F - 1) // 2
+    T = tail_width if tail_slot >= 0 else 0
+    pofs, tofs = (T, 0) if tail_first else (0, P)
     iu = torch.triu_indices(F, F, offset=1)
     G = torch.zeros(B, F, F, dtype=x.dtype, device=x.device)
-    G[:, iu[0], iu[1]] = dout[:, :P]
+    G[:, iu[0], iu[1]] = dout[:, pofs:pofs + P]
     dx = torch.bmm(G + G.transpose(1, 2), x)
-    if tail_slot >= 0 and tail_width > 0:
-        dx[:, tail_slot, :tail_width] += dout[:, P:P + tail_width]
+    if T > 0:
+        dx[:, tail_slot, :T] += dout[:, tofs:tofs + T]
     return dx
 
 

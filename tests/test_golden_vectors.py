@@ -52,7 +52,93 @@ def test_oracle_losses_match_the_reference_loss_classes():
     np.testing.assert_allclose(G["ce_loss_onehot"], G["ce_loss"], atol=1e-6)  # one-hot column 0 == class index 0
 
 
+def _dl_stack():
+    """The DLRM-layout fixture's inputs as the stacked [B, F, D] tensor in StackFeatures' sorted-key order."""
+    names = [str(n) for n in G["dl_names"]]
+    feats = {**{n: G[f"dl_emb_{n}"] for n in names}, "bottom_block": G["dl_bottom"]}
+    order = sorted(feats)
+    return np.stack([feats[k] for k in order], axis=1), order.index("bottom_block"), names
+
+
+def test_oracle_dlrm_top_input_layout_matches_reference_key_logic():
+    """[bottom_block | interactions]: the fixture is what the reference's OWN source produces -- WithShortcut's branch dict,
+    ParallelBlock.call's merge, Filter.call and ConcatFeatures.call (tf/core/combinators.py:564-569,669-693,
+    tf/core/tabular.py:552-576, tf/core/aggregation.py:54-66) executed by tests/golden/make_golden.py, and the torch twin
+    InteractionBlock.forward (torch/blocks/dlrm.py:92-104)."""
+    assert [str(k) for k in G["dl_key_order"]] == ["bottom_block", "sequential_block_7"]
+    assert "shortcut" not in [str(k) for k in G["dl_merged_keys"]]  # the Filter's dict is merged by update: its key survives
+    X, slot, _ = _dl_stack()
+    D = X.shape[2]
+    np.testing.assert_array_equal(G["dl_top_in"][:, :D], G["dl_bottom"])
+    np.testing.assert_allclose(O.dlrm_interaction_concat(X, G["dl_bottom"]), G["dl_top_in"], atol=1e-5)
+    np.testing.assert_allclose(O.dlrm_interaction_concat(X, G["dl_bottom"]), G["dl_twin_top_in"], atol=1e-5)
+
+
+def test_oracle_dense_matches_reference_mlp_block():
+    """Dense (a6) pinned through the module sequence the reference's torch MLPBlock.__init__ builds (Linear -> ReLU per layer,
+    torch/blocks/mlp.py:51-84), executed from the reference source with fixed weights."""
+    assert [str(m) for m in G["mlp_layers"]] == ["Identity", "LazyLinear", "ReLU", "LazyLinear", "ReLU", "LazyLinear", "ReLU"]
+    layers = [(G[f"mlp_W{i}"], G[f"mlp_b{i}"], "relu") for i in range(3)]
+    np.testing.assert_allclose(O.mlp(G["mlp_x"], layers), G["mlp_y"], atol=1e-5, rtol=1e-5)
+
+
 # ---- the same vectors through the HIP path ------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_dlrm_top_input_layout_matches_reference_key_logic(device):
+    """The unfused kernel, the fused gather -> interaction kernel and a whole DLRMBlock reproduce the reference's
+    [bottom_block | interactions] rows (fixture dl_top_in)."""
+    import torch
+
+    import models_amd as mm
+    from models_amd import ops, schema as S
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    X, slot, names = _dl_stack()
+    B, F, D = X.shape
+    out = ops.dot_interaction(t(X), t(G["dl_bottom"]))
+    np.testing.assert_allclose(out.cpu().numpy(), G["dl_top_in"], atol=ATOL, rtol=1e-5)
+    # fused: every embedding "table" is the fixture's [B, D] block looked up with ids 0..B-1; D = 8 is outside the fused
+    # kernel's {16, 32, 64, 128}, so pad the rows with zeros to 16 (dot products unchanged) and compare the pair columns
+    pad = lambda a: np.concatenate([a, np.zeros_like(a)], axis=1)
+    order = sorted(names + ["bottom_block"])
+    tabs = [None if k == "bottom_block" else t(pad(G[f"dl_emb_{k}"])) for k in order]
+    ids = [None if k == "bottom_block" else torch.arange(B, dtype=torch.int32, device=device) for k in order]
+    fused = ops.dlrm_interaction_fused(tabs, ids, t(pad(G["dl_bottom"]))).cpu().numpy()
+    np.testing.assert_array_equal(fused[:, :D], G["dl_bottom"])
+    np.testing.assert_allclose(fused[:, 2 * D:], G["dl_top_in"][:, D:], atol=ATOL, rtol=1e-5)
+    # a whole DLRMBlock with identity bottom / top blocks would hide nothing either: build one and read its top-MLP input
+    cols = [S.categorical(n, B) for n in names] + [S.continuous("I1")]
+    block = mm.DLRMBlock(mm.Schema(cols), embedding_dim=D, bottom_block=mm.MLPBlock([D], device=device),
+                         top_block=mm.MLPBlock([4], device=device), device=device)
+    for n in names:
+        block.embeddings.feature_table[n].table.data.copy_(t(G[f"dl_emb_{n}"]))
+    dense = block.bottom_block.layers[-1]
+    x_in = {n: torch.arange(B, device=device).reshape(B, 1) for n in names}
+    x_in["I1"] = torch.rand(B, 1, device=device)
+    block(x_in)
+    bottom = block.bottom_block(block.continuous(x_in)).cpu().numpy()
+    top_in = block._top_in.cpu().numpy()
+    feats = {**{n: G[f"dl_emb_{n}"] for n in names}, "bottom_block": bottom}
+    ref = O.dlrm_interaction_concat(np.stack([feats[k] for k in sorted(feats)], axis=1), bottom)
+    np.testing.assert_array_equal(top_in[:, :D], bottom)
+    np.testing.assert_allclose(top_in, ref, atol=ATOL, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_dense_matches_reference_mlp_block(device):
+    import torch
+
+    from models_amd import ops
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    h = t(G["mlp_x"])
+    for i in range(3):
+        h = ops.linear(h, t(G[f"mlp_W{i}"]), t(G[f"mlp_b{i}"]), "relu")
+    np.testing.assert_allclose(h.cpu().numpy(), G["mlp_y"], atol=ATOL, rtol=1e-5)
+    y = ops.mlp_chain(t(G["mlp_x"]), [t(G[f"mlp_W{i}"]) for i in range(3)], [t(G[f"mlp_b{i}"]) for i in range(3)], ["relu"] * 3)
+    np.testing.assert_allclose((y[-1] if isinstance(y, (list, tuple)) else y).cpu().numpy(), G["mlp_y"], atol=ATOL, rtol=1e-5)
+
+
 @pytest.mark.gpu
 def test_hip_scorer_matches_reference_vectors(device):
     import torch

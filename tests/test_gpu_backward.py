@@ -56,6 +56,10 @@ def test_dot_interaction_backward(device, F, D, with_tail):
     out.backward(dout)
     dx = ops.dot_interaction_backward(X.detach().to(device), dout.to(device), slot if with_tail else -1, D if with_tail else 0)
     torch.testing.assert_close(dx.cpu(), X.grad, atol=2e-4 * max(1.0, D / 64), rtol=1e-4)
+    if with_tail:  # the appended column order: the same gradient from the swapped row
+        dswap = torch.cat([dout[:, D:], dout[:, :D]], dim=1)
+        dx2 = ops.dot_interaction_backward(X.detach().to(device), dswap.to(device), slot, D, tail_first=False)
+        assert torch.equal(dx2, dx)
 
 
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])

@@ -69,9 +69,12 @@ def test_dot_interaction_matches_oracle(device, F, D, with_tail):
     X = rng.normal(size=(B, F, D)).astype(np.float32)
     tail = X[:, -1].copy() if with_tail else None
     out = ops.dot_interaction(_t(X, device), None if tail is None else _t(tail, device)).cpu().numpy()
-    ref = O.dlrm_interaction_concat(X, tail)
+    ref = O.dlrm_interaction_concat(X, tail)  # [bottom | interactions], the reference's order
     assert out.shape == ref.shape
     np.testing.assert_allclose(out, ref, atol=ATOL * max(1.0, D / 64), rtol=1e-5)
+    if with_tail:  # the other column order of the C ABI (a shortcut key sorting behind the block's name): same values, swapped parts
+        alt = ops.dot_interaction(_t(X, device), _t(tail, device), tail_first=False).cpu().numpy()
+        np.testing.assert_array_equal(alt, np.concatenate([out[:, D:], out[:, :D]], axis=1))
 
 
 def test_dot_interaction_asymmetric_order(device):
@@ -119,10 +122,19 @@ def test_fused_gather_interaction_fwd_bwd(device, F, D, dense_pos, idt):
     dx_ref = ops.dot_interaction_backward(_t(X, device), _t(dout, device), -1 if dense_pos is None else dense_pos,
                                           0 if dense_pos is None else D)
     torch.testing.assert_close(dx, dx_ref, atol=1e-5, rtol=1e-5)
+    if dense is not None:  # appended order of the C ABI: same values with the two parts of every row swapped, forward and backward
+        swap = lambda a: np.concatenate([a[:, D:], a[:, :D]], axis=1)
+        alt = ops.dlrm_interaction_fused(tabs, ids, _t(dense, device), tail_first=False).cpu().numpy()
+        np.testing.assert_array_equal(alt, swap(out))
+        dx_alt = ops.dlrm_interaction_fused_backward(tabs, ids, _t(dense, device), _t(swap(dout), device), tail_first=False)
+        assert torch.equal(dx_alt, dx)
+        dx_alt_u = ops.dot_interaction_backward(_t(X, device), _t(swap(dout), device), dense_pos, D, tail_first=False)
+        assert torch.equal(dx_alt_u, dx_ref)
 
 
+@pytest.mark.parametrize("tail_first", [True, False])
 @pytest.mark.parametrize("F,D,dense_pos", [(27, 64, 26), (5, 16, 2), (17, 32, 0), (9, 128, None), (32, 16, 31), (12, 128, 3), (2, 64, 0)])
-def test_fused_forward_coalesced_output_path_equals_scattered_path(device, F, D, dense_pos):
+def test_fused_forward_coalesced_output_path_equals_scattered_path(device, F, D, dense_pos, tail_first):
     """Output rows that are 16-byte aligned (ld % 4 == 0) leave the fused kernel as two float4 stores per lane staged through
     the LDS slab; any other row takes the scattered dword stores.  Same arithmetic: the two agree bit for bit, the columns
     behind the row (the ld padding) are never written, and a chunk boundary (B not a multiple of the wavefront count) works."""
@@ -143,16 +155,19 @@ def test_fused_forward_coalesced_output_path_equals_scattered_path(device, F, D,
     ld_u = ld_a + 1                       # rows that are not 16-byte aligned
     buf_a = torch.full((B, ld_a), -7.0, device=device)
     buf_u = torch.full((B, ld_u), -7.0, device=device)
-    ops.dlrm_interaction_fused(tabs, ids, dense, out=buf_a[:, :n])
-    ops.dlrm_interaction_fused(tabs, ids, dense, out=buf_u[:, :n])
+    ops.dlrm_interaction_fused(tabs, ids, dense, out=buf_a[:, :n], tail_first=tail_first)
+    ops.dlrm_interaction_fused(tabs, ids, dense, out=buf_u[:, :n], tail_first=tail_first)
     assert torch.equal(buf_a[:, :n], buf_u[:, :n])
     assert bool((buf_a[:, n:] == -7.0).all()) and bool((buf_u[:, n:] == -7.0).all())
-    ref = ops.dlrm_interaction_fused(tabs, ids, dense)
+    ref = ops.dlrm_interaction_fused(tabs, ids, dense, tail_first=tail_first)
     assert torch.equal(ref, buf_a[:, :n])
+    if dense is not None:
+        assert torch.equal(ref[:, :D] if tail_first else ref[:, n - D:], dense)
 
 
+@pytest.mark.parametrize("tail_first", [True, False])
 @pytest.mark.parametrize("F,D,T", [(27, 64, 64), (5, 16, 16), (17, 32, 0), (32, 16, 16), (12, 128, 40), (2, 64, 64), (27, 64, 100)])
-def test_interaction_forward_coalesced_output_path_equals_scattered_path(device, F, D, T):
+def test_interaction_forward_coalesced_output_path_equals_scattered_path(device, F, D, T, tail_first):
     """mh_dot_interaction_fwd: aligned output rows take the staged float4 stores, other rows (and tails wider than 64) the
     scattered ones; bit-identical, the ld padding untouched."""
     g = torch.Generator().manual_seed(F * D + T)
@@ -163,14 +178,15 @@ def test_interaction_forward_coalesced_output_path_equals_scattered_path(device,
     ld_a = (n + 3) // 4 * 4 + 4
     buf_a = torch.full((B, ld_a), -7.0, device=device)
     buf_u = torch.full((B, ld_a + 1), -7.0, device=device)
-    ops.dot_interaction(x, tail, out=buf_a[:, :n])
-    ops.dot_interaction(x, tail, out=buf_u[:, :n])
+    ops.dot_interaction(x, tail, out=buf_a[:, :n], tail_first=tail_first)
+    ops.dot_interaction(x, tail, out=buf_u[:, :n], tail_first=tail_first)
     assert torch.equal(buf_a[:, :n], buf_u[:, :n])
     assert bool((buf_a[:, n:] == -7.0).all()) and bool((buf_u[:, n:] == -7.0).all())
     ref = O.dot_interaction(x.cpu().numpy())
-    np.testing.assert_allclose(buf_a[:, :n - T].cpu().numpy(), ref, atol=ATOL * max(1.0, D / 64) * 4, rtol=1e-5)
+    pofs, tofs = (T, 0) if tail_first else (0, n - T)
+    np.testing.assert_allclose(buf_a[:, pofs:pofs + n - T].cpu().numpy(), ref, atol=ATOL * max(1.0, D / 64) * 4, rtol=1e-5)
     if T:
-        assert torch.equal(buf_a[:, n - T:n], tail)
+        assert torch.equal(buf_a[:, tofs:tofs + T], tail)
 
 
 @pytest.mark.parametrize("idt", [torch.int32, torch.int64])

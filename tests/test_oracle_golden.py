@@ -95,7 +95,10 @@ def test_dot_interaction_shape_and_order():
         np.testing.assert_allclose(out[:, p], (X[:, i] * X[:, j]).sum(-1), rtol=1e-5, atol=1e-6)
     top_in = O.dlrm_interaction_concat(X, X[:, -1])
     assert top_in.shape == (4, 10 + 8)  # F(F-1)/2 + D
-    np.testing.assert_array_equal(top_in[:, 10:], X[:, -1])
+    # [bottom_block | interactions]: tf/core/combinators.py:564-569 (dict-valued branches merged by update) +
+    # tf/core/aggregation.py:54-66 (sorted keys); pinned by the dl_* fixtures (test_golden_vectors.py)
+    np.testing.assert_array_equal(top_in[:, :8], X[:, -1])
+    np.testing.assert_array_equal(top_in[:, 8:], out)
 
 
 def test_l2norm_unit_rows():

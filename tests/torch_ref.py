@@ -19,7 +19,7 @@ def dot_interaction(X, tail=None):
     Z = torch.bmm(X, X.transpose(1, 2))
     iu = torch.triu_indices(F, F, offset=1)
     out = Z[:, iu[0], iu[1]]
-    return out if tail is None else torch.cat([out, tail], dim=1)
+    return out if tail is None else torch.cat([tail, out], dim=1)  # [bottom | interactions]: the reference's order
 
 
 def dlrm_forward(cat_ids, cont, tables, bottom, top, head):
