@@ -585,6 +585,43 @@ def run_dcn(args, device, tm: Timing):
 
 
 # ------------------------------------------------------------------------------------------------------------
+def resolve_launch(gpus: int, environ, device_count: int, argv, free_port=None):
+    """How this invocation becomes `gpus` ranks (the role `horovodrun -np N` plays for the reference,
+    tf/distributed/backend.py:12-21, examples/usecases/multi-gpu/hvd_wrapper.sh:4-13).  Pure function of its arguments:
+
+      ("run", world)    this process IS a rank (launched by torch.distributed.run, or N = 1): carry on;
+      ("spawn", cmd)    `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU;
+      SystemExit(2)     the request cannot be honoured -- fewer visible GPUs than ranks, or a launcher whose WORLD_SIZE
+                        disagrees with --gpus.  Never a line with another n_gpus than the one asked for."""
+    if gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {gpus}: need at least one GPU")
+    if "WORLD_SIZE" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {gpus}: pass --gpus {world} "
+                             f"(the line's n_gpus must be the number of ranks that ran)")
+        if device_count < int(environ.get("LOCAL_WORLD_SIZE", world)):
+            raise SystemExit(f"bench.py: {world} ranks on this node but only {device_count} visible GPU(s)")
+        return "run", world
+    if gpus == 1:
+        return "run", 1
+    if device_count < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but only {device_count} visible GPU(s) on this node: refusing to report a "
+                         f"line for fewer ranks than requested")
+    port = free_port() if free_port else 29500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    return "spawn", cmd
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["dlrm", "twotower", "topk", "dcn"], default="dlrm",
@@ -615,9 +652,15 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / cache-busting extras of the default line")
     args = ap.parse_args()
 
+    action, what = resolve_launch(args.gpus, os.environ, torch.cuda.device_count(), sys.argv[1:], _free_port)
+    if action == "spawn":  # `python bench.py --gpus N`: become N ranks (rank 0 of the child job prints the line)
+        import subprocess
+
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        raise SystemExit(subprocess.call(what, env=env))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    world = what
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:

@@ -508,7 +508,9 @@ int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* 
  * only: a step built from them is a fixed launch sequence (hipGraph-capturable).  RCCL is resolved with dlopen at the
  * first call (the copy PyTorch already loaded wins: one RCCL per process).
  *   mh_comm_unique_id: rank 0 obtains the 128-byte id; the caller broadcasts it over its own channel (MPI, a TCP store,
- *                      torch.distributed's store) and every rank calls mh_comm_init (world == 1 needs no id). */
+ *                      torch.distributed's store) and every rank calls mh_comm_init.  world == 1 needs no id: without one
+ *                      the collectives of a one-rank communicator are device copies / no-ops; WITH one it owns a real
+ *                      one-rank RCCL communicator and every call goes through RCCL (the single-GPU execution of the N-rank code). */
 typedef void* mh_comm_t;
 int32_t mh_comm_unique_id(void* id128);
 int32_t mh_comm_init(int32_t rank, int32_t world, const void* unique_id128, mh_comm_t* comm_out);

@@ -258,19 +258,30 @@ class BatchNormalization(Block):
         self.device = torch.device(device) if device is not None else default_device()
         self.gamma: Optional[Parameter] = None
         self.beta: Optional[Parameter] = None
-        self.moving_mean: Optional[torch.Tensor] = None
-        self.moving_variance: Optional[torch.Tensor] = None
+        # the moving statistics are WEIGHTS of the layer (Keras: non-trainable weights, part of save_weights / get_weights):
+        # non-trainable, non-sparse Parameters, so that checkpoints / state_dict / the rank-0 broadcast carry them while every
+        # optimizer skips them (no gradient, trainable=False)
+        self._moving_mean: Optional[Parameter] = None
+        self._moving_variance: Optional[Parameter] = None
+
+    @property
+    def moving_mean(self) -> Optional[torch.Tensor]:
+        return None if self._moving_mean is None else self._moving_mean.data
+
+    @property
+    def moving_variance(self) -> Optional[torch.Tensor]:
+        return None if self._moving_variance is None else self._moving_variance.data
 
     def build(self, n: int) -> None:
         if self.scale:
             self.gamma = Parameter(torch.ones(n, device=self.device), name=f"{self.name}/gamma")
         if self.center:
             self.beta = Parameter(torch.zeros(n, device=self.device), name=f"{self.name}/beta")
-        self.moving_mean = torch.zeros(n, device=self.device)
-        self.moving_variance = torch.ones(n, device=self.device)
+        self._moving_mean = Parameter(torch.zeros(n, device=self.device), name=f"{self.name}/moving_mean", trainable=False)
+        self._moving_variance = Parameter(torch.ones(n, device=self.device), name=f"{self.name}/moving_variance", trainable=False)
 
     def own_parameters(self):
-        return [p for p in (self.gamma, self.beta) if p is not None]
+        return [p for p in (self.gamma, self.beta, self._moving_mean, self._moving_variance) if p is not None]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.moving_mean is None:

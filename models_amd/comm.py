@@ -55,22 +55,54 @@ def default() -> Optional["Comm"]:
         return None
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or dist.get_backend() != "nccl":
         return None
-    try:
-        c = Comm.create()
-        c.self_check()
+    # Every rank must end up on the SAME side: one rank on torch.distributed while the others use this communicator is a set of
+    # mismatched collectives, i.e. a hang (round-3 advisor finding).  The outcome of each stage is agreed with an all-reduce(MIN)
+    # of an ok flag over torch.distributed BEFORE the next stage's collectives start.
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def agreed(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    c, why = None, ""
+    try:  # stage 0 (local): the library and RCCL resolve on this rank -- a rank that fails here never enters ncclCommInitRank
+        probe = (C.c_char * 128)()
+        check(_lib.load().mh_comm_unique_id(probe), "mh_comm_unique_id")
+        ok = True
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, f"{type(e).__name__}: {e}"
+    if agreed(ok):
+        try:
+            c = Comm.create()
+            ok = True
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if agreed(ok):
+            try:
+                c.self_check()
+                ok = True
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"{type(e).__name__}: {e}"
+            ok = agreed(ok)
+        else:
+            ok = False
+    else:
+        ok = False
+    if ok:
         _DEFAULT = c
-    except Exception as e:  # noqa: BLE001 -- the torch.distributed path is always available
-        print(f"[models_amd.comm] C-ABI communicator disabled ({type(e).__name__}: {e}); using torch.distributed", file=sys.stderr)
+    else:
+        print(f"[models_amd.comm] C-ABI communicator disabled on every rank ({why or 'another rank failed'}); using torch.distributed",
+              file=sys.stderr)
         _DEFAULT = None
     return _DEFAULT
 
 
 def _wait_or_die(what: str, seconds: float = 180.0) -> None:
-    """Wait for the current stream with a deadline.  A collective that never completes cannot be cancelled from here (the
-    stream is stuck behind it), so the only useful outcome is a message and a non-zero exit instead of a silent hang of
-    every rank; ``MERLIN_HIP_COMM=torch`` then runs the same job on torch.distributed."""
+    """Wait for the current stream with a deadline and RAISE when it passes (library code does not end the process: the
+    caller -- ``default()`` -- reports the failure, the ranks agree on it and fall back to torch.distributed together;
+    a collective that never completes still blocks its stream, which a caller that wants to go on must abandon)."""
     import os
-    import sys
     import time
 
     ev = torch.cuda.Event()
@@ -78,9 +110,8 @@ def _wait_or_die(what: str, seconds: float = 180.0) -> None:
     deadline = time.monotonic() + float(os.environ.get("MERLIN_HIP_COMM_TIMEOUT", seconds))
     while not ev.query():
         if time.monotonic() > deadline:
-            print(f"[models_amd.comm] {what} did not complete within the deadline: giving up "
-                  "(set MERLIN_HIP_COMM=torch to keep the collectives on torch.distributed)", file=sys.stderr, flush=True)
-            os._exit(3)
+            raise TimeoutError(f"{what} did not complete within the deadline "
+                               "(set MERLIN_HIP_COMM=torch to keep the collectives on torch.distributed)")
         time.sleep(0.002)
 
 
@@ -130,7 +161,10 @@ class Comm:
             raise RuntimeError("self-check against torch.distributed failed")
 
     @classmethod
-    def create(cls) -> "Comm":
+    def create(cls, force_rccl: bool = False) -> "Comm":
+        """``force_rccl``: at world size 1 build a REAL one-rank RCCL communicator (unique id passed to ``mh_comm_init``), so
+        that every collective of this object goes through RCCL instead of the one-rank shortcuts (GPU tests, single-GPU
+        bring-up of the N-rank code path)."""
         import torch.distributed as dist
 
         lib = _lib.load()
@@ -142,8 +176,10 @@ class Comm:
             box = [bytes(uid)]
             dist.broadcast_object_list(box, src=0)
             uid = (C.c_char * 128).from_buffer_copy(box[0])
+        elif force_rccl:
+            check(lib.mh_comm_unique_id(uid), "mh_comm_unique_id")
         h = C.c_void_p()
-        check(lib.mh_comm_init(rank, world, uid, C.byref(h)), "mh_comm_init")
+        check(lib.mh_comm_init(rank, world, uid if (world > 1 or force_rccl) else None, C.byref(h)), "mh_comm_init")
         return cls(h, rank, world)
 
     def destroy(self) -> None:

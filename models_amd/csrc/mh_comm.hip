@@ -13,6 +13,7 @@
 //   mh_allreduce_dense    = in-place SUM: reduce-scatter + all-gather (every xGMI link carries 1/W per phase)
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "mh_common.h"
@@ -88,16 +89,22 @@ struct MhComm {
         }                                                                                                \
     } while (0)
 
-// equal windows of `bytes` per peer; W == 1 is a device copy (never part of a captured multi-GPU step: the product
-// path at W == 1 aliases instead, see models_amd/distributed.py)
+// equal windows of `bytes` per peer; W == 1 without an RCCL communicator is a device copy (never part of a captured
+// multi-GPU step: the product path at W == 1 aliases instead, see models_amd/distributed.py).  A one-rank communicator that
+// was created WITH a unique id owns a real RCCL communicator and takes the RCCL path below (send / recv to itself): the
+// single-GPU execution of exactly the code an N-rank job runs.
 int32_t alltoall_bytes(RcclApi* R, MhComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s, const char* what) {
     if (bytes <= 0) return MH_OK;
-    if (c->world == 1) {
+    if (c->world == 1 && !c->comm) {
         if (hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             mh_set_error("%s: device copy failed", what);
             return MH_ERR_LAUNCH;
         }
         return MH_OK;
+    }
+    if (!R) {
+        mh_set_error("%s: librccl.so not found", what);
+        return MH_ERR_UNSUPPORTED;
     }
     MH_RCCL(R->GroupStart(), what);
     for (int p = 0; p < c->world; ++p) {
@@ -151,9 +158,9 @@ int32_t mh_comm_unique_id(void* id128) {
 
 int32_t mh_comm_init(int32_t rank, int32_t world, const void* unique_id128, void** comm_out) {
     MH_REQUIRE(comm_out && world >= 1 && rank >= 0 && rank < world && world <= 64, "mh_comm_init: bad rank / world");
+    MH_REQUIRE(world == 1 || unique_id128, "mh_comm_init: the unique id (mh_comm_unique_id on rank 0, broadcast by the caller) is required");
     MhComm* c = new MhComm{nullptr, rank, world};
-    if (world > 1) {
-        MH_REQUIRE(unique_id128, "mh_comm_init: the unique id (mh_comm_unique_id on rank 0, broadcast by the caller) is required");
+    if (unique_id128) {  // world == 1 WITH an id: a real one-rank RCCL communicator (RCCL accepts it) instead of the copy shortcut
         RcclApi* R = rccl();
         if (!R) {
             delete c;
@@ -193,10 +200,15 @@ int32_t mh_comm_alltoall(void* comm, const void* send, void* recv, int64_t bytes
 int32_t mh_allreduce_dense(void* comm, float* buf, int64_t n, mh_stream_t stream) {
     MhComm* c = static_cast<MhComm*>(comm);
     MH_REQUIRE(c && (buf || n == 0) && n >= 0, "mh_allreduce_dense: bad argument");
-    if (c->world == 1 || n == 0) return MH_OK;
+    if ((c->world == 1 && !c->comm) || n == 0) return MH_OK;
     RcclApi* R = rccl();
+    MH_REQUIRE(R, "mh_allreduce_dense: librccl.so not found");
     hipStream_t s = mh_stream(stream);
-    if (n % c->world == 0) {  // reduce-scatter into this rank's slice (in place), then all-gather the slices
+    // MERLIN_HIP_ALLREDUCE=plain: one ncclAllReduce also for divisible sizes (A/B of the two forms; the only way to reach the
+    // plain form on a one-rank communicator, where every n is divisible)
+    const char* form = getenv("MERLIN_HIP_ALLREDUCE");  // read per call: a host-side string compare beside a collective
+    const bool plain = form && !strcmp(form, "plain");
+    if (n % c->world == 0 && !plain) {  // reduce-scatter into this rank's slice (in place), then all-gather the slices
         const size_t per = (size_t)(n / c->world);
         MH_RCCL(R->ReduceScatter(buf, buf + (size_t)c->rank * per, per, NCCL_FLOAT32, NCCL_SUM, c->comm, s), "mh_allreduce_dense");
         MH_RCCL(R->AllGather(buf + (size_t)c->rank * per, buf, per, NCCL_FLOAT32, c->comm, s), "mh_allreduce_dense");

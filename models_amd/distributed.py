@@ -270,6 +270,12 @@ class ShardedEmbeddingGroup:
         a._rows = None
         a.capacity, a._capacity_n, a._steps, a._max_count, a._since_check = None, 0, 0, 0, 0
         a.overflow = torch.zeros_like(self.overflow)
+        # The request count of a ragged route is this rank's nnz: it differs from rank to rank and from step to step, so neither
+        # "n <= the count the window was sized for" nor a window derived from a local n is a decision every rank takes alike --
+        # ranks on different branches issue mismatched collectives and hang (round-3 advisor finding, reproduced on two gloo
+        # ranks).  Alias routes therefore stay on the dense exchange (exact per-peer counts, one host read per step) for good.
+        a._never_fixed = True
+        a._fmap_cache = {}
         return a
 
     # ---- capacity management ------------------------------------------------------------------------------------
@@ -336,13 +342,15 @@ class ShardedEmbeddingGroup:
             slots, n_slots = list(layout[0]), int(layout[1])
         else:
             slots, n_slots = list(range(F_sh)), F_sh
-        if self.capacity is None and self.calibration <= 0:
+        never_fixed = getattr(self, "_never_fixed", False)
+        if self.capacity is None and self.calibration <= 0 and not never_fixed:
             self.freeze_capacity(n)
         # The window was sized for _capacity_n requests.  A call with MORE requests (evaluate / predict with a larger batch,
         # a bigger train batch) would overflow it and silently drop requests: such a call takes the dense exchange (host-side
-        # counts, exact).  n is the same on every rank (equal per-rank batches -- the fixed all-to-all needs that anyway), so
-        # all ranks take the same branch.
-        fixed = self.capacity is not None and n <= self._capacity_n
+        # counts, exact).  For the one-hot routes that reach this point n = F x B is the same on every rank (equal per-rank
+        # batches -- the fixed all-to-all needs that anyway), so all ranks take the same branch; routes whose n is rank-local
+        # (ragged aliases) never leave the dense exchange.
+        fixed = self.capacity is not None and n <= self._capacity_n and not never_fixed
         if fixed and self.check_every > 0:
             self._since_check += 1
             capturing = send_capturing()
@@ -366,7 +374,7 @@ class ShardedEmbeddingGroup:
             n_recv = sum(self._recv_counts)
             self._max_count = max(self._max_count, max(self._send_counts), max(self._recv_counts))
             self._steps += 1
-            if self.capacity is None and self._steps >= self.calibration:
+            if self.capacity is None and self._steps >= self.calibration and not never_fixed:
                 if W > 1:  # every rank must choose the same window
                     m = torch.tensor([self._max_count], dtype=torch.int64, device=send_keys.device)
                     dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
@@ -374,7 +382,13 @@ class ShardedEmbeddingGroup:
                 self._freeze_after = n
         if features is not None and list(features) != list(range(F_sh)):
             # the route numbers the id columns 0 .. F_sh - 1; ``features`` says which features of the GROUP they are
-            fmap = torch.tensor(list(features), dtype=torch.int64, device=send_keys.device)
+            # one tensor per (features, device), built once: a per-lookup torch.tensor(list) is a pageable host-to-device copy
+            # and a synchronisation in every step, and illegal while a step is being captured
+            cache = self.__dict__.setdefault("_fmap_cache", {})
+            fkey = (tuple(int(f) for f in features), str(send_keys.device))
+            fmap = cache.get(fkey)
+            if fmap is None:
+                fmap = cache[fkey] = torch.tensor(list(fkey[0]), dtype=torch.int64, device=send_keys.device)
             low = (1 << 40) - 1
             send_keys = torch.where(send_keys >= 0, (fmap[(send_keys >> 40).clamp(min=0)] << 40) | (send_keys & low), send_keys)
         self._pos_of, self._src_row, self._n_send = pos_of, src_row, send_keys.numel()

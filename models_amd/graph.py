@@ -176,12 +176,11 @@ class SegmentedStep:
         return self.output
 
     def _launch(self, i, sg) -> None:
-        if not self._first:
+        # segments that captured nothing (two cuts in a row) were flagged at capture time and are in _skip; a launch failure of
+        # any OTHER segment is a real error -- dropping it would silently remove a part of the train step
+        try:
             sg["graph"].replay()
-            return
-        try:  # first replay: a segment that captured nothing (two cuts in a row) may refuse to launch -- drop it
-            sg["graph"].replay()
-        except RuntimeError:
-            self._skip.add(i)
+        except RuntimeError as e:
+            raise RuntimeError(f"segmented step: segment {i} (stream {sg['stream']!r}) failed to launch: {e}") from e
 
     __call__ = replay

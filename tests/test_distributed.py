@@ -483,14 +483,20 @@ def _list_parts():
     return m
 
 
-def _list_batches(world, B, steps, seed=31):
-    """per step: (per-rank inputs, labels [world, B, 1]); ragged histories with empty bags and pruned (-1) ids."""
+_UNEVEN_HI = [(5, 5), (5, 5), (2, 9), (9, 2), (3, 8), (8, 3)]  # bag-length bound per (step, rank)
+
+
+def _list_batches(world, B, steps, seed=31, uneven=False):
+    """per step: (per-rank inputs, labels [world, B, 1]); ragged histories with empty bags and pruned (-1) ids.
+    ``uneven``: after the calibration steps one rank's nnz falls far below and the other's rises far above the counts seen
+    before -- the request count of the ragged route is rank-local (the advisor's hang scenario)."""
     g = torch.Generator().manual_seed(seed)
     out = []
-    for _ in range(steps):
+    for s_ in range(steps):
         ranks = []
         for _r in range(world):
-            lens = torch.randint(0, 5, (B,), generator=g)
+            hi = _UNEVEN_HI[s_ % len(_UNEVEN_HI)][_r % 2] if uneven else 5
+            lens = torch.randint(0, hi, (B,), generator=g)
             lens[3] = 0
             offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
             vals = torch.randint(0, 2003, (int(offs[-1]),), generator=g)
@@ -510,7 +516,7 @@ def _list_inputs(r):
     return x
 
 
-def _list_worker(rank, world, port, q):
+def _list_worker(rank, world, port, q, uneven=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -519,9 +525,9 @@ def _list_worker(rank, world, port, q):
         import ops_shim
 
         ops_shim.install()
-        B, steps = 40, 4
+        B, steps = 40, (6 if uneven else 4)
         model = _list_parts()
-        batches = _list_batches(world, B, steps)
+        batches = _list_batches(world, B, steps, uneven=uneven)
         model(_list_inputs(batches[0][0][rank]))
         _reseed(model)
         dm = D.DistributedModel(model, shard_threshold=1000)
@@ -540,20 +546,26 @@ def _list_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_distributed_model_world2_list_features_on_sharded_tables():
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("uneven", [False, True])
+def test_distributed_model_world2_list_features_on_sharded_tables(uneven):
     """A ragged history that SHARES the row-sharded item table with the one-hot item id, and a dense list over another sharded
     table: two ranks with half a batch each end where ONE model trained on the concatenated batch ends -- rows fetched per
     value through the alias route, combined on the requesting rank, gradient rows expanded per value and applied by the owner
-    together with the one-hot lookups' rows in ONE Adagrad step per table."""
+    together with the one-hot lookups' rows in ONE Adagrad step per table.
+    uneven: the two ranks' nnz diverge after the calibration steps (one far below, one far above what the windows saw): a
+    rank-local "fits the window" decision sent the ranks down different branches (mismatched collectives, a hang)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import ops_shim
     from models_amd import ops
 
-    world, B, steps = 2, 40, 4
+    world, B, steps = 2, 40, (6 if uneven else 4)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_list_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_list_worker, args=(r, world, port, q, uneven)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
@@ -566,7 +578,7 @@ def test_distributed_model_world2_list_features_on_sharded_tables():
         import models_amd as mm
 
         model = _list_parts()
-        batches = _list_batches(world, B, steps)
+        batches = _list_batches(world, B, steps, uneven=uneven)
         model(_list_inputs(batches[0][0][0]))
         _reseed(model)
         ref_losses = []

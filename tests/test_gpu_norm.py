@@ -112,3 +112,24 @@ def test_mlp_block_with_dropout_and_batch_norm_trains_like_the_statement(device)
     assert losses[-1] < losses[0] * 0.9
     bnl = [l for l in model.body.top_block.layers if isinstance(l, mm.BatchNormalization)][0]
     assert float(bnl.moving_mean.abs().max()) > 0
+    # save -> load -> eval round trip: the moving statistics are weights of the layer (Keras save_weights includes non-trainable
+    # weights); a restored model must normalise with the trained statistics, not with mean 0 / variance 1
+    import os
+    import tempfile
+
+    want = model(xb).cpu()
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.npz")
+        model.save_weights(path)
+        fresh = mm.DLRMModel(mm.Schema(cols), embedding_dim=8, bottom_block=mm.MLPBlock([8], device=device),
+                             top_block=mm.MLPBlock([16, 8], dropout=0.1, normalization="batch_norm", device=device), device=device)
+        fresh.compile(optimizer="adagrad", learning_rate=0.05)
+        fresh(xb)  # build
+        assert not torch.allclose(fresh(xb).cpu(), want, atol=1e-3)
+        fresh.load_weights(path)
+    fbn = [l for l in fresh.body.top_block.layers if isinstance(l, mm.BatchNormalization)][0]
+    assert torch.equal(fbn.moving_mean, bnl.moving_mean) and torch.equal(fbn.moving_variance, bnl.moving_variance)
+    torch.testing.assert_close(fresh(xb).cpu(), want, atol=1e-6, rtol=0)
+    names = [p.name for p in model.parameters()]
+    assert any(n.endswith("/moving_mean") for n in names) and any(n.endswith("/moving_variance") for n in names)
+    assert all(not p.trainable for p in model.parameters() if "moving_" in p.name)

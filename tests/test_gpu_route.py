@@ -84,11 +84,17 @@ def test_route_build_fixed_capacity_matches_statement(W, cap):
     assert torch.equal(r_hip, r_ref) and bool((r_hip[got[0] < 0] == -1).all()) and bool((r_hip == -1).any())
 
 
+@pytest.mark.parametrize("rccl", [False, True])
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])
-def test_comm_sharded_lookup_single_rank_matches_direct_path(opt):
-    """mh_comm_* / mh_sharded_lookup_fwd / _bwd with a world of one: the exchange degenerates to device copies, so the
-    result must equal the unsharded gather and the unsharded fused update bit for bit (same kernels, same order of the
-    duplicate rows: the route keeps request order within an owner)."""
+def test_comm_sharded_lookup_single_rank_matches_direct_path(opt, rccl, monkeypatch):
+    """mh_comm_* / mh_sharded_lookup_fwd / _bwd with a world of one: the result must equal the unsharded gather and the
+    unsharded fused update (same kernels, same order of the duplicate rows: the route keeps request order within an owner).
+    rccl=False: the exchange degenerates to device copies.  rccl=True: the communicator is a REAL one-rank RCCL communicator
+    (mh_comm_unique_id -> mh_comm_init with the id: dlopen of librccl, ncclGetUniqueId, ncclCommInitRank with the 128-byte id
+    BY VALUE) and every exchange runs ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, the bucket reduction
+    ncclReduceScatter + ncclAllGather, and with MERLIN_HIP_ALLREDUCE=plain ncclAllReduce -- the code an N-rank job runs, on
+    one GPU (reference role: sok.lookup_sparse, tf/distributed/embedding.py:117-149; hvd.DistributedOptimizer,
+    tf/models/base.py:476-508)."""
     from models_amd import comm as mc
     from models_amd import ops
 
@@ -99,7 +105,7 @@ def test_comm_sharded_lookup_single_rank_matches_direct_path(opt):
     ids = [torch.randint(0, r, (B,), generator=g).to(torch.int32).to(dev) for r in rows]
     ids[1][:50] = 7  # duplicates
     F = len(rows)
-    c = mc.Comm.create()
+    c = mc.Comm.create(force_rccl=rccl)
     assert (c.rank, c.world) == (0, 1)
     local = torch.cat(tabs).contiguous()
     base = torch.tensor([0, rows[0], rows[0] + rows[1]], dtype=torch.int64, device=dev)
@@ -131,8 +137,19 @@ def test_comm_sharded_lookup_single_rank_matches_direct_path(opt):
 
     flat = torch.randn(1000, device=dev)
     keep = flat.clone()
-    assert torch.equal(c.allreduce_(flat), keep)  # world of one: identity
+    assert torch.equal(c.allreduce_(flat), keep)  # world of one: identity (reduce-scatter + all-gather under rccl=True)
+    monkeypatch.setenv("MERLIN_HIP_ALLREDUCE", "plain")
+    assert torch.equal(c.allreduce_(flat), keep)  # one ncclAllReduce under rccl=True
+    monkeypatch.delenv("MERLIN_HIP_ALLREDUCE")
     a, b = torch.arange(64, device=dev, dtype=torch.float32), torch.empty(64, device=dev)
     c.alltoall(a, b)
     assert torch.equal(a, b)
+    # the asynchronous forms the sharded step uses (communicator's own stream, event hand-off)
+    b.zero_()
+    w1 = c.alltoall_async(a, b)
+    w2 = c.allreduce_async(flat)
+    w1.wait()
+    w2.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(flat, keep)
     c.destroy()
