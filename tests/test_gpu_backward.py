@@ -224,8 +224,16 @@ def test_dlrm_train_steps_adam_lazyadam_match_reference_formulas(device):
         grads = torch.autograd.grad(ref_loss, params)
         lr_t = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
         with torch.no_grad():
+            names = list(tables)
             for k, (p, gr) in enumerate(zip(params, grads)):
-                touched = (gr != 0).any(dim=-1, keepdim=True) if k < len(tables) else torch.ones_like(p, dtype=torch.bool)
+                if k < len(tables):
+                    # the rows of the IndexedSlices are the LOOKED-UP rows, whatever their gradient values: a sample whose ReLUs
+                    # are all dead contributes a zero gradient row, and LazyAdam still decays that row's moments and moves it
+                    # (tf/blocks/optimizer.py:412-437 scatters over `indices`); `gr != 0` would call such a row untouched
+                    touched = torch.zeros(p.shape[0], 1, dtype=torch.bool)
+                    touched[x[names[k]].reshape(-1)] = True
+                else:
+                    touched = torch.ones_like(p, dtype=torch.bool)
                 m2 = b1 * ms[k] + (1 - b1) * gr
                 v2 = b2 * vs[k] + (1 - b2) * gr * gr
                 w2 = p - lr_t * m2 / (v2.sqrt() + eps)
