@@ -473,8 +473,25 @@ int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad,
                                       float* const* state2, float beta1, float beta2, const float* lr_device,
                                       mh_stream_t stream);
 
+/* Backward of a cross layer  out = x0 * p + x,  p = x W + b  (Cross.call, blocks/cross.py:188-202, differentiated by the
+ * GradientTape of BaseModel.train_step, models/base.py:1121-1174):
+ *     g = d loss / d p = dout * x0;   d loss / d x0 (this layer's share) = dout * p;   d loss / d x = g W^T + dout;
+ *     dW = x^T g;   db = column sums of g.
+ * All operands are contiguous [M, d] with d % 4 == 0 (zero-padded layers) and 16-byte aligned.  The non-NULL outputs select
+ * the phases, so that the caller can run dX on its launch stream and dW / db beside it on another:
+ *   dx0_acc != NULL : ONE element-wise pass: g = dout * x0 (written to the caller's [M, d] buffer `g`) and
+ *                     dx0_acc = (accumulate_dx0 ? dx0_acc : 0) + dout * p  (the sum over the layers of a CrossBlock);
+ *   dx      != NULL : dx [M, d] = g W^T + dout on the MFMA GEMM, the residual add in its epilogue.  W is [d, r] row-major,
+ *                     g [M, r]: r = d for a full-rank layer; for a low-rank layer (DenseMaybeLowRank, blocks/mlp.py:304-396)
+ *                     the caller passes g = d loss / d h [M, r] and W = U [d, r];
+ *   dW      != NULL : dW [d, d] = x^T g and db [d] (full-rank layer; workspace mh_linear_bwd_workspace_bytes(M, d, d)). */
+int32_t mh_cross_layer_bwd(const float* x0, const float* x, const float* p, const float* dout, const float* W, int64_t M,
+                           int32_t d, int32_t r, float* g, float* dx0_acc, int32_t accumulate_dx0, float* dx, float* dW,
+                           float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+
 /* Elementwise helper of the cross-layer backward (blocks/cross.py:188-202 under GradientTape):
- * op 0: out = a*b;  op 1: out = a+b;  op 2: out = a*b + c.  n contiguous floats. */
+ * op 0: out = a*b;  op 1: out = a+b;  op 2: out = a*b + c.  n contiguous floats (float4 path when n % 4 == 0 and the
+ * pointers are 16-byte aligned).  The full-rank cross backward no longer uses it (mh_cross_layer_bwd). */
 int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, float* out, int64_t n,
                    mh_stream_t stream);
 

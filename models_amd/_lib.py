@@ -70,6 +70,7 @@ SIGNATURES = {
     "mh_cross_layer_fwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
     "mh_cross_layer_fwd_save": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "mh_cross_layer_lowrank_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "mh_cross_layer_bwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _i32, _p, _p, _p, _p, _i64, _p]),
     "mh_l2norm_rows": (_i32, [_p, _i64, _i32, _f32, _p, _p]),
     "mh_l2norm_rows_bwd": (_i32, [_p, _p, _i64, _i32, _f32, _p, _p]),
     "mh_inbatch_softmax_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),

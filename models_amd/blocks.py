@@ -645,25 +645,37 @@ class Cross(Block):
         self._h = ops.linear(xw, self.kernel_u.data, None, None)  # [B, r4], pad columns exactly zero
         return ops.cross_layer_lowrank(x0w, xw, self._h, self.kernel.data, self.bias.data)[:, :d]
 
-    def backward(self, dout):
-        """out = x0 * p + x with p = x W + b (W = U V when low-rank): returns (dx0, dx); sets the grads."""
+    def backward(self, dout, dx0_acc: Optional[torch.Tensor] = None):
+        """out = x0 * p + x with p = x W + b (W = U V when low-rank): returns (dx0_acc, dx); sets the grads.  ``dx0_acc``: the
+        running sum of d loss / d x0 over the layers of the CrossBlock -- this layer's share ``dout * p`` is ADDED to it in the
+        same pass that forms g = dout * x0 (``mh_cross_layer_bwd``), and dx = g W^T + dout leaves the GEMM with the residual
+        already added: no element-wise launch of its own per layer, where the first version needed four."""
         x0, x = self._x0, self._x
         d, d4 = self.d, self.d4
         dout = _widen(dout, d4)
+        if not dout.is_contiguous():
+            dout = dout.contiguous()
         src = x if self.kernel_u is None else self._h
         p = getattr(self, "_p", None)  # stored by the forward under blocks.tape() ...
         if p is None:
             p = ops.linear(src, self.kernel.data, self.bias.data, None)  # ... recomputed otherwise
         self._p = None
-        dx0 = ops.eltwise("mul", dout, p)
+        if self.kernel_u is None:
+            dx0_acc, dx, dW, db = ops.cross_layer_backward(x0, x, p, dout, self.kernel.data, dx0_acc)
+            self.kernel.grad, self.bias.grad = dW, db
+            return dx0_acc, dx
+        # low-rank: p = (x U) V + b.  g and this layer's dx0 share by the fused element-wise ops; dh = g V^T, dV = h^T g, db through
+        # the Dense backward; dx = dh U^T + dout with the residual add in the GEMM epilogue; dU = x^T dh
+        dx0 = ops.eltwise("mul", dout, p) if dx0_acc is None else ops.eltwise("fma", dout, p, dx0_acc)
         g = ops.eltwise("mul", dout, x0)                             # d loss / d p
-        dsrc, dW, db = ops.linear_backward(src, self.kernel.data, None, g, None, need_dx=True, need_db=True)
-        self.kernel.grad, self.bias.grad = dW, db
-        if self.kernel_u is not None:
-            dh = _widen(dsrc, self.r4)
-            dsrc, dU, _ = ops.linear_backward(x, self.kernel_u.data, None, dh, None, need_dx=True, need_db=False)
-            self.kernel_u.grad = dU
-        return dx0, ops.eltwise("add", _widen(dsrc, d4), dout)  # both [B, d4], pad columns zero
+        dh, dV, db = ops.linear_backward(src, self.kernel.data, None, g, None, need_dx=True, need_db=True)
+        self.kernel.grad, self.bias.grad = dV, db
+        dh = _widen(dh, self.r4)
+        if not dh.is_contiguous():
+            dh = dh.contiguous()
+        _, dU, _ = ops.linear_backward(x, self.kernel_u.data, None, dh, None, need_dx=False, need_db=False)
+        self.kernel_u.grad = dU
+        return dx0, ops.cross_lowrank_dx(dh, self.kernel_u.data, dout)  # both [B, d4], pad columns zero
 
 
 class CrossBlock(Block):
@@ -691,8 +703,7 @@ class CrossBlock(Block):
         dx0_total = None
         dx = grad
         for layer in reversed(self.layers):
-            dx0, dx = layer.backward(dx)  # [B, d4] zero-padded
-            dx0_total = dx0 if dx0_total is None else ops.eltwise("add", dx0_total, dx0)
+            dx0_total, dx = layer.backward(dx, dx0_total)  # [B, d4] zero-padded; every layer adds its share of d loss / d x0
         return ops.eltwise("add", dx0_total, dx)[:, :self.layers[0].d]  # layer 0 has x = x0
 
 

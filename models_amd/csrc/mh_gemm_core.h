@@ -215,7 +215,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 }
 
 // ---- epilogue shared by every GEMM kernel (both cores) ----------------------------------------------------------------
-// out = x_act'(maskx) * act( [x0 * (acc + bias) + xres]  or  (acc + bias) ),  optionally p_out = acc + bias.
+// out = x_act'(maskx) * act( [x0 * (acc + bias) + xres]  or  (acc + bias) ) [+ addend],  optionally p_out = acc + bias.
 struct EpiArgs {
     const float* bias;  // [N] or NULL
     int act;            // MH_ACT_*
@@ -227,6 +227,8 @@ struct EpiArgs {
     const float* maskx;  // dX: the producer's activation derivative folded in (x_act of mh_linear_bias_act_bwd)
     int64_t ldm;
     int x_act;
+    const float* addend;  // out += addend[row, col] at the very end (dX of a cross layer: dx = g W^T + dout), [M, ld_add]
+    int64_t ld_add;
 };
 
 template <int A>
@@ -254,7 +256,30 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
                                            int col_base, int64_t M, int N, int lane, const EpiArgs& ep) {
     const int l31 = lane & 31, h = lane >> 5;
     const bool full = row_base + TM * 32 <= M && col_base + TN * 32 <= N;  // uniform per wavefront
-    const bool plain = !ep.x0 && !ep.p_out && (ep.x_act == MH_ACT_NONE || (ep.x_act == MH_ACT_RELU && !ep.bias && ep.act == MH_ACT_NONE));
+    const bool plain = !ep.x0 && !ep.p_out && !ep.addend &&
+                       (ep.x_act == MH_ACT_NONE || (ep.x_act == MH_ACT_RELU && !ep.bias && ep.act == MH_ACT_NONE));
+    if (full && ep.addend && !ep.x0 && !ep.p_out && !ep.bias && ep.act == MH_ACT_NONE && ep.x_act == MH_ACT_NONE) {
+        // dX of a cross layer: out = acc + addend.  The addend values of four rows x TN column blocks are fetched together and
+        // then used (same reason as in the cross branch below: loads inside per-element tests compile to a round trip each)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t r0 = row_base + tm * 32 + 8 * g + 4 * h;
+                const float* pa = ep.addend + r0 * ep.ld_add + col_base + l31;
+                float ad[4][TN];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) ad[q][tn] = pa[q * ep.ld_add + 32 * tn];
+                float* pc = C + r0 * ldc + col_base + l31;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) pc[q * ldc + 32 * tn] = acc[tm][tn][4 * g + q] + ad[q][tn];
+            }
+        return;
+    }
     if (full && plain) {
         float bv[TN];
 #pragma unroll
@@ -364,6 +389,7 @@ __device__ __forceinline__ void store_tile(f32x16 (&acc)[TM][TN], float* __restr
                         const float xx = ep.maskx[row * ep.ldm + col];
                         v *= xx * (1.f - xx);
                     }
+                    if (ep.addend) v += ep.addend[row * ep.ld_add + col];
                     C[row * ldc + col] = v;
                 }
             }

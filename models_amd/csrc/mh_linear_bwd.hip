@@ -63,6 +63,24 @@ __global__ __launch_bounds__(256) void act_grad_colsum_kernel(const float* __res
 // independent loads in flight, then the 16 group sums are combined in fixed order through LDS -> deterministic, and S
 // sequential HBM round trips become S/64 (with 4 groups a thread walked S/4 slices four at a time: 16 dependent rounds of HBM
 // latency for the 256 splits of the 415 x 128 layer, 37 us for 54 MB).
+// Few slabs (S <= 8) of a LONG vector -- dW of a wide layer, e.g. the 3344 x 3344 cross kernel split in two over the batch: the
+// general kernel below spends a 1024-thread workgroup on 64 outputs (14 of its 16 groups idle at S = 2: 2.85 ms for 134 MB, round-3
+// profile).  Here: one float4 of the output per thread, the slabs summed in ascending order (deterministic), streaming loads.
+__global__ __launch_bounds__(256) void reduce_slabs_vec_kernel(const float* __restrict__ part, int S, int64_t len4,
+                                                              float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len4) return;
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < S) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part) + (int64_t)k * len4 + i);
+    f32x4 t = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < S) t += v[k];
+    reinterpret_cast<f32x4*>(out)[i] = t;
+}
+
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int S,
                                                               int64_t len, float* __restrict__ out,
                                                               const float* __restrict__ part2, int64_t len2,
@@ -133,7 +151,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const float* __re
                                                      const float* __restrict__ Bm, int64_t ldb, int64_t M,
                                                      int Nout, int Kc, float* __restrict__ Cm, int64_t ldc,
                                                      int vec_a, int vec_b, const float* __restrict__ maskx,
-                                                     int64_t ldm, int x_act) {
+                                                     int64_t ldm, int x_act, const float* __restrict__ addend,
+                                                     int64_t ld_add) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDK + 2 * BN * LDK];
     float* As0 = smem;
@@ -179,6 +198,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const float* __re
     ep.maskx = maskx;
     ep.ldm = ldm;
     ep.x_act = maskx ? x_act : MH_ACT_NONE;
+    ep.addend = addend;
+    ep.ld_add = ld_add;
     store_tile<TM, TN>(acc, Cm, ldc, row0 + wm * TM * 32, n0 + wn * TN * 32, M, Nout, lane, ep);
 }
 
@@ -474,6 +495,9 @@ BwdPlan make_plan(int64_t M, int K, int N) {
 int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout,
                                  int Kc, float* Cm, int64_t ldc, const float* maskx, int64_t ldm, int x_act,
                                  hipStream_t s);
+int32_t mh_internal_gemm_nt_ep(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout,
+                               int Kc, float* Cm, int64_t ldc, const float* maskx, int64_t ldm, int x_act,
+                               const float* addend, int64_t ld_add, hipStream_t s);
 
 int32_t mh_internal_gemm_nt(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout, int Kc,
                             float* Cm, int64_t ldc, hipStream_t s) {
@@ -483,6 +507,13 @@ int32_t mh_internal_gemm_nt(const float* A, int64_t lda, const float* Bm, int64_
 int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout,
                                  int Kc, float* Cm, int64_t ldc, const float* maskx, int64_t ldm, int x_act,
                                  hipStream_t s) {
+    return mh_internal_gemm_nt_ep(A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, maskx, ldm, x_act, nullptr, 0, s);
+}
+
+// C = A B^T, optionally with the producer's activation derivative folded in (maskx, x_act) and / or `+ addend` at the end
+int32_t mh_internal_gemm_nt_ep(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t M, int Nout,
+                               int Kc, float* Cm, int64_t ldc, const float* maskx, int64_t ldm, int x_act,
+                               const float* addend, int64_t ld_add, hipStream_t s) {
     const int vec_a = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
     const int vec_b = ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0) && (ldb % 4 == 0);
     static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
@@ -492,6 +523,8 @@ int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, i
         ep.maskx = maskx;
         ep.ldm = ldm;
         ep.x_act = maskx ? x_act : MH_ACT_NONE;
+        ep.addend = addend;
+        ep.ld_add = ld_add;
         const hipError_t e = mhgemm2::launch<256, 128, 4, 2, true, 3>(A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, ep, s);
         if (e != hipSuccess) {
             mh_set_error("gemm_nt: launch failed: %s", hipGetErrorString(e));
@@ -505,7 +538,7 @@ int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, i
     // on a CU for the dW GEMM that the eager / segmented step runs beside dX on a side stream: those steps LOSE 30-45 us
     // (0.967 -> 1.012 ms eager, same box, four alternating runs each; profiles/r3_notes.md).
     static const bool astat = getenv("MERLIN_HIP_ASTAT") != nullptr;
-    if (astat && (!maskx || x_act == MH_ACT_NONE) && Kc == 128 && vec_a && vec_b && Nout >= 128 && mh_ceil_div(M, 256) * 10 >= (int64_t)mh_num_cus() * 9) {
+    if (astat && !addend && (!maskx || x_act == MH_ACT_NONE) && Kc == 128 && vec_a && vec_b && Nout >= 128 && mh_ceil_div(M, 256) * 10 >= (int64_t)mh_num_cus() * 9) {
         auto kern = gemm_nt_astat_kernel<128>;
         const size_t lds = (size_t)(2 * 64 * 128 + 8 * 32 * 36) * sizeof(float);  // two B stages + one transpose patch per wavefront
         static bool attr_done = false;
@@ -519,13 +552,13 @@ int32_t mh_internal_gemm_nt_mask(const float* A, int64_t lda, const float* Bm, i
     }
     if (Nout > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(Nout, 128));
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
     } else if (Nout > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
     } else {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
     }
     MH_CHECK_LAUNCH("gemm_nt");
     return MH_OK;
@@ -592,9 +625,12 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
         static const bool no_v2 = getenv("MERLIN_HIP_GEMM_V1") != nullptr;
         // second-generation core (DMA tiles, 3-deep ring): 415 x 128 211 -> 199 us with dX, 3344 x 3344 27.0 -> 23.7 ms; the
         // 256 x 128 layer of the two-tower config is faster on the first generation (measured, profiles/r2_notes.md)
+        // one slab: the GEMM writes dW / db themselves, nothing to reduce
+        float* out_dw = (p.splits == 1) ? dW : ws_dw;
+        float* out_db = (p.splits == 1) ? db : ws_db;
         if (!no_v2 && vec_x && vec_dy && K >= 256 && N >= 128 && (int64_t)K * N >= 49152) {
             const hipError_t e = mhgemm2::launch_tn<256, 128, 4, 2, 3>(x, ldx, dy, lddy, M, K, N, p.rows_per_split, p.splits,
-                                                                       ws_dw, db ? ws_db : nullptr, s);
+                                                                       out_dw, db ? out_db : nullptr, s);
             if (e != hipSuccess) {
                 mh_set_error("mh_linear_bias_act_bwd: launch failed: %s", hipGetErrorString(e));
                 return MH_ERR_LAUNCH;
@@ -602,18 +638,90 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
         } else if (big_tiles(K, N)) {
             dim3 grid((unsigned)mh_ceil_div(K, 128), (unsigned)mh_ceil_div(N, 128), (unsigned)p.splits);
             hipLaunchKernelGGL((gemm_tn_splitm_kernel<128, 128>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
-                               p.rows_per_split, ws_dw, vec_x, vec_dy, db ? ws_db : nullptr);
+                               p.rows_per_split, out_dw, vec_x, vec_dy, db ? out_db : nullptr);
         } else {
             dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), (unsigned)p.splits);
             hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
-                               p.rows_per_split, ws_dw, vec_x, vec_dy, db ? ws_db : nullptr);
+                               p.rows_per_split, out_dw, vec_x, vec_dy, db ? out_db : nullptr);
         }
         const int64_t len = (int64_t)K * N;
-        const int b1 = (int)mh_ceil_div(len, 64), b2 = db ? (int)mh_ceil_div(N, 64) : 0;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(b1 + b2)), dim3(1024), 0, s, ws_dw, p.splits, len, dW,
-                           ws_db, (int64_t)N, db, b1);  // dW and db slabs in ONE launch
+        if (p.splits == 1) {
+            // nothing to reduce
+        } else if (p.splits <= 8 && len % 4 == 0 && len >= (1 << 16) && (reinterpret_cast<uintptr_t>(dW) & 15) == 0) {
+            // few slabs of a long vector (wide layers): float4 per thread; db (N floats x S slabs) keeps the small general kernel
+            hipLaunchKernelGGL(reduce_slabs_vec_kernel, dim3((unsigned)mh_ceil_div(len / 4, 256)), dim3(256), 0, s, ws_dw, p.splits,
+                               len / 4, dW);
+            if (db)
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(1024), 0, s, ws_db, p.splits,
+                                   (int64_t)N, db, (const float*)nullptr, (int64_t)0, (float*)nullptr, (int)mh_ceil_div(N, 64));
+        } else {
+            const int b1 = (int)mh_ceil_div(len, 64), b2 = db ? (int)mh_ceil_div(N, 64) : 0;
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(b1 + b2)), dim3(1024), 0, s, ws_dw, p.splits, len, dW,
+                               ws_db, (int64_t)N, db, b1);  // dW and db slabs in ONE launch
+        }
     }
     MH_CHECK_LAUNCH("mh_linear_bias_act_bwd");
+    return MH_OK;
+}
+
+// ---- backward of a DCN-v2 cross layer  out = x0 * p + x,  p = x W + b  (blocks/cross.py:188-202 under the tape) ---------
+//   d loss / d p  = g   = dout * x0
+//   d loss / d x0 (this layer's share) = dout * p            -> accumulated over the layers of a CrossBlock
+//   d loss / d x  = g W^T + dout                              -> the residual add rides in the GEMM epilogue
+//   dW = x^T g,  db = column sums of g
+// Three phases selected by the non-NULL outputs (the caller may run dX on its launch stream and dW beside it on another):
+//   dx0_acc != NULL : ONE pass over [M, d]: g = dout * x0 and dx0_acc = (accumulate ? dx0_acc : 0) + dout * p
+//   dx      != NULL : dx = a W^T + dout on the MFMA GEMM (a = g; for a low-rank layer the caller passes a = d loss / d h and
+//                     W = U [d, r]: `r` is the contraction width)
+//   dW      != NULL : dW [d, d] = x^T g, db [d]  (workspace: mh_linear_bwd_workspace_bytes(M, d, d))
+namespace {
+__global__ __launch_bounds__(256) void cross_bwd_pre_kernel(const f32x4* __restrict__ dout, const f32x4* __restrict__ x0,
+                                                           const f32x4* __restrict__ p, f32x4* __restrict__ g,
+                                                           f32x4* __restrict__ dx0_acc, int accumulate, int64_t n4) {
+    // one float4 per thread, one pass: the hardware workgroup dispatcher beats a persistent loop for pure streaming on this
+    // chip (profiles/r3_notes.md, copy lab); dout / x0 / p are read once here -> streaming loads
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 d = __builtin_nontemporal_load(dout + i);
+    const f32x4 a = __builtin_nontemporal_load(x0 + i);
+    const f32x4 q = __builtin_nontemporal_load(p + i);
+    f32x4 acc = d * q;
+    if (accumulate) acc += dx0_acc[i];
+    g[i] = d * a;
+    dx0_acc[i] = acc;
+}
+}  // namespace
+
+int32_t mh_cross_layer_bwd(const float* x0, const float* x, const float* p, const float* dout, const float* W, int64_t M,
+                           int32_t d, int32_t r, float* g, float* dx0_acc, int32_t accumulate_dx0, float* dx, float* dW,
+                           float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0, "mh_cross_layer_bwd: d=%d must be a positive multiple of 4 (zero-padded layers)", d);
+    MH_REQUIRE(g && dout, "mh_cross_layer_bwd: g and dout are required");
+    MH_REQUIRE(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0,
+               "mh_cross_layer_bwd: operands must be 16-byte aligned");
+    hipStream_t s = mh_stream(stream);
+    if (dx0_acc) {
+        MH_REQUIRE(x0 && p, "mh_cross_layer_bwd: x0 and p are required for the element-wise phase");
+        MH_REQUIRE(((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(dx0_acc)) & 15) == 0,
+                   "mh_cross_layer_bwd: operands must be 16-byte aligned");
+        const int64_t n4 = M * (int64_t)(d / 4);
+        hipLaunchKernelGGL(cross_bwd_pre_kernel, dim3((unsigned)mh_ceil_div(n4, 256)), dim3(256), 0, s,
+                           reinterpret_cast<const f32x4*>(dout), reinterpret_cast<const f32x4*>(x0),
+                           reinterpret_cast<const f32x4*>(p), reinterpret_cast<f32x4*>(g), reinterpret_cast<f32x4*>(dx0_acc),
+                           accumulate_dx0 ? 1 : 0, n4);
+        MH_CHECK_LAUNCH("mh_cross_layer_bwd(pre)");
+    }
+    if (dx) {
+        MH_REQUIRE(W && r >= 4 && r % 4 == 0, "mh_cross_layer_bwd: W [d, r] with r a positive multiple of 4 is required for dx");
+        const int32_t st = mh_internal_gemm_nt_ep(g, (int64_t)r, W, (int64_t)r, M, d, r, dx, (int64_t)d, nullptr, 0, MH_ACT_NONE,
+                                                  dout, (int64_t)d, s);
+        if (st != MH_OK) return st;
+    }
+    if (dW) {
+        MH_REQUIRE(x, "mh_cross_layer_bwd: x is required for dW");
+        return mh_linear_bias_act_bwd(x, (int64_t)d, nullptr, nullptr, 0, g, (int64_t)d, M, d, d, MH_ACT_NONE, MH_ACT_NONE,
+                                      nullptr, 0, dW, db, workspace, workspace_bytes, stream);
+    }
     return MH_OK;
 }
 

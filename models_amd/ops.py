@@ -1264,6 +1264,66 @@ def cross_layer_lowrank(x0: torch.Tensor, x: torch.Tensor, h: torch.Tensor, V: t
     return out
 
 
+def cross_layer_backward(x0: torch.Tensor, x: torch.Tensor, p: torch.Tensor, dout: torch.Tensor, W: torch.Tensor,
+                         dx0_acc: Optional[torch.Tensor] = None):
+    """Backward of a full-rank cross layer ``out = x0 * (x W + b) + x`` (tf/blocks/cross.py:188-202 under the tape) through
+    ``mh_cross_layer_bwd``: ONE element-wise pass (g = dout * x0, dx0_acc (+)= dout * p), dx = g W^T + dout with the residual add in
+    the GEMM epilogue, dW = x^T g and db.  All operands contiguous [M, d4].  Returns ``(dx0_acc, dx, dW, db)``; ``dx0_acc`` is
+    accumulated in place when given (the sum over the layers of a CrossBlock), created otherwise.  dW / db run on the "dw" side
+    stream beside dX when side streams are active."""
+    lib = _lib.load()
+    M, d = x.shape
+    for t, n in ((x0, "x0"), (x, "x"), (p, "p"), (dout, "dout")):
+        _dev(t, n, torch.float32)
+        if t.shape != (M, d) or not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous [{M}, {d}]")
+    if d % 4 or tuple(W.shape) != (d, d) or not W.is_contiguous():
+        raise ValueError("cross_layer_backward: W must be contiguous [d, d] with d % 4 == 0 (zero-padded layer)")
+    accumulate = dx0_acc is not None
+    if dx0_acc is None:
+        dx0_acc = torch.empty_like(x)
+    g = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    dW = torch.empty((d, d), dtype=torch.float32, device=x.device)
+    db = torch.empty((d,), dtype=torch.float32, device=x.device)
+    nbytes = lib.mh_linear_bwd_workspace_bytes(M, d, d)
+    if SIDE.active("dw"):
+        check(lib.mh_cross_layer_bwd(_ptr(x0), None, _ptr(p), _ptr(dout), _ptr(W), M, d, d, _ptr(g), _ptr(dx0_acc),
+                                     1 if accumulate else 0, _ptr(dx), None, None, None, 0, _stream()), "mh_cross_layer_bwd")
+        ws = _workspace(nbytes, x.device, "linear_bwd_side")
+        with SIDE.on("dw", keep=(x, g)):
+            check(lib.mh_cross_layer_bwd(None, _ptr(x), None, _ptr(dout), None, M, d, d, _ptr(g), None, 0, None, _ptr(dW), _ptr(db),
+                                         _ptr(ws), ws.numel(), _stream()), "mh_cross_layer_bwd")
+        SIDE.maybe_join()
+        return dx0_acc, dx, dW, db
+    ws = _workspace(nbytes, x.device, "linear_bwd")
+    # element-wise pass: reads dout, x0, p (+ dx0_acc), writes g, dx0_acc; GEMMs: 2 x 2 M d^2 flops
+    with _timed(f"cross_bwd_{d}", nbytes=4 * M * d * (9 if accumulate else 8) + 8 * d * d, flops=4 * M * d * d):
+        check(lib.mh_cross_layer_bwd(_ptr(x0), _ptr(x), _ptr(p), _ptr(dout), _ptr(W), M, d, d, _ptr(g), _ptr(dx0_acc),
+                                     1 if accumulate else 0, _ptr(dx), _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+              "mh_cross_layer_bwd")
+    return dx0_acc, dx, dW, db
+
+
+def cross_lowrank_dx(dh: torch.Tensor, U: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    """dx = dh U^T + dout of a LOW-RANK cross layer (the last GEMM of its backward, residual add in the epilogue):
+    dh [M, r4], U [d4, r4], dout [M, d4]."""
+    lib = _lib.load()
+    M, r = dh.shape
+    d = U.shape[0]
+    for t, n in ((dh, "dh"), (U, "U"), (dout, "dout")):
+        _dev(t, n, torch.float32)
+        if not t.is_contiguous():
+            raise ValueError(f"{n} must be contiguous")
+    if U.shape[1] != r or dout.shape != (M, d) or r % 4 or d % 4:
+        raise ValueError("cross_lowrank_dx: shapes must be dh [M, r], U [d, r], dout [M, d] with r, d multiples of 4")
+    dx = torch.empty_like(dout)
+    with _timed(f"cross_lowrank_dx_{d}x{r}", nbytes=4 * (M * r + d * r + 2 * M * d), flops=2 * M * d * r):
+        check(lib.mh_cross_layer_bwd(None, None, None, _ptr(dout), _ptr(U), M, d, r, _ptr(dh), None, 0, _ptr(dx), None, None, None, 0,
+                                     _stream()), "mh_cross_layer_bwd")
+    return dx
+
+
 def eltwise(op: str, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``mul``: a*b, ``add``: a+b, ``fma``: a*b+c on contiguous fp32 tensors of one shape."""
     lib = _lib.load()

@@ -232,6 +232,17 @@ def cross_layer(x0, x, W, b, save_p=False):
     return (x0 * p + x, p) if save_p else x0 * p + x
 
 
+def cross_layer_backward(x0, x, p, dout, W, dx0_acc=None):
+    g = dout * x0
+    share = dout * p
+    dx0_acc = share if dx0_acc is None else dx0_acc.add_(share)
+    return dx0_acc, g @ W.t() + dout, x.t() @ g, g.sum(0)
+
+
+def cross_lowrank_dx(dh, U, dout):
+    return dh @ U.t() + dout
+
+
 def _scorer_terms(q, item, neg, pos_ids, neg_ids, T, fns, pos_logq, neg_logq, after):
     pos = (q * item).sum(-1, keepdim=True)
     ng = q @ neg.t()
@@ -291,7 +302,7 @@ def install():
 
     for name in ("embedding_gather", "linear", "dot_interaction", "dot_interaction_backward", "linear_backward",
                  "embedding_gather_backward", "bce", "dense_optimizer_step_multi", "route_build", "eltwise", "rowwise_dot",
-                 "cross_layer", "inbatch_softmax", "inbatch_softmax_train", "inbatch_softmax_backward", "l2norm", "embedding_bag",
+                 "cross_layer", "cross_layer_backward", "cross_lowrank_dx", "inbatch_softmax", "inbatch_softmax_train", "inbatch_softmax_backward", "l2norm", "embedding_bag",
                  "embedding_dense_list", "embedding_bag_expand", "embedding_bag_backward"):
         setattr(ops, name, globals()[name])
     ops.route_local_rows = D.route_local_rows_torch

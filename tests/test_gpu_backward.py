@@ -317,6 +317,68 @@ def test_wide_linear_backward(device, M, K, N, ldx, act, x_act):
     torch.testing.assert_close(db.cpu(), b.grad, **tol)
 
 
+@pytest.mark.parametrize("M,K,N", [(200, 512, 256), (2000, 1024, 1024), (700, 1024, 512)])
+def test_linear_backward_slab_reductions(device, M, K, N):
+    """dW / db when the batch is ONE slab (the GEMM writes them itself, nothing to reduce), and when a long dW is split into a
+    few slabs (<= 8: the float4 slab reduction instead of the general 64-outputs-per-workgroup kernel)."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(device)
+    W = (torch.randn(K, N, generator=g) * 0.05).to(device)
+    dy = torch.randn(M, N, generator=g).to(device)
+    dx, dW, db = ops.linear_backward(x, W, None, dy.clone(), None)
+    torch.testing.assert_close(dW.double(), x.double().T @ dy.double(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(db.double(), dy.double().sum(0), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dx.double(), dy.double() @ W.double().T, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,d", [(300, 20), (1000, 132), (33000, 512)])  # first-generation NT core ... second-generation core (fills the chip)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_cross_layer_backward_fused(device, M, d, accumulate):
+    """mh_cross_layer_bwd: g = dout * x0, dx0_acc (+)= dout * p in one pass, dx = g W^T + dout (residual add in the GEMM epilogue),
+    dW = x^T g, db -- against fp64 autograd of out = x0 * (x W + b) + x (tf/blocks/cross.py:188-202)."""
+    g = torch.Generator().manual_seed(M + d)
+    x0 = torch.randn(M, d, generator=g).to(device)
+    x = torch.randn(M, d, generator=g).to(device)
+    W = (torch.randn(d, d, generator=g) / d ** 0.5).to(device)
+    b = (torch.randn(d, generator=g) * 0.1).to(device)
+    dout = torch.randn(M, d, generator=g).to(device)
+    prev = torch.randn(M, d, generator=g).to(device) if accumulate else None
+    out, p = ops.cross_layer(x0, x, W, b, save_p=True)
+    x064, x64, W64, b64 = (t.double().requires_grad_() for t in (x0, x, W, b))
+    ref = x064 * (x64 @ W64 + b64) + x64
+    torch.testing.assert_close(out.double(), ref.detach(), atol=1e-4, rtol=1e-4)
+    ref.backward(dout.double())
+    acc_in = None if prev is None else prev.clone()
+    dx0_acc, dx, dW, db = ops.cross_layer_backward(x0, x, p, dout, W, acc_in)
+    want0 = x064.grad if prev is None else x064.grad + prev.double()
+    tol = dict(atol=2e-4 * max(1.0, (M / 1000) ** 0.5), rtol=1e-4)
+    torch.testing.assert_close(dx0_acc.double(), want0, atol=1e-5, rtol=1e-5)
+    if accumulate:
+        assert dx0_acc.data_ptr() == acc_in.data_ptr()  # accumulated in place: the running sum of a CrossBlock
+    torch.testing.assert_close(dx.double(), x64.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(dW.double(), W64.grad, **tol)
+    torch.testing.assert_close(db.double(), b64.grad, **tol)
+
+
+def test_cross_lowrank_dx_phase(device):
+    g = torch.Generator().manual_seed(9)
+    M, d, r = 777, 36, 8
+    dh = torch.randn(M, r, generator=g).to(device)
+    U = torch.randn(d, r, generator=g).to(device)
+    dout = torch.randn(M, d, generator=g).to(device)
+    dx = ops.cross_lowrank_dx(dh, U, dout)
+    torch.testing.assert_close(dx.double(), dh.double() @ U.double().T + dout.double(), atol=1e-5, rtol=1e-5)
+
+
+def test_eltwise_vector_and_scalar_paths(device):
+    g = torch.Generator().manual_seed(3)
+    for n in (4096 * 3, 1001):  # float4 path / scalar path (n % 4 != 0)
+        a, b, c = (torch.randn(n, generator=g).to(device) for _ in range(3))
+        assert torch.equal(ops.eltwise("mul", a, b), a * b)
+        assert torch.equal(ops.eltwise("add", a, b), a + b)
+        torch.testing.assert_close(ops.eltwise("fma", a, b, c), torch.addcmul(c, a, b), atol=1e-6, rtol=1e-6)
+
+
 def test_wide_backward_equals_first_generation_core(device):
     """y and dX are bit-identical between the two GEMM cores (one k-ascending chain per output); dW sums the same slices
     of the batch in the same row order -> identical too; db groups its partial sums differently."""
