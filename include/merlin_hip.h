@@ -304,6 +304,10 @@ int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y
 int32_t mh_l2norm_rows_bwd(const float* x, const float* dy, int64_t M, int32_t N, float eps, float* dx,
                            mh_stream_t stream);
 
+/* Mean of n floats into mean[0] (Keras' SUM_OVER_BATCH_SIZE reduction of a per-sample loss, e.g. the softmax-CE rows of
+ * the retrieval step, losses/listwise.py:38-52): two launches, fixed summation order (deterministic).  workspace: 256 floats. */
+int32_t mh_mean(const float* x, int64_t n, float* mean, float* workspace, mh_stream_t stream);
+
 /* DotProduct.call (outputs/base.py:307-310): out[m] = sum_n a[m,n] * b[m,n]  (positive scores;
  * the inference branch of ContrastiveOutput, outputs/contrastive.py:221). */
 int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t M,

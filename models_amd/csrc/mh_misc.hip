@@ -54,6 +54,21 @@ __global__ __launch_bounds__(64) void bce_mean_finish_kernel(const float* __rest
     if (lane == 0) *mean = t / (float)M;
 }
 
+// mean of n floats, deterministic: <= 256 workgroups each write one partial (fixed assignment of elements to threads, fixed
+// LDS tree), bce_mean_finish_kernel adds the partials in a fixed order and divides
+__global__ __launch_bounds__(256) void mean_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // one 64-lane wavefront per row: tf.linalg.l2_normalize(x, axis=-1) = x * rsqrt(max(sum x^2, eps^2))
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, int64_t M, int N, float eps,
                                                     float* __restrict__ y) {
@@ -549,6 +564,17 @@ int32_t mh_bce_mean_fwd_bwd(const float* p, const float* label, int64_t M, float
                        workspace, dlogit);
     hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, M, loss_mean);
     MH_CHECK_LAUNCH("mh_bce_mean_fwd_bwd");
+    return MH_OK;
+}
+
+int32_t mh_mean(const float* x, int64_t n, float* mean, float* workspace, mh_stream_t stream) {
+    MH_REQUIRE(x && mean && workspace, "mh_mean: null argument");
+    MH_REQUIRE(n >= 1, "mh_mean: an empty vector has no mean");
+    int64_t nb = mh_ceil_div(n, 256);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(mean_partial_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), x, n, workspace);
+    hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, n, mean);
+    MH_CHECK_LAUNCH("mh_mean");
     return MH_OK;
 }
 

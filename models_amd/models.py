@@ -8,7 +8,7 @@
 from __future__ import annotations
 
 import time
-from typing import Dict, Iterable, List, Optional, Union
+from typing import Dict, Iterable, List, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -368,15 +368,29 @@ def DLRMModel(schema: Schema, *, embedding_dim: Optional[int] = None, embeddings
 
 class DCNBody(Block):
     """ranking.py:159-168: InputBlockV2 (concat) -> CrossBlock -> deep MLP (stacked) or
-    concat(cross, deep) (parallel)."""
+    concat(cross, deep) (parallel).
+
+    Column order of the PARALLEL form.  The reference builds ``input_block.connect_branch(CrossBlock(depth), deep_block,
+    aggregation="concat")`` (ranking.py:161-164): ``ParallelBlock(*branches)`` keys each branch by its Keras layer name
+    (tf/core/combinators.py:366-368, ``use_layer_name``), both branches are ``SequentialBlock``s -- auto-named
+    ``sequential_block``, ``sequential_block_1``, ... in CREATION order over the whole process -- and ``ConcatFeatures`` sorts
+    those names as STRINGS (tf/core/aggregation.py:54-66).  The order is therefore not a property of the model: it depends on
+    how many SequentialBlocks the process created before (``sequential_block_12`` sorts before ``sequential_block_3``; the
+    import-time default ``deep_block`` of ranking.py:98 is named without a suffix and sorts first).  ``parallel_concat`` states
+    the order explicitly: ``("cross", "deep")`` (default) or ``("deep", "cross")`` -- to load weights exported from a reference
+    model, pass the order its two layer names sort in (``[l.name for l in model.blocks[0].layers[-1].parallel_layers]``)."""
 
     def __init__(self, schema: Schema, depth: int, deep_block: Block, stacked: bool = True, input_block=None,
-                 embedding_dim: Optional[int] = None, device=None, low_rank_dim: Optional[int] = None):
+                 embedding_dim: Optional[int] = None, device=None, low_rank_dim: Optional[int] = None,
+                 parallel_concat: Sequence[str] = ("cross", "deep")):
         super().__init__("dcn_body")
         self.input_block = input_block or InputBlockV2(schema, dim=embedding_dim, device=device)
         self.cross = CrossBlock(depth, low_rank_dim=low_rank_dim, device=device)
         self.deep = deep_block
         self.stacked = stacked
+        if tuple(parallel_concat) not in (("cross", "deep"), ("deep", "cross")):
+            raise ValueError("parallel_concat must be ('cross', 'deep') or ('deep', 'cross')")
+        self.parallel_concat = tuple(parallel_concat)
 
     def children(self):
         return [self.input_block, self.cross, self.deep]
@@ -385,7 +399,9 @@ class DCNBody(Block):
         x = self.input_block(inputs)
         if self.stacked:
             return self.deep(self.cross(x))
-        return torch.cat([self.cross(x), self.deep(x)], dim=-1)
+        c, dp = self.cross(x), self.deep(x)
+        self._split = c.shape[1] if self.parallel_concat[0] == "cross" else dp.shape[1]
+        return torch.cat([c, dp] if self.parallel_concat[0] == "cross" else [dp, c], dim=-1)
 
     def backward(self, grad):
         if self.stacked:
@@ -393,19 +409,21 @@ class DCNBody(Block):
             g = self.cross.backward(g)
             return self.input_block.backward(g)
         # parallel form: the head saw concat([cross(x), deep(x)]); both branches read the same x
-        d = self.cross.layers[0].d
-        gc = self.cross.backward(grad[:, :d].contiguous())
-        gd = self.deep.backward(grad[:, d:].contiguous())
+        k = self._split
+        first, second = grad[:, :k].contiguous(), grad[:, k:].contiguous()
+        gcross, gdeep = (first, second) if self.parallel_concat[0] == "cross" else (second, first)
+        gc = self.cross.backward(gcross)
+        gd = self.deep.backward(gdeep)
         return self.input_block.backward(ops.eltwise("add", gc.contiguous(), gd.contiguous()))
 
 
 def DCNModel(schema: Schema, depth: int, deep_block: Optional[Block] = None, stacked: bool = True,
              input_block=None, embedding_dim: Optional[int] = None, prediction_tasks=None, device=None,
-             low_rank_dim: Optional[int] = None) -> RankingModel:
+             low_rank_dim: Optional[int] = None, parallel_concat: Sequence[str] = ("cross", "deep")) -> RankingModel:
     """ranking.py:95-168 (deep_block default MLPBlock([512, 256]), :98; ``**kwargs`` of the reference reach
     ``CrossBlock``, of which ``low_rank_dim`` is the one on the hot path)."""
     deep_block = deep_block or MLPBlock([512, 256], device=device)
-    body = DCNBody(schema, depth, deep_block, stacked, input_block, embedding_dim, device, low_rank_dim)
+    body = DCNBody(schema, depth, deep_block, stacked, input_block, embedding_dim, device, low_rank_dim, parallel_concat)
     head = prediction_tasks or BinaryOutput(_target_column(schema), device=device)
     return RankingModel(body, head, schema, name="dcn_model")
 
@@ -465,7 +483,7 @@ class RetrievalModel(Model):
             self.body.parallel_layers["query"].backward(dq)
             self.body.parallel_layers["item"].backward(ditem)
             self.optimizer.apply(self)
-        return _with_regularization(self, res.loss.mean())
+        return _with_regularization(self, ops.mean(res.loss) if res.loss.is_cuda else res.loss.mean())
 
     def evaluate(self, batches, k: int = 10, **kwargs) -> Dict[str, float]:
         """In-batch evaluation as the reference runs it under ``testing=True`` (outputs/contrastive.py:223-344): every

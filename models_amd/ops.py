@@ -677,6 +677,9 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     return buf
 
 
+_DW_EARLY = __import__("os").environ.get("MERLIN_HIP_DW_EARLY", "0") == "1"
+
+
 def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True, x_activation=None,
                     zero_pad: bool = True):
     """Backward of ``linear``: returns (dx | None, dW, db | None).  ``dy`` is overwritten with
@@ -713,15 +716,25 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         # dX first, on the launch stream; dW / db start on the "dw" stream only when dX is done, so that the MFMA-bound dW
         # runs beside whatever FOLLOWS dX on the launch stream (for the top-MLP layer of a DLRM: the HBM-bound interaction
         # backward) instead of competing with dX for the matrix pipe
-        if need_dx:
-            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
-                                             ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
-                  "mh_linear_bias_act_bwd")
-        ws = _workspace(nbytes, x.device, "linear_bwd_side")
-        with SIDE.on("dw", keep=(x, dy)):
-            check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
-                                             None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
-                  "mh_linear_bias_act_bwd")
+        def run_dx():
+            if need_dx:
+                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
+                                                 ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
+                      "mh_linear_bias_act_bwd")
+
+        def run_dw():
+            ws = _workspace(nbytes, x.device, "linear_bwd_side")
+            with SIDE.on("dw", keep=(x, dy)):
+                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
+                                                 None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                      "mh_linear_bias_act_bwd")
+
+        if _DW_EARLY:  # experiment switch (MERLIN_HIP_DW_EARLY=1): dW forked BEFORE dX, i.e. the two GEMMs share the matrix pipe
+            run_dw()
+            run_dx()
+        else:
+            run_dx()
+            run_dw()
         SIDE.maybe_join()
         return dx, dW, db
     ws = _workspace(nbytes, x.device, "linear_bwd")
@@ -993,6 +1006,22 @@ def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
         check(lib.mh_bce_mean_fwd_bwd(_ptr(p), _ptr(label), M, 1.0 / M, _ptr(mean), _ptr(dlogit), _ptr(ws), _stream()),
               "mh_bce_mean_fwd_bwd")
     return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
+
+
+def mean(x: torch.Tensor) -> torch.Tensor:
+    """Mean of a contiguous fp32 tensor as a 0-d device tensor (``mh_mean``: deterministic two-stage sum; replaces the
+    torch reduction kernel that used to run once per retrieval train step)."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    if not x.is_contiguous():
+        raise ValueError("mean: x must be contiguous")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        out.fill_(float("nan"))
+        return out[0]
+    ws = _workspace(1024, x.device, "mean")
+    check(lib.mh_mean(_ptr(x), x.numel(), _ptr(out), _ptr(ws), _stream()), "mh_mean")
+    return out[0]
 
 
 def bce_per_sample(p: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -113,3 +113,13 @@ def test_concat_columns_equals_torch_cat_and_zero_pads(device, B):
     agg = ConcatFeatures()
     named = {f"c{i:02d}": c for i, c in enumerate(cols)}
     assert torch.equal(agg(named), ref)
+
+
+def test_mean_matches_fp64(device):
+    g = torch.Generator().manual_seed(2)
+    for n in (1, 255, 32768, 100003):
+        x = torch.randn(n, generator=g).to(device)
+        m = ops.mean(x)
+        assert m.dim() == 0
+        assert abs(float(m) - float(x.double().mean())) < 1e-6
+        assert float(ops.mean(x)) == float(m)  # deterministic

@@ -334,15 +334,19 @@ def test_loader_feeds_train_steps_and_batch_predict(device):
     np.testing.assert_array_equal(frame[qschema.first.name], data[qschema.first.name])
 
 
-@pytest.mark.parametrize("stacked", [True, False])
+@pytest.mark.parametrize("stacked", [True, False, "deep_first"])
 @pytest.mark.parametrize("low_rank_dim", [None, 6])
 def test_dcn_variants_train_step_matches_torch(device, stacked, low_rank_dim):
-    """Low-rank cross kernels (W = U V) and the parallel DCN form (concat(cross, deep)): forward and one SGD step
-    against torch autograd on the reference-shaped weights."""
+    """Low-rank cross kernels (W = U V) and the parallel DCN form (concat(cross, deep), or concat(deep, cross) when the
+    reference's two layer names sort that way: DCNBody docstring): forward and one SGD step against torch autograd on the
+    reference-shaped weights."""
     schema = _dcn_schema()
     lr = 0.05
+    deep_first = stacked == "deep_first"
+    stacked = stacked is True
     model = mm.DCNModel(schema, depth=2, deep_block=mm.MLPBlock([32, 16], device=device), embedding_dim=16,
-                        device=device, stacked=stacked, low_rank_dim=low_rank_dim)
+                        device=device, stacked=stacked, low_rank_dim=low_rank_dim,
+                        parallel_concat=("deep", "cross") if deep_first else ("cross", "deep"))
     model.compile(optimizer="sgd", learning_rate=lr)
     g = torch.Generator().manual_seed(4)
     x, xd = _batch(schema, 150, g, device)
@@ -375,7 +379,7 @@ def test_dcn_variants_train_step_matches_torch(device, stacked, low_rank_dim):
         dd = h if stacked else h0
         for W, b, a in deep:
             dd = R.act(dd @ W + b, a)
-        out = dd if stacked else torch.cat([h, dd], dim=1)
+        out = dd if stacked else torch.cat([dd, h] if deep_first else [h, dd], dim=1)
         return torch.sigmoid(out @ head[0] + head[1])
 
     np.testing.assert_allclose(p.cpu().numpy(), fwd().detach().numpy(), atol=ATOL)
