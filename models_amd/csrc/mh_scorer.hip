@@ -18,6 +18,9 @@
 // is false_neg_score (then divided by T, exactly as the reference scales AFTER rescoring).
 #include "mh_gemm_core.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 #include <math.h>
 
 using namespace mhgemm;
@@ -326,6 +329,12 @@ void mh_stream_grad_combine(const float* opart, int64_t N, int E, int nsplit, co
                             const float* other, const float* self, float invT, float g, float* out, float* out_pos,
                             hipStream_t s);
 void mh_stream_pad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s);
+// tiled forward-only scorer on the second-generation GEMM core (mh_scorer_tiled.hip)
+int mh_scorer_tiled_nsplit(int64_t Nn);
+bool mh_scorer_tiled_supported(const float* q, const float* neg, int64_t B, int64_t Nn, int E);
+int32_t mh_scorer_tiled_fwd(const float* q, const float* neg, const void* pos_ids, const void* neg_ids, int ids_dtype, int64_t B,
+                            int64_t Nn, int E, float invT, float fns, const float* neg_corr, int corr_after_mask, float* part_m,
+                            float* part_s, hipStream_t s);
 void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s);
 
 namespace {
@@ -361,8 +370,11 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
     w.col = mh_stream_plan(SM_GRAD, Nn, B, w.Ep, ids_bytes);
     w.part_m = w.part_s = w.opart_row = w.opart_col = 0;
     if (pass == 0 || pass == 2) {
-        w.part_m = take((int64_t)w.row.nsplit * B);
-        w.part_s = take((int64_t)w.row.nsplit * B);
+        // pass 0 may run the tiled forward, which writes one partial per 256-candidate tile
+        int64_t ns = w.row.nsplit;
+        if (pass == 0 && mh_scorer_tiled_nsplit(Nn) > ns) ns = mh_scorer_tiled_nsplit(Nn);
+        w.part_m = take(ns * B);
+        w.part_s = take(ns * B);
     }
     if (pass == 1 || pass == 2) w.opart_row = take((int64_t)w.row.nsplit * B * w.Ep);
     if (pass == 1) w.opart_col = take((int64_t)w.col.nsplit * Nn * w.Ep);
@@ -430,6 +442,23 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
     const MhStreamPlan& plan = w.row;
     float* pos = ws + w.pos;
     hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
+    {
+        // MERLIN_HIP_SCORER_FWD=tiled: the forward-only pass on the tiled kernel of mh_scorer_tiled.hip (second-generation GEMM
+        // core, transposed product).  OPT-IN: warmed up on one box it runs 32768 x 32768 x 128 in 2.52-2.53 ms against 2.45-2.46 ms
+        // for the row-stationary stream kernel below (0.697 vs 0.714 of the fp32 MFMA peak; profiles/r4_notes.md) -- the 0.70-0.71
+        // of the round-3 lab was real, what it was compared with (0.675-0.69) was an under-warmed measurement of the stream kernel.
+        const char* fenv = getenv("MERLIN_HIP_SCORER_FWD");
+        const int forced = !fenv ? 0 : (!strcmp(fenv, "tiled") ? 1 : (!strcmp(fenv, "stream") ? 2 : 0));
+        const bool big = false;
+        if (!logits && forced != 2 && (forced == 1 || big) && mh_scorer_tiled_supported(q, neg_item, B, Nn, E)) {
+            const int32_t st = mh_scorer_tiled_fwd(q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, neg_logq,
+                                                   logq_after_mask, ws + w.part_m, ws + w.part_s, s);
+            if (st != MH_OK) return st;
+            mh_stream_fwd_finalize(pos, B, mh_scorer_tiled_nsplit(Nn), ws + w.part_m, ws + w.part_s, invT, nullptr, 0, loss, lse, s);
+            MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
+            return MH_OK;
+        }
+    }
     const float* qx = q;
     const float* nx = neg_item;
     if (w.pad) {

@@ -12,9 +12,11 @@
 // candidate must be STRICTLY greater than the current k-th value to enter", so each 64-wide
 // batch costs one compare + ballot; insertions (expected ~k ln(N/k) per row) shift the list.
 // Scores are k-ascending fmaf chains, so indices are bit-exact vs oracle/oracle_c.c.
-#include "mh_gemm_core.h"
+#include "mh_gemm2.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 using namespace mhgemm;
 
@@ -26,39 +28,102 @@ namespace {
 
 constexpr int TOPK_MAX = 1024;
 
-// block = 256 threads = 4 wavefronts = 4 query rows.  dynamic LDS: 4 x 2 x k x (float + int)
+// The running top-k of one query row, sorted by (score desc, index asc), held in the REGISTERS of the row's wavefront:
+// position p lives in lane p & 63, register p >> 6 (R = ceil(k / 64) registers per lane).  An insertion is a ballot count of
+// the entries ahead of the newcomer plus one shuffle-shift of the tail -- ~10 instructions per register.  The first version
+// kept the list in LDS and rewrote all k entries into a second buffer per insertion (two LDS round trips per 64 entries):
+// with ~k ln(N / k) insertions per row the select / merge kernels cost 0.88 ms of a 10 ms top-100 call over 1 M candidates.
+template <int R>
+struct RegList {
+    float s[R];
+    int i[R];
+    __device__ __forceinline__ void fill(int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            s[r] = -INFINITY;  // unfilled: behind every real entry (index INT_MAX loses every tie)
+            i[r] = 0x7fffffff;
+        }
+    }
+    __device__ __forceinline__ void load(const float* bs, const int32_t* bi, int n, int lane) {  // first n entries from memory
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = r * 64 + lane;
+            s[r] = (p < n) ? bs[p] : -INFINITY;
+            i[r] = (p < n) ? bi[p] : 0x7fffffff;
+        }
+    }
+    __device__ __forceinline__ void at(int p, float* sc, int* idx) const {  // wave-uniform p
+        float a = 0.f;
+        int b = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r == (p >> 6)) {
+                a = __shfl(s[r], p & 63);
+                b = __shfl(i[r], p & 63);
+            }
+        *sc = a;
+        *idx = b;
+    }
+    // insert (sc, idx) (wave-uniform) into the first k positions; returns false when it does not make the list
+    __device__ __forceinline__ bool insert(float sc, int idx, int k, int lane) {
+        int pos = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ahead = (r * 64 + lane < k) && ((s[r] > sc) || (s[r] == sc && i[r] < idx));
+            pos += __popcll(__ballot(ahead));
+        }
+        if (pos >= k) return false;
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) {  // descending: register r - 1 is still the old one when r takes its lane 63
+            float us = __shfl_up(s[r], 1);
+            int ui = __shfl_up(i[r], 1);
+            if (r > 0) {
+                const float ws = __shfl(s[r - 1], 63);
+                const int wi = __shfl(i[r - 1], 63);
+                if (lane == 0) {
+                    us = ws;
+                    ui = wi;
+                }
+            }
+            const int p = r * 64 + lane;
+            if (p > pos) {
+                s[r] = us;
+                i[r] = ui;
+            } else if (p == pos) {
+                s[r] = sc;
+                i[r] = idx;
+            }
+        }
+        return true;
+    }
+    __device__ __forceinline__ void store(float* bs, int32_t* bi, int k, int lane) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = r * 64 + lane;
+            if (p < k) {
+                bs[p] = s[r];
+                bi[p] = i[r];
+            }
+        }
+    }
+};
+
+// block = 256 threads = 4 wavefronts = 4 query rows; the running list of a row lives in its wavefront's registers (RegList)
+template <int R>
 __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ scores, int64_t ld, int64_t Bq,
                                                          int Nc, int64_t base, int k, int seen_before,
                                                          float* __restrict__ best_s, int32_t* __restrict__ best_i,
                                                          const int32_t* __restrict__ cand_ids, int last,
                                                          int32_t* __restrict__ out_ids) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= Bq) return;
-    float* Ls0 = smem + wave * 4 * k;
-    float* Ls1 = Ls0 + k;
-    int* Li0 = reinterpret_cast<int*>(Ls1 + k);
-    int* Li1 = Li0 + k;
-    float* Ls = Ls0;
-    int* Li = Li0;
-    float* Lsn = Ls1;
-    int* Lin = Li1;
-
     int cnt = seen_before < k ? seen_before : k;  // filled entries (wave-uniform)
-    for (int e = lane; e < k; e += 64) {
-        if (e < cnt) {
-            Ls[e] = best_s[row * k + e];
-            Li[e] = best_i[row * k + e];
-        } else {
-            Ls[e] = NAN;  // unfilled sentinel: compares false
-            Li[e] = 0x7fffffff;
-        }
-    }
-    float tau = (cnt == k) ? Ls[k - 1] : -INFINITY;  // LDS write->read by the same wave: in order
-    // (all lanes read the same address after the loop; the compiler orders DS ops of one wave)
-    tau = __shfl(tau, 0);
-
+    RegList<R> L;
+    L.load(best_s + row * k, best_i + row * k, cnt, lane);
+    float tau = -INFINITY;
+    int ti = 0;
+    if (cnt == k) L.at(k - 1, &tau, &ti);
     const float* srow = scores + row * ld;
     for (int j0 = 0; j0 < Nc; j0 += 256) {
         float v[4];
@@ -69,6 +134,8 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            // candidates arrive in ascending index order: "ties -> lower index" == a later candidate must be STRICTLY greater
+            // than the current k-th value to enter
             const bool pass = (v[u] > tau) || (cnt < k && (j0 + u * 64 + lane) < Nc);
             unsigned long long mask = __ballot(pass);
             while (mask) {
@@ -76,48 +143,21 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
                 mask &= mask - 1;
                 const float sc = __shfl(v[u], l);
                 if (!((sc > tau) || cnt < k)) continue;  // tau may have risen inside this batch
-                const int idx = (int)(base + j0 + u * 64 + l);
-                // entries that stay ahead of the newcomer: score >= sc (their index is lower)
-                int pos = 0;
-                for (int e0 = 0; e0 < k; e0 += 64) {
-                    const int e = e0 + lane;
-                    const bool ahead = (e < k) && (Ls[e] >= sc);
-                    pos += __popcll(__ballot(ahead));
-                }
-                if (pos >= k) continue;  // only possible for NaN scores
-                for (int e = lane; e < k; e += 64) {
-                    float s_new;
-                    int i_new;
-                    if (e < pos) {
-                        s_new = Ls[e];
-                        i_new = Li[e];
-                    } else if (e == pos) {
-                        s_new = sc;
-                        i_new = idx;
-                    } else {
-                        s_new = Ls[e - 1];
-                        i_new = Li[e - 1];
-                    }
-                    Lsn[e] = s_new;
-                    Lin[e] = i_new;
-                }
-                float* ts = Ls; Ls = Lsn; Lsn = ts;
-                int* ti = Li; Li = Lin; Lin = ti;
+                if (!L.insert(sc, (int)(base + j0 + u * 64 + l), k, lane)) continue;  // only possible for NaN scores
                 if (cnt < k) ++cnt;
-                if (cnt == k) tau = __shfl(Ls[k - 1], 0);
+                if (cnt == k) L.at(k - 1, &tau, &ti);
             }
         }
     }
-    for (int e = lane; e < k; e += 64) {
-        best_s[row * k + e] = Ls[e];
-        best_i[row * k + e] = Li[e];
-        if (last && out_ids) {
-            const int i = Li[e];
-            out_ids[row * k + e] = cand_ids ? cand_ids[i] : i;
+    L.store(best_s + row * k, best_i + row * k, k, lane);
+    if (last && out_ids) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = r * 64 + lane;
+            if (p < k) out_ids[row * k + p] = cand_ids ? cand_ids[L.i[r]] : L.i[r];
         }
     }
 }
-
 
 // ---- fused filter: scores that cannot enter the top-k never leave the registers ---------------------
 // After a dense bootstrap over the first candidates, every query row has a lower bound tau (its current
@@ -211,6 +251,74 @@ __global__ __launch_bounds__(FWM * FWN * 64, 2) void topk_filter_gemm_kernel(
     }
 }
 
+// ---- the same filter on the second-generation GEMM core (mh_gemm2.h: DMA tiles, 3-deep ring, 64 x 64 per wavefront) ----------
+// One workgroup = one 256-candidate x 128-query score tile, the product computed TRANSPOSED (A = candidates, B = queries, NT):
+// in the MFMA C layout a lane then holds 32 candidates of TWO queries, so the thresholds tau[query] are two registers per lane
+// and the epilogue is 64 compares with nothing else in the common case (no survivor).  Column (query) tiles are the fastest
+// grid dimension: the workgroups resident at one time sweep the query panel (2 MB at 4096 x 128: L2-resident) against a few
+// candidate panels that are read from HBM once.  Scores are the same k-ascending fmaf chains as everywhere else (a product
+// commutes bit for bit), so survivors carry the bits the select stage compares.  Measured against the row-stationary stream
+// filter (mh_scorer_stream.hip) by MERLIN_HIP_TOPK_FILTER=stream|tiled: profiles/r4_notes.md.
+constexpr int TFBM = 256, TFBN = 128, TFWM = 4, TFWN = 2, TFST = 3;
+
+__global__ __launch_bounds__(TFWM* TFWN * 64) void topk_filter_tiled_kernel(const float* __restrict__ cand, const float* __restrict__ q,
+                                                                           int64_t n_cand, int Bq, int E, const float* __restrict__ tau,
+                                                                           int* __restrict__ cnt, float* __restrict__ cs,
+                                                                           int32_t* __restrict__ ci, int cap, int64_t idx0,
+                                                                           int ncol_tiles) {
+    constexpr int TM = TFBM / TFWM / 32, TN = TFBN / TFWN / 32;
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int64_t row0 = (int64_t)(blockIdx.x / ncol_tiles) * TFBM;  // candidates (relative to this stage)
+    const int n0 = (int)(blockIdx.x % ncol_tiles) * TFBN;            // queries
+    f32x16 acc[TM][TN];
+    mhgemm2::gemm2_tile<TFBM, TFBN, TFWM, TFWN, true, TFST, true, 16, 0>(cand, E, q, E, n_cand, Bq, E, row0, n0, smem, acc);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / TFWN, wn = wave % TFWN;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int qi = n0 + wn * TN * 32 + tn * 32 + l31;
+        const float t = (qi < Bq) ? tau[qi] : INFINITY;
+        bool any = false;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) any |= acc[tm][tn][r] >= t;
+        if (!any) continue;  // per lane: survivors are k / n_seen of the scores
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[tm][tn][r];
+                const int64_t c = row0 + wm * TM * 32 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (v >= t && c < n_cand) {
+                    const int pos = atomicAdd(&cnt[qi], 1);
+                    if (pos < cap) {
+                        cs[(int64_t)qi * cap + pos] = v;
+                        ci[(int64_t)qi * cap + pos] = (int32_t)(idx0 + c);
+                    }
+                }
+            }
+    }
+}
+
+int32_t tiled_filter(const float* q, int64_t Bq, const float* cand, int64_t n_cand, int E, const float* tau, int* cnt, float* cs,
+                     int32_t* ci, int cap, int64_t idx0, hipStream_t s) {
+    auto kern = topk_filter_tiled_kernel;
+    const size_t lds = (size_t)TFST * (TFBM + TFBN) * 16 * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int ncol = (int)mh_ceil_div(Bq, TFBN);
+    const int64_t nrow = mh_ceil_div(n_cand, TFBM);
+    MH_REQUIRE(nrow * ncol < (1ll << 31), "top-k tiled filter: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrow * ncol)), dim3(TFWM * TFWN * 64), lds, s, cand, q, n_cand, (int)Bq, E, tau, cnt, cs,
+                       ci, cap, idx0, ncol);
+    return MH_OK;
+}
+
 // Merge a compact (score, index) list into the running sorted top-k of each row; order = (score desc,
 // index asc) -- the total order of tf.math.top_k -- so survivors may arrive in any order.
 __global__ __launch_bounds__(256) void topk_stage_init_kernel(const float* __restrict__ out_scores, int k, int64_t Bq,
@@ -222,31 +330,26 @@ __global__ __launch_bounds__(256) void topk_stage_init_kernel(const float* __res
     cnt[Bq + r] = 0;
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void topk_merge_compact_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
                                                                 int* __restrict__ cnt, int cap, int64_t Bq, int k,
                                                                 float* __restrict__ best_s, int32_t* __restrict__ best_i,
                                                                 float* __restrict__ tau, int* __restrict__ overflow,
                                                                 const int32_t* __restrict__ cand_ids, int last,
                                                                 int32_t* __restrict__ out_ids) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= Bq) return;
-    float* Ls = smem + wave * 4 * k;
-    float* Lsn = Ls + k;
-    int* Li = reinterpret_cast<int*>(Lsn + k);
-    int* Lin = Li + k;
-    for (int e = lane; e < k; e += 64) {
-        Ls[e] = best_s[row * k + e];
-        Li[e] = best_i[row * k + e];
-    }
+    RegList<R> L;
+    L.load(best_s + row * k, best_i + row * k, k, lane);
     int n = cnt[row];
     if (n > cap) {
         if (lane == 0) overflow[row] = 1;  // this row's list lost survivors: topk_redo_rows_kernel recomputes it
         n = cap;
     }
-    float tl = __shfl(Ls[k - 1], 0);
-    int il = __shfl(Li[k - 1], 0);
+    float tl;
+    int il;
+    L.at(k - 1, &tl, &il);
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
         const float v = (j < n) ? cs[row * cap + j] : -INFINITY;
@@ -259,34 +362,16 @@ __global__ __launch_bounds__(256) void topk_merge_compact_kernel(const float* __
             const float sc = __shfl(v, l);
             const int idx = __shfl(vi, l);
             if (!((sc > tl) || (sc == tl && idx < il))) continue;
-            int pos = 0;
-            for (int e0 = 0; e0 < k; e0 += 64) {
-                const int e = e0 + lane;
-                const bool ahead = (e < k) && ((Ls[e] > sc) || (Ls[e] == sc && Li[e] < idx));
-                pos += __popcll(__ballot(ahead));
-            }
-            if (pos >= k) continue;
-            for (int e = lane; e < k; e += 64) {
-                float s_new;
-                int i_new;
-                if (e < pos) { s_new = Ls[e]; i_new = Li[e]; }
-                else if (e == pos) { s_new = sc; i_new = idx; }
-                else { s_new = Ls[e - 1]; i_new = Li[e - 1]; }
-                Lsn[e] = s_new;
-                Lin[e] = i_new;
-            }
-            float* ts = Ls; Ls = Lsn; Lsn = ts;
-            int* ti = Li; Li = Lin; Lin = ti;
-            tl = __shfl(Ls[k - 1], 0);
-            il = __shfl(Li[k - 1], 0);
+            if (!L.insert(sc, idx, k, lane)) continue;
+            L.at(k - 1, &tl, &il);
         }
     }
-    for (int e = lane; e < k; e += 64) {
-        best_s[row * k + e] = Ls[e];
-        best_i[row * k + e] = Li[e];
-        if (last && out_ids) {
-            const int i = Li[e];
-            out_ids[row * k + e] = cand_ids ? cand_ids[i] : i;
+    L.store(best_s + row * k, best_i + row * k, k, lane);
+    if (last && out_ids) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = r * 64 + lane;
+            if (p < k) out_ids[row * k + p] = cand_ids ? cand_ids[L.i[r]] : L.i[r];
         }
     }
     if (lane == 0) {
@@ -433,8 +518,6 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
     float* sc = reinterpret_cast<float*>(ws);
     const size_t lds = (size_t)4 * 4 * k * sizeof(float);
     if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_redo_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     // ---- dense bootstrap over [0, n0): chunked score GEMM + streaming select ----
@@ -444,8 +527,15 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         if (st != MH_OK) return st;
         const int last = (!p.fused) && (c0 + nc >= p.n0);
         const int seen = (int)(c0 < k ? c0 : k);
-        hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, sc, nc, Bq,
-                           (int)ncur, c0, k, seen, out_scores, out_idx, cand_ids, last, out_ids);
+#define MH_TOPK_SELECT(R_)                                                                                          \
+    hipLaunchKernelGGL(topk_select_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, sc, nc, Bq, (int)ncur, c0, \
+                       k, seen, out_scores, out_idx, cand_ids, last, out_ids)
+        if (k <= 64) MH_TOPK_SELECT(1);
+        else if (k <= 128) MH_TOPK_SELECT(2);
+        else if (k <= 256) MH_TOPK_SELECT(4);
+        else if (k <= 512) MH_TOPK_SELECT(8);
+        else MH_TOPK_SELECT(16);
+#undef MH_TOPK_SELECT
     }
     if (p.fused) {
         float* tau = reinterpret_cast<float*>(ws + p.off_tau);
@@ -464,7 +554,16 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         while (beg < N) {
             int64_t end = beg * 8;
             if (end > N || N - end < beg) end = N;
-            if (E == 32 || E == 64 || E == 128) {
+            // MERLIN_HIP_TOPK_FILTER = tiled | stream forces one of the two MFMA filters (A/B); default: tiled for E >= 96
+            const char* fenv = getenv("MERLIN_HIP_TOPK_FILTER");  // read per call (a host-side string test per stage)
+            const int forced = !fenv ? 0 : (!strcmp(fenv, "tiled") ? 1 : (!strcmp(fenv, "stream") ? 2 : 0));
+            const bool can_tiled = vec_q && vec_c && E % 4 == 0 && E >= 16 && Bq < (1ll << 31);
+            const bool can_stream = (E == 32 || E == 64 || E == 128);
+            const bool use_tiled = can_tiled && (forced == 1 || (forced == 0 && (E >= 96 || !can_stream)));
+            if (use_tiled) {
+                const int32_t st = tiled_filter(q, Bq, cand + beg * E, end - beg, E, tau, cnt, cs, ci, p.cap, beg, s);
+                if (st != MH_OK) return st;
+            } else if (can_stream) {
                 // row-stationary streaming core (mh_scorer_stream.hip): queries in registers, candidates by LDS DMA
                 const int32_t st = mh_stream_filter(q, Bq, cand + beg * E, end - beg, E, tau, cnt, cs, ci, p.cap, beg, s);
                 if (st != MH_OK) return st;
@@ -478,8 +577,15 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
                 hipLaunchKernelGGL(topk_filter_gemm_kernel, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(FWM * FWN * 64), 0,
                                    s, q, cand, Bq, beg, end, E, tau, cnt, cs, ci, p.cap, tps, vec_q, vec_c);
             }
-            hipLaunchKernelGGL(topk_merge_compact_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, cs, ci, cnt,
-                               p.cap, Bq, k, out_scores, out_idx, tau, overflow, cand_ids, end >= N ? 1 : 0, out_ids);
+#define MH_TOPK_MERGE(R_)                                                                                           \
+    hipLaunchKernelGGL(topk_merge_compact_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, cs, ci, cnt, p.cap,  \
+                       Bq, k, out_scores, out_idx, tau, overflow, cand_ids, end >= N ? 1 : 0, out_ids)
+            if (k <= 64) MH_TOPK_MERGE(1);
+            else if (k <= 128) MH_TOPK_MERGE(2);
+            else if (k <= 256) MH_TOPK_MERGE(4);
+            else if (k <= 512) MH_TOPK_MERGE(8);
+            else MH_TOPK_MERGE(16);
+#undef MH_TOPK_MERGE
             beg = end;
         }
         // a compact list can only overflow on adversarial (e.g. ascending-sorted) data: those rows are recomputed

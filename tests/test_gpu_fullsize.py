@@ -60,7 +60,9 @@ def test_c3_scorer_full_batch_properties(device):
     fused = ops.inbatch_softmax(q, it, it, ids, ids, materialize=False)
     full = ops.inbatch_softmax(q, it, it, ids, ids, materialize=True)
     assert full.logits.shape == (B, B + 1)
-    torch.testing.assert_close(fused.loss, full.loss, atol=0, rtol=0)
+    # forward-only (tiled kernel: per-tile partials merged) vs the materialising stream kernel: the same logits, two summation
+    # orders of the softmax -- a few ulp of the ~10.4 log-sum-exp
+    torch.testing.assert_close(fused.loss, full.loss, atol=4e-6, rtol=0)
     torch.testing.assert_close(full.logits[:, 0], (q * it).sum(-1), atol=1e-5, rtol=1e-5)
     diag = full.logits[:, 1:].diagonal()
     assert bool((diag == torch.tensor(O.MIN_FLOAT, dtype=torch.float32, device=device)).all())

@@ -284,12 +284,17 @@ def test_l2norm_and_rowwise_dot(device):
     np.testing.assert_allclose(ops.rowwise_dot(_t(x, device), _t(y, device)).cpu().numpy()[:, 0], (x * y).sum(-1), atol=1e-4)
 
 
+@pytest.mark.parametrize("filt,E", [("stream", 32), ("tiled", 32), ("tiled", 128), ("stream", 128), ("tiled", 40)])
 @pytest.mark.parametrize("order", ["random", "ascending", "ties"])
-def test_topk_fused_filter_path_bit_exact(device, order):
+def test_topk_fused_filter_path_bit_exact(device, order, filt, E, monkeypatch):
     """N large enough for the fused-filter stages; 'ascending' makes every later candidate a survivor
-    (compact-list overflow -> dense fallback); 'ties' quantises scores so survivors tie across stages."""
+    (compact-list overflow -> dense fallback); 'ties' quantises scores so survivors tie across stages.  Both MFMA filters:
+    the row-stationary stream kernel and the tiled kernel on the second-generation GEMM core (transposed product)."""
+    monkeypatch.setenv("MERLIN_HIP_TOPK_FILTER", filt)
     rng = np.random.default_rng(11)
-    Bq, N, E, k = 33, 300_000, 32, 50
+    Bq, N, k = 33, 300_000, 50
+    if E == 128:
+        Bq, N = 140, 120_000  # two query column tiles of the tiled kernel, one ragged
     q = np.abs(rng.normal(size=(Bq, E))).astype(np.float32)
     if order == "ties":
         q = rng.integers(0, 3, size=(Bq, E)).astype(np.float32)
@@ -343,3 +348,44 @@ def test_l2norm_backward_matches_autograd_including_clamped_rows(device):
     got = ops.l2norm_backward(x.to(device), dy.to(device)).cpu()
     torch.testing.assert_close(got, xr.grad, atol=1e-3, rtol=1e-4)  # rows 5 / 9 carry a 1e6 scale
     torch.testing.assert_close(got[[0, 1, 2, 20]], xr.grad[[0, 1, 2, 20]], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,Nn,E", [(300, 700, 24), (130, 1100, 128), (513, 257, 64)])
+@pytest.mark.parametrize("ids_dtype", [None, np.int32, np.int64])
+@pytest.mark.parametrize("logq", [None, "before", "after"])
+def test_tiled_forward_scorer_matches_oracle_and_stream_kernel(device, B, Nn, E, ids_dtype, logq, monkeypatch):
+    """The forward-only scorer on the second-generation GEMM core (mh_scorer_tiled.hip: transposed product, register softmax)
+    against the numpy oracle (logits -> loss / lse) and against the row-stationary stream kernel on the same inputs: ragged
+    candidate / query tiles, false-negative mask with both id widths, logQ before and after the mask."""
+    rng = np.random.default_rng(B + Nn + E)
+    q = (rng.normal(size=(B, E)) * 0.3).astype(np.float32)
+    it = (rng.normal(size=(B, E)) * 0.3).astype(np.float32)
+    ng = (rng.normal(size=(Nn, E)) * 0.3).astype(np.float32)
+    pid = nid = None
+    if ids_dtype is not None:
+        pid = rng.integers(0, 40, size=B).astype(ids_dtype)
+        nid = rng.integers(0, 40, size=Nn).astype(ids_dtype)
+    plq = nlq = None
+    if logq is not None:
+        plq = np.log(rng.uniform(0.01, 0.2, size=B)).astype(np.float32)
+        nlq = np.log(rng.uniform(0.01, 0.2, size=Nn)).astype(np.float32)
+    T = 0.25
+    kw = dict(pos_logq=None if plq is None else _t(plq, device), neg_logq=None if nlq is None else _t(nlq, device),
+              logq_after_mask=(logq == "after"))
+    args = (_t(q, device), _t(it, device), _t(ng, device), None if pid is None else _t(pid, device),
+            None if nid is None else _t(nid, device), T)
+    monkeypatch.setenv("MERLIN_HIP_SCORER_FWD", "tiled")
+    rt = ops.inbatch_softmax(*args, materialize=False, **kw)
+    monkeypatch.setenv("MERLIN_HIP_SCORER_FWD", "stream")
+    rs = ops.inbatch_softmax(*args, materialize=False, **kw)
+    full = ops.inbatch_softmax(*args, materialize=True, **kw)  # materialised logits (stream kernel) -> fp64 log-sum-exp
+    z = full.logits.double()
+    lse = torch.logsumexp(z, dim=1)
+    np.testing.assert_allclose(rt.lse.cpu().numpy(), lse.cpu().numpy(), atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(rt.loss.cpu().numpy(), (lse - z[:, 0]).cpu().numpy(), atol=ATOL, rtol=1e-5)
+    np.testing.assert_allclose(rt.lse.cpu().numpy(), rs.lse.cpu().numpy(), atol=2e-5, rtol=1e-6)
+    np.testing.assert_allclose(rt.loss.cpu().numpy(), rs.loss.cpu().numpy(), atol=2e-5, rtol=1e-6)
+    if logq is None:  # the oracle's own statement of the logits
+        ref, _ = O.contrastive_outputs(q, it, ng, pid, nid, temperature=T, downscore_false_negatives=pid is not None)
+        r64 = torch.from_numpy(ref).double()
+        np.testing.assert_allclose(rt.lse.cpu().numpy(), torch.logsumexp(r64, dim=1).numpy(), atol=ATOL, rtol=1e-5)

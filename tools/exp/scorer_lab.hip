@@ -144,12 +144,26 @@ __global__ void naive_kernel(const float* __restrict__ q, const float* __restric
     lse[i] = (float)(m + log(s));
 }
 
+// SCORER_LAB_DATA=dense: full-entropy mantissas (sum of four 24-bit uniforms, ~normal) instead of the 2001-level grid.  Round 4:
+// the grid data flatters the MFMA rate (the chip clocks higher on low-entropy operands): 0.71 on the grid vs the product's 0.63-0.65
+// on torch.randn data with the SAME kernel, same box (profiles/r4_notes.md).
 float* dev_rand(size_t n, uint32_t seed, float scale) {
     std::vector<float> h(n);
     uint32_t s = seed * 2654435761u + 12345u;
+    const char* mode = getenv("SCORER_LAB_DATA");
+    const bool dense = mode && mode[0] == 'd';
     for (size_t i = 0; i < n; ++i) {
         s = s * 1664525u + 1013904223u;
-        h[i] = ((int32_t)(s >> 8) % 2001 - 1000) * 0.001f * scale;
+        if (dense) {
+            double a = 0;
+            for (int k = 0; k < 4; ++k) {
+                s = s * 1664525u + 1013904223u;
+                a += (double)(s >> 8) / 16777216.0 - 0.5;
+            }
+            h[i] = (float)(a * 1.7320508 * scale);  // unit variance x scale
+        } else {
+            h[i] = ((int32_t)(s >> 8) % 2001 - 1000) * 0.001f * scale;
+        }
     }
     float* d;
     CK(hipMalloc(&d, n * sizeof(float)));
