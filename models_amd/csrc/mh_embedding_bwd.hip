@@ -1083,6 +1083,7 @@ static int32_t gather_bwd_impl(float* const* tables, float* const* state, const 
         optimizer = MH_OPT_SGD;
         state = state2 = nullptr;
     }
+    if (B <= 0) return MH_OK;  // before the pointer checks: an empty gradient buffer has no address
     MH_REQUIRE(tables && table_rows && ids && grad && grad_offset, "mh_embedding_gather_bwd: null argument");
     MH_REQUIRE(F >= 1 && F < MH_MAX_FEATURES, "mh_embedding_gather_bwd: F=%d outside [1,%d]", F, MH_MAX_FEATURES - 1);
     MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "mh_embedding_gather_bwd: D=%d must be a multiple of 4 in [4,1024]", D);

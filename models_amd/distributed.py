@@ -250,7 +250,14 @@ class ShardedEmbeddingGroup:
         self._capacity_n = 0                         # request count the window was derived from
         self._steps, self._max_count = 0, 0
         self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.check_every = 64                        # fixed-window calls between two automatic overflow checks (0: never)
+        self.check_every = 64                        # CAPTURED steps only: fixed-window calls between two automatic overflow checks
+        # Eager calls never lose a request: right behind the route kernel -- before anything is exchanged -- the ranks agree
+        # (all-reduce MAX of the overflow flag, one host read) whether ANY window overflowed; if one did, THIS call takes the dense
+        # exchange (exact per-peer counts) and the window is re-derived from the counts it sees.  SparseOperationKit never drops
+        # (tf/distributed/embedding.py:144-148); a step replayed from a captured graph cannot branch on the host, so it keeps the
+        # flag and raises at the next check.
+        self.lossless = True
+        self.spills = 0                              # calls that overflowed their window and were served by the dense exchange
         self._since_check = 0
         self._parent: Optional["ShardedEmbeddingGroup"] = None
         self._deferred: List = []                    # (rows, gradient rows) handed over by aliases: ONE update per step
@@ -351,15 +358,27 @@ class ShardedEmbeddingGroup:
         # batches -- the fixed all-to-all needs that anyway), so all ranks take the same branch; routes whose n is rank-local
         # (ragged aliases) never leave the dense exchange.
         fixed = self.capacity is not None and n <= self._capacity_n and not never_fixed
-        if fixed and self.check_every > 0:
+        capturing = send_capturing()
+        if fixed and self.check_every > 0 and (capturing or not self.lossless):
             self._since_check += 1
-            capturing = send_capturing()
             if self._since_check >= self.check_every and not capturing:
                 self._since_check = 0
                 self.check_overflow()  # one host read every check_every steps: a dropped request never goes unnoticed for long
-        if fixed:                       # ---- fixed windows: no host sync ----
+        if fixed:                       # ---- fixed windows ----
             cap = self.capacity
             send_keys, pos_of, src_row, _ = self.route_fn(ids, W, slots, n_slots, cap, self.overflow)
+            if self.lossless and W > 1 and not capturing:
+                # nothing has been exchanged yet: agree on the outcome of the route (every rank takes the same branch)
+                dist.all_reduce(self.overflow, op=dist.ReduceOp.MAX, group=self.group)
+                if int(self.overflow.item()) != 0:
+                    self.overflow.zero_()
+                    self.spills += 1
+                    # this call is served exactly by the dense exchange below, which also re-derives the window from the
+                    # counts it sees (max over the ranks x capacity_factor): the skew that overflowed it is the new normal
+                    self.capacity, self._capacity_n = None, 0
+                    self._steps = max(self.calibration - 1, 0)
+                    fixed = False
+        if fixed:
             self._send_counts = self._recv_counts = None
             n_recv = W * cap
         else:                           # ---- dense: per-peer counts on the host (calibration steps) ----

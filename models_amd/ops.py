@@ -842,6 +842,8 @@ def embedding_gather_backward(tables: Sequence[torch.Tensor], states: Optional[S
     if not grad.is_contiguous():
         raise ValueError("grad must be contiguous")
     B = grad.shape[0]
+    if B == 0:
+        return  # no gradient rows (a rank that owns none of a skewed batch's requested rows): nothing to update
     D = tables[0].shape[1]
     row_stride = grad.numel() // max(B, 1)
     idt = _ids_dtype(ids[0], "ids[0]")

@@ -39,6 +39,8 @@ def embedding_gather(tables, ids, out=None, out_slot=None, n_slots=None, out_off
         n_slots = (max(slots) + 1) if out is None else out.shape[1]
     if out is None:
         out = torch.empty((B, n_slots, D), dtype=torch.float32, device=tables[0].device)
+    if B == 0:  # a rank that owns none of the requested rows (all ids of a skewed batch on one owner)
+        return out
     flat = out.view(B, -1)
     offs = [s * D for s in slots] if out_offset is None else list(out_offset)
     for t, i, o in zip(tables, ids, offs):
@@ -98,6 +100,8 @@ def embedding_gather_backward(tables, states, ids, grad, grad_offset, optimizer=
     if optimizer not in ("sgd", "adagrad"):
         raise NotImplementedError("shim: sgd / adagrad only")
     B = grad.shape[0]
+    if B == 0:  # nothing arrived for this rank's shards (mh_embedding_gather_bwd returns at once for B <= 0)
+        return
     g2 = grad.reshape(B, -1)
     D = tables[0].shape[1]
     seen = {}

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
+import pytest as _pytest
 import torch.multiprocessing as mp
 
 from models_amd import distributed as D
@@ -172,18 +173,23 @@ def _dlrm_parts(seed=5):
     return m, schema, cards
 
 
-def _dlrm_batches(cards, world, B, steps, seed=11):
+def _dlrm_batches(cards, world, B, steps, seed=11, skew_from=None):
+    """``skew_from``: from that step on every id of the row-sharded features C1 / C3 is EVEN -- under owner = row % 2 all their
+    requests go to rank 0, twice what the calibration steps saw: the fixed window overflows."""
     g = torch.Generator().manual_seed(seed)
     out = []
-    for _ in range(steps):
+    for s_ in range(steps):
         x = {n: torch.randint(0, v, (world, B), generator=g) for n, v in cards.items()}
+        if skew_from is not None and s_ >= skew_from:
+            for n in ("C1", "C3"):
+                x[n] = x[n] // 2 * 2
         x.update({f"I{i}": torch.rand(world, B, 1, generator=g) for i in range(1, 4)})
         y = torch.randint(0, 2, (world, B, 1), generator=g).float()
         out.append((x, y))
     return out
 
 
-def _dlrm_worker(rank, world, port, q):
+def _dlrm_worker(rank, world, port, q, skew=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -192,9 +198,9 @@ def _dlrm_worker(rank, world, port, q):
         import ops_shim
 
         ops_shim.install()
-        B, steps = 64, 3
+        B, steps = (200 if skew else 64), (7 if skew else 3)  # 400 requests per rank: the 1.25 x window (320 slots) is below all-to-one-owner
         model, schema, cards = _dlrm_parts()
-        batches = _dlrm_batches(cards, world, B, steps)
+        batches = _dlrm_batches(cards, world, B, steps, skew_from=3 if skew else None)
         model({k: v[rank] for k, v in batches[0][0].items()})  # build lazily-shaped layers
         dd = D.DistributedDLRM(model, shard_threshold=1000)
         assert sorted(dd.sharded) == ["C1", "C3"]
@@ -202,10 +208,11 @@ def _dlrm_worker(rank, world, port, q):
         for x, y in batches:
             losses.append(float(dd.train_step({k: v[rank] for k, v in x.items()}, y[rank])))
         # numpy (pickled by value): tensors would travel as file descriptors of a process that is about to exit
-        state = {"loss": losses,
+        state = {"loss": losses, "spills": dd.group_sh.spills, "capacity": dd.group_sh.capacity,
                  "dense": [p.data.numpy().copy() for p in model.parameters() if not p.sparse],
                  "rep": {n: model.body.embeddings.feature_table[n].table.data.numpy().copy() for n in dd.replicated},
                  "shard": {n: dd.sharded[n].numpy().copy() for n in dd.sharded}}
+        dd.check_overflow()  # nothing was dropped
         q.put((rank, "ok", state))
     except Exception:  # pragma: no cover
         import traceback
@@ -215,18 +222,23 @@ def _dlrm_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_distributed_dlrm_step_world2_matches_full_batch_model():
+@_pytest.mark.parametrize("skew", [False, True])
+def test_distributed_dlrm_step_world2_matches_full_batch_model(skew):
     """Two ranks, half a batch each, row-sharded C1/C3 + replicated C2/C4: after three Adagrad steps every rank
-    holds the parameters a single model trained on the concatenated batch holds (and reports its loss)."""
+    holds the parameters a single model trained on the concatenated batch holds (and reports its loss).
+    skew: after the windows were frozen (two calibration steps + one fixed step) every sharded id becomes even -- all requests go
+    to rank 0, twice the calibrated count: the window overflows.  No request may be lost: the ranks agree on the overflow right
+    behind the route kernel, that call is served by the dense exchange and the window is re-derived (SOK never drops,
+    tf/distributed/embedding.py:144-148) -- the parameters still equal the single model's, which a dropped row would break."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import ops_shim
     from models_amd import ops
 
-    world, B, steps = 2, 64, 3
+    world, B, steps = 2, (200 if skew else 64), (7 if skew else 3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dlrm_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dlrm_worker, args=(r, world, port, q, skew)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
@@ -238,7 +250,7 @@ def test_distributed_dlrm_step_world2_matches_full_batch_model():
     try:
         ops_shim.install()
         model, schema, cards = _dlrm_parts()
-        batches = _dlrm_batches(cards, world, B, steps)
+        batches = _dlrm_batches(cards, world, B, steps, skew_from=3 if skew else None)
         model({k: v[0] for k, v in batches[0][0].items()})
         ref_losses = []
         for x, y in batches:
@@ -249,6 +261,10 @@ def test_distributed_dlrm_step_world2_matches_full_batch_model():
             setattr(ops, n, v)
     ref_dense = [p.data for p in model.parameters() if not p.sparse]
     for rank, _, st in res:
+        if skew:  # exactly one call overflowed (the first skewed one); the re-derived window holds the later ones
+            assert st["spills"] == 1 and st["capacity"] is not None and st["capacity"] >= 2 * B, (st["spills"], st["capacity"])
+        else:
+            assert st["spills"] == 0
         np.testing.assert_allclose(st["loss"], ref_losses, rtol=1e-5, atol=1e-6)
         for a, b in zip(st["dense"], ref_dense):
             np.testing.assert_allclose(a, b.numpy(), atol=2e-5, rtol=1e-4)
@@ -459,6 +475,7 @@ def test_fixed_windows_do_not_drop_requests_of_a_larger_batch():
     rows = grp.lookup(small)                                        # a smaller batch still fits the fixed window
     for f in range(2):
         torch.testing.assert_close(rows[f], fulls[f][small[f]])
+    grp.lossless = False                                            # the mode of captured steps: flag + periodic host read
     grp.check_every = 2                                             # the periodic check reads the flag by itself
     grp.overflow.fill_(1)
     import pytest
@@ -544,9 +561,6 @@ def _list_worker(rank, world, port, q, uneven=False):
         q.put((rank, "FAIL: " + traceback.format_exc(), None))
     finally:
         dist.destroy_process_group()
-
-
-import pytest as _pytest
 
 
 @_pytest.mark.parametrize("uneven", [False, True])

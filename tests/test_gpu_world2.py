@@ -53,17 +53,21 @@ def _dlrm(device):
     return m, cards
 
 
-def _batches(cards, world, B, steps, seed=11):
+def _batches(cards, world, B, steps, seed=11, skew_from=None):
+    """``skew_from``: from that step on every id of the row-sharded features is even: all requests go to rank 0 (row % 2)."""
     g = torch.Generator().manual_seed(seed)
     out = []
-    for _ in range(steps):
+    for s_ in range(steps):
         x = {n: torch.randint(0, v, (world, B), generator=g, dtype=torch.int32) for n, v in cards.items()}
+        if skew_from is not None and s_ >= skew_from:
+            for n in ("C1", "C3", "C5"):
+                x[n] = x[n] // 2 * 2
         x.update({f"I{i}": torch.rand(world, B, 1, generator=g) for i in range(1, 4)})
         out.append((x, torch.randint(0, 2, (world, B, 1), generator=g).float()))
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, skew=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -75,15 +79,16 @@ def _worker(rank, world, port, q):
         from models_amd import distributed as D
 
         dev = torch.device("cuda:0")
-        B, steps = 512, 5  # two calibration steps (dense exchange), then fixed-capacity windows
+        B, steps = 512, (7 if skew else 5)  # two calibration steps (dense exchange), then fixed-capacity windows
         model, cards = _dlrm(dev)  # full tables, sliced by DistributedDLRM: the same values as the one-process reference
-        batches = _batches(cards, world, B, steps)
+        batches = _batches(cards, world, B, steps, skew_from=3 if skew else None)
         mine = lambda x: {k: v[rank].to(dev) for k, v in x.items()}
         model(mine(batches[0][0]))
         dd = D.DistributedDLRM(model, shard_threshold=1000)
         assert sorted(dd.sharded) == ["C1", "C3", "C5"]
         losses = [float(dd.train_step(mine(x), y[rank].to(dev))) for x, y in batches]
         dd.check_overflow()
+        assert dd.group_sh.spills == (1 if skew else 0), dd.group_sh.spills  # the first skewed call overflowed its window: served densely
         assert model.body._fused, "the sharded step should run the fused gather -> interaction kernels"
         pred = dd(mine(batches[0][0])).cpu().numpy()
         state = {"loss": losses, "pred": pred,
@@ -99,16 +104,20 @@ def _worker(rank, world, port, q):
         q.put((rank, "FAIL: " + traceback.format_exc(), None))
 
 
-def test_sharded_dlrm_step_world2_on_hip_matches_the_full_batch_model(device):
+@pytest.mark.parametrize("skew", [False, True])
+def test_sharded_dlrm_step_world2_on_hip_matches_the_full_batch_model(device, skew):
+    """skew: after the windows are frozen every sharded id becomes even (all requests to rank 0, twice the calibrated count):
+    the overflowing call must be served without losing a request (dense exchange, window re-derived) -- through the real route
+    kernels, with a rank that owns NONE of the requested rows (zero-row gathers and updates)."""
     import torch.multiprocessing as mp
 
     from models_amd import distributed as D
 
-    world, B, steps = 2, 512, 5
+    world, B, steps = 2, 512, (7 if skew else 5)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, skew)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
@@ -117,7 +126,7 @@ def test_sharded_dlrm_step_world2_on_hip_matches_the_full_batch_model(device):
     assert all(m == "ok" for _, m, _ in res), [m for _, m, _ in res]
     # reference: ONE model on the concatenated batch (plain RankingModel.train_step, same kernels, one process)
     model, cards = _dlrm(device)
-    batches = _batches(cards, world, B, steps)
+    batches = _batches(cards, world, B, steps, skew_from=3 if skew else None)
     full = lambda x: {k: v.reshape(world * B, *v.shape[2:]).to(device) for k, v in x.items()}
     model(full(batches[0][0]))
     ref_losses = [float(model.train_step(full(x), y.reshape(world * B, 1).to(device))) for x, y in batches]
