@@ -254,6 +254,9 @@ class Model(Block):
                     n += self._batch_size(x)
                     steps += 1
             torch.cuda.synchronize()
+            for smp in getattr(getattr(self, "output", None), "negative_samplers", None) or ():  # device-side status words
+                if hasattr(smp, "check_status"):
+                    smp.check_status()
             if last is not None:
                 history["loss"].append(float(last))
             if t0 is not None and steps:

@@ -1594,6 +1594,16 @@ def log_uniform_sample(range_max: int, n: int, unique: bool, rng_state: torch.Te
     return out
 
 
+def log_uniform_sample_status(device) -> int:
+    """The status word the LAST ``mh_log_uniform_sample`` call on ``device`` left in its workspace (0 = every requested class
+    was drawn; 1 = the unique draw gave up before reaching ``n`` classes: a broken argument combination).  One host read --
+    call it outside captured / timed regions (``PopularityBasedSamplerV2.check_status``: epoch ends)."""
+    buf = _WS.get((str(torch.device(device) if not isinstance(device, torch.device) else device), "log_uniform"))
+    if buf is None:
+        return 0
+    return int(buf[:4].view(torch.int32).item())
+
+
 def topk_metrics(labels_sorted: torch.Tensor, k: int, relevant_counts: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-query ranking metrics @k on pre-sorted labels -> [B, 6] (TOPK_METRIC_NAMES order)."""
     lib = _lib.load()

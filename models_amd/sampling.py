@@ -154,6 +154,16 @@ class PopularityBasedSamplerV2(CandidateSampler):
         ids = ops.log_uniform_sample(self.max_id - self.min_id, self.max_num_samples, self.unique, st, self.min_id)
         return Candidate(ids.reshape(-1, 1), {})
 
+    def check_status(self) -> None:
+        """Host read of the sampler kernel's status word on every device it drew on (the kernel cannot raise, and a captured step
+        cannot read it): call at epoch ends / after evaluation (``Model.fit`` does)."""
+        from . import ops
+
+        for dev in self._rng_state:
+            if ops.log_uniform_sample_status(dev) != 0:
+                raise RuntimeError(f"PopularityBasedSamplerV2: the unique draw of {self.max_num_samples} ids from "
+                                   f"[{self.min_id}, {self.max_id}) did not complete on {dev}")
+
     def get_sampling_distribution(self) -> torch.Tensor:
         """Probability of every id under the sampler (popularity.py:139-166); with ``unique`` the probability of being
         drawn at least once in ``max_num_samples`` trials, 1 - (1 - p)^n computed as -expm1(n log1p(-p))."""

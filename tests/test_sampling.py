@@ -101,6 +101,10 @@ def test_popularity_sampler_on_the_device(device):
     assert len(torch.unique(out.id)) == num_sampled and bool((out.id >= min_id).all()) and bool((out.id < num_classes - 1 + min_id).all())
     out2 = s(mm.Candidate(item_ids, {}))
     assert not torch.equal(out.id, out2.id)  # the call counter is device state
+    s.check_status()  # the kernel's status word (what Model.fit reads at epoch ends): the unique draw completed
+    from models_amd import ops
+
+    assert ops.log_uniform_sample_status(device) == 0
     # Zipfian: low ids are drawn far more often
     s2 = mm.PopularityBasedSamplerV2(max_num_samples=2000, max_id=100_000, unique=False, seed=0)
     ids = s2.sample(device=device).id.reshape(-1)
