@@ -42,6 +42,15 @@ extern "C" {
 #define MH_ACT_NONE 0
 #define MH_ACT_RELU 1
 #define MH_ACT_SIGMOID 2
+/* activations that run as their own element-wise layer (mh_activation), not in a GEMM epilogue */
+#define MH_ACTX_TANH 10
+#define MH_ACTX_ELU 11
+#define MH_ACTX_SELU 12
+#define MH_ACTX_SOFTPLUS 13
+#define MH_ACTX_SWISH 14
+#define MH_ACTX_GELU 15
+#define MH_ACTX_LEAKY_RELU 16
+#define MH_ACTX_RELU6 17
 
 /* sequence combiners (inputs/embedding.py:432-441, 1545-1587) */
 #define MH_COMBINER_SUM 0
@@ -303,6 +312,13 @@ int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y
  * for rows below the clamp.  x, dy, dx contiguous [M, N]. */
 int32_t mh_l2norm_rows_bwd(const float* x, const float* dy, int64_t M, int32_t N, float eps, float* dx,
                            mh_stream_t stream);
+
+/* tf.keras.layers.Activation for the Keras activation names MLPBlock accepts (blocks/mlp.py:35-139) beyond relu / sigmoid /
+ * linear, which are fused into the GEMM epilogues: tanh, elu, selu, softplus, swish (silu), gelu (exact, erf), leaky_relu
+ * (slope 0.2, tf.nn.leaky_relu's default), relu6.  dy == NULL: out = f(x).  dy != NULL: out = dy * f'(x) with x the layer's
+ * SAVED INPUT (the pre-activation).  Row-major [M, N] operands, each with its own leading dimension; out may alias x or dy. */
+int32_t mh_activation(int32_t act, const float* x, int64_t ldx, const float* dy, int64_t lddy, float* out, int64_t ldo,
+                      int64_t M, int32_t N, mh_stream_t stream);
 
 /* Mean of n floats into mean[0] (Keras' SUM_OVER_BATCH_SIZE reduction of a per-sample loss, e.g. the softmax-CE rows of
  * the retrieval step, losses/listwise.py:38-52): two launches, fixed summation order (deterministic).  workspace: 256 floats. */

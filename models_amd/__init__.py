@@ -12,7 +12,7 @@ from .inputs import (  # noqa: F401
     InputBlock, InputBlockV2, Ragged, infer_embedding_dim,
 )
 from .blocks import (  # noqa: F401
-    BatchNormalization, Cross, CrossBlock, DLRMBlock, DotProductInteraction, DotProductInteractionBlock, Dropout, MLPBlock,
+    Activation, BatchNormalization, Cross, CrossBlock, DLRMBlock, DotProductInteraction, DotProductInteractionBlock, Dropout, MLPBlock,
     TwoTowerBlock, set_seed,
 )
 from .outputs import (  # noqa: F401

@@ -92,6 +92,7 @@ SIGNATURES = {
     "mh_bce_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p]),
     "mh_bce_mean_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p, _p]),
     "mh_mean": (_i32, [_p, _i64, _p, _p, _p]),
+    "mh_activation": (_i32, [_i32, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p]),
 }
 
 _LIB = None

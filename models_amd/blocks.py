@@ -63,7 +63,8 @@ class _Dense(Block):
                  name: Optional[str] = None, device=None, seed: Optional[int] = None):
         super().__init__(name)
         if activation not in _SUPPORTED_ACT:
-            raise NotImplementedError(f"activation {activation!r} is not on the HIP hot path (relu/sigmoid/linear)")
+            raise NotImplementedError(f"activation {activation!r} is not fused into the Dense kernels (relu / sigmoid / linear are); "
+                                      f"MLPBlock(activation=...) places {sorted(ops.ACTX)} behind a linear Dense as an Activation layer")
         self.units = int(units)
         self.activation = None if activation == "linear" else activation
         self.use_bias = use_bias
@@ -218,6 +219,25 @@ def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False, z
     return grad
 
 
+class Activation(Block):
+    """tf.keras.layers.Activation(name) for the Keras activations an ``MLPBlock(activation=...)`` may name beyond relu / sigmoid /
+    linear (those ride in the GEMM epilogues): tanh, elu, selu, softplus, swish / silu, gelu, leaky_relu, relu6.  The Dense layer in
+    front of it runs linear; this layer keeps its input for the backward (``mh_activation``)."""
+
+    def __init__(self, activation: str, name: Optional[str] = None):
+        super().__init__(name)
+        if activation not in ops.ACTX:
+            raise ValueError(f"Unknown activation {activation!r}; element-wise activation layers: {sorted(ops.ACTX)}")
+        self.activation = activation
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._x = x
+        return ops.activation(x, self.activation)
+
+    def backward(self, grad: torch.Tensor) -> torch.Tensor:
+        return ops.activation(self._x, self.activation, dy=grad)
+
+
 class Dropout(Block):
     """tf.keras.layers.Dropout(rate) behind a Dense layer of an MLPBlock (mlp.py:108-114, 126-127): active under
     ``blocks.tape()`` (the training forward), identity otherwise.  The mask is counter-based (``mh_dropout``): nothing is kept
@@ -329,9 +349,17 @@ def MLPBlock(dimensions: Sequence[int], activation: Union[str, List[str]] = "rel
             act = "linear"
         elif dropout:
             drop = Dropout(dropout, seed=None if seed is None else seed + 100 + idx, device=device)
+        post = None
+        if act not in _SUPPORTED_ACT and act not in ops.ACTX:
+            raise ValueError(f"Unknown activation {act!r}: fused into the Dense kernels: relu, sigmoid, linear; as an Activation "
+                             f"layer: {sorted(ops.ACTX)}")
+        if act in ops.ACTX:  # not an epilogue activation: Dense(linear) + an element-wise Activation layer (same function)
+            post, act = Activation(act), "linear"
         layers.append(_Dense(dim, activation=act, use_bias=use_bias, kernel_initializer=kernel_initializer,
                              bias_initializer=bias_initializer, device=device,
                              seed=None if seed is None else seed + idx))
+        if post is not None:
+            layers.append(post)
         if drop is not None:
             layers.append(drop)
         if normalization == "batch_norm":
@@ -756,4 +784,10 @@ def _copy_mlp(block: Block, device=None) -> Block:
         return _Dense(block.units, activation=block.activation or "linear", use_bias=block.use_bias,
                       kernel_initializer=block.kernel_initializer, bias_initializer=block.bias_initializer,
                       device=device or block.device)
+    if isinstance(block, Activation):
+        return Activation(block.activation)
+    if isinstance(block, Dropout):
+        return Dropout(block.rate, device=device)
+    if isinstance(block, BatchNormalization):
+        return BatchNormalization(block.momentum, block.epsilon, block.center, block.scale, device=device or block.device)
     raise NotImplementedError(f"cannot copy tower layer {type(block).__name__}")

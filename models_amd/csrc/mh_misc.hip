@@ -242,6 +242,55 @@ __global__ __launch_bounds__(256) void eltwise_vec_kernel(const f32x4* __restric
     out[i] = v;
 }
 
+// ---- Keras activations that are not fused into the GEMM epilogues (MLPBlock(activation=...), blocks/mlp.py:35-139 accepts any
+// Keras activation name; relu / sigmoid / linear ride in the epilogues, these run as their own element-wise layer, like
+// tf.keras.layers.Activation).  Forward y = f(x); backward dx = dy * f'(x) from the SAVED INPUT (swish / gelu need it).
+__device__ __forceinline__ float actx_fwd(float x, int act) {
+    switch (act) {
+        case MH_ACTX_TANH: return tanhf(x);
+        case MH_ACTX_ELU: return x > 0.f ? x : expm1f(x);
+        case MH_ACTX_SELU: return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * expm1f(x));
+        case MH_ACTX_SOFTPLUS: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+        case MH_ACTX_SWISH: return x / (1.f + expf(-x));
+        case MH_ACTX_GELU: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+        case MH_ACTX_LEAKY_RELU: return x > 0.f ? x : 0.2f * x;
+        case MH_ACTX_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float actx_grad(float x, int act) {
+    switch (act) {
+        case MH_ACTX_TANH: {
+            const float t = tanhf(x);
+            return 1.f - t * t;
+        }
+        case MH_ACTX_ELU: return x > 0.f ? 1.f : expf(x);
+        case MH_ACTX_SELU: return 1.0507009873554805f * (x > 0.f ? 1.f : 1.6732632423543772f * expf(x));
+        case MH_ACTX_SOFTPLUS: return 1.f / (1.f + expf(-x));
+        case MH_ACTX_SWISH: {
+            const float sg = 1.f / (1.f + expf(-x));
+            return sg + x * sg * (1.f - sg);
+        }
+        case MH_ACTX_GELU:
+            return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        case MH_ACTX_LEAKY_RELU: return x > 0.f ? 1.f : 0.2f;
+        case MH_ACTX_RELU6: return (x > 0.f && x < 6.f) ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+// dy == NULL: forward (out = f(x)); else backward (out = dy * f'(x)).  [M, N] operands with their own leading dimensions.
+__global__ __launch_bounds__(256) void activation_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                        int64_t lddy, float* __restrict__ out, int64_t ldo, int64_t M, int N,
+                                                        int act) {
+    const int64_t n = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / N;
+        const int c = (int)(i - r * N);
+        const float xv = x[r * ldx + c];
+        out[r * ldo + c] = dy ? dy[r * lddy + c] * actx_grad(xv, act) : actx_fwd(xv, act);
+    }
+}
+
 // l2_batch_regularization (inputs/embedding.py:463-464): loss += factor * sum(out^2), d loss / d out = 2 factor out.
 // Pass 1: grad[b, d] += 2 factor out[b, d] over the [B, D] view (row strides ld_out / ld_grad), per-workgroup partial of
 // sum(out^2); pass 2 adds the partials in a fixed order into loss_accum (deterministic).
@@ -564,6 +613,19 @@ int32_t mh_bce_mean_fwd_bwd(const float* p, const float* label, int64_t M, float
                        workspace, dlogit);
     hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, M, loss_mean);
     MH_CHECK_LAUNCH("mh_bce_mean_fwd_bwd");
+    return MH_OK;
+}
+
+int32_t mh_activation(int32_t act, const float* x, int64_t ldx, const float* dy, int64_t lddy, float* out, int64_t ldo, int64_t M,
+                      int32_t N, mh_stream_t stream) {
+    MH_REQUIRE(x && out && N >= 1 && ldx >= N && ldo >= N && (!dy || lddy >= N), "mh_activation: bad argument");
+    MH_REQUIRE(act >= MH_ACTX_TANH && act <= MH_ACTX_RELU6, "mh_activation: unknown activation %d", act);
+    if (M <= 0) return MH_OK;
+    int64_t nb = mh_ceil_div(M * N, 256);
+    const int64_t cap = (int64_t)mh_num_cus() * 32;
+    if (nb > cap) nb = cap;
+    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), x, ldx, dy, lddy, out, ldo, M, N, act);
+    MH_CHECK_LAUNCH("mh_activation");
     return MH_OK;
 }
 

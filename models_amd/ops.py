@@ -1010,6 +1010,27 @@ def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
     return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
 
 
+ACTX = {"tanh": 10, "elu": 11, "selu": 12, "softplus": 13, "swish": 14, "silu": 14, "gelu": 15, "leaky_relu": 16, "relu6": 17}
+
+
+def activation(x: torch.Tensor, name: str, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``f(x)`` (``dy`` None) or ``dy * f'(x)`` for the element-wise activations of ``ACTX`` (``mh_activation``); x is the
+    layer's input (pre-activation) in both directions.  2-D row-major operands."""
+    lib = _lib.load()
+    if name not in ACTX:
+        raise ValueError(f"unknown activation {name!r} (element-wise layer: {sorted(ACTX)})")
+    _rowmajor_2d(x, "x")
+    if dy is not None:
+        _rowmajor_2d(dy, "dy")
+        if dy.shape != x.shape:
+            raise ValueError("activation: dy must have the shape of x")
+    M, N = x.shape
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib.mh_activation(ACTX[name], _ptr(x), x.stride(0), _ptr(dy), 0 if dy is None else dy.stride(0), _ptr(out), N, M, N,
+                            _stream()), "mh_activation")
+    return out
+
+
 def mean(x: torch.Tensor) -> torch.Tensor:
     """Mean of a contiguous fp32 tensor as a 0-d device tensor (``mh_mean``: deterministic two-stage sum; replaces the
     torch reduction kernel that used to run once per retrieval train step)."""

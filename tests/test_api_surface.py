@@ -58,8 +58,12 @@ def test_pretrained_table_and_trainable_flag():
 def test_mlp_block_construction_errors():
     with pytest.raises(ValueError, match="mismatch"):
         mm.MLPBlock([8, 4], activation=["relu"])
-    with pytest.raises(NotImplementedError):
-        mm.MLPBlock([8], activation="tanh")
+    # Keras activations beyond relu / sigmoid / linear: a linear Dense followed by an element-wise Activation layer
+    t = mm.MLPBlock([8, 4], activation="tanh", device=CPU)
+    assert [type(l).__name__ for l in t.layers] == ["_Dense", "Activation", "_Dense", "Activation"]
+    assert [l.activation for l in t.layers] == [None, "tanh", None, "tanh"]
+    with pytest.raises(ValueError, match="Unknown activation"):
+        mm.MLPBlock([8], activation="not_an_activation", device=CPU)
     blk = mm.MLPBlock([8, 4], no_activation_last_layer=True, device=CPU)
     assert [l.activation for l in blk.layers] == ["relu", None]
 

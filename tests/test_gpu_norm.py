@@ -133,3 +133,41 @@ def test_mlp_block_with_dropout_and_batch_norm_trains_like_the_statement(device)
     names = [p.name for p in model.parameters()]
     assert any(n.endswith("/moving_mean") for n in names) and any(n.endswith("/moving_variance") for n in names)
     assert all(not p.trainable for p in model.parameters() if "moving_" in p.name)
+
+
+@pytest.mark.parametrize("name", ["tanh", "elu", "selu", "softplus", "swish", "gelu", "leaky_relu", "relu6"])
+def test_elementwise_activation_layer(device, name):
+    """mh_activation forward against the oracle's Keras definitions and torch; backward against torch autograd; through an
+    MLPBlock(activation=name) (Dense(linear) + Activation) forward + backward."""
+    tfn = {"tanh": torch.tanh, "elu": torch.nn.functional.elu, "selu": torch.nn.functional.selu,
+           "softplus": torch.nn.functional.softplus, "swish": torch.nn.functional.silu,
+           "gelu": lambda t: torch.nn.functional.gelu(t), "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.2),
+           "relu6": torch.nn.functional.relu6}[name]
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(301, 37, generator=g) * 3).requires_grad_()
+    dy = torch.randn(301, 37, generator=g)
+    y = tfn(x)
+    y.backward(dy)
+    yd = ops.activation(x.detach().to(device), name)
+    np.testing.assert_allclose(yd.cpu().numpy(), O._act(x.detach().numpy(), name), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(yd.cpu(), y.detach(), atol=2e-6, rtol=1e-5)
+    dx = ops.activation(x.detach().to(device), name, dy=dy.to(device))
+    torch.testing.assert_close(dx.cpu(), x.grad, atol=2e-6, rtol=1e-5)
+    # as the activation of an MLPBlock: structure Dense(linear) -> Activation per layer; forward and input gradient vs torch
+    blk = mm.MLPBlock([24, 8], activation=name, device=device, seed=3)
+    xin = torch.randn(65, 13, generator=g)
+    with blocks.tape():
+        out = blk(xin.to(device))
+    assert [type(l).__name__ for l in blk.layers] == ["_Dense", "Activation", "_Dense", "Activation"]
+    xt = xin.clone().requires_grad_()
+    h = xt
+    for l in blk.layers:
+        if isinstance(l, mm.Activation):
+            h = tfn(h)
+        else:
+            h = h @ l.kernel.data.cpu() + l.bias.data.cpu()
+    torch.testing.assert_close(out.cpu(), h.detach(), atol=1e-5, rtol=1e-4)
+    go = torch.randn(65, 8, generator=g)
+    h.backward(go)
+    gin = blk.backward(go.to(device))
+    torch.testing.assert_close(gin.cpu(), xt.grad, atol=1e-5, rtol=1e-4)
