@@ -150,12 +150,17 @@ struct Pass0 {
 
 // cnt[(tile0[s] + t) * 2^RBITS_MAX + d] = number of entries of tile t of segment s whose digit is d (tile-major: a
 // tile's counters are one contiguous, coalesced block for the histogram, the scan and the scatter alike)
+// cnt1 != NULL (pass 0 of a LOOK-BACK sort, see radix_scatter_kernel): the tile's counts of the SECOND digit (bits rbits ..
+// 2 rbits - 1 of the same keys) go to cnt1 as well -- the digit totals of a segment do not depend on the order of its entries,
+// so the scan that follows pass 0's histogram can already produce pass 1's digit bases, and pass 1 needs neither a histogram
+// nor a scan launch of its own.
 template <typename IdT>
 __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const void* keys0, const void* keys1, int pass,
                                                         int shift, int rbits, int* __restrict__ cnt, int fast,
                                                         uint4* __restrict__ clear, int64_t clear_vec,
-                                                        unsigned int* __restrict__ clear_word) {
+                                                        unsigned int* __restrict__ clear_word, int* __restrict__ cnt1) {
     __shared__ int hist[1 << RBITS_MAX];
+    __shared__ int hist1[1 << RBITS_MAX];
     const int s = seg_of_tile(a, blockIdx.x);
     // Pass 0 (every workgroup runs it) also zeroes what the later stages accumulate into -- the carried rows and the piece
     // counter: each workgroup clears its slice with fire-and-forget 16-byte stores before its own loads (a separate fill
@@ -171,7 +176,11 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const
     // input of pass p = output of pass p - 1 (see radix_scatter_kernel for the buffer parity)
     const uint32_t* keys_in = static_cast<const uint32_t*>(((a.npass[s] - pass) & 1) ? keys0 : keys1);
     const int R = 1 << rbits;
-    for (int d = threadIdx.x; d < R; d += 256) hist[d] = 0;
+    const bool dual = cnt1 != nullptr && pass == 0 && a.npass[s] >= 2;  // block-uniform
+    for (int d = threadIdx.x; d < R; d += 256) {
+        hist[d] = 0;
+        if (dual) hist1[d] = 0;
+    }
     const int t = blockIdx.x - a.tile0[s];
     const int64_t seg_base = (int64_t)a.seg_f0[s] * a.B;
     const int64_t n_s = (int64_t)(a.seg_f0[s + 1] - a.seg_f0[s]) * a.B;
@@ -211,21 +220,73 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const
     // (27 vs 20 us on the Criteo tables) -- the ballot loop costs more than the serialised same-address atomics save
 #pragma unroll
     for (int it = 0; it < RITEMS; ++it)
-        if (e0 + it * 64 + lane < n_s) atomicAdd(&hist[(k[it] >> shift) & (uint32_t)(R - 1)], 1);
+        if (e0 + it * 64 + lane < n_s) {
+            atomicAdd(&hist[(k[it] >> shift) & (uint32_t)(R - 1)], 1);
+            if (dual) atomicAdd(&hist1[(k[it] >> (shift + rbits)) & (uint32_t)(R - 1)], 1);
+        }
     __syncthreads();
     int* out = cnt + (int64_t)blockIdx.x * (1 << RBITS_MAX);
     for (int d = threadIdx.x; d < R; d += 256) out[d] = hist[d];
+    if (dual) {
+        int* out1 = cnt1 + (int64_t)blockIdx.x * (1 << RBITS_MAX);
+        for (int d = threadIdx.x; d < R; d += 256) out1[d] = hist1[d];
+    }
 }
 
 // one workgroup per segment: cnt[t][d] := first output slot of (digit d, tile t) inside the segment, i.e. the exclusive
 // prefix in digit-major order.  A thread owns 2 digits: tile totals (coalesced loop over the tiles), block scan over the
 // digits, then the running prefix over the tiles.
+// cnt1 != NULL (pass 0 of a look-back sort): the segment's totals of the SECOND digit, exclusive-scanned over the digits, go to
+// base1[s][d] (first output slot of digit d in pass 1), and the tile flags of the segment are cleared for pass 1's look-back.
 __global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int pass, int rbits, int* __restrict__ cnt,
-                                                         int keep_regs) {
+                                                         int keep_regs, const int* __restrict__ cnt1, int* __restrict__ base1,
+                                                         int* __restrict__ flags) {
     constexpr int RS = 1 << RBITS_MAX;
     __shared__ int wsum[16];
     const int s = blockIdx.x;
     if (pass >= a.npass[s]) return;
+    if (cnt1 != nullptr && pass == 0 && a.npass[s] >= 2) {  // block-uniform
+        __shared__ int wsum1[16];
+        const int R = 1 << rbits;
+        const int nt = a.tile0[s + 1] - a.tile0[s];
+        const int* c1 = cnt1 + (int64_t)a.tile0[s] * RS;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int d0 = 2 * threadIdx.x;
+        const bool on = d0 < R;
+        int t0 = 0, t1 = 0;
+        if (on) {
+            int t = 0;
+            for (; t + 8 <= nt; t += 8) {
+                int2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const int2*>(c1 + (int64_t)(t + u) * RS + d0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    t0 += v[u].x;
+                    t1 += v[u].y;
+                }
+            }
+            for (; t < nt; ++t) {
+                const int2 v = *reinterpret_cast<const int2*>(c1 + (int64_t)t * RS + d0);
+                t0 += v.x;
+                t1 += v.y;
+            }
+        }
+        const int tot = t0 + t1;
+        int x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum1[wave] = x;
+        __syncthreads();
+        int run0 = x - tot;
+        for (int w = 0; w < wave; ++w) run0 += wsum1[w];
+        if (on) *reinterpret_cast<int2*>(base1 + (int64_t)s * RS + d0) = make_int2(run0, run0 + t0);
+        for (int t = threadIdx.x; t < nt; t += 1024) flags[a.tile0[s] + t] = 0;
+        __syncthreads();  // wsum (below) is a different array, but keep the two phases apart for the sake of `on` reuse
+    }
     const int R = 1 << rbits;
     const int nt = a.tile0[s + 1] - a.tile0[s];
     int* c = cnt + (int64_t)a.tile0[s] * RS;
@@ -311,10 +372,17 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(const SortArgs a, int 
 // counters, 16 rounds of 64 consecutive entries per wavefront; inside a round a ballot match gives the lanes that
 // share the digit) + the scanned global offset of (digit, tile).  A segment's LAST pass emits compact keys.  The
 // passes of a segment alternate between the two buffers such that its last pass lands in buffer 1.
+// LOOK-BACK mode (lb_hist != NULL, used for pass 1): there was no histogram / scan launch for this pass.  The tile forms its
+// digit counts itself (it needs them for the ranks anyway: wcnt), publishes them to lb_hist[tile] and raises lb_flags[tile]; the
+// first output slot of (digit, tile) is lb_base[segment][digit] (digit totals of the segment, scanned beside pass 0: they do not
+// depend on the order) + the counts of the EARLIER tiles of the segment, which the tile reads once their flags are up.  A tile
+// only ever waits for tiles with a LOWER workgroup index: the dispatcher hands workgroups out in index order, so whatever a
+// waiting tile needs is already running (or done) -- no deadlock, whatever else shares the chip.
 template <typename IdT, typename KeyT>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, int pass, int shift, int rbits,
                                                            const int* __restrict__ cnt, void* keys0, uint32_t* vals0,
-                                                           void* keys1, uint32_t* vals1, int fast) {
+                                                           void* keys1, uint32_t* vals1, int fast, int* __restrict__ lb_hist,
+                                                           const int* __restrict__ lb_base, int* __restrict__ lb_flags) {
     __shared__ int wcnt[4][1 << RBITS_MAX];
     const int s = seg_of_tile(a, blockIdx.x);
     const int np = a.npass[s];
@@ -400,13 +468,54 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, in
     __syncthreads();
     // wcnt[w][d] := global offset of (d, tile) + entries of waves < w with digit d
     const int* c = cnt + (int64_t)blockIdx.x * (1 << RBITS_MAX);
-    for (int d = threadIdx.x; d < R; d += 256) {
-        int run = c[d];
+    if (lb_hist != nullptr) {  // kernel-uniform: look-back instead of a scanned count
+        constexpr int RS = 1 << RBITS_MAX;
+        int* mine = lb_hist + (int64_t)blockIdx.x * RS;
+        for (int d = threadIdx.x; d < R; d += 256) mine[d] = (wcnt[0][d] + wcnt[1][d]) + (wcnt[2][d] + wcnt[3][d]);
+        __threadfence();   // the counts are visible device-wide before the flag
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&lb_flags[blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int tfirst = a.tile0[s];
+        // every thread waits for the earlier tiles itself (one flag per tile, read past the L1): bounded, so that a broken
+        // launch order ends in wrong output (caught by the tests) instead of a hung GPU
+        for (int tp = tfirst + (int)(threadIdx.x & 63); tp < (int)blockIdx.x; tp += 64) {
+            int spins = 0;
+            while (__hip_atomic_load(&lb_flags[tp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 24))
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        const int* bs = lb_base + (int64_t)s * RS;
+        // plain loads (the acquire above invalidated the L1; a line of lb_hist is only ever read after its tile's flag), eight
+        // in flight per digit: as relaxed ATOMIC loads they were issued one at a time -- 120 dependent L2 round trips per thread,
+        // the whole pass 48 us slower than the three classic launches it replaces
+        const int* hp = lb_hist + (int64_t)tfirst * RS;
+        const int nprev = (int)blockIdx.x - tfirst;
+        for (int d = threadIdx.x; d < R; d += 256) {
+            int run = bs[d];
+            int tp = 0;
+            for (; tp + 8 <= nprev; tp += 8) {
+                int v[8];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int n = wcnt[w][d];
-            wcnt[w][d] = run;
-            run += n;
+                for (int u = 0; u < 8; ++u) v[u] = hp[(int64_t)(tp + u) * RS + d];
+                run += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; tp < nprev; ++tp) run += hp[(int64_t)tp * RS + d];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int n = wcnt[w][d];
+                wcnt[w][d] = run;
+                run += n;
+            }
+        }
+    } else {
+        for (int d = threadIdx.x; d < R; d += 256) {
+            int run = c[d];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int n = wcnt[w][d];
+                wcnt[w][d] = run;
+                run += n;
+            }
         }
     }
     __syncthreads();
@@ -844,7 +953,8 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
 
 struct WsLayout {
     int64_t n, nchunks, max_tiles;
-    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_home, off_pieces, off_counter, off_cnt, total;
+    size_t off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_carry, off_home, off_pieces, off_counter, off_cnt, off_cnt1, off_base1,
+        off_flags, total;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -867,6 +977,10 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->off_pieces = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 16, 256);  // <= one cut per run + per chunk
     L->off_home = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 4, 256);
     L->off_cnt = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << RBITS_MAX) * 4, 256);
+    // look-back sort: second-digit tile counts (then pass 1's published tile counts), per-segment digit bases, tile flags
+    L->off_cnt1 = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << RBITS_MAX) * 4, 256);
+    L->off_base1 = o; o = align_up(o + (size_t)MAX_SEG * ((size_t)1 << RBITS_MAX) * 4, 256);
+    L->off_flags = o; o = align_up(o + (size_t)L->max_tiles * 4, 256);
     L->total = o;
     return true;
 }
@@ -900,17 +1014,35 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     const int ntiles = sa.tile0[sa.nseg];
     constexpr int fast = 1;  // pass 0 reads the id columns from a wave-uniform base (decided in round 2: 396 -> 385 us)
     constexpr int lean = 1;  // pass 0 of the histogram kernel clears the carried rows; the scan keeps tile counts in registers
+    // LOOK-BACK second pass (OPT-IN: MERLIN_HIP_SORT=lookback; asked for by the round-3 review as "3 launches instead of 6"): pass
+    // 0's histogram also counts the second digit, its scan also produces the second pass's digit bases, and the second scatter
+    // finds its tile offsets by looking back at the earlier tiles of its segment -- 4 sort launches instead of 6.  Correct (the
+    // whole sparse-update suite passes with it) and SLOWER, same box, alternating: C2 Adagrad launch 308 -> 342 us, 26 x 1 M rows
+    // 391 -> 445 us; the look-back scatter takes ~67 us against 41 us for the histogram + scan + scatter it replaces.  On this
+    // chip every XCD has its own L2: publishing a tile's counts to the other XCDs needs an agent-scope release (write back the
+    // XCD's dirty L2 lines -- pass 0 has just written 13.6 MB of keys) and reading them an agent-scope acquire (invalidate), and
+    // those cost more than two kernel boundaries, which do the same thing once for everybody.  (Relaxed atomic loads for the
+    // counts were worse still: issued one at a time, 120 dependent round trips per thread.)
+    static const bool classic = [] { const char* e = getenv("MERLIN_HIP_SORT"); return !(e && !strcmp(e, "lookback")); }();
+    const bool lookback = !classic && npass >= 2;
+    int* cnt1 = reinterpret_cast<int*>(ws + L.off_cnt1);
+    int* base1 = reinterpret_cast<int*>(ws + L.off_base1);
+    int* flags = reinterpret_cast<int*>(ws + L.off_flags);
     for (int p = 0; (phases & PH_PREPARE) && p < npass; ++p) {
         const int shift = p * rbits;
         // pass 0 clears the carried rows (not accumulated into in deterministic mode) and the piece counter on the way
         const bool clr = (p == 0) && lean;
-        hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
-                           (const void*)kbuf[1], p, shift, rbits, cnt, fast, reinterpret_cast<uint4*>(carry),
-                           (clr && !det) ? (int64_t)((L.off_counter - L.off_carry) / 16) : (int64_t)0,
-                           clr ? counter : (unsigned int*)nullptr);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt, lean);
+        const bool lb = lookback && p == 1;  // this pass runs as ONE launch
+        if (!lb) {
+            hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
+                               (const void*)kbuf[1], p, shift, rbits, cnt, fast, reinterpret_cast<uint4*>(carry),
+                               (clr && !det) ? (int64_t)((L.off_counter - L.off_carry) / 16) : (int64_t)0,
+                               clr ? counter : (unsigned int*)nullptr, (lookback && p == 0) ? cnt1 : (int*)nullptr);
+            hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt, lean,
+                               (lookback && p == 0) ? (const int*)cnt1 : (const int*)nullptr, base1, flags);
+        }
         hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, p, shift, rbits, cnt,
-                           kbuf[0], vbuf[0], kbuf[1], vbuf[1], fast);
+                           kbuf[0], vbuf[0], kbuf[1], vbuf[1], fast, lb ? cnt1 : (int*)nullptr, (const int*)base1, flags);
     }
     const KeyT* keys = static_cast<const KeyT*>(kbuf[1]);
     const uint32_t* vals = vbuf[1];
