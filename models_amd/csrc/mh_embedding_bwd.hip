@@ -1023,7 +1023,8 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     // XCD's dirty L2 lines -- pass 0 has just written 13.6 MB of keys) and reading them an agent-scope acquire (invalidate), and
     // those cost more than two kernel boundaries, which do the same thing once for everybody.  (Relaxed atomic loads for the
     // counts were worse still: issued one at a time, 120 dependent round trips per thread.)
-    static const bool classic = [] { const char* e = getenv("MERLIN_HIP_SORT"); return !(e && !strcmp(e, "lookback")); }();
+    const char* sort_env = getenv("MERLIN_HIP_SORT");  // read per launch (host-side string test): tests switch it in-process
+    const bool classic = !(sort_env && !strcmp(sort_env, "lookback"));
     const bool lookback = !classic && npass >= 2;
     int* cnt1 = reinterpret_cast<int*>(ws + L.off_cnt1);
     int* base1 = reinterpret_cast<int*>(ws + L.off_base1);
