@@ -677,9 +677,6 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     return buf
 
 
-_DW_EARLY = __import__("os").environ.get("MERLIN_HIP_DW_EARLY", "0") == "1"
-
-
 def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True, x_activation=None,
                     zero_pad: bool = True):
     """Backward of ``linear``: returns (dx | None, dW, db | None).  ``dy`` is overwritten with
@@ -729,12 +726,10 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
                                                  None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
                       "mh_linear_bias_act_bwd")
 
-        if _DW_EARLY:  # experiment switch (MERLIN_HIP_DW_EARLY=1): dW forked BEFORE dX, i.e. the two GEMMs share the matrix pipe
-            run_dw()
-            run_dx()
-        else:
-            run_dx()
-            run_dw()
+        # (round 4 re-measured the alternatives on one box -- dW forked before dX, dW on its own stream, both, three streams: all
+        # 15-25 us slower per step than dX first and dW behind it on the shared side stream: profiles/r4_ab_side_streams.txt)
+        run_dx()
+        run_dw()
         SIDE.maybe_join()
         return dx, dW, db
     ws = _workspace(nbytes, x.device, "linear_bwd")
