@@ -143,17 +143,27 @@ class StepRecorder:
     def wait(self, marker: _Marker) -> None:
         self._cut([marker.seg])
 
-    def enter(self, name: str, after) -> None:
+    def enter(self, name: str, after, kind: str = None) -> None:
         prev = self._close()
         deps = [m.seg for m in after] if after else [prev]
         self._stack.append(name)
+        self._kinds = getattr(self, "_kinds", [])
+        self._kinds.append(kind or name)
         self._open(name, deps)
 
     def leave(self) -> None:
         ended = self._close()
         name = self._stack.pop()
         self._pending[name] = ended
+        self._kind_last = getattr(self, "_kind_last", {})
+        self._kind_last[self._kinds.pop()] = ended   # several kinds may share one logical stream: join_kind waits for ONE of them
         self._open(self._stack[-1], [])
+
+    def join_kind(self, kind: str) -> None:
+        """Main waits for the last block of one KIND of side work only (the stream it shares with other kinds keeps running)."""
+        seg = getattr(self, "_kind_last", {}).get(kind)
+        if seg is not None:
+            self._cut([seg])
 
     def join(self, names=None) -> None:
         names = list(self._pending) if names is None else [n for n in names if n in self._pending]
@@ -192,6 +202,7 @@ class _SideStreams:
         # (sort -> [dW, after dX] -> sparse apply, which needs the sort).  Measured on one box, alternating runs: eager
         # 0.966 -> 0.953 ms, segmented 1.000 -> 0.989 ms; dW alone moved onto the sort stream: +10..20 us.
         # MERLIN_HIP_SIDE_ALIAS=none restores one stream per kind; "dw=sort" style lists are accepted for experiments.
+        self._kind_event = {}
         spec = os.environ.get("MERLIN_HIP_SIDE_ALIAS", "dw=sort,sparse=sort")
         self._alias = dict(kv.split("=") for kv in spec.split(",") if "=" in kv)
 
@@ -230,14 +241,15 @@ class _SideStreams:
             torch.cuda.current_stream().wait_event(marker)
 
     class _On:
-        def __init__(self, owner, name, after, keep):
-            self.owner, self.name, self.after, self.keep = owner, name, after, keep
+        def __init__(self, owner, name, after, keep, kind=None):
+            self.owner, self.name, self.after, self.keep, self.kind = owner, name, after, keep, kind or name
             self._ctx = None
+            self._st = None
 
         def __enter__(self):
             o = self.owner
             if o.recorder is not None:
-                o.recorder.enter(self.name, self.after)
+                o.recorder.enter(self.name, self.after, self.kind)
                 return self
             st = o.stream(self.name)
             if self.after:
@@ -247,20 +259,26 @@ class _SideStreams:
                 st.wait_stream(torch.cuda.current_stream())
             o._pending.add(st)
             o._keep.extend(self.keep)
+            self._st = st
             self._ctx = torch.cuda.stream(st)
             self._ctx.__enter__()
             return self
 
         def __exit__(self, *exc):
             if self._ctx is not None:
-                return self._ctx.__exit__(*exc)
+                r = self._ctx.__exit__(*exc)
+                if self.owner._alias:  # kinds share a stream: remember where THIS kind's work ends on it
+                    ev = torch.cuda.Event()
+                    ev.record(self._st)
+                    self.owner._kind_event[self.kind] = ev
+                return r
             self.owner.recorder.leave()
             return False
 
     def on(self, name: str, after=None, keep=()):
         """Context: the block's launches go to side stream ``name``, ordered after ``after`` (a list of ``mark()``s) or,
         by default, after everything enqueued so far on the current stream."""
-        return _SideStreams._On(self, self._alias.get(name, name), [a for a in (after or []) if a is not None], keep)
+        return _SideStreams._On(self, self._alias.get(name, name), [a for a in (after or []) if a is not None], keep, kind=name)
 
     def retire(self, buf) -> None:
         """A workspace being replaced: keep it alive until the next join if any side stream has work in flight."""
@@ -268,6 +286,7 @@ class _SideStreams:
             self._keep.append(buf)
 
     def join(self) -> None:
+        self._kind_event.clear()
         if self.recorder is not None:
             self.recorder.join()
             return
@@ -279,7 +298,17 @@ class _SideStreams:
         self._keep.clear()
 
     def join_stream(self, name: str) -> None:
-        """The current stream waits for ONE side stream (its kept tensors stay alive until the full join)."""
+        """The current stream waits for ONE kind of side work (its kept tensors stay alive until the full join).  When kinds
+        share a physical stream, only for the end of that kind's last block -- not for what other kinds queued behind it
+        (the optimizer joins "dw" while the sparse apply is running on the same stream)."""
+        if self._alias.get(name, name) != name or name in self._alias.values():
+            if self.recorder is not None:
+                self.recorder.join_kind(name)
+                return
+            ev = self._kind_event.pop(name, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            return
         name = self._alias.get(name, name)
         if self.recorder is not None:
             self.recorder.join([name])
