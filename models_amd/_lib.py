@@ -47,6 +47,8 @@ SIGNATURES = {
     "mh_mlp_chain_fwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "mh_mlp_chain_bwd_workspace_bytes": (_i64, [_i64, _i32, _p]),
     "mh_mlp_chain_bwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_mlp_chain_bwd_partial": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p]),
+    "mh_mlp_chain_bwd_reduce": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
     "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p]),
     "mh_rowwise_dot": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p]),
@@ -90,6 +92,8 @@ SIGNATURES = {
     "mh_log_uniform_sample": (_i32, [_i64, _i64, _i64, _i32, _p, _p, _p, _i64, _p]),
     "mh_bce_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p]),
     "mh_bce_mean_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p, _p]),
+    "mh_bce_mean_partial": (_i32, [_p, _p, _i64, _f32, _p, _p, _p]),
+    "mh_bce_mean_finish": (_i32, [_p, _i64, _p, _p]),
 }
 
 _LIB = None

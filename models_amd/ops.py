@@ -587,6 +587,41 @@ def mlp_chain(x: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[Optional
     return ys
 
 
+# Work whose result nothing on the step's critical path waits for (the slab reduction of a chain backward: dW / db are first read by the
+# optimizer; the final sum of the BCE partials: the scalar is only reported) is collected here while a train step runs and issued at
+# the step's TAIL, on the launch stream, where that stream idles behind the side stream's sparse apply -- not between the kernels of
+# the dependent chain (6 + 5 us there).  Not a side stream: a cross-stream hand-off costs more than these kernels.
+TAIL = [None]   # None: issue immediately; a list: collect (see tail_work / run_tail)
+
+
+class _TailWork:
+    def __enter__(self):
+        self._outer = TAIL[0]
+        TAIL[0] = []
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                run_tail()
+        finally:
+            TAIL[0] = self._outer
+        return False
+
+
+def tail_work():
+    """Context of one train step: ops may park their non-critical second halves; ``run_tail()`` (called by the optimizer in front of
+    the dense update, and at exit) issues them in order."""
+    return _TailWork()
+
+
+def run_tail() -> None:
+    if TAIL[0]:
+        for f in TAIL[0]:
+            f()
+        TAIL[0].clear()
+
+
 def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence[torch.Tensor],
                        activations: Sequence[Optional[str]], grad: torch.Tensor, pre_masked: bool = False,
                        need_dx: bool = True, need_db: Optional[Sequence[bool]] = None, x_activation: Optional[str] = None):
@@ -613,14 +648,23 @@ def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence
     nbytes = lib.mh_mlp_chain_bwd_workspace_bytes(M, L, cdims)
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_mlp_chain_bwd_workspace_bytes: unsupported chain")
-    ws = _workspace(nbytes, x.device, "mlp_chain_bwd")
+    name = "mlp_chain_bwd_" + "x".join(str(d) for d in dims)
+    # a parked slab reduction must not meet another chain's slabs: one workspace per parked position of the step
+    ws = _workspace(nbytes, x.device, name if TAIL[0] is None else f"{name}#{len(TAIL[0])}")
     cW = _host_ptr_array([W.data_ptr() for W in Ws])
     cact = (C.c_int32 * L)(*[ACT[a] for a in activations])
     cy = _host_ptr_array([_rowmajor_2d(y, "y").data_ptr() for y in ys])
     cld = (C.c_int64 * L)(*[y.stride(0) for y in ys])
     cdW = _host_ptr_array([t.data_ptr() for t in dWs])
     cdb = _host_ptr_array([0 if t is None else t.data_ptr() for t in dbs])
-    name = "mlp_chain_bwd_" + "x".join(str(d) for d in dims)
+    if TAIL[0] is not None and not TIMER.enabled:
+        # the strip kernel (dx: what the previous layer's backward waits for) now, the slab reduction (dW / db) at the step's tail
+        check(lib.mh_mlp_chain_bwd_partial(_ptr(x), x.stride(0), M, L, cdims, cW, cact, cy, cld, _ptr(grad), grad.stride(0),
+                                           1 if pre_masked else 0, ACT[x_activation], _ptr(dx), lddx, _ptr(ws), ws.numel(), _stream()),
+              "mh_mlp_chain_bwd_partial")
+        TAIL[0].append(lambda: check(lib.mh_mlp_chain_bwd_reduce(M, L, cdims, cdW, cdb, _ptr(ws), ws.numel(), _stream()),
+                                     "mh_mlp_chain_bwd_reduce"))
+        return dx, dWs, dbs
     with _timed(name, nbytes=4 * M * (sum(dims) + (dims[0] if need_dx else 0) + dims[-1]),
                 flops=(4 * M * sum(dims[i] * dims[i + 1] for i in range(L)))):
         check(lib.mh_mlp_chain_bwd(_ptr(x), x.stride(0), M, L, cdims, cW, cact, cy, cld, _ptr(grad), grad.stride(0),
@@ -1015,6 +1059,10 @@ def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
         mean.fill_(float("nan"))
         return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
     ws = _workspace(1024, p.device, "bce")
+    if TAIL[0] is not None and not TIMER.enabled:
+        check(lib.mh_bce_mean_partial(_ptr(p), _ptr(label), M, 1.0 / M, _ptr(dlogit), _ptr(ws), _stream()), "mh_bce_mean_partial")
+        TAIL[0].append(lambda: check(lib.mh_bce_mean_finish(_ptr(ws), M, _ptr(mean), _stream()), "mh_bce_mean_finish"))
+        return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
     with _timed("bce"):
         check(lib.mh_bce_mean_fwd_bwd(_ptr(p), _ptr(label), M, 1.0 / M, _ptr(mean), _ptr(dlogit), _ptr(ws), _stream()),
               "mh_bce_mean_fwd_bwd")
