@@ -597,7 +597,9 @@ TAIL = [None]   # None: issue immediately; a list: collect (see tail_work / run_
 class _TailWork:
     def __enter__(self):
         self._outer = TAIL[0]
-        TAIL[0] = []
+        import os as _os
+
+        TAIL[0] = [] if _os.environ.get("MERLIN_HIP_TAIL", "1") != "0" else None  # (env: A/B switch of the prepared branch)
         return self
 
     def __exit__(self, *exc):
