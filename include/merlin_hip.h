@@ -239,6 +239,16 @@ int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
                          const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
                          float* const* dW, float* const* db, void* workspace, int64_t workspace_bytes,
                          mh_stream_t stream);
+/* The same backward in two launches: _partial runs the strip kernel (dx -- what the previous layer's backward waits for -- and one
+ * partial dW / db slab per workgroup, left in the workspace); _reduce sums the slabs into dW / db in the fixed order of
+ * mh_mlp_chain_bwd (same bits) and can be issued later on the same stream (the weight gradients are first needed by the optimizer
+ * step: base.py:1164-1174): a step issues it at its tail.  The workspace must not be reused in between. */
+int32_t mh_mlp_chain_bwd_partial(const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
+                                 const float* const* W, const int32_t* act, const float* const* y, const int64_t* ldy,
+                                 const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
+                                 void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_mlp_chain_bwd_reduce(int64_t M, int32_t L, const int32_t* dims, float* const* dW, float* const* db, void* workspace,
+                                int64_t workspace_bytes, mh_stream_t stream);
 
 /* ---- a7: DLRM pairwise dot interaction --------------------------------------------------
  * Replaces tf.matmul(x, x, transpose_b=True) + strict-upper-triangle boolean_mask in
@@ -475,6 +485,13 @@ int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad
  * in a fixed order; workspace: 256 floats.  loss_mean[1]. */
 int32_t mh_bce_mean_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale, float* loss_mean,
                             float* dlogit, float* workspace, mh_stream_t stream);
+/* The two launches of mh_bce_mean_fwd_bwd as separate calls: _partial writes dlogit (what the backward waits for) and one partial
+ * sum per workgroup; _finish adds the partials into loss_mean in the same fixed order (same bits) and can be issued any time later
+ * on the same stream -- the scalar is only reported (`train_step` returns it, models/base.py:1174), so a step issues it at its tail,
+ * where the launch stream idles behind the side stream.  The workspace must not be reused in between. */
+int32_t mh_bce_mean_partial(const float* p, const float* label, int64_t M, float grad_scale, float* dlogit, float* workspace,
+                            mh_stream_t stream);
+int32_t mh_bce_mean_finish(const float* workspace, int64_t M, float* loss_mean, mh_stream_t stream);
 
 /* ---- dense optimizer step for MLP / cross / head weights (models/base.py:1161) -----------
  * SGD: w -= lr*g.  ADAGRAD (keras): state += g^2; w -= lr * g / (sqrt(state) + eps).

@@ -603,17 +603,33 @@ int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad
     return MH_OK;
 }
 
+static int64_t bce_partials(int64_t M) {
+    int64_t nb = mh_ceil_div(M, 256);
+    return nb > 256 ? 256 : nb;
+}
+
+int32_t mh_bce_mean_partial(const float* p, const float* label, int64_t M, float grad_scale, float* dlogit, float* workspace,
+                            mh_stream_t stream) {
+    MH_REQUIRE(p && label && workspace, "mh_bce_mean_partial: null argument");
+    MH_REQUIRE(M >= 1, "mh_bce_mean_partial: empty batch has no mean");
+    hipLaunchKernelGGL(bce_mean_kernel, dim3((unsigned)bce_partials(M)), dim3(256), 0, mh_stream(stream), p, label, M, grad_scale,
+                       workspace, dlogit);
+    MH_CHECK_LAUNCH("mh_bce_mean_partial");
+    return MH_OK;
+}
+
+int32_t mh_bce_mean_finish(const float* workspace, int64_t M, float* loss_mean, mh_stream_t stream) {
+    MH_REQUIRE(workspace && loss_mean && M >= 1, "mh_bce_mean_finish: null argument or empty batch");
+    hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)bce_partials(M), M, loss_mean);
+    MH_CHECK_LAUNCH("mh_bce_mean_finish");
+    return MH_OK;
+}
+
 int32_t mh_bce_mean_fwd_bwd(const float* p, const float* label, int64_t M, float grad_scale, float* loss_mean,
                             float* dlogit, float* workspace, mh_stream_t stream) {
-    MH_REQUIRE(p && label && loss_mean && workspace, "mh_bce_mean_fwd_bwd: null argument");
-    MH_REQUIRE(M >= 1, "mh_bce_mean_fwd_bwd: empty batch has no mean");
-    int64_t nb = mh_ceil_div(M, 256);
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(bce_mean_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), p, label, M, grad_scale,
-                       workspace, dlogit);
-    hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, M, loss_mean);
-    MH_CHECK_LAUNCH("mh_bce_mean_fwd_bwd");
-    return MH_OK;
+    MH_REQUIRE(loss_mean, "mh_bce_mean_fwd_bwd: null argument");
+    const int32_t st = mh_bce_mean_partial(p, label, M, grad_scale, dlogit, workspace, stream);
+    return st != MH_OK ? st : mh_bce_mean_finish(workspace, M, loss_mean, stream);
 }
 
 int32_t mh_activation(int32_t act, const float* x, int64_t ldx, const float* dy, int64_t lddy, float* out, int64_t ldo, int64_t M,

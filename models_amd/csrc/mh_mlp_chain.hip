@@ -780,18 +780,49 @@ int32_t mh_mlp_chain_fwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
     return MH_OK;
 }
 
+// phases: 1 = the strip kernel (dx, one partial dW / db slab per workgroup in the workspace), 2 = the slab reduction (dW, db), 3 = both
+static int32_t chain_bwd_phases(int phases, const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
+                                const float* const* W, const int32_t* act, const float* const* y, const int64_t* ldy,
+                                const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
+                                float* const* dW, float* const* db, void* workspace, int64_t workspace_bytes,
+                                mh_stream_t stream);
+
 int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
                          const float* const* W, const int32_t* act, const float* const* y, const int64_t* ldy,
                          const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
                          float* const* dW, float* const* db, void* workspace, int64_t workspace_bytes,
                          mh_stream_t stream) {
-    MH_REQUIRE(x && dims && W && act && y && ldy && g && dW, "mh_mlp_chain_bwd: null argument");
+    return chain_bwd_phases(3, x, ldx, M, L, dims, W, act, y, ldy, g, ldg, pre_masked, x_act, dx, lddx, dW, db, workspace,
+                            workspace_bytes, stream);
+}
+
+int32_t mh_mlp_chain_bwd_partial(const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
+                                 const float* const* W, const int32_t* act, const float* const* y, const int64_t* ldy,
+                                 const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
+                                 void* workspace, int64_t workspace_bytes, mh_stream_t stream) {
+    return chain_bwd_phases(1, x, ldx, M, L, dims, W, act, y, ldy, g, ldg, pre_masked, x_act, dx, lddx, nullptr, nullptr, workspace,
+                            workspace_bytes, stream);
+}
+
+int32_t mh_mlp_chain_bwd_reduce(int64_t M, int32_t L, const int32_t* dims, float* const* dW, float* const* db, void* workspace,
+                                int64_t workspace_bytes, mh_stream_t stream) {
+    return chain_bwd_phases(2, nullptr, 0, M, L, dims, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, 0, dW, db,
+                            workspace, workspace_bytes, stream);
+}
+
+static int32_t chain_bwd_phases(int phases, const float* x, int64_t ldx, int64_t M, int32_t L, const int32_t* dims,
+                                const float* const* W, const int32_t* act, const float* const* y, const int64_t* ldy,
+                                const float* g, int64_t ldg, int32_t pre_masked, int32_t x_act, float* dx, int64_t lddx,
+                                float* const* dW, float* const* db, void* workspace, int64_t workspace_bytes,
+                                mh_stream_t stream) {
+    const bool do_main = phases & 1, do_red = phases & 2;
+    MH_REQUIRE(dims && (!do_main || (x && W && act && y && ldy && g)) && (!do_red || dW), "mh_mlp_chain_bwd: null argument");
     const SigEntry* sig = find_sig(L, dims);
     if (!sig) {
         mh_set_error("mh_mlp_chain_bwd: no fused kernel covers this chain (L=%d): use mh_linear_bias_act_bwd per layer", L);
         return MH_ERR_UNSUPPORTED;
     }
-    MH_REQUIRE(M >= 1 && ldx >= dims[0] && ldg >= dims[L], "mh_mlp_chain_bwd: bad shape M=%lld", (long long)M);
+    MH_REQUIRE(M >= 1 && (!do_main || (ldx >= dims[0] && ldg >= dims[L])), "mh_mlp_chain_bwd: bad shape M=%lld", (long long)M);
     MH_REQUIRE(x_act >= MH_ACT_NONE && x_act <= MH_ACT_SIGMOID, "mh_mlp_chain_bwd: bad x_act");
     MH_REQUIRE(!dx || lddx >= dims[0], "mh_mlp_chain_bwd: lddx < K");
     const int64_t need = mh_mlp_chain_bwd_workspace_bytes(M, L, dims);
@@ -806,14 +837,19 @@ int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
     for (int l = 0; l <= L; ++l) a.dims[l] = dims[l];
     ReduceArgs r{};
     for (int l = 0; l < L; ++l) {
-        MH_REQUIRE(W[l] && y[l] && dW[l] && ldy[l] >= dims[l + 1], "mh_mlp_chain_bwd: layer %d: null W / y / dW or ldy < N", l);
-        MH_REQUIRE(act[l] >= MH_ACT_NONE && act[l] <= MH_ACT_SIGMOID, "mh_mlp_chain_bwd: bad activation %d", act[l]);
-        a.W[l] = W[l];
-        a.act[l] = act[l];
-        a.y[l] = const_cast<float*>(y[l]);
-        a.ldy[l] = ldy[l];
-        r.dW[l] = dW[l];
-        r.db[l] = db ? db[l] : nullptr;
+        if (do_main) {
+            MH_REQUIRE(W[l] && y[l] && ldy[l] >= dims[l + 1], "mh_mlp_chain_bwd: layer %d: null W / y or ldy < N", l);
+            MH_REQUIRE(act[l] >= MH_ACT_NONE && act[l] <= MH_ACT_SIGMOID, "mh_mlp_chain_bwd: bad activation %d", act[l]);
+            a.W[l] = W[l];
+            a.act[l] = act[l];
+            a.y[l] = const_cast<float*>(y[l]);
+            a.ldy[l] = ldy[l];
+        }
+        if (do_red) {
+            MH_REQUIRE(dW[l], "mh_mlp_chain_bwd: layer %d: null dW", l);
+            r.dW[l] = dW[l];
+            r.db[l] = db ? db[l] : nullptr;
+        }
         r.nw[l] = dims[l] * dims[l + 1];
         r.nb[l] = dims[l + 1];
     }
@@ -835,8 +871,11 @@ int32_t mh_mlp_chain_bwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
     auto kern = dx ? sig->bwd_dx : sig->bwd_nodx;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CW * 64), lds, s, a);
-    MH_CHECK_LAUNCH("mh_mlp_chain_bwd");
+    if (do_main) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(CW * 64), lds, s, a);
+        MH_CHECK_LAUNCH("mh_mlp_chain_bwd");
+    }
+    if (!do_red) return MH_OK;
     r.slabs = a.slabs;
     r.G = grid;
     r.ptotal = a.ptotal;

@@ -1277,6 +1277,7 @@ class DistributedModel:
                 emb._pending, emb._pending_event = None, None
                 emb._apply_sparse_now(opt, *pending)  # sharded: gradient all-to-all started; replicated: into the bucket
             ops.SIDE.join()  # dW / db GEMMs ran on their side stream: the bucket reads them
+        ops.run_tail()  # parked chain slab reductions: the bucket reads their dW / db too (and the BCE sum)
         if dense:
             torch.cat([q.grad.reshape(-1) for q in dense], out=bucket[:n_dense])
         works = allreduce_flat_(bucket, self.group, async_op=True)

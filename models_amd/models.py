@@ -287,6 +287,10 @@ class RankingModel(Model):
         with blocks_tape():
             p = self._predict(x)
         self.optimizer.ensure_begun(p.device)
+        with ops.tail_work():  # second halves nothing on the critical path waits for (BCE partial sum, chain slab reductions) go to the tail
+            return self._train_tail(p, x, targets, fused_head)
+
+    def _train_tail(self, p, x, targets, fused_head):
         loss, dlogit = self.output.loss_and_grad(p, targets)
         div = getattr(self, "loss_grad_divisor", 1)
         if div != 1:  # data parallel: gradients are partial sums of the GLOBAL-mean loss, every reduction a plain SUM

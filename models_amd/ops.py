@@ -143,17 +143,27 @@ class StepRecorder:
     def wait(self, marker: _Marker) -> None:
         self._cut([marker.seg])
 
-    def enter(self, name: str, after) -> None:
+    def enter(self, name: str, after, kind: str = None) -> None:
         prev = self._close()
         deps = [m.seg for m in after] if after else [prev]
         self._stack.append(name)
+        self._kinds = getattr(self, "_kinds", [])
+        self._kinds.append(kind or name)
         self._open(name, deps)
 
     def leave(self) -> None:
         ended = self._close()
         name = self._stack.pop()
         self._pending[name] = ended
+        self._kind_last = getattr(self, "_kind_last", {})
+        self._kind_last[self._kinds.pop()] = ended   # several kinds may share one logical stream: join_kind waits for ONE of them
         self._open(self._stack[-1], [])
+
+    def join_kind(self, kind: str) -> None:
+        """Main waits for the last block of one KIND of side work only (the stream it shares with other kinds keeps running)."""
+        seg = getattr(self, "_kind_last", {}).get(kind)
+        if seg is not None:
+            self._cut([seg])
 
     def join(self, names=None) -> None:
         names = list(self._pending) if names is None else [n for n in names if n in self._pending]
@@ -192,6 +202,7 @@ class _SideStreams:
         # (sort -> [dW, after dX] -> sparse apply, which needs the sort).  Measured on one box, alternating runs: eager
         # 0.966 -> 0.953 ms, segmented 1.000 -> 0.989 ms; dW alone moved onto the sort stream: +10..20 us.
         # MERLIN_HIP_SIDE_ALIAS=none restores one stream per kind; "dw=sort" style lists are accepted for experiments.
+        self._kind_event = {}
         spec = os.environ.get("MERLIN_HIP_SIDE_ALIAS", "dw=sort,sparse=sort")
         self._alias = dict(kv.split("=") for kv in spec.split(",") if "=" in kv)
 
@@ -230,14 +241,15 @@ class _SideStreams:
             torch.cuda.current_stream().wait_event(marker)
 
     class _On:
-        def __init__(self, owner, name, after, keep):
-            self.owner, self.name, self.after, self.keep = owner, name, after, keep
+        def __init__(self, owner, name, after, keep, kind=None):
+            self.owner, self.name, self.after, self.keep, self.kind = owner, name, after, keep, kind or name
             self._ctx = None
+            self._st = None
 
         def __enter__(self):
             o = self.owner
             if o.recorder is not None:
-                o.recorder.enter(self.name, self.after)
+                o.recorder.enter(self.name, self.after, self.kind)
                 return self
             st = o.stream(self.name)
             if self.after:
@@ -247,20 +259,26 @@ class _SideStreams:
                 st.wait_stream(torch.cuda.current_stream())
             o._pending.add(st)
             o._keep.extend(self.keep)
+            self._st = st
             self._ctx = torch.cuda.stream(st)
             self._ctx.__enter__()
             return self
 
         def __exit__(self, *exc):
             if self._ctx is not None:
-                return self._ctx.__exit__(*exc)
+                r = self._ctx.__exit__(*exc)
+                if self.owner._alias:  # kinds share a stream: remember where THIS kind's work ends on it
+                    ev = torch.cuda.Event()
+                    ev.record(self._st)
+                    self.owner._kind_event[self.kind] = ev
+                return r
             self.owner.recorder.leave()
             return False
 
     def on(self, name: str, after=None, keep=()):
         """Context: the block's launches go to side stream ``name``, ordered after ``after`` (a list of ``mark()``s) or,
         by default, after everything enqueued so far on the current stream."""
-        return _SideStreams._On(self, self._alias.get(name, name), [a for a in (after or []) if a is not None], keep)
+        return _SideStreams._On(self, self._alias.get(name, name), [a for a in (after or []) if a is not None], keep, kind=name)
 
     def retire(self, buf) -> None:
         """A workspace being replaced: keep it alive until the next join if any side stream has work in flight."""
@@ -268,6 +286,7 @@ class _SideStreams:
             self._keep.append(buf)
 
     def join(self) -> None:
+        self._kind_event.clear()
         if self.recorder is not None:
             self.recorder.join()
             return
@@ -279,7 +298,17 @@ class _SideStreams:
         self._keep.clear()
 
     def join_stream(self, name: str) -> None:
-        """The current stream waits for ONE side stream (its kept tensors stay alive until the full join)."""
+        """The current stream waits for ONE kind of side work (its kept tensors stay alive until the full join).  When kinds
+        share a physical stream, only for the end of that kind's last block -- not for what other kinds queued behind it
+        (the optimizer joins "dw" while the sparse apply is running on the same stream)."""
+        if self._alias.get(name, name) != name or name in self._alias.values():
+            if self.recorder is not None:
+                self.recorder.join_kind(name)
+                return
+            ev = self._kind_event.pop(name, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            return
         name = self._alias.get(name, name)
         if self.recorder is not None:
             self.recorder.join([name])
@@ -558,6 +587,43 @@ def mlp_chain(x: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[Optional
     return ys
 
 
+# Work whose result nothing on the step's critical path waits for (the slab reduction of a chain backward: dW / db are first read by the
+# optimizer; the final sum of the BCE partials: the scalar is only reported) is collected here while a train step runs and issued at
+# the step's TAIL, on the launch stream, where that stream idles behind the side stream's sparse apply -- not between the kernels of
+# the dependent chain (6 + 5 us there).  Not a side stream: a cross-stream hand-off costs more than these kernels.
+TAIL = [None]   # None: issue immediately; a list: collect (see tail_work / run_tail)
+
+
+class _TailWork:
+    def __enter__(self):
+        self._outer = TAIL[0]
+        import os as _os
+
+        TAIL[0] = [] if _os.environ.get("MERLIN_HIP_TAIL", "1") != "0" else None  # (env: A/B switch of the prepared branch)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                run_tail()
+        finally:
+            TAIL[0] = self._outer
+        return False
+
+
+def tail_work():
+    """Context of one train step: ops may park their non-critical second halves; ``run_tail()`` (called by the optimizer in front of
+    the dense update, and at exit) issues them in order."""
+    return _TailWork()
+
+
+def run_tail() -> None:
+    if TAIL[0]:
+        for f in TAIL[0]:
+            f()
+        TAIL[0].clear()
+
+
 def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence[torch.Tensor],
                        activations: Sequence[Optional[str]], grad: torch.Tensor, pre_masked: bool = False,
                        need_dx: bool = True, need_db: Optional[Sequence[bool]] = None, x_activation: Optional[str] = None):
@@ -584,14 +650,23 @@ def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence
     nbytes = lib.mh_mlp_chain_bwd_workspace_bytes(M, L, cdims)
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_mlp_chain_bwd_workspace_bytes: unsupported chain")
-    ws = _workspace(nbytes, x.device, "mlp_chain_bwd")
+    name = "mlp_chain_bwd_" + "x".join(str(d) for d in dims)
+    # a parked slab reduction must not meet another chain's slabs: one workspace per parked position of the step
+    ws = _workspace(nbytes, x.device, name if TAIL[0] is None else f"{name}#{len(TAIL[0])}")
     cW = _host_ptr_array([W.data_ptr() for W in Ws])
     cact = (C.c_int32 * L)(*[ACT[a] for a in activations])
     cy = _host_ptr_array([_rowmajor_2d(y, "y").data_ptr() for y in ys])
     cld = (C.c_int64 * L)(*[y.stride(0) for y in ys])
     cdW = _host_ptr_array([t.data_ptr() for t in dWs])
     cdb = _host_ptr_array([0 if t is None else t.data_ptr() for t in dbs])
-    name = "mlp_chain_bwd_" + "x".join(str(d) for d in dims)
+    if TAIL[0] is not None and not TIMER.enabled:
+        # the strip kernel (dx: what the previous layer's backward waits for) now, the slab reduction (dW / db) at the step's tail
+        check(lib.mh_mlp_chain_bwd_partial(_ptr(x), x.stride(0), M, L, cdims, cW, cact, cy, cld, _ptr(grad), grad.stride(0),
+                                           1 if pre_masked else 0, ACT[x_activation], _ptr(dx), lddx, _ptr(ws), ws.numel(), _stream()),
+              "mh_mlp_chain_bwd_partial")
+        TAIL[0].append(lambda: check(lib.mh_mlp_chain_bwd_reduce(M, L, cdims, cdW, cdb, _ptr(ws), ws.numel(), _stream()),
+                                     "mh_mlp_chain_bwd_reduce"))
+        return dx, dWs, dbs
     with _timed(name, nbytes=4 * M * (sum(dims) + (dims[0] if need_dx else 0) + dims[-1]),
                 flops=(4 * M * sum(dims[i] * dims[i + 1] for i in range(L)))):
         check(lib.mh_mlp_chain_bwd(_ptr(x), x.stride(0), M, L, cdims, cW, cact, cy, cld, _ptr(grad), grad.stride(0),
@@ -999,6 +1074,10 @@ def bce(p: torch.Tensor, label: torch.Tensor, need_grad: bool = True):
         mean.fill_(float("nan"))
         return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
     ws = _workspace(1024, p.device, "bce")
+    if TAIL[0] is not None and not TIMER.enabled:
+        check(lib.mh_bce_mean_partial(_ptr(p), _ptr(label), M, 1.0 / M, _ptr(dlogit), _ptr(ws), _stream()), "mh_bce_mean_partial")
+        TAIL[0].append(lambda: check(lib.mh_bce_mean_finish(_ptr(ws), M, _ptr(mean), _stream()), "mh_bce_mean_finish"))
+        return mean[0], (None if dlogit is None else dlogit.reshape(-1, 1))
     with _timed("bce"):
         check(lib.mh_bce_mean_fwd_bwd(_ptr(p), _ptr(label), M, 1.0 / M, _ptr(mean), _ptr(dlogit), _ptr(ws), _stream()),
               "mh_bce_mean_fwd_bwd")

@@ -51,6 +51,7 @@ class Optimizer:
             for blk in _walk(model):
                 if hasattr(blk, "apply_sparse"):
                     blk.apply_sparse(self)
+            ops.run_tail()  # parked slab reductions (chain dW / db) and the BCE sum: here the launch stream idles behind the sparse apply
             ops.SIDE.join_stream("dw")  # the dW / db GEMMs of the MLP backward ran on their own stream
             dense = [p for p in params if not p.sparse and p.trainable and p.grad is not None]  # (one walk of the model per step)
             ops.dense_optimizer_step_multi(self, dense)  # one launch for all MLP / cross / head tensors

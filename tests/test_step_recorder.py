@@ -130,3 +130,20 @@ def test_concat_features_takes_the_hip_kernel_only_for_device_columns():
     assert out.shape == (3, 3) and torch.equal(out[:, 0], torch.ones(3)) and torch.equal(out[:, 1:], cols["b"])  # sorted-key order
     with pytest.raises(_lib.MerlinHipError):
         ops.concat_columns([torch.ones(3)])
+
+
+def test_join_of_one_kind_does_not_wait_for_other_kinds_on_the_shared_stream(recorder):
+    """optim.py joins the dW GEMMs before the dense update while the sparse apply is already queued on the same side stream: the
+    edge must point at the dW segment, not at the apply's."""
+    with ops.SIDE.on("dw"):
+        pass
+    with ops.SIDE.on("sparse"):
+        pass
+    ops.SIDE.join_stream("dw")
+    segs_now = len(recorder.segments)
+    dense = recorder.segments[-1]
+    side = [i for i, s in enumerate(recorder.segments) if s["stream"] == "sort"]
+    assert len(side) == 2 and dense["stream"] == "main" and dense["deps"] == [side[0]]
+    ops.SIDE.join()
+    segs = _finish(recorder)
+    assert side[1] in segs[-1]["deps"] and len(segs) > segs_now
