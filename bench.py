@@ -709,7 +709,7 @@ def main():
                     help="BASELINE configs[3] (C4): add one table of this many rows (100000000 = 25.6 GB fp32 at D=64), "
                          "row-sharded over the ranks; the default 0 is the headline config C2")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
-    ap.add_argument("--launch", choices=["auto", "graph", "segmented"], default="auto",
+    ap.add_argument("--launch", choices=["auto", "graph", "segmented", "recorded"], default="auto",
                     help="auto: probe one hipGraph / eager launches with side streams / the segmented replay and time the fastest "
                          "(DLRM train); graph, segmented: time that mode without probing")
     ap.add_argument("--negatives", default="", help="with --workload twotower: comma list of 'queue', 'popularity' -- the negative-sampler "
@@ -824,6 +824,20 @@ def main():
                     step, graphed, best, launch_mode = seg_step, None, ps, "segmented graph replay"
             except Exception as e:  # noqa: BLE001
                 launch_probe["segmented_error"] = f"{type(e).__name__}: {e}"
+            if not sharded:
+                try:  # the launch sequence recorded by the C library itself and replayed by ONE C call per step (graph.RecordedStep)
+                    from models_amd.graph import RecordedStep
+
+                    rec = RecordedStep(eager, batches[0])
+                    rec_step = lambda i: rec.replay(batches[i % nb])
+                    pr = probe(rec_step)
+                    launch_probe["recorded_replay_ms"] = pr
+                    launch_probe["recorded_launches"] = rec.n_launches
+                    launch_probe["recorded_hand_offs"] = rec.n_hand_offs
+                    if pr < best * 0.995:
+                        step, graphed, best, launch_mode = rec_step, None, pr, "recorded launch sequence (C replay)"
+                except Exception as e:  # noqa: BLE001
+                    launch_probe["recorded_error"] = f"{type(e).__name__}: {e}"
         except Exception as e:  # noqa: BLE001 -- the replayed graph stays the timed mode
             launch_probe = {"error": f"{type(e).__name__}: {e}"}
     elif graphed and args.launch == "segmented" and args.mode == "train":
@@ -831,6 +845,11 @@ def main():
 
         seg = SegmentedStep(eager, batches[0])
         step, graphed, launch_mode = (lambda i: seg.replay(batches[i % nb])), None, "segmented graph replay"
+    elif graphed and args.launch == "recorded" and args.mode == "train":
+        from models_amd.graph import RecordedStep
+
+        rec = RecordedStep(eager, batches[0])
+        step, graphed, launch_mode = (lambda i: rec.replay(batches[i % nb])), None, "recorded launch sequence (C replay)"
     dt, _, step_stats = run_steps(step, args, tm, sustain_now=False)  # the sustained region runs LAST (below)
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
     if hasattr(runner, "check_overflow"):

@@ -330,6 +330,12 @@ int32_t mh_l2norm_rows_bwd(const float* x, const float* dy, int64_t M, int32_t N
 int32_t mh_activation(int32_t act, const float* x, int64_t ldx, const float* dy, int64_t lddy, float* out, int64_t ldo,
                       int64_t M, int32_t N, mh_stream_t stream);
 
+/* buf[m, col0 : col0 + ncols] = value for the M rows of a row-major buffer of pitch ld: the pad columns between a row's width
+ * and its 16-byte aligned pitch (the reference has no such op: its tensors are dense, tf.concat at
+ * merlin/models/tf/core/aggregation.py:54-66; the padded pitch is this library's layout).  A library launch rather than a
+ * tensor-library fill so that a recorded step (mh_record_*) holds every launch of the step. */
+int32_t mh_fill_columns(float* buf, int64_t M, int64_t ld, int32_t col0, int32_t ncols, float value, mh_stream_t stream);
+
 /* Mean of n floats into mean[0] (Keras' SUM_OVER_BATCH_SIZE reduction of a per-sample loss, e.g. the softmax-CE rows of
  * the retrieval step, losses/listwise.py:38-52): two launches, fixed summation order (deterministic).  workspace: 256 floats. */
 int32_t mh_mean(const float* x, int64_t n, float* mean, float* workspace, mh_stream_t stream);
@@ -591,6 +597,24 @@ int32_t mh_sharded_lookup_bwd(mh_comm_t comm, int32_t F, int64_t B, int64_t capa
                               float* local_shards, float* state, float* state2, int64_t local_rows_total,
                               int32_t optimizer, float lr, float eps, float beta1, float beta2, const float* lr_device,
                               void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+
+/* ---- launch recorder: a train step traced once, replayed without re-entering the host language ----------------------------
+ * Replaces the role of Keras' traced `train_function` (BaseModel.fit -> make_train_function, models/base.py:1361-1421): between
+ * mh_record_begin and mh_record_end every kernel launch of this library is executed AND kept (kernel, geometry, stream, arguments by
+ * value), together with the event hand-offs between streams the host issues through mh_record_event / mh_record_wait_event;
+ * mh_record_replay re-issues the sequence in order on the same streams.  Contract of a replayed step = contract of a captured
+ * graph: fixed shapes, every buffer the launches address stays alive and in place (the host mirror stages each batch into static
+ * inputs and keeps the step's intermediates allocated).  Unlike a hipGraph the replay keeps the step's multi-stream overlap, and
+ * unlike per-stream graph segments it pays no graph-launch latency: a few microseconds of host time per launch.
+ * One recording at a time per process; the host side must be single-threaded while a recording is open. */
+int32_t mh_record_begin(void);
+int32_t mh_record_end(void** handle_out);
+int32_t mh_record_abort(void);
+int32_t mh_record_event(mh_stream_t stream, int64_t* event_id_out);   /* record an event on `stream` (recording only) */
+int32_t mh_record_wait_event(mh_stream_t stream, int64_t event_id);   /* `stream` waits for that event */
+int32_t mh_record_replay(void* handle);
+int32_t mh_record_info(void* handle, int64_t* launches, int64_t* hand_offs);
+int32_t mh_record_free(void* handle);
 
 #ifdef __cplusplus
 }

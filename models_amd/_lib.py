@@ -51,8 +51,6 @@ SIGNATURES = {
     "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "mh_mlp_chain_bwd_partial": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "mh_mlp_chain_bwd_reduce": (_i32, [_i64, _i32, _p, _p, _p, _p, _i64, _p]),
-    "mh_dot_interaction_fwd": (_i32, [_p, _i64, _i32, _i32, _p, _i64, _i32, _p, _i64, _p]),
-    "mh_dot_interaction_bwd": (_i32, [_p, _p, _i64, _i64, _i32, _i32, _p, _i32, _i32, _p]),
     "mh_rowwise_dot": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _p, _p]),
     "mh_dense_optimizer_step_multi": (_i32, [_p, _p, _p, _p, _i32, _i32, _f32, _f32, _p, _f32, _f32, _p, _p]),
     "mh_eltwise": (_i32, [_i32, _p, _p, _p, _p, _i64, _p]),
@@ -96,7 +94,16 @@ SIGNATURES = {
     "mh_bce_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p]),
     "mh_bce_mean_fwd_bwd": (_i32, [_p, _p, _i64, _f32, _p, _p, _p, _p]),
     "mh_mean": (_i32, [_p, _i64, _p, _p, _p]),
+    "mh_record_begin": (_i32, []),
+    "mh_record_end": (_i32, [C.POINTER(_p)]),
+    "mh_record_abort": (_i32, []),
+    "mh_record_event": (_i32, [_p, C.POINTER(_i64)]),
+    "mh_record_wait_event": (_i32, [_p, _i64]),
+    "mh_record_replay": (_i32, [_p]),
+    "mh_record_info": (_i32, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mh_record_free": (_i32, [_p]),
     "mh_activation": (_i32, [_i32, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _p]),
+    "mh_fill_columns": (_i32, [_p, _i64, _i64, _i32, _i32, _f32, _p]),
     "mh_bce_mean_partial": (_i32, [_p, _p, _i64, _f32, _p, _p, _p]),
     "mh_bce_mean_finish": (_i32, [_p, _i64, _p, _p]),
 }

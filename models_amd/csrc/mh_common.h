@@ -30,6 +30,33 @@ void mh_set_error(const char* fmt, ...);
 
 static inline hipStream_t mh_stream(mh_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- launch recorder (mh_record.hip) ------------------------------------------------------------------------------------
+// Every kernel launch of the library goes through MH_LAUNCH.  While a recording is open (mh_record_begin .. mh_record_end) the
+// launch is ALSO kept -- kernel, geometry, stream and a by-value copy of its arguments -- and mh_record_replay re-issues the whole
+// sequence, in order, on the streams it was issued on, with the recorded event hand-offs in between: the launch sequence of a train
+// step replayed from C at a few microseconds of host time per launch, with the multi-stream overlap of the eager step (a hipGraph
+// of the same step replays on ONE hardware queue under ROCm 7).  Same contract as graph capture: fixed shapes, persistent buffers.
+#include <functional>
+#ifdef MH_STANDALONE  // tools/exp labs that include the GEMM headers without linking the library
+static inline bool mh_recording() { return false; }
+static inline void mh_record_op(std::function<void()>&&) {}
+#else
+bool mh_recording();
+void mh_record_op(std::function<void()>&& op);
+#endif
+
+#define MH_LAUNCH(kern, grid, block, lds, stream, ...)                                                     \
+    do {                                                                                                   \
+        if (mh_recording()) {                                                                              \
+            auto mh_k_ = kern;                                                                             \
+            const dim3 mh_g_ = (grid), mh_b_ = (block);                                                    \
+            const size_t mh_l_ = (size_t)(lds);                                                            \
+            hipStream_t mh_s_ = (stream);                                                                  \
+            mh_record_op([=]() { hipLaunchKernelGGL(mh_k_, mh_g_, mh_b_, mh_l_, mh_s_, __VA_ARGS__); });   \
+        }                                                                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                   \
+    } while (0)
+
 static inline int64_t mh_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Fill of `words` 32-bit words as a KERNEL on the stream (mh_misc.hip).  hipMemsetAsync is not used anywhere in the library:

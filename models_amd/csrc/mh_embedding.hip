@@ -178,13 +178,13 @@ int launch_bag(const float* table, int64_t rows, const void* values, const void*
     const bool coop = pow2 && LPR <= 32 && nnz_hint >= 8 * B;
     if (coop) {
         dim3 grid((unsigned)mh_ceil_div(B, 4));
-        hipLaunchKernelGGL((bag_fwd_kernel<IdT, true>), grid, dim3(256), 0, s, table, rows,
+        MH_LAUNCH((bag_fwd_kernel<IdT, true>), grid, dim3(256), 0, s, table, rows,
                            (const IdT*)values, (const IdT*)offsets, L, B, LPR, combiner, out,
                            out_row_stride);
     } else {
         const int groups = 256 / LPR;
         dim3 grid((unsigned)mh_ceil_div(B, groups));
-        hipLaunchKernelGGL((bag_fwd_kernel<IdT, false>), grid, dim3(256), 0, s, table, rows,
+        MH_LAUNCH((bag_fwd_kernel<IdT, false>), grid, dim3(256), 0, s, table, rows,
                            (const IdT*)values, (const IdT*)offsets, L, B, LPR, combiner, out,
                            out_row_stride);
     }
@@ -225,9 +225,9 @@ int32_t mh_embedding_gather_fwd(const float* const* tables, const int64_t* table
     dim3 grid((unsigned)mh_ceil_div(B, rows_per_block), (unsigned)F);
     hipStream_t s = mh_stream(stream);
     if (ids_dtype == MH_I32)
-        hipLaunchKernelGGL((gather_fwd_kernel<int32_t, R>), grid, dim3(256), 0, s, a, B, LPR, out, out_row_stride);
+        MH_LAUNCH((gather_fwd_kernel<int32_t, R>), grid, dim3(256), 0, s, a, B, LPR, out, out_row_stride);
     else
-        hipLaunchKernelGGL((gather_fwd_kernel<int64_t, R>), grid, dim3(256), 0, s, a, B, LPR, out, out_row_stride);
+        MH_LAUNCH((gather_fwd_kernel<int64_t, R>), grid, dim3(256), 0, s, a, B, LPR, out, out_row_stride);
     MH_CHECK_LAUNCH("mh_embedding_gather_fwd");
     return MH_OK;
 }

@@ -1035,14 +1035,14 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         const bool clr = (p == 0) && lean;
         const bool lb = lookback && p == 1;  // this pass runs as ONE launch
         if (!lb) {
-            hipLaunchKernelGGL((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
+            MH_LAUNCH((radix_hist_kernel<IdT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, (const void*)kbuf[0],
                                (const void*)kbuf[1], p, shift, rbits, cnt, fast, reinterpret_cast<uint4*>(carry),
                                (clr && !det) ? (int64_t)((L.off_counter - L.off_carry) / 16) : (int64_t)0,
                                clr ? counter : (unsigned int*)nullptr, (lookback && p == 0) ? cnt1 : (int*)nullptr);
-            hipLaunchKernelGGL(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt, lean,
+            MH_LAUNCH(radix_scan_kernel, dim3((unsigned)sa.nseg), dim3(1024), 0, s, sa, p, rbits, cnt, lean,
                                (lookback && p == 0) ? (const int*)cnt1 : (const int*)nullptr, base1, flags);
         }
-        hipLaunchKernelGGL((radix_scatter_kernel<IdT, KeyT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, p, shift, rbits, cnt,
+        MH_LAUNCH((radix_scatter_kernel<IdT, KeyT>), dim3((unsigned)ntiles), dim3(256), 0, s, sa, p, shift, rbits, cnt,
                            kbuf[0], vbuf[0], kbuf[1], vbuf[1], fast, lb ? cnt1 : (int*)nullptr, (const int*)base1, flags);
     }
     const KeyT* keys = static_cast<const KeyT*>(kbuf[1]);
@@ -1057,7 +1057,7 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     const int LPR = D / 4;
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     if (phases & PH_PREPARE)
-        hipLaunchKernelGGL((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
+        MH_LAUNCH((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
                            keys, vals, L.n, pieces, home, counter);
     if (!(phases & PH_APPLY)) {
         MH_CHECK_LAUNCH("mh_embedding_gather_bwd_prepare");
@@ -1077,10 +1077,10 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         }
         const int64_t cap = (int64_t)mh_num_cus() * resident[vmode];
         if (nb > cap) nb = cap;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad, grad_row_stride, carry, home,
+        MH_LAUNCH(kern, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad, grad_row_stride, carry, home,
                            pieces, counter, optimizer, hp, det);
     }
-    hipLaunchKernelGGL((carry_apply_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, groups)), dim3(256), 0, s, a, keys,
+    MH_LAUNCH((carry_apply_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, groups)), dim3(256), 0, s, a, keys,
                        vals, L.n, D, LPR, carry, optimizer, hp, grad, grad_row_stride, det);
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;
@@ -1377,20 +1377,20 @@ int32_t mh_embedding_bag_expand(const float* table, int64_t rows, const void* va
     float* scale = scale_ws;
     if (combiner == MH_COMBINER_MAX) {
         if (ids_dtype == MH_I32)
-            hipLaunchKernelGGL((bag_expand_max_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
+            MH_LAUNCH((bag_expand_max_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
                                (const int32_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
         else
-            hipLaunchKernelGGL((bag_expand_max_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
+            MH_LAUNCH((bag_expand_max_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, table, rows,
                                (const int64_t*)values, L, B, LPR, grad, grad_row_stride, gexp);
     } else if (ids_dtype == MH_I32) {
-        hipLaunchKernelGGL((bag_scale_kernel<int32_t>), gs, dim3(256), 0, s, (const int32_t*)values,
+        MH_LAUNCH((bag_scale_kernel<int32_t>), gs, dim3(256), 0, s, (const int32_t*)values,
                            (const int32_t*)offsets, L, B, combiner, scale);
-        hipLaunchKernelGGL((bag_expand_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int32_t*)offsets, L,
+        MH_LAUNCH((bag_expand_kernel<int32_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int32_t*)offsets, L,
                            B, nnz, LPR, scale, grad, grad_row_stride, gexp);
     } else {
-        hipLaunchKernelGGL((bag_scale_kernel<int64_t>), gs, dim3(256), 0, s, (const int64_t*)values,
+        MH_LAUNCH((bag_scale_kernel<int64_t>), gs, dim3(256), 0, s, (const int64_t*)values,
                            (const int64_t*)offsets, L, B, combiner, scale);
-        hipLaunchKernelGGL((bag_expand_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int64_t*)offsets, L,
+        MH_LAUNCH((bag_expand_kernel<int64_t>), dim3((unsigned)nb), dim3(256), 0, s, (const int64_t*)offsets, L,
                            B, nnz, LPR, scale, grad, grad_row_stride, gexp);
     }
     MH_CHECK_LAUNCH("mh_embedding_bag_expand");

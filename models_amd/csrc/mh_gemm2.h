@@ -254,7 +254,7 @@ inline hipError_t launch(const float* A, int64_t lda, const float* B, int64_t ld
     }
     const int ncol = (int)((N + BN - 1) / BN);
     const int64_t nrow = (M + BM - 1) / BM;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nrow * ncol)), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, M, N, K, C, ldc, ep, ncol);
+    MH_LAUNCH(kern, dim3((unsigned)(nrow * ncol)), dim3(WM * WN * 64), lds, s, A, lda, B, ldb, M, N, K, C, ldc, ep, ncol);
     return hipGetLastError();
 }
 
@@ -428,7 +428,7 @@ inline hipError_t launch_tn(const float* X, int64_t ldx, const float* Z, int64_t
         attr_done = true;
     }
     dim3 grid((unsigned)((K + BMO - 1) / BMO), (unsigned)((N + BNO - 1) / BNO), (unsigned)splits);
-    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, X, ldx, Z, ldz, M, K, N, rows_per_split, part, db_part);
+    MH_LAUNCH(kern, grid, dim3(WM * WN * 64), lds, s, X, ldx, Z, ldz, M, K, N, rows_per_split, part, db_part);
     return hipGetLastError();
 }
 

@@ -862,9 +862,9 @@ int32_t mh_dot_interaction_fwd(const float* x, int64_t B, int32_t F, int32_t D, 
                             P + T <= F * (D + 4);
         auto kern = staged ? dot_interaction_fwd_pipe_kernel<8, true> : dot_interaction_fwd_pipe_kernel<8, false>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, mh_stream(stream), x, B, F, D, tail, ld_tail, T, tail_first, out, ldo);
+        MH_LAUNCH(kern, grid, dim3(256), lds, mh_stream(stream), x, B, F, D, tail, ld_tail, T, tail_first, out, ldo);
     } else {
-        hipLaunchKernelGGL(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
+        MH_LAUNCH(dot_interaction_fwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, B, F, D,
                            tail, ld_tail, T, tail_first, out, ldo);
     }
     MH_CHECK_LAUNCH("mh_dot_interaction_fwd");
@@ -902,7 +902,7 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
     {                                                                                                            \
         auto kern = dot_interaction_bwd_pipe_kernel<DT, 8>;                                                      \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, x, dout, ldo, B, F, dx, tail_slot, T, tail_first);    \
+        MH_LAUNCH(kern, grid, dim3(256), lds, s_, x, dout, ldo, B, F, dx, tail_slot, T, tail_first);    \
     }
         if (D == 16) MH_LAUNCH_BWD_PIPE(1)
         else if (D == 32) MH_LAUNCH_BWD_PIPE(2)
@@ -910,7 +910,7 @@ int32_t mh_dot_interaction_bwd(const float* x, const float* dout, int64_t ldo, i
         else MH_LAUNCH_BWD_PIPE(8)
 #undef MH_LAUNCH_BWD_PIPE
     } else {
-        hipLaunchKernelGGL(dot_interaction_bwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, dout, ldo, B, F, D,
+        MH_LAUNCH(dot_interaction_bwd_kernel, grid, dim3(256), lds, mh_stream(stream), x, dout, ldo, B, F, D,
                            dx, tail_slot, T, tail_first);
     }
     MH_CHECK_LAUNCH("mh_dot_interaction_bwd");
@@ -982,7 +982,7 @@ int32_t mh_dlrm_interaction_fused_fwd(const float* const* slot_tables, const int
     {                                                                                                            \
         auto kern = staged ? dlrm_fused_fwd_kernel<IDT, DT, 8, true> : dlrm_fused_fwd_kernel<IDT, DT, 8, false>; \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, append_dense, tail_first ? 1 : 0, out, ldo); \
+        MH_LAUNCH(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dense_slot, B, F, append_dense, tail_first ? 1 : 0, out, ldo); \
     }
     if (ids_dtype == MH_I32) {
         if (D == 16) MH_LAUNCH_FUSED_FWD(int32_t, 1)
@@ -1029,7 +1029,7 @@ int32_t mh_dlrm_interaction_fused_bwd(const float* const* slot_tables, const int
     {                                                                                                            \
         auto kern = dlrm_fused_bwd_kernel<IDT, DT, 8>;                                                           \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dout, ldo, B, F, dx, tail_slot, T, tail_first ? 1 : 0); \
+        MH_LAUNCH(kern, grid, dim3(256), lds, s_, a, dense, ld_dense, dout, ldo, B, F, dx, tail_slot, T, tail_first ? 1 : 0); \
     }
     if (ids_dtype == MH_I32) {
         if (D == 16) MH_LAUNCH_FUSED_BWD(int32_t, 1)

@@ -134,7 +134,7 @@ int32_t mh_linear_bias_act_fwd(const float* x, int64_t ldx, const float* W, cons
     hipStream_t s = mh_stream(stream);
     if (N <= 4) {
         dim3 grid((unsigned)mh_ceil_div(M, 16));
-        hipLaunchKernelGGL((linear_small_n_kernel<4>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy);
+        MH_LAUNCH((linear_small_n_kernel<4>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy);
         MH_CHECK_LAUNCH("mh_linear_bias_act_fwd");
         return MH_OK;
     }
@@ -202,13 +202,13 @@ int32_t mh_internal_linear(const float* x, int64_t ldx, const float* W, const fl
     if (mh_internal_linear_v2(x, ldx, W, b, M, K, N, act, y, ldy, x0, xres, nullptr, s)) return MH_OK;
     if (N > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(N, 128));
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
+        MH_LAUNCH((linear_fwd_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     } else if (N > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
+        MH_LAUNCH((linear_fwd_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     } else {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((linear_fwd_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
+        MH_LAUNCH((linear_fwd_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, x, ldx, W, b, M, K, N, act, y, ldy, vec_x, vec_w, x0, xres);
     }
     MH_CHECK_LAUNCH("mh_linear_bias_act_fwd");
     return MH_OK;

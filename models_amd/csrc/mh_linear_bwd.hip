@@ -546,19 +546,19 @@ int32_t mh_internal_gemm_nt_ep(const float* A, int64_t lda, const float* Bm, int
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)mh_ceil_div(M, 256)), dim3(512), lds, s, A, lda, Bm, ldb, M, Nout, Cm, ldc);
+        MH_LAUNCH(kern, dim3((unsigned)mh_ceil_div(M, 256)), dim3(512), lds, s, A, lda, Bm, ldb, M, Nout, Cm, ldc);
         MH_CHECK_LAUNCH("gemm_nt(astat)");
         return MH_OK;
     }
     if (Nout > 64) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), (unsigned)mh_ceil_div(Nout, 128));
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
+        MH_LAUNCH((gemm_nt_kernel<128, 128, 4, 2>), grid, dim3(512), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
     } else if (Nout > 32) {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
+        MH_LAUNCH((gemm_nt_kernel<128, 64, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
     } else {
         dim3 grid((unsigned)mh_ceil_div(M, 128), 1);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
+        MH_LAUNCH((gemm_nt_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, A, lda, Bm, ldb, M, Nout, Kc, Cm, ldc, vec_a, vec_b, maskx, ldm, x_act, addend, ld_add);
     }
     MH_CHECK_LAUNCH("gemm_nt");
     return MH_OK;
@@ -570,7 +570,7 @@ int32_t mh_internal_gemm_tn(const float* X, int64_t ldx, const float* Z, int64_t
     const int vec_z = ((reinterpret_cast<uintptr_t>(Z) & 15) == 0) && (ldz % 4 == 0);
     const int64_t rps = mh_ceil_div(M, BK) * BK;
     dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), 1);
-    hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, X, ldx, Z, ldz, M, K, N, rps, out, vec_x, vec_z, (float*)nullptr);
+    MH_LAUNCH((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, X, ldx, Z, ldz, M, K, N, rps, out, vec_x, vec_z, (float*)nullptr);
     MH_CHECK_LAUNCH("gemm_tn");
     return MH_OK;
 }
@@ -608,10 +608,10 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
             int64_t nb = mh_ceil_div(M * (N / 4), 256);
             const int64_t cap = (int64_t)mh_num_cus() * 16;
             if (nb > cap) nb = cap;
-            hipLaunchKernelGGL(act_grad_vec_kernel, dim3((unsigned)nb), dim3(256), 0, s, y, ldy, dy, lddy, M, N / 4, act);
+            MH_LAUNCH(act_grad_vec_kernel, dim3((unsigned)nb), dim3(256), 0, s, y, ldy, dy, lddy, M, N / 4, act);
         } else {
             const int CW = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
-            hipLaunchKernelGGL(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
+            MH_LAUNCH(act_grad_colsum_kernel, dim3(p.act_blocks), dim3(256), 0, s, y, ldy, dy, lddy, M, N,
                                act, CW, (float*)nullptr);
         }
     }
@@ -637,11 +637,11 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
             }
         } else if (big_tiles(K, N)) {
             dim3 grid((unsigned)mh_ceil_div(K, 128), (unsigned)mh_ceil_div(N, 128), (unsigned)p.splits);
-            hipLaunchKernelGGL((gemm_tn_splitm_kernel<128, 128>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
+            MH_LAUNCH((gemm_tn_splitm_kernel<128, 128>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
                                p.rows_per_split, out_dw, vec_x, vec_dy, db ? out_db : nullptr);
         } else {
             dim3 grid((unsigned)mh_ceil_div(K, 64), (unsigned)mh_ceil_div(N, 64), (unsigned)p.splits);
-            hipLaunchKernelGGL((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
+            MH_LAUNCH((gemm_tn_splitm_kernel<64, 64>), grid, dim3(256), 0, s, x, ldx, dy, lddy, M, K, N,
                                p.rows_per_split, out_dw, vec_x, vec_dy, db ? out_db : nullptr);
         }
         const int64_t len = (int64_t)K * N;
@@ -649,14 +649,14 @@ int32_t mh_linear_bias_act_bwd(const float* x, int64_t ldx, const float* W, cons
             // nothing to reduce
         } else if (p.splits <= 8 && len % 4 == 0 && len >= (1 << 16) && (reinterpret_cast<uintptr_t>(dW) & 15) == 0) {
             // few slabs of a long vector (wide layers): float4 per thread; db (N floats x S slabs) keeps the small general kernel
-            hipLaunchKernelGGL(reduce_slabs_vec_kernel, dim3((unsigned)mh_ceil_div(len / 4, 256)), dim3(256), 0, s, ws_dw, p.splits,
+            MH_LAUNCH(reduce_slabs_vec_kernel, dim3((unsigned)mh_ceil_div(len / 4, 256)), dim3(256), 0, s, ws_dw, p.splits,
                                len / 4, dW);
             if (db)
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(1024), 0, s, ws_db, p.splits,
+                MH_LAUNCH(reduce_partials_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(1024), 0, s, ws_db, p.splits,
                                    (int64_t)N, db, (const float*)nullptr, (int64_t)0, (float*)nullptr, (int)mh_ceil_div(N, 64));
         } else {
             const int b1 = (int)mh_ceil_div(len, 64), b2 = db ? (int)mh_ceil_div(N, 64) : 0;
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(b1 + b2)), dim3(1024), 0, s, ws_dw, p.splits, len, dW,
+            MH_LAUNCH(reduce_partials_kernel, dim3((unsigned)(b1 + b2)), dim3(1024), 0, s, ws_dw, p.splits, len, dW,
                                ws_db, (int64_t)N, db, b1);  // dW and db slabs in ONE launch
         }
     }
@@ -705,7 +705,7 @@ int32_t mh_cross_layer_bwd(const float* x0, const float* x, const float* p, cons
         MH_REQUIRE(((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(dx0_acc)) & 15) == 0,
                    "mh_cross_layer_bwd: operands must be 16-byte aligned");
         const int64_t n4 = M * (int64_t)(d / 4);
-        hipLaunchKernelGGL(cross_bwd_pre_kernel, dim3((unsigned)mh_ceil_div(n4, 256)), dim3(256), 0, s,
+        MH_LAUNCH(cross_bwd_pre_kernel, dim3((unsigned)mh_ceil_div(n4, 256)), dim3(256), 0, s,
                            reinterpret_cast<const f32x4*>(dout), reinterpret_cast<const f32x4*>(x0),
                            reinterpret_cast<const f32x4*>(p), reinterpret_cast<f32x4*>(g), reinterpret_cast<f32x4*>(dx0_acc),
                            accumulate_dx0 ? 1 : 0, n4);

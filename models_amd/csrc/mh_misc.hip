@@ -341,7 +341,7 @@ int32_t mh_fill_words(void* dst, uint32_t value, int64_t words, hipStream_t s) {
     int64_t nb = mh_ceil_div(words, 256 * 4);
     const int64_t cap = (int64_t)mh_num_cus() * 8;
     if (nb > cap) nb = cap;
-    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)nb), dim3(256), 0, s, static_cast<uint32_t*>(dst), value, words);
+    MH_LAUNCH(fill_words_kernel, dim3((unsigned)nb), dim3(256), 0, s, static_cast<uint32_t*>(dst), value, words);
     MH_CHECK_LAUNCH("mh_fill_words");
     return MH_OK;
 }
@@ -462,7 +462,7 @@ int32_t mh_copy_many(const void* const* src, void* const* dst, const int64_t* by
         if (big == 0) continue;
         int64_t gx = mh_ceil_div(big, 256 * 16);  // 16 words (64 bytes) per thread of the largest buffer
         if (gx > 64) gx = 64;
-        hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, a);
+        MH_LAUNCH(copy_many_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, a);
     }
     MH_CHECK_LAUNCH("mh_copy_many");
     return MH_OK;
@@ -499,7 +499,7 @@ int32_t mh_concat_columns(const float* const* src, const int64_t* ld, const int3
     const size_t lds = (size_t)256 * (Wp + 1) * sizeof(float);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(concat_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(concat_columns_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), lds, mh_stream(stream), a, B, out, ldo);
+    MH_LAUNCH(concat_columns_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), lds, mh_stream(stream), a, B, out, ldo);
     MH_CHECK_LAUNCH("mh_concat_columns");
     return MH_OK;
 }
@@ -511,7 +511,7 @@ int32_t mh_stream_copy(const void* src, void* dst, int64_t bytes, mh_stream_t st
     const int64_t n4 = bytes / 16;
     const int64_t nb = mh_ceil_div(n4, 256);
     MH_REQUIRE(nb < (1ll << 31), "mh_stream_copy: at most 2^31 workgroups of 4 KB");
-    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), static_cast<const f32x4*>(src),
+    MH_LAUNCH(stream_copy_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), static_cast<const f32x4*>(src),
                        static_cast<f32x4*>(dst), n4);
     MH_CHECK_LAUNCH("mh_stream_copy");
     return MH_OK;
@@ -524,9 +524,9 @@ int32_t mh_l2_batch_reg(const float* out, int64_t ld_out, float* grad, int64_t l
     if (B <= 0) return MH_OK;
     int64_t nb = mh_ceil_div(B * (D / 4), 256);
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(l2_batch_reg_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), out, ld_out, grad, ld_grad, B,
+    MH_LAUNCH(l2_batch_reg_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), out, ld_out, grad, ld_grad, B,
                        D / 4, factor, workspace);
-    hipLaunchKernelGGL(l2_batch_reg_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, factor, loss_accum);
+    MH_LAUNCH(l2_batch_reg_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, factor, loss_accum);
     MH_CHECK_LAUNCH("mh_l2_batch_reg");
     return MH_OK;
 }
@@ -554,7 +554,7 @@ int32_t mh_dense_optimizer_step_multi(float* const* w, const float* const* grad,
     int64_t bx = mh_ceil_div(nmax, 256);
     if (bx > 1024) bx = 1024;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(dense_opt_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, mh_stream(stream), a,
+    MH_LAUNCH(dense_opt_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, mh_stream(stream), a,
                        optimizer, lr, eps, beta1, beta2, lr_device);
     MH_CHECK_LAUNCH("mh_dense_optimizer_step_multi");
     return MH_OK;
@@ -564,7 +564,7 @@ int32_t mh_topk_metrics(const float* labels_sorted, int64_t ld, const float* rel
                         float* out, mh_stream_t stream) {
     MH_REQUIRE(labels_sorted && out && k >= 1 && ld >= k, "mh_topk_metrics: bad argument");
     if (B <= 0) return MH_OK;
-    hipLaunchKernelGGL(topk_metrics_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, mh_stream(stream),
+    MH_LAUNCH(topk_metrics_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, mh_stream(stream),
                        labels_sorted, ld, relevant_counts, B, k, out);
     MH_CHECK_LAUNCH("mh_topk_metrics");
     return MH_OK;
@@ -582,11 +582,11 @@ int32_t mh_eltwise(int32_t op, const float* a, const float* b, const float* c, f
         const f32x4 *a4 = reinterpret_cast<const f32x4*>(a), *b4 = reinterpret_cast<const f32x4*>(b),
                     *c4 = reinterpret_cast<const f32x4*>(c);
         f32x4* o4 = reinterpret_cast<f32x4*>(out);
-        if (op == 0) hipLaunchKernelGGL(eltwise_vec_kernel<0>, grid, dim3(256), 0, mh_stream(stream), a4, b4, c4, o4, n4);
-        else if (op == 1) hipLaunchKernelGGL(eltwise_vec_kernel<1>, grid, dim3(256), 0, mh_stream(stream), a4, b4, c4, o4, n4);
-        else hipLaunchKernelGGL(eltwise_vec_kernel<2>, grid, dim3(256), 0, mh_stream(stream), a4, b4, c4, o4, n4);
+        if (op == 0) MH_LAUNCH(eltwise_vec_kernel<0>, grid, dim3(256), 0, mh_stream(stream), a4, b4, c4, o4, n4);
+        else if (op == 1) MH_LAUNCH(eltwise_vec_kernel<1>, grid, dim3(256), 0, mh_stream(stream), a4, b4, c4, o4, n4);
+        else MH_LAUNCH(eltwise_vec_kernel<2>, grid, dim3(256), 0, mh_stream(stream), a4, b4, c4, o4, n4);
     } else {
-        hipLaunchKernelGGL(eltwise_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), op, a, b,
+        MH_LAUNCH(eltwise_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), op, a, b,
                            c, out, n);
     }
     MH_CHECK_LAUNCH("mh_eltwise");
@@ -597,7 +597,7 @@ int32_t mh_bce_fwd_bwd(const float* p, const float* label, int64_t M, float grad
                        float* dlogit, mh_stream_t stream) {
     MH_REQUIRE(p && label, "mh_bce_fwd_bwd: null argument");
     if (M <= 0) return MH_OK;
-    hipLaunchKernelGGL(bce_kernel, dim3((unsigned)mh_ceil_div(M, 256)), dim3(256), 0, mh_stream(stream), p, label,
+    MH_LAUNCH(bce_kernel, dim3((unsigned)mh_ceil_div(M, 256)), dim3(256), 0, mh_stream(stream), p, label,
                        M, grad_scale, loss, dlogit);
     MH_CHECK_LAUNCH("mh_bce_fwd_bwd");
     return MH_OK;
@@ -612,7 +612,7 @@ int32_t mh_bce_mean_partial(const float* p, const float* label, int64_t M, float
                             mh_stream_t stream) {
     MH_REQUIRE(p && label && workspace, "mh_bce_mean_partial: null argument");
     MH_REQUIRE(M >= 1, "mh_bce_mean_partial: empty batch has no mean");
-    hipLaunchKernelGGL(bce_mean_kernel, dim3((unsigned)bce_partials(M)), dim3(256), 0, mh_stream(stream), p, label, M, grad_scale,
+    MH_LAUNCH(bce_mean_kernel, dim3((unsigned)bce_partials(M)), dim3(256), 0, mh_stream(stream), p, label, M, grad_scale,
                        workspace, dlogit);
     MH_CHECK_LAUNCH("mh_bce_mean_partial");
     return MH_OK;
@@ -620,7 +620,7 @@ int32_t mh_bce_mean_partial(const float* p, const float* label, int64_t M, float
 
 int32_t mh_bce_mean_finish(const float* workspace, int64_t M, float* loss_mean, mh_stream_t stream) {
     MH_REQUIRE(workspace && loss_mean && M >= 1, "mh_bce_mean_finish: null argument or empty batch");
-    hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)bce_partials(M), M, loss_mean);
+    MH_LAUNCH(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)bce_partials(M), M, loss_mean);
     MH_CHECK_LAUNCH("mh_bce_mean_finish");
     return MH_OK;
 }
@@ -640,8 +640,27 @@ int32_t mh_activation(int32_t act, const float* x, int64_t ldx, const float* dy,
     int64_t nb = mh_ceil_div(M * N, 256);
     const int64_t cap = (int64_t)mh_num_cus() * 32;
     if (nb > cap) nb = cap;
-    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), x, ldx, dy, lddy, out, ldo, M, N, act);
+    MH_LAUNCH(activation_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), x, ldx, dy, lddy, out, ldo, M, N, act);
     MH_CHECK_LAUNCH("mh_activation");
+    return MH_OK;
+}
+
+// buf[m, col0 : col0 + ncols] = value: the pad columns between a row's width and its 16-byte aligned pitch
+__global__ __launch_bounds__(256) void fill_columns_kernel(float* __restrict__ buf, int64_t M, int64_t ld, int32_t col0, int32_t ncols,
+                                                           float value) {
+    const int64_t n = M * ncols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        buf[(i / ncols) * ld + col0 + (int32_t)(i % ncols)] = value;
+}
+
+int32_t mh_fill_columns(float* buf, int64_t M, int64_t ld, int32_t col0, int32_t ncols, float value, mh_stream_t stream) {
+    MH_REQUIRE(buf && col0 >= 0 && ncols >= 0 && (int64_t)col0 + ncols <= ld, "mh_fill_columns: bad argument");
+    if (M <= 0 || ncols == 0) return MH_OK;
+    int64_t nb = mh_ceil_div(M * ncols, 256);
+    const int64_t cap = (int64_t)mh_num_cus() * 8;
+    if (nb > cap) nb = cap;
+    MH_LAUNCH(fill_columns_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), buf, M, ld, col0, ncols, value);
+    MH_CHECK_LAUNCH("mh_fill_columns");
     return MH_OK;
 }
 
@@ -650,8 +669,8 @@ int32_t mh_mean(const float* x, int64_t n, float* mean, float* workspace, mh_str
     MH_REQUIRE(n >= 1, "mh_mean: an empty vector has no mean");
     int64_t nb = mh_ceil_div(n, 256);
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(mean_partial_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), x, n, workspace);
-    hipLaunchKernelGGL(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, n, mean);
+    MH_LAUNCH(mean_partial_kernel, dim3((unsigned)nb), dim3(256), 0, mh_stream(stream), x, n, workspace);
+    MH_LAUNCH(bce_mean_finish_kernel, dim3(1), dim3(64), 0, mh_stream(stream), workspace, (int)nb, n, mean);
     MH_CHECK_LAUNCH("mh_mean");
     return MH_OK;
 }
@@ -659,7 +678,7 @@ int32_t mh_mean(const float* x, int64_t n, float* mean, float* workspace, mh_str
 int32_t mh_l2norm_rows(const float* x, int64_t M, int32_t N, float eps, float* y, mh_stream_t stream) {
     MH_REQUIRE(x && y && N >= 1, "mh_l2norm_rows: bad argument");
     if (M <= 0) return MH_OK;
-    hipLaunchKernelGGL(l2norm_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, M, N,
+    MH_LAUNCH(l2norm_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, M, N,
                        eps, y);
     MH_CHECK_LAUNCH("mh_l2norm_rows");
     return MH_OK;
@@ -669,7 +688,7 @@ int32_t mh_l2norm_rows_bwd(const float* x, const float* dy, int64_t M, int32_t N
                            mh_stream_t stream) {
     MH_REQUIRE(x && dy && dx && N >= 1, "mh_l2norm_rows_bwd: bad argument");
     if (M <= 0) return MH_OK;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, dy, M,
+    MH_LAUNCH(l2norm_bwd_kernel, dim3((unsigned)mh_ceil_div(M, 4)), dim3(256), 0, mh_stream(stream), x, dy, M,
                        N, eps, dx);
     MH_CHECK_LAUNCH("mh_l2norm_rows_bwd");
     return MH_OK;
@@ -679,7 +698,7 @@ int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb,
                        float* out, mh_stream_t stream) {
     MH_REQUIRE(a && b && out && N >= 1 && lda >= N && ldb >= N, "mh_rowwise_dot: bad argument");
     if (M <= 0) return MH_OK;
-    hipLaunchKernelGGL(rowwise_dot_kernel, dim3((unsigned)mh_ceil_div(M, 16)), dim3(256), 0, mh_stream(stream), a,
+    MH_LAUNCH(rowwise_dot_kernel, dim3((unsigned)mh_ceil_div(M, 16)), dim3(256), 0, mh_stream(stream), a,
                        lda, b, ldb, M, N, out);
     MH_CHECK_LAUNCH("mh_rowwise_dot");
     return MH_OK;
@@ -687,7 +706,7 @@ int32_t mh_rowwise_dot(const float* a, int64_t lda, const float* b, int64_t ldb,
 
 int32_t mh_adam_tick(float* step, float lr, float beta1, float beta2, float* lr_t, mh_stream_t stream) {
     MH_REQUIRE(step && lr_t, "mh_adam_tick: null argument");
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, mh_stream(stream), step, lr, beta1, beta2, lr_t);
+    MH_LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, mh_stream(stream), step, lr, beta1, beta2, lr_t);
     MH_CHECK_LAUNCH("mh_adam_tick");
     return MH_OK;
 }
@@ -699,7 +718,7 @@ int32_t mh_dense_optimizer_step(float* w, const float* grad, float* state, int64
     MH_REQUIRE(optimizer == MH_OPT_SGD || (optimizer == MH_OPT_ADAGRAD && state) || (optimizer == MH_OPT_ADAM && state && state2),
                "mh_dense_optimizer_step: bad optimizer/state");
     if (n <= 0) return MH_OK;
-    hipLaunchKernelGGL(dense_opt_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), w,
+    MH_LAUNCH(dense_opt_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream), w,
                        grad, state, state2, n, optimizer, lr, eps, beta1, beta2, lr_device);
     MH_CHECK_LAUNCH("mh_dense_optimizer_step");
     return MH_OK;

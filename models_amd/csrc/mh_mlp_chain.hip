@@ -775,7 +775,7 @@ int32_t mh_mlp_chain_fwd(const float* x, int64_t ldx, int64_t M, int32_t L, cons
     auto kern = vec ? sig->fwd_vec : sig->fwd_sca;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CW * 64), lds, mh_stream(stream), a);
+    MH_LAUNCH(kern, dim3(grid), dim3(CW * 64), lds, mh_stream(stream), a);
     MH_CHECK_LAUNCH("mh_mlp_chain_fwd");
     return MH_OK;
 }
@@ -872,7 +872,7 @@ static int32_t chain_bwd_phases(int phases, const float* x, int64_t ldx, int64_t
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (do_main) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(CW * 64), lds, s, a);
+        MH_LAUNCH(kern, dim3(grid), dim3(CW * 64), lds, s, a);
         MH_CHECK_LAUNCH("mh_mlp_chain_bwd");
     }
     if (!do_red) return MH_OK;
@@ -884,7 +884,7 @@ static int32_t chain_bwd_phases(int phases, const float* x, int64_t ldx, int64_t
         r.poff_w[l] = a.poff_w[l];
         r.poff_b[l] = a.poff_b[l];
     }
-    hipLaunchKernelGGL(chain_reduce_kernel, dim3((unsigned)mh_ceil_div(a.ptotal, 64)), dim3(1024), 0, s, r);
+    MH_LAUNCH(chain_reduce_kernel, dim3((unsigned)mh_ceil_div(a.ptotal, 64)), dim3(1024), 0, s, r);
     MH_CHECK_LAUNCH("mh_mlp_chain_bwd(reduce)");
     return MH_OK;
 }

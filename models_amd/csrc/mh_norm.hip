@@ -167,8 +167,8 @@ int32_t mh_dropout(const float* x, float* y, int64_t n, float rate, uint64_t* rn
     const uint32_t thresh = (uint32_t)fmin(4294967295.0, (double)rate * 4294967296.0);
     const int64_t nb = mh_ceil_div(mh_ceil_div(n, 4), 256);
     hipStream_t s = mh_stream(stream);
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, y, n, thresh, 1.f / (1.f - rate), rng_state, (int)backward);
-    if (!backward) hipLaunchKernelGGL(dropout_tick_kernel, dim3(1), dim3(1), 0, s, rng_state);
+    MH_LAUNCH(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, y, n, thresh, 1.f / (1.f - rate), rng_state, (int)backward);
+    if (!backward) MH_LAUNCH(dropout_tick_kernel, dim3(1), dim3(1), 0, s, rng_state);
     MH_CHECK_LAUNCH("mh_dropout");
     return MH_OK;
 }
@@ -194,15 +194,15 @@ int32_t mh_batchnorm_fwd(const float* x, int64_t ldx, int64_t M, int32_t N, cons
         }
         float* part = static_cast<float*>(workspace);
         const int nblk = (int)mh_ceil_div(M, SLAB);
-        hipLaunchKernelGGL(colsum_kernel<0>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)nullptr, (int64_t)0,
+        MH_LAUNCH(colsum_kernel<0>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)nullptr, (int64_t)0,
                            (const float*)nullptr, (const float*)nullptr, M, (int)N, part);
-        hipLaunchKernelGGL(bn_stats_finish_kernel, dim3(nc), dim3(256), 0, s, part, nblk, M, (int)N, eps, momentum, save_mean,
+        MH_LAUNCH(bn_stats_finish_kernel, dim3(nc), dim3(256), 0, s, part, nblk, M, (int)N, eps, momentum, save_mean,
                            save_invstd, moving_mean, moving_var);
-        hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, (const float*)nullptr,
+        MH_LAUNCH(bn_apply_kernel<0>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, (const float*)nullptr,
                            (int64_t)0, save_mean, save_invstd, gamma, beta, (const float*)nullptr, (const float*)nullptr, M, (int)N, y, ldy);
     } else {
-        hipLaunchKernelGGL(bn_invstd_kernel, dim3(nc), dim3(256), 0, s, moving_var, (int)N, eps, save_invstd);
-        hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, (const float*)nullptr,
+        MH_LAUNCH(bn_invstd_kernel, dim3(nc), dim3(256), 0, s, moving_var, (int)N, eps, save_invstd);
+        MH_LAUNCH(bn_apply_kernel<0>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, (const float*)nullptr,
                            (int64_t)0, moving_mean, save_invstd, gamma, beta, (const float*)nullptr, (const float*)nullptr, M, (int)N, y, ldy);
     }
     MH_CHECK_LAUNCH("mh_batchnorm_fwd");
@@ -224,13 +224,13 @@ int32_t mh_batchnorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t l
     float* part = static_cast<float*>(workspace);
     const int nblk = (int)mh_ceil_div(M, SLAB);
     const int nc = (int)mh_ceil_div(N, 256);
-    hipLaunchKernelGGL(colsum_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, save_mean, save_invstd, M, (int)N, part);
-    hipLaunchKernelGGL(bn_grad_finish_kernel, dim3(nc), dim3(256), 0, s, part, nblk, (int)N, dbeta, dgamma);
+    MH_LAUNCH(colsum_kernel<1>, dim3(nblk), dim3(256), 0, s, dy, lddy, x, ldx, save_mean, save_invstd, M, (int)N, part);
+    MH_LAUNCH(bn_grad_finish_kernel, dim3(nc), dim3(256), 0, s, part, nblk, (int)N, dbeta, dgamma);
     if (training)
-        hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, dy, lddy, save_mean,
+        MH_LAUNCH(bn_apply_kernel<1>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, dy, lddy, save_mean,
                            save_invstd, gamma, (const float*)nullptr, dbeta, dgamma, M, (int)N, dx, lddx);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<2>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, dy, lddy, save_mean,
+        MH_LAUNCH(bn_apply_kernel<2>, dim3((unsigned)mh_ceil_div(M * N, 256)), dim3(256), 0, s, x, ldx, dy, lddy, save_mean,
                            save_invstd, gamma, (const float*)nullptr, dbeta, dgamma, M, (int)N, dx, lddx);
     MH_CHECK_LAUNCH("mh_batchnorm_bwd");
     return MH_OK;

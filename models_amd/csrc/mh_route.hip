@@ -276,16 +276,16 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
     int* scan = reinterpret_cast<int*>(ws + L.off_scan);
     const dim3 grid((unsigned)L.ntiles);
     if (ids_dtype == MH_I32)
-        hipLaunchKernelGGL(route_count_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
+        MH_LAUNCH(route_count_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
     else
-        hipLaunchKernelGGL(route_count_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
-    hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, s, hist, scan, L.ntiles * W);
-    hipLaunchKernelGGL(route_counts_kernel, dim3(1), dim3(64), 0, s, scan, L.ntiles, W, n, counts);
+        MH_LAUNCH(route_count_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, hist);
+    MH_LAUNCH(route_scan_kernel, dim3(1), dim3(1024), 0, s, hist, scan, L.ntiles * W);
+    MH_LAUNCH(route_counts_kernel, dim3(1), dim3(64), 0, s, scan, L.ntiles, W, n, counts);
     if (ids_dtype == MH_I32)
-        hipLaunchKernelGGL(route_scatter_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
+        MH_LAUNCH(route_scatter_kernel<int32_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
                            send_keys, pos_of, src_row, capacity, overflow);
     else
-        hipLaunchKernelGGL(route_scatter_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
+        MH_LAUNCH(route_scatter_kernel<int64_t>, grid, dim3(256), 0, s, a, n, B, W, L.ntiles, F_total, scan,
                            send_keys, pos_of, src_row, capacity, overflow);
     MH_CHECK_LAUNCH("mh_route_build");
     return MH_OK;
@@ -296,7 +296,7 @@ int32_t mh_route_local_rows(const int64_t* recv_keys, int64_t n, const int64_t* 
     if (n <= 0) return MH_OK;
     MH_REQUIRE(recv_keys && base && rows, "mh_route_local_rows: null argument");
     MH_REQUIRE(F >= 1 && F <= MH_MAX_FEATURES, "mh_route_local_rows: F=%d outside [1,%d]", F, MH_MAX_FEATURES);
-    hipLaunchKernelGGL(route_local_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream),
+    MH_LAUNCH(route_local_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, mh_stream(stream),
                        recv_keys, n, base, shard_rows, F, rows);
     MH_CHECK_LAUNCH("mh_route_local_rows");
     return MH_OK;

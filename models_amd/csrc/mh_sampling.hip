@@ -141,7 +141,7 @@ int32_t mh_log_uniform_sample(int64_t range_max, int64_t min_id, int64_t n, int3
     const uint32_t cap = unique ? table_capacity(n) : 1;
     unsigned long long* tkey = reinterpret_cast<unsigned long long*>(ws + 256);
     unsigned long long* town = tkey + cap;
-    hipLaunchKernelGGL(log_uniform_sample_kernel, dim3(1), dim3(ST), 0, mh_stream(stream), range_max, min_id, n, (int)unique,
+    MH_LAUNCH(log_uniform_sample_kernel, dim3(1), dim3(ST), 0, mh_stream(stream), range_max, min_id, n, (int)unique,
                        rng_state, out_ids, tkey, town, cap - 1, status);
     MH_CHECK_LAUNCH("mh_log_uniform_sample");
     return MH_OK;

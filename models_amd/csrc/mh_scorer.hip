@@ -292,15 +292,15 @@ void launch_scorer(const Plan& p, const float* q, const float* neg, const void* 
     const int vec_n = ((reinterpret_cast<uintptr_t>(neg) & 15) == 0) && (E % 4 == 0);
     dim3 grid((unsigned)p.row_tiles, (unsigned)p.nsplit);
     if (!pos_ids) {
-        hipLaunchKernelGGL((scorer_kernel<MODE, false, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)nullptr,
+        MH_LAUNCH((scorer_kernel<MODE, false, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)nullptr,
                            (const int32_t*)nullptr, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
                            gscale, ds, vec_q, vec_n, neg_corr, corr_after_mask);
     } else if (ids_dtype == MH_I32) {
-        hipLaunchKernelGGL((scorer_kernel<MODE, true, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)pos_ids,
+        MH_LAUNCH((scorer_kernel<MODE, true, int32_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int32_t*)pos_ids,
                            (const int32_t*)neg_ids, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
                            gscale, ds, vec_q, vec_n, neg_corr, corr_after_mask);
     } else {
-        hipLaunchKernelGGL((scorer_kernel<MODE, true, int64_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int64_t*)pos_ids,
+        MH_LAUNCH((scorer_kernel<MODE, true, int64_t, SWM, SWN>), grid, dim3(SWM * SWN * 64), 0, s, q, neg, (const int64_t*)pos_ids,
                            (const int64_t*)neg_ids, B, Nn, E, invT, fns, logits, ld_logits, part_m, part_s, p.tps, lse,
                            gscale, ds, vec_q, vec_n, neg_corr, corr_after_mask);
     }
@@ -430,10 +430,10 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
         float* pos = ws;
         float* part_m = pos + B;
         float* part_s = part_m + (int64_t)p.nsplit * B;
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
+        MH_LAUNCH(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
         launch_scorer<0>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, logits, ld_logits,
                          part_m, part_s, nullptr, 0.f, nullptr, neg_logq, logq_after_mask, s);
-        hipLaunchKernelGGL(scorer_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, p.nsplit,
+        MH_LAUNCH(scorer_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, p.nsplit,
                            part_m, part_s, invT, logits, ld_logits, loss, lse);
         MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
         return MH_OK;
@@ -441,7 +441,7 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
     const StreamWs w = stream_ws(0, B, Nn, E, 8);
     const MhStreamPlan& plan = w.row;
     float* pos = ws + w.pos;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
+    MH_LAUNCH(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
     {
         // MERLIN_HIP_SCORER_FWD=tiled: the forward-only pass on the tiled kernel of mh_scorer_tiled.hip (second-generation GEMM
         // core, transposed product).  OPT-IN: warmed up on one box it runs 32768 x 32768 x 128 in 2.52-2.53 ms against 2.45-2.46 ms
@@ -503,7 +503,7 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
     const StreamWs w = stream_ws(2, B, Nn, E, 8);
     const MhStreamPlan& plan = w.row;
     float* pos = ws + w.pos;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
+    MH_LAUNCH(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
     const float *qx = q, *ix = item, *nx = neg_item;
     if (w.pad) {
         mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);
@@ -553,14 +553,14 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
         float* pos = ws;
         float* ds = pos + B;
         Plan p = make_plan(B, Nn);
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
+        MH_LAUNCH(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
         launch_scorer<1>(p, q, neg_item, pos_ids, neg_ids, ids_dtype, B, Nn, E, invT, false_neg_score, nullptr, 0, nullptr,
                          nullptr, lse, gscale, ds, neg_logq, logq_after_mask, s);
         int32_t st = mh_internal_linear(ds, Nn, neg_item, nullptr, B, (int)Nn, E, MH_ACT_NONE, dq, E, nullptr, nullptr, s);
         if (st != MH_OK) return st;
         st = mh_internal_gemm_tn(ds, Nn, q, E, B, (int)Nn, E, dneg_item, s);
         if (st != MH_OK) return st;
-        hipLaunchKernelGGL(scorer_pos_grad_kernel, dim3((unsigned)mh_ceil_div(B * E, 256)), dim3(256), 0, s, q, item, pos, lse,
+        MH_LAUNCH(scorer_pos_grad_kernel, dim3((unsigned)mh_ceil_div(B * E, 256)), dim3(256), 0, s, q, item, pos, lse,
                            B, E, invT, gscale, dq, ditem);
         MH_CHECK_LAUNCH("mh_inbatch_softmax_bwd");
         return MH_OK;
@@ -570,7 +570,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
     //   column pass:                                                              X = neg, Y = q   -> dneg_item
     const StreamWs w = stream_ws(1, B, Nn, E, 8);
     float* pos = ws + w.pos;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
+    MH_LAUNCH(rowdot_kernel, dim3((unsigned)mh_ceil_div(B, 16)), dim3(256), 0, s, q, item, B, E, pos, pos_logq);
     const float *qx = q, *ix = item, *nx = neg_item;
     if (w.pad) {
         mh_stream_pad_rows(q, B, E, w.Ep, ws + w.qp, s);

@@ -562,7 +562,7 @@ int32_t launch_mode(const StreamArgs& a, int ids_dtype, dim3 grid, size_t lds, h
             }                                                                                                        \
             attr_done = true;                                                                                        \
         }                                                                                                            \
-        hipLaunchKernelGGL(kern, grid, dim3(SW * 64), lds, s, a);                                                    \
+        MH_LAUNCH(kern, grid, dim3(SW * 64), lds, s, a);                                                    \
     } while (0)
     if (!a.x_ids) MH_LAUNCH_STREAM(int32_t, false);
     else if (ids_dtype == MH_I32) MH_LAUNCH_STREAM(int32_t, true);
@@ -632,29 +632,29 @@ int32_t mh_stream_launch(int mode, int lse_stream, const MhStreamPlan& p, const 
 
 void mh_stream_fwd_finalize(const float* pos, int64_t B, int nsplit, const float* part_m, const float* part_s, float invT,
                             float* logits, int64_t ld_logits, float* loss, float* lse, hipStream_t s) {
-    hipLaunchKernelGGL(fwd_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, nsplit, part_m,
+    MH_LAUNCH(fwd_finalize_kernel, dim3((unsigned)mh_ceil_div(B, 256)), dim3(256), 0, s, pos, B, nsplit, part_m,
                        part_s, invT, logits, ld_logits, loss, lse);
 }
 
 void mh_stream_fwd_grad_combine(const float* q, const float* item, const float* pos, int64_t B, int E, int nsplit,
                                 const float* part_m, const float* part_s, const float* opart, float invT, float g,
                                 float* loss, float* lse, float* dq, float* ditem, hipStream_t s) {
-    hipLaunchKernelGGL(fwd_grad_combine_kernel, dim3((unsigned)mh_ceil_div(B * (E / 4), 256)), dim3(256), 0, s, q, item, pos,
+    MH_LAUNCH(fwd_grad_combine_kernel, dim3((unsigned)mh_ceil_div(B * (E / 4), 256)), dim3(256), 0, s, q, item, pos,
                        B, E, nsplit, part_m, part_s, opart, invT, g, loss, lse, dq, ditem);
 }
 
 void mh_stream_grad_combine(const float* opart, int64_t N, int E, int nsplit, const float* pos, const float* lse,
                             const float* other, const float* self, float invT, float g, float* out, float* out_pos,
                             hipStream_t s) {
-    hipLaunchKernelGGL(grad_combine_kernel, dim3((unsigned)mh_ceil_div(N * (E / 4), 256)), dim3(256), 0, s, opart, N, E,
+    MH_LAUNCH(grad_combine_kernel, dim3((unsigned)mh_ceil_div(N * (E / 4), 256)), dim3(256), 0, s, opart, N, E,
                        nsplit, pos, lse, other, self, invT, g, out, out_pos);
 }
 
 void mh_stream_pad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)mh_ceil_div(N * Ep, 256)), dim3(256), 0, s, src, N, E, Ep, dst);
+    MH_LAUNCH(pad_rows_kernel, dim3((unsigned)mh_ceil_div(N * Ep, 256)), dim3(256), 0, s, src, N, E, Ep, dst);
 }
 void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)mh_ceil_div(N * E, 256)), dim3(256), 0, s, src, N, E, Ep, dst);
+    MH_LAUNCH(unpad_rows_kernel, dim3((unsigned)mh_ceil_div(N * E, 256)), dim3(256), 0, s, src, N, E, Ep, dst);
 }
 
 // top-k threshold filter on the same core (mh_topk.hip): X = queries (stationary), Y = candidates n_beg .. n_end

@@ -134,7 +134,7 @@ int32_t mh_scorer_tiled_fwd(const float* q, const float* neg, const void* pos_id
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_done = true;                                                                                                  \
         }                                                                                                                      \
-        hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, neg, q, Nn, (int)B, E, invT, fns, (const IDT*)pos_ids,       \
+        MH_LAUNCH(kern, grid, dim3(WM * WN * 64), lds, s, neg, q, Nn, (int)B, E, invT, fns, (const IDT*)pos_ids,       \
                            (const IDT*)neg_ids, neg_corr, corr_after_mask, part_m, part_s, ncol);                              \
     }
     if (!pos_ids) {

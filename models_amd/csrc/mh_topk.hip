@@ -314,7 +314,7 @@ int32_t tiled_filter(const float* q, int64_t Bq, const float* cand, int64_t n_ca
     const int ncol = (int)mh_ceil_div(Bq, TFBN);
     const int64_t nrow = mh_ceil_div(n_cand, TFBM);
     MH_REQUIRE(nrow * ncol < (1ll << 31), "top-k tiled filter: grid too large");
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nrow * ncol)), dim3(TFWM * TFWN * 64), lds, s, cand, q, n_cand, (int)Bq, E, tau, cnt, cs,
+    MH_LAUNCH(kern, dim3((unsigned)(nrow * ncol)), dim3(TFWM * TFWN * 64), lds, s, cand, q, n_cand, (int)Bq, E, tau, cnt, cs,
                        ci, cap, idx0, ncol);
     return MH_OK;
 }
@@ -528,7 +528,7 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         const int last = (!p.fused) && (c0 + nc >= p.n0);
         const int seen = (int)(c0 < k ? c0 : k);
 #define MH_TOPK_SELECT(R_)                                                                                          \
-    hipLaunchKernelGGL(topk_select_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, sc, nc, Bq, (int)ncur, c0, \
+    MH_LAUNCH(topk_select_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, sc, nc, Bq, (int)ncur, c0, \
                        k, seen, out_scores, out_idx, cand_ids, last, out_ids)
         if (k <= 64) MH_TOPK_SELECT(1);
         else if (k <= 128) MH_TOPK_SELECT(2);
@@ -545,7 +545,7 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         int32_t* ci = reinterpret_cast<int32_t*>(ws + p.off_ci);
         // tau[row] = current k-th best (strided read of the running list); survivor counts and dirty flags cleared.
         // One kernel node, not memset / memcpy nodes: see mh_fill_words in mh_common.h
-        hipLaunchKernelGGL(topk_stage_init_kernel, dim3((unsigned)mh_ceil_div(Bq, 256)), dim3(256), 0, s, out_scores, k, Bq, tau, cnt);
+        MH_LAUNCH(topk_stage_init_kernel, dim3((unsigned)mh_ceil_div(Bq, 256)), dim3(256), 0, s, out_scores, k, Bq, tau, cnt);
         const int vec_q = ((reinterpret_cast<uintptr_t>(q) & 15) == 0) && (E % 4 == 0);
         const int vec_c = ((reinterpret_cast<uintptr_t>(cand) & 15) == 0) && (E % 4 == 0);
         const int row_tiles = (int)mh_ceil_div(Bq, FBM);
@@ -574,11 +574,11 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
                 if (want > nct) want = nct;
                 const int tps = (int)mh_ceil_div(nct, want);
                 const int nsplit = (int)mh_ceil_div(nct, tps);
-                hipLaunchKernelGGL(topk_filter_gemm_kernel, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(FWM * FWN * 64), 0,
+                MH_LAUNCH(topk_filter_gemm_kernel, dim3((unsigned)row_tiles, (unsigned)nsplit), dim3(FWM * FWN * 64), 0,
                                    s, q, cand, Bq, beg, end, E, tau, cnt, cs, ci, p.cap, tps, vec_q, vec_c);
             }
 #define MH_TOPK_MERGE(R_)                                                                                           \
-    hipLaunchKernelGGL(topk_merge_compact_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, cs, ci, cnt, p.cap,  \
+    MH_LAUNCH(topk_merge_compact_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, cs, ci, cnt, p.cap,  \
                        Bq, k, out_scores, out_idx, tau, overflow, cand_ids, end >= N ? 1 : 0, out_ids)
             if (k <= 64) MH_TOPK_MERGE(1);
             else if (k <= 128) MH_TOPK_MERGE(2);
@@ -590,7 +590,7 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
         }
         // a compact list can only overflow on adversarial (e.g. ascending-sorted) data: those rows are recomputed
         // exactly on the device (clean rows exit at once) -- no host read-back, the call stays graph-capturable
-        hipLaunchKernelGGL(topk_redo_rows_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, q, cand, Bq, N, E, k,
+        MH_LAUNCH(topk_redo_rows_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), lds, s, q, cand, Bq, N, E, k,
                            overflow, out_scores, out_idx, cand_ids, out_ids);
     }
     MH_CHECK_LAUNCH("mh_topk_dot");

@@ -810,7 +810,7 @@ class DistributedDLRM:
         ld = (width + 3) // 4 * 4
         buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
         if ld != width:
-            buf[:, width:].zero_()
+            ops.zero_pad_columns(buf, width)
         top_in = buf[:, :width]
         body.interaction.forward(stacked, tail, out=top_in)
         body._top_in = top_in
@@ -859,7 +859,7 @@ class DistributedDLRM:
         ld = (width + 3) // 4 * 4
         buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
         if ld != width:
-            buf[:, width:].zero_()
+            ops.zero_pad_columns(buf, width)
         top_in = buf[:, :width]
         with phase("gather_interaction_fwd"):
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)

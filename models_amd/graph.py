@@ -97,6 +97,131 @@ class GraphedStep:
     __call__ = replay
 
 
+class _KeepAllocations:
+    """While active, every CUDA tensor an aten op returns is kept alive (a TorchDispatchMode): the storage a recorded step
+    allocated stays allocated -- and in place -- for as long as the recording that addresses it (the role of a graph's private
+    memory pool, without depending on which allocator pool a block came from or on ``empty_cache`` leaving it alone)."""
+
+    def __init__(self):
+        from torch.utils._python_dispatch import TorchDispatchMode
+
+        keep = self.keep = []
+        impure = self.impure = []  # aten ops that launch kernels of their own: a recorded step would not replay them
+        pure = ("empty", "view", "as_strided", "slice", "select", "reshape", "unsqueeze", "squeeze", "expand", "permute",
+                "transpose", "detach", "alias", "t.default", "split", "unbind", "narrow", "_unsafe_view", "_local_scalar_dense",
+                "_to_copy", "lift_fresh", "is_pinned", "stride", "size", "numel", "storage_offset", "sym_")
+
+        class _Mode(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                out = func(*args, **(kwargs or {}))
+                cuda = False
+                for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        keep.append(t)
+                        cuda = True
+                if not cuda:
+                    cuda = any(isinstance(a, torch.Tensor) and a.is_cuda for a in args)
+                name = str(func)
+                if cuda and not any(p_ in name for p_ in pure):
+                    impure.append(name)
+                return out
+
+        self._mode = _Mode()
+
+    def __enter__(self):
+        self._mode.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._mode.__exit__(*exc)
+
+
+class RecordedStep:
+    """``fn(static_inputs)`` executed ONCE while ``libmerlin_hip.so`` records its launch sequence (``mh_record_begin / _end``: every
+    kernel launch with its arguments by value, on the stream it was issued on, plus the event hand-offs between the streams, which
+    ``ops.SIDE`` issues through the library while ``crec`` is set) and replayed by ONE C call per step (``mh_record_replay``).
+
+    What the three other launch modes cost: eager launches from Python are host-bound in stretches (~35 launches and a dozen stream /
+    event operations per step); ONE hipGraph replays on one hardware queue (no overlap); per-stream graph segments
+    (``SegmentedStep``) keep the overlap but pay a graph launch + hand-off per segment.  The recorded sequence is the eager step's
+    own sequence -- same streams, same overlap -- issued from C.  Same contract as a captured graph: static inputs (every batch is
+    staged into them), fixed shapes, no host-side decision inside the step; the step must consist of library launches only (a torch
+    kernel inside it would not be replayed: ``assert_pure`` checks the recording against a kernel-free torch dispatch).
+    Same interface as ``GraphedStep`` / ``SegmentedStep``."""
+
+    def __init__(self, fn: Callable, inputs, warmup: int = 3, assert_pure: bool = True):
+        import ctypes as C
+
+        from . import _lib, ops
+
+        self.packed = None
+        if isinstance(inputs, PackedBatch):
+            self.packed = PackedBatch(inputs.tensors)
+            self.inputs = self.packed.tensors
+        else:
+            self.inputs = {k: v.clone() for k, v in inputs.items()}
+        self.fn = fn
+        for _ in range(warmup):  # eager: builds lazy layers, sizes every workspace, sets the kernels' LDS attributes
+            fn(self.inputs)
+        torch.cuda.synchronize()
+        if ops.SIDE.recorder is not None or ops.SIDE.crec:
+            raise RuntimeError("a step is already being recorded")
+        lib = _lib.load()
+        self._lib = lib
+        self._keep = _KeepAllocations()
+        _lib.check(lib.mh_record_begin(), "mh_record_begin")
+        ops.SIDE.crec = True
+        ops.CAPTURING[0] += 1  # persistent buffers touched now are addressed by the recording for good (note_captured / park_replaced)
+        ok = False
+        try:
+            with self._keep:
+                self.output = fn(self.inputs)  # executes for real AND is recorded
+            ok = True
+        finally:
+            ops.SIDE.crec = False
+            ops.CAPTURING[0] -= 1
+            if not ok:
+                lib.mh_record_abort()
+        h = C.c_void_p()
+        _lib.check(lib.mh_record_end(C.byref(h)), "mh_record_end")
+        self.handle = h
+        self.impure_ops = sorted(set(self._keep.impure))
+        if assert_pure and self.impure_ops:
+            lib.mh_record_free(h)
+            self.handle = None
+            raise RuntimeError("the step launches kernels outside libmerlin_hip.so, which a recorded launch sequence would not "
+                               f"replay: {self.impure_ops}")
+        n, e = C.c_int64(), C.c_int64()
+        _lib.check(lib.mh_record_info(h, C.byref(n), C.byref(e)), "mh_record_info")
+        self.n_launches, self.n_hand_offs = int(n.value), int(e.value)
+        torch.cuda.synchronize()
+        # side streams the recording issues on: they must outlive it (ops.SIDE keeps them), and so must the launch stream
+        self._stream = torch.cuda.current_stream()
+
+    def replay(self, new_inputs=None):
+        if new_inputs is not None:
+            if self.packed is not None:
+                self.packed.copy_from(new_inputs)
+            else:
+                _stage(self.inputs, new_inputs)
+        if torch.cuda.current_stream() != self._stream:
+            raise RuntimeError("a recorded step replays on the stream it was recorded on")
+        from . import _lib
+
+        _lib.check(self._lib.mh_record_replay(self.handle), "mh_record_replay")
+        return self.output
+
+    __call__ = replay
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.mh_record_free(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class SegmentedStep:
     """``fn(static_inputs)`` recorded ONCE as a list of per-stream hipGraph segments (``ops.StepRecorder``: every
     ``SIDE.on / mark / wait / join`` of the step cuts a segment and notes a dependency edge) and replayed by launching the

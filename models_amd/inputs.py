@@ -522,7 +522,7 @@ class InputBlockV2(Block):
         dev = (self.categorical.feature_table[cat_names[0]].table.data.device if cat_names else first.device)
         buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
         if ld != W:
-            buf[:, W:].zero_()
+            ops.zero_pad_columns(buf, W)
         aligned = all(offsets[n] % 4 == 0 for n in cat_names)
         self._fused = aligned and len({widths[n] for n in cat_names}) <= 1 and all(
             self.categorical._is_onehot(inputs[n]) for n in cat_names)

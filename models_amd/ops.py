@@ -87,6 +87,15 @@ class _Marker:
         self.seg = seg
 
 
+class _CEvent:
+    """An event owned by the open launch recording of the C library (``mh_record_event``)."""
+
+    __slots__ = ("eid",)
+
+    def __init__(self, eid: int):
+        self.eid = int(eid)
+
+
 class StepRecorder:
     """Records ONE step as a list of SEGMENTS -- maximal runs of launches on one logical stream -- each captured into its own
     hipGraph, with the dependency edges between them; ``graph.SegmentedStep`` replays the list on real streams.
@@ -189,14 +198,15 @@ class _SideStreams:
     def __init__(self):
         import os
 
-        mode = os.environ.get("MERLIN_HIP_SIDE_STREAMS", "1")  # "0" | "1" | "dw" | "sparse" (one kind only: debugging)
+        mode = os.environ.get("MERLIN_HIP_SIDE_STREAMS", "1")  # "0" | "1" | a comma list of kinds, e.g. "sort,sparse" (experiments)
         self.enabled = mode != "0"
-        self.kinds = {"dw", "sparse", "sort"} if mode in ("0", "1") else {mode}
+        self.kinds = {"dw", "sparse", "sort"} if mode in ("0", "1") else {k.strip() for k in mode.split(",") if k.strip()}
         self._streams = {}
         self._pending = set()
         self._keep = []
         self._defer = 0
         self.recorder: Optional[StepRecorder] = None
+        self.crec = False  # the C library is recording the launch sequence (graph.RecordedStep): hand-offs go through its events
         # ONE physical side stream for all three kinds: every extra stream is one more join at the end of the step and more
         # cross-stream hand-offs in between, and a hand-off costs of the order of 20 us here.  The side work is a chain anyway
         # (sort -> [dW, after dX] -> sparse apply, which needs the sort).  Measured on one box, alternating runs: eager
@@ -223,13 +233,32 @@ class _SideStreams:
         return st
 
     # -- events ---------------------------------------------------------------------------------------------------------
+    # Eager mode has two flavours of event: the framework's (torch.cuda.Event), and -- while the C library is RECORDING the launch
+    # sequence of a step (graph.RecordedStep: ``crec`` set) -- the library's own (mh_record_event / mh_record_wait_event), so that
+    # the hand-offs between the streams are part of the recorded sequence and are replayed with it.
+    def _ev_record(self, stream=None):
+        if self.crec:
+            st = stream if stream is not None else torch.cuda.current_stream()
+            eid = C.c_int64(-1)
+            check(_lib.load().mh_record_event(C.c_void_p(st.cuda_stream), C.byref(eid)), "mh_record_event")
+            return _CEvent(eid.value)
+        ev = torch.cuda.Event()
+        ev.record(stream) if stream is not None else ev.record()
+        return ev
+
+    def _ev_wait(self, stream, ev) -> None:
+        if isinstance(ev, _CEvent):
+            if not self.crec:
+                raise RuntimeError("an event of a recorded launch sequence used outside its recording")
+            check(_lib.load().mh_record_wait_event(C.c_void_p(stream.cuda_stream), ev.eid), "mh_record_wait_event")
+        else:
+            stream.wait_event(ev)
+
     def mark(self):
         """An ordering point on the current stream: pass it to ``on(after=[...])`` or ``wait``."""
         if self.recorder is not None:
             return self.recorder.mark()
-        ev = torch.cuda.Event()
-        ev.record()
-        return ev
+        return self._ev_record()
 
     def wait(self, marker) -> None:
         """The current stream waits for ``marker``."""
@@ -238,7 +267,7 @@ class _SideStreams:
                 raise RuntimeError("a marker of a recorded step used outside its recording")
             self.recorder.wait(marker)
         else:
-            torch.cuda.current_stream().wait_event(marker)
+            self._ev_wait(torch.cuda.current_stream(), marker)
 
     class _On:
         def __init__(self, owner, name, after, keep, kind=None):
@@ -254,9 +283,9 @@ class _SideStreams:
             st = o.stream(self.name)
             if self.after:
                 for ev in self.after:
-                    st.wait_event(ev)
+                    o._ev_wait(st, ev)
             else:
-                st.wait_stream(torch.cuda.current_stream())
+                o._ev_wait(st, o._ev_record())  # == st.wait_stream(current stream)
             o._pending.add(st)
             o._keep.extend(self.keep)
             self._st = st
@@ -268,9 +297,7 @@ class _SideStreams:
             if self._ctx is not None:
                 r = self._ctx.__exit__(*exc)
                 if self.owner._alias:  # kinds share a stream: remember where THIS kind's work ends on it
-                    ev = torch.cuda.Event()
-                    ev.record(self._st)
-                    self.owner._kind_event[self.kind] = ev
+                    self.owner._kind_event[self.kind] = self.owner._ev_record(self._st)
                 return r
             self.owner.recorder.leave()
             return False
@@ -293,7 +320,7 @@ class _SideStreams:
         if self._pending:
             cur = torch.cuda.current_stream()
             for st in self._pending:
-                cur.wait_stream(st)
+                self._ev_wait(cur, self._ev_record(st))  # == cur.wait_stream(st)
             self._pending.clear()
         self._keep.clear()
 
@@ -307,7 +334,7 @@ class _SideStreams:
                 return
             ev = self._kind_event.pop(name, None)
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                self._ev_wait(torch.cuda.current_stream(), ev)
             return
         name = self._alias.get(name, name)
         if self.recorder is not None:
@@ -315,7 +342,7 @@ class _SideStreams:
             return
         st = self._streams.get((torch.cuda.current_device(), name)) if torch.cuda.is_available() else None
         if st is not None and st in self._pending:
-            torch.cuda.current_stream().wait_stream(st)
+            self._ev_wait(torch.cuda.current_stream(), self._ev_record(st))
             self._pending.discard(st)
 
     def maybe_join(self) -> None:
@@ -599,7 +626,13 @@ class _TailWork:
         self._outer = TAIL[0]
         import os as _os
 
-        TAIL[0] = [] if _os.environ.get("MERLIN_HIP_TAIL", "1") != "0" else None  # (env: A/B switch of the prepared branch)
+        # Parking moves two small launches behind the sparse hand-off.  Measured (round 4, alternating runs on one box each): it LOSES
+        # ~20 us in the eager step (0.945 -> 0.966 ms) and in the C-recorded replay (0.958 -> 0.976), and WINS ~10 us when the step is
+        # replayed as hipGraph segments (segmented 0.977 -> 0.967).  So: on while a step is stream-captured, off otherwise;
+        # MERLIN_HIP_TAIL=0 / 1 forces it.
+        env = _os.environ.get("MERLIN_HIP_TAIL")
+        replayed = SIDE.recorder is not None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+        TAIL[0] = [] if (env == "1" or (env is None and replayed)) else None
         return self
 
     def __exit__(self, *exc):
@@ -643,7 +676,7 @@ def mlp_chain_backward(x: torch.Tensor, Ws: Sequence[torch.Tensor], ys: Sequence
         lddx = (dims[0] + 3) // 4 * 4
         buf = torch.empty((M, lddx), dtype=torch.float32, device=x.device)
         if lddx != dims[0]:
-            buf[:, dims[0]:].zero_()
+            zero_pad_columns(buf, dims[0])
         dx = buf[:, :dims[0]]
     dWs = [torch.empty((dims[l], dims[l + 1]), dtype=torch.float32, device=x.device) for l in range(L)]
     dbs = [torch.empty((dims[l + 1],), dtype=torch.float32, device=x.device) if need_db[l] else None for l in range(L)]
@@ -774,7 +807,7 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         lddx = (K + 3) // 4 * 4  # 16-byte aligned rows for whoever consumes dx next
         buf = torch.empty((M, lddx), dtype=torch.float32, device=x.device)
         if lddx != K and zero_pad:  # consumers that widen dx to its leading dimension expect zeros there (blocks._widen)
-            buf[:, K:].zero_()
+            zero_pad_columns(buf, K)
         dx = buf[:, :K]
     dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
@@ -1103,6 +1136,18 @@ def activation(x: torch.Tensor, name: str, dy: Optional[torch.Tensor] = None) ->
     check(lib.mh_activation(ACTX[name], _ptr(x), x.stride(0), _ptr(dy), 0 if dy is None else dy.stride(0), _ptr(out), N, M, N,
                             _stream()), "mh_activation")
     return out
+
+
+def zero_pad_columns(buf: torch.Tensor, width: int) -> None:
+    """``buf[:, width:] = 0`` for a row-major fp32 [M, ld] buffer (``mh_fill_columns``): a library launch, so a recorded step
+    (graph.RecordedStep) holds it -- a torch fill would be missing from the replay."""
+    ld = buf.stride(0) if buf.dim() == 2 and buf.shape[0] > 1 else buf.shape[-1]
+    if buf.dim() != 2 or buf.dtype != torch.float32 or buf.stride(1) != 1 or width > buf.shape[1]:
+        raise ValueError("zero_pad_columns wants a row-major fp32 [M, ld] buffer")
+    if buf.shape[1] == width or buf.shape[0] == 0:
+        return
+    _dev(buf, "buf", torch.float32)
+    check(_lib.load().mh_fill_columns(_ptr(buf), buf.shape[0], ld, width, buf.shape[1] - width, 0.0, _stream()), "mh_fill_columns")
 
 
 def mean(x: torch.Tensor) -> torch.Tensor:

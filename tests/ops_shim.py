@@ -300,6 +300,11 @@ def l2norm(x, eps=1e-6):
     return x / x.norm(dim=1, keepdim=True).clamp_min(eps)
 
 
+def zero_pad_columns(buf, width):
+    if buf.shape[1] != width:
+        buf[:, width:].zero_()
+
+
 def install():
     """Replace the HIP wrappers of ``models_amd.ops`` by the statements above (this process only)."""
     from models_amd import ops
@@ -307,6 +312,6 @@ def install():
     for name in ("embedding_gather", "linear", "dot_interaction", "dot_interaction_backward", "linear_backward",
                  "embedding_gather_backward", "bce", "dense_optimizer_step_multi", "route_build", "eltwise", "rowwise_dot",
                  "cross_layer", "cross_layer_backward", "cross_lowrank_dx", "inbatch_softmax", "inbatch_softmax_train", "inbatch_softmax_backward", "l2norm", "embedding_bag",
-                 "embedding_dense_list", "embedding_bag_expand", "embedding_bag_backward"):
+                 "embedding_dense_list", "embedding_bag_expand", "embedding_bag_backward", "zero_pad_columns"):
         setattr(ops, name, globals()[name])
     ops.route_local_rows = D.route_local_rows_torch

@@ -123,3 +123,13 @@ def test_mean_matches_fp64(device):
         assert m.dim() == 0
         assert abs(float(m) - float(x.double().mean())) < 1e-6
         assert float(ops.mean(x)) == float(m)  # deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,ld,width", [(1, 4, 3), (257, 28, 26), (4096, 3344, 3341), (5, 8, 8)])
+def test_zero_pad_columns_touches_only_the_pad(device, M, ld, width):
+    """``mh_fill_columns``: the pad columns of an ld-pitched buffer become zero, nothing else changes."""
+    from models_amd import ops
+    buf = torch.full((M, ld), 3.5, device=device)
+    ops.zero_pad_columns(buf, width)
+    assert bool((buf[:, :width] == 3.5).all()) and bool((buf[:, width:] == 0).all())

@@ -484,16 +484,17 @@ def test_two_tower_v2_encoders_equal_v1_model(device):
     np.testing.assert_allclose(emb, v2.query_embeddings(batches[0]).cpu().numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("mode", ["one_graph", "segmented", "segmented_deterministic"])
+@pytest.mark.parametrize("mode", ["one_graph", "segmented", "segmented_deterministic", "recorded", "recorded_deterministic"])
 def test_graph_replayed_train_steps_equal_eager_steps(device, mode, monkeypatch):
     """The headline number of bench.py is a replay of the captured train step -- ONE hipGraph, or the per-stream graph
     segments of graph.SegmentedStep (what Model.fit uses): replaying it on a sequence of NEW batches must leave the model
     exactly where eager steps on the same batches leave it."""
-    from models_amd.graph import GraphedStep, SegmentedStep
+    from models_amd.graph import GraphedStep, RecordedStep, SegmentedStep
 
-    exact = mode == "segmented_deterministic"  # no float atomics in the sparse update: replay == eager BIT FOR BIT
+    # "recorded": the launch sequence kept by libmerlin_hip.so itself and replayed by one C call (graph.RecordedStep)
+    exact = mode.endswith("_deterministic")  # no float atomics in the sparse update: replay == eager BIT FOR BIT
     monkeypatch.setenv("MERLIN_HIP_DETERMINISTIC", "1" if exact else "0")
-    mode = "segmented" if exact else mode
+    mode = mode.replace("_deterministic", "")
     cards = {"C1": 5000, "C2": 7, "C3": 300, "C4": 50}
     cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
     cols.append(S.binary_target("label"))
@@ -522,7 +523,11 @@ def test_graph_replayed_train_steps_equal_eager_steps(device, mode, monkeypatch)
 
     static = dict(batches[0][0])
     static["__label__"] = batches[0][1]
-    gs = (GraphedStep if mode == "one_graph" else SegmentedStep)(step, static, warmup=2)  # warm-up steps DO train b: put it back to the initial state in place
+    gs = {"one_graph": GraphedStep, "segmented": SegmentedStep, "recorded": RecordedStep}[mode](step, static, warmup=2)  # warm-up steps DO train b: put it back to the initial state in place
+    if mode == "recorded":
+        # every launch of the step is in the recording, with the hand-offs to and from the side stream; nothing of the step ran
+        # outside the library (an aten kernel would be missing from the replay)
+        assert gs.n_launches >= 15 and gs.n_hand_offs >= 4 and gs.impure_ops == []
     if mode == "segmented":
         streams = {sg["stream"] for sg in gs.segments}
         assert {"main", "sort"} <= streams and len(gs.segments) >= 5  # the step really was cut along its side work (one physical side stream: ops._SideStreams)

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4c18; rm -rf $O; mkdir -p $O
+run() { n=$1; shift
+  env "$@" python bench.py --no-secondary --no-cpu-baseline --steps 200 --warmup 30 --sustain 2 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$n', round(d['ms_per_step'],4), d['config']['launch'], {k:round(v,4) for k,v in d['config']['launch_probe'].items() if isinstance(v,float)})
+" | tee -a $O/ab.txt
+}
+for r in 1 2; do
+run base X=1
+run dw_serial MERLIN_HIP_SIDE_STREAMS=sort,sparse
+run sparse_only MERLIN_HIP_SIDE_STREAMS=sparse
+run sort_only MERLIN_HIP_SIDE_STREAMS=sort
+done
