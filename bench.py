@@ -293,7 +293,7 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain, batch=None):
     train = args.mode == "train"
     eager = (lambda inp: runner.train_step(inp)) if train else (lambda inp: runner(inp, training=True))
     if tm.world > 1:
-        for i in range(3):  # calibration of the fixed-capacity exchange
+        for i in range(5):  # calibration of the fixed-capacity exchange (twice when the route drops its de-duplication)
             eager(batches[i % len(batches)].tensors)
     graphed = None
     if not args.eager and tm.world == 1:
@@ -787,8 +787,9 @@ def main():
         return runner(x) if args.mode == "fwd" else runner.train_step(x, y)
 
     graphed = None
-    if sharded:  # calibration steps of the row-sharded exchange (dense mode, host-side counts), then fixed windows
-        for i in range(3):
+    if sharded:  # calibration steps of the row-sharded exchange (dense mode, host-side counts), then fixed windows; five: a route
+        # that finds no duplicates worth removing calibrates a second time without the de-duplication (distributed.py, "auto")
+        for i in range(5):
             eager(batches[i % nb].tensors)
     if not args.eager and getattr(runner, "graph_capturable", not sharded):
         graphed = graph_or_eager(eager, batches[0], True)  # whole step captured once into a hipGraph

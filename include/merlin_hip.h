@@ -556,6 +556,18 @@ int32_t mh_route_build(const void* const* ids, int32_t ids_dtype, int32_t F, int
                        const int32_t* slots, int32_t F_total, int64_t capacity, int64_t* send_keys, int64_t* pos_of,
                        int64_t* src_row, int64_t* counts, int32_t* overflow, void* workspace, int64_t workspace_bytes,
                        mh_stream_t stream);
+/* The same route with per-(sender, owner) DE-DUPLICATION: a row many samples of the batch ask for is requested -- and its
+ * gradient returned -- once (what SparseOperationKit does inside `sok.lookup_sparse`, reached from
+ * merlin/models/tf/distributed/embedding.py:144-148).  send_keys holds each distinct (feature, id) once, grouped by owner, in
+ * the order of FIRST occurrence in entry order (a pure function of the ids); counts[w] = distinct keys for owner w;
+ * pos_of[e] = the send slot of entry e's key (entries with equal keys share it; -1: negative id, or the key fell outside a
+ * fixed window, overflow[0] |= 1).  The rows come back once per slot: the forward is the gather out[e] = back[pos_of[e]], the
+ * backward the segment sum send[p] = sum over {e: pos_of[e] == p} of grad[e] (mh_embedding_gather_bwd, SGD with lr = -1 onto a
+ * zero [n_send, D] buffer, does exactly that).  capacity as in mh_route_build; there is no src_row. */
+int64_t mh_route_dedup_workspace_bytes(int64_t n, int32_t W);
+int32_t mh_route_build_dedup(const void* const* ids, int32_t ids_dtype, int32_t F, int64_t B, int32_t W, int64_t capacity,
+                             int64_t* send_keys, int64_t* pos_of, int64_t* counts, int32_t* overflow, void* workspace,
+                             int64_t workspace_bytes, mh_stream_t stream);
 /* Owner side: rows[i] = base[key >> 40] + (key & (2^40 - 1)): row of the rank's concatenated local shards; -1 (read as a
  * zero row by the gather, skipped by the fused update) for padding keys (< 0) and for local rows >= shard_rows[f]
  * (an id beyond the table's cardinality; shard_rows may be NULL = unchecked). */

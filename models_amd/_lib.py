@@ -56,6 +56,8 @@ SIGNATURES = {
     "mh_eltwise": (_i32, [_i32, _p, _p, _p, _p, _i64, _p]),
     "mh_route_workspace_bytes": (_i64, [_i64, _i32]),
     "mh_route_build": (_i32, [_p, _i32, _i32, _i64, _i32, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "mh_route_dedup_workspace_bytes": (_i64, [_i64, _i32]),
+    "mh_route_build_dedup": (_i32, [_p, _i32, _i32, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "mh_route_local_rows": (_i32, [_p, _i64, _p, _p, _i32, _p, _p]),
     "mh_comm_unique_id": (_i32, [_p]),
     "mh_comm_init": (_i32, [_i32, _i32, _p, C.POINTER(_p)]),

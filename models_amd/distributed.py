@@ -152,14 +152,67 @@ class ShardedEmbeddingTable:
         self.update_fn(self.table, self.state, self._route.recv_rows, g)
 
 
+def _route_build_dedup_torch(idm: torch.Tensor, owner: torch.Tensor, W: int, capacity: int, overflow):
+    """Framework-op statement of ``mh_route_build_dedup``: every distinct (feature, id) once per owner, in the order of first
+    occurrence (entry order e = f*B + b) within the owner; ``pos_of`` maps equal requests to one slot; negative ids -> -1."""
+    F, B = idm.shape
+    n = F * B
+    dev = idm.device
+    feat = torch.arange(F, device=dev, dtype=torch.int64).unsqueeze(1)
+    flat = idm.reshape(-1)
+    valid = flat >= 0
+    gkey = ((feat << 40) | idm.clamp(min=0)).reshape(-1)
+    e = torch.arange(n, device=dev, dtype=torch.int64)
+    uniq, inv = torch.unique(gkey, return_inverse=True)
+    first = torch.full((uniq.numel(),), n, dtype=torch.int64, device=dev)
+    first.scatter_reduce_(0, inv[valid], e[valid], "amin")
+    leader = valid & (first[inv] == e)
+    lead_e = e[leader]                                   # ascending entry order
+    lo = owner[lead_e]
+    order = torch.argsort(lo, stable=True)
+    sel, so = lead_e[order], lo[order]                   # leaders grouped by owner, first occurrence first
+    counts = torch.bincount(lo, minlength=W)
+    key = ((feat << 40) | torch.div(idm, W, rounding_mode="floor")).reshape(-1)
+    m = sel.numel()
+    if not capacity:
+        p = torch.arange(m, device=dev, dtype=torch.int64)
+        send_keys = key[sel]
+    else:
+        start = torch.cumsum(counts, 0) - counts
+        rank_in = torch.arange(m, device=dev, dtype=torch.int64) - start[so]
+        keep = rank_in < capacity
+        p = torch.where(keep, so * capacity + rank_in, torch.full_like(rank_in, -1))
+        send_keys = torch.full((W * capacity,), -1, dtype=torch.int64, device=dev)
+        send_keys[p[keep]] = key[sel][keep]
+        if overflow is not None and m:
+            overflow |= (~keep).any().to(overflow.dtype)
+    slot_of_key = torch.full((uniq.numel(),), -1, dtype=torch.int64, device=dev)
+    slot_of_key[inv[sel]] = p
+    pos_of = torch.where(valid, slot_of_key[inv], torch.full_like(e, -1))
+    return send_keys, pos_of.reshape(F, B), None, counts
+
+
+def segment_sum_torch(dstack: torch.Tensor, slots: Sequence[int], pos_of: torch.Tensor, n_send: int) -> torch.Tensor:
+    """send[p] = sum over {(f, b): pos_of[f, b] == p} of dstack[b, slots[f]]: the gradient rows of a de-duplicated route."""
+    B, F, D = dstack.shape
+    send = torch.zeros((n_send, D), dtype=dstack.dtype, device=dstack.device)
+    g = dstack[:, torch.tensor(list(slots), dtype=torch.int64, device=dstack.device)].transpose(0, 1).reshape(-1, D)
+    pos = pos_of.reshape(-1)
+    keep = pos >= 0
+    send.index_add_(0, pos[keep], g[keep])
+    return send
+
+
 def route_build_torch(ids: Sequence[torch.Tensor], world_size: int, slots: Sequence[int], n_slots: int,
-                      capacity: int = 0, overflow: Optional[torch.Tensor] = None):
+                      capacity: int = 0, overflow: Optional[torch.Tensor] = None, dedup: bool = False):
     """Framework-op statement of ``mh_route_build`` (same contract, any device): what the gloo tests inject and
     what the HIP kernel is checked against.  Entry e = f*B + b; stable order within an owner.  ``capacity`` > 0:
     fixed windows of that many slots per owner, padding -1, dropped requests ``pos_of`` = -1 (``overflow`` |= 1)."""
     idm = torch.stack([i.reshape(-1).to(torch.int64) for i in ids])  # [F, B]
     F, B = idm.shape
     owner = torch.remainder(idm, world_size).reshape(-1)
+    if dedup:
+        return _route_build_dedup_torch(idm, owner, world_size, capacity, overflow)
     order = torch.argsort(owner, stable=True)
     feat = torch.arange(F, device=idm.device, dtype=torch.int64).unsqueeze(1)
     key = ((feat << 40) | torch.div(idm, world_size, rounding_mode="floor")).reshape(-1)
@@ -217,10 +270,20 @@ class ShardedEmbeddingGroup:
     def __init__(self, tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None,
                  route_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None,
                  feature_table: Optional[Sequence[int]] = None, presharded: bool = False,
-                 global_rows: Optional[Sequence[int]] = None, capacity_factor: float = 1.25, calibration: int = 2):
+                 global_rows: Optional[Sequence[int]] = None, capacity_factor: float = 1.25, calibration: int = 2,
+                 dedup="auto", reduce_fn: Optional[Callable] = None):
         self.rank, self.world_size = world()
         self.group = group
         self.gather_fn, self.update_fn = gather_fn, update_fn
+        # Per-(sender, owner) de-duplication of the requests (SparseOperationKit does it inside sok.lookup_sparse,
+        # tf/distributed/embedding.py:144-148): True / False / "auto" = on when there is somebody to send to, and switched off at
+        # the end of calibration if the batches turn out to hold (almost) no duplicates -- the ranks agree on that figure
+        # (all-reduce), the hash pass and the segment sum of the gradient rows then cost more than the bytes they save.
+        self.dedup = (self.world_size > 1) if dedup == "auto" else bool(dedup)
+        self._dedup_auto = dedup == "auto"
+        self.dedup_min_saving = 0.15              # "auto": keep de-duplicating if >= 15 % of the requests are duplicates
+        self._seen_requests = self._seen_unique = 0
+        self.reduce_fn = reduce_fn or segment_sum_torch
         self.route_fn = route_fn or route_build_torch
         self.rows_fn = rows_fn or route_local_rows_torch
         W = self.world_size
@@ -282,6 +345,7 @@ class ShardedEmbeddingGroup:
         # ranks on different branches issue mismatched collectives and hang (round-3 advisor finding, reproduced on two gloo
         # ranks).  Alias routes therefore stay on the dense exchange (exact per-peer counts, one host read per step) for good.
         a._never_fixed = True
+        a.dedup, a._dedup_auto = False, False  # one request per VALUE of a list: the owner-side update de-duplicates
         a._fmap_cache = {}
         return a
 
@@ -366,7 +430,7 @@ class ShardedEmbeddingGroup:
                 self.check_overflow()  # one host read every check_every steps: a dropped request never goes unnoticed for long
         if fixed:                       # ---- fixed windows ----
             cap = self.capacity
-            send_keys, pos_of, src_row, _ = self.route_fn(ids, W, slots, n_slots, cap, self.overflow)
+            send_keys, pos_of, src_row, _ = self._route(ids, W, slots, n_slots, cap, self.overflow)
             if self.lossless and W > 1 and not capturing:
                 # nothing has been exchanged yet: agree on the outcome of the route (every rank takes the same branch)
                 dist.all_reduce(self.overflow, op=dist.ReduceOp.MAX, group=self.group)
@@ -382,7 +446,7 @@ class ShardedEmbeddingGroup:
             self._send_counts = self._recv_counts = None
             n_recv = W * cap
         else:                           # ---- dense: per-peer counts on the host (calibration steps) ----
-            send_keys, pos_of, src_row, send_counts = self.route_fn(ids, W, slots, n_slots)
+            send_keys, pos_of, src_row, send_counts = self._route(ids, W, slots, n_slots)
             recv_counts = torch.empty_like(send_counts)
             if W > 1:
                 dist.all_to_all_single(recv_counts, send_counts, group=self.group)
@@ -391,14 +455,28 @@ class ShardedEmbeddingGroup:
             both = torch.stack([send_counts, recv_counts]).tolist()  # the one host sync of a calibration step
             self._send_counts, self._recv_counts = both[0], both[1]
             n_recv = sum(self._recv_counts)
+            if self.dedup:  # the route filled the first sum(counts) slots of an n-entry buffer
+                send_keys = send_keys[:sum(self._send_counts)]
+            self._seen_requests += n
+            self._seen_unique += sum(self._send_counts)
             self._max_count = max(self._max_count, max(self._send_counts), max(self._recv_counts))
             self._steps += 1
             if self.capacity is None and self._steps >= self.calibration and not never_fixed:
-                if W > 1:  # every rank must choose the same window
-                    m = torch.tensor([self._max_count], dtype=torch.int64, device=send_keys.device)
-                    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
-                    self._max_count = int(m.item())
-                self._freeze_after = n
+                if W > 1:  # every rank must choose the same window (and the same answer to "does de-duplication pay")
+                    m = torch.tensor([self._max_count, self._seen_unique, self._seen_requests], dtype=torch.int64,
+                                     device=send_keys.device)
+                    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)  # the rank whose batches held the most distinct keys
+                    both = m.tolist()
+                    self._max_count, uniq, req = int(both[0]), int(both[1]), int(both[2])
+                else:
+                    uniq, req = self._seen_unique, self._seen_requests
+                if self.dedup and self._dedup_auto and req > 0 and 1.0 - uniq / req < self.dedup_min_saving:
+                    # (almost) no duplicates: calibrate again without the de-duplication (its windows hold requests, not keys)
+                    self.dedup = False
+                    self._steps, self._max_count = 0, 0
+                else:
+                    self._freeze_after = n
+                self._seen_requests = self._seen_unique = 0
         if features is not None and list(features) != list(range(F_sh)):
             # the route numbers the id columns 0 .. F_sh - 1; ``features`` says which features of the GROUP they are
             # one tensor per (features, device), built once: a per-lookup torch.tensor(list) is a pageable host-to-device copy
@@ -411,6 +489,7 @@ class ShardedEmbeddingGroup:
             low = (1 << 40) - 1
             send_keys = torch.where(send_keys >= 0, (fmap[(send_keys >> 40).clamp(min=0)] << 40) | (send_keys & low), send_keys)
         self._pos_of, self._src_row, self._n_send = pos_of, src_row, send_keys.numel()
+        self._dedup_call = src_row is None  # this call's route was de-duplicated: the backward is a segment sum over pos_of
         self._fwd_layout = (list(slots), int(n_slots))
         recv_keys, _ = self._exchange(send_keys, n_recv, self._recv_counts, self._send_counts)
         self._rows = self.rows_fn(recv_keys, self.base, self.shard_rows)  # rows of the concatenated local buffer (-1: none)
@@ -418,6 +497,11 @@ class ShardedEmbeddingGroup:
         # the row exchange runs on RCCL's stream: whatever the caller enqueues before lookup_end() overlaps it
         back, work = self._exchange(rows, self._n_send, self._send_counts, self._recv_counts, async_op=True)
         self._pending_lookup = (work, back, rows, scatter_into, F_sh, B)
+
+    def _route(self, ids, W, slots, n_slots, cap: int = 0, overflow=None):
+        if self.dedup:
+            return self.route_fn(ids, W, slots, n_slots, cap, overflow, dedup=True)
+        return self.route_fn(ids, W, slots, n_slots, cap, overflow)
 
     def prepare_update(self) -> None:
         """Training step, HIP path: the owner-side rows of this step's requests are known since ``lookup_begin`` -- start the
@@ -464,7 +548,13 @@ class ShardedEmbeddingGroup:
             send = torch.zeros((self._n_send, D), dtype=grad.dtype, device=grad.device)
             pos = self._pos_of.reshape(-1)
             keep = pos >= 0
-            send[pos[keep]] = flat[keep]
+            if self._dedup_call:
+                send.index_add_(0, pos[keep], flat[keep])  # equal requests share a slot: their gradient rows are summed here
+            else:
+                send[pos[keep]] = flat[keep]
+        elif self._dedup_call:
+            dstack, slots, _ = from_stacked
+            send = self.reduce_fn(dstack, list(slots), self._pos_of, self._n_send)
         else:
             dstack, slots, gather_fn = from_stacked
             B, F, D = dstack.shape
@@ -644,7 +734,20 @@ def _hip_group_fns(owner):
     return gather_fn, update_fn
 
 
-def _build_group(owner, emb, names, group, capacity_factor, calibration):
+def _hip_segment_sum(dstack, slots, pos_of, n_send):
+    """Gradient rows of a de-duplicated route: ``send[p] = sum of dstack[b, slots[f]] over pos_of[f, b] == p`` by the fused sparse
+    update itself (SGD, lr = -1, onto zeros: its sort + piece reduction is the segment sum; slots < 0 are skipped)."""
+    from . import ops
+
+    B, F, D = dstack.shape
+    send = torch.zeros((n_send, D), dtype=dstack.dtype, device=dstack.device)
+    if n_send and B:
+        ops.embedding_gather_backward([send] * len(slots), None, [pos_of[f] for f in range(len(slots))], dstack.contiguous(),
+                                      [int(sl) * D for sl in slots], "sgd", -1.0, 0.0)
+    return send
+
+
+def _build_group(owner, emb, names, group, capacity_factor, calibration, dedup="auto"):
     """One ShardedEmbeddingGroup over the DISTINCT tables of the sharded features ``names`` of an EmbeddingsBlock
     (features sharing a table -- same Parameter -- share one shard); rebinds every table to a view of its shard."""
     from . import ops
@@ -663,7 +766,7 @@ def _build_group(owner, emb, names, group, capacity_factor, calibration):
     grp = ShardedEmbeddingGroup([t.table.data for t in tabs], gather_fn, update_fn, group, route_fn=ops.route_build,
                                 rows_fn=ops.route_local_rows, feature_table=ft, presharded=all(pre) and len(pre) > 0,
                                 global_rows=[t.input_dim for t in tabs], capacity_factor=capacity_factor,
-                                calibration=calibration)
+                                calibration=calibration, reduce_fn=_hip_segment_sum, dedup=dedup)
     for t, view in zip(tabs, grp.views):
         t.table.data = view  # drop the replicated copy; keep a view of the local shard
         t.shard = (grp.rank, grp.world_size)
@@ -678,7 +781,7 @@ class DistributedDLRM:
     (``graph_capturable``); one rank (``force_shard``) uses them from the first step."""
 
     def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False,
-                 capacity_factor: float = 1.25, calibration: int = 2):
+                 capacity_factor: float = 1.25, calibration: int = 2, dedup="auto"):
         self.model = model
         self.body = model.body
         self.group = group
@@ -691,7 +794,7 @@ class DistributedDLRM:
         self.sharded_tables: List = []
         if names:
             self.group_sh, self.sharded_tables = _build_group(self, emb, names, group, capacity_factor,
-                                                              0 if self.world_size == 1 else calibration)
+                                                              0 if self.world_size == 1 else calibration, dedup)
         self.sharded_names = names
         self._bucket: Optional[torch.Tensor] = None
         self.replicated = [n for n in self.body.cat_names if n not in names]
@@ -985,6 +1088,10 @@ class DistributedDLRM:
             D = gs.local.shape[1]
             out["a2a_ids"] = (W - 1) * cap * 8
             out["a2a_rows"] = out["a2a_grads"] = (W - 1) * cap * D * 4
+            # de-duplicated route: a window holds the distinct keys of a (sender, owner) pair, not its requests
+            out["dedup"] = bool(gs.dedup)
+            out["window_slots"] = int(cap)
+            out["requests_per_owner"] = (len(self.sharded_names) * batch + W - 1) // W
         if self._bucket is not None and W > 1:
             out["allreduce"] = int(2 * (W - 1) / W * self._bucket.numel() * 4)
         return out
@@ -999,7 +1106,7 @@ class _ShardedEmbeddings:
     and ``_apply_sparse_now`` (backward: sharded gradient rows go to their owners; gradients of replicated tables are
     accumulated as dense [V, D] buffers inside the owner's flat bucket)."""
 
-    def __init__(self, owner, emb, names, group, capacity_factor, calibration):
+    def __init__(self, owner, emb, names, group, capacity_factor, calibration, dedup="auto"):
         from .inputs import EmbeddingsBlock
 
         self.owner, self.emb = owner, emb
@@ -1011,7 +1118,7 @@ class _ShardedEmbeddings:
         for d, ns in by_dim.items():
             holder = type("_G", (), {})()  # update_fn reads .model / .group_sh of its owner: one holder per group
             holder.model = owner.model
-            grp, tabs = _build_group(holder, emb, ns, group, capacity_factor, calibration)
+            grp, tabs = _build_group(holder, emb, ns, group, capacity_factor, calibration, dedup)
             holder.group_sh = grp
             self.groups[d] = (grp, ns)
             self.sharded_tables += tabs
@@ -1188,7 +1295,7 @@ class DistributedModel:
     single-GPU path steps touched rows only, LazyAdam) -- identical for SGD / Adagrad."""
 
     def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False,
-                 capacity_factor: float = 1.25, calibration: int = 2):
+                 capacity_factor: float = 1.25, calibration: int = 2, dedup="auto"):
         from .inputs import EmbeddingsBlock
 
         self.model = model
@@ -1202,7 +1309,7 @@ class DistributedModel:
         for emb in model.blocks_of_type(EmbeddingsBlock):
             names = [n for n, t in emb.feature_table.items()
                      if active and (t.input_dim >= shard_threshold or getattr(t, "shard", None) is not None)]
-            sh = _ShardedEmbeddings(self, emb, names, group, capacity_factor, 0 if W == 1 else calibration)
+            sh = _ShardedEmbeddings(self, emb, names, group, capacity_factor, 0 if W == 1 else calibration, dedup)
             self.shards.append(sh)
             shard_ids |= {id(t.table) for t in sh.sharded_tables}
         for emb in model.blocks_of_type(EmbeddingsBlock):

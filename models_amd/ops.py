@@ -1762,7 +1762,7 @@ def topk_metrics(labels_sorted: torch.Tensor, k: int, relevant_counts: Optional[
 
 # --- multi-GPU: row-sharded embedding exchange --------------------------------------------------
 def route_build(ids: Sequence[torch.Tensor], world_size: int, slots: Optional[Sequence[int]] = None,
-                n_slots: Optional[int] = None, capacity: int = 0, overflow: Optional[torch.Tensor] = None):
+                n_slots: Optional[int] = None, capacity: int = 0, overflow: Optional[torch.Tensor] = None, dedup: bool = False):
     """Send order of the row-sharded lookup (``mh_route_build``): stable counting sort of the F*B requests
     by owner = id % W.  Returns ``(send_keys int64, pos_of [F, B] int64, src_row int64, counts [W] int64)``; see
     include/merlin_hip.h for the meaning of each.  ``capacity`` > 0: fixed windows of that many slots per owner
@@ -1790,10 +1790,21 @@ def route_build(ids: Sequence[torch.Tensor], world_size: int, slots: Optional[Se
     n_send = world_size * int(capacity) if capacity else n
     send_keys = torch.empty(n_send, dtype=torch.int64, device=dev)
     pos_of = torch.empty((F, B), dtype=torch.int64, device=dev)
-    src_row = torch.empty(n_send, dtype=torch.int64, device=dev)
     counts = torch.empty(world_size, dtype=torch.int64, device=dev)
     if overflow is not None:
         _dev(overflow, "overflow", torch.int32)
+    if dedup:
+        # every distinct (feature, id) once per owner (``mh_route_build_dedup``): dense mode fills the first sum(counts) entries of
+        # ``send_keys``; ``pos_of`` maps equal requests to one slot; there is no ``src_row`` (the backward is a segment sum)
+        nbytes = lib.mh_route_dedup_workspace_bytes(n, world_size)
+        if nbytes < 0:
+            raise _lib.MerlinHipError("mh_route_dedup_workspace_bytes failed")
+        ws = _workspace(nbytes, dev, "route_dedup")
+        check(lib.mh_route_build_dedup(_host_ptr_array([i.data_ptr() for i in flat]), idt, F, B, world_size, int(capacity),
+                                       _ptr(send_keys), _ptr(pos_of), _ptr(counts), _ptr(overflow), _ptr(ws), ws.numel(),
+                                       _stream()), "mh_route_build_dedup")
+        return send_keys, pos_of, None, counts
+    src_row = torch.empty(n_send, dtype=torch.int64, device=dev)
     nbytes = lib.mh_route_workspace_bytes(n, world_size)
     if nbytes < 0:
         raise _lib.MerlinHipError("mh_route_workspace_bytes failed")

@@ -217,10 +217,11 @@ def dense_optimizer_step_multi(opt, params):
         p.grad = None
 
 
-def route_build(ids, world_size, slots=None, n_slots=None, capacity=0, overflow=None):
+def route_build(ids, world_size, slots=None, n_slots=None, capacity=0, overflow=None, dedup=False):
     F = len(ids)
     slots = list(range(F)) if slots is None else list(slots)
-    return D.route_build_torch(ids, world_size, slots, (max(slots) + 1) if n_slots is None else n_slots, capacity, overflow)
+    return D.route_build_torch(ids, world_size, slots, (max(slots) + 1) if n_slots is None else n_slots, capacity, overflow,
+                               dedup=dedup)
 
 
 def eltwise(op, a, b, c=None):

@@ -112,6 +112,34 @@ def _worker(rank, world, port, V, Dm, B, q):
             ref_f = fulls[f].clone()
             ref_f.index_add_(0, idg_all[f].reshape(-1), -0.1 * gg_all[:, f].reshape(-1, Dm))
             torch.testing.assert_close(grp2.views[f], D.shard_table(ref_f, rank, world), atol=1e-5, rtol=1e-5)
+        # de-duplicated route on FIXED windows: two small tables, every row asked for many times -- one calibration step (dense
+        # exchange of the distinct keys), then windows sized for the DISTINCT keys, far below the request count; four steps of
+        # lookups + SGD updates equal the full-table reference (the senders sum the gradient rows of equal requests)
+        small = [torch.randn(v, Dm, generator=g) for v in (23, 40)]
+        def gather_pad(table, rows):  # rows -1 (window padding) read as zero rows, like the HIP gather
+            return torch.where((rows >= 0).unsqueeze(1), table[rows.clamp(min=0)], torch.zeros(1, table.shape[1]))
+
+        def update_pad(table, state, rows, grads):
+            ok = rows >= 0
+            table.index_add_(0, rows[ok].long(), -0.1 * grads[ok])
+
+        grp3 = D.ShardedEmbeddingGroup(small, gather_pad, update_pad, dedup="auto", calibration=1)
+        ref3 = [t.clone() for t in small]
+        for step in range(4):
+            ids3 = [torch.randint(0, t.shape[0], (world, B), generator=g) for t in small]
+            g3 = torch.randn(world, 2, B, Dm, generator=g)
+            rows3 = grp3.lookup([i[rank] for i in ids3])
+            for f in range(2):
+                torch.testing.assert_close(rows3[f], ref3[f][ids3[f][rank]], atol=1e-5, rtol=1e-5)
+            dst = torch.zeros(B, 2, Dm)
+            for f in range(2):
+                dst[:, f] = g3[rank, f]
+            grp3.backward_update(None, from_stacked=(dst, [0, 1], lambda tab, idx: tab[idx]))
+            for f in range(2):
+                ref3[f].index_add_(0, ids3[f].reshape(-1), -0.1 * g3[:, f].reshape(-1, Dm))
+                torch.testing.assert_close(grp3.views[f], D.shard_table(ref3[f], rank, world), atol=1e-4, rtol=1e-4)
+        assert grp3.dedup and grp3.capacity is not None and grp3.capacity <= 64 < 2 * B // world and grp3.spills == 0
+        grp3.check_overflow()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -119,6 +147,36 @@ def _worker(rank, world, port, V, Dm, B, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+def test_dedup_route_statement_contract():
+    """``route_build_torch(dedup=True)`` -- the statement the HIP kernel is checked against: every distinct (feature, id) once per
+    owner, owners back to back, first occurrence first; equal requests share a slot; negative ids and keys beyond a fixed window
+    map to -1 (the latter raise the overflow flag)."""
+    W = 3
+    ids = [torch.tensor([7, 4, 7, 1, 4, -2, 10]), torch.tensor([7, 7, 3, 3, 0, 6, 9])]
+    keys, pos, src, counts = D.route_build_torch(ids, W, [0, 1], 2, dedup=True)
+    assert src is None
+    low = (1 << 40) - 1
+    # owner 0: f1:3 f1:0 f1:6 f1:9 | owner 1: f0:7 f0:4 f0:1 f0:10 f1:7 | owner 2: none
+    assert counts.tolist() == [4, 5, 0]
+    assert [(int(k) >> 40, int(k) & low) for k in keys] == [(1, 1), (1, 0), (1, 2), (1, 3), (0, 2), (0, 1), (0, 0), (0, 3), (1, 2)]
+    assert pos.tolist() == [[4, 5, 4, 6, 5, -1, 7], [8, 8, 0, 0, 1, 2, 3]]
+    # fixed windows of 3 slots: the 4th key of owner 0 and the 4th / 5th of owner 1 fall out, with every request for them
+    over = torch.zeros(1, dtype=torch.int32)
+    keys, pos, _, counts = D.route_build_torch(ids, W, [0, 1], 2, capacity=3, overflow=over, dedup=True)
+    assert int(over) == 1 and counts.tolist() == [4, 5, 0] and keys.numel() == 9
+    assert [int(k) for k in keys[6:]] == [-1, -1, -1]
+    assert pos.tolist() == [[3, 4, 3, 5, 4, -1, -1], [-1, -1, 0, 0, 1, 2, -1]]
+    # the gradient rows of equal requests are summed into their slot
+    dstack = torch.arange(7 * 2 * 2, dtype=torch.float32).reshape(7, 2, 2)
+    send = D.segment_sum_torch(dstack, [0, 1], pos, 9)
+    want = torch.zeros(9, 2)
+    for f in range(2):
+        for b in range(7):
+            if pos[f, b] >= 0:
+                want[pos[f, b]] += dstack[b, f]
+    assert torch.equal(send, want)
 
 
 @pytest.mark.parametrize("world", [2])
@@ -189,7 +247,7 @@ def _dlrm_batches(cards, world, B, steps, seed=11, skew_from=None):
     return out
 
 
-def _dlrm_worker(rank, world, port, q, skew=False):
+def _dlrm_worker(rank, world, port, q, skew=False, dedup=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -202,13 +260,14 @@ def _dlrm_worker(rank, world, port, q, skew=False):
         model, schema, cards = _dlrm_parts()
         batches = _dlrm_batches(cards, world, B, steps, skew_from=3 if skew else None)
         model({k: v[rank] for k, v in batches[0][0].items()})  # build lazily-shaped layers
-        dd = D.DistributedDLRM(model, shard_threshold=1000)
+        dd = D.DistributedDLRM(model, shard_threshold=1000, dedup=dedup)
         assert sorted(dd.sharded) == ["C1", "C3"]
+        assert dd.group_sh.dedup == (dedup is not False)  # "auto": on at world 2 until calibration says otherwise
         losses = []
         for x, y in batches:
             losses.append(float(dd.train_step({k: v[rank] for k, v in x.items()}, y[rank])))
         # numpy (pickled by value): tensors would travel as file descriptors of a process that is about to exit
-        state = {"loss": losses, "spills": dd.group_sh.spills, "capacity": dd.group_sh.capacity,
+        state = {"loss": losses, "spills": dd.group_sh.spills, "capacity": dd.group_sh.capacity, "dedup": dd.group_sh.dedup,
                  "dense": [p.data.numpy().copy() for p in model.parameters() if not p.sparse],
                  "rep": {n: model.body.embeddings.feature_table[n].table.data.numpy().copy() for n in dd.replicated},
                  "shard": {n: dd.sharded[n].numpy().copy() for n in dd.sharded}}
@@ -222,14 +281,17 @@ def _dlrm_worker(rank, world, port, q, skew=False):
         dist.destroy_process_group()
 
 
-@_pytest.mark.parametrize("skew", [False, True])
-def test_distributed_dlrm_step_world2_matches_full_batch_model(skew):
+@_pytest.mark.parametrize("skew,dedup", [(False, False), (True, False), (False, True), (True, True), (True, "auto")])
+def test_distributed_dlrm_step_world2_matches_full_batch_model(skew, dedup):
     """Two ranks, half a batch each, row-sharded C1/C3 + replicated C2/C4: after three Adagrad steps every rank
     holds the parameters a single model trained on the concatenated batch holds (and reports its loss).
     skew: after the windows were frozen (two calibration steps + one fixed step) every sharded id becomes even -- all requests go
     to rank 0, twice the calibrated count: the window overflows.  No request may be lost: the ranks agree on the overflow right
     behind the route kernel, that call is served by the dense exchange and the window is re-derived (SOK never drops,
-    tf/distributed/embedding.py:144-148) -- the parameters still equal the single model's, which a dropped row would break."""
+    tf/distributed/embedding.py:144-148) -- the parameters still equal the single model's, which a dropped row would break.
+    dedup: every distinct (feature, id) travels once per (sender, owner) and its gradient rows are summed before they are sent --
+    the same parameters again (sums of the same rows in another order); "auto" finds (almost) no duplicates in these batches
+    (400 requests over 4001 / 2500 rows) and switches the de-duplication off at the end of calibration, on both ranks alike."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import ops_shim
     from models_amd import ops
@@ -238,13 +300,15 @@ def test_distributed_dlrm_step_world2_matches_full_batch_model(skew):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dlrm_worker, args=(r, world, port, q, skew)) for r in range(world)]
+    procs = [ctx.Process(target=_dlrm_worker, args=(r, world, port, q, skew, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(30)
     assert all(m == "ok" for _, m, _ in res), [m for _, m, _ in res]
+    if dedup == "auto":
+        assert [st["dedup"] for _, _, st in res] == [False, False]
     # single-process reference on the full batch (same shim ops, plain RankingModel.train_step)
     saved = {n: getattr(ops, n) for n in dir(ops)}
     try:
@@ -261,8 +325,10 @@ def test_distributed_dlrm_step_world2_matches_full_batch_model(skew):
             setattr(ops, n, v)
     ref_dense = [p.data for p in model.parameters() if not p.sparse]
     for rank, _, st in res:
-        if skew:  # exactly one call overflowed (the first skewed one); the re-derived window holds the later ones
+        if skew and dedup != "auto":  # exactly one call overflowed (the first skewed one); the re-derived window holds the later ones
             assert st["spills"] == 1 and st["capacity"] is not None and st["capacity"] >= 2 * B, (st["spills"], st["capacity"])
+        elif skew:  # "auto" calibrated a second time, without the de-duplication, over the skewed steps: their counts made the window
+            assert st["spills"] == 0 and st["capacity"] >= 2 * B
         else:
             assert st["spills"] == 0
         np.testing.assert_allclose(st["loss"], ref_losses, rtol=1e-5, atol=1e-6)

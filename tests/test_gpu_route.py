@@ -153,3 +153,65 @@ def test_comm_sharded_lookup_single_rank_matches_direct_path(opt, rccl, monkeypa
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(flat, keep)
     c.destroy()
+
+
+@pytest.mark.parametrize("W", [1, 2, 8, 64])
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("F,B,card", [(1, 1, 5), (3, 257, 40), (8, 4099, 1 << 20), (26, 2048, 300), (26, 65536, 20000)])
+def test_route_build_dedup_matches_statement(W, dtype, F, B, card):
+    """``mh_route_build_dedup`` (hash leader election + counting sort of the leaders) against the framework-op statement, bit for
+    bit: the send slot of a key is the rank of its FIRST occurrence among its owner's distinct keys, whatever order the atomics
+    ran in.  card = 40 / 300: nearly every request is a duplicate; 2^20: nearly none."""
+    from models_amd import ops
+    from models_amd.distributed import route_build_torch
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(F * 1000 + B + W)
+    ids = [torch.randint(0, card, (B,), generator=g).to(dtype).to(dev) for _ in range(F)]
+    if B > 4:
+        ids[0][3] = -5  # a negative id: no owner has it (pos_of -1), and it must not poison the table
+    keys, pos, src, counts = ops.route_build(ids, W, dedup=True)
+    wk, wp, ws, wc = route_build_torch(ids, W, list(range(F)), F, dedup=True)
+    assert src is None and ws is None
+    assert torch.equal(counts, wc)
+    total = int(wc.sum())
+    assert keys.numel() == F * B and torch.equal(keys[:total], wk)
+    assert torch.equal(pos, wp)
+    for run in range(2):  # same answer again (atomics race differently; the workspace is reused)
+        k2, p2, _, c2 = ops.route_build(ids, W, dedup=True)
+        assert torch.equal(k2[:total], wk) and torch.equal(p2, wp) and torch.equal(c2, wc)
+
+
+@pytest.mark.parametrize("W,cap,card", [(2, 4096, 3000), (8, 64, 5000), (8, 128, 600)])
+def test_route_build_dedup_fixed_windows_match_statement(W, cap, card):
+    from models_amd import ops
+    from models_amd.distributed import route_build_torch
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(W * 7 + cap)
+    F, B = 6, 3001
+    ids = [torch.randint(0, card, (B,), generator=g).to(dev) for _ in range(F)]
+    over, wover = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    keys, pos, _, counts = ops.route_build(ids, W, capacity=cap, overflow=over, dedup=True)
+    wk, wp, _, wc = route_build_torch(ids, W, list(range(F)), F, capacity=cap, overflow=wover, dedup=True)
+    assert torch.equal(keys, wk) and torch.equal(pos, wp) and torch.equal(counts, wc) and int(over) == int(wover)
+    assert int(over) == int(bool((wc > cap).any()))
+
+
+def test_dedup_segment_sum_through_the_fused_update():
+    """The sender side of a de-duplicated backward: gradient rows of equal requests summed into their send slot by
+    ``mh_embedding_gather_bwd`` (SGD, lr = -1, onto zeros) == the framework-op statement."""
+    from models_amd import ops
+    from models_amd.distributed import _hip_segment_sum, route_build_torch, segment_sum_torch
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    F, B, D, W = 5, 3000, 16, 4
+    ids = [torch.randint(0, 500, (B,), generator=g).to(dev) for _ in range(F)]
+    keys, pos, _, counts = ops.route_build(ids, W, capacity=640, overflow=torch.zeros(1, dtype=torch.int32, device=dev), dedup=True)
+    dstack = torch.randn(B, F + 2, D, generator=g).to(dev)
+    slots = [6, 0, 3, 1, 4]
+    got = _hip_segment_sum(dstack, slots, pos, keys.numel())
+    want = segment_sum_torch(dstack.cpu().double(), slots, pos.cpu(), keys.numel())
+    torch.testing.assert_close(got.cpu().double(), want, atol=1e-5, rtol=1e-5)
+    assert bool((got[keys < 0] == 0).all())  # padding slots carry no gradient

@@ -67,7 +67,7 @@ def _batches(cards, world, B, steps, seed=11, skew_from=None):
     return out
 
 
-def _worker(rank, world, port, q, skew=False):
+def _worker(rank, world, port, q, skew=False, dedup=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -84,11 +84,13 @@ def _worker(rank, world, port, q, skew=False):
         batches = _batches(cards, world, B, steps, skew_from=3 if skew else None)
         mine = lambda x: {k: v[rank].to(dev) for k, v in x.items()}
         model(mine(batches[0][0]))
-        dd = D.DistributedDLRM(model, shard_threshold=1000)
-        assert sorted(dd.sharded) == ["C1", "C3", "C5"]
+        dd = D.DistributedDLRM(model, shard_threshold=1000, dedup=dedup)
+        assert sorted(dd.sharded) == ["C1", "C3", "C5"] and dd.group_sh.dedup == dedup
         losses = [float(dd.train_step(mine(x), y[rank].to(dev))) for x, y in batches]
         dd.check_overflow()
         assert dd.group_sh.spills == (1 if skew else 0), dd.group_sh.spills  # the first skewed call overflowed its window: served densely
+        if dedup and not skew:  # the windows hold DISTINCT keys: 1.25 x ~half of them, below the request count 3 x 512
+            assert dd.group_sh.capacity < 3 * B, dd.group_sh.capacity
         assert model.body._fused, "the sharded step should run the fused gather -> interaction kernels"
         pred = dd(mine(batches[0][0])).cpu().numpy()
         state = {"loss": losses, "pred": pred,
@@ -104,9 +106,11 @@ def _worker(rank, world, port, q, skew=False):
         q.put((rank, "FAIL: " + traceback.format_exc(), None))
 
 
+@pytest.mark.parametrize("dedup", [False, True])
 @pytest.mark.parametrize("skew", [False, True])
-def test_sharded_dlrm_step_world2_on_hip_matches_the_full_batch_model(device, skew):
-    """skew: after the windows are frozen every sharded id becomes even (all requests to rank 0, twice the calibrated count):
+def test_sharded_dlrm_step_world2_on_hip_matches_the_full_batch_model(device, skew, dedup):
+    """dedup: mh_route_build_dedup + the sender-side segment sum of the gradient rows (the fused sparse update onto zeros).
+    skew: after the windows are frozen every sharded id becomes even (all requests to rank 0, twice the calibrated count):
     the overflowing call must be served without losing a request (dense exchange, window re-derived) -- through the real route
     kernels, with a rank that owns NONE of the requested rows (zero-row gathers and updates)."""
     import torch.multiprocessing as mp
@@ -117,7 +121,7 @@ def test_sharded_dlrm_step_world2_on_hip_matches_the_full_batch_model(device, sk
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, skew)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, skew, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
