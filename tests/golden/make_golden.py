@@ -210,6 +210,94 @@ def dense_mlp(out, g):
     out.update(mlp_x=x, mlp_y=h.detach(), mlp_layers=np.array([type(m).__name__ for m in mods]))
 
 
+def batchnorm_mlp(out, g):
+    """Dense -> BatchNormalization (``MLPBlock(normalization=...)``, tf/blocks/mlp.py:129-135) through the reference's torch
+    MLPBlock, whose __init__ places the normalization module it is handed behind `Linear -> activation` (torch/blocks/mlp.py:
+    70-76).  The module carries Keras' constants (epsilon 1e-3; Keras momentum 0.99 = torch momentum 0.01): the training-mode
+    output, its gradients under autograd, the moving mean after one training call and the inference-mode output are then the
+    Keras layer's.  One documented difference: torch feeds the UNBIASED batch variance into running_var, Keras the biased one --
+    the fixture stores torch's running_var and the batch size; the test converts."""
+    tree = ast.parse((REF / "merlin/models/torch/blocks/mlp.py").read_text())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "MLPBlock")
+    init = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    init.decorator_list = []
+    for a in init.args.args + init.args.kwonlyargs:
+        a.annotation = None
+    captured = {}
+    src = ast.unparse(init).replace("super().__init__", "_capture")
+    ns = {"nn": torch.nn, "_capture": lambda *m, **kw: captured.__setitem__("modules", list(m))}
+    exec(src, ns)
+    din, n, M = 11, 24, 29
+    bn = torch.nn.BatchNorm1d(n, eps=1e-3, momentum=0.01)
+    ns["__init__"](types.SimpleNamespace(), [n], normalization=bn, pre_agg=torch.nn.Identity())
+    mods = captured["modules"]
+    lin = torch.nn.Linear(din, n)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(n, din, generator=g) * 0.4)
+        lin.bias.copy_(torch.randn(n, generator=g) * 0.1)
+        bn.weight.copy_(1.0 + 0.3 * torch.randn(n, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(n, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(n, generator=g))
+        bn.running_var.copy_(1.0 + 0.2 * torch.rand(n, generator=g))
+    out.update(bn_W=lin.weight.detach().T.contiguous(), bn_b=lin.bias.detach().clone(), bn_gamma=bn.weight.detach().clone(),
+               bn_beta=bn.bias.detach().clone(), bn_mean0=bn.running_mean.clone(), bn_var0=bn.running_var.clone())
+    mods = [lin if isinstance(m, torch.nn.LazyLinear) else m for m in mods]
+    x = torch.randn(M, din, generator=g, requires_grad=True)
+    dy = torch.randn(M, n, generator=g)
+
+    def run(inp):
+        h = inp
+        for m in mods:
+            h = m(h)
+        return h
+
+    bn.train()
+    y = run(x)
+    y.backward(dy)
+    out.update(bn_x=x.detach().clone(), bn_dy=dy, bn_y_train=y.detach().clone(), bn_dx=x.grad.clone(),
+               bn_dW=lin.weight.grad.T.contiguous().clone(), bn_db=lin.bias.grad.clone(), bn_dgamma=bn.weight.grad.clone(),
+               bn_dbeta=bn.bias.grad.clone(), bn_mean1=bn.running_mean.clone(), bn_var1_unbiased=bn.running_var.clone(),
+               bn_layers=np.array([type(m).__name__ for m in captured["modules"]]))
+    bn.eval()
+    with torch.no_grad():
+        out["bn_y_infer"] = run(x.detach()).clone()
+
+
+def adagrad_steps(out, g):
+    """Adagrad through the optimizer the reference's `create_optimizer(module, "adagrad")` builds (torch/models/base.py:443-480,
+    executed from source: `optim.Adagrad(params, lr=0.01)`), with Keras' initial accumulator 0.1 and epsilon 1e-7 written into
+    its param group / state: two steps on a table whose gradient comes from autograd of a lookup with DUPLICATE ids (their
+    rows' gradients are summed before the update: Keras' _deduplicate_indexed_slices; rows that were not looked up have
+    gradient 0 and do not move)."""
+    import typing
+
+    V, D = 17, 8
+    create_optimizer = load("merlin/models/torch/models/base.py", "create_optimizer", None,
+                            {"optim": torch.optim, "nn": torch.nn, "Iterator": typing.Iterator})
+    table = torch.nn.Embedding(V, D)
+    with torch.no_grad():
+        table.weight.copy_(torch.randn(V, D, generator=g))
+    opt = create_optimizer(table, "adagrad")
+    assert type(opt).__name__ == "Adagrad" and opt.param_groups[0]["lr"] == 0.01
+    opt.param_groups[0]["eps"] = 1e-7                      # Keras' epsilon
+    opt.state[table.weight]["sum"].fill_(0.1)             # Keras' initial_accumulator_value
+    out.update(ada_w0=table.weight.detach().clone(), ada_lr=np.float32(0.01))
+    ids, dys = [], []
+    for step in range(2):
+        i = torch.randint(0, V, (12,), generator=g)
+        i[5] = i[0]
+        i[7] = i[0]                                        # a row looked up three times
+        dy = torch.randn(12, D, generator=g)
+        opt.zero_grad()
+        table(i).backward(dy)
+        opt.step()
+        ids.append(i)
+        dys.append(dy)
+        out[f"ada_w{step + 1}"] = table.weight.detach().clone()
+        out[f"ada_acc{step + 1}"] = opt.state[table.weight]["sum"].clone()
+    out.update(ada_ids=torch.stack(ids), ada_dy=torch.stack(dys))
+
+
 def main():
     g = torch.Generator().manual_seed(20260925)
     out = {}
@@ -337,6 +425,8 @@ def main():
     # --- DLRM top-MLP input layout (appended: earlier draws are unchanged) ----------------------------------------
     dlrm_layout(out, g)
     dense_mlp(out, g)
+    batchnorm_mlp(out, g)  # appended: the generator state of everything above is unchanged
+    adagrad_steps(out, g)
 
     np.savez_compressed(OUT / "reference_vectors.npz",
                         **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})

@@ -82,6 +82,45 @@ def test_oracle_dense_matches_reference_mlp_block():
     np.testing.assert_allclose(O.mlp(G["mlp_x"], layers), G["mlp_y"], atol=1e-5, rtol=1e-5)
 
 
+def _bn_keras_var(var_torch, var0, m_rows, momentum=0.99):
+    """torch feeds the UNBIASED batch variance into running_var, Keras the biased one: the fixture's running_var in Keras'
+    convention (same batch, same momentum)."""
+    batch_unbiased = (var_torch - momentum * var0) / (1.0 - momentum)
+    return momentum * var0 + (1.0 - momentum) * batch_unbiased * (m_rows - 1) / m_rows
+
+
+def test_oracle_batchnorm_matches_reference_mlp_block():
+    """BatchNormalization pinned through the reference's torch MLPBlock (Linear -> ReLU -> the normalization module it was
+    handed, torch/blocks/mlp.py:65-76) with Keras' constants: training output, moving mean, moving variance (converted from
+    torch's unbiased convention), inference output."""
+    assert [str(m) for m in G["bn_layers"]] == ["Identity", "LazyLinear", "ReLU", "BatchNorm1d"]
+    h = O.mlp(G["bn_x"], [(G["bn_W"], G["bn_b"], "relu")])
+    y, mean1, var1 = O.batchnorm_train(h, G["bn_gamma"], G["bn_beta"], G["bn_mean0"], G["bn_var0"])
+    np.testing.assert_allclose(y, G["bn_y_train"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(mean1, G["bn_mean1"], atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(var1, _bn_keras_var(G["bn_var1_unbiased"], G["bn_var0"], h.shape[0]), atol=1e-6, rtol=1e-6)
+    yi = O.batchnorm_infer(h, G["bn_gamma"], G["bn_beta"], G["bn_mean1"], G["bn_var1_unbiased"])
+    np.testing.assert_allclose(yi, G["bn_y_infer"], atol=2e-5, rtol=1e-5)
+
+
+def test_oracle_sparse_adagrad_matches_reference_optimizer():
+    """Adagrad pinned through the optimizer the reference's torch `create_optimizer(module, "adagrad")` builds (fixture ada_*:
+    Keras' accumulator start 0.1 and epsilon 1e-7 written into it): two IndexedSlices steps of the oracle -- duplicates summed,
+    only looked-up rows touched -- leave the table and the accumulator where the reference's optimizer leaves them."""
+    w, acc = G["ada_w0"].copy(), np.full_like(G["ada_w0"], 0.1)
+    for step in range(2):
+        ids, dy = G["ada_ids"][step], G["ada_dy"][step]
+        uniq, inv = np.unique(ids, return_inverse=True)
+        assert len(uniq) < len(ids)  # the fixture has duplicate ids
+        gsum = np.zeros((len(uniq), w.shape[1]), dtype=np.float32)
+        np.add.at(gsum, inv, dy)
+        w_rows, s_rows = w[uniq], acc[uniq]
+        O._optimizer_update(w_rows, gsum, s_rows, "adagrad", float(G["ada_lr"]))
+        w[uniq], acc[uniq] = w_rows, s_rows
+        np.testing.assert_allclose(w, G[f"ada_w{step + 1}"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(acc, G[f"ada_acc{step + 1}"], atol=1e-6, rtol=1e-5)
+
+
 # ---- the same vectors through the HIP path ------------------------------------------------------
 @pytest.mark.gpu
 def test_hip_dlrm_top_input_layout_matches_reference_key_logic(device):
@@ -215,3 +254,58 @@ def test_hip_losses_match_the_reference_loss_classes(device):
     for mat in (True, False):
         r = ops.inbatch_softmax(t(G["sc_q"]), t(G["sc_pos"]), t(G["sc_pos"]), ids, ids, materialize=mat)
         np.testing.assert_allclose(r.loss.mean().item(), G["ce_loss"], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_batchnorm_mlp_block_matches_reference_mlp_block(device):
+    """``mm.MLPBlock([24], normalization="batch_norm")`` with the fixture's weights: training output, every gradient of the
+    reference's autograd pass, the moving statistics after one training call, and the inference output."""
+    import torch
+
+    import models_amd as mm
+    from models_amd import blocks
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    blk = mm.MLPBlock([24], normalization="batch_norm", device=device)
+    dense, bn = blk.layers
+    x = t(G["bn_x"])
+    blk(x)  # build
+    dense.kernel.data.copy_(t(G["bn_W"]))
+    dense.bias.data.copy_(t(G["bn_b"]))
+    bn.gamma.data.copy_(t(G["bn_gamma"]))
+    bn.beta.data.copy_(t(G["bn_beta"]))
+    bn.moving_mean.copy_(t(G["bn_mean0"]))
+    bn.moving_variance.copy_(t(G["bn_var0"]))
+    with blocks.tape():
+        y = blk(x)
+    np.testing.assert_allclose(y.cpu().numpy(), G["bn_y_train"], atol=ATOL, rtol=1e-5)
+    dx = blk.backward(t(G["bn_dy"]).clone())
+    np.testing.assert_allclose(dx.cpu().numpy(), G["bn_dx"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(dense.kernel.grad.cpu().numpy(), G["bn_dW"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(dense.bias.grad.cpu().numpy(), G["bn_db"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(bn.gamma.grad.cpu().numpy(), G["bn_dgamma"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(bn.beta.grad.cpu().numpy(), G["bn_dbeta"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(bn.moving_mean.cpu().numpy(), G["bn_mean1"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(bn.moving_variance.cpu().numpy(),
+                               _bn_keras_var(G["bn_var1_unbiased"], G["bn_var0"], x.shape[0]), atol=1e-6, rtol=1e-5)
+    bn.moving_variance.copy_(t(G["bn_var1_unbiased"]))  # the statistics the reference's inference call used
+    np.testing.assert_allclose(blk(x).cpu().numpy(), G["bn_y_infer"], atol=ATOL, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deterministic", ["0", "1"])
+def test_hip_sparse_adagrad_matches_reference_optimizer(device, deterministic, monkeypatch):
+    """``mh_embedding_gather_bwd`` (Adagrad) on the fixture of the reference's optimizer: table and accumulator after two steps."""
+    import torch
+
+    from models_amd import ops
+
+    monkeypatch.setenv("MERLIN_HIP_DETERMINISTIC", deterministic)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    w, acc = t(G["ada_w0"]), torch.full(G["ada_w0"].shape, 0.1, device=device)
+    for step in range(2):
+        ids, dy = t(G["ada_ids"][step]), t(G["ada_dy"][step])
+        ops.embedding_gather_backward([w], [acc], [ids], dy.reshape(dy.shape[0], 1, -1).contiguous(), [0], "adagrad",
+                                      float(G["ada_lr"]), 1e-7)
+        np.testing.assert_allclose(w.cpu().numpy(), G[f"ada_w{step + 1}"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(acc.cpu().numpy(), G[f"ada_acc{step + 1}"], atol=1e-6, rtol=1e-5)
