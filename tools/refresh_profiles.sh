@@ -3,7 +3,7 @@
 #   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
-timeout 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # HBM traffic of the HBM-bound launches FIRST, and into profiles/ on this box: the bench lines below then carry roofline.traffic
 # measured with exactly the kernels they time (bench.py refuses a file stamped with other kernel sources)
@@ -31,5 +31,9 @@ done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python bench.py --no-cpu-baseline --no-secondary --sustain 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/twotower -o w -- python bench.py --workload twotower --no-cpu-baseline --steps 5 --warmup 2 --sustain 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcn -o d -- python bench.py --workload dcn --no-cpu-baseline --steps 3 --warmup 1 --sustain 0 > /dev/null 2>&1
-for w in train twotower dcn; do cp $(ls $O/$w/*kernel_stats.csv | head -1) $O/bench_${w}_kernel_stats.csv; rm -rf $O/$w; done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/topk -o k -- python bench.py --workload topk --no-cpu-baseline --steps 3 --warmup 2 --sustain 0 > /dev/null 2>&1
+for w in train twotower dcn topk; do cp $(ls $O/$w/*kernel_stats.csv | head -1) $O/bench_${w}_kernel_stats.csv; rm -rf $O/$w; done
+# warmed-up forward scorer: stream vs tiled kernel on the same inputs, and the launch-mode A/B of the headline step
+timeout 300 python tools/dbg/scorer_probe.py > $O/scorer_probe.txt 2>&1
+timeout 300 python tools/dbg/route_probe.py > $O/route_probe.txt 2>&1
 ls -la $O
