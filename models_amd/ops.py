@@ -228,7 +228,10 @@ class _SideStreams:
         dev = torch.cuda.current_device()
         st = self._streams.get((dev, name))
         if st is None:
-            st = torch.cuda.Stream(device=dev)
+            # MERLIN_HIP_SIDE_PRIORITY=-1: a high-priority HIP stream for the side work (experiments; 0 = default priority)
+            import os as _os
+
+            st = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MERLIN_HIP_SIDE_PRIORITY", "0")))
             self._streams[(dev, name)] = st
         return st
 
