@@ -93,8 +93,17 @@ struct MhComm {
 // multi-GPU step: the product path at W == 1 aliases instead, see models_amd/distributed.py).  A one-rank communicator that
 // was created WITH a unique id owns a real RCCL communicator and takes the RCCL path below (send / recv to itself): the
 // single-GPU execution of exactly the code an N-rank job runs.
+int32_t alltoall_issue(RcclApi* R, MhComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s, const char* what);
+
+// While the library records a step's launch sequence (mh_record_begin), a collective is part of that sequence: it is kept as a
+// closure over its by-value arguments like a kernel launch and re-issued by mh_record_replay in the same place.
 int32_t alltoall_bytes(RcclApi* R, MhComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s, const char* what) {
     if (bytes <= 0) return MH_OK;
+    if (mh_recording()) mh_record_op([=]() { (void)alltoall_issue(R, c, send, recv, bytes, s, what); });
+    return alltoall_issue(R, c, send, recv, bytes, s, what);
+}
+
+int32_t alltoall_issue(RcclApi* R, MhComm* c, const void* send, void* recv, int64_t bytes, hipStream_t s, const char* what) {
     if (c->world == 1 && !c->comm) {
         if (hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             mh_set_error("%s: device copy failed", what);
@@ -197,6 +206,8 @@ int32_t mh_comm_alltoall(void* comm, const void* send, void* recv, int64_t bytes
     return alltoall_bytes(rccl(), c, send, recv, bytes_per_peer, mh_stream(stream), "mh_comm_alltoall");
 }
 
+static int32_t allreduce_issue(RcclApi* R, MhComm* c, float* buf, int64_t n, hipStream_t s);
+
 int32_t mh_allreduce_dense(void* comm, float* buf, int64_t n, mh_stream_t stream) {
     MhComm* c = static_cast<MhComm*>(comm);
     MH_REQUIRE(c && (buf || n == 0) && n >= 0, "mh_allreduce_dense: bad argument");
@@ -204,6 +215,11 @@ int32_t mh_allreduce_dense(void* comm, float* buf, int64_t n, mh_stream_t stream
     RcclApi* R = rccl();
     MH_REQUIRE(R, "mh_allreduce_dense: librccl.so not found");
     hipStream_t s = mh_stream(stream);
+    if (mh_recording()) mh_record_op([=]() { (void)allreduce_issue(R, c, buf, n, s); });  // see alltoall_bytes
+    return allreduce_issue(R, c, buf, n, s);
+}
+
+static int32_t allreduce_issue(RcclApi* R, MhComm* c, float* buf, int64_t n, hipStream_t s) {
     // MERLIN_HIP_ALLREDUCE=plain: one ncclAllReduce also for divisible sizes (A/B of the two forms; the only way to reach the
     // plain form on a one-rank communicator, where every n is divisible)
     const char* form = getenv("MERLIN_HIP_ALLREDUCE");  // read per call: a host-side string compare beside a collective

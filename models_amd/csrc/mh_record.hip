@@ -4,8 +4,11 @@
 // `make_train_function`): trace the step once, then run it without re-entering Python.  Here the "trace" is not a graph handed to a
 // runtime: it is the literal list of HIP launches and event hand-offs the eager step issued, on the streams it issued them on.
 // Why not a hipGraph: ROCm 7.2 replays a captured graph on one hardware queue (no overlap between its branches: measured in rounds
-// 2-3), and per-stream graph segments pay ~10 us of launch overhead each plus their hand-offs; the eager step has the overlap but
-// issues ~35 launches from Python and is host-bound in stretches (two more Python-issued calls cost it 20 us, round 4).
+// 2-3), and per-stream graph segments pay ~10 us of launch overhead each plus their hand-offs.  What the recorder settled (round 4,
+// profiles/r4_notes.md): replayed from C with nothing between the launches, the DLRM step takes 0.957-0.960 ms against 0.945-0.950
+// for the same launches issued from Python -- the step is bound by its GPU critical path, not by its host.  The recorder stays as
+// the host-free launch mode for hosts slower than the one measured (bench.py --launch recorded, graph.RecordedStep).
+// Collectives of the C-ABI communicator (mh_comm.hip) are recorded and replayed like launches.
 #include "mh_common.h"
 
 #include <vector>

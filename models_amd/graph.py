@@ -108,8 +108,10 @@ class _KeepAllocations:
         keep = self.keep = []
         impure = self.impure = []  # aten ops that launch kernels of their own: a recorded step would not replay them
         pure = ("empty", "view", "as_strided", "slice", "select", "reshape", "unsqueeze", "squeeze", "expand", "permute",
-                "transpose", "detach", "alias", "t.default", "split", "unbind", "narrow", "_unsafe_view", "_local_scalar_dense",
-                "_to_copy", "lift_fresh", "is_pinned", "stride", "size", "numel", "storage_offset", "sym_")
+                "transpose", "detach", "alias", "t.default", "split", "unbind", "narrow", "_unsafe_view", "lift_fresh",
+                "is_pinned", "stride", "size", "numel", "storage_offset", "sym_")
+        # NOT in the list on purpose: _to_copy of a device tensor (a conversion / copy kernel) and _local_scalar_dense (``.item()``:
+        # a host read the replay would not repeat -- a step that branches on one cannot be recorded)
 
         class _Mode(TorchDispatchMode):
             def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -141,10 +143,12 @@ class RecordedStep:
     kernel launch with its arguments by value, on the stream it was issued on, plus the event hand-offs between the streams, which
     ``ops.SIDE`` issues through the library while ``crec`` is set) and replayed by ONE C call per step (``mh_record_replay``).
 
-    What the three other launch modes cost: eager launches from Python are host-bound in stretches (~35 launches and a dozen stream /
-    event operations per step); ONE hipGraph replays on one hardware queue (no overlap); per-stream graph segments
-    (``SegmentedStep``) keep the overlap but pay a graph launch + hand-off per segment.  The recorded sequence is the eager step's
-    own sequence -- same streams, same overlap -- issued from C.  Same contract as a captured graph: static inputs (every batch is
+    What the three other launch modes cost: eager launches need ~0.75 ms of Python per step (~35 launches and a dozen stream /
+    event operations); ONE hipGraph replays on one hardware queue (no overlap); per-stream graph segments (``SegmentedStep``) keep
+    the overlap but pay a graph launch + hand-off per segment.  The recorded sequence is the eager step's own sequence -- same
+    streams, same overlap -- issued from C.  Measured (round 4, ``profiles/r4_notes.md``): 0.957-0.960 ms against 0.945-0.950 for
+    the eager step on the same box -- on that host the step is bound by its GPU critical path, so eager stays the default and this
+    class is the host-free mode for slower hosts.  Same contract as a captured graph: static inputs (every batch is
     staged into them), fixed shapes, no host-side decision inside the step; the step must consist of library launches only (a torch
     kernel inside it would not be replayed: ``assert_pure`` checks the recording against a kernel-free torch dispatch).
     Same interface as ``GraphedStep`` / ``SegmentedStep``."""

@@ -215,3 +215,39 @@ def test_dedup_segment_sum_through_the_fused_update():
     want = segment_sum_torch(dstack.cpu().double(), slots, pos.cpu(), keys.numel())
     torch.testing.assert_close(got.cpu().double(), want, atol=1e-5, rtol=1e-5)
     assert bool((got[keys < 0] == 0).all())  # padding slots carry no gradient
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_recorded_collectives_are_replayed(rccl):
+    """A collective of the C-ABI communicator issued while the library records a step's launch sequence is part of the recording
+    (``mh_record_*``): the replay moves the data again -- through RCCL on the one-rank communicator, a device copy without one."""
+    import ctypes as C
+
+    from models_amd import _lib, comm as mc
+
+    dev = _dev()
+    lib = _lib.load()
+    c = mc.Comm.create(force_rccl=rccl)
+    send = torch.arange(4096, dtype=torch.float32, device=dev)
+    recv = torch.zeros_like(send)
+    flat = torch.full((1024,), 3.0, device=dev)
+    _lib.check(lib.mh_record_begin(), "mh_record_begin")
+    try:
+        c.alltoall(send, recv)
+        c.allreduce_(flat)
+    except Exception:
+        lib.mh_record_abort()
+        raise
+    h = C.c_void_p()
+    _lib.check(lib.mh_record_end(C.byref(h)), "mh_record_end")
+    n, e = C.c_int64(), C.c_int64()
+    _lib.check(lib.mh_record_info(h, C.byref(n), C.byref(e)), "mh_record_info")
+    assert n.value == (2 if rccl else 1)  # without RCCL a one-rank all-reduce is nothing at all
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send)
+    send.mul_(2.0)
+    recv.zero_()
+    _lib.check(lib.mh_record_replay(h), "mh_record_replay")
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send) and bool((flat == 3.0).all())  # a one-rank sum leaves the bucket as it is
+    lib.mh_record_free(h)
