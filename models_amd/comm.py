@@ -30,7 +30,9 @@ class _Work:
         self.event, self.keep = event, keep
 
     def wait(self) -> None:
-        torch.cuda.current_stream().wait_event(self.event)
+        from .ops import SIDE
+
+        SIDE._ev_wait(torch.cuda.current_stream(), self.event)  # a recorded hand-off while the library records the step
         self.keep = None
 
 
@@ -126,12 +128,16 @@ class Comm:
         return self._stream
 
     def _async(self, fn, keep) -> _Work:
+        from .ops import SIDE
+
         st = self.side_stream()
-        st.wait_stream(torch.cuda.current_stream())
+        # the hand-offs to and from the communicator's stream go through ops.SIDE's event helpers: framework events in eager
+        # steps, the library's own while it records the step's launch sequence (graph.RecordedStep) -- a replay then repeats
+        # them together with the collective itself
+        SIDE._ev_wait(st, SIDE._ev_record())  # == st.wait_stream(current stream)
         with torch.cuda.stream(st):
             fn()
-            ev = torch.cuda.Event()
-            ev.record()
+            ev = SIDE._ev_record(st)
         return _Work(ev, keep)
 
     def alltoall_async(self, send: torch.Tensor, recv: torch.Tensor) -> _Work:

@@ -742,9 +742,19 @@ def _hip_segment_sum(dstack, slots, pos_of, n_send):
     B, F, D = dstack.shape
     send = torch.zeros((n_send, D), dtype=dstack.dtype, device=dstack.device)
     if n_send and B:
-        ops.embedding_gather_backward([send] * len(slots), None, [pos_of[f] for f in range(len(slots))], dstack.contiguous(),
-                                      [int(sl) * D for sl in slots], "sgd", -1.0, 0.0)
+        dstack = dstack.contiguous()
+        step = _lib_max_features()
+        for f0 in range(0, len(slots), step):  # one launch holds at most that many id columns; the launches add into `send`
+            fs = range(f0, min(f0 + step, len(slots)))
+            ops.embedding_gather_backward([send] * len(fs), None, [pos_of[f] for f in fs], dstack,
+                                          [int(slots[f]) * D for f in fs], "sgd", -1.0, 0.0)
     return send
+
+
+def _lib_max_features() -> int:
+    from . import _lib
+
+    return _lib.MAX_FEATURES - 1
 
 
 def _build_group(owner, emb, names, group, capacity_factor, calibration, dedup="auto"):

@@ -251,3 +251,24 @@ def test_recorded_collectives_are_replayed(rccl):
     torch.cuda.synchronize()
     assert torch.equal(recv, send) and bool((flat == 3.0).all())  # a one-rank sum leaves the bucket as it is
     lib.mh_record_free(h)
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_async_collectives_on_the_communicator_stream(rccl):
+    """``Comm.alltoall_async`` / ``allreduce_async`` (what the N-rank exchange calls): issued on the communicator's own stream
+    behind the caller's work so far, ``wait()`` orders the caller's stream behind them."""
+    from models_amd import comm as mc
+
+    dev = _dev()
+    c = mc.Comm.create(force_rccl=rccl)
+    send = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
+    recv = torch.empty_like(send)
+    send.add_(5.0)                      # enqueued on the caller's stream BEFORE the collective: it must see the 5s
+    w = c.alltoall_async(send, recv)
+    w.wait()
+    got = recv.clone()                  # on the caller's stream, behind the wait
+    flat = torch.full((4096,), 2.0, device=dev)
+    w2 = c.allreduce_async(flat)
+    w2.wait()
+    torch.cuda.synchronize()
+    assert bool((got == 5.0).all()) and bool((flat == 2.0).all())
