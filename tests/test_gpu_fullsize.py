@@ -90,7 +90,9 @@ def test_c2_embedding_backward_full_batch_properties(device):
     for f in range(F):
         delta = tabs[f].double() - tabs0[f].double()
         want = -lr * grad[:, f].double().sum(0)
-        torch.testing.assert_close(delta.sum(0), want, rtol=1e-6, atol=2e-3)  # fp32 rounding of each row update
+        # fp32 rounding of each row update; 5e-6: MERLIN_HIP_DETERMINISTIC=1 sums the ~21 K gradient rows of a 3-row table one
+        # after the other in fp32 (sample order) instead of 16:1 pre-summed pieces -- measured 2.4e-6 there
+        torch.testing.assert_close(delta.sum(0), want, rtol=5e-6, atol=2e-3)
         touched = torch.zeros(tabs[f].shape[0], dtype=torch.bool, device=device)
         touched[ids[f].long()] = True
         changed = (delta != 0).any(dim=1)

@@ -1,4 +1,6 @@
 """mm.TwoTowerModel / mm.DCNModel / top-k encoder on the HIP path vs oracle + torch reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -524,11 +526,13 @@ def test_graph_replayed_train_steps_equal_eager_steps(device, mode, monkeypatch)
     static = dict(batches[0][0])
     static["__label__"] = batches[0][1]
     gs = {"one_graph": GraphedStep, "segmented": SegmentedStep, "recorded": RecordedStep}[mode](step, static, warmup=2)  # warm-up steps DO train b: put it back to the initial state in place
+    default_cfg = not any(os.environ.get(k) for k in ("MERLIN_HIP_SIDE_STREAMS", "MERLIN_HIP_MLP_CHAIN", "MERLIN_HIP_FUSED_DLRM",
+                                                       "MERLIN_HIP_SIDE_ALIAS"))  # the structure asserted below is the default's
     if mode == "recorded":
         # every launch of the step is in the recording, with the hand-offs to and from the side stream; nothing of the step ran
         # outside the library (an aten kernel would be missing from the replay)
-        assert gs.n_launches >= 15 and gs.n_hand_offs >= 4 and gs.impure_ops == []
-    if mode == "segmented":
+        assert gs.n_launches >= 15 and gs.impure_ops == [] and (gs.n_hand_offs >= 4 or not default_cfg)
+    if mode == "segmented" and default_cfg:
         streams = {sg["stream"] for sg in gs.segments}
         assert {"main", "sort"} <= streams and len(gs.segments) >= 5  # the step really was cut along its side work (one physical side stream: ops._SideStreams)
         assert all(d < i for i, sg in enumerate(gs.segments) for d in sg["deps"])  # edges point backwards in launch order
@@ -613,10 +617,11 @@ def test_captured_step_survives_buffer_growth_elsewhere_and_empty_cache(device, 
     torch.cuda.synchronize()
     grown = [k for k, (ptr, n) in before.items() if ops._WS[k].data_ptr() != ptr]
     assert grown, "the scenario must replace at least one workspace"
-    if mode == "segmented":
+    if mode == "segmented" and os.environ.get("MERLIN_HIP_SIDE_STREAMS") is None:
         assert marked & set(grown), "... one that the captured step addresses (the sparse-update preparation's)"
     # kept: the old input buffer and every replaced workspace the captured step addresses; freed: the rest
-    assert len(ops._PARKED) - parked_before == len(marked & set(grown)) + 1
+    fused = os.environ.get("MERLIN_HIP_FUSED_DLRM", "1") != "0"  # the fused block owns the persistent padded input buffer
+    assert len(ops._PARKED) - parked_before == len(marked & set(grown)) + (1 if fused else 0)
     torch.cuda.empty_cache()
     # whatever was freed is handed out again: blocks of exactly the replaced sizes, filled with a pattern the replay must not touch
     junk = [torch.full((n,), 0xAB, dtype=torch.uint8, device=device) for k in grown for n in [before[k][1]] * 3]

@@ -1,4 +1,6 @@
 """Scorer / top-k / cross HIP kernels vs the oracle and the reference's known answers."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -52,7 +54,9 @@ def test_inbatch_scorer_matches_oracle(device, B, E, temperature, idt):
     r2 = ops.inbatch_softmax(_t(q, device), _t(it, device), _t(it, device), _t(ids, device), _t(ids, device), temperature,
                              materialize=False)
     assert r2.logits is None
-    torch.testing.assert_close(r2.loss, r.loss, atol=0, rtol=0)
+    # one kernel family behind both modes: bit for bit -- unless the opt-in tiled forward kernel (another summation order) is on
+    tiled = os.environ.get("MERLIN_HIP_SCORER_FWD") == "tiled"
+    torch.testing.assert_close(r2.loss, r.loss, atol=2e-6 if tiled else 0, rtol=1e-6 if tiled else 0)
 
 
 def test_scorer_scores_are_fmaf_chains(device):
