@@ -943,6 +943,42 @@ def main():
     pmc_fresh = pmc.get("source_hash") == source_hash()
     pmc_ok = pmc_fresh and B == 65536 and args.ids == "uniform" and not args.extra_table_rows and not sharded
 
+    def apply_phase(bytes_per_launch, iters=24):
+        """The launch in the two halves the step runs it in: the id-only half (sort + piece list: `mh_embedding_gather_bwd_prepare`, on
+        the side stream beside the forward pass) is issued untimed, then the gradient-dependent half (`_apply`: segmented reduce +
+        fused optimizer + carried rows -- the HBM-bound part, and the part on the step's critical path) is timed with events over
+        the rotating batches.  A ZERO gradient: every byte moves, no value changes (the model goes on to the sustained region)."""
+        from models_amd import ops
+
+        emb = model.body.embeddings
+        names = list(model.body.cat_names)
+        fts = [emb.feature_table[n] for n in names]
+        tabs = [ft.table.data for ft in fts]
+        sts = [ft.table.state.get("accumulator") for ft in fts] if args.optimizer == "adagrad" else None
+        if args.optimizer not in ("sgd", "adagrad") or (sts is not None and any(st is None for st in sts)):
+            return None
+        D = tabs[0].shape[1]
+        grad = torch.zeros((args.batch, len(names) * D), dtype=torch.float32, device=device)
+        offs = [i * D for i in range(len(names))]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for i in range(iters + 4):
+            ids = [batches[i % nb].tensors[n].reshape(-1) for n in names]
+            prep = ops.embedding_gather_backward_prepare(tabs, ids, tag=":bench_apply")
+            if prep is None:
+                return None
+            if i >= 4:
+                ev[i - 4][0].record()
+            ops.embedding_gather_backward(tabs, sts, ids, grad, offs, args.optimizer, 0.01, 1e-7, prepared=prep)
+            if i >= 4:
+                ev[i - 4][1].record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[iters // 2]
+        by = bytes_per_launch - sum(batches[0].tensors[n].numel() * batches[0].tensors[n].element_size() for n in names)
+        return {"kernels": "piece_reduce_apply_kernel + carry_apply_kernel (mh_embedding_gather_bwd_apply; ids sorted beforehand by "
+                           "mh_embedding_gather_bwd_prepare, untimed)", "ms": ms, "algorithmic_bytes": by,
+                "achieved": by / (ms * 1e-3) / 1e9, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "timing": f"median of {iters} hipEvent-bracketed launches on the launch stream, rotating batches"}
+
     def dedup_aware(rl):
         """SURVEY 8d prices the embedding backward at 5 row passes per LOOKED-UP row (duplicates counted as if unique).
         With skewed ids most lookups repeat a row, the kernel touches each table / state row once, and that figure divided
@@ -971,6 +1007,10 @@ def main():
         rl["achieved"] = rl["frac_dedup_aware"] * HBM_PEAK_GBS
         rl["frac"] = rl["frac_dedup_aware"]
         rl["algorithmic_bytes_per_launch"] = per_launch
+        try:
+            rl["apply_phase"] = apply_phase(per_launch)
+        except Exception as e:  # noqa: BLE001 -- a reporting extra must not cost the line
+            rl["apply_phase"] = {"error": f"{type(e).__name__}: {e}"}
         rl["definition"] = ("frac / achieved: dedup-aware algorithmic bytes (gradient rows once, table + state rows read and written "
                             "once per UNIQUE id of the batch) / launch time; frac_survey_8d: SURVEY 8d's B*F*(5*D*4 + 4), which counts "
                             "repeated rows as unique")
