@@ -718,7 +718,12 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / cache-busting extras of the default line")
     args = ap.parse_args()
 
-    action, what = resolve_launch(args.gpus, os.environ, torch.cuda.device_count(), sys.argv[1:], _free_port)
+    # MH_BENCH_SHARED_GPU=1 (tests/test_gpu_bench_world2.py only): the ranks of a launcher share GPU 0 and talk over gloo -- RCCL
+    # refuses two ranks on one device -- so that the N > 1 branches of THIS file run on a one-GPU box before a multi-GPU node sees
+    # them.  The line it prints says so (`data`), and is no measurement.
+    shared_gpu = os.environ.get("MH_BENCH_SHARED_GPU") == "1" and "WORLD_SIZE" in os.environ
+    ndev = int(os.environ["WORLD_SIZE"]) if shared_gpu else torch.cuda.device_count()
+    action, what = resolve_launch(args.gpus, os.environ, ndev, sys.argv[1:], _free_port)
     if action == "spawn":  # `python bench.py --gpus N`: become N ranks (rank 0 of the child job prints the line)
         import subprocess
 
@@ -727,16 +732,23 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = what
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     tm = Timing(world, device)
     common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "cpu_baseline": None}
+    if shared_gpu:
+        common["data"] = "synthetic; TEST TRANSPORT: all ranks share GPU 0 over gloo (MH_BENCH_SHARED_GPU=1) -- not a measurement"
 
     def finish(res):
         if rank == 0:

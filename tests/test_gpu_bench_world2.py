@@ -1,0 +1,51 @@
+"""bench.py at WORLD SIZE 2 on one GPU: the N > 1 branches of the bench itself -- N-rank launch check, calibration of the
+row-sharded exchange, barrier + MAX-over-ranks timing, the sharded report (time split, bytes per rank, the W = N forward against
+the W = 1 oracle), one JSON line from rank 0 with n_gpus = 2 -- executed before a multi-GPU node runs them.  Two processes share
+cuda:0 over gloo (tests/bench_world2_harness.py); the line is marked as a test transport and is no measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(extra, timeout=600):
+    env = dict(os.environ, MH_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_world2_harness.py"), "--gpus", "2", *extra]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads(lines[0])
+
+
+def test_dlrm_bench_line_at_world_2(device):
+    d = _run(["--steps", "6", "--warmup", "3", "--batch", "4096", "--sustain", "0", "--no-cpu-baseline", "--shard-threshold", "100000"])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 4096 and "TEST TRANSPORT" in d["data"]
+    assert d["value"] > 0 and d["scaling"] == "weak" and "row-sharded" in d["config"]["parallelism"]
+    rep = d["sharded"]
+    assert "error" not in rep, rep
+    assert rep["bytes_sent_per_rank_per_step"]["a2a_rows"] > 0 and rep["time_split_ms_serialised"]
+    # the W = 2 forward equals the W = 1 numpy oracle on rank 0's first rows (rows fetched from their owners by plain indexing)
+    assert rep["max_abs_err_vs_w1_oracle"] < 1e-4, rep
+
+
+@pytest.mark.parametrize("workload", ["twotower", "dcn"])
+def test_secondary_workloads_at_world_2(device, workload):
+    extra = ["--workload", workload, "--steps", "3", "--warmup", "2", "--sustain", "0", "--no-cpu-baseline", "--shard-threshold", "100000"]
+    extra += ["--tt-batch", "2048"] if workload == "twotower" else ["--batch", "1024"]
+    d = _run(extra)
+    assert d["n_gpus"] == 2 and d["value"] > 0
