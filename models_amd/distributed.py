@@ -270,7 +270,7 @@ class ShardedEmbeddingGroup:
     def __init__(self, tables: Sequence[torch.Tensor], gather_fn: Callable, update_fn: Callable, group=None,
                  route_fn: Optional[Callable] = None, rows_fn: Optional[Callable] = None,
                  feature_table: Optional[Sequence[int]] = None, presharded: bool = False,
-                 global_rows: Optional[Sequence[int]] = None, capacity_factor: float = 1.25, calibration: int = 2,
+                 global_rows: Optional[Sequence[int]] = None, capacity_factor: Optional[float] = None, calibration: int = 2,
                  dedup="auto", reduce_fn: Optional[Callable] = None):
         self.rank, self.world_size = world()
         self.group = group
@@ -307,7 +307,16 @@ class ShardedEmbeddingGroup:
         self.state: Optional[torch.Tensor] = None
         self.state2: Optional[torch.Tensor] = None
         self._rows: Optional[torch.Tensor] = None
-        self.capacity_factor = float(capacity_factor)
+        # Slack of a fixed window over the largest per-owner count the calibration saw.  None (default): a statistical margin --
+        # count + 8 sqrt(count) + 3 % -- because padding slots travel like requests (at 1.25 x a quarter of the row and
+        # row-gradient bytes on the wire is padding) and an eager step that overflows its window loses nothing: the call is
+        # served by the dense exchange and the window re-derived (`lossless`).  Steps captured into a hipGraph cannot branch on
+        # the host: where those are asked for (MERLIN_HIP_GRAPH_DISTRIBUTED=1) the default stays the generous 1.25 x.
+        if capacity_factor is None:
+            import os as _os
+
+            capacity_factor = 1.25 if _os.environ.get("MERLIN_HIP_GRAPH_DISTRIBUTED") == "1" else 0.0
+        self.capacity_factor = float(capacity_factor)  # 0.0 = the statistical margin
         self.calibration = int(calibration)
         self.capacity: Optional[int] = None          # slots per (sender, owner) window once frozen
         self._capacity_n = 0                         # request count the window was derived from
@@ -352,14 +361,17 @@ class ShardedEmbeddingGroup:
     # ---- capacity management ------------------------------------------------------------------------------------
     def freeze_capacity(self, n_requests: int, capacity: Optional[int] = None) -> int:
         """Switch to the fixed-capacity exchange.  Default window: the largest per-owner count seen during calibration
-        (maximum over the ranks) x ``capacity_factor``; one rank needs no slack (its window holds every request)."""
+        (maximum over the ranks) plus the slack of ``capacity_factor`` (see __init__); one rank needs none (its window holds every
+        request)."""
         W = self.world_size
         if capacity is None:
             if W == 1:
                 capacity = n_requests
             else:
                 seen = self._max_count if self._max_count else (n_requests + W - 1) // W
-                capacity = min(n_requests, int(seen * self.capacity_factor) + 1)
+                slack = (int(seen * self.capacity_factor) if self.capacity_factor > 0 else
+                         seen + int(8.0 * seen ** 0.5) + int(0.03 * seen))
+                capacity = min(n_requests, slack + 1)
         self.capacity = (max(int(capacity), 1) + 63) // 64 * 64
         self._capacity_n = int(n_requests)
         return self.capacity
@@ -791,7 +803,7 @@ class DistributedDLRM:
     (``graph_capturable``); one rank (``force_shard``) uses them from the first step."""
 
     def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False,
-                 capacity_factor: float = 1.25, calibration: int = 2, dedup="auto"):
+                 capacity_factor: Optional[float] = None, calibration: int = 2, dedup="auto"):
         self.model = model
         self.body = model.body
         self.group = group
@@ -1305,7 +1317,7 @@ class DistributedModel:
     single-GPU path steps touched rows only, LazyAdam) -- identical for SGD / Adagrad."""
 
     def __init__(self, model, shard_threshold: int = 200_000, group=None, force_shard: bool = False,
-                 capacity_factor: float = 1.25, calibration: int = 2, dedup="auto"):
+                 capacity_factor: Optional[float] = None, calibration: int = 2, dedup="auto"):
         from .inputs import EmbeddingsBlock
 
         self.model = model

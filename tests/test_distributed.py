@@ -138,7 +138,7 @@ def _worker(rank, world, port, V, Dm, B, q):
             for f in range(2):
                 ref3[f].index_add_(0, ids3[f].reshape(-1), -0.1 * g3[:, f].reshape(-1, Dm))
                 torch.testing.assert_close(grp3.views[f], D.shard_table(ref3[f], rank, world), atol=1e-4, rtol=1e-4)
-        assert grp3.dedup and grp3.capacity is not None and grp3.capacity <= 64 < 2 * B // world and grp3.spills == 0
+        assert grp3.dedup and grp3.capacity is not None and grp3.capacity <= 128 < 2 * B // world and grp3.spills == 0
         grp3.check_overflow()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
@@ -260,7 +260,9 @@ def _dlrm_worker(rank, world, port, q, skew=False, dedup=False):
         model, schema, cards = _dlrm_parts()
         batches = _dlrm_batches(cards, world, B, steps, skew_from=3 if skew else None)
         model({k: v[rank] for k, v in batches[0][0].items()})  # build lazily-shaped layers
-        dd = D.DistributedDLRM(model, shard_threshold=1000, dedup=dedup)
+        # capacity_factor 1.25: the window this scenario was written for (320 slots for ~200 requests per owner: below the 400 of
+        # the skewed steps); the default statistical margin is relatively wider at such small counts
+        dd = D.DistributedDLRM(model, shard_threshold=1000, dedup=dedup, capacity_factor=1.25)
         assert sorted(dd.sharded) == ["C1", "C3"]
         assert dd.group_sh.dedup == (dedup is not False)  # "auto": on at world 2 until calibration says otherwise
         losses = []

@@ -84,7 +84,7 @@ def _worker(rank, world, port, q, skew=False, dedup=False):
         batches = _batches(cards, world, B, steps, skew_from=3 if skew else None)
         mine = lambda x: {k: v[rank].to(dev) for k, v in x.items()}
         model(mine(batches[0][0]))
-        dd = D.DistributedDLRM(model, shard_threshold=1000, dedup=dedup)
+        dd = D.DistributedDLRM(model, shard_threshold=1000, dedup=dedup, capacity_factor=1.25)  # the window the skew scenario assumes
         assert sorted(dd.sharded) == ["C1", "C3", "C5"] and dd.group_sh.dedup == dedup
         losses = [float(dd.train_step(mine(x), y[rank].to(dev))) for x, y in batches]
         dd.check_overflow()
