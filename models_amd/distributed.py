@@ -967,6 +967,11 @@ class DistributedDLRM:
                 gs.lookup_end(scatter=lambda back, pos: got.update(back=back, pos=pos))
         idt = inputs[body.cat_names[0]].dtype
         sh_index = {n: i for i, n in enumerate(self.sharded_names)}
+        # positions of the sharded features' requests in the returned-row buffer, in the id dtype of the other slots: ONE
+        # conversion of the [F_sh, B] tensor (per feature it was eight 5 us launches in front of the fused kernel)
+        pos_all = None
+        if gs is not None:
+            pos_all = gs._pos_of if gs._pos_of.dtype == idt else gs._pos_of.to(idt)  # [F_sh, B]
         slot_tables, slot_ids = [], []
         for k in body.stack_order:
             if k == "bottom_block":
@@ -974,7 +979,7 @@ class DistributedDLRM:
                 slot_ids.append(None)
             elif k in sh_index:
                 slot_tables.append(got["back"])
-                slot_ids.append(got["pos"][sh_index[k]].to(idt))
+                slot_ids.append(pos_all[sh_index[k]])
             else:
                 slot_tables.append(emb.feature_table[k].table.data)
                 slot_ids.append(inputs[k])
@@ -982,9 +987,12 @@ class DistributedDLRM:
         P = F * (F - 1) // 2
         width = P + D
         ld = (width + 3) // 4 * 4
-        buf = torch.empty((B, ld), dtype=torch.float32, device=dev)
-        if ld != width:
-            ops.zero_pad_columns(buf, width)
+        # persistent per wrapper, like the one-GPU block's: the alignment column behind `width` is zeroed ONCE, not in every step
+        buf = getattr(self, "_top_buf", None)
+        if buf is None or buf.shape != (B, ld) or buf.device != dev:
+            ops.park_replaced(buf)  # a captured step may still address the old one
+            buf = self._top_buf = torch.zeros((B, ld), dtype=torch.float32, device=dev)
+        ops.note_captured(buf)
         top_in = buf[:, :width]
         with phase("gather_interaction_fwd"):
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4c37; rm -rf $O; mkdir -p $O
+MH_FORCE_DISTRIBUTED=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tl -o t -- python bench.py --no-secondary --no-cpu-baseline --steps 30 --warmup 10 --sustain 0 > $O/bench.json 2>$O/err.txt
+f=$(find $O/tl -name "*kernel_trace.csv" | head -1)
+python tools/step_timeline.py $f concat_columns 20 > $O/timeline_sharded_w1.txt 2>&1
+rm -rf $O/tl
+cat $O/timeline_sharded_w1.txt
