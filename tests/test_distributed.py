@@ -688,3 +688,53 @@ def test_distributed_model_world2_list_features_on_sharded_tables(uneven):
         for n, (t, shard) in st["tabs"].items():
             want = ref_tabs[n] if shard is None else ref_tabs[n][shard[0]::shard[1]]
             np.testing.assert_allclose(t, want, atol=2e-5, rtol=1e-4, err_msg=n)
+
+
+def test_dedup_route_statement_properties_random():
+    """Properties of ``route_build_torch(dedup=True)`` on random id columns (the HIP kernel is pinned to this statement bit for
+    bit, so the statement itself is checked against first principles): every non-negative request finds its own key in its
+    owner's window; a window holds each key once, in the order of first occurrence; counts = distinct keys per owner; negative ids
+    and keys beyond a fixed window map to -1, and the overflow flag says whether any did."""
+    low = (1 << 40) - 1
+    g = torch.Generator().manual_seed(7)
+    for trial in range(40):
+        W = int(torch.randint(1, 9, (1,), generator=g))
+        F = int(torch.randint(1, 5, (1,), generator=g))
+        B = int(torch.randint(1, 200, (1,), generator=g))
+        card = int(torch.randint(1, 60, (1,), generator=g))
+        ids = [torch.randint(-2 if trial % 3 == 0 else 0, card, (B,), generator=g) for _ in range(F)]
+        cap = 0 if trial % 2 == 0 else int(torch.randint(1, 40, (1,), generator=g))
+        over = torch.zeros(1, dtype=torch.int32)
+        keys, pos, src, counts = D.route_build_torch(ids, W, list(range(F)), F, capacity=cap, overflow=over, dedup=True)
+        assert src is None
+        # distinct (feature, id) per owner, in order of first occurrence (entry order e = f * B + b)
+        want = {w: [] for w in range(W)}
+        for f in range(F):
+            for b in range(B):
+                i = int(ids[f][b])
+                if i >= 0 and (f, i) not in want[i % W]:
+                    want[i % W].append((f, i))
+        assert counts.tolist() == [len(want[w]) for w in range(W)]
+        start, dropped = 0, False
+        for w in range(W):
+            held = want[w] if not cap else want[w][:cap]
+            dropped |= len(held) < len(want[w])
+            base = w * cap if cap else start
+            got = [(int(k) >> 40, (int(k) & low) * W + w) for k in keys[base:base + len(held)]]
+            assert got == held
+            if cap:
+                assert all(int(k) == -1 for k in keys[base + len(held):base + cap])
+            for j, (f, i) in enumerate(held):
+                for b in range(B):
+                    if int(ids[f][b]) == i:
+                        assert int(pos[f, b]) == base + j
+            for (f, i) in want[w][len(held):]:
+                for b in range(B):
+                    if int(ids[f][b]) == i:
+                        assert int(pos[f, b]) == -1
+            start += len(want[w])
+        for f in range(F):
+            for b in range(B):
+                if int(ids[f][b]) < 0:
+                    assert int(pos[f, b]) == -1
+        assert int(over) == int(dropped)
