@@ -315,6 +315,9 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain, batch=None):
            "sustained": sustained, "step_ms": stats,
            "mfma": mfma_rates(km, ["inbatch_softmax_fwd", "inbatch_softmax_fwd_dq", "inbatch_softmax_bwd"]),
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
+    if tm.world > 1:
+        res["exchange"] = exchange_summary(runner)
+        res["config"]["parallelism"] = f"dp{tm.world} + row-sharded user_id / item_id tables (all-to-all), in-batch negatives rank-local"
     k = "inbatch_softmax_fwd_dq" if train else "inbatch_softmax_fwd"
     if k in km and km[k]["flops"]:
         tf = km[k]["flops"] / (km[k]["total_ms"] * 1e-3) / 1e12
@@ -642,12 +645,210 @@ def run_dcn(args, device, tm: Timing):
                                   f"B={args.batch} per GPU", "launch": "eager", "distinct_batches": nb, "parallelism": f"dp{tm.world}"},
            "sustained": sustained, "step_ms": stats, "mfma": mfma_rates(km, [k for k in km if k.startswith(("cross_", "linear_"))]),
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
+    if tm.world > 1:
+        res["exchange"] = exchange_summary(runner)
+        res["exchange"]["dense_bucket_bytes"] = int(runner._bucket.numel() * 4) if getattr(runner, "_bucket", None) is not None else None
     if cross:
         tf = km[cross]["flops"] / (km[cross]["total_ms"] * 1e-3) / 1e12
         res["roofline"] = {"kernel": "gemm2_kernel<256,128,4,2,NN,3> (mh_gemm2.h: DMA tiles, 3-deep ring; cross epilogue, p = xW + b stored for the backward in train mode)", "op": cross, "bound": "mfma", "achieved": tf,
                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
                            "avg_launch_ms": km[cross]["avg_ms"]}
     return res
+
+
+def exchange_summary(runner):
+    """What the row-sharded exchange of `runner` decided after calibration, per group of sharded features: whether the
+    per-(sender, owner) de-duplication stayed on ("auto" drops it when < 15 % of the requests are duplicates), the fixed
+    window, the shard size -- and which communicator carries the collectives of this process."""
+    from models_amd import comm
+
+    groups = []
+    gs = getattr(runner, "group_sh", None)
+    cand = [(gs, list(getattr(runner, "sharded_names", [])))] if gs is not None else []
+    for sh in getattr(runner, "shards", []):
+        cand += [(g, list(ns)) for g, ns in sh.groups.values()]
+    for g, names in cand:
+        groups.append({"features": [str(n) for n in names], "dedup": bool(getattr(g, "dedup", False)),
+                       "dedup_policy": "auto" if getattr(g, "_dedup_auto", False) else "fixed",
+                       "window_slots": None if g.capacity is None else int(g.capacity),
+                       "local_rows": int(g.local.shape[0]), "dim": int(g.local.shape[1])})
+    return {"communicator": comm.which(), "groups": groups}
+
+
+def run_c4_sharded(args, device, tm: Timing, rank, rows, steps=40):
+    """BASELINE configs[3] as north_star states it: configs[1] + one `rows`-row x 64 table ALLOCATED as row shards over the N
+    ranks (`row % N`: 100 M rows = 3.2 GB + 3.2 GB Adagrad state per GPU at N = 8), ids -> owners and rows -> requesters by
+    all-to-all, dense gradients through the reduce-scatter + all-gather bucket, B per GPU.  Warm-up until flat, K eager steps
+    (barrier + synchronise, MAX over ranks), the serialised time split, bytes per rank and the W = N forward against the W = 1
+    oracle.  Collective: every rank runs it.  Mirrors tf/distributed/embedding.py:117-149 (the SOK table's role)."""
+    from models_amd.distributed import DistributedDLRM, sharded_tables
+    from models_amd.graph import PackedBatch
+
+    with sharded_tables(args.shard_threshold):
+        model, _ = build_model(device, extra_rows=rows)
+    model.compile(optimizer=args.optimizer, learning_rate=0.01)
+    B = args.batch
+    nb = 4
+    batches = [PackedBatch(make_batch(device, B, 500 + rank * 1000 + i, args.ids, rows)) for i in range(nb)]
+    split = lambda t: ({k: v for k, v in t.items() if k != "__label__"}, t["__label__"])
+    model(split(batches[0].tensors)[0])
+    runner = DistributedDLRM(model, shard_threshold=args.shard_threshold)
+    step = lambda i: runner.train_step(*split(batches[i % nb].tensors))
+    for i in range(5):  # calibration of the fixed-window exchange
+        step(i)
+    flat = warm_until_flat(step, tm, max_groups=12)
+    dt = tm.timed(step, steps, 0)
+    runner.check_overflow()
+    km = kernel_times(step, 4)
+    out = {"metric": "samples/sec at batch 64K (DLRM + 100M-row table)", "value": tm.world * B * steps / dt, "unit": "samples/s",
+           "n_gpus": tm.world, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup_ms_per_step": flat,
+           "config": {"workload": f"BASELINE configs[3]: configs[1] + one {rows}-row x 64 table row-sharded over {tm.world} ranks "
+                                  f"({-(-rows // tm.world)} rows = {-(-rows // tm.world) * 256 / 1e9:.2f} GB per GPU + Adagrad state), "
+                                  f"train ({args.optimizer}), B={B} per GPU, ids={args.ids}",
+                      "global_batch": tm.world * B, "per_gpu_batch": B, "launch": "eager + side streams",
+                      "parallelism": f"dp{tm.world} + row-sharded tables (all-to-all)"},
+           "exchange": exchange_summary(runner), "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
+    for k in ("dlrm_fused_fwd", "dlrm_fused_bwd", "embedding_bwd"):
+        r2 = hbm_roofline(km, k, k)
+        if r2:
+            out[f"roofline_{k}"] = {"achieved": r2["achieved"], "frac": r2["frac"], "avg_launch_ms": r2["avg_launch_ms"]}
+    try:
+        out["sharded"] = sharded_report(runner, model, batches, B, tm.world, rank, device, split)
+    except Exception as e:  # noqa: BLE001
+        out["sharded"] = {"error": f"{type(e).__name__}: {e}"}
+    del runner, model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_multi_gpu_secondaries(args, device, tm: Timing, rank, sec):
+    """N > 1: the rest of north_star's multi-GPU story in the driver's ONE command (`bench.py --gpus N`), as `secondary` objects of
+    the headline line -- configs[3] with the big table allocated as shards, the TwoTower train step (configs[2]; the metric names
+    both models) at 32 K and 64 K per GPU with its item / user tables row-sharded, and the data-parallel DCN-v2 step (configs[4],
+    the 141 MB dense bucket).  Every rank runs every entry in the same order (they are collectives); each entry in its own try;
+    `sec` is filled in place so that the deadline watchdog can print what has finished."""
+    pick = lambda d, keys: {k: d[k] for k in keys if k in d}
+
+    def secondary(name, fn):
+        t0 = time.perf_counter()
+        try:
+            sec[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- rank-symmetric failures (a code path, an allocation) cost one entry, not the line
+            sec[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        if isinstance(sec[name], dict):
+            sec[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+
+    def tt(B, steps):
+        r = run_twotower(args, device, tm, steps=steps, warmup=3, sustain=0.0, batch=B)
+        return pick(r, ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline", "exchange"))
+
+    def dcn():
+        sub = argparse.Namespace(**vars(args))
+        sub.steps, sub.warmup, sub.sustain, sub.batches, sub.mode = 6, 2, 0.0, 2, "train"
+        r = run_dcn(sub, device, tm)
+        return pick(r, ("metric", "value", "unit", "ms_per_step", "config", "mfma", "kernels_ms", "roofline", "exchange"))
+
+    if args.c4_rows > 0:
+        secondary("c4", lambda: run_c4_sharded(args, device, tm, rank, args.c4_rows))
+    for i, B in enumerate(int(b) for b in args.tt_batches.split(",") if b.strip()):
+        secondary("twotower_train" if i == 0 else f"twotower_train_b{B // 1024}k", lambda B=B: tt(B, 20 if B <= 32768 else 8))
+    secondary("dcn_train", dcn)
+    for v in sec.values():
+        if isinstance(v, dict) and "value" in v:
+            v.setdefault("n_gpus", tm.world)
+    return sec
+
+
+class Deadline:
+    """Wall-clock backstop of the N > 1 secondaries: a collective that one rank never enters would hang every rank until the
+    process group's own timeout and cost the headline line.  When the deadline passes, rank 0 prints the line it has (headline
+    + whatever secondaries finished + a note) and every rank leaves with os._exit."""
+
+    def __init__(self, seconds, rank, line_fn):
+        import threading
+
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.rank, self.line_fn, self.seconds = rank, line_fn, seconds
+
+    def _fire(self):
+        if self.rank == 0:
+            try:
+                out = self.line_fn()
+                out["secondary_aborted"] = f"deadline of {self.seconds:.0f} s passed inside the N > 1 secondaries: the line holds what had finished"
+                print(json.dumps(out), flush=True)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] deadline fired and the line could not be printed: {e}", file=sys.stderr, flush=True)
+        os._exit(0 if self.rank == 0 else 0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+
+
+def sharded_report(runner, model, batches, batch_size, world, rank, device, split_xy):
+    """N > 1 (and the forced one-rank run of the same code): the time split of the step with the phases serialised
+    (models_amd.distributed.PHASES), the bytes each rank sends per step against the xGMI peak, and a W = N forward against
+    the W = 1 numpy oracle on rank 0's first rows -- the rows fetched from their owners by plain indexing + all-reduce,
+    an independent path from the route kernels.  All outside the timed regions."""
+    import torch.distributed as dist
+
+    from models_amd.distributed import PHASES
+    from oracle import oracle as O
+
+    nb = len(batches)
+    PHASES.start()
+    for i in range(5):
+        runner.train_step(*split_xy(batches[i % nb].tensors))
+    split = PHASES.stop()
+    xb = runner.exchange_bytes_per_step(batch_size)
+    rep = {"time_split_ms_serialised": {k: round(v, 4) for k, v in split.items()}, "bytes_sent_per_rank_per_step": xb,
+           "xgmi_peak_GBps_per_gpu": 7 * 153.0}
+    t_lookup = split.get("a2a_ids_route_owner_gather", 0.0) + split.get("a2a_rows_wait", 0.0)
+    if t_lookup > 0 and xb["a2a_rows"]:
+        rep["lookup_exchange_GBps_lower_bound"] = (xb["a2a_ids"] + xb["a2a_rows"]) / (t_lookup * 1e-3) / 1e9
+    t_ar = split.get("allreduce_issue", 0.0) + split.get("allreduce_wait", 0.0)
+    if t_ar > 0 and xb["allreduce"]:
+        rep["allreduce_GBps_lower_bound"] = xb["allreduce"] / (t_ar * 1e-3) / 1e9
+    # ---- W = N forward == W = 1 oracle ----
+    n = 256
+    b0 = batches[0].tensors
+    x0 = split_xy(b0)[0]
+    p = runner(x0)[:n]
+    body = model.body
+    W_, r_ = world, rank
+    compact, remap = {}, {}
+    for name in body.cat_names:
+        ids = x0[name][:n].reshape(-1).long().clone()
+        if W_ > 1:
+            dist.broadcast(ids, 0)
+        tab = body.embeddings.feature_table[name].table.data
+        if name in getattr(runner, "sharded_names", []):
+            mine = (ids % W_) == r_
+            rows = torch.zeros((n, tab.shape[1]), device=device)
+            rows[mine] = tab[(ids[mine] // W_)]
+            if W_ > 1:
+                dist.all_reduce(rows)
+        else:
+            rows = tab[ids]
+        u, inv = np.unique(ids.cpu().numpy(), return_inverse=True)
+        first = np.zeros(len(u), dtype=np.int64)
+        first[inv] = np.arange(n)
+        compact[name] = rows.cpu().numpy()[first]
+        remap[name] = inv.reshape(-1, 1)
+    if rank == 0:
+        lay = lambda blk: [(l.kernel.numpy(), l.bias.numpy(), l.activation) for l in blk.layers]
+        hd = model.output.to_call
+        ref = O.dlrm_forward(remap, {k: x0[k][:n].cpu().numpy() for k in body.continuous.features}, compact,
+                             lay(body.bottom_block), lay(body.top_block), (hd.kernel.numpy(), hd.bias.numpy()))
+        rep["max_abs_err_vs_w1_oracle"] = float(np.abs(p.cpu().numpy() - ref["prob"]).max())
+        rep["oracle_rows_checked"] = n
+    return rep
+
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -714,6 +915,11 @@ def main():
                          "(DLRM train); graph, segmented: time that mode without probing")
     ap.add_argument("--negatives", default="", help="with --workload twotower: comma list of 'queue', 'popularity' -- the negative-sampler "
                                                       "variants of SURVEY 8f-4 as the line's `negatives` object")
+    ap.add_argument("--c4-rows", type=int, default=100_000_000,
+                    help="N > 1: rows of the row-sharded table of the `c4` secondary (BASELINE configs[3]); 0 = skip it")
+    ap.add_argument("--tt-batches", default="32768,65536", help="N > 1: per-GPU batches of the TwoTower secondaries")
+    ap.add_argument("--secondary-deadline", type=float, default=480.0,
+                    help="N > 1: wall-clock seconds after which the secondaries are abandoned and the line printed as it stands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / cache-busting extras of the default line")
     args = ap.parse_args()
@@ -867,64 +1073,6 @@ def main():
     km = kernel_times(lambda i: eager(batches[i % nb].tensors), min(args.steps, 8))
     if hasattr(runner, "check_overflow"):
         runner.check_overflow()  # one host read, outside the timed regions: no request of the run was dropped
-    def sharded_report():
-        """N > 1 (and the forced one-rank run of the same code): the time split of the step with the phases serialised
-        (models_amd.distributed.PHASES), the bytes each rank sends per step against the xGMI peak, and a W = N forward against
-        the W = 1 numpy oracle on rank 0's first rows -- the rows fetched from their owners by plain indexing + all-reduce,
-        an independent path from the route kernels.  All outside the timed regions."""
-        import torch.distributed as dist
-
-        from models_amd.distributed import PHASES
-        from oracle import oracle as O
-
-        PHASES.start()
-        for i in range(5):
-            eager_step(i)
-        split = PHASES.stop()
-        xb = runner.exchange_bytes_per_step(args.batch)
-        rep = {"time_split_ms_serialised": {k: round(v, 4) for k, v in split.items()}, "bytes_sent_per_rank_per_step": xb,
-               "xgmi_peak_GBps_per_gpu": 7 * 153.0}
-        t_lookup = split.get("a2a_ids_route_owner_gather", 0.0) + split.get("a2a_rows_wait", 0.0)
-        if t_lookup > 0 and xb["a2a_rows"]:
-            rep["lookup_exchange_GBps_lower_bound"] = (xb["a2a_ids"] + xb["a2a_rows"]) / (t_lookup * 1e-3) / 1e9
-        t_ar = split.get("allreduce_issue", 0.0) + split.get("allreduce_wait", 0.0)
-        if t_ar > 0 and xb["allreduce"]:
-            rep["allreduce_GBps_lower_bound"] = xb["allreduce"] / (t_ar * 1e-3) / 1e9
-        # ---- W = N forward == W = 1 oracle ----
-        n = 256
-        b0 = batches[0].tensors
-        x0 = split_xy(b0)[0]
-        p = runner(x0)[:n]
-        body = model.body
-        W_, r_ = world, rank
-        compact, remap = {}, {}
-        for name in body.cat_names:
-            ids = x0[name][:n].reshape(-1).long().clone()
-            if W_ > 1:
-                dist.broadcast(ids, 0)
-            tab = body.embeddings.feature_table[name].table.data
-            if name in getattr(runner, "sharded_names", []):
-                mine = (ids % W_) == r_
-                rows = torch.zeros((n, tab.shape[1]), device=device)
-                rows[mine] = tab[(ids[mine] // W_)]
-                if W_ > 1:
-                    dist.all_reduce(rows)
-            else:
-                rows = tab[ids]
-            u, inv = np.unique(ids.cpu().numpy(), return_inverse=True)
-            first = np.zeros(len(u), dtype=np.int64)
-            first[inv] = np.arange(n)
-            compact[name] = rows.cpu().numpy()[first]
-            remap[name] = inv.reshape(-1, 1)
-        if rank == 0:
-            lay = lambda blk: [(l.kernel.numpy(), l.bias.numpy(), l.activation) for l in blk.layers]
-            hd = model.output.to_call
-            ref = O.dlrm_forward(remap, {k: x0[k][:n].cpu().numpy() for k in body.continuous.features}, compact,
-                                 lay(body.bottom_block), lay(body.top_block), (hd.kernel.numpy(), hd.bias.numpy()))
-            rep["max_abs_err_vs_w1_oracle"] = float(np.abs(p.cpu().numpy() - ref["prob"]).max())
-            rep["oracle_rows_checked"] = n
-        return rep
-
     def sustained_last():
         # the long steady region is the last GPU work of the run (every rank takes part), >= --sustain seconds: what the
         # driver's utilisation sampler sees, and a second reading of the step time
@@ -936,10 +1084,16 @@ def main():
     shard_rep = None
     if sharded and args.mode == "train":
         try:
-            shard_rep = sharded_report()  # collective: every rank runs it
+            shard_rep = sharded_report(runner, model, batches, args.batch, world, rank, device, split_xy)  # collective: every rank runs it
         except Exception as e:  # noqa: BLE001 -- a reporting extra must not cost the line
             shard_rep = {"error": f"{type(e).__name__}: {e}"}
+    # N > 1: configs[3] / TwoTower / DCN-v2 as secondaries of this one line (collectives: every rank runs them, same order)
+    multi_sec = {}
+    want_multi = world > 1 and not args.no_secondary and not args.extra_table_rows and args.mode == "train" and not force
     if rank != 0:
+        if want_multi:
+            with Deadline(args.secondary_deadline, rank, None):
+                run_multi_gpu_secondaries(args, device, tm, rank, multi_sec)
         sustained_last()
         return finish({})
 
@@ -1064,6 +1218,15 @@ def main():
         "step_ms": step_stats,
         "sharded": shard_rep,
     }
+    if sharded:
+        try:
+            res["exchange"] = exchange_summary(runner)
+        except Exception as e:  # noqa: BLE001
+            res["exchange"] = {"error": f"{type(e).__name__}: {e}"}
+    if want_multi:
+        res["secondary"] = multi_sec
+        with Deadline(args.secondary_deadline, rank, lambda: dict(common, **res)):
+            run_multi_gpu_secondaries(args, device, tm, rank, multi_sec)
     if world == 1 and not args.no_secondary and not args.extra_table_rows and not force:
         sec = {}
 

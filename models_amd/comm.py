@@ -84,6 +84,13 @@ def default() -> Optional["Comm"]:
             try:
                 c.self_check()
                 ok = True
+            except TimeoutError as e:
+                # A collective of the new communicator never completed: it still blocks this device's current stream, so NOTHING
+                # ordered behind that stream can run any more -- not the all-reduce the ranks would agree on the fallback with,
+                # not its `.item()` (round-4 advisor finding: the agreement itself hung).  The only honest outcome is a message
+                # and a non-zero exit; the launcher takes the other ranks down.
+                print(f"[models_amd.comm] FATAL: {e}", file=sys.stderr, flush=True)
+                os._exit(3)
             except Exception as e:  # noqa: BLE001
                 ok, why = False, f"{type(e).__name__}: {e}"
             ok = agreed(ok)
@@ -96,8 +103,25 @@ def default() -> Optional["Comm"]:
     else:
         print(f"[models_amd.comm] C-ABI communicator disabled on every rank ({why or 'another rank failed'}); using torch.distributed",
               file=sys.stderr)
+        if c is not None:  # created on this rank, but the ranks agreed to fall back: do not leak the RCCL communicator
+            try:
+                c.destroy()
+            except Exception:  # noqa: BLE001
+                pass
         _DEFAULT = None
     return _DEFAULT
+
+
+def which() -> str:
+    """Which transport carries the collectives of ``models_amd.distributed`` in this process (reported by bench.py)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return "none (one rank)"
+    if _DEFAULT is not None:
+        return "mh_comm (RCCL driven from libmerlin_hip.so: mh_comm_alltoall / mh_allreduce_dense)"
+    why = "not tried yet" if not _DEFAULT_TRIED else "fallback or MERLIN_HIP_COMM=torch or non-nccl backend"
+    return f"torch.distributed ({dist.get_backend()}; {why})"
 
 
 def _wait_or_die(what: str, seconds: float = 180.0) -> None:

@@ -476,12 +476,16 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, in
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(&lb_flags[blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const int tfirst = a.tile0[s];
-        // every thread waits for the earlier tiles itself (one flag per tile, read past the L1): bounded, so that a broken
-        // launch order ends in wrong output (caught by the tests) instead of a hung GPU
+        // every thread waits for the earlier tiles itself (one flag per tile, read past the L1).  The spin is bounded; when the
+        // bound is hit (workgroups NOT dispatched in index order: the assumption of this opt-in pass is broken) the wavefront
+        // TRAPS: the launch fails with a HIP error at the next synchronisation instead of handing a corrupted sort to the fused
+        // optimizer (round-4 advisor finding: silently wrong rows updated)
         for (int tp = tfirst + (int)(threadIdx.x & 63); tp < (int)blockIdx.x; tp += 64) {
             int spins = 0;
-            while (__hip_atomic_load(&lb_flags[tp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 24))
+            while (__hip_atomic_load(&lb_flags[tp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (++spins >= (1 << 24)) __builtin_trap();
                 __builtin_amdgcn_s_sleep(2);
+            }
         }
         __syncthreads();
         const int* bs = lb_base + (int64_t)s * RS;

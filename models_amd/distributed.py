@@ -440,6 +440,13 @@ class ShardedEmbeddingGroup:
             if self._since_check >= self.check_every and not capturing:
                 self._since_check = 0
                 self.check_overflow()  # one host read every check_every steps: a dropped request never goes unnoticed for long
+        if fixed and capturing:
+            self._captured_once = True
+        elif fixed and self.lossless and W > 1 and getattr(self, "_captured_once", False):
+            # Replays of a captured step cannot branch on the host: they leave the flag set and go on.  An eager call that
+            # follows must not mistake that flag for its own overflow (it would zero it, re-derive the window, and the requests
+            # dropped inside the replays would never be reported -- round-4 advisor finding): read it FIRST and raise.
+            self.check_overflow()
         if fixed:                       # ---- fixed windows ----
             cap = self.capacity
             send_keys, pos_of, src_row, _ = self._route(ids, W, slots, n_slots, cap, self.overflow)

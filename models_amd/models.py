@@ -39,6 +39,11 @@ def prepare_features(inputs: TabularData) -> TabularData:
     return out
 
 
+# checkpoint layout tag written by save_weights: "2" = DLRM top-MLP input [bottom output | interactions] (the reference's
+# order), BatchNormalization with four tensors (gamma, beta, moving mean, moving variance)
+CHECKPOINT_FORMAT = "models_amd/2"
+
+
 class Model(Block):
     """Sequence of blocks ending in an output head (models/base.py:1805-1854 ``Model.call``)."""
 
@@ -108,6 +113,7 @@ class Model(Block):
             for k, v in p.state.items():
                 arrays[f"s{i}:{k}"] = v.detach().cpu().numpy()
         arrays["__names__"] = np.array(names)
+        arrays["__format__"] = np.array(CHECKPOINT_FORMAT)
         opt = self.optimizer
         if opt is not None and getattr(opt, "_step_dev", None) is not None:
             arrays["__adam_step__"] = opt._step_dev.detach().cpu().numpy()
@@ -122,10 +128,33 @@ class Model(Block):
         names = [str(n) for n in z["__names__"]]
         if len(names) != len(params):
             raise ValueError(f"checkpoint has {len(names)} parameters, the model has {len(params)}")
+        # Layout tag (round-4 advisor finding).  Checkpoints written before the tag existed fed the DLRM top MLP
+        # [interactions | bottom output]; the reference -- and this package since -- feeds it [bottom output | interactions]
+        # (blocks.DLRMBlock).  Parameters are stored by position and shape, so such a file would load without an error with the
+        # first top-MLP kernel's rows applied to the wrong columns: its last D rows are rotated to the front here (the
+        # optimizer state of that kernel with them), with a warning.
+        rotate = {}
+        if "__format__" not in z.files:
+            from .blocks import DLRMBlock, _dense_layers
+
+            for blk in self.blocks_of_type(DLRMBlock):
+                tl = _dense_layers(blk.top_block) if blk.top_block is not None else None
+                if tl and blk.bottom_block is not None:
+                    rotate[id(tl[0].kernel)] = blk.dim
+            if rotate:
+                import warnings
+
+                warnings.warn("untagged checkpoint (written before the DLRM top-MLP input order changed to the reference's "
+                              "[bottom | interactions]): rotating the first top-MLP kernel's rows", stacklevel=2)
+        elif str(z["__format__"]) != CHECKPOINT_FORMAT:
+            raise ValueError(f"checkpoint format {str(z['__format__'])!r} is not {CHECKPOINT_FORMAT!r}")
+        fix = lambda a, D: np.concatenate([a[-D:], a[:-D]], axis=0)
         for i, p in enumerate(params):
             if id(p) in skip:
                 continue
             w = z[f"p{i}"]
+            if id(p) in rotate and tuple(w.shape) == tuple(p.data.shape):
+                w = fix(w, rotate[id(p)])
             if tuple(w.shape) != tuple(p.data.shape):
                 raise ValueError(f"parameter {i} ({p.name}): checkpoint shape {w.shape} != model shape {tuple(p.data.shape)}")
             p.data.copy_(torch.from_numpy(w))
@@ -135,7 +164,10 @@ class Model(Block):
                 if k not in keys:
                     del p.state[k]
             for k in keys:
-                val = torch.from_numpy(z[prefix + k]).to(p.data.device)
+                arr = z[prefix + k]
+                if id(p) in rotate and tuple(arr.shape) == tuple(p.data.shape):
+                    arr = fix(arr, rotate[id(p)])
+                val = torch.from_numpy(arr).to(p.data.device)
                 if k in p.state and p.state[k].shape == val.shape:
                     p.state[k].copy_(val)
                 else:

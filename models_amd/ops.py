@@ -1741,7 +1741,10 @@ def log_uniform_sample_status(device) -> int:
     """The status word the LAST ``mh_log_uniform_sample`` call on ``device`` left in its workspace (0 = every requested class
     was drawn; 1 = the unique draw gave up before reaching ``n`` classes: a broken argument combination).  One host read --
     call it outside captured / timed regions (``PopularityBasedSamplerV2.check_status``: epoch ends)."""
-    buf = _WS.get((str(torch.device(device) if not isinstance(device, torch.device) else device), "log_uniform"))
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type == "cuda" and dev.index is None:  # "cuda" and "cuda:<current>" are one device; the workspace is keyed by the
+        dev = torch.device("cuda", torch.cuda.current_device())  # device of the rng-state TENSOR, which always carries its index
+    buf = _WS.get((str(dev), "log_uniform"))
     if buf is None:
         return 0
     return int(buf[:4].view(torch.int32).item())

@@ -151,6 +151,50 @@ def test_save_and_load_weights_round_trip(tmp_path):
         c.load_weights(tmp_path / "ckpt")
 
 
+def test_untagged_checkpoint_of_the_old_dlrm_layout_is_rotated_not_misapplied(tmp_path):
+    """Checkpoints carry a layout tag; a file without one was written when the top MLP's input was [interactions | bottom]:
+    the first top-MLP kernel's last D rows (and its optimizer state) move to the front on load, with a warning; a file with
+    an unknown tag is refused."""
+    import numpy as np
+    import torch
+    from models_amd import schema as S
+    from models_amd.models import CHECKPOINT_FORMAT
+
+    schema = mm.Schema([S.categorical("a", 50), S.categorical("b", 20), S.continuous("x"), S.binary_target("y")])
+    D = 8
+
+    def build(seed):
+        m = mm.DLRMModel(schema, embedding_dim=D, bottom_block=mm.MLPBlock([D], device="cpu", seed=seed),
+                         top_block=mm.MLPBlock([8, 4], device="cpu", seed=seed + 1), device="cpu")
+        m.compile(optimizer="adagrad", learning_rate=0.1)
+        m.body.bottom_block.layers[0].build(1)
+        m.body.top_block.layers[0].build(3 + D)
+        m.body.top_block.layers[1].build(8)
+        m.output.to_call.build(4)
+        return m
+
+    a, b = build(1), build(5)
+    k = a.body.top_block.layers[0].kernel
+    k.state["accumulator"] = torch.arange(k.data.numel(), dtype=torch.float32).reshape(k.data.shape)
+    a.save_weights(tmp_path / "new")
+    z = dict(np.load(tmp_path / "new.npz"))
+    assert str(z["__format__"]) == CHECKPOINT_FORMAT
+    # the same weights as an OLD file: no tag, the kernel's rows in [interactions | bottom] order
+    pos = [i for i, p in enumerate(a.parameters()) if p is k][0]
+    old = {key: v for key, v in z.items() if key != "__format__"}
+    for key in (f"p{pos}", f"s{pos}:accumulator"):
+        old[key] = np.concatenate([z[key][D:], z[key][:D]], axis=0)
+    np.savez(tmp_path / "old", **old)
+    with pytest.warns(UserWarning, match="untagged checkpoint"):
+        b.load_weights(tmp_path / "old")
+    kb = b.body.top_block.layers[0].kernel
+    assert torch.equal(kb.data, k.data) and torch.equal(kb.state["accumulator"], k.state["accumulator"])
+    z["__format__"] = np.array("models_amd/99")
+    np.savez(tmp_path / "future", **z)
+    with pytest.raises(ValueError, match="format"):
+        b.load_weights(tmp_path / "future")
+
+
 def test_embedding_initializer_statistics():
     """tests/unit/tf/inputs/test_embedding.py:372-393, 591-629: the keras Embedding default "uniform" draws from
     U(-0.05, 0.05); the V1 EmbeddingFeatures default is TruncatedNormal(0, 0.05) (two-sigma truncation)."""

@@ -79,3 +79,43 @@ def test_gpus_2_on_a_box_without_two_gpus_exits_nonzero():
 
     if torch.cuda.device_count() < 2:
         assert out.returncode != 0 and "visible GPU" in out.stderr and '"n_gpus"' not in out.stdout
+
+
+def test_multi_gpu_secondaries_run_in_one_order_and_contain_their_failures(monkeypatch):
+    """The N > 1 secondaries are collectives: every rank must walk the SAME list in the SAME order, and a (rank-symmetric)
+    failure of one entry must cost that entry only."""
+    import argparse
+
+    b = _bench_module()
+    calls = []
+    monkeypatch.setattr(b, "run_c4_sharded", lambda args, device, tm, rank, rows: calls.append(("c4", rows)) or {"value": 1.0, "ms_per_step": 1.0})
+
+    def tt(args, device, tm, steps, warmup, sustain, batch=None):
+        calls.append(("tt", batch))
+        if batch == 65536:
+            raise RuntimeError("boom")
+        return {"value": 2.0, "ms_per_step": 2.0, "metric": "m", "junk": 1}
+
+    monkeypatch.setattr(b, "run_twotower", tt)
+    monkeypatch.setattr(b, "run_dcn", lambda args, device, tm: calls.append(("dcn", args.steps)) or {"value": 3.0, "ms_per_step": 3.0})
+    monkeypatch.setattr(b.torch.cuda, "empty_cache", lambda: None)
+    args = argparse.Namespace(c4_rows=100, tt_batches="32768,65536", steps=20, warmup=5, sustain=5.0, batches=8, mode="train")
+    tm = argparse.Namespace(world=4)
+    sec = b.run_multi_gpu_secondaries(args, None, tm, 0, {})
+    assert calls == [("c4", 100), ("tt", 32768), ("tt", 65536), ("dcn", 6)]
+    assert list(sec) == ["c4", "twotower_train", "twotower_train_b64k", "dcn_train"]
+    assert sec["twotower_train_b64k"]["error"].startswith("RuntimeError") and "junk" not in sec["twotower_train"]
+    assert all(sec[k]["n_gpus"] == 4 for k in ("c4", "twotower_train", "dcn_train"))
+
+
+def test_deadline_prints_the_line_it_has_and_ends_the_process():
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import importlib.util as u\n"
+            "sp = u.spec_from_file_location('b', %r); b = u.module_from_spec(sp); sp.loader.exec_module(b)\n"
+            "with b.Deadline(0.5, 0, lambda: {'metric': 'm', 'value': 1.0}):\n"
+            "    time.sleep(60)\n" % (str(ROOT), str(ROOT / "bench.py")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    import json
+
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert out.returncode == 0 and line["value"] == 1.0 and "deadline" in line["secondary_aborted"]

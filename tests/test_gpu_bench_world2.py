@@ -33,7 +33,8 @@ def _run(extra, timeout=600):
 
 
 def test_dlrm_bench_line_at_world_2(device):
-    d = _run(["--steps", "6", "--warmup", "3", "--batch", "4096", "--sustain", "0", "--no-cpu-baseline", "--shard-threshold", "100000"])
+    d = _run(["--steps", "6", "--warmup", "3", "--batch", "4096", "--sustain", "0", "--no-cpu-baseline", "--shard-threshold", "100000",
+              "--no-secondary"])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 4096 and "TEST TRANSPORT" in d["data"]
     assert d["value"] > 0 and d["scaling"] == "weak" and "row-sharded" in d["config"]["parallelism"]
     rep = d["sharded"]
@@ -49,3 +50,27 @@ def test_secondary_workloads_at_world_2(device, workload):
     extra += ["--tt-batch", "2048"] if workload == "twotower" else ["--batch", "1024"]
     d = _run(extra)
     assert d["n_gpus"] == 2 and d["value"] > 0
+
+
+def test_the_one_driver_command_carries_the_multi_gpu_secondaries(device):
+    """`bench.py --gpus N` (N > 1) is the only command the driver runs on a multi-GPU node: its line must hold configs[3] with the
+    big table allocated as row shards, the TwoTower train step and the data-parallel DCN-v2 step as `secondary` objects, each with
+    n_gpus == N, the communicator that ran and the de-duplication decision (round-4 review, item 1)."""
+    d = _run(["--steps", "4", "--warmup", "2", "--batch", "2048", "--sustain", "0", "--no-cpu-baseline", "--shard-threshold", "100000",
+              "--c4-rows", "1000001", "--tt-batches", "2048,4096"], timeout=900)
+    assert d["n_gpus"] == 2 and "secondary_aborted" not in d
+    assert "communicator" in d["exchange"] and d["exchange"]["groups"]
+    sec = d["secondary"]
+    assert set(sec) >= {"c4", "twotower_train", "twotower_train_b4k", "dcn_train"}, sorted(sec)
+    for name in ("c4", "twotower_train", "twotower_train_b4k", "dcn_train"):
+        e = sec[name]
+        assert "error" not in e, (name, e)
+        assert e["n_gpus"] == 2 and e["value"] > 0 and e["ms_per_step"] > 0, (name, e)
+        assert "communicator" in e["exchange"], name
+    c4 = sec["c4"]
+    assert "configs[3]" in c4["config"]["workload"] and "row-sharded" in c4["config"]["parallelism"]
+    g = [g for g in c4["exchange"]["groups"] if "C27" in g["features"]]
+    assert g and g[0]["local_rows"] >= 500_000 and isinstance(g[0]["dedup"], bool)  # the shard of the big table lives on this rank
+    assert c4["sharded"]["max_abs_err_vs_w1_oracle"] < 1e-4, c4["sharded"]
+    assert any(gr["features"] for gr in sec["twotower_train"]["exchange"]["groups"])  # user_id / item_id tables are row-sharded
+    assert sec["dcn_train"]["exchange"]["dense_bucket_bytes"] > 0
