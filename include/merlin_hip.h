@@ -426,6 +426,26 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
                     int32_t* out_idx, void* workspace, int64_t workspace_bytes,
                     mh_stream_t stream);
 
+/* ---- a14 on the bf16 matrix pipe, same contract: BruteForce.index (outputs/topk.py:124-180) + BruteForce.call (:182-237) ----
+ * mh_topk_split is what `BruteForce.index(candidates)` runs ONCE: every fp32 value x is split into two bf16 values,
+ * hi = bf16(x) and lo = bf16(x - hi) (hi[n, E], lo[n, E] uint16 bit patterns); norm2[n] (may be NULL) receives |x_row|^2 and
+ * *norm2_max (device float, may be NULL, zeroed by the caller) is raised to the largest of them.  E in {32, 64, 128, 256}.
+ * mh_topk_dot_split returns EXACTLY what mh_topk_dot returns -- scores are the k-ascending fp32 fmaf chains, indices follow
+ * tf.math.top_k's tie rule, bit for bit -- but runs the threshold filter over the catalogue as a 3-term split product
+ * (hi hi + hi lo + lo hi) on v_mfma_f32_32x32x16_bf16, keeps the best k' = k + slack approximate scores per row, proves from the
+ * error bound 2^-13 |q| max|c| that they contain the exact top-k, re-scores those k' in exact fp32 and orders them; rows for
+ * which the proof fails (more than `slack` candidates within the error band of the k-th score) are recomputed exactly on the
+ * device.  Catalogues too small for the filter path and E != 128 run mh_topk_dot itself.  No host synchronisation: capturable.
+ * workspace: mh_topk_split_workspace_bytes(Bq, N, k, E) (>= mh_topk_workspace_bytes). */
+int32_t mh_topk_split(const float* x, int64_t n, int32_t E, uint16_t* hi, uint16_t* lo, float* norm2,
+                      float* norm2_max, mh_stream_t stream);
+int64_t mh_topk_split_workspace_bytes(int64_t Bq, int64_t N, int32_t k, int32_t E);
+int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* cand_hi,
+                          const uint16_t* cand_lo, const float* cand_norm2_max, const int32_t* cand_ids,
+                          int64_t Bq, int64_t N, int32_t E, int32_t k, float* out_scores,
+                          int32_t* out_ids, int32_t* out_idx, void* workspace,
+                          int64_t workspace_bytes, mh_stream_t stream);
+
 /* ---- top-k ranking metrics (metrics/topk.py:48-195) on pre-sorted labels ----------------------------
  * labels_sorted[b, j] = relevance of the j-th best candidate of query b (what BruteForce.call returns as
  * targets in testing mode, outputs/topk.py:224-236); relevant_counts[b] = total relevant items (NULL -> 1).

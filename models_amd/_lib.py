@@ -83,6 +83,9 @@ SIGNATURES = {
     "mh_inbatch_softmax_bwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _f32, _f32, _p, _p, _i32, _p, _f32, _p, _p, _p, _p, _i64, _p]),
     "mh_topk_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "mh_topk_dot": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
+    "mh_topk_split": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mh_topk_split_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "mh_topk_dot_split": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "mh_topk_metrics": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p]),
     "mh_dropout": (_i32, [_p, _p, _i64, _f32, _p, _i32, _p]),
     "mh_batchnorm_workspace_bytes": (_i64, [_i64, _i32]),

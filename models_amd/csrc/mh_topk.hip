@@ -455,6 +455,272 @@ __global__ __launch_bounds__(256) void topk_redo_rows_kernel(const float* __rest
     }
 }
 
+
+// =====================================================================================================================
+// Split-bf16 ("bf16x3") filter: the top-k FILTER on the bf16 matrix pipe, the RESULT still bit-exact
+// =====================================================================================================================
+// fp32 MFMA runs at 1/16 of the bf16 rate on gfx950, and the filter stages above are MFMA-bound (0.71 of the fp32 peak).  A
+// score does not have to be exact to be REJECTED.  Every fp32 value is split once, x = hi + lo + r with hi = bf16(x),
+// lo = bf16(x - hi), and the filter multiplies   q . c  ~=  sum_e  hi_q hi_c + hi_q lo_c + lo_q hi_c   on
+// v_mfma_f32_32x32x16_bf16 (three bf16 MFMAs per fp32-equivalent one: 16 / 3 of the fp32 rate).
+//
+// Error bound.  With u = 2^-9 (bf16 round-to-nearest): |x - hi| <= u |x| and |x - hi - lo| <= u^2 |x|.  The dropped terms
+// lo_q lo_c + r_q c + (hi_q + lo_q) r_c are <= 3.0001 u^2 |q_e c_e| = 1.15e-5 |q_e c_e| per element; bf16 x bf16 products are
+// exact in fp32; the 3 E = 384 fp32 additions of the accumulation cost <= 384 * 2^-23 = 4.6e-5 sum_e |q_e c_e| even if the
+// matrix pipe truncated instead of rounding; the exact k-ascending fp32 fmaf chain itself is within 128 * 2^-24 = 0.8e-5 of
+// the real product.  Together |A - X| <= 6.6e-5 sum_e |q_e c_e| <= 6.6e-5 |q|_2 |c|_2 (A approximate, X the exact fmaf chain).
+// The code uses  m(row) = 2^-13 |q_row|_2 max_j |c_j|_2  (1.22e-4: almost twice the bound; measured: 2.3e-6, r3_bf16x3_lab.txt).
+//
+// Selection.  The whole staged pipeline (bootstrap -> filter -> merge) runs on approximate scores and keeps the best k' = k +
+// slack of them per row (k' = the next multiple of 64 above k + 16).  Let a_k be the k-th and a_k' the k'-th best approximate
+// score of a row.  k candidates have A >= a_k, hence X >= a_k - m, so the exact k-th best score is t >= a_k - m; every member of
+// the exact top-k has X >= t, hence A >= a_k - 2 m.  If  a_k' < a_k - 2 m  the k' kept candidates therefore CONTAIN the exact
+// top-k: they are re-scored with the exact fmaf chain (k' * Bq dot products: nothing), sorted by (score desc, index asc), and the
+// first k are the answer -- scores and indices bit-identical to the fp32 pipeline and to oracle/oracle_c.c.  A row whose band
+// [a_k - 2 m, a_k] holds more than `slack` candidates (piles of near-duplicate items) is marked dirty and recomputed exactly by
+// topk_redo_rows_kernel, like a row whose survivor list overflowed.
+//
+// Kernel (structure of tools/exp/bf16x3_lab.hip): a workgroup of 4 wavefronts owns 256 queries and one split of the stage's
+// candidates.  The query fragments of a wavefront (64 queries x 128 x {hi, lo} = 128 VGPRs) stay in registers; candidate tiles
+// (32 rows x 128 x {hi, lo} = 16 KB) stream through a 4-deep LDS ring by DMA (global_load_lds_dwordx4, chunk-swizzled source
+// addresses: ds_read_b128 of 16 consecutive rows hits 16 distinct 4-bank groups).  The product is transposed (rows = candidates,
+// columns = queries): a lane holds 16 candidates of ONE query per 32-wide block, the threshold is one register per block, and
+// the epilogue is 32 compares and nothing else unless a candidate survives.  Workgroup -> (split, query block) is XCD-aware: the
+// 16 query blocks of one split run on ONE XCD at the same time, so a candidate tile enters that XCD's L2 once and is read 16 times.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int SX_E = 128, SX_KS = SX_E / 16, SX_NWV = 4, SX_QW = 64, SX_QB = SX_QW * SX_NWV, SX_CT = 32, SX_STAGES = 4;
+constexpr int SX_ARR = SX_CT * SX_E * 2, SX_TILE = 2 * SX_ARR, SX_DMA = SX_TILE / (SX_NWV * 64 * 16);
+constexpr float SX_MREL = 1.0f / 8192.0f;  // 2^-13: margin = SX_MREL |q| max|c|
+
+__device__ __forceinline__ uint16_t sx_bf16_rne(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan: truncate (keeps the class)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float sx_bf16_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// x[rows, E] -> hi, lo (bf16) and, per row, |x_row|^2: stored (norm2 != null) and / or folded into a device-wide maximum
+// (max_bits: the float's bit pattern, non-negative, so an unsigned atomicMax orders it).  LPR = E / 4 lanes own one row.
+template <int LPR>
+__global__ __launch_bounds__(256) void topk_split_kernel(const float4* __restrict__ x, uint2* __restrict__ hi, uint2* __restrict__ lo,
+                                                        int64_t n4, float* __restrict__ norm2, unsigned* __restrict__ max_bits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float ss = 0.f;
+    if (i < n4) {
+        const float4 v = x[i];
+        const float a[4] = {v.x, v.y, v.z, v.w};
+        uint16_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = sx_bf16_rne(a[j]);
+            l[j] = sx_bf16_rne(a[j] - sx_bf16_f32(h[j]));
+            ss = fmaf(a[j], a[j], ss);
+        }
+        hi[i] = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        lo[i] = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+    if (i < n4 && (threadIdx.x & (LPR - 1)) == 0) {
+        if (norm2) norm2[i / LPR] = ss;
+        if (max_bits) atomicMax(max_bits, __float_as_uint(ss));
+    }
+}
+
+__device__ __forceinline__ void sx_dma16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void sx_wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
+    const uint16_t* __restrict__ chi, const uint16_t* __restrict__ clo, const uint16_t* __restrict__ qhi,
+    const uint16_t* __restrict__ qlo, int64_t c_beg, int64_t c_end, int Bq, const float* __restrict__ tau, int* __restrict__ cnt,
+    float* __restrict__ cs, int32_t* __restrict__ ci, int cap, int nqb, int nsplit, int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sx_smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    // XCD-aware work mapping: workgroup b runs on XCD b % 8; the j-th workgroup of an XCD takes query block j % nqb of split
+    // xcd + 8 (j / nqb) -- the nqb query blocks of a split are neighbours in time on one XCD (nsplit is a multiple of 8)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int sp = xcd + 8 * (j / nqb), qb = j % nqb;
+    if (sp >= nsplit) return;
+    const int64_t n_stage = c_end - c_beg;
+    const int64_t tiles_all = (n_stage + SX_CT - 1) / SX_CT;
+    const int64_t t_beg = (int64_t)sp * tiles_per_split;
+    int T = (int)((t_beg + tiles_per_split <= tiles_all) ? tiles_per_split : (tiles_all - t_beg));
+    if (T <= 0) return;
+    const int64_t c0 = c_beg + t_beg * SX_CT;  // first candidate row of this split
+
+    // query fragments (B operand: lane = column l31, k = 16 ks + 8 h .. + 7); rows past Bq repeat the last query (masked below)
+    bf16x8_t qh[2][SX_KS], ql[2][SX_KS];
+    float thr[2];
+    int qrow[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int qi = qb * SX_QB + wave * SX_QW + tn * 32 + l31;
+        const int qc = qi < Bq ? qi : Bq - 1;
+        qrow[tn] = qi < Bq ? qi : -1;
+        thr[tn] = qi < Bq ? tau[qi] : INFINITY;
+#pragma unroll
+        for (int ks = 0; ks < SX_KS; ++ks) {
+            qh[tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qhi + (int64_t)qc * SX_E + ks * 16 + h * 8));
+            ql[tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qlo + (int64_t)qc * SX_E + ks * 16 + h * 8));
+        }
+    }
+    // DMA sources of this thread inside a tile: chunk position L = (jj NWV + wave) 64 + lane of the 1024-chunk tile image;
+    // rows past the end of the stage re-read its last row (their scores are masked in the epilogue)
+    int rsrc[SX_DMA], csrc[SX_DMA], asrc[SX_DMA];
+#pragma unroll
+    for (int jj = 0; jj < SX_DMA; ++jj) {
+        const int L = (jj * SX_NWV + wave) * 64 + lane;
+        const int Lp = L & 511, r = Lp >> 4, p = Lp & 15;
+        asrc[jj] = L >> 9;
+        rsrc[jj] = r;
+        csrc[jj] = (p ^ (r & 15)) * 8;
+    }
+    const int64_t last_row = c_end - 1;
+    auto issue = [&](int t) {
+        unsigned char* st = sx_smem + (t % SX_STAGES) * SX_TILE;
+#pragma unroll
+        for (int jj = 0; jj < SX_DMA; ++jj) {
+            int64_t row = c0 + (int64_t)t * SX_CT + rsrc[jj];
+            row = row < last_row ? row : last_row;
+            sx_dma16((asrc[jj] ? clo : chi) + row * SX_E + csrc[jj], st + (jj * SX_NWV + wave) * 1024);
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the query fragments: keeps the ring's vmcnt arithmetic exact
+#pragma unroll
+    for (int t = 0; t < SX_STAGES - 1; ++t)
+        if (t < T) issue(t);
+    const int rd = l31 * 256;  // byte offset of this lane's candidate row inside a tile array
+    for (int t = 0; t < T; ++t) {
+        // tile t is complete when at most the loads of tiles t+1 .. t+STAGES-2 are outstanding
+        if (t + SX_STAGES - 2 < T) sx_wait_vm_and_barrier<(SX_STAGES - 2) * SX_DMA>();
+        else sx_wait_vm_and_barrier<0>();
+        if (t + SX_STAGES - 1 < T) issue(t + SX_STAGES - 1);
+        const unsigned char* st = sx_smem + (t % SX_STAGES) * SX_TILE;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < SX_KS; ++ks) {
+            const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
+            const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + rd + pos));
+            const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + SX_ARR + rd + pos));
+            // small terms first
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[0][ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[1][ks], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[0][ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[1][ks], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[0][ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[1][ks], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            float mx = acc[tn][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = __builtin_fmaxf(mx, acc[tn][i]);
+            if (!(mx >= thr[tn])) continue;  // per lane; survivors are ~k' / n_seen of the scores
+            const int64_t cb = c0 + (int64_t)t * SX_CT + h * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[tn][i];
+                const int64_t c = cb + (i >> 2) * 8 + (i & 3);
+                if (v >= thr[tn] && c < c_end && qrow[tn] >= 0) {
+                    const int pos = atomicAdd(&cnt[qrow[tn]], 1);
+                    if (pos < cap) {
+                        cs[(int64_t)qrow[tn] * cap + pos] = v;
+                        ci[(int64_t)qrow[tn] * cap + pos] = (int32_t)c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// The last stage of the split pipeline: decide per row whether the k' kept candidates provably contain the exact top-k (see the
+// block comment above), re-score them with the exact k-ascending fmaf chain, sort by (score desc, index asc), write the first k.
+// One wavefront per row; the query row sits in LDS (read as a broadcast), every lane walks the candidate rows of its entries.
+template <int R>
+__global__ __launch_bounds__(256) void topk_finalize_exact_kernel(const float* __restrict__ q, const float* __restrict__ cand,
+                                                                 int64_t Bq, int E, int k, int kp, const float* __restrict__ list_s,
+                                                                 const int32_t* __restrict__ list_i, const float* __restrict__ qnorm2,
+                                                                 const unsigned* __restrict__ cmax_bits, int* __restrict__ dirty,
+                                                                 float* __restrict__ out_scores, int32_t* __restrict__ out_idx,
+                                                                 const int32_t* __restrict__ cand_ids, int32_t* __restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) float fz_smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= Bq) return;
+    if (dirty[row]) return;  // survivor list overflowed in some stage: topk_redo_rows_kernel recomputes the row
+    RegList<R> L;
+    L.load(list_s + row * kp, list_i + row * kp, kp, lane);
+    float ak, alast;
+    int tmp;
+    L.at(k - 1, &ak, &tmp);
+    L.at(kp - 1, &alast, &tmp);
+    const float m = SX_MREL * sqrtf(qnorm2[row]) * sqrtf(__uint_as_float(*cmax_bits)) * 1.0001f;
+    if (alast > -INFINITY && !(alast < ak - 2.f * m)) {  // the band [a_k - 2 m, a_k] may reach beyond the kept candidates
+        if (lane == 0) dirty[row] = 1;
+        return;
+    }
+    float* qs = fz_smem + wave * E;
+    for (int e = lane; e < E; e += 64) qs[e] = q[row * E + e];
+    __builtin_amdgcn_wave_barrier();  // the slice is private to this wavefront (LDS operations of a wavefront execute in order)
+    float ex[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int idx = L.i[r];
+        float acc = -INFINITY;
+        if (idx != 0x7fffffff && L.s[r] > -INFINITY) {
+            const float* cr = cand + (int64_t)idx * E;
+            acc = 0.f;
+            if ((E & 3) == 0 && (reinterpret_cast<uintptr_t>(cand) & 15) == 0) {
+                for (int e = 0; e < E; e += 4) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(cr + e);
+                    acc = fmaf(qs[e], c4.x, acc);
+                    acc = fmaf(qs[e + 1], c4.y, acc);
+                    acc = fmaf(qs[e + 2], c4.z, acc);
+                    acc = fmaf(qs[e + 3], c4.w, acc);
+                }
+            } else {
+                for (int e = 0; e < E; ++e) acc = fmaf(qs[e], cr[e], acc);
+            }
+        }
+        ex[r] = acc;
+    }
+    RegList<R> M;
+    M.fill(lane);
+    for (int p = 0; p < kp; ++p) {
+        float sc = 0.f;
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r == (p >> 6)) {
+                sc = __shfl(ex[r], p & 63);
+                idx = __shfl(L.i[r], p & 63);
+            }
+        if (idx == 0x7fffffff || !(sc > -INFINITY)) continue;
+        M.insert(sc, idx, kp, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = r * 64 + lane;
+        if (p < k) {
+            out_scores[row * k + p] = M.s[r];
+            out_idx[row * k + p] = M.i[r];
+            if (out_ids) out_ids[row * k + p] = cand_ids ? cand_ids[M.i[r]] : M.i[r];
+        }
+    }
+}
+
+int split_kprime(int k) { return (k + 16 + 63) / 64 * 64; }
+
 int64_t chunk_cols(int64_t Bq, int64_t N) {
     int64_t nc = (32ll << 20) / (Bq > 0 ? Bq : 1);  // 128 MiB of fp32 scores
     if (nc > 65536) nc = 65536;
@@ -490,6 +756,184 @@ FusedPlan make_fused_plan(int64_t Bq, int64_t N, int k) {
     return p;
 }
 
+
+struct SplitPlan {
+    FusedPlan f;       // the fp32 plan's geometry with k' in place of k (dense chunk, tau, counts, survivor lists)
+    int kp;
+    int64_t off_ls, off_li, off_qhi, off_qlo, off_qn, total;
+};
+
+SplitPlan make_split_plan(int64_t Bq, int64_t N, int k, int E) {
+    SplitPlan p;
+    p.kp = split_kprime(k);
+    p.f = make_fused_plan(Bq, N, p.kp);
+    auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+    int64_t o = p.f.total;
+    p.off_ls = o;  o = al(o + Bq * (int64_t)p.kp * 4);
+    p.off_li = o;  o = al(o + Bq * (int64_t)p.kp * 4);
+    p.off_qhi = o; o = al(o + Bq * (int64_t)E * 2);
+    p.off_qlo = o; o = al(o + Bq * (int64_t)E * 2);
+    p.off_qn = o;  o = al(o + Bq * 4);
+    p.total = o;
+    return p;
+}
+
+int32_t launch_split(const float* x, int64_t n, int E, uint16_t* hi, uint16_t* lo, float* norm2, float* norm2_max, hipStream_t s) {
+    const int64_t n4 = n * E / 4;
+    const unsigned grid = (unsigned)mh_ceil_div(n4, 256);
+    auto* x4 = reinterpret_cast<const float4*>(x);
+    auto* h2 = reinterpret_cast<uint2*>(hi);
+    auto* l2 = reinterpret_cast<uint2*>(lo);
+    auto* mb = reinterpret_cast<unsigned*>(norm2_max);
+    if (E == 128) MH_LAUNCH(topk_split_kernel<32>, dim3(grid), dim3(256), 0, s, x4, h2, l2, n4, norm2, mb);
+    else if (E == 64) MH_LAUNCH(topk_split_kernel<16>, dim3(grid), dim3(256), 0, s, x4, h2, l2, n4, norm2, mb);
+    else if (E == 32) MH_LAUNCH(topk_split_kernel<8>, dim3(grid), dim3(256), 0, s, x4, h2, l2, n4, norm2, mb);
+    else if (E == 256) MH_LAUNCH(topk_split_kernel<64>, dim3(grid), dim3(256), 0, s, x4, h2, l2, n4, norm2, mb);
+    else {
+        mh_set_error("mh_topk_split: E=%d (supported: 32, 64, 128, 256)", E);
+        return MH_ERR_INVALID_ARGUMENT;
+    }
+    return MH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mh_topk_split_workspace_bytes(int64_t Bq, int64_t N, int32_t k, int32_t E) {
+    if (Bq <= 0 || N <= 0) return 0;
+    return make_split_plan(Bq, N, k, E).total;
+}
+
+int32_t mh_topk_split(const float* x, int64_t n, int32_t E, uint16_t* hi, uint16_t* lo, float* norm2, float* norm2_max,
+                      mh_stream_t stream) {
+    MH_REQUIRE(x && hi && lo, "mh_topk_split: null argument");
+    MH_REQUIRE(n >= 0 && E >= 4, "mh_topk_split: bad shape");
+    MH_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(hi) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(lo) & 7) == 0, "mh_topk_split: x must be 16-byte, hi / lo 8-byte aligned");
+    if (n == 0) return MH_OK;
+    const int32_t st = launch_split(x, n, E, hi, lo, norm2, norm2_max, mh_stream(stream));
+    if (st != MH_OK) return st;
+    MH_CHECK_LAUNCH("mh_topk_split");
+    return MH_OK;
+}
+
+int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* cand_hi, const uint16_t* cand_lo,
+                          const float* cand_norm2_max, const int32_t* cand_ids, int64_t Bq, int64_t N, int32_t E, int32_t k,
+                          float* out_scores, int32_t* out_ids, int32_t* out_idx, void* workspace, int64_t workspace_bytes,
+                          mh_stream_t stream) {
+    MH_REQUIRE(q && cand && cand_hi && cand_lo && cand_norm2_max && out_scores && out_idx, "mh_topk_dot_split: null argument");
+    MH_REQUIRE(Bq >= 0 && N >= 1 && E >= 1, "mh_topk_dot_split: bad shape");
+    MH_REQUIRE(k >= 1 && k <= TOPK_MAX && k <= N, "mh_topk_dot_split: k=%d must be in [1, min(%d, N=%lld)]", k, TOPK_MAX, (long long)N);
+    MH_REQUIRE(N < (1ll << 31), "mh_topk_dot_split: N must fit int32 indices");
+    if (Bq == 0) return MH_OK;
+    const SplitPlan p = make_split_plan(Bq, N, k, E);
+    if (!workspace || workspace_bytes < p.total) {
+        mh_set_error("mh_topk_dot_split: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)p.total);
+        return MH_ERR_WORKSPACE;
+    }
+    const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cand) | reinterpret_cast<uintptr_t>(cand_hi) |
+                           reinterpret_cast<uintptr_t>(cand_lo)) & 15) == 0;
+    if (!(p.f.fused && E == SX_E && aligned && Bq < (1 << 30))) {
+        // small catalogues (the dense path scores everything exactly anyway), other widths: the fp32 pipeline
+        return mh_topk_dot(q, cand, cand_ids, Bq, N, E, k, out_scores, out_ids, out_idx, workspace, workspace_bytes, stream);
+    }
+    hipStream_t s = mh_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* sc = reinterpret_cast<float*>(ws);
+    float* tau = reinterpret_cast<float*>(ws + p.f.off_tau);
+    int* cnt = reinterpret_cast<int*>(ws + p.f.off_cnt);
+    int* dirty = cnt + Bq;
+    float* cs = reinterpret_cast<float*>(ws + p.f.off_cs);
+    int32_t* ci = reinterpret_cast<int32_t*>(ws + p.f.off_ci);
+    float* ls = reinterpret_cast<float*>(ws + p.off_ls);
+    int32_t* li = reinterpret_cast<int32_t*>(ws + p.off_li);
+    uint16_t* qhi = reinterpret_cast<uint16_t*>(ws + p.off_qhi);
+    uint16_t* qlo = reinterpret_cast<uint16_t*>(ws + p.off_qlo);
+    float* qn = reinterpret_cast<float*>(ws + p.off_qn);
+    const int kp = p.kp;
+    const int64_t nc = chunk_cols(Bq, N);
+    {
+        const int32_t st = launch_split(q, Bq, E, qhi, qlo, qn, nullptr, s);
+        if (st != MH_OK) return st;
+    }
+#define MH_TOPK_BY_R(MACRO)            \
+    do {                               \
+        if (kp <= 64) MACRO(1);        \
+        else if (kp <= 128) MACRO(2);  \
+        else if (kp <= 256) MACRO(4);  \
+        else if (kp <= 512) MACRO(8);  \
+        else MACRO(17);                \
+    } while (0)
+    // ---- dense bootstrap over [0, n0) in exact fp32 (0.8 % of the candidates): the first k' entries of every row's list ----
+    for (int64_t c0 = 0; c0 < p.f.n0; c0 += nc) {
+        const int64_t ncur = (c0 + nc < p.f.n0) ? nc : p.f.n0 - c0;
+        const int32_t st = mh_internal_gemm_nt(q, E, cand + c0 * E, E, Bq, (int)ncur, E, sc, nc, s);
+        if (st != MH_OK) return st;
+        const int seen = (int)(c0 < kp ? c0 : kp);
+#define MH_SEL(R_)                                                                                                          \
+    MH_LAUNCH(topk_select_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, sc, nc, Bq, (int)ncur, c0, kp, seen, \
+              ls, li, (const int32_t*)nullptr, 0, (int32_t*)nullptr)
+        MH_TOPK_BY_R(MH_SEL);
+#undef MH_SEL
+    }
+    MH_LAUNCH(topk_stage_init_kernel, dim3((unsigned)mh_ceil_div(Bq, 256)), dim3(256), 0, s, ls, kp, Bq, tau, cnt);
+    // ---- filter stages on the bf16 pipe (3-term split product), survivors merged by their approximate scores ----
+    static bool attr_done = false;
+    const size_t lds = (size_t)SX_STAGES * SX_TILE;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_filter_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    const int nqb = (int)mh_ceil_div(Bq, SX_QB);
+    const char* senv = getenv("MERLIN_HIP_TOPK_SPLITS");
+    const char* genv = getenv("MERLIN_HIP_TOPK_GROWTH");
+    int growth = genv ? atoi(genv) : 8;
+    if (growth < 2) growth = 2;
+    int64_t beg = p.f.n0;
+    while (beg < N) {
+        int64_t end = beg * growth;
+        if (end > N || N - end < beg) end = N;
+        const int64_t tiles_all = mh_ceil_div(end - beg, SX_CT);
+        // enough workgroups to fill 256 CUs x 2 twice, a multiple of 8 splits (one XCD per split), >= 8 tiles per split
+        int nsplit = senv ? atoi(senv) : (int)mh_ceil_div(4 * mh_num_cus(), nqb);
+        nsplit = (nsplit + 7) / 8 * 8;
+        if (nsplit < 8) nsplit = 8;
+        while (nsplit > 8 && tiles_all / nsplit < 8) nsplit -= 8;
+        const int tps = (int)mh_ceil_div(tiles_all, nsplit);
+        MH_LAUNCH(topk_filter_bf16x3_kernel, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
+                  (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, cnt, cs, ci, p.f.cap, nqb,
+                  nsplit, tps);
+#define MH_MRG(R_)                                                                                                         \
+    MH_LAUNCH(topk_merge_compact_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, cs, ci, cnt, p.f.cap, Bq, kp, \
+              ls, li, tau, dirty, (const int32_t*)nullptr, 0, (int32_t*)nullptr)
+        MH_TOPK_BY_R(MH_MRG);
+#undef MH_MRG
+        beg = end;
+    }
+    // ---- exact re-score of the k' kept candidates, (score desc, index asc) order, first k out; rows that cannot be decided
+    //      (or whose survivor list overflowed) are recomputed exactly on the device: no host read-back, graph-capturable ----
+    const unsigned* cmax_bits = reinterpret_cast<const unsigned*>(cand_norm2_max);
+#define MH_FIN(R_)                                                                                                          \
+    MH_LAUNCH(topk_finalize_exact_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), (size_t)4 * E * sizeof(float), s, q, \
+              cand, Bq, (int)E, (int)k, kp, (const float*)ls, (const int32_t*)li, (const float*)qn, cmax_bits, dirty, out_scores, \
+              out_idx, cand_ids, out_ids)
+    MH_TOPK_BY_R(MH_FIN);
+#undef MH_FIN
+#undef MH_TOPK_BY_R
+    const size_t rlds = (size_t)4 * 4 * k * sizeof(float);
+    if (rlds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_redo_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+    }
+    MH_LAUNCH(topk_redo_rows_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), rlds, s, q, cand, Bq, N, (int)E, (int)k,
+              (const int*)dirty, out_scores, out_idx, cand_ids, out_ids);
+    MH_CHECK_LAUNCH("mh_topk_dot_split");
+    return MH_OK;
+}
+
+}  // extern "C"
+
+namespace {
 }  // namespace
 
 extern "C" {

@@ -1372,8 +1372,39 @@ def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None,
     return dq, ditem, dneg
 
 
-def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch.Tensor], k: int):
-    """Brute-force retrieval: (scores[Bq,k] desc, ids[Bq,k] int32, idx[Bq,k] int32); ties -> lower index."""
+class TopKSplit:
+    """The bf16 (hi, lo) split of a candidate matrix (``mh_topk_split``): what ``BruteForce.index`` keeps beside the fp32 rows so
+    that ``mh_topk_dot_split`` can run its threshold filter on the bf16 matrix pipe.  ``norm2_max``: device float, max |row|^2."""
+
+    def __init__(self, candidates: torch.Tensor):
+        lib = _lib.load()
+        _dev(candidates, "candidates", torch.float32)
+        if candidates.dim() != 2 or not candidates.is_contiguous():
+            raise ValueError("candidates must be contiguous 2-D")
+        N, E = candidates.shape
+        self.shape = (N, E)
+        self.hi = torch.empty((N, E), dtype=torch.int16, device=candidates.device)
+        self.lo = torch.empty((N, E), dtype=torch.int16, device=candidates.device)
+        self.norm2_max = torch.zeros(1, dtype=torch.float32, device=candidates.device)
+        if N:
+            check(lib.mh_topk_split(_ptr(candidates), N, E, _ptr(self.hi), _ptr(self.lo), None, _ptr(self.norm2_max), _stream()),
+                  "mh_topk_split")
+
+    @staticmethod
+    def supported(E: int) -> bool:
+        return int(E) == 128  # the width the filter kernel is written for; others run the fp32 pipeline
+
+
+def topk_mode() -> str:
+    """MERLIN_HIP_TOPK = split (default: filter on the bf16 pipe where a split catalogue exists, result bit-identical) | f32."""
+    import os
+
+    return "f32" if os.environ.get("MERLIN_HIP_TOPK", "split") == "f32" else "split"
+
+
+def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch.Tensor], k: int, split: Optional[TopKSplit] = None):
+    """Brute-force retrieval: (scores[Bq,k] desc, ids[Bq,k] int32, idx[Bq,k] int32); ties -> lower index.  ``split``: the
+    catalogue's ``TopKSplit`` (built once by ``BruteForce.index``): same result bit for bit, filter stages on the bf16 MFMA."""
     lib = _lib.load()
     _dev(q, "q", torch.float32)
     _dev(candidates, "candidates", torch.float32)
@@ -1387,6 +1418,17 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
     ids = torch.empty((Bq, k), dtype=torch.int32, device=q.device)
     idx = torch.empty((Bq, k), dtype=torch.int32, device=q.device)
     if Bq == 0:
+        return scores, ids, idx
+    if split is not None and topk_mode() == "split":
+        if split.shape != (N, E):
+            raise ValueError(f"split catalogue has shape {split.shape}, candidates {(N, E)}")
+        ws = _workspace(lib.mh_topk_split_workspace_bytes(Bq, N, k, E), q.device, "topk")
+        with _timed("topk_dot_split", nbytes=4 * (N + Bq) * E, flops=2 * Bq * N * E):
+            check(
+                lib.mh_topk_dot_split(_ptr(q), _ptr(candidates), _ptr(split.hi), _ptr(split.lo), _ptr(split.norm2_max), _ptr(cand_ids),
+                                      Bq, N, E, k, _ptr(scores), _ptr(ids), _ptr(idx), _ptr(ws), ws.numel(), _stream()),
+                "mh_topk_dot_split",
+            )
         return scores, ids, idx
     ws = _workspace(lib.mh_topk_workspace_bytes(Bq, N, k), q.device, "topk")
     with _timed("topk_dot", nbytes=4 * (N + Bq) * E, flops=2 * Bq * N * E):

@@ -242,6 +242,7 @@ class BruteForce(Block):
         self._k = int(k)
         self._candidates: Optional[torch.Tensor] = None
         self._ids: Optional[torch.Tensor] = None
+        self._split = None
 
     def index(self, candidates: torch.Tensor, identifiers: Optional[torch.Tensor] = None) -> "BruteForce":
         if candidates.dim() != 2:
@@ -256,6 +257,11 @@ class BruteForce(Block):
             )
         self._ids = identifiers.to(torch.int32).contiguous()  # topk.py:162-179: ids stored as int32
         self._candidates = candidates.to(torch.float32).contiguous()
+        # the bf16 (hi, lo) split of the catalogue, built once here: the filter stages of the call then run on the bf16 matrix
+        # pipe while scores and indices stay bit-identical to the fp32 pipeline (ops.TopKSplit; MERLIN_HIP_TOPK=f32 turns it off)
+        self._split = None
+        if self._candidates.is_cuda and ops.TopKSplit.supported(self._candidates.shape[1]) and ops.topk_mode() == "split":
+            self._split = ops.TopKSplit(self._candidates)
         return self
 
     def forward(self, inputs: torch.Tensor, targets: Optional[torch.Tensor] = None, testing: bool = False,
@@ -268,7 +274,7 @@ class BruteForce(Block):
                 "Query and candidates vectors must have the same embedding size "
                 f"(got query dimension of {inputs.shape[1]} and candidates dimension of {self._candidates.shape[1]} "
             )
-        scores, ids, _ = ops.topk_dot(inputs, self._candidates, self._ids, k)
+        scores, ids, _ = ops.topk_dot(inputs, self._candidates, self._ids, k, split=getattr(self, "_split", None))
         if testing:
             if targets is None:
                 raise ValueError("Targets should be provided during the evaluation mode")
