@@ -109,14 +109,16 @@ class _Dense(Block):
                              self.activation, out=out)
         return self._y
 
-    def backward(self, grad, need_dx: bool = True, pre_masked: bool = False, x_activation=None, zero_pad: bool = True):
+    def backward(self, grad, need_dx: bool = True, pre_masked: bool = False, x_activation=None, zero_pad: bool = True,
+                 late_dw: Optional[list] = None):
         """``pre_masked``: ``grad`` is already dz (the consumer folded this layer's activation
         derivative into its dX epilogue).  ``x_activation``: activation that produced this layer's
         input; its derivative is folded into the returned dx.  ``zero_pad=False``: the consumer of dx never reads the
         alignment columns beyond K (saves a fill launch)."""
         dx, dW, db = ops.linear_backward(self._x, self.kernel.data, self._y, grad,
                                          None if pre_masked else self.activation, need_dx=need_dx,
-                                         need_db=self.bias is not None, x_activation=x_activation, zero_pad=zero_pad)
+                                         need_db=self.bias is not None, x_activation=x_activation, zero_pad=zero_pad,
+                                         late_dw=late_dw)
         self.kernel.grad = dW
         if self.bias is not None:
             self.bias.grad = db
@@ -191,7 +193,8 @@ def mlp_forward(layers, x, out_last: Optional[torch.Tensor] = None):
     return x
 
 
-def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False, zero_pad: bool = True):
+def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False, zero_pad: bool = True,
+                 late_dw_first: Optional[list] = None):
     """Backward through consecutive _Dense layers, chaining the activation derivative of layer i-1
     into the dX epilogue of layer i (no separate elementwise pass between layers); the fused runs of
     ``mlp_forward`` go back through one ``ops.mlp_chain_backward`` launch each."""
@@ -204,7 +207,7 @@ def mlp_backward(layers, grad, need_dx: bool = True, pre_masked: bool = False, z
             want_dx = (i > 0) or need_dx
             if r == 1:
                 grad = layers[i].backward(grad, need_dx=want_dx, pre_masked=pre_masked, x_activation=prev_act,
-                                          zero_pad=zero_pad or i > 0)
+                                          zero_pad=zero_pad or i > 0, late_dw=late_dw_first if i == 0 else None)
             else:
                 seg = layers[i:i + r]
                 grad, dWs, dbs = ops.mlp_chain_backward(seg[0]._x, [l.kernel.data for l in seg], [l._y for l in seg],
@@ -572,11 +575,22 @@ class DLRMBlock(Block):
     def backward(self, grad, pre_masked: bool = False):
         D = self.dim
         head = getattr(self, "_head", None)
+        late_dw = None
         if self.top_block is not None:
             tl = _dense_layers(self.top_block)
             # zero_pad=False: the interaction backward reads the P + D gradient columns only, never the alignment column of dx
+            # The dW GEMM of the FIRST top-MLP layer (K = P + D = 415 at C2: the one large dW of the step) is not launched beside
+            # its dX: it would run beside the LDS-filling interaction backward (84 us alone, 279 us there, and the interaction
+            # backward itself 190 -> 237 us), with the sparse apply queued behind it on the side stream.  It is launched on the
+            # launch stream BEHIND the bottom-MLP backward instead, where that stream otherwise only waits for the HBM-bound sparse
+            # apply: MFMA work beside memory work.  MERLIN_HIP_DW_LATE=0 restores the old placement.
+            import os as _os
+
+            late = [] if (getattr(self, "_fused", False) and self.bottom_block is not None
+                          and _os.environ.get("MERLIN_HIP_DW_LATE", "1") != "0") else None
             if head is not None and tl:  # grad is the head's dz (the loss gradient w.r.t. its pre-activation)
-                grad = mlp_backward(tl + [head], grad, True, pre_masked=True, zero_pad=False)
+                grad = mlp_backward(tl + [head], grad, True, pre_masked=True, zero_pad=False, late_dw_first=late)
+                late_dw = late
             else:
                 if head is not None:
                     grad = head.backward(grad, pre_masked=True)
@@ -597,6 +611,8 @@ class DLRMBlock(Block):
                 mlp_backward(layers, g, need_dx=False)
             else:
                 self.bottom_block.backward(g.contiguous())
+        for fn in (late_dw or ()):
+            fn()
         return None
 
 

@@ -491,6 +491,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int SX_E = 128, SX_KS = SX_E / 16, SX_NWV = 4, SX_QW = 64, SX_QB = SX_QW * SX_NWV, SX_CT = 32, SX_STAGES = 4;
 constexpr int SX_ARR = SX_CT * SX_E * 2, SX_TILE = 2 * SX_ARR, SX_DMA = SX_TILE / (SX_NWV * 64 * 16);
+constexpr int SX_MAX_SPLITS = 256;
 constexpr float SX_MREL = 1.0f / 8192.0f;  // 2^-13: margin = SX_MREL |q| max|c|
 
 __device__ __forceinline__ uint16_t sx_bf16_rne(float x) {
@@ -540,21 +541,36 @@ __device__ __forceinline__ void sx_wait_vm_and_barrier() {
 __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
     const uint16_t* __restrict__ chi, const uint16_t* __restrict__ clo, const uint16_t* __restrict__ qhi,
     const uint16_t* __restrict__ qlo, int64_t c_beg, int64_t c_end, int Bq, const float* __restrict__ tau, int* __restrict__ cnt,
-    float* __restrict__ cs, int32_t* __restrict__ ci, int cap, int nqb, int nsplit, int tiles_per_split) {
+    float* __restrict__ cs, int32_t* __restrict__ ci, int segcap, int* __restrict__ dirty, int nqb, int nsplit,
+    int tiles_per_split, int xcd_map) {
+    // Survivors go to a segment PRIVATE to this workgroup: list[(row nsplit + split) segcap ..], its fill count kept in LDS (one
+    // counter per query of the workgroup) and written out once at the end.  No global atomic: the first version reserved slots with
+    // atomicAdd on a per-row counter -- a returning device-scope atomic is ~2 us of latency in the middle of the MFMA loop, and the
+    // s_waitcnt it forces also drains the candidate DMA ring (first stage: ~16 survivors per wavefront and tile, 645 us for 6 % of
+    // the catalogue).  A lane reserves the slots of ALL its survivors of a tile with ONE ds_add_rtn.
     extern __shared__ __attribute__((aligned(1024))) unsigned char sx_smem[];
+    __shared__ int sx_cnt[SX_QB];
+    sx_cnt[threadIdx.x] = 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     // XCD-aware work mapping: workgroup b runs on XCD b % 8; the j-th workgroup of an XCD takes query block j % nqb of split
     // xcd + 8 (j / nqb) -- the nqb query blocks of a split are neighbours in time on one XCD (nsplit is a multiple of 8)
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int sp = xcd + 8 * (j / nqb), qb = j % nqb;
+    const int sp = xcd_map ? xcd + 8 * (j / nqb) : (int)(blockIdx.x / nqb);
+    const int qb = xcd_map ? j % nqb : (int)(blockIdx.x % nqb);
     if (sp >= nsplit) return;
     const int64_t n_stage = c_end - c_beg;
     const int64_t tiles_all = (n_stage + SX_CT - 1) / SX_CT;
     const int64_t t_beg = (int64_t)sp * tiles_per_split;
     int T = (int)((t_beg + tiles_per_split <= tiles_all) ? tiles_per_split : (tiles_all - t_beg));
-    if (T <= 0) return;
+    if (T <= 0) {  // an empty split of a small stage: its segments are empty
+        const int qi = qb * SX_QB + threadIdx.x;
+        if (qi < Bq) cnt[(int64_t)qi * nsplit + sp] = 0;
+        return;
+    }
     const int64_t c0 = c_beg + t_beg * SX_CT;  // first candidate row of this split
+    const int c0i = (int)c0;
+    const int n_split = (int)((c_end - c0 < (int64_t)T * SX_CT) ? (c_end - c0) : (int64_t)T * SX_CT);  // valid rows of this split
 
     // query fragments (B operand: lane = column l31, k = 16 ks + 8 h .. + 7); rows past Bq repeat the last query (masked below)
     bf16x8_t qh[2][SX_KS], ql[2][SX_KS];
@@ -607,11 +623,22 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+        // Software-pipelined over the 8 k-steps: the A fragments (hi, lo) of step ks + 1 are read from LDS BEFORE the six MFMAs of
+        // step ks are issued (192 cycles of matrix work cover the ~128-cycle LDS round trip).  Left to itself the compiler used one
+        // register quad for every fragment -- ds_read, s_waitcnt lgkmcnt(0), 2-4 MFMAs, 16 times per tile: every LDS round trip
+        // exposed, hidden only by the second wavefront of the SIMD (rocprof: 0.43 of the bf16 peak).
+        auto lds_frag = [&](int ks, int arr) {
+            const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
+            return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + arr * SX_ARR + rd + pos));
+        };
+        bf16x8_t ah = lds_frag(0, 0), al = lds_frag(0, 1);
 #pragma unroll
         for (int ks = 0; ks < SX_KS; ++ks) {
-            const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
-            const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + rd + pos));
-            const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + SX_ARR + rd + pos));
+            bf16x8_t nh = ah, nl = al;
+            if (ks + 1 < SX_KS) {
+                nh = lds_frag(ks + 1, 0);
+                nl = lds_frag(ks + 1, 1);
+            }
             // small terms first
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[0][ks], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[1][ks], acc[1], 0, 0, 0);
@@ -619,28 +646,106 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[1][ks], acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[0][ks], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[1][ks], acc[1], 0, 0, 0);
+            ah = nh;
+            al = nl;
         }
+        // the schedule of the unrolled tile, in order: fragments of step 0; then for every step the two LDS reads of the NEXT step
+        // ahead of the six MFMAs of this one
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int ks = 0; ks + 1 < SX_KS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        const int cb = t * SX_CT + h * 4;  // candidate of accumulator entry i, relative to c0: cb + (i >> 2) * 8 + (i & 3)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            float mx = acc[tn][0];
+            // common case first: the largest of the 16 scores against the threshold (v_max3: 8 instructions), the mask only behind it
+            float mx = __builtin_fmaxf(acc[tn][0], acc[tn][1]);
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = __builtin_fmaxf(mx, acc[tn][i]);
+            for (int i = 2; i < 16; ++i) mx = __builtin_fmaxf(mx, acc[tn][i]);
             if (!(mx >= thr[tn])) continue;  // per lane; survivors are ~k' / n_seen of the scores
-            const int64_t cb = c0 + (int64_t)t * SX_CT + h * 4;
+            if (qrow[tn] < 0) continue;
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m |= (acc[tn][i] >= thr[tn] ? 1u : 0u) << i;
+            if (t * SX_CT + SX_CT > n_split) {  // the stage's last tile: rows past c_end repeat its last row
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (cb + (i >> 2) * 8 + (i & 3) >= n_split) m &= ~(1u << i);
+                if (m == 0) continue;
+            }
+            const int base = atomicAdd(&sx_cnt[wave * SX_QW + tn * 32 + l31], __popc(m));  // LDS: both half-wavefronts hold this query
+            // entry r of split sp of a row sits at [(row segcap + r) nsplit + sp]: the merge reads one entry of 64 splits per load
+            const int64_t seg = (int64_t)qrow[tn] * segcap * nsplit + sp;
+            float* csr = cs + seg;
+            int32_t* cir = ci + seg;
+            int pos = base;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = acc[tn][i];
-                const int64_t c = cb + (i >> 2) * 8 + (i & 3);
-                if (v >= thr[tn] && c < c_end && qrow[tn] >= 0) {
-                    const int pos = atomicAdd(&cnt[qrow[tn]], 1);
-                    if (pos < cap) {
-                        cs[(int64_t)qrow[tn] * cap + pos] = v;
-                        ci[(int64_t)qrow[tn] * cap + pos] = (int32_t)c;
+                if ((m >> i) & 1u) {
+                    if (pos < segcap) {
+                        csr[(int64_t)pos * nsplit] = acc[tn][i];
+                        cir[(int64_t)pos * nsplit] = c0i + cb + (i >> 2) * 8 + (i & 3);
                     }
+                    ++pos;
                 }
             }
         }
     }
+    __syncthreads();
+    {
+        const int qi = qb * SX_QB + threadIdx.x;
+        if (qi < Bq) {
+            const int n = sx_cnt[threadIdx.x];
+            cnt[(int64_t)qi * nsplit + sp] = n < segcap ? n : segcap;
+            if (n > segcap) dirty[qi] = 1;  // survivors were lost: topk_redo_rows_kernel recomputes the row exactly
+        }
+    }
+}
+
+// Merge the survivor segments of a row (one per split of the stage, written by topk_filter_bf16x3_kernel) into its running list.
+// Lane s of the wavefront walks segment s0 + s: a round hands the wavefront one entry of each of 64 segments.  Order =
+// (score desc, index asc), so the arrival order does not matter.
+template <int R>
+__global__ __launch_bounds__(256) void topk_merge_segments_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
+                                                                 const int* __restrict__ cnt, int segcap, int nsplit, int64_t Bq, int k,
+                                                                 float* __restrict__ best_s, int32_t* __restrict__ best_i,
+                                                                 float* __restrict__ tau) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= Bq) return;
+    RegList<R> L;
+    L.load(best_s + row * k, best_i + row * k, k, lane);
+    float tl;
+    int il;
+    L.at(k - 1, &tl, &il);
+    for (int s0 = 0; s0 < nsplit; s0 += 64) {
+        const int sg = s0 + lane;
+        const int n = sg < nsplit ? cnt[row * nsplit + sg] : 0;
+        const int64_t seg = row * (int64_t)segcap * nsplit + sg;
+        int nmax = n;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+        for (int r = 0; r < nmax; ++r) {
+            const float v = (r < n) ? cs[seg + (int64_t)r * nsplit] : -INFINITY;
+            const int vi = (r < n) ? ci[seg + (int64_t)r * nsplit] : 0x7fffffff;
+            const bool pass = (r < n) && ((v > tl) || (v == tl && vi < il));
+            unsigned long long mask = __ballot(pass);
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const float sc = __shfl(v, l);
+                const int idx = __shfl(vi, l);
+                if (!((sc > tl) || (sc == tl && idx < il))) continue;
+                if (!L.insert(sc, idx, k, lane)) continue;
+                L.at(k - 1, &tl, &il);
+            }
+        }
+    }
+    L.store(best_s + row * k, best_i + row * k, k, lane);
+    if (lane == 0) tau[row] = tl;
 }
 
 // The last stage of the split pipeline: decide per row whether the k' kept candidates provably contain the exact top-k (see the
@@ -760,13 +865,23 @@ FusedPlan make_fused_plan(int64_t Bq, int64_t N, int k) {
 struct SplitPlan {
     FusedPlan f;       // the fp32 plan's geometry with k' in place of k (dense chunk, tau, counts, survivor lists)
     int kp;
-    int64_t off_ls, off_li, off_qhi, off_qlo, off_qn, total;
+    int64_t off_ls, off_li, off_qhi, off_qlo, off_qn, off_seg, total;
 };
 
 SplitPlan make_split_plan(int64_t Bq, int64_t N, int k, int E) {
     SplitPlan p;
     p.kp = split_kprime(k);
     p.f = make_fused_plan(Bq, N, p.kp);
+    if (p.f.fused) {
+        // The dense bootstrap only has to hand the filter stages a first threshold: 16 k' candidates (2048 at k = 100) instead of
+        // the fp32 pipeline's 128 MiB chunk -- the streaming select costs ~0.5 us per list insertion, the filter stages that take
+        // over the difference run at the bf16 rate.  MERLIN_HIP_TOPK_N0 overrides (experiments).
+        const char* e = getenv("MERLIN_HIP_TOPK_N0");
+        int64_t n0 = e ? atoll(e) : 16 * (int64_t)p.kp;
+        if (n0 < 16 * (int64_t)p.kp) n0 = 16 * (int64_t)p.kp;
+        n0 = (n0 + 127) / 128 * 128;
+        if (n0 < p.f.n0) p.f.n0 = n0;
+    }
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
     int64_t o = p.f.total;
     p.off_ls = o;  o = al(o + Bq * (int64_t)p.kp * 4);
@@ -774,6 +889,7 @@ SplitPlan make_split_plan(int64_t Bq, int64_t N, int k, int E) {
     p.off_qhi = o; o = al(o + Bq * (int64_t)E * 2);
     p.off_qlo = o; o = al(o + Bq * (int64_t)E * 2);
     p.off_qn = o;  o = al(o + Bq * 4);
+    p.off_seg = o; o = al(o + Bq * (int64_t)SX_MAX_SPLITS * 4);  // survivor counts per (row, split)
     p.total = o;
     return p;
 }
@@ -851,6 +967,7 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
     uint16_t* qhi = reinterpret_cast<uint16_t*>(ws + p.off_qhi);
     uint16_t* qlo = reinterpret_cast<uint16_t*>(ws + p.off_qlo);
     float* qn = reinterpret_cast<float*>(ws + p.off_qn);
+    int* segcnt = reinterpret_cast<int*>(ws + p.off_seg);
     const int kp = p.kp;
     const int64_t nc = chunk_cols(Bq, N);
     {
@@ -888,7 +1005,9 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
     const int nqb = (int)mh_ceil_div(Bq, SX_QB);
     const char* senv = getenv("MERLIN_HIP_TOPK_SPLITS");
     const char* genv = getenv("MERLIN_HIP_TOPK_GROWTH");
-    int growth = genv ? atoi(genv) : 8;
+    int growth = genv ? atoi(genv) : 4;
+    const char* menv = getenv("MERLIN_HIP_TOPK_XCD_MAP");
+    const int xcd_map = menv ? atoi(menv) : 0;  // measured: the plain order (query block fastest) is 3 % faster than one-split-per-XCD
     if (growth < 2) growth = 2;
     int64_t beg = p.f.n0;
     while (beg < N) {
@@ -899,14 +1018,16 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
         int nsplit = senv ? atoi(senv) : (int)mh_ceil_div(4 * mh_num_cus(), nqb);
         nsplit = (nsplit + 7) / 8 * 8;
         if (nsplit < 8) nsplit = 8;
+        if (nsplit > SX_MAX_SPLITS) nsplit = SX_MAX_SPLITS;
         while (nsplit > 8 && tiles_all / nsplit < 8) nsplit -= 8;
         const int tps = (int)mh_ceil_div(tiles_all, nsplit);
+        const int segcap = p.f.cap / nsplit;  // the row's survivor capacity divided among the splits' private segments
         MH_LAUNCH(topk_filter_bf16x3_kernel, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
-                  (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, cnt, cs, ci, p.f.cap, nqb,
-                  nsplit, tps);
-#define MH_MRG(R_)                                                                                                         \
-    MH_LAUNCH(topk_merge_compact_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, cs, ci, cnt, p.f.cap, Bq, kp, \
-              ls, li, tau, dirty, (const int32_t*)nullptr, 0, (int32_t*)nullptr)
+                  (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, segcnt, cs, ci, segcap, dirty, nqb,
+                  nsplit, tps, xcd_map);
+#define MH_MRG(R_)                                                                                                             \
+    MH_LAUNCH(topk_merge_segments_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, (const float*)cs,              \
+              (const int32_t*)ci, (const int*)segcnt, segcap, nsplit, Bq, kp, ls, li, tau)
         MH_TOPK_BY_R(MH_MRG);
 #undef MH_MRG
         beg = end;

@@ -789,10 +789,12 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
 
 
 def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db: bool = True, x_activation=None,
-                    zero_pad: bool = True):
+                    zero_pad: bool = True, late_dw: Optional[list] = None):
     """Backward of ``linear``: returns (dx | None, dW, db | None).  ``dy`` is overwritten with
     dz = dy * act'(y) when an activation is given.  ``x_activation`` names the activation that
-    produced ``x``: its derivative is folded into dx, which is then the producer's dz."""
+    produced ``x``: its derivative is folded into dx, which is then the producer's dz.  ``late_dw`` (a list; side-stream steps
+    only): dW / db are NOT launched here -- a closure that launches them on the then-current stream is appended to the list and
+    the caller runs it later in the step (blocks.DLRMBlock.backward: behind the bottom-MLP backward, beside the sparse apply)."""
     lib = _lib.load()
     _rowmajor_2d(x, "x")
     _rowmajor_2d(dy, "dy")
@@ -840,7 +842,16 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         # (round 4 re-measured the alternatives on one box -- dW forked before dX, dW on its own stream, both, three streams: all
         # 15-25 us slower per step than dX first and dW behind it on the shared side stream: profiles/r4_ab_side_streams.txt)
         run_dx()
-        run_dw()
+        if late_dw is not None:
+            def run_dw_late():
+                ws = _workspace(nbytes, x.device, "linear_bwd_late")
+                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
+                                                 None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                      "mh_linear_bias_act_bwd")
+
+            late_dw.append(run_dw_late)
+        else:
+            run_dw()
         SIDE.maybe_join()
         return dx, dW, db
     ws = _workspace(nbytes, x.device, "linear_bwd")

@@ -86,7 +86,7 @@ def dot_interaction_backward(x, dout, tail_slot=-1, tail_width=0, tail_first=Tru
     return dx
 
 
-def linear_backward(x, W, y, dy, activation=None, need_dx=True, need_db=True, x_activation=None, zero_pad=True):
+def linear_backward(x, W, y, dy, activation=None, need_dx=True, need_db=True, x_activation=None, zero_pad=True, late_dw=None):
     if activation not in (None, "linear"):
         dy.copy_(_act_grad(y, dy, activation))  # in place, like the kernel
     dx = None
