@@ -795,20 +795,40 @@ def run_fit_from_parquet(args, device, rows=4_194_304, min_seconds=2.5):
         torch.cuda.synchronize()
         loader_rate = k * B / (time.perf_counter() - t0)
         # fit until >= min_seconds have been spent in it
-        h = model.fit(loader, epochs=1)  # builds the layers, captures the step
-        rates, t_fit, epochs = [], 0.0, 0
-        torch.cuda.synchronize()
-        while t_fit < min_seconds and epochs < 400:
+        def timed_fit(ld):
+            """ONE fit() call sized to last >= min_seconds (a short call first gives the time per epoch): the step is captured once
+            and the launch-mode probe runs once, as in a real training run.  WALL CLOCK of that call -- every step of every epoch,
+            epoch boundaries (iterator start, chunk staging, fit's synchronisation and loss read-back) included."""
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            h = model.fit(loader, epochs=8)
-            t_fit += time.perf_counter() - t0
-            rates += h["examples_per_sec"]
-            epochs += 8
-        # `value`: WALL CLOCK of the fit() calls -- every step of every epoch, the epoch boundaries (iterator start, the chunk copy of
-        # the next epoch, fit's own synchronisation and loss read-back) included; the reference's callback figure (first step of an
-        # epoch discarded) is reported beside it
-        fit_rate = epochs * nb * B / t_fit
-        callback_rate = float(np.median(rates))
+            model.fit(ld, epochs=2)
+            per_epoch = max((time.perf_counter() - t0) / 2, 1e-3)
+            epochs = int(min(max(4, math.ceil(min_seconds / per_epoch)), 2000))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h = model.fit(ld, epochs=epochs)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            return epochs * len(ld) * B / dt, float(np.median(h["examples_per_sec"])), epochs, dt, h
+
+        fit_rate, callback_rate, epochs, t_fit, h = timed_fit(loader)
+        resident = getattr(loader, "_dev_cache", None) is not None
+        # the same files with the device-resident cache off: every epoch's chunks cross the host link again
+        stream_rate = None
+        if resident:
+            ld2 = mm.Loader(path, schema, batch_size=B, shuffle=True, seed=1, device=device, drop_last=True, device_resident_bytes=0)
+            stream_rate, _, _, _, _ = timed_fit(ld2)
+            del ld2
+        pin = torch.empty(256 << 20, dtype=torch.uint8).pin_memory()
+        dst = torch.empty(256 << 20, dtype=torch.uint8, device=device)
+        dst.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            dst.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_gbps = 4 * (256 << 20) / (time.perf_counter() - t0) / 1e9
+        del pin, dst
         # the same model's step on resident batches (what the headline times), for the share
         from models_amd.graph import PackedBatch, SegmentedStep
 
@@ -827,6 +847,9 @@ def run_fit_from_parquet(args, device, rows=4_194_304, min_seconds=2.5):
         return {"workload": f"synthetic Criteo-shaped Parquet ({rows} rows, {size / 1e6:.0f} MB uncompressed, 40 columns) -> mm.Loader (device-chunk "
                             f"mode, shuffle) -> DLRMModel.fit, B={B}, {args.optimizer}",
                 "value": fit_rate, "unit": "samples/s", "examples_per_sec_callback_formula": callback_rate, "fit_epochs": epochs, "fit_seconds": t_fit, "batches_per_epoch": nb,
+                "device_resident_dataset": resident, "dataset_bytes": getattr(loader, "dataset_bytes", None),
+                "fit_samples_per_s_streaming_every_epoch_over_the_host_link": stream_rate, "pinned_h2d_GBps": h2d_gbps,
+                "host_link_needed_GBps_at_step_rate": 160 * step_rate / 1e9,
                 "loader_alone_samples_per_s": loader_rate, "resident_step_samples_per_s": step_rate,
                 "fit_over_resident_step": fit_rate / step_rate, "input_share_of_fit_time": max(0.0, 1.0 - fit_rate / step_rate),
                 "parquet_decode_and_pin_s": t_load, "parquet_write_s": t_write, "launch_probe": h.get("launch_probe"),

@@ -153,6 +153,12 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
 /* Deterministic mode of the fused sparse update (process-wide; initial value from MERLIN_HIP_DETERMINISTIC=1 at load time):
  * crossing runs are walked in sample order instead of summed with float atomics -- bit-reproducible, slower on very hot rows. */
 int32_t mh_set_deterministic(int32_t on);
+/* Arithmetic of the gradient passes of the in-batch scorer (mh_inbatch_softmax_fwd_dq / _bwd) at E = 128:
+ *   0 (default) exact fp32 MFMA, every score one k-ascending fmaf chain;
+ *   1 "bf16x3": every fp32 operand split into two bf16 values, every product of both GEMMs of a pass formed as hi hi + hi lo + lo hi
+ *     on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (error of a dot product <= ~2.3e-6 |q| |item| measured; 16 / 3 of the fp32
+ *     MFMA rate).  Not bit-identical to mode 0: opt-in (initial value MERLIN_HIP_SCORER_ARITH=bf16x3 through the Python layer). */
+int32_t mh_set_scorer_arith(int32_t mode);
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
                                 const int64_t* table_rows /*HOST [F]*/,

@@ -22,6 +22,11 @@ from .models import (  # noqa: F401
     DCNModel, DLRMModel, Encoder, Model, RankingModel, RetrievalModel, TopKEncoder, TwoTowerModel, TwoTowerModelV2,
 )
 from .loader import Loader  # noqa: F401
+from .optim import LazyAdam  # noqa: F401
+from .compat import (  # noqa: F401
+    AvgPrecisionAt, BinaryClassificationTask, ItemRetrievalScorer, ItemRetrievalTask, L2Norm, LogitsTemperatureScaler, MRRAt,
+    MultiOptimizer, NDCGAt, OptimizerBlocks, PrecisionAt, RecallAt, TopKMetricsAggregator, split_embeddings_on_size,
+)
 from .sampling import (  # noqa: F401
     CachedCrossBatchSampler, Candidate, CandidateSampler, FIFOQueue, InBatchSamplerV2, PopularityBasedSamplerV2,
     PopularityLogitsCorrection,

@@ -583,11 +583,11 @@ class DLRMBlock(Block):
             # its dX: it would run beside the LDS-filling interaction backward (84 us alone, 279 us there, and the interaction
             # backward itself 190 -> 237 us), with the sparse apply queued behind it on the side stream.  It is launched on the
             # launch stream BEHIND the bottom-MLP backward instead, where that stream otherwise only waits for the HBM-bound sparse
-            # apply: MFMA work beside memory work.  MERLIN_HIP_DW_LATE=0 restores the old placement.
+            # apply: MFMA work beside memory work.  OPT-IN (MERLIN_HIP_DW_LATE=1): measured neutral in the eager step (0.952 vs 0.955 ms) and worse under the segmented replay (1.107 vs 0.978 ms) -- beside the persistent, HBM-saturating apply kernel the GEMM takes 250 us instead of 84 and the apply 275-300 instead of 186: the two serialise whichever way they are queued (profiles/r5_notes.md).
             import os as _os
 
             late = [] if (getattr(self, "_fused", False) and self.bottom_block is not None
-                          and _os.environ.get("MERLIN_HIP_DW_LATE", "1") != "0") else None
+                          and _os.environ.get("MERLIN_HIP_DW_LATE", "0") == "1") else None
             if head is not None and tl:  # grad is the head's dz (the loss gradient w.r.t. its pre-activation)
                 grad = mlp_backward(tl + [head], grad, True, pre_masked=True, zero_pad=False, late_dw_first=late)
                 late_dw = late

@@ -1,0 +1,330 @@
+"""The remaining ``mm`` names of the hot path that reference scripts import (merlin/models/tf/__init__.py:42-47, 100-102, 127-132,
+165): thin classes over the code that already does the work -- ``L2Norm`` (``l2_normalization=`` of the towers), the V1 scorer /
+task vocabulary (``ItemRetrievalScorer``, ``ItemRetrievalTask``, ``BinaryClassificationTask``, ``LogitsTemperatureScaler``: what
+``ContrastiveOutput`` / ``BinaryOutput`` are in the V2 vocabulary), ``MultiOptimizer`` / ``OptimizerBlocks`` /
+``split_embeddings_on_size`` (per-block optimizers) and the top-k metric classes over ``mh_topk_metrics``."""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import ops, optim
+from .core import Block
+from .inputs import EmbeddingsBlock, EmbeddingTable
+from .outputs import MIN_FLOAT, BinaryOutput, ContrastiveOutput, Prediction
+from .schema import ColumnSchema, Schema, Tags
+
+
+class L2Norm(Block):
+    """transforms/regularization.py:27-62: L2-normalise a tensor or every tensor of a dict along the last axis
+    (``mh_l2norm``); ``backward`` maps the output gradient back (same structure as the input)."""
+
+    def forward(self, inputs, axis: int = -1):
+        if axis not in (-1, 1):
+            raise NotImplementedError("L2Norm on the HIP path normalises the last axis of [B, E] tensors")
+        self._x = inputs
+        if isinstance(inputs, dict):
+            return {k: ops.l2norm(v) for k, v in inputs.items()}
+        return ops.l2norm(inputs)
+
+    def backward(self, grad):
+        if isinstance(self._x, dict):
+            return {k: ops.l2norm_backward(self._x[k], g) for k, g in grad.items()}
+        return ops.l2norm_backward(self._x, grad)
+
+
+class LogitsTemperatureScaler(Block):
+    """transforms/bias.py:30-73: ``logits / temperature`` on a ``Prediction`` in training / testing, identity otherwise.
+    (``ContrastiveOutput(logits_temperature=...)`` applies the same factor inside the fused scorer kernel.)"""
+
+    def __init__(self, temperature: float, name: Optional[str] = None):
+        super().__init__(name)
+        self.temperature = float(temperature)
+
+    def forward(self, outputs, training: bool = False, testing: bool = False):
+        if (training or testing) and isinstance(outputs, Prediction):
+            return outputs._replace(outputs=self.apply_temperature(outputs.outputs))
+        return outputs
+
+    def apply_temperature(self, predictions: torch.Tensor) -> torch.Tensor:
+        if not isinstance(predictions, torch.Tensor):
+            raise AssertionError("Predictions must be a tensor")
+        return predictions / self.temperature
+
+
+class ItemRetrievalScorer(ContrastiveOutput):
+    """blocks/retrieval/base.py:130-420 (the V1 scorer) in its own argument names: in-batch (and sampler-provided) negatives,
+    false negatives rescored to ``sampling_downscore_false_negatives_value``, positives in column 0 -- the computation of
+    ``ContrastiveOutput`` (one fused kernel: ``mh_inbatch_softmax_*``)."""
+
+    def __init__(self, samplers: Sequence = (), sampling_downscore_false_negatives: bool = True,
+                 sampling_downscore_false_negatives_value: float = MIN_FLOAT, item_id_feature_name: str = "item_id",
+                 item_domain: str = "item_id", query_name: str = "query", item_name: str = "item", cache_query: bool = False,
+                 sampled_softmax_mode: bool = False, store_negative_ids: bool = False, logits_temperature: float = 1.0,
+                 item_id_column: Optional[ColumnSchema] = None, post=None, name: Optional[str] = None):
+        if sampled_softmax_mode:
+            raise NotImplementedError("sampled_softmax_mode (output-layer weights as candidates): use ContrastiveOutput(EmbeddingTable)")
+        if cache_query:
+            raise NotImplementedError("cache_query (ModelContext) is outside the hot path")
+        super().__init__(item_id_column, list(samplers) if samplers else "in-batch",
+                         downscore_false_negatives=sampling_downscore_false_negatives and item_id_column is not None,
+                         false_negative_score=sampling_downscore_false_negatives_value, logits_temperature=logits_temperature,
+                         store_negative_ids=store_negative_ids, query_name=query_name, candidate_name=item_name, post=post, name=name)
+        self.item_id_feature_name, self.item_domain = item_id_feature_name, item_domain
+
+
+class ItemRetrievalTask:
+    """prediction_tasks/retrieval.py:33-140: the V1 prediction task of ``TwoTowerModel(prediction_tasks=...)`` -- a recipe for
+    ``ItemRetrievalScorer`` + ``LogitsTemperatureScaler`` over the schema's item-id column.  ``to_output()`` builds the scorer."""
+
+    DEFAULT_LOSS = "categorical_crossentropy"
+
+    def __init__(self, schema: Schema, samplers: Sequence = (), target_name: Optional[str] = None, task_name: Optional[str] = None,
+                 task_block=None, post_logits=None, logits_temperature: float = 1.0, cache_query: bool = False,
+                 store_negative_ids: bool = False):
+        if task_block is not None:
+            raise NotImplementedError("task_block is outside the hot path")
+        ids = schema.select_by_tag(Tags.ITEM_ID)
+        if len(ids) < 1:
+            raise ValueError("ItemRetrievalTask needs a column tagged Tags.ITEM_ID in the schema")
+        self.schema, self.samplers, self.post_logits = schema, samplers, post_logits
+        self.logits_temperature, self.cache_query, self.store_negative_ids = float(logits_temperature), cache_query, store_negative_ids
+        self.item_id_feature_name = ids.column_names[0]
+        self.target_name, self.task_name = target_name, task_name or "item_retrieval_task"
+
+    def to_output(self, downscore_false_negatives: bool = True) -> ItemRetrievalScorer:
+        col = self.schema.select_by_tag(Tags.ITEM_ID).first
+        return ItemRetrievalScorer(samplers=self.samplers, sampling_downscore_false_negatives=downscore_false_negatives,
+                                   item_id_feature_name=self.item_id_feature_name, item_domain=self.item_id_feature_name,
+                                   cache_query=self.cache_query, store_negative_ids=self.store_negative_ids,
+                                   logits_temperature=self.logits_temperature, item_id_column=col, post=self.post_logits)
+
+
+class BinaryClassificationTask:
+    """prediction_tasks/classification.py:37-130: the V1 name of ``BinaryOutput`` (Dense(1, sigmoid) + BCE).  ``target``: a column
+    name, or a schema with exactly one column tagged BINARY_CLASSIFICATION; ``to_output()`` builds the head."""
+
+    DEFAULT_LOSS = "binary_crossentropy"
+
+    def __init__(self, target: Optional[Union[str, Schema]] = None, task_name: Optional[str] = None, task_block=None):
+        if task_block is not None:
+            raise NotImplementedError("task_block is outside the hot path")
+        if isinstance(target, Schema):
+            cols = target.select_by_tag(Tags.BINARY_CLASSIFICATION).column_names
+            if not cols:
+                raise ValueError("Binary classification task requires a column with a `Tags.BINARY_CLASSIFICATION` tag.")
+            if len(cols) > 1:
+                raise ValueError(f"Binary classification task requires a single target column, got {cols}")
+            target = cols[0]
+        self.target_name = target
+        self.task_name = task_name or (f"{target}/binary_classification_task" if target else "binary_classification_task")
+
+    def to_output(self, device=None) -> BinaryOutput:
+        return BinaryOutput(self.target_name, device=device)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# per-block optimizers
+# --------------------------------------------------------------------------------------------------------------------
+@dataclass
+class OptimizerBlocks:
+    """blocks/optimizer.py:42-70: an optimizer and the blocks whose variables it updates."""
+
+    optimizer: Union[str, optim.Optimizer]
+    blocks: Union[Block, Sequence[Block]]
+
+    def __post_init__(self):
+        self.optimizer = optim.get(self.optimizer)
+        self.blocks = [self.blocks] if isinstance(self.blocks, Block) else list(self.blocks)
+
+
+def split_embeddings_on_size(embeddings, threshold: int) -> Tuple[List[Block], List[Block]]:
+    """blocks/optimizer.py:461-477: (large, small) embedding tables of an ``Embeddings`` block by row count."""
+    tables = embeddings.feature_table if isinstance(embeddings, EmbeddingsBlock) else embeddings.parallel_dict
+    seen, large, small = set(), [], []
+    for t in tables.values():
+        if id(t) in seen:
+            continue
+        seen.add(id(t))
+        (large if t.input_dim >= threshold else small).append(t)
+    if not large:
+        warnings.warn(f"All embedding tables have a smaller input dim than threshold {threshold}, thus return empty list.")
+    return large, small
+
+
+class MultiOptimizer(optim.Optimizer):
+    """blocks/optimizer.py:73-340: different optimizers for different blocks of ONE model; variables of no listed block take
+    ``default_optimizer`` (the reference defaults to "rmsprop", which has no fused kernel here: name one of sgd / adagrad /
+    adam).  Dense tensors: one ``mh_dense_optimizer_step_multi`` launch per optimizer.  Embedding tables: the fused sparse
+    update of an ``Embeddings`` block runs once per optimizer over the tables that optimizer owns (an ``EmbeddingTable`` listed
+    in a pair, or every table of a listed block)."""
+
+    name = "multi"
+
+    def __init__(self, optimizers_and_blocks: Sequence[OptimizerBlocks], default_optimizer: Union[str, optim.Optimizer] = "adagrad",
+                 name: str = "MultiOptimizer"):
+        if not optimizers_and_blocks:
+            raise ValueError("`optimizers_and_blocks` can't be empty")
+        self.default_optimizer = optim.get(default_optimizer)
+        super().__init__(self.default_optimizer.learning_rate)
+        self.optimizers_and_blocks = [p if isinstance(p, OptimizerBlocks) else OptimizerBlocks(*p) for p in optimizers_and_blocks]
+        self._name = name
+
+    @property
+    def optimizers(self) -> List[optim.Optimizer]:
+        out, seen = [], set()
+        for o in [p.optimizer for p in self.optimizers_and_blocks] + [self.default_optimizer]:
+            if id(o) not in seen:
+                seen.add(id(o))
+                out.append(o)
+        return out
+
+    def _owner(self, model) -> Dict[int, optim.Optimizer]:
+        """id(Parameter) -> optimizer, from the listed blocks (a later pair wins, like the reference's variable assignment)."""
+        own: Dict[int, optim.Optimizer] = {}
+        for pair in self.optimizers_and_blocks:
+            for blk in pair.blocks:
+                for p in blk.parameters():
+                    own[id(p)] = pair.optimizer
+        return own
+
+    def ensure_begun(self, device) -> None:
+        for o in self.optimizers:
+            o.ensure_begun(device)
+
+    def apply(self, model) -> None:
+        params = model.parameters()
+        if not params:
+            return
+        self.ensure_begun(params[0].data.device)
+        own = self._owner(model)
+        with ops.SIDE.deferred():
+            for blk in optim._walk(model):
+                if isinstance(blk, EmbeddingsBlock) and getattr(blk, "_pending", None) is not None:
+                    tabs = {id(t.table): own.get(id(t.table), self.default_optimizer) for t in blk.feature_table.values()}
+                    used = {id(o): o for o in tabs.values()}
+                    if len(used) == 1:
+                        blk.apply_sparse(next(iter(used.values())))
+                        continue
+                    # several optimizers inside one Embeddings block: one fused update per optimizer over its own tables
+                    grad, offsets = blk._pending
+                    blk._pending, blk._pending_event = None, None
+                    ops.SIDE.join()  # the gradient's producer: the per-optimizer launches below run on the launch stream
+                    for o in used.values():
+                        mine = {n: off for n, off in offsets.items() if tabs[id(blk.feature_table[n].table)] is o}
+                        if mine:
+                            blk._apply_sparse_now(o, grad, mine)
+                elif hasattr(blk, "apply_sparse") and not isinstance(blk, EmbeddingsBlock):
+                    blk.apply_sparse(self.default_optimizer)
+            ops.run_tail()
+            ops.SIDE.join_stream("dw")
+            dense = [p for p in params if not p.sparse and p.trainable and p.grad is not None]
+            for o in self.optimizers:
+                mine = [p for p in dense if own.get(id(p), self.default_optimizer) is o]
+                if mine:
+                    ops.dense_optimizer_step_multi(o, mine)
+        for o in self.optimizers:
+            o._begun = False
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# top-k metrics (metrics/topk.py:48-520) over mh_topk_metrics
+# --------------------------------------------------------------------------------------------------------------------
+class TopkMetric:
+    """Streaming mean of one ranking metric @k.  ``update_state(y_true, y_pred, label_relevant_counts=None)``: with
+    ``pre_sorted=True`` (default, what ``BruteForce`` / ``ContrastiveOutput`` hand over in testing mode) ``y_true`` holds the
+    relevance of the candidates already ordered by score; otherwise the rows are ordered by ``y_pred`` first
+    (``extract_topk``, metrics/topk.py:430-470; ties -> lower index)."""
+
+    _column = 0
+    _short = "recall"
+
+    def __init__(self, k: int = 5, pre_sorted: bool = True, name: Optional[str] = None):
+        self.k, self._pre_sorted = int(k), pre_sorted
+        self.name = name or f"{self._short}_at_{k}"
+        self.reset_state()
+
+    @property
+    def pre_sorted(self) -> bool:
+        return self._pre_sorted
+
+    @pre_sorted.setter
+    def pre_sorted(self, v: bool) -> None:
+        self._pre_sorted = bool(v)
+
+    def reset_state(self) -> None:
+        self._sum, self._n = 0.0, 0
+
+    def _rows(self, y_true: torch.Tensor, y_pred: torch.Tensor, label_relevant_counts):
+        if not self._pre_sorted:
+            k = min(self.k, y_pred.shape[1])
+            if label_relevant_counts is None:
+                label_relevant_counts = y_true.sum(dim=1)
+            order = torch.argsort(y_pred, dim=1, descending=True, stable=True)[:, :k]
+            y_true = torch.gather(y_true, 1, order)
+        return ops.topk_metrics(y_true.to(torch.float32).contiguous(), min(self.k, y_true.shape[1]), label_relevant_counts)
+
+    def update_state(self, y_true: torch.Tensor, y_pred: torch.Tensor, sample_weight=None, label_relevant_counts=None) -> None:
+        if sample_weight is not None:
+            raise NotImplementedError("sample_weight is outside the hot path")
+        m = self._rows(y_true, y_pred, label_relevant_counts)[:, self._column]
+        self._sum += float(m.sum())
+        self._n += int(m.shape[0])
+
+    def result(self) -> float:
+        return self._sum / self._n if self._n else 0.0
+
+
+def _metric(column: str):
+    idx = ops.TOPK_METRIC_NAMES.index(column)
+    return type(f"_{column}", (TopkMetric,), {"_column": idx, "_short": column})
+
+
+class RecallAt(_metric("recall")):
+    """metrics/topk.py RecallAt"""
+
+
+class PrecisionAt(_metric("precision")):
+    """metrics/topk.py PrecisionAt"""
+
+
+class AvgPrecisionAt(_metric("map")):
+    """metrics/topk.py AvgPrecisionAt (MAP@k)"""
+
+
+class NDCGAt(_metric("ndcg")):
+    """metrics/topk.py NDCGAt"""
+
+
+class MRRAt(_metric("mrr")):
+    """metrics/topk.py MRRAt"""
+
+
+class TopKMetricsAggregator:
+    """metrics/topk.py:522-600: several top-k metrics fed by ONE extraction / ONE ``mh_topk_metrics`` launch per k."""
+
+    def __init__(self, *topk_metrics: TopkMetric):
+        if not topk_metrics:
+            raise ValueError("TopKMetricsAggregator needs at least one metric")
+        self.topk_metrics = list(topk_metrics)
+
+    @classmethod
+    def default_metrics(cls, top_ks: Sequence[int], **kwargs) -> "TopKMetricsAggregator":
+        ms: List[TopkMetric] = []
+        for k in top_ks:
+            ms += [RecallAt(k), MRRAt(k), NDCGAt(k), AvgPrecisionAt(k), PrecisionAt(k)]
+        return cls(*ms)
+
+    def update_state(self, y_true, y_pred, sample_weight=None, label_relevant_counts=None) -> None:
+        for m in self.topk_metrics:
+            m.update_state(y_true, y_pred, sample_weight, label_relevant_counts)
+
+    def result(self) -> Dict[str, float]:
+        return {m.name: m.result() for m in self.topk_metrics}
+
+    def reset_state(self) -> None:
+        for m in self.topk_metrics:
+            m.reset_state()

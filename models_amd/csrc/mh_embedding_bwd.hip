@@ -29,6 +29,7 @@
 #include <cstring>
 
 #include "mh_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -1079,7 +1080,16 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, kern, 256, 0) != hipSuccess || r < 1) r = 4;
             resident[vmode] = r;
         }
-        const int64_t cap = (int64_t)mh_num_cus() * resident[vmode];
+        // MERLIN_HIP_APPLY_RESIDENT = n caps the persistent grid at n workgroups per compute unit (default: all the register budget
+        // allows, 5): a full grid leaves no registers on any SIMD for kernels of OTHER streams until it ends (the step's dW GEMM
+        // needs 120 per lane, this kernel 96 x 5 of 512)
+        static int cap_env = -1;
+        if (cap_env < 0) {
+            const char* e = getenv("MERLIN_HIP_APPLY_RESIDENT");
+            cap_env = e ? atoi(e) : 0;
+        }
+        const int res = (cap_env > 0 && cap_env < resident[vmode]) ? cap_env : resident[vmode];
+        const int64_t cap = (int64_t)mh_num_cus() * res;
         if (nb > cap) nb = cap;
         MH_LAUNCH(kern, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad, grad_row_stride, carry, home,
                            pieces, counter, optimizer, hp, det);

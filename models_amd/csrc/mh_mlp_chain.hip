@@ -632,26 +632,37 @@ struct ReduceArgs {
     float* db[MAXL];
 };
 
-// out[p] = sum_g slabs[g][p] in a fixed order: a workgroup owns 64 parameters, its 16 wavefronts take every 16th slab
-// (4 independent chains each: 4 dependent load rounds for 256 slabs instead of 16), then a fixed-order tree through LDS
-__global__ __launch_bounds__(1024) void chain_reduce_kernel(const ReduceArgs a) {
+// out[p] = sum_g slabs[g][p] in a fixed order: a workgroup owns 64 parameters; 16 slab classes (slab k belongs to class k % 16)
+// with 4 independent chains each, then a fixed-order tree through LDS.  A workgroup is 4 wavefronts, each walking 4 of the 16
+// classes: 16 independent load chains per thread.  (First version: 1024-thread workgroups, one class per wavefront -- the same
+// sums, but a 16-wavefront workgroup needs 16 free wave slots on ONE compute unit: beside the persistent sparse-apply kernel,
+// which holds 5 of 5 wave slots' worth of registers on every SIMD until it ends, the launch waited for that kernel to finish --
+// 5 us alone, 155 us in the step, on the launch stream's critical path.  A 4-wavefront workgroup of 32 registers fits beside it.)
+// The order of every addition is the one of the first version: results are bit-identical.
+__global__ __launch_bounds__(256) void chain_reduce_kernel(const ReduceArgs a) {
     __shared__ float red[1024];
-    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int o = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int p = blockIdx.x * 64 + o;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (p < a.ptotal) {
-        int k = grp;
-        for (; k + 48 < a.G; k += 64) {
-            s0 += a.slabs[(int64_t)k * a.ptotal + p];
-            s1 += a.slabs[(int64_t)(k + 16) * a.ptotal + p];
-            s2 += a.slabs[(int64_t)(k + 32) * a.ptotal + p];
-            s3 += a.slabs[(int64_t)(k + 48) * a.ptotal + p];
+#pragma unroll 1  // 32 registers: what the sparse-apply kernel leaves free on a SIMD (see above); the 4 chains of a class are in flight
+    for (int c = 0; c < 4; ++c) {
+        const int grp = w * 4 + c;  // the class (the first version's wavefront index)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (p < a.ptotal) {
+            const int64_t step = (int64_t)a.ptotal;  // floats per slab
+            const float* q = a.slabs + (int64_t)grp * step + p;
+            int k = grp;
+            for (; k + 48 < a.G; k += 64, q += 64 * step) {
+                s0 += q[0];
+                s1 += q[16 * step];
+                s2 += q[32 * step];
+                s3 += q[48 * step];
+            }
+            for (; k < a.G; k += 16, q += 16 * step) s0 += q[0];
         }
-        for (; k < a.G; k += 16) s0 += a.slabs[(int64_t)k * a.ptotal + p];
+        red[grp * 64 + o] = (s0 + s1) + (s2 + s3);
     }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (grp != 0 || p >= a.ptotal) return;
+    if (w != 0 || p >= a.ptotal) return;
     float v = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; g += 4) v += (red[g * 64 + o] + red[(g + 1) * 64 + o]) + (red[(g + 2) * 64 + o] + red[(g + 3) * 64 + o]);
@@ -884,7 +895,7 @@ static int32_t chain_bwd_phases(int phases, const float* x, int64_t ldx, int64_t
         r.poff_w[l] = a.poff_w[l];
         r.poff_b[l] = a.poff_b[l];
     }
-    MH_LAUNCH(chain_reduce_kernel, dim3((unsigned)mh_ceil_div(a.ptotal, 64)), dim3(1024), 0, s, r);
+    MH_LAUNCH(chain_reduce_kernel, dim3((unsigned)mh_ceil_div(a.ptotal, 64)), dim3(256), 0, s, r);
     MH_CHECK_LAUNCH("mh_mlp_chain_bwd(reduce)");
     return MH_OK;
 }

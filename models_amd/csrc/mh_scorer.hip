@@ -336,8 +336,21 @@ int32_t mh_scorer_tiled_fwd(const float* q, const float* neg, const void* pos_id
                             int64_t Nn, int E, float invT, float fns, const float* neg_corr, int corr_after_mask, float* part_m,
                             float* part_s, hipStream_t s);
 void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s);
+// opt-in bf16x3 arithmetic of the gradient passes (mh_scorer_split.hip): hi / lo bf16 split of both matrices, 3-term products
+struct MhSplitMatrix {
+    uint16_t *hi, *lo, *hiT, *loT;
+    int64_t ldT;
+};
+int64_t mh_split_matrix_bytes(int64_t N);
+MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, hipStream_t s);
+int mh_split_plan(int64_t Nx, int64_t Ny, int* tiles_per_split);
+int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X, int64_t Nx, const MhSplitMatrix& Y, int64_t Ny,
+                               const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
+                               float fns, float gscale, float* part_m, float* part_s, float* opart, hipStream_t s);
 
 namespace {
+
+int g_scorer_arith = 0;  // 0 = f32 (default), 1 = bf16x3 (mh_set_scorer_arith)
 
 inline int padded_E(int E) { return E <= 32 ? 32 : (E <= 64 ? 64 : 128); }
 inline int64_t align64(int64_t n) { return (n + 63) / 64 * 64; }  // floats: keeps every sub-buffer 256-byte aligned
@@ -348,7 +361,7 @@ inline int64_t align64(int64_t n) { return (n + 63) / 64 * 64; }  // floats: kee
 struct StreamWs {
     int Ep;
     bool pad;
-    int64_t pos, qp, itemp, negp, part_m, part_s, opart_row, opart_col, outp_row, outp_col, outp_item, total;
+    int64_t pos, qp, itemp, negp, part_m, part_s, opart_row, opart_col, outp_row, outp_col, outp_item, split_q, split_n, total;
     MhStreamPlan row, col;
 };
 
@@ -383,13 +396,33 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         w.outp_item = take(B * w.Ep);
         if (pass == 1) w.outp_col = take(Nn * w.Ep);
     }
+    w.split_q = w.split_n = 0;
+    if (pass != 0 && E == 128) {  // the bf16 (hi, lo) splits of q and of the negatives, both orientations (bf16x3 arithmetic)
+        w.split_q = take(mh_split_matrix_bytes(B) / 4);
+        w.split_n = take(mh_split_matrix_bytes(Nn) / 4);
+    }
     w.total = o;
     return w;
+}
+
+// the bf16x3 kernels cover the plain in-batch case: E = 128, no logQ correction inside the kernel, 16-byte aligned rows, and never
+// more candidate splits than the fp32 plan the partial buffers were sized for
+bool split_ok(int64_t Nx, int64_t Ny, int E, const float* x_corr, const float* y_corr, const float* a, const float* b, int fp32_nsplit) {
+    if (g_scorer_arith != 1 || E != 128 || x_corr || y_corr || Ny < 64) return false;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return false;
+    int tps = 0;
+    return mh_split_plan(Nx, Ny, &tps) <= fp32_nsplit;
 }
 
 }  // namespace
 
 extern "C" {
+
+int32_t mh_set_scorer_arith(int32_t mode) {
+    MH_REQUIRE(mode == 0 || mode == 1, "mh_set_scorer_arith: mode must be 0 (f32) or 1 (bf16x3)");
+    g_scorer_arith = mode;
+    return MH_OK;
+}
 
 int64_t mh_inbatch_softmax_workspace_bytes(int64_t B, int64_t Nn, int32_t E, int32_t pass) {
     if (B <= 0 || E <= 0) return 0;
@@ -513,13 +546,24 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
         ix = ws + w.itemp;
         nx = ws + w.negp;
     }
-    int32_t st = mh_stream_launch(SM_FWD_GRAD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT,
-                                  false_neg_score, 1.f, nullptr, 0, ws + w.part_m, ws + w.part_s, ws + w.opart_row, nullptr, neg_logq,
-                                  logq_after_mask, s);
+    int32_t st;
+    int nsplit = plan.nsplit;
+    if (split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {
+        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, s);
+        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, s);
+        int tps = 0;
+        nsplit = mh_split_plan(B, Nn, &tps);
+        st = mh_stream_split_launch(SM_FWD_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
+                                    1.f, ws + w.part_m, ws + w.part_s, ws + w.opart_row, s);
+    } else {
+        st = mh_stream_launch(SM_FWD_GRAD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT,
+                              false_neg_score, 1.f, nullptr, 0, ws + w.part_m, ws + w.part_s, ws + w.opart_row, nullptr, neg_logq,
+                              logq_after_mask, s);
+    }
     if (st != MH_OK) return st;
     float* dq_o = w.pad ? ws + w.outp_row : dq;
     float* di_o = ditem ? (w.pad ? ws + w.outp_item : ditem) : nullptr;
-    mh_stream_fwd_grad_combine(qx, ix, pos, B, w.Ep, plan.nsplit, ws + w.part_m, ws + w.part_s, ws + w.opart_row, invT, g,
+    mh_stream_fwd_grad_combine(qx, ix, pos, B, w.Ep, nsplit, ws + w.part_m, ws + w.part_s, ws + w.opart_row, invT, g,
                                loss, lse, dq_o, di_o, s);
     if (w.pad) {
         mh_stream_unpad_rows(dq_o, B, E, w.Ep, dq, s);
@@ -581,14 +625,30 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
         nx = ws + w.negp;
     }
     int32_t st;
+    // bf16x3 arithmetic: both matrices split once for the two passes of this call
+    const bool use_split = split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, w.row.nsplit) &&
+                           split_ok(Nn, B, E, neg_logq, nullptr, q, neg_item, w.col.nsplit) && B >= 64;
+    MhSplitMatrix sq{}, sn{};
+    if (use_split) {
+        sq = mh_split_prepare(q, B, ws + w.split_q, s);
+        sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, s);
+    }
     if (dq) {
         const MhStreamPlan& pr = w.row;
-        st = mh_stream_launch(SM_GRAD, 0, pr, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT,
-                              false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_row, nullptr, neg_logq, logq_after_mask, s);
+        int ns = pr.nsplit;
+        if (use_split) {
+            int tps = 0;
+            ns = mh_split_plan(B, Nn, &tps);
+            st = mh_stream_split_launch(SM_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT, false_neg_score,
+                                        gscale, nullptr, nullptr, ws + w.opart_row, s);
+        } else {
+            st = mh_stream_launch(SM_GRAD, 0, pr, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT,
+                                  false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_row, nullptr, neg_logq, logq_after_mask, s);
+        }
         if (st != MH_OK) return st;
         float* dq_o = w.pad ? ws + w.outp_row : dq;
         float* di_o = ditem ? (w.pad ? ws + w.outp_item : ditem) : nullptr;
-        mh_stream_grad_combine(ws + w.opart_row, B, w.Ep, pr.nsplit, pos, lse, ix, qx, invT, gscale, dq_o, di_o, s);
+        mh_stream_grad_combine(ws + w.opart_row, B, w.Ep, ns, pos, lse, ix, qx, invT, gscale, dq_o, di_o, s);
         if (w.pad) {
             mh_stream_unpad_rows(dq_o, B, E, w.Ep, dq, s);
             if (ditem) mh_stream_unpad_rows(di_o, B, E, w.Ep, ditem, s);
@@ -597,11 +657,19 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
         MH_REQUIRE(ditem == nullptr, "mh_inbatch_softmax_bwd: ditem needs dq (both come from the row pass)");
     }
     const MhStreamPlan& pc = w.col;
-    st = mh_stream_launch(SM_GRAD, 1, pc, nx, Nn, qx, B, w.Ep, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT,
-                          false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_col, neg_logq, nullptr, logq_after_mask, s);
+    int nsc = pc.nsplit;
+    if (use_split) {
+        int tps = 0;
+        nsc = mh_split_plan(Nn, B, &tps);
+        st = mh_stream_split_launch(SM_GRAD, 1, sn, Nn, sq, B, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT, false_neg_score, gscale,
+                                    nullptr, nullptr, ws + w.opart_col, s);
+    } else {
+        st = mh_stream_launch(SM_GRAD, 1, pc, nx, Nn, qx, B, w.Ep, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT,
+                              false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_col, neg_logq, nullptr, logq_after_mask, s);
+    }
     if (st != MH_OK) return st;
     float* dn_o = w.pad ? ws + w.outp_col : dneg_item;
-    mh_stream_grad_combine(ws + w.opart_col, Nn, w.Ep, pc.nsplit, nullptr, nullptr, nullptr, nullptr, invT, gscale, dn_o,
+    mh_stream_grad_combine(ws + w.opart_col, Nn, w.Ep, nsc, nullptr, nullptr, nullptr, nullptr, invT, gscale, dn_o,
                            nullptr, s);
     if (w.pad) mh_stream_unpad_rows(dn_o, Nn, E, w.Ep, dneg_item, s);
     MH_CHECK_LAUNCH("mh_inbatch_softmax_bwd");

@@ -395,13 +395,23 @@ def _target_column(schema: Schema) -> Optional[ColumnSchema]:
     return t.first if len(t) else None
 
 
+def _binary_head(prediction_tasks, schema: Schema, device) -> BinaryOutput:
+    """``prediction_tasks=``: a ``BinaryOutput`` (V2 vocabulary), a ``BinaryClassificationTask`` (V1: prediction_tasks/
+    classification.py:37-130), or None (the schema's target column)."""
+    if prediction_tasks is None:
+        return BinaryOutput(_target_column(schema), device=device)
+    if hasattr(prediction_tasks, "to_output"):
+        return prediction_tasks.to_output(device=device)
+    return prediction_tasks
+
+
 def DLRMModel(schema: Schema, *, embedding_dim: Optional[int] = None, embeddings=None,
               bottom_block: Optional[Block] = None, top_block: Optional[Block] = None,
               prediction_tasks: Optional[BinaryOutput] = None, device=None) -> RankingModel:
     """ranking.py:23-92."""
     body = DLRMBlock(schema, embedding_dim=embedding_dim, embeddings=embeddings, bottom_block=bottom_block,
                      top_block=top_block, device=device)
-    head = prediction_tasks or BinaryOutput(_target_column(schema), device=device)
+    head = _binary_head(prediction_tasks, schema, device)
     return RankingModel(body, head, schema, name="dlrm_model")
 
 
@@ -463,7 +473,7 @@ def DCNModel(schema: Schema, depth: int, deep_block: Optional[Block] = None, sta
     ``CrossBlock``, of which ``low_rank_dim`` is the one on the hot path)."""
     deep_block = deep_block or MLPBlock([512, 256], device=device)
     body = DCNBody(schema, depth, deep_block, stacked, input_block, embedding_dim, device, low_rank_dim, parallel_concat)
-    head = prediction_tasks or BinaryOutput(_target_column(schema), device=device)
+    head = _binary_head(prediction_tasks, schema, device)
     return RankingModel(body, head, schema, name="dcn_model")
 
 
@@ -625,13 +635,16 @@ class TopKEncoder(Block):
 def TwoTowerModel(schema: Schema, query_tower: Block, item_tower: Optional[Block] = None,
                   query_tower_tag=Tags.USER, item_tower_tag=Tags.ITEM, embedding_dim: Optional[int] = None,
                   samplers=(), logits_temperature: float = 1.0, l2_normalization: bool = False,
-                  downscore_false_negatives: bool = True, post_logits=None, device=None) -> RetrievalModel:
+                  downscore_false_negatives: bool = True, post_logits=None, device=None, prediction_tasks=None) -> RetrievalModel:
     """retrieval.py:106-203 (V1 route; same scorer math, item branch key "item").  ``samplers``: "in-batch" (default)
     and / or sampler objects of ``models_amd.sampling`` (e.g. ``CachedCrossBatchSampler``); ``post_logits``: a
     ``PopularityLogitsCorrection`` (the reference's logQ correction for popularity-biased in-batch negatives)."""
     body = TwoTowerBlock(schema, query_tower, item_tower, query_tower_tag, item_tower_tag, embedding_dim,
                          l2_normalization, device)
     item_id = schema.select_by_tag(Tags.ITEM_ID)
+    if prediction_tasks is not None:  # V1 vocabulary: ItemRetrievalTask(schema, samplers=..., logits_temperature=...) (retrieval.py:163-177)
+        out = prediction_tasks.to_output(downscore_false_negatives) if hasattr(prediction_tasks, "to_output") else prediction_tasks
+        return RetrievalModel(body, out, schema, name="two_tower_model")
     out = ContrastiveOutput(item_id.first if len(item_id) else None, list(samplers) if samplers else "in-batch",
                             downscore_false_negatives=downscore_false_negatives and len(item_id) > 0,
                             logits_temperature=logits_temperature, post=post_logits)

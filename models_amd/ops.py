@@ -1293,6 +1293,27 @@ def _logq_pair(pos_logq, neg_logq, B, Nn):
     return pos_logq, neg_logq
 
 
+_ARITH = [None]
+
+
+def _sync_scorer_arith(lib) -> None:
+    """MERLIN_HIP_SCORER_ARITH = f32 (default) | bf16x3 is read HERE (a dict lookup per call) and handed to the library when it
+    changes (``mh_set_scorer_arith``): the opt-in split-bf16 arithmetic of the scorer's gradient passes at E = 128 -- dot products
+    within ~2.3e-6 |q| |item| of the exact ones at 16 / 3 of the fp32 MFMA rate; never the default, reported under its own dtype."""
+    import os
+
+    want = 1 if os.environ.get("MERLIN_HIP_SCORER_ARITH", "f32") == "bf16x3" else 0
+    if _ARITH[0] != want:
+        check(lib.mh_set_scorer_arith(want), "mh_set_scorer_arith")
+        _ARITH[0] = want
+
+
+def scorer_arith() -> str:
+    import os
+
+    return "bf16x3" if os.environ.get("MERLIN_HIP_SCORER_ARITH", "f32") == "bf16x3" else "f32"
+
+
 def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: float = 1.0,
                     false_neg_score: float = -655.04, materialize: bool = True, pos_logq=None, neg_logq=None,
                     logq_after_mask: bool = False) -> ScorerResult:
@@ -1345,6 +1366,7 @@ def inbatch_softmax_train(q, item, neg_item, pos_ids=None, neg_ids=None, tempera
     dq = torch.empty_like(q)
     ditem = torch.empty_like(item)
     ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 2), q.device, "scorer_fwd_dq")
+    _sync_scorer_arith(lib)
     with _timed("inbatch_softmax_fwd_dq", nbytes=4 * (4 * B + Nn) * E, flops=4 * B * Nn * E):
         check(
             lib.mh_inbatch_softmax_fwd_dq(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
@@ -1372,6 +1394,7 @@ def inbatch_softmax_backward(q, item, neg_item, lse, pos_ids=None, neg_ids=None,
     ditem = torch.empty_like(item) if need_dq else None
     dneg = torch.empty_like(neg_item)
     ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 1), q.device, "scorer_bwd")
+    _sync_scorer_arith(lib)
     with _timed("inbatch_softmax_bwd", nbytes=4 * (3 * B + 2 * Nn) * E, flops=(8 if dq is not None else 4) * B * Nn * E):
         check(
             lib.mh_inbatch_softmax_bwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,

@@ -276,3 +276,47 @@ def test_parameters_walk_is_the_preorder_of_the_recursive_definition():
         assert [id(p) for p in m.parameters()] == [id(p) for p in rec_params(m)]
         assert [id(b) for b in optim._walk(m)] == [id(b) for b in rec_walk(m)]
         assert len(m.parameters()) > 0
+
+
+def test_reference_names_of_the_hot_path_exist_and_build():
+    """merlin/models/tf/__init__.py:42-47, 100-102, 127-132, 165: a reference script importing these names must not fail at import;
+    each is a thin class over the code that does the work (models_amd/compat.py)."""
+    from models_amd import schema as S
+
+    for n in ("L2Norm", "ItemRetrievalScorer", "LogitsTemperatureScaler", "LazyAdam", "MultiOptimizer", "OptimizerBlocks",
+              "split_embeddings_on_size", "BinaryClassificationTask", "ItemRetrievalTask", "RecallAt", "NDCGAt", "MRRAt",
+              "PrecisionAt", "AvgPrecisionAt", "TopKMetricsAggregator"):
+        assert hasattr(mm, n), n
+    schema = mm.Schema([S.categorical("user_id", 500, [S.Tags.USER, S.Tags.USER_ID]),
+                        S.categorical("item_id", 300, [S.Tags.ITEM, S.Tags.ITEM_ID]), S.binary_target("click")])
+    # V1 retrieval vocabulary -> the same scorer object the V2 vocabulary builds
+    task = mm.ItemRetrievalTask(schema, logits_temperature=0.5, store_negative_ids=True)
+    m = mm.TwoTowerModel(schema, mm.MLPBlock([16], device="cpu"), embedding_dim=8, device="cpu", prediction_tasks=task)
+    assert isinstance(m.output, mm.ItemRetrievalScorer) and isinstance(m.output, mm.ContrastiveOutput)
+    assert m.output.logits_temperature == 0.5 and m.output.store_negative_ids and m.output.col_schema.name == "item_id"
+    with pytest.raises(ValueError):
+        mm.ItemRetrievalTask(mm.Schema([S.categorical("a", 5)]))
+    # V1 ranking vocabulary
+    t = mm.BinaryClassificationTask("click")
+    d = mm.DLRMModel(schema, embedding_dim=8, top_block=mm.MLPBlock([8], device="cpu"), prediction_tasks=t, device="cpu")
+    assert isinstance(d.output, mm.BinaryOutput) and d.output.target == "click" and t.task_name == "click/binary_classification_task"
+    assert mm.BinaryClassificationTask(schema.select_by_tag(S.Tags.BINARY_CLASSIFICATION) if hasattr(S.Tags, "BINARY_CLASSIFICATION") else "click").target_name == "click"
+    # temperature scaler: Prediction in training / testing only
+    sc = mm.LogitsTemperatureScaler(0.25)
+    import torch
+
+    p = mm.Prediction(torch.ones(2, 3), torch.zeros(2, 3))
+    assert torch.equal(sc(p, training=True).outputs, torch.full((2, 3), 4.0)) and sc(p) is p
+    # per-block optimizers
+    emb = d.body.embeddings
+    large, small = mm.split_embeddings_on_size(emb, 400)
+    assert [t_.input_dim for t_ in large] == [500] and len(small) == 1
+    mo = mm.MultiOptimizer([mm.OptimizerBlocks("sgd", large), mm.OptimizerBlocks(mm.LazyAdam(0.01), small)], default_optimizer="adagrad")
+    own = mo._owner(d)
+    assert own[id(large[0].table)].name == "sgd" and own[id(small[0].table)].name == "adam" and len(mo.optimizers) == 3
+    with pytest.raises(ValueError):
+        mm.MultiOptimizer([], "sgd")
+    with pytest.raises(ValueError):  # the reference's default "rmsprop" has no fused kernel here: it must be named explicitly
+        mm.MultiOptimizer([mm.OptimizerBlocks("sgd", large)], default_optimizer="rmsprop")
+    assert [m_.name for m_ in mm.TopKMetricsAggregator.default_metrics([10]).topk_metrics] == \
+        ["recall_at_10", "mrr_at_10", "ndcg_at_10", "map_at_10", "precision_at_10"]

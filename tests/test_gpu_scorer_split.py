@@ -1,0 +1,65 @@
+"""The opt-in bf16x3 arithmetic of the in-batch scorer's gradient passes (mh_set_scorer_arith(1), mh_scorer_split.hip): loss, lse,
+dq, ditem, dneg against the exact-fp32 kernels on the same inputs and against a float64 statement of
+ContrastiveOutput.outputs + CategoricalCrossEntropy (tf/outputs/contrastive.py:276-344, tf/losses/listwise.py:38-52), at
+north_star's tolerance: logits / lse within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from models_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref64(q, it, neg, pid, nid, T, fns):
+    """float64: logits = [pos, q neg^T with false negatives rescored] / T; loss = lse - pos; gradients of mean loss."""
+    q64, i64, n64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (q, it, neg))
+    pos = (q64 * i64).sum(1, keepdim=True)
+    s = q64 @ n64.T
+    if pid is not None:
+        mask = torch.tensor(pid.reshape(-1, 1) == nid.reshape(1, -1))
+        s = torch.where(mask, torch.full_like(s, fns), s)
+    logits = torch.cat([pos, s], dim=1) / T
+    lse = torch.logsumexp(logits, dim=1)
+    loss = lse - logits[:, 0]
+    loss.mean().backward()
+    return loss.detach().numpy(), lse.detach().numpy(), q64.grad.numpy(), i64.grad.numpy(), n64.grad.numpy()
+
+
+@pytest.mark.parametrize("B,Nn,ids,idt", [(512, 512, True, np.int32), (300, 300, True, np.int64), (256, 1000, False, None), (4096, 4096, True, np.int32)])
+def test_bf16x3_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, Nn, ids, idt):
+    rng = np.random.default_rng(B + Nn)
+    E, T, fns = 128, 0.05, -655.04
+    unit = lambda a: (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    q, it = unit(rng.normal(size=(B, E))), unit(rng.normal(size=(B, E)))
+    neg = it if Nn == B else unit(rng.normal(size=(Nn, E)))
+    pid = nid = None
+    if ids:
+        pid = rng.integers(0, max(B // 2, 8), size=B).astype(idt)  # duplicates: false negatives beside the diagonal
+        nid = pid if Nn == B else rng.integers(0, max(B // 2, 8), size=Nn).astype(idt)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    args = (t(q), t(it), t(neg), t(pid), t(nid), T, fns)
+
+    def run():
+        res, dq, ditem = ops.inbatch_softmax_train(*args)
+        _, _, dneg = ops.inbatch_softmax_backward(args[0], args[1], args[2], res.lse, args[3], args[4], T, fns, need_dq=False)
+        dq2, ditem2, dneg2 = ops.inbatch_softmax_backward(args[0], args[1], args[2], res.lse, args[3], args[4], T, fns)
+        return [x.cpu().numpy() for x in (res.loss, res.lse, dq, ditem, dneg, dq2, ditem2, dneg2)]
+
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
+    f32 = run()
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "bf16x3")
+    sp = run()
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
+    names = ("loss", "lse", "dq", "ditem", "dneg", "dq(bwd)", "ditem(bwd)", "dneg(bwd)")
+    assert any(not np.array_equal(a, b) for a, b in zip(f32, sp)), "the bf16x3 switch did not change the arithmetic"
+    for n, a, b in zip(names, f32, sp):
+        tol = 1e-4 if n in ("loss", "lse") else 2e-6  # gradients of the MEAN loss carry 1 / B
+        np.testing.assert_allclose(b, a, atol=tol, rtol=2e-4, err_msg=n)
+    if B <= 512:
+        loss, lse, dq, ditem, dneg = _ref64(q, it, neg, pid, nid, T, fns)
+        np.testing.assert_allclose(sp[0], loss, atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(sp[1], lse, atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(sp[2], dq, atol=2e-6, rtol=2e-4)
+        np.testing.assert_allclose(sp[3], ditem, atol=2e-6, rtol=2e-4)
+        np.testing.assert_allclose(sp[4], dneg, atol=2e-6, rtol=2e-4)

@@ -23,7 +23,7 @@ fns = {"embedding_bag": lambda: bench.run_embedding_bag(device, **kw),
        "fit_from_parquet": lambda: bench.run_fit_from_parquet(args, device, **kw),
        "topk": lambda: bench.run_topk(args, device, steps=8, warmup=4),
        "topk_f32": lambda: bench.run_topk(args, device, steps=6, warmup=4, mode="f32"),
-       "c4_one_gpu": lambda: bench.run_c4_one_gpu(args, device, tm),
+       "c4_one_gpu": lambda: bench.run_c4_one_gpu(args, device, tm, **kw),
        "dcn_train": lambda: bench.run_dcn(argparse.Namespace(**dict(vars(args), steps=6, warmup=2, batches=2)), device, tm),
        "twotower": lambda: bench.run_twotower(args, device, tm, steps=20, warmup=3, sustain=0.0, **kw)}
 print(json.dumps(fns[name](), indent=None))
