@@ -315,6 +315,11 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain, batch=None):
            "sustained": sustained, "step_ms": stats,
            "mfma": mfma_rates(km, ["inbatch_softmax_fwd", "inbatch_softmax_fwd_dq", "inbatch_softmax_bwd"]),
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
+    from models_amd import ops as _ops
+
+    if _ops.scorer_arith() == "bf16x3":
+        res["dtype"] = "bf16x3 (fp32-equivalent split: every product of the scorer's gradient passes = hi hi + hi lo + lo hi on the bf16 MFMA, fp32 accumulators); towers and embeddings f32"
+        res["accuracy_vs_f32_kernels"] = scorer_arith_error(device)
     if tm.world > 1:
         res["exchange"] = exchange_summary(runner)
         res["config"]["parallelism"] = f"dp{tm.world} + row-sharded user_id / item_id tables (all-to-all), in-batch negatives rank-local"
@@ -325,6 +330,36 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain, batch=None):
                                      + (" + dq" if train else ""), "op": k, "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
                            "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": km[k]["avg_ms"]}
     return res
+
+
+def scorer_arith_error(device, B=16384, E=128, T=0.05):
+    """The opt-in bf16x3 scorer against the exact-fp32 kernels on the same inputs (L2-normalised rows, the temperature of the
+    retrieval configs, duplicate ids so that false negatives are rescored): max |difference| of the per-row lse (a logit-scale
+    quantity: north_star's tolerance is 1e-4) and of the gradients of the MEAN loss scaled back by B."""
+    from models_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    unit = lambda x: (x / x.norm(dim=1, keepdim=True)).to(device)
+    q, it = unit(torch.randn(B, E, generator=g)), unit(torch.randn(B, E, generator=g))
+    ids = torch.randint(0, B // 2, (B,), generator=g, dtype=torch.int32).to(device)
+    prev = os.environ.get("MERLIN_HIP_SCORER_ARITH")
+    out = {}
+    try:
+        for mode in ("f32", "bf16x3"):
+            os.environ["MERLIN_HIP_SCORER_ARITH"] = mode
+            res, dq, ditem = ops.inbatch_softmax_train(q, it, it, ids, ids, T)
+            _, _, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, T, need_dq=False)
+            out[mode] = (res.lse.clone(), res.loss.clone(), dq.clone(), dneg.clone())
+    finally:
+        if prev is None:
+            os.environ.pop("MERLIN_HIP_SCORER_ARITH", None)
+        else:
+            os.environ["MERLIN_HIP_SCORER_ARITH"] = prev
+    a, b = out["f32"], out["bf16x3"]
+    d = lambda i: float((a[i] - b[i]).abs().max())
+    return {"shape": f"{B} x {B} x {E}, L2-normalised rows, 1/T = {1 / T:.0f}, ids with duplicates", "max_abs_lse_err": d(0), "max_abs_loss_err": d(1),
+            "max_abs_dq_err_times_B": d(2) * B, "max_abs_dneg_err_times_B": d(3) * B, "max_abs_dq_times_B": float(a[2].abs().max()) * B,
+            "tolerance": "north_star: logits / scores within 1e-4"}
 
 
 def run_negatives(args, device, tm: Timing, kinds, steps=20, warmup=6):
@@ -1497,6 +1532,22 @@ def main():
                                                  ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline")))
         secondary("twotower_train_b64k", lambda: pick(run_twotower(args, device, tm, steps=8, warmup=2, sustain=0.0, batch=65536),
                                                       ("metric", "value", "unit", "ms_per_step", "steps", "mfma", "kernels_ms")))
+
+        def tt_split(batch, steps):
+            # the SAME train step with the scorer's gradient passes in the opt-in bf16x3 arithmetic (every other line stays f32)
+            prev = os.environ.get("MERLIN_HIP_SCORER_ARITH")
+            os.environ["MERLIN_HIP_SCORER_ARITH"] = "bf16x3"
+            try:
+                r = run_twotower(args, device, tm, steps=steps, warmup=3, sustain=0.0, batch=batch)
+            finally:
+                if prev is None:
+                    os.environ.pop("MERLIN_HIP_SCORER_ARITH", None)
+                else:
+                    os.environ["MERLIN_HIP_SCORER_ARITH"] = prev
+            return pick(r, ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "accuracy_vs_f32_kernels", "kernels_ms"))
+
+        secondary("twotower_train_bf16x3", lambda: tt_split(None, 20))
+        secondary("twotower_train_b64k_bf16x3", lambda: tt_split(65536, 8))
         tk = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "roofline", "dtype", "bit_identical_to_f32_pipeline",
               "index_split_ms", "fp32_equivalent_tflops", "kernels_ms")
         secondary("topk", lambda: pick(run_topk(args, device, steps=6, warmup=4), tk))

@@ -386,11 +386,19 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         // pass 0 may run the tiled forward, which writes one partial per 256-candidate tile
         int64_t ns = w.row.nsplit;
         if (pass == 0 && mh_scorer_tiled_nsplit(Nn) > ns) ns = mh_scorer_tiled_nsplit(Nn);
+        int tps2 = 0;
+        if (E == 128 && pass == 2 && mh_split_plan(B, Nn, &tps2) > ns) ns = mh_split_plan(B, Nn, &tps2);
         w.part_m = take(ns * B);
         w.part_s = take(ns * B);
     }
-    if (pass == 1 || pass == 2) w.opart_row = take((int64_t)w.row.nsplit * B * w.Ep);
-    if (pass == 1) w.opart_col = take((int64_t)w.col.nsplit * Nn * w.Ep);
+    // partials: the larger of the fp32 plan's and the bf16x3 plan's split count (64-row tiles: up to twice as many splits)
+    int ns_row = w.row.nsplit, ns_col = w.col.nsplit, tps_ = 0;
+    if (E == 128 && pass != 0) {
+        if (mh_split_plan(B, Nn, &tps_) > ns_row) ns_row = mh_split_plan(B, Nn, &tps_);
+        if (mh_split_plan(Nn, B, &tps_) > ns_col) ns_col = mh_split_plan(Nn, B, &tps_);
+    }
+    if (pass == 1 || pass == 2) w.opart_row = take((int64_t)ns_row * B * w.Ep);
+    if (pass == 1) w.opart_col = take((int64_t)ns_col * Nn * w.Ep);
     if (w.pad && pass != 0) {
         w.outp_row = take(B * w.Ep);
         w.outp_item = take(B * w.Ep);
@@ -405,13 +413,14 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
     return w;
 }
 
-// the bf16x3 kernels cover the plain in-batch case: E = 128, no logQ correction inside the kernel, 16-byte aligned rows, and never
-// more candidate splits than the fp32 plan the partial buffers were sized for
+// the bf16x3 kernels cover the plain in-batch case: E = 128, no logQ correction inside the kernel, 16-byte aligned rows (the partial
+// buffers are sized for the larger of the two plans' split counts: stream_ws)
 bool split_ok(int64_t Nx, int64_t Ny, int E, const float* x_corr, const float* y_corr, const float* a, const float* b, int fp32_nsplit) {
     if (g_scorer_arith != 1 || E != 128 || x_corr || y_corr || Ny < 64) return false;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return false;
-    int tps = 0;
-    return mh_split_plan(Nx, Ny, &tps) <= fp32_nsplit;
+    (void)Nx;
+    (void)fp32_nsplit;
+    return true;
 }
 
 }  // namespace

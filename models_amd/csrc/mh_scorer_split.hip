@@ -28,6 +28,7 @@
 #include "mh_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -35,8 +36,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int PE = 128;            // embedding width (the whole K of GEMM 1)
 constexpr int PKS = PE / 16;       // k-steps of GEMM 1
-constexpr int PNW = 4;             // wavefronts per workgroup
-constexpr int PXB = 64 * PNW;      // stationary rows per workgroup
+constexpr int PXB = 256;           // stationary rows per workgroup
 constexpr int PBN = 64;            // streamed rows per tile (two 32-row units)
 constexpr int P_ARR = PBN * PE * 2;                // one of {hi, lo} of either image: 16 KB
 constexpr int P_STAGE = 4 * P_ARR;                 // Y hi, Y lo, Y^T hi, Y^T lo: 64 KB
@@ -121,13 +121,16 @@ __device__ __forceinline__ void p_dma4(const void* g, void* lds) {
 }
 __device__ __forceinline__ f32x16 p_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM>
-__global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitArgs a) {
+// XT = 32-row blocks of X per wavefront: 2 -> 4 wavefronts per workgroup, one per SIMD with 512 registers; 1 -> 8 wavefronts, two
+// per SIMD with 256 registers each (the epilogue of one hides behind the MFMAs of the other; twice the LDS reads per MFMA)
+template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT>
+__global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitArgs a) {
     constexpr int IDW = sizeof(IdT) / 4;
+    constexpr int NW = 8 / XT;  // wavefronts per workgroup
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-    const int64_t x0 = (int64_t)blockIdx.x * PXB + wave * 64;
+    const int64_t x0 = (int64_t)blockIdx.x * PXB + wave * 32 * XT;
     const int split = blockIdx.y;
     const int nt_all = (int)((a.Ny + PBN - 1) / PBN);
     const int t_beg = split * a.tiles_per_split;
@@ -138,18 +141,18 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
         unsigned char* st = smem + stage * P_STAGE;
         const int64_t row0 = (int64_t)t * PBN;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // row-major image: position (r, p) holds chunk p ^ (r & 15) of row r (rows clamped)
-            const int L = (j * PNW + wave) * 64 + lane;
+        for (int j = 0; j < 32 / NW; ++j) {  // row-major image: position (r, p) holds chunk p ^ (r & 15) of row r (rows clamped)
+            const int L = (j * NW + wave) * 64 + lane;
             const int arr = L >> 10, Lp = L & 1023, r = Lp >> 4, p = Lp & 15, c = p ^ (r & 15);
             int64_t row = row0 + r;
             if (row > a.Ny - 1) row = a.Ny - 1;
-            p_dma16((arr ? a.ylo : a.yhi) + row * PE + c * 8, st + (j * PNW + wave) * 1024);
+            p_dma16((arr ? a.ylo : a.yhi) + row * PE + c * 8, st + (j * NW + wave) * 1024);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // transposed image: position (e, p) holds chunk p ^ ((e >> 1) & 7) of row e (8 rows of Y each)
-            const int L = (j * PNW + wave) * 64 + lane;
+        for (int j = 0; j < 32 / NW; ++j) {  // transposed image: position (e, p) holds chunk p ^ ((e >> 1) & 7) of row e (8 rows of Y each)
+            const int L = (j * NW + wave) * 64 + lane;
             const int arr = L >> 10, Lp = L & 1023, e = Lp >> 3, p = Lp & 7, c = p ^ ((e >> 1) & 7);
-            p_dma16((arr ? a.ytlo : a.ythi) + (int64_t)e * a.ldT + row0 + c * 8, st + 2 * P_ARR + (j * PNW + wave) * 1024);
+            p_dma16((arr ? a.ytlo : a.ythi) + (int64_t)e * a.ldT + row0 + c * 8, st + 2 * P_ARR + (j * NW + wave) * 1024);
         }
         if (HAS_IDS && wave < IDW) {  // 64 ids = IDW wave-instructions of 64 words
             int64_t w = row0 * IDW + wave * 64 + lane;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
             if (w > last) w = last;
             p_dma4(static_cast<const uint32_t*>(a.y_ids) + w, smem + P_AUX + stage * 512 + wave * 256);
         }
-        if (MODE == PM_GRAD && LSE_STREAM && wave == 3) {
+        if (MODE == PM_GRAD && LSE_STREAM && wave == NW - 1) {
             int64_t w = row0 + lane;
             if (w > a.Ny - 1) w = a.Ny - 1;
             p_dma4(a.lse + w, smem + P_AUX + 1024 + stage * 256);
@@ -166,12 +169,12 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
     if (t_beg < t_end) issue(t_beg, 0);
 
     // stationary fragments (B operand of GEMM 1: lane = column l31 of its 32-row block, k = 16 ks + 8 h .. + 7)
-    bf16x8_t xh[2][PKS], xl[2][PKS];
-    bool xvalid[2];
-    IdT x_id[2];
-    float lse2_x[2], m_run[2], s_run[2];
+    bf16x8_t xh[XT][PKS], xl[XT][PKS];
+    bool xvalid[XT];
+    IdT x_id[XT];
+    float lse2_x[XT], m_run[XT], s_run[XT];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < XT; ++tn) {
         int64_t xrow = x0 + tn * 32 + l31;
         xvalid[tn] = xrow < a.Nx;
         if (!xvalid[tn]) xrow = a.Nx - 1;
@@ -188,11 +191,11 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
         s_run[tn] = 0.f;
     }
     const float scale2 = a.invT * P_LOG2E;
-    f32x16 o[4][2];  // O^T: block eb of 32 columns e x block tn of 32 stationary rows; lane: row x = l31, e = (i & 3) + 8 (i >> 2) + 4 h
+    f32x16 o[4][XT];  // O^T: block eb of 32 columns e x block tn of 32 stationary rows; lane: row x = l31, e = (i & 3) + 8 (i >> 2) + 4 h
 #pragma unroll
     for (int eb = 0; eb < 4; ++eb)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < XT; ++tn)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[eb][tn][i] = 0.f;
 
@@ -210,9 +213,11 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
         for (int u = 0; u < 2; ++u) {
             if (u * 32 >= nvalid) break;
             // ---- GEMM 1 on the unit's 32 streamed rows, software-pipelined over the 8 k-steps ---------------------------------
-            f32x16 acc[2];
+            f32x16 acc[XT];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+            for (int tn = 0; tn < XT; ++tn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
             const int rd = (u * 32 + l31) * 256;
             auto frag = [&](int ks, int arr) {
                 const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
@@ -226,20 +231,20 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
                     nh = frag(ks + 1, 0);
                     nl = frag(ks + 1, 1);
                 }
-                acc[0] = p_mfma(al, xh[0][ks], acc[0]);  // small terms first
-                acc[1] = p_mfma(al, xh[1][ks], acc[1]);
-                acc[0] = p_mfma(ah, xl[0][ks], acc[0]);
-                acc[1] = p_mfma(ah, xl[1][ks], acc[1]);
-                acc[0] = p_mfma(ah, xh[0][ks], acc[0]);
-                acc[1] = p_mfma(ah, xh[1][ks], acc[1]);
+#pragma unroll
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(al, xh[tn][ks], acc[tn]);  // small terms first
+#pragma unroll
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(ah, xl[tn][ks], acc[tn]);
+#pragma unroll
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(ah, xh[tn][ks], acc[tn]);
                 ah = nh;
                 al = nl;
             }
             // ---- epilogue: lane = stationary row tn * 32 + l31, streamed rows jl(i) = u * 32 + (i >> 2) * 8 + 4 h + (i & 3) ----------
-            bf16x8_t ph[2][2], pl[2][2];  // [tn][k-step]: the probabilities as the B operand of GEMM 2, hi and lo
+            bf16x8_t ph[XT][2], pl[XT][2];  // [tn][k-step]: the probabilities as the B operand of GEMM 2, hi and lo
             const int jl0 = u * 32 + 4 * h;
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
+            for (int tn = 0; tn < XT; ++tn) {
                 // the 16 scores of this lane are turned into base-2 logits and then into probabilities IN PLACE (acc[tn]); the mask
                 // of rescored false negatives is one bit per score
                 unsigned mbits = 0;
@@ -313,12 +318,12 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
                     const uint2 l1 = *reinterpret_cast<const uint2*>(row_h + P_ARR + (((c0 + 1) ^ sw) << 4));
                     const bf16x8_t ath = __builtin_bit_cast(bf16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
                     const bf16x8_t atl = __builtin_bit_cast(bf16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
-                    o[eb][0] = p_mfma(atl, ph[0][s], o[eb][0]);
-                    o[eb][1] = p_mfma(atl, ph[1][s], o[eb][1]);
-                    o[eb][0] = p_mfma(ath, pl[0][s], o[eb][0]);
-                    o[eb][1] = p_mfma(ath, pl[1][s], o[eb][1]);
-                    o[eb][0] = p_mfma(ath, ph[0][s], o[eb][0]);
-                    o[eb][1] = p_mfma(ath, ph[1][s], o[eb][1]);
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) o[eb][tn] = p_mfma(atl, ph[tn][s], o[eb][tn]);
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) o[eb][tn] = p_mfma(ath, pl[tn][s], o[eb][tn]);
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) o[eb][tn] = p_mfma(ath, ph[tn][s], o[eb][tn]);
                 }
             }
         }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
     // ---- results: the partial layouts of mh_scorer_stream.hip ---------------------------------------------------------------------
     if (MODE == PM_FWD_GRAD) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+        for (int tn = 0; tn < XT; ++tn) {
             const float ss = s_run[tn] + __shfl_xor(s_run[tn], 32);  // the two lanes of a row share m_run
             if (h == 0 && xvalid[tn]) {
                 a.part_m[(int64_t)split * a.Nx + x0 + tn * 32 + l31] = m_run[tn];
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
     }
     float* op = a.opart + (int64_t)split * a.Nx * PE;
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
+    for (int tn = 0; tn < XT; ++tn) {
         if (!xvalid[tn]) continue;
         float* orow = op + (x0 + tn * 32 + l31) * PE;
 #pragma unroll
@@ -351,11 +356,11 @@ __global__ __launch_bounds__(PNW * 64, 1) void stream_split_kernel(const SplitAr
     }
 }
 
-template <int MODE, bool LSE_STREAM>
+template <int MODE, bool LSE_STREAM, int XT>
 int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStream_t s) {
 #define MH_LAUNCH_SPLIT(IdT, HAS)                                                                                          \
     do {                                                                                                                   \
-        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM>;                                                       \
+        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT>;                                                   \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
@@ -365,7 +370,7 @@ int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStrea
             }                                                                                                              \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
-        MH_LAUNCH(kern, grid, dim3(PNW * 64), (size_t)P_LDS, s, a);                                                        \
+        MH_LAUNCH(kern, grid, dim3(512 / XT), (size_t)P_LDS, s, a);                                                        \
     } while (0)
     if (!a.x_ids) MH_LAUNCH_SPLIT(int32_t, false);
     else if (ids_dtype == MH_I32) MH_LAUNCH_SPLIT(int32_t, true);
@@ -429,7 +434,18 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
     const int nsplit = mh_split_plan(Nx, Ny, &tps);
     a.tiles_per_split = tps;
     dim3 grid((unsigned)mh_ceil_div(Nx, PXB), (unsigned)nsplit);
-    if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false>(a, ids_dtype, grid, s);
-    if (lse_stream) return launch_split_mode<PM_GRAD, true>(a, ids_dtype, grid, s);
-    return launch_split_mode<PM_GRAD, false>(a, ids_dtype, grid, s);
+    // MERLIN_HIP_SCORER_XT = 1 | 2 (experiments): 32-row blocks of X per wavefront (see the kernel)
+    static int xt = -1;
+    if (xt < 0) {
+        const char* e = getenv("MERLIN_HIP_SCORER_XT");
+        xt = (e && atoi(e) == 2) ? 2 : 1;
+    }
+    if (xt == 2) {
+        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2>(a, ids_dtype, grid, s);
+        if (lse_stream) return launch_split_mode<PM_GRAD, true, 2>(a, ids_dtype, grid, s);
+        return launch_split_mode<PM_GRAD, false, 2>(a, ids_dtype, grid, s);
+    }
+    if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1>(a, ids_dtype, grid, s);
+    if (lse_stream) return launch_split_mode<PM_GRAD, true, 1>(a, ids_dtype, grid, s);
+    return launch_split_mode<PM_GRAD, false, 1>(a, ids_dtype, grid, s);
 }

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from models_amd import ops  # noqa: E402
 
 dev = torch.device("cuda", 0)
-B, D = 65536, 64
+B, D = int(os.environ.get("PROBE_B", 65536)), 64
 g = torch.Generator(device=dev).manual_seed(0)
 
 
@@ -26,7 +26,7 @@ def timed(fn, n=20):
     return a.elapsed_time(b) / n
 
 
-for F in (24, 25, 26, 27, 28, 29, 30, 31, 32):
+for F in ([int(v) for v in sys.argv[1:]] or (24, 25, 26, 27, 28, 29, 30, 31, 32)):
     tabs = [torch.rand((100_000, D), device=dev, generator=g) for _ in range(F - 1)] + [None]
     ids = [torch.randint(0, 100_000, (B, 1), dtype=torch.int32, device=dev, generator=g) for _ in range(F - 1)] + [None]
     dense = torch.rand((B, D), device=dev, generator=g)

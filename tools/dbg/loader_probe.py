@@ -39,6 +39,15 @@ for rep in range(3):
     t4 = time.perf_counter()
     print(f"epoch {rep}: first batch host {1e3 * (t1 - t0):.1f} ms (+ device {1e3 * (t2 - t1):.1f}), remaining {n - 1} batches host {1e3 * (t3 - t2):.1f} ms "
           f"(+ device {1e3 * (t4 - t3):.1f}) = {1e3 * (t3 - t2) / max(n - 1, 1):.3f} ms per batch")
+import cProfile
+import pstats
+
+pr = cProfile.Profile()
+pr.enable()
+for _ in ld:
+    pass
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
 x = torch.randint(0, 1000, (rows,), dtype=torch.int32, device=dev)
 perm = torch.randperm(rows, device=dev)
 for name, fn in (("index_select int32 4M", lambda: x.index_select(0, perm)), ("x[perm]", lambda: x[perm]), ("randperm 4M", lambda: torch.randperm(rows, device=dev))):
