@@ -99,9 +99,14 @@ def test_c3_scorer_backward_full_batch(device, case):
     np.testing.assert_allclose(r.loss[rows].cpu().numpy(), o_loss, atol=1e-4, rtol=1e-5)
     np.testing.assert_allclose(r.lse[rows].cpu().numpy(), o_lse, atol=1e-4, rtol=1e-5)
 
+    # Under the opt-in bf16x3 arithmetic (the suite is also run with MERLIN_HIP_SCORER_ARITH=bf16x3) a dot product carries
+    # ~2.3e-6 |q| |item| of error: at the tower-like magnitudes of "unique" and of L2-normalised rows that is inside 1e-4 on a logit;
+    # this case scales items up to 2.5 x, plants two 4-5 x spikes and divides by T = 0.1 (|q| |item| / T in the hundreds): one row in
+    # 32 768 lands at 1.7e-4 absolute = 3.8e-5 relative.  The fp32 arithmetic keeps the 1e-4 bound here too.
+    loose = case == "duplicates_rescale" and ops.scorer_arith() == "bf16x3"
     for got in (r, r0):
-        torch.testing.assert_close(got.loss.double(), want_loss, atol=1e-4, rtol=1e-5)
-        torch.testing.assert_close(got.lse.double(), want_lse, atol=1e-4, rtol=1e-6)
+        torch.testing.assert_close(got.loss.double(), want_loss, atol=3e-4 if loose else 1e-4, rtol=5e-5 if loose else 1e-5)
+        torch.testing.assert_close(got.lse.double(), want_lse, atol=3e-4 if loose else 1e-4, rtol=5e-5 if loose else 1e-6)
     # gradients of the MEAN loss are O(1 / (B T)): the absolute floor is relative to the largest entry (the same
     # 1e-4-of-scale the small-shape tests use; a wrong or missing tile is off by O(scale))
     scale = float(want_dq.abs().max())
