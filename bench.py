@@ -17,8 +17,12 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Beyond the contra
   roofline_gather   the multi-table gather (the kernel north_star names)
   mfma              flop rates of the tower GEMMs against the 157.3 TF fp32 MFMA peak
   sustained         the same step repeated for >= --sustain seconds (the K-step region of a 1.5 ms step is 30 ms)
-  secondary         (N = 1) BASELINE configs[2]: TwoTower train step + scorer kernels, brute-force top-k, and the
-                    cache-busting single-table gather
+  secondary         (N = 1) BASELINE configs[2]: TwoTower train step + scorer kernels (f32, and the opt-in bf16x3 arithmetic under
+                    its own dtype label), brute-force top-k (bf16-pipe filter + exact re-score, bit-identical to `topk_f32` beside
+                    it), the cache-busting single-table gather, the multi-hot lookup (`embedding_bag`), `fit_from_parquet`
+                    (Parquet -> mm.Loader -> model.fit, wall clock), configs[3] on one GPU, configs[4];
+                    (N > 1) configs[3] with the big table allocated as row shards, TwoTower 32 K / 64 K, DCN-v2 -- collectives every
+                    rank walks in the same order, behind a wall-clock deadline
   cpu_baseline      (N = 1) the torch-CPU all-threads statement of the same step (oracle/oracle_torch.py) on the
                     host cores at the FULL batch, a bounded number of steps
 ``--workload twotower|dcn|topk`` runs a secondary configuration as the headline of its own line; twotower and dcn
