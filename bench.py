@@ -1505,6 +1505,13 @@ def main():
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()},
         "step_ms": step_stats,
         "sharded": shard_rep,
+        "parity_notes": {"pinned": "every section-8 row against the reference's own KATs and fixtures regenerated from /root/reference by "
+                                   "tests/golden/make_golden.py (torch twin where the TF statement cannot run here)",
+                         "unpinned": "the `sqrtn` combiner and the pruning of negative ids of ragged lookups follow the documented behaviour of "
+                                     "tf.nn.safe_embedding_lookup_sparse (tf/inputs/embedding.py:432-441): a TensorFlow op, absent from the "
+                                     "reference tree and from this image -- pinned to the oracle's reading of it only",
+                         "opt_in_arithmetic": "secondary *_bf16x3 lines are NOT bit-identical to the f32 lines (error table inside them); "
+                                              "secondary.topk IS (checked in the line)"},
     }
     if sharded:
         try:

@@ -110,7 +110,10 @@ def test_c3_scorer_backward_full_batch(device, case):
     # gradients of the MEAN loss are O(1 / (B T)): the absolute floor is relative to the largest entry (the same
     # 1e-4-of-scale the small-shape tests use; a wrong or missing tile is off by O(scale))
     scale = float(want_dq.abs().max())
-    tol = dict(atol=1e-4 * scale, rtol=3e-4)
+    # (bf16x3, adversarial case: the standalone passes exponentiate APPROXIMATE logits against the lse of the EXACT forward-only
+    # kernel -- a 1.7e-4 logit error is a 1.7e-4 relative error of a probability that the fused pass, whose lse comes from the same
+    # approximate logits, normalises away)
+    tol = dict(atol=(1e-3 if loose else 1e-4) * scale, rtol=3e-4)
     for name, got, want in (("dq", dq, want_dq), ("ditem", ditem, want_ditem), ("dneg", dneg, want_dneg),
                             ("dq0", dq0, want_dq), ("ditem0", ditem0, want_ditem), ("dneg0", dneg0, want_dneg)):
         torch.testing.assert_close(got.double(), want, msg=lambda m, n=name: f"{n}: {m}", **tol)

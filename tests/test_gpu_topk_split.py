@@ -105,3 +105,20 @@ def test_bruteforce_layer_builds_the_split_at_index_time(device, monkeypatch):
     assert torch.equal(out.identifiers, ref.identifiers) and torch.equal(out.scores, ref.scores)
     small = mm.BruteForce(5).index(torch.randn(100, 32, generator=g).to(device))  # other widths: no split, fp32 pipeline
     assert small._split is None
+
+
+@pytest.mark.parametrize("Bq,N,k", [(3, 300_000, 10), (257, 280_000, 500), (64, 270_000, 1)])
+def test_split_topk_few_queries_and_large_k(device, Bq, N, k):
+    """One (ragged) query block and up to 256 candidate splits per stage; k = 500 -> k' = 576 (nine list registers per lane)."""
+    rng = np.random.default_rng(Bq)
+    q = rng.normal(size=(Bq, 128)).astype(np.float32)
+    c = rng.normal(size=(N, 128)).astype(np.float32)
+    qd, cd = _t(q, device), _t(c, device)
+    sp = ops.TopKSplit(cd)
+    s1, _, x1 = ops.topk_dot(qd, cd, None, k, split=sp)
+    s0, _, x0 = ops.topk_dot(qd, cd, None, k)
+    assert torch.equal(x1, x0) and torch.equal(s1.view(torch.int32), s0.view(torch.int32))
+    rows = np.arange(min(Bq, 3))
+    vals, _, idx = cbind.bruteforce_topk(q[rows], c, None, k)
+    np.testing.assert_array_equal(x1.cpu().numpy()[rows], idx)
+    np.testing.assert_array_equal(s1.cpu().numpy()[rows], vals)
