@@ -933,10 +933,22 @@ def run_dcn(args, device, tm: Timing):
                                   f"B={args.batch} per GPU", "launch": "eager", "distinct_batches": nb, "parallelism": f"dp{tm.world}"},
            "sustained": sustained, "step_ms": stats, "mfma": mfma_rates(km, [k for k in km if k.startswith(("cross_", "linear_"))]),
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
+    from models_amd import ops as _ops
+
+    if _ops.gemm_arith() == "bf16x3":
+        res["dtype"] = ("bf16x3 (fp32-equivalent split: the three GEMMs of every cross layer = hi hi + hi lo + lo hi on the bf16 MFMA, fp32 "
+                        "accumulators); embeddings, deep MLP and optimizer f32")
+        res["mfma"] = {}  # the f32-peak fractions do not apply to these launches
     if tm.world > 1:
         res["exchange"] = exchange_summary(runner)
         res["exchange"]["dense_bucket_bytes"] = int(runner._bucket.numel() * 4) if getattr(runner, "_bucket", None) is not None else None
-    if cross:
+    if cross and _ops.gemm_arith() == "bf16x3":
+        tf = km[cross]["flops"] / (km[cross]["total_ms"] * 1e-3) / 1e12
+        res["roofline"] = {"kernel": "gemm_split_nt_kernel<1> (mh_gemm_split.hip: 256 x 128 tiles, hi / lo k-tiles through a 3-deep LDS DMA ring) + "
+                                     "the split of x and the transposed split of W", "op": cross, "bound": "mfma", "achieved": 3 * tf,
+                           "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3 * tf / MFMA_BF16_PEAK_TF, "traffic": None,
+                           "fp32_equivalent_tflops": tf, "avg_launch_ms": km[cross]["avg_ms"]}
+    elif cross:
         tf = km[cross]["flops"] / (km[cross]["total_ms"] * 1e-3) / 1e12
         res["roofline"] = {"kernel": "gemm2_kernel<256,128,4,2,NN,3> (mh_gemm2.h: DMA tiles, 3-deep ring; cross epilogue, p = xW + b stored for the backward in train mode)", "op": cross, "bound": "mfma", "achieved": tf,
                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
@@ -1571,8 +1583,24 @@ def main():
             torch.cuda.empty_cache()
             return pick(r, ("metric", "value", "unit", "ms_per_step", "config", "mfma", "kernels_ms", "roofline"))
 
+        def dcn_train_split():
+            prev = os.environ.get("MERLIN_HIP_GEMM_ARITH")
+            os.environ["MERLIN_HIP_GEMM_ARITH"] = "bf16x3"
+            try:
+                sub = argparse.Namespace(**vars(args))
+                sub.steps, sub.warmup, sub.sustain, sub.batches, sub.mode = 6, 2, 0.0, 2, "train"
+                r = run_dcn(sub, device, tm)
+            finally:
+                if prev is None:
+                    os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
+                else:
+                    os.environ["MERLIN_HIP_GEMM_ARITH"] = prev
+            torch.cuda.empty_cache()
+            return pick(r, ("metric", "value", "unit", "ms_per_step", "config", "dtype", "kernels_ms", "roofline"))
+
         if args.mode == "train":
             secondary("dcn_train", dcn_train)
+            secondary("dcn_train_bf16x3", dcn_train_split)
             secondary("embedding_bwd_nodup", lambda: run_embedding_bwd_nodup(device))
             secondary("c4_one_gpu", lambda: run_c4_one_gpu(args, device, tm))
             secondary("negatives", lambda: run_negatives(args, device, tm, ["queue", "popularity"], steps=10))

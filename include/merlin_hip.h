@@ -159,6 +159,20 @@ int32_t mh_set_deterministic(int32_t on);
  *     on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (error of a dot product <= ~2.3e-6 |q| |item| measured; 16 / 3 of the fp32
  *     MFMA rate).  Not bit-identical to mode 0: opt-in (initial value MERLIN_HIP_SCORER_ARITH=bf16x3 through the Python layer). */
 int32_t mh_set_scorer_arith(int32_t mode);
+
+/* ---- a9 in the same opt-in arithmetic: the three GEMMs of a full-rank DCN-v2 cross layer (Cross.call, blocks/cross.py:188-202) ----
+ * mh_cross_layer_fwd_split = mh_cross_layer_fwd / _fwd_save (p_out may be NULL), mh_cross_layer_bwd_split = mh_cross_layer_bwd
+ * (same phases, selected by the non-NULL outputs) with every product formed as hi hi + hi lo + lo hi on the bf16 MFMA (fp32
+ * accumulators; operands split -- and, for dW, transposed -- once per call into the workspace).  d % 4 == 0 (zero-padded layer).
+ * mh_set_gemm_arith(1) only records the caller's choice for hosts that dispatch on it (initial value MERLIN_HIP_GEMM_ARITH=bf16x3
+ * through the Python layer): the two entry points below ALWAYS compute in the split arithmetic. */
+int32_t mh_set_gemm_arith(int32_t mode);
+int64_t mh_cross_layer_split_workspace_bytes(int64_t M, int32_t d);
+int32_t mh_cross_layer_fwd_split(const float* x0, const float* x, const float* W, const float* b, int64_t M, int32_t d,
+                                 float* out, float* p_out, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p, const float* dout, const float* W,
+                                 int64_t M, int32_t d, float* g, float* dx0_acc, int32_t accumulate_dx0, float* dx,
+                                 float* dW, float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
                                 const int64_t* table_rows /*HOST [F]*/,

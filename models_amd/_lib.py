@@ -33,6 +33,10 @@ SIGNATURES = {
     "mh_embedding_dense_list_fwd": (_i32, [_p, _i64, _p, _i32, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_set_deterministic": (_i32, [_i32]),
     "mh_set_scorer_arith": (_i32, [_i32]),
+    "mh_set_gemm_arith": (_i32, [_i32]),
+    "mh_cross_layer_split_workspace_bytes": (_i64, [_i64, _i32]),
+    "mh_cross_layer_fwd_split": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "mh_cross_layer_bwd_split": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _i64, _p]),
     "mh_embedding_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_embedding_bag_expand": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _p, _i64, _p, _p, _p]),
     "mh_embedding_bag_bwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),

@@ -1,0 +1,524 @@
+// The three GEMMs of a full-rank DCN-v2 cross layer in the OPT-IN "bf16x3" arithmetic (mh_set_gemm_arith(1)):
+//   forward   out = x0 * (x W + b) + x            (Cross.call, tf/blocks/cross.py:188-202; W [d, d], d = 3341 padded to 3344 at C5)
+//   backward  dx = g W^T + dout,  dW = x^T g,  db = column sums of g     (g = dout * x0; mh_cross_layer_bwd's phases)
+// The exact-fp32 kernels (mh_gemm2.h) run these at 0.76-0.82 of the 157 TF fp32 MFMA peak: the DCN step is the sum of its GEMMs
+// (115 ms, 84 ms at 100 % of that peak).  Here every fp32 operand is split once into two bf16 values, x = hi + lo + r with
+// |r| <= 2^-18 |x|, and every product is hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulators: three bf16
+// MFMAs per fp32-equivalent one, 16 / 3 of the fp32 rate.  NOT bit-identical to the fp32 path (dropped terms <= 3 * 2^-18 |a b|
+// per element): never the default, reported under its own dtype label.
+//
+// ONE kernel form: C[M, N] = A[M, K] B^T with BOTH operands K-contiguous ("NT").  The prepare kernels make that true for the three
+// products -- forward: A = x, B^T = W^T; dX: A = g, B^T = W (row-major [d_in, d_out] IS [n][k] for it); dW: A = x^T, B^T = g^T
+// (contraction over the batch: both operands are transposed once, 0.35 ms each at 65536 x 3344).  K is padded to a multiple of 32
+// with zeros by the same kernels, so the loop has no k-tail.
+//
+// Kernel: 256 x 128 output tile per workgroup, 8 wavefronts (4 x 2) of 64 x 64 (2 x 2 accumulators of 32 x 32), 32-wide k-tiles of
+// A (hi, lo) and B (hi, lo) through a 3-deep LDS ring by direct-to-LDS DMA, one barrier per k-tile; the LDS image is chunk-swizzled
+// by permuting the per-lane SOURCE address (chunk c of row r at position c ^ ((r >> 2) & 3): ds_read_b128 of 16 consecutive rows
+// hits 16 distinct 4-bank groups).  Column tiles are the fastest grid dimension: the workgroups resident at one time sweep the B
+// panel (L2-resident) against a few A panels read from HBM once.
+#include "mh_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int GBK = 32;
+// Two geometries of the same kernel (template parameter BM):
+//   BM = 256: 8 wavefronts, 3 LDS stages of 48 KB (144 KB): ONE workgroup per CU, its eight wavefronts in lock step at the barriers;
+//   BM = 128: 4 wavefronts, 2 stages of 32 KB (64 KB): TWO independent workgroups per CU -- the barrier stall of one is covered
+//             by the MFMAs of the other; the A panel is re-read twice as often from L2.
+//   BM = 256, BN = 256: 8 wavefronts of 64 x 128 (2 x 4 accumulators), 2 stages of 64 KB: half the barriers and 3 / 4 of the LDS reads per
+//             MFMA of the 256 x 128 tile; 7 % of the column tiles of d = 3344 are padding (3.3 % at BN = 128).
+template <int BM, int BN>
+struct Geo {
+    static constexpr int NT = BM * 2;                    // threads: 64 rows per wavefront, two column wavefronts
+    static constexpr int NB = BN / 64;                   // 32-column blocks per wavefront
+    static constexpr int ST = (BM == 256 && BN == 128) ? 3 : 2;  // ring depth
+    static constexpr int A_ARR = BM * GBK * 2;
+    static constexpr int B_ARR = BN * GBK * 2;
+    static constexpr int STAGE = 2 * A_ARR + 2 * B_ARR;
+    static constexpr int LDS = ST * STAGE;
+    static constexpr int DMA_A = 2 * BM * 4 / NT;        // A chunks of 16 bytes per thread and k-tile
+    static constexpr int DMA_B = 2 * BN * 4 / NT;
+    static constexpr int DMA = DMA_A + DMA_B;
+};
+
+__device__ __forceinline__ uint16_t g_bf16(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float g_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// x [R, C] (leading dimension ld) -> hi, lo [R, Cp] bf16, columns C .. Cp - 1 zero (Cp % 8 == 0).  One 8-column group per thread.
+__global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int Cp,
+                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+    const int g8 = Cp / 8;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * g8) return;
+    const int64_t r = i / g8;
+    const int c0 = (int)(i - r * g8) * 8;
+    // two 16-byte loads where the row allows them (C % 4 == 0 and 16-byte aligned rows: what the callers pass), scalars otherwise
+    float v8[8];
+    const bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = c0 + 4 * q;
+        if (vec && c + 4 <= C) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+            v8[4 * q] = t.x; v8[4 * q + 1] = t.y; v8[4 * q + 2] = t.z; v8[4 * q + 3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v8[4 * q + j] = (c + j < C) ? x[r * ld + c + j] : 0.f;
+        }
+    }
+    uint32_t wh[4], wl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float v0 = v8[2 * k], v1 = v8[2 * k + 1];
+        const uint16_t h0 = g_bf16(v0), h1 = g_bf16(v1);
+        wh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        wl[k] = (uint32_t)g_bf16(v0 - g_f32(h0)) | ((uint32_t)g_bf16(v1 - g_f32(h1)) << 16);
+    }
+    *reinterpret_cast<uint4*>(hi + r * Cp + c0) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+    *reinterpret_cast<uint4*>(lo + r * Cp + c0) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+}
+
+// x [R, C] (ld) -> hiT, loT [C, Rp] bf16 (the transpose), columns R .. Rp - 1 zero (Rp % 64 == 0).  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int64_t Rp,
+                                                                uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT) {
+    __shared__ uint16_t sh[64][66], sl[64][66];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        float v = 0.f;
+        if (r0 + r < R && c0 + c < C) v = x[(r0 + r) * ld + c0 + c];
+        const uint16_t h = g_bf16(v);
+        sh[r][c] = h;
+        sl[r][c] = g_bf16(v - g_f32(h));
+    }
+    __syncthreads();
+    // thread (c, seg): rows seg * 16 .. + 15 of column c -> 32 contiguous bytes of row c0 + c of the transposed arrays
+    const int c = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    if (c0 + c >= C) return;
+    uint32_t wh[8], wl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = seg * 16 + 2 * k;
+        wh[k] = (uint32_t)sh[r][c] | ((uint32_t)sh[r + 1][c] << 16);
+        wl[k] = (uint32_t)sl[r][c] | ((uint32_t)sl[r + 1][c] << 16);
+    }
+    uint16_t* ph = hiT + (int64_t)(c0 + c) * Rp + r0 + seg * 16;
+    uint16_t* pl = loT + (int64_t)(c0 + c) * Rp + r0 + seg * 16;
+    *reinterpret_cast<uint4*>(ph) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+    *reinterpret_cast<uint4*>(ph + 8) = make_uint4(wh[4], wh[5], wh[6], wh[7]);
+    *reinterpret_cast<uint4*>(pl) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    *reinterpret_cast<uint4*>(pl + 8) = make_uint4(wl[4], wl[5], wl[6], wl[7]);
+}
+
+struct GsArgs {
+    const uint16_t *ah, *al, *bh, *bl;  // A [M, lda], B^T [N, ldb] bf16 bit patterns, K-contiguous, zero-padded to Kp
+    int64_t M, lda, ldb;
+    int N, Kp;
+    float* C;
+    int64_t ldc;
+    int ntn;             // column tiles
+    int xcd_map;         // see the kernel
+    int kt_per_split;    // k-tiles per blockIdx.y (split-K: slab z of C at C + z * slab)
+    int64_t slab;
+    // epilogues
+    const float* addend;  // EPI 0: C = acc (+ addend[m, n])
+    int64_t ld_add;
+    const float *bias, *x0, *xres;  // EPI 1: p = acc + bias[n]; C = x0 * p + xres (all [M, ld_e]); p_out optional
+    float* p_out;
+    int64_t ld_e;
+};
+
+__device__ __forceinline__ void g_dma16(const void* g, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void g_wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ f32x16 g_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <int EPI, int BM, int BN>
+__global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kernel(const GsArgs a) {
+    using G = Geo<BM, BN>;
+    constexpr int GBM = BM, GBN = BN, GNT = G::NT, GST = G::ST, G_A_ARR = G::A_ARR, G_B_ARR = G::B_ARR, G_STAGE = G::STAGE, G_DMA = G::DMA;
+    constexpr int NB = G::NB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroup -> output tile.  Plain: column tiles fastest.  XCD-aware (a.xcd_map): workgroup b runs on XCD b % 8 (round-robin
+    // dispatch); the j-th workgroup of an XCD takes column tile j % ntn of row tile xcd + 8 (j / ntn) -- all column tiles of one A row
+    // panel run on ONE XCD, so the panel (3.5 MB of hi + lo at K = 3392) enters one L2 instead of eight.
+    int64_t rt = blockIdx.x / a.ntn;
+    int ct = (int)(blockIdx.x % a.ntn);
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        rt = xcd + 8 * (int64_t)(j / a.ntn);
+        ct = j % a.ntn;
+        if (rt * GBM >= a.M) return;
+    }
+    const int64_t row0 = rt * GBM;
+    const int n0 = ct * GBN;
+    const int nkt_all = a.Kp / GBK;
+    const int kt_beg = blockIdx.y * a.kt_per_split;
+    const int kt_end = (kt_beg + a.kt_per_split < nkt_all) ? kt_beg + a.kt_per_split : nkt_all;
+    const int T = kt_end - kt_beg;
+
+    // DMA sources of this thread inside a k-tile (rows clamped to the last valid row: their products are never stored)
+    const uint16_t* src[G_DMA];
+#pragma unroll
+    for (int j = 0; j < G::DMA_A; ++j) {  // A: 2 arrays x BM rows x 4 chunks
+        const int L = j * GNT + threadIdx.x;
+        const int arr = L / (BM * 4), Lp = L % (BM * 4), r = Lp >> 2, p = Lp & 3, c = p ^ ((r >> 2) & 3);
+        int64_t row = row0 + r;
+        if (row > a.M - 1) row = a.M - 1;
+        src[j] = (arr ? a.al : a.ah) + row * a.lda + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < G::DMA_B; ++j) {  // B: 2 arrays x BN rows x 4 chunks
+        const int L = j * GNT + threadIdx.x;
+        const int arr = L / (BN * 4), Lp = L % (BN * 4), r = Lp >> 2, p = Lp & 3, c = p ^ ((r >> 2) & 3);
+        int col = n0 + r;
+        if (col > a.N - 1) col = a.N - 1;
+        src[G::DMA_A + j] = (arr ? a.bl : a.bh) + (int64_t)col * a.ldb + c * 8;
+    }
+    auto issue = [&](int t) {  // k-tile kt_beg + t -> stage t % GST
+        unsigned char* st = smem + (t % GST) * G_STAGE;
+        const int64_t koff = (int64_t)(kt_beg + t) * GBK;
+#pragma unroll
+        for (int j = 0; j < G::DMA_A; ++j) g_dma16(src[j] + koff, st + (j * GNT + wave * 64) * 16);
+#pragma unroll
+        for (int j = 0; j < G::DMA_B; ++j) g_dma16(src[G::DMA_A + j] + koff, st + 2 * G_A_ARR + (j * GNT + wave * 64) * 16);
+    };
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < GST - 1; ++t)
+        if (t < T) issue(t);
+    // LDS byte offsets of this lane's fragments inside a stage (k-step s adds the swizzled chunk)
+    int a_off[2], a_sw[2], b_off[NB], b_sw[NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int r = wm * 64 + mb * 32 + l31;
+        a_off[mb] = r * 64;
+        a_sw[mb] = (r >> 2) & 3;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int r = wn * (BN / 2) + nb * 32 + l31;
+        b_off[nb] = 2 * G_A_ARR + r * 64;
+        b_sw[nb] = (r >> 2) & 3;
+    }
+    for (int t = 0; t < T; ++t) {
+        // tile t is complete when at most the loads of tiles t + 1 .. t + GST - 2 are outstanding
+        if (t + GST - 2 < T) g_wait_vm_and_barrier<(GST - 2) * G_DMA>();
+        else g_wait_vm_and_barrier<0>();
+        if (t + GST - 1 < T) issue(t + GST - 1);
+        const unsigned char* st = smem + (t % GST) * G_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = 2 * s + h;
+            bf16x8_t ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const unsigned char* p = st + a_off[mb] + ((c ^ a_sw[mb]) << 4);
+                ah[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+                al[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_A_ARR));
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const unsigned char* p = st + b_off[nb] + ((c ^ b_sw[nb]) << 4);
+                bh[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+                bl[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_B_ARR));
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[mb][nb] = g_mfma(al[mb], bh[nb], acc[mb][nb]);  // small terms first
+                    acc[mb][nb] = g_mfma(ah[mb], bl[nb], acc[mb][nb]);
+                    acc[mb][nb] = g_mfma(ah[mb], bh[nb], acc[mb][nb]);
+                }
+        }
+    }
+    // ---- epilogue: acc[mb][nb][i] = C[row0 + wm 64 + mb 32 + (i & 3) + 8 (i >> 2) + 4 h][n0 + wn 64 + nb 32 + l31] --------------------
+    // The operands of an epilogue (x0 and x of the cross form, the addend of the dX form) are fetched for a whole 32 x 32 block before
+    // the first of them is used: 16-32 loads in flight.  (First version: load, use, store per element -- 64 dependent round trips per
+    // lane at the end of every workgroup, ~40 % of its life at K = 3392.)  Rows past M read row M - 1 and are not stored.
+    float* C = a.C + (int64_t)blockIdx.y * a.slab;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + wn * (BN / 2) + nb * 32 + l31;
+        const bool n_ok = n < a.N;
+        const int nc = n_ok ? n : a.N - 1;
+        float bias = 0.f;
+        if (EPI == 1 && a.bias) bias = a.bias[nc];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int64_t mbase = row0 + wm * 64 + mb * 32 + 4 * h;
+            float e0[16], e1[16];
+            if (EPI == 1 || a.addend) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    int64_t m = mbase + (i & 3) + 8 * (i >> 2);
+                    if (m > a.M - 1) m = a.M - 1;
+                    if (EPI == 1) {
+                        e0[i] = a.x0[m * a.ld_e + nc];
+                        e1[i] = a.xres[m * a.ld_e + nc];
+                    } else {
+                        e0[i] = a.addend[m * a.ld_add + nc];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = mbase + (i & 3) + 8 * (i >> 2);
+                float v = acc[mb][nb][i];
+                if (EPI == 1) {
+                    v += bias;
+                    if (a.p_out && n_ok && m < a.M) a.p_out[m * a.ld_e + n] = v;
+                    v = fmaf(e0[i], v, e1[i]);
+                } else if (a.addend) {
+                    v += e0[i];
+                }
+                if (n_ok && m < a.M) C[m * a.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// out[i] = sum_s part[s][i]  (S slabs of len4 float4, ascending order: deterministic)
+__global__ __launch_bounds__(256) void gs_reduce_slabs_kernel(const f32x4* __restrict__ part, int S, int64_t len4, f32x4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len4) return;
+    f32x4 t = part[i];
+    for (int s = 1; s < S; ++s) t += part[(int64_t)s * len4 + i];
+    out[i] = t;
+}
+
+// column sums of g [M, d]: stage 1 -- workgroup (column block of 64, row slab) sums its rows in a fixed order
+__global__ __launch_bounds__(256) void gs_colsum_kernel(const float* __restrict__ g, int64_t M, int d, int64_t ld, int rows_per_slab,
+                                                       float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    int64_t r1 = r0 + rows_per_slab;
+    if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (c < d)
+        for (int64_t r = r0 + q; r < r1; r += 4) s += g[r * ld + c];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < d) part[(int64_t)blockIdx.y * d + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void gs_colsum_finish_kernel(const float* __restrict__ part, int S, int d, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(int64_t)k * d + c];
+    out[c] = s;
+}
+
+int g_gemm_arith = 0;  // 0 = f32 (default), 1 = bf16x3 (mh_set_gemm_arith)
+
+inline int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
+inline int64_t pad_to(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct SplitBuf {
+    uint16_t *hi, *lo;
+    int64_t ld;
+};
+
+// carve a [rows, ld] hi / lo pair out of the workspace cursor
+SplitBuf take_pair(char*& p, int64_t rows, int64_t ld) {
+    SplitBuf b;
+    b.ld = ld;
+    b.hi = reinterpret_cast<uint16_t*>(p);
+    p += al256(rows * ld * 2);
+    b.lo = reinterpret_cast<uint16_t*>(p);
+    p += al256(rows * ld * 2);
+    return b;
+}
+inline int64_t pair_bytes(int64_t rows, int64_t ld) { return 2 * al256(rows * ld * 2); }
+
+void split_rows(const float* x, int64_t R, int C, int64_t ld, const SplitBuf& b, hipStream_t s) {
+    const int64_t n = R * (b.ld / 8);
+    MH_LAUNCH(gs_split_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, s, x, R, C, ld, (int)b.ld, b.hi, b.lo);
+}
+void split_transpose(const float* x, int64_t R, int C, int64_t ld, const SplitBuf& b, hipStream_t s) {
+    MH_LAUNCH(gs_split_transpose_kernel, dim3((unsigned)(b.ld / 64), (unsigned)mh_ceil_div(C, 64)), dim3(256), 0, s, x, R, C, ld, b.ld,
+              b.hi, b.lo);
+}
+
+template <int EPI, int BM, int BN>
+int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
+    using G = Geo<BM, BN>;
+    auto kern = gemm_split_nt_kernel<EPI, BM, BN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
+            mh_set_error("gemm (bf16x3): cannot raise the dynamic LDS limit");
+            return MH_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    a.ntn = (int)mh_ceil_div(a.N, BN);
+    const int nkt = a.Kp / GBK;
+    a.kt_per_split = (int)mh_ceil_div(nkt, splits);
+    static int xmap = -1;  // MERLIN_HIP_GEMM_SPLIT_XCD = 0 | 1
+    if (xmap < 0) {
+        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_XCD");
+        xmap = e ? atoi(e) : 1;
+    }
+    a.xcd_map = xmap;
+    int64_t nrt = mh_ceil_div(a.M, BM);
+    if (xmap) nrt = mh_ceil_div(nrt, 8) * 8;  // whole groups of 8 row tiles (the surplus workgroups exit at once)
+    const int64_t tiles = nrt * a.ntn;
+    MH_REQUIRE(tiles < (1ll << 31), "gemm (bf16x3): grid too large");
+    MH_LAUNCH(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(G::NT), (size_t)G::LDS, s, a);
+    return MH_OK;
+}
+
+int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 128x128
+    static int geo = -1;
+    if (geo < 0) {
+        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_GEO");
+        // measured at 65536 x 3344 x 3344 (DCN-v2 step, same box): 256x256 56.9 ms, 256x128 59.5 ms, 128x128 79 ms
+        geo = !e ? 2 : (!strcmp(e, "128x128") ? 1 : (!strcmp(e, "256x128") ? 0 : 2));
+    }
+    return geo;
+}
+
+template <int EPI>
+int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
+    const int geo = gemm_geo();
+    if (geo == 1) return launch_gemm_geo<EPI, 128, 128>(a, splits, s);
+    if (geo == 2) return launch_gemm_geo<EPI, 256, 256>(a, splits, s);
+    return launch_gemm_geo<EPI, 256, 128>(a, splits, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mh_set_gemm_arith(int32_t mode) {
+    MH_REQUIRE(mode == 0 || mode == 1, "mh_set_gemm_arith: mode must be 0 (f32) or 1 (bf16x3)");
+    g_gemm_arith = mode;
+    return MH_OK;
+}
+
+int64_t mh_cross_layer_split_workspace_bytes(int64_t M, int32_t d) {
+    if (M <= 0 || d <= 0) return 0;
+    const int64_t Kp = pad_to(d, 64), Mp = pad_to(M, 64);
+    // forward: x, W^T;  backward: g, W, x^T, g^T, two dW slabs, db partials
+    const int64_t fwd = pair_bytes(M, Kp) + pair_bytes(d, Kp);
+    const int64_t bwd = pair_bytes(M, Kp) + pair_bytes(d, Kp) + 2 * pair_bytes(d, Mp) + al256(8 * (int64_t)d * d * 4) + al256(64 * (int64_t)d * 4);
+    return (fwd > bwd ? fwd : bwd) + 1024;
+}
+
+int32_t mh_cross_layer_fwd_split(const float* x0, const float* x, const float* W, const float* b, int64_t M, int32_t d, float* out,
+                                 float* p_out, void* workspace, int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(x0 && x && W && out, "mh_cross_layer_fwd_split: null argument");
+    MH_REQUIRE(M >= 0 && d >= 8 && d % 4 == 0, "mh_cross_layer_fwd_split: bad shape M=%lld d=%d (d must be a multiple of 4)", (long long)M, d);
+    if (M == 0) return MH_OK;
+    MH_REQUIRE(workspace && workspace_bytes >= mh_cross_layer_split_workspace_bytes(M, d), "mh_cross_layer_fwd_split: workspace too small");
+    hipStream_t s = mh_stream(stream);
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t Kp = pad_to(d, 64);
+    const SplitBuf sx = take_pair(p, M, Kp), sw = take_pair(p, d, Kp);
+    split_rows(x, M, d, d, sx, s);
+    split_transpose(W, d, d, d, sw, s);  // W^T [n = d_out][k = d_in], pad columns zero (Kp is a multiple of 64: whole tiles)
+    GsArgs a{};
+    a.ah = sx.hi; a.al = sx.lo; a.bh = sw.hi; a.bl = sw.lo;
+    a.M = M; a.N = d; a.Kp = (int)Kp; a.lda = Kp; a.ldb = Kp;
+    a.C = out; a.ldc = d; a.slab = 0;
+    a.bias = b; a.x0 = x0; a.xres = x; a.p_out = p_out; a.ld_e = d;
+    const int32_t st = launch_gemm<1>(a, 1, s);
+    if (st != MH_OK) return st;
+    MH_CHECK_LAUNCH("mh_cross_layer_fwd_split");
+    return MH_OK;
+}
+
+// same phases as mh_cross_layer_bwd (selected by the non-NULL outputs); the element-wise phase is shared with it
+int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p, const float* dout, const float* W, int64_t M,
+                                 int32_t d, float* g, float* dx0_acc, int32_t accumulate_dx0, float* dx, float* dW, float* db,
+                                 void* workspace, int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(M >= 1 && d >= 8 && d % 4 == 0, "mh_cross_layer_bwd_split: d=%d must be a positive multiple of 4", d);
+    MH_REQUIRE(g && dout, "mh_cross_layer_bwd_split: g and dout are required");
+    hipStream_t s = mh_stream(stream);
+    if (dx0_acc) {  // g = dout * x0, dx0_acc (+)= dout * p: the fp32 library's element-wise pass
+        const int32_t st = mh_cross_layer_bwd(x0, nullptr, p, dout, nullptr, M, d, d, g, dx0_acc, accumulate_dx0, nullptr, nullptr, nullptr,
+                                              nullptr, 0, stream);
+        if (st != MH_OK) return st;
+    }
+    if (!dx && !dW) return MH_OK;
+    MH_REQUIRE(workspace && workspace_bytes >= mh_cross_layer_split_workspace_bytes(M, d), "mh_cross_layer_bwd_split: workspace too small");
+    char* wp = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t Kp = pad_to(d, 64), Mp = pad_to(M, 64);
+    const SplitBuf sg = take_pair(wp, M, Kp), sw = take_pair(wp, d, Kp), sxt = take_pair(wp, d, Mp), sgt = take_pair(wp, d, Mp);
+    float* slabs = reinterpret_cast<float*>(wp);
+    wp += al256(8 * (int64_t)d * d * 4);
+    float* dbp = reinterpret_cast<float*>(wp);
+    if (dx) {
+        MH_REQUIRE(W, "mh_cross_layer_bwd_split: W is required for dx");
+        split_rows(g, M, d, d, sg, s);
+        split_rows(W, d, d, d, sw, s);  // W [d_in, d_out] row-major = B^T [n = d_in][k = d_out]
+        GsArgs a{};
+        a.ah = sg.hi; a.al = sg.lo; a.bh = sw.hi; a.bl = sw.lo;
+        a.M = M; a.N = d; a.Kp = (int)Kp; a.lda = Kp; a.ldb = Kp;
+        a.C = dx; a.ldc = d; a.addend = dout; a.ld_add = d;
+        const int32_t st = launch_gemm<0>(a, 1, s);
+        if (st != MH_OK) return st;
+    }
+    if (dW) {
+        MH_REQUIRE(x, "mh_cross_layer_bwd_split: x is required for dW");
+        split_transpose(x, M, d, d, sxt, s);  // x^T [d_in, Mp]
+        split_transpose(g, M, d, d, sgt, s);  // g^T [d_out, Mp]
+        GsArgs a{};
+        a.ah = sxt.hi; a.al = sxt.lo; a.bh = sgt.hi; a.bl = sgt.lo;
+        a.M = d; a.N = d; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
+        // few output tiles (378 of 256 x 128 at d = 3344, 196 of 256 x 256), a long contraction: split it so that the grid fills the 256 CUs
+        // about three times over
+        const int64_t otiles = mh_ceil_div(d, 256) * mh_ceil_div(d, gemm_geo() == 2 ? 256 : 128);
+        int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
+        if (splits > 8) splits = 8;
+        if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);
+        if (splits < 1) splits = 1;
+        a.C = splits > 1 ? slabs : dW; a.ldc = d; a.slab = (int64_t)d * d;
+        const int32_t st = launch_gemm<0>(a, splits, s);
+        if (st != MH_OK) return st;
+        if (splits > 1) {
+            const int64_t len4 = (int64_t)d * d / 4;
+            MH_LAUNCH(gs_reduce_slabs_kernel, dim3((unsigned)mh_ceil_div(len4, 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(slabs), splits,
+                      len4, reinterpret_cast<f32x4*>(dW));
+        }
+        if (db) {
+            const int S = 64;
+            const int rps = (int)mh_ceil_div(M, S);
+            MH_LAUNCH(gs_colsum_kernel, dim3((unsigned)mh_ceil_div(d, 64), (unsigned)S), dim3(256), 0, s, (const float*)g, M, (int)d, (int64_t)d, rps, dbp);
+            MH_LAUNCH(gs_colsum_finish_kernel, dim3((unsigned)mh_ceil_div(d, 256)), dim3(256), 0, s, (const float*)dbp, S, (int)d, db);
+        }
+    }
+    MH_CHECK_LAUNCH("mh_cross_layer_bwd_split");
+    return MH_OK;
+}
+
+}  // extern "C"

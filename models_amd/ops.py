@@ -1474,6 +1474,18 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
     return scores, ids, idx
 
 
+def gemm_arith() -> str:
+    """MERLIN_HIP_GEMM_ARITH = f32 (default) | bf16x3: the opt-in three-term split-bf16 arithmetic of the DCN-v2 cross layer's GEMMs
+    (``mh_cross_layer_fwd_split`` / ``_bwd_split``; not bit-identical to the fp32 kernels, reported under its own dtype label)."""
+    import os
+
+    return "bf16x3" if os.environ.get("MERLIN_HIP_GEMM_ARITH", "f32") == "bf16x3" else "f32"
+
+
+def _cross_split_ok(M: int, d: int, W: torch.Tensor) -> bool:
+    return gemm_arith() == "bf16x3" and d % 4 == 0 and d >= 64 and M >= 256 and tuple(W.shape) == (d, d)
+
+
 def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], save_p: bool = False):
     """DCN-v2 cross layer ``x0 * (x @ W + b) + x`` (full-rank W [d, d]).  ``save_p``: also return ``p = x @ W + b``
     (what the backward multiplies the incoming gradient with), stored by the same kernel."""
@@ -1484,6 +1496,13 @@ def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[
             raise ValueError(f"{n_} must be contiguous 2-D")
     M, d = x.shape
     out = torch.empty_like(x)
+    if _cross_split_ok(M, d, W):
+        p = torch.empty_like(x) if save_p else None
+        ws = _workspace(lib.mh_cross_layer_split_workspace_bytes(M, d), x.device, "cross_split")
+        with _timed(f"cross_{d}", nbytes=4 * ((5 if save_p else 4) * M * d + d * d), flops=2 * M * d * d):
+            check(lib.mh_cross_layer_fwd_split(_ptr(x0), _ptr(x), _ptr(W), _ptr(b), M, d, _ptr(out), _ptr(p), _ptr(ws), ws.numel(),
+                                               _stream()), "mh_cross_layer_fwd_split")
+        return (out, p) if save_p else out
     if save_p:
         p = torch.empty_like(x)
         with _timed(f"cross_{d}", nbytes=4 * (5 * M * d + d * d), flops=2 * M * d * d):
@@ -1536,6 +1555,25 @@ def cross_layer_backward(x0: torch.Tensor, x: torch.Tensor, p: torch.Tensor, dou
     dx = torch.empty_like(x)
     dW = torch.empty((d, d), dtype=torch.float32, device=x.device)
     db = torch.empty((d,), dtype=torch.float32, device=x.device)
+    if _cross_split_ok(M, d, W):  # opt-in bf16x3 arithmetic: the same three phases through mh_cross_layer_bwd_split
+        nb = lib.mh_cross_layer_split_workspace_bytes(M, d)
+        if SIDE.active("dw"):
+            ws = _workspace(nb, x.device, "cross_split")
+            check(lib.mh_cross_layer_bwd_split(_ptr(x0), None, _ptr(p), _ptr(dout), _ptr(W), M, d, _ptr(g), _ptr(dx0_acc),
+                                               1 if accumulate else 0, _ptr(dx), None, None, _ptr(ws), ws.numel(), _stream()),
+                  "mh_cross_layer_bwd_split")
+            ws2 = _workspace(nb, x.device, "cross_split_side")
+            with SIDE.on("dw", keep=(x, g)):
+                check(lib.mh_cross_layer_bwd_split(None, _ptr(x), None, _ptr(dout), None, M, d, _ptr(g), None, 0, None, _ptr(dW), _ptr(db),
+                                                   _ptr(ws2), ws2.numel(), _stream()), "mh_cross_layer_bwd_split")
+            SIDE.maybe_join()
+            return dx0_acc, dx, dW, db
+        ws = _workspace(nb, x.device, "cross_split")
+        with _timed(f"cross_bwd_{d}", nbytes=4 * M * d * (9 if accumulate else 8) + 8 * d * d, flops=4 * M * d * d):
+            check(lib.mh_cross_layer_bwd_split(_ptr(x0), _ptr(x), _ptr(p), _ptr(dout), _ptr(W), M, d, _ptr(g), _ptr(dx0_acc),
+                                               1 if accumulate else 0, _ptr(dx), _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                  "mh_cross_layer_bwd_split")
+        return dx0_acc, dx, dW, db
     nbytes = lib.mh_linear_bwd_workspace_bytes(M, d, d)
     if SIDE.active("dw"):
         check(lib.mh_cross_layer_bwd(_ptr(x0), None, _ptr(p), _ptr(dout), _ptr(W), M, d, d, _ptr(g), _ptr(dx0_acc),

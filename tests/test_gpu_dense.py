@@ -267,6 +267,10 @@ def test_cross_layer_with_saved_preactivation(device, M, d):
     W = _t(O.glorot_uniform(rng, d, d), device)
     b = _t(rng.normal(size=d).astype(np.float32) * 0.1, device)
     out, p = ops.cross_layer(x0, x, W, b, save_p=True)
-    assert torch.equal(p, ops.linear(x, W, b, None))           # p = x W + b, the same fmaf chains
+    if ops.gemm_arith() == "bf16x3":  # the suite is also run under the opt-in split arithmetic: p within 1e-4 of its scale
+        ref = ops.linear(x, W, b, None)
+        torch.testing.assert_close(p, ref, atol=1e-4 * float(ref.abs().max()), rtol=1e-4)
+    else:
+        assert torch.equal(p, ops.linear(x, W, b, None))           # p = x W + b, the same fmaf chains
     torch.testing.assert_close(out, ops.cross_layer(x0, x, W, b), atol=1e-6, rtol=1e-6)
     torch.testing.assert_close(out, x0 * p + x, atol=1e-5, rtol=1e-5)

@@ -1,0 +1,46 @@
+"""The DCN-v2 cross layer in the opt-in bf16x3 arithmetic (mh_cross_layer_fwd_split / _bwd_split, MERLIN_HIP_GEMM_ARITH=bf16x3)
+against the exact-fp32 kernels on the same inputs and against float64 (Cross.call and its gradients, tf/blocks/cross.py:188-202)."""
+import numpy as np
+import pytest
+import torch
+
+from models_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,d", [(512, 128), (1000, 200), (700, 3344), (4096, 448)])
+def test_cross_layer_split_matches_fp32_and_float64(device, monkeypatch, M, d):
+    g = torch.Generator().manual_seed(M + d)
+    x0 = torch.randn(M, d, generator=g)
+    x = torch.randn(M, d, generator=g)
+    W = torch.randn(d, d, generator=g) * (1.0 / np.sqrt(d))
+    b = torch.randn(d, generator=g) * 0.1
+    dout = torch.randn(M, d, generator=g)
+    acc0 = torch.randn(M, d, generator=g)
+    dev = lambda t: t.to(device)
+
+    def run():
+        out, p = ops.cross_layer(dev(x0), dev(x), dev(W), dev(b), save_p=True)
+        out2 = ops.cross_layer(dev(x0), dev(x), dev(W), dev(b))
+        dx0, dx, dW, db = ops.cross_layer_backward(dev(x0), dev(x), p, dev(dout), dev(W), dev(acc0).clone())
+        dx0n, _, _, _ = ops.cross_layer_backward(dev(x0), dev(x), p, dev(dout), dev(W))
+        return [t.cpu().double() for t in (out, p, out2, dx0, dx, dW, db, dx0n)]
+
+    monkeypatch.setenv("MERLIN_HIP_GEMM_ARITH", "f32")
+    f32 = run()
+    monkeypatch.setenv("MERLIN_HIP_GEMM_ARITH", "bf16x3")
+    sp = run()
+    monkeypatch.setenv("MERLIN_HIP_GEMM_ARITH", "f32")
+    assert any(not torch.equal(a, b_) for a, b_ in zip(f32, sp)), "the bf16x3 switch did not change the arithmetic"
+    x064, x64, W64, b64, d64 = (t.double() for t in (x0, x, W, b, dout))
+    p64 = x64 @ W64 + b64
+    out64 = x064 * p64 + x64
+    g64 = d64 * x064
+    want = [out64, p64, out64, acc0.double() + d64 * p64, g64 @ W64.T + d64, x64.T @ g64, g64.sum(0), d64 * p64]
+    names = ("out", "p", "out (no p)", "dx0_acc", "dx", "dW", "db", "dx0 (fresh)")
+    for n, got, ref, w in zip(names, sp, f32, want):
+        scale = float(w.abs().max())
+        # bf16x3 against float64: 1e-4 of the largest entry (dW sums M products per entry: its fp32 accumulation error alone is ~1e-5 of scale)
+        torch.testing.assert_close(got, w, atol=1e-4 * scale, rtol=1e-4, msg=lambda m, n=n: f"{n} vs float64: {m}")
+        torch.testing.assert_close(got, ref, atol=1e-4 * scale, rtol=1e-4, msg=lambda m, n=n: f"{n} vs fp32 kernels: {m}")
