@@ -150,7 +150,7 @@ __device__ __forceinline__ void g_wait_vm_and_barrier() {
 }
 __device__ __forceinline__ f32x16 g_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-template <int EPI, int BM, int BN>
+template <int EPI, int BM, int BN, bool PIPE>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kernel(const GsArgs a) {
     using G = Geo<BM, BN>;
     constexpr int GBM = BM, GBN = BN, GNT = G::NT, GST = G::ST, G_A_ARR = G::A_ARR, G_B_ARR = G::B_ARR, G_STAGE = G::STAGE, G_DMA = G::DMA;
@@ -233,30 +233,40 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
         else g_wait_vm_and_barrier<0>();
         if (t + GST - 1 < T) issue(t + GST - 1);
         const unsigned char* st = smem + (t % GST) * G_STAGE;
+        // The fragments of BOTH 16-wide k-steps of the tile are read from LDS up front (LDS returns in order: the MFMAs of step 0 wait
+        // for the first half only), so the reads of step 1 can run behind the MFMAs of step 0; PIPE adds a scheduling hint that pins
+        // "all reads, then all MFMAs".  Measured: no gain (57.4 ms for the DCN-v2 step without the hint, 59.1 with it): the k-loop is
+        // not bound by an un-overlapped LDS phase.
+        bf16x8_t ah[2][2], al[2][2], bh[2][NB], bl[2][NB];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int c = 2 * s + h;
-            bf16x8_t ah[2], al[2], bh[NB], bl[NB];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const unsigned char* p = st + a_off[mb] + ((c ^ a_sw[mb]) << 4);
-                ah[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
-                al[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_A_ARR));
+                ah[s][mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+                al[s][mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_A_ARR));
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const unsigned char* p = st + b_off[nb] + ((c ^ b_sw[nb]) << 4);
-                bh[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
-                bl[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_B_ARR));
+                bh[s][nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+                bl[s][nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_B_ARR));
             }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    acc[mb][nb] = g_mfma(al[mb], bh[nb], acc[mb][nb]);  // small terms first
-                    acc[mb][nb] = g_mfma(ah[mb], bl[nb], acc[mb][nb]);
-                    acc[mb][nb] = g_mfma(ah[mb], bh[nb], acc[mb][nb]);
+                    acc[mb][nb] = g_mfma(al[s][mb], bh[s][nb], acc[mb][nb]);  // small terms first
+                    acc[mb][nb] = g_mfma(ah[s][mb], bl[s][nb], acc[mb][nb]);
+                    acc[mb][nb] = g_mfma(ah[s][mb], bh[s][nb], acc[mb][nb]);
                 }
+        if (PIPE) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (4 + 2 * NB), 0);  // every LDS read of the tile ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * 2 * NB * 3, 0);    // ... ahead of its MFMAs
         }
     }
     // ---- epilogue: acc[mb][nb][i] = C[row0 + wm 64 + mb 32 + (i & 3) + 8 (i >> 2) + 4 h][n0 + wn 64 + nb 32 + l31] --------------------
@@ -368,10 +378,10 @@ void split_transpose(const float* x, int64_t R, int C, int64_t ld, const SplitBu
               b.hi, b.lo);
 }
 
-template <int EPI, int BM, int BN>
+template <int EPI, int BM, int BN, bool PIPE>
 int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
     using G = Geo<BM, BN>;
-    auto kern = gemm_split_nt_kernel<EPI, BM, BN>;
+    auto kern = gemm_split_nt_kernel<EPI, BM, BN, PIPE>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
@@ -410,9 +420,14 @@ int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 1
 template <int EPI>
 int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
     const int geo = gemm_geo();
-    if (geo == 1) return launch_gemm_geo<EPI, 128, 128>(a, splits, s);
-    if (geo == 2) return launch_gemm_geo<EPI, 256, 256>(a, splits, s);
-    return launch_gemm_geo<EPI, 256, 128>(a, splits, s);
+    static int pipe = -1;  // MERLIN_HIP_GEMM_SPLIT_PIPE = 0 | 1: the schedule hint of the k-loop (see the kernel)
+    if (pipe < 0) {
+        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_PIPE");
+        pipe = e ? atoi(e) : 0;  // measured (DCN-v2 step, same box): 57.4 ms without the hint, 59.1 with it
+    }
+    if (geo == 1) return launch_gemm_geo<EPI, 128, 128, false>(a, splits, s);
+    if (geo == 2) return pipe ? launch_gemm_geo<EPI, 256, 256, true>(a, splits, s) : launch_gemm_geo<EPI, 256, 256, false>(a, splits, s);
+    return pipe ? launch_gemm_geo<EPI, 256, 128, true>(a, splits, s) : launch_gemm_geo<EPI, 256, 128, false>(a, splits, s);
 }
 
 }  // namespace

@@ -387,7 +387,7 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         int64_t ns = w.row.nsplit;
         if (pass == 0 && mh_scorer_tiled_nsplit(Nn) > ns) ns = mh_scorer_tiled_nsplit(Nn);
         int tps2 = 0;
-        if (E == 128 && pass == 2 && mh_split_plan(B, Nn, &tps2) > ns) ns = mh_split_plan(B, Nn, &tps2);
+        if (E == 128 && mh_split_plan(B, Nn, &tps2) > ns) ns = mh_split_plan(B, Nn, &tps2);
         w.part_m = take(ns * B);
         w.part_s = take(ns * B);
     }
@@ -405,7 +405,7 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         if (pass == 1) w.outp_col = take(Nn * w.Ep);
     }
     w.split_q = w.split_n = 0;
-    if (pass != 0 && E == 128) {  // the bf16 (hi, lo) splits of q and of the negatives, both orientations (bf16x3 arithmetic)
+    if (E == 128) {  // the bf16 (hi, lo) splits of q and of the negatives, both orientations (bf16x3 arithmetic)
         w.split_q = take(mh_split_matrix_bytes(B) / 4);
         w.split_n = take(mh_split_matrix_bytes(Nn) / 4);
     }
@@ -500,6 +500,18 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
             MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
             return MH_OK;
         }
+    }
+    if (!logits && split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {  // opt-in bf16x3 arithmetic, loss / lse only
+        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, s);
+        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, s);
+        int tps = 0;
+        const int ns = mh_split_plan(B, Nn, &tps);
+        const int32_t st = mh_stream_split_launch(SM_FWD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
+                                                  1.f, ws + w.part_m, ws + w.part_s, nullptr, s);
+        if (st != MH_OK) return st;
+        mh_stream_fwd_finalize(pos, B, ns, ws + w.part_m, ws + w.part_s, invT, nullptr, 0, loss, lse, s);
+        MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
+        return MH_OK;
     }
     const float* qx = q;
     const float* nx = neg_item;

@@ -46,7 +46,7 @@ constexpr float P_LOG2E = 1.4426950408889634f;
 constexpr float P_NEG_BIG = -1.0e30f;
 constexpr float P_LAZY = 16.f;
 
-enum { PM_GRAD = 1, PM_FWD_GRAD = 2 };
+enum { PM_FWD = 0, PM_GRAD = 1, PM_FWD_GRAD = 2 };  // PM_FWD: loss / lse only (no second GEMM, no transposed image)
 
 __device__ __forceinline__ uint16_t p_bf16(float x) {  // round to nearest even (finite inputs; inf / nan keep their class)
     uint32_t u = __float_as_uint(x);
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
             if (row > a.Ny - 1) row = a.Ny - 1;
             p_dma16((arr ? a.ylo : a.yhi) + row * PE + c * 8, st + (j * NW + wave) * 1024);
         }
+        if (MODE != PM_FWD)
 #pragma unroll
         for (int j = 0; j < 32 / NW; ++j) {  // transposed image: position (e, p) holds chunk p ^ ((e >> 1) & 7) of row e (8 rows of Y each)
             const int L = (j * NW + wave) * 64 + lane;
@@ -187,13 +188,14 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         if (HAS_IDS) x_id[tn] = static_cast<const IdT*>(a.x_ids)[xrow];
         lse2_x[tn] = 0.f;
         if (MODE == PM_GRAD && !LSE_STREAM) lse2_x[tn] = a.lse[xrow] * P_LOG2E;
-        m_run[tn] = (MODE == PM_FWD_GRAD) ? a.pos[xrow] * a.invT * P_LOG2E : P_NEG_BIG;  // the reference max starts at the positive logit
+        m_run[tn] = (MODE != PM_GRAD) ? a.pos[xrow] * a.invT * P_LOG2E : P_NEG_BIG;  // the reference max starts at the positive logit
         s_run[tn] = 0.f;
     }
     const float scale2 = a.invT * P_LOG2E;
-    f32x16 o[4][XT];  // O^T: block eb of 32 columns e x block tn of 32 stationary rows; lane: row x = l31, e = (i & 3) + 8 (i >> 2) + 4 h
+    constexpr int OB = (MODE == PM_FWD) ? 1 : 4;  // forward-only: no output accumulators (one dummy block keeps the code uniform)
+    f32x16 o[OB][XT];  // O^T: block eb of 32 columns e x block tn of 32 stationary rows; lane: row x = l31, e = (i & 3) + 8 (i >> 2) + 4 h
 #pragma unroll
-    for (int eb = 0; eb < 4; ++eb)
+    for (int eb = 0; eb < OB; ++eb)
 #pragma unroll
         for (int tn = 0; tn < XT; ++tn)
 #pragma unroll
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                         const float e = __builtin_amdgcn_exp2f(acc[tn][i] - l2) * a.gscale;  // -inf on invalid rows -> 0
                         acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
                     }
-                } else {  // FWD_GRAD: lazy reference max shared by the two lanes of a row
+                } else {  // FWD / FWD_GRAD: lazy reference max shared by the two lanes of a row
                     float tmax = acc[tn][0];
 #pragma unroll
                     for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[tn][i]);
@@ -275,8 +277,9 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                         const float f = __builtin_amdgcn_exp2f(m_run[tn] - m_new);
                         s_run[tn] *= f;
                         m_run[tn] = m_new;
+                        if (MODE != PM_FWD)
 #pragma unroll
-                        for (int eb = 0; eb < 4; ++eb)
+                        for (int eb = 0; eb < OB; ++eb)
 #pragma unroll
                             for (int i = 0; i < 16; ++i) o[eb][tn][i] *= f;  // every accumulator element of this lane belongs to its row
                     }
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                     }
                     s_run[tn] += s_add;
                 }
+                if (MODE != PM_FWD)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     uint32_t wh[4], wl[4];
@@ -305,8 +309,9 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
             }
             // ---- GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x]; A = two 8-byte pieces of row e of the transposed image ----------
             const unsigned char* yt = st + 2 * P_ARR;
+            if (MODE != PM_FWD)
 #pragma unroll
-            for (int eb = 0; eb < 4; ++eb) {
+            for (int eb = 0; eb < OB; ++eb) {
                 const int e = eb * 32 + l31, sw = (e >> 1) & 7;
                 const unsigned char* row_h = yt + e * 128 + 8 * h;
 #pragma unroll
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     }
 
     // ---- results: the partial layouts of mh_scorer_stream.hip ---------------------------------------------------------------------
-    if (MODE == PM_FWD_GRAD) {
+    if (MODE != PM_GRAD) {
 #pragma unroll
         for (int tn = 0; tn < XT; ++tn) {
             const float ss = s_run[tn] + __shfl_xor(s_run[tn], 32);  // the two lanes of a row share m_run
@@ -341,13 +346,14 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
             }
         }
     }
+    if (MODE == PM_FWD) return;
     float* op = a.opart + (int64_t)split * a.Nx * PE;
 #pragma unroll
     for (int tn = 0; tn < XT; ++tn) {
         if (!xvalid[tn]) continue;
         float* orow = op + (x0 + tn * 32 + l31) * PE;
 #pragma unroll
-        for (int eb = 0; eb < 4; ++eb)
+        for (int eb = 0; eb < OB; ++eb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {o[eb][tn][4 * g], o[eb][tn][4 * g + 1], o[eb][tn][4 * g + 2], o[eb][tn][4 * g + 3]};
@@ -422,7 +428,8 @@ int mh_split_plan(int64_t Nx, int64_t Ny, int* tiles_per_split) {
     return (int)mh_ceil_div(nt, tps);
 }
 
-// mode: 1 = GRAD (p = exp(z - lse) g), 2 = FWD_GRAD (online max, part_m / part_s); same outputs as mh_stream_launch
+// mode: 0 = FWD (part_m / part_s only), 1 = GRAD (p = exp(z - lse) g), 2 = FWD_GRAD (online max, part_m / part_s, opart); same outputs
+// as mh_stream_launch
 int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X, int64_t Nx, const MhSplitMatrix& Y, int64_t Ny,
                                const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
                                float fns, float gscale, float* part_m, float* part_s, float* opart, hipStream_t s) {
@@ -440,6 +447,7 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
         const char* e = getenv("MERLIN_HIP_SCORER_XT");
         xt = (e && atoi(e) == 2) ? 2 : 1;
     }
+    if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1>(a, ids_dtype, grid, s);
     if (xt == 2) {
         if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2>(a, ids_dtype, grid, s);
         if (lse_stream) return launch_split_mode<PM_GRAD, true, 2>(a, ids_dtype, grid, s);

@@ -44,17 +44,18 @@ def test_bf16x3_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, 
         res, dq, ditem = ops.inbatch_softmax_train(*args)
         _, _, dneg = ops.inbatch_softmax_backward(args[0], args[1], args[2], res.lse, args[3], args[4], T, fns, need_dq=False)
         dq2, ditem2, dneg2 = ops.inbatch_softmax_backward(args[0], args[1], args[2], res.lse, args[3], args[4], T, fns)
-        return [x.cpu().numpy() for x in (res.loss, res.lse, dq, ditem, dneg, dq2, ditem2, dneg2)]
+        fw = ops.inbatch_softmax(*args, materialize=False)  # forward-only pass (evaluation): loss / lse
+        return [x.cpu().numpy() for x in (res.loss, res.lse, dq, ditem, dneg, dq2, ditem2, dneg2, fw.loss, fw.lse)]
 
     monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
     f32 = run()
     monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "bf16x3")
     sp = run()
     monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
-    names = ("loss", "lse", "dq", "ditem", "dneg", "dq(bwd)", "ditem(bwd)", "dneg(bwd)")
+    names = ("loss", "lse", "dq", "ditem", "dneg", "dq(bwd)", "ditem(bwd)", "dneg(bwd)", "loss(fwd)", "lse(fwd)")
     assert any(not np.array_equal(a, b) for a, b in zip(f32, sp)), "the bf16x3 switch did not change the arithmetic"
     for n, a, b in zip(names, f32, sp):
-        tol = 1e-4 if n in ("loss", "lse") else 2e-6  # gradients of the MEAN loss carry 1 / B
+        tol = 1e-4 if n.startswith(("loss", "lse")) else 2e-6  # gradients of the MEAN loss carry 1 / B
         np.testing.assert_allclose(b, a, atol=tol, rtol=2e-4, err_msg=n)
     if B <= 512:
         loss, lse, dq, ditem, dneg = _ref64(q, it, neg, pid, nid, T, fns)
@@ -63,3 +64,5 @@ def test_bf16x3_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, 
         np.testing.assert_allclose(sp[2], dq, atol=2e-6, rtol=2e-4)
         np.testing.assert_allclose(sp[3], ditem, atol=2e-6, rtol=2e-4)
         np.testing.assert_allclose(sp[4], dneg, atol=2e-6, rtol=2e-4)
+        np.testing.assert_allclose(sp[8], loss, atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(sp[9], lse, atol=1e-4, rtol=1e-5)
