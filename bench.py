@@ -731,7 +731,10 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
     bwd_bytes_dd = F * B * (D * 4 + 8) + nnz * 4 + uniq * 4 * D * 4  # bag gradients once, table + state rows r / w once per unique id
     res = {"shape": f"{F} ragged features x {B} bags, nnz ~ Poisson({mean_nnz}) ({nnz} ids), D={D}, Criteo-cardinality tables, int32 ids",
            "algorithmic_bytes_fwd": fwd_bytes, "kernel": "bag_fwd_kernel<int32, COOP> (mh_embedding.hip): wavefront-shuffle segmented reduce",
-           "fwd": {}, "bwd_adagrad": {}}
+           "fwd": {}, "bwd_adagrad": {}, "bwd_adagrad_one_update": {},
+           "bwd_note": "bwd_adagrad: one mh_embedding_bag_bwd per feature (expanded [nnz, D] gradient + its own sort and update); "
+                       "bwd_adagrad_one_update: mh_embedding_bag_bwd_multi, all 26 features in one sort / segmented reduce / Adagrad "
+                       "that reads gradient rows through the bag index"}
     for comb in ("mean", "sum", "sqrtn"):
         def fwd(comb=comb):
             for f, (v, o) in enumerate(feats):
@@ -746,6 +749,14 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
         res["bwd_adagrad"][comb] = {"ms": ms, "GBps_dedup_aware": bwd_bytes_dd / (ms * 1e-3) / 1e9,
                                     "frac": bwd_bytes_dd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "frac_survey_8d": bwd_bytes_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        vs, os_ = [v for v, _ in feats], [o for _, o in feats]
+
+        def bwd_multi(comb=comb):
+            ops.embedding_bag_backward_multi(tabs, accs, vs, os_, grad, [f * D for f in range(F)], comb, optimizer="adagrad", lr=0.0)
+        ms = timed(bwd_multi, 3)
+        res["bwd_adagrad_one_update"][comb] = {"ms": ms, "GBps_dedup_aware": bwd_bytes_dd / (ms * 1e-3) / 1e9,
+                                               "frac": bwd_bytes_dd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "frac_survey_8d": bwd_bytes_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     res["unique_rows"] = uniq
     res["roofline"] = {"bound": "hbm", "achieved": res["fwd"]["mean"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": res["fwd"]["mean"]["frac"], "traffic": None,
@@ -1475,12 +1486,30 @@ def main():
         rl["algorithmic_bytes_per_launch"] = per_launch
         try:
             rl["apply_phase"] = apply_phase(per_launch)
+            ap_t = apply_traffic()
+            rl["apply_phase"]["traffic"] = ap_t
+            if ap_t:
+                rl["apply_phase"]["traffic_source"] = ("profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of piece_reduce_apply_kernel and "
+                                                       "carry_apply_kernel alone (per launch, calibrated units)")
         except Exception as e:  # noqa: BLE001 -- a reporting extra must not cost the line
             rl["apply_phase"] = {"error": f"{type(e).__name__}: {e}"}
         rl["definition"] = ("frac / achieved: dedup-aware algorithmic bytes (gradient rows once, table + state rows read and written "
                             "once per UNIQUE id of the batch) / launch time; frac_survey_8d: SURVEY 8d's B*F*(5*D*4 + 4), which counts "
                             "repeated rows as unique")
         return rl
+
+    def apply_traffic():
+        """HBM bytes of the gradient-dependent half alone (the two kernels of `_apply`) out of the per-kernel PMC figures."""
+        if not pmc_ok:
+            return None
+        cal, e = pmc.get("calibration", {}), pmc.get("embedding_bwd", {})
+        tot = 0.0
+        for counter, unit in (("FETCH_SIZE", cal.get("fetch_bytes_per_unit")), ("WRITE_SIZE", cal.get("write_bytes_per_unit"))):
+            per = e.get(counter)
+            if not per or not unit:
+                return None
+            tot += sum(v["units_per_launch"] for k, v in per.items() if "piece_reduce_apply" in k or "carry_apply" in k) * unit
+        return tot or None
 
     def traffic(name):
         t = pmc.get(name, {}).get("traffic_bytes") if pmc_ok else None
@@ -1550,6 +1579,24 @@ def main():
         secondary("gather_cold", lambda: run_gather_cold(device))
         secondary("embedding_bag", lambda: run_embedding_bag(device))
         secondary("scorer_fwd", lambda: run_scorer_fwd(device))
+
+        def scorer_fwd_split():
+            prev = os.environ.get("MERLIN_HIP_SCORER_ARITH")
+            os.environ["MERLIN_HIP_SCORER_ARITH"] = "bf16x3"
+            try:
+                r = run_scorer_fwd(device)
+            finally:
+                if prev is None:
+                    os.environ.pop("MERLIN_HIP_SCORER_ARITH", None)
+                else:
+                    os.environ["MERLIN_HIP_SCORER_ARITH"] = prev
+            r["dtype"] = "bf16x3 (fp32-equivalent split on the bf16 MFMA)"
+            r["frac_of_bf16_peak"] = 3 * r["tflops"] / MFMA_BF16_PEAK_TF
+            r["fp32_equivalent_tflops"] = r.pop("tflops")
+            r.pop("frac_of_peak", None)
+            return r
+
+        secondary("scorer_fwd_bf16x3", scorer_fwd_split)
         secondary("dcn_cross_gemm", lambda: run_cross_gemm(device))
         secondary("twotower_train", lambda: pick(run_twotower(args, device, tm, steps=20, warmup=3, sustain=0.0),
                                                  ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline")))

@@ -126,6 +126,21 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
                              int32_t combiner, const float* grad, int64_t grad_row_stride, int32_t optimizer,
                              float lr, float eps, float beta1, float beta2, const float* lr_device,
                              void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+/* F list features over F DISTINCT tables of one width in ONE update (the embedding variables of a model's multi-hot columns:
+ * inputs/embedding.py:398-428 looks each one up, models/base.py:1121-1174 applies every IndexedSlices in one optimizer step):
+ * the combiner divisors and the bag index of every value in two launches, then one sort / segmented reduce / fused optimizer over
+ * all F x max(nnz) values that reads a value's gradient row THROUGH its bag index -- no expanded [nnz, D] gradient is written.
+ * values[f] / offsets[f]: device pointers of feature f (offsets == NULL: every feature is a dense [B, L] list);
+ * grad: [B, grad_row_stride] floats, feature f's [B, D] block starts grad_offset[f] floats into the row.  Same terms and optimizer
+ * arithmetic as F calls of mh_embedding_bag_bwd; a run of equal ids may be cut into partial sums at other places (a few ulp).
+ * Combiners SUM / MEAN / SQRTN. */
+int64_t mh_embedding_bag_bwd_multi_workspace_bytes(int64_t B, int64_t max_nnz, int32_t F, int32_t D);
+int32_t mh_embedding_bag_bwd_multi(float* const* tables, float* const* state, float* const* state2, const int64_t* table_rows,
+                                   const void* const* values, const int64_t* nnz, const void* const* offsets, int64_t L,
+                                   int32_t ids_dtype, int64_t B, int32_t F, int32_t D, int32_t combiner, const float* grad,
+                                   int64_t grad_row_stride, const int64_t* grad_offset, int32_t optimizer, float lr, float eps,
+                                   float beta1, float beta2, const float* lr_device, void* workspace, int64_t workspace_bytes,
+                                   mh_stream_t stream);
 
 /* Dense fixed-length list [B, L] with a string combiner over axis 1 (mean / sum):
  * process_str_sequence_combiner (inputs/embedding.py:1556-1587): every position counts
@@ -173,6 +188,15 @@ int32_t mh_cross_layer_fwd_split(const float* x0, const float* x, const float* W
 int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p, const float* dout, const float* W,
                                  int64_t M, int32_t d, float* g, float* dx0_acc, int32_t accumulate_dx0, float* dx,
                                  float* dW, float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+/* Dense layer (blocks/mlp.py:275-280) in the same opt-in arithmetic: the contracts of mh_linear_bias_act_fwd / _bwd (same argument
+ * meaning, dy overwritten with dz, dx masked by x_act, dW / db optional) with the three GEMMs on the bf16x3 kernel; the workspace
+ * (mh_linear_split_workspace_bytes) is needed by every phase.  Meant for wide layers (N >= 256: whole 256 x 256 output tiles). */
+int64_t mh_linear_split_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int32_t mh_linear_bias_act_fwd_split(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int32_t K, int32_t N,
+                                     int32_t act, float* y, int64_t ldy, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W, const float* y, int64_t ldy, float* dy, int64_t lddy,
+                                     int64_t M, int32_t K, int32_t N, int32_t act, int32_t x_act, float* dx, int64_t lddx, float* dW,
+                                     float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
                                 const int64_t* table_rows /*HOST [F]*/,

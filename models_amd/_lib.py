@@ -41,6 +41,8 @@ SIGNATURES = {
     "mh_embedding_bag_expand": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _p, _i64, _p, _p, _p]),
     "mh_embedding_bag_bwd_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "mh_embedding_bag_bwd": (_i32, [_p, _p, _p, _i64, _p, _i64, _p, _i64, _i32, _i64, _i32, _i32, _p, _i64, _i32, _f32, _f32, _f32, _f32, _p, _p, _i64, _p]),
+    "mh_embedding_bag_bwd_multi_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "mh_embedding_bag_bwd_multi": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i64, _i32, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _i64, _p]),
     "mh_embedding_gather_bwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _f32, _f32, _p, _p, _i64, _p]),
     "mh_embedding_gather_bwd_prepare": (_i32, [_p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p]),
     "mh_embedding_gather_bwd_apply": (_i32, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, _p, _i64, _p, _i32, _f32, _f32, _p, _f32, _f32, _p, _p, _i64, _p]),
@@ -48,6 +50,9 @@ SIGNATURES = {
     "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_linear_bias_act_bwd": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_linear_split_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "mh_linear_bias_act_fwd_split": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p]),
+    "mh_linear_bias_act_bwd_split": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
     "mh_mlp_chain_supported": (_i32, [_i32, _p]),
     "mh_mlp_chain_fwd": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "mh_mlp_chain_bwd_workspace_bytes": (_i64, [_i64, _i32, _p]),

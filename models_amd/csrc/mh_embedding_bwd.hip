@@ -50,6 +50,16 @@ struct BwdArgs {
     int64_t first[MH_MAX_FEATURES];   // first compact key of the feature's table (shared tables share it)
 };
 
+// Optional indirection between a lookup position and its gradient row (multi-hot lookups, mh_embedding_bag_bwd_multi): position
+// p of feature f reads gradient row map[f * map_stride + p] (its BAG) and divides it by scale[f * scale_stride + row] (the bag's
+// combiner divisor) -- exactly the value bag_expand_kernel would have materialised, without the nnz x D round trip through HBM.
+struct GradMap {
+    const int32_t* map;  // nullptr: identity (one-hot lookups)
+    int64_t map_stride;
+    const float* scale;
+    int64_t scale_stride;
+};
+
 // ---- segmented LSD radix sort ---------------------------------------------------------------------------------------
 constexpr int RTILE = 4096;     // entries per workgroup tile (256 threads x 16)
 constexpr int RITEMS = 16;
@@ -788,15 +798,24 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
 // and the piece's <= 16 sample indices ONE iteration ahead, by the group's first 16 lanes in one coalesced load; the
 // gradient-row loop takes them from those lanes with wavefront shuffles.  The LDS partials are double-buffered, so an
 // iteration has one barrier instead of two.  Sums are formed in the same order: results are bit-identical to VMODE 0.
-template <int VMODE>
+// RUNS 1 (the multi-hot update, `gm` set: entries are values of bags, a 4-row table of a 1.3 M-value feature has runs of 20 000
+// pieces; RUNS 0 compiles the bag indirection out -- the one-hot kernel keeps its 96 registers): a workgroup takes the list in
+// tiles of 2^tile_log2 consecutive iterations and carries the partial sum of the run that leaves an iteration into the next one
+// (`pend`, double-buffered in LDS) instead of adding it to carry[] at once: one set of same-line atomics per run and TILE instead of
+// one per iteration, while all workgroups still walk one window of the list (the gradient block of one or two features stays cached).
+template <int VMODE, int RUNS>
 __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a, const uint32_t* __restrict__ vals,
                                                                 int D, int LPR, const float* __restrict__ grad,
                                                                 int64_t grad_row_stride, float* __restrict__ carry,
                                                                 const int* __restrict__ home,
                                                                 const ulonglong2* __restrict__ pieces,
                                                                 const unsigned int* __restrict__ counter, int opt,
-                                                                const OptHyper hp, int deterministic) {
+                                                                const OptHyper hp, int deterministic, const GradMap gm,
+                                                                int tile_log2) {
     constexpr int NBUF = VMODE ? 2 : 1;
+    __shared__ f32x4 pend_s[2][64];  // RUNS: sum of the run that left the previous iteration through its last group
+    __shared__ uint64_t pend_key[2];
+    __shared__ int pend_home[2];
     __shared__ f32x4 part_s[NBUF][256];      // partial sum of every group (one f32x4 per thread)
     __shared__ uint64_t part_key[NBUF][64];  // key of a group's partial-run piece, ~0 if it has none
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
@@ -812,17 +831,36 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         feat[f].first = a.first[f];
         feat[f].offset = a.offset[f];
     }
+    if (RUNS && threadIdx.x < 2) pend_key[threadIdx.x] = ~0ull;
     __syncthreads();
     const int64_t np = (int64_t)*counter;
-    const int64_t stride = (int64_t)gridDim.x * groups;
+    // first piece of iteration `it` of this workgroup: grid-stride over iterations (RUNS 0) or over tiles of iterations (RUNS 1)
+    auto piece0 = [&](int64_t it) -> int64_t {
+        if (!RUNS) return ((int64_t)blockIdx.x + it * gridDim.x) * groups;
+        const int64_t tile = it >> tile_log2, r = it - (tile << tile_log2);
+        return (((tile * gridDim.x + blockIdx.x) << tile_log2) + r) * groups;
+    };
+    constexpr uint32_t PMASK = (1u << 26) - 1;
+    // multi-hot lookups: the position of an entry is replaced by its gradient row (bag) where the entry is fetched from the sorted
+    // list -- one iteration ahead of its use in VMODE 1 -- so that the row loads below keep their chain length
+    auto remap = [&](uint32_t v) -> uint32_t {
+        if (!RUNS) return v;
+        return (v & ~PMASK) | (uint32_t)gm.map[(int64_t)(v >> 26) * gm.map_stride + (v & PMASK)];
+    };
     auto row = [&](uint32_t v) -> f32x4 {
         const int f = (int)(v >> 26);
+        if (RUNS) {  // bag gradients are re-read by every value of the bag: cached loads, divided by the bag's divisor
+            const f32x4 g = *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & PMASK) * grad_row_stride + feat[f].offset + c4 * 4);
+            const float dv = gm.scale[(int64_t)f * gm.scale_stride + (v & PMASK)];
+            return g / dv;
+        }
         // gradient rows are read exactly once: streaming loads (the table / state rows of hot ids stay cached)
-        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + (int64_t)(v & PMASK) * grad_row_stride +
                                                                          feat[f].offset + c4 * 4));
     };
     // records as scalar pairs (rec, key); a record of length 0 stands for "no piece"
-    int64_t base = (int64_t)blockIdx.x * groups;  // block-uniform: the loop carries barriers
+    int64_t it = 0;
+    int64_t base = piece0(0);  // block-uniform: the loop carries barriers
     uint64_t next_rec = 0, next_key = ~0ull, next2_rec = 0, next2_key = ~0ull;
     uint32_t myv = 0;  // VMODE 1: lane c4 < len holds the sample index of entry c4 of the CURRENT piece
     if (gi < groups && base + gi < np) {
@@ -831,15 +869,15 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         next_key = r.y;
     }
     if (VMODE) {
-        if (gi < groups && base + gi + stride < np) {
-            const ulonglong2 r = pieces[base + gi + stride];
+        if (gi < groups && piece0(1) + gi < np) {
+            const ulonglong2 r = pieces[piece0(1) + gi];
             next2_rec = r.x;
             next2_key = r.y;
         }
-        if (c4 < (int)((next_rec >> 32) & 31)) myv = vals[(int64_t)(next_rec & 0xffffffffull) + c4];
+        if (c4 < (int)((next_rec >> 32) & 31)) myv = remap(vals[(int64_t)(next_rec & 0xffffffffull) + c4]);
     }
-    int buf = 0;
-    for (; base < np; base += stride) {
+    int buf = 0, pb = 0;
+    for (; base < np; base = piece0(++it)) {
         const int64_t p = base + gi;
         const bool active = gi < groups && p < np;
         const uint64_t rec = next_rec, key = next_key;
@@ -847,18 +885,22 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         if (VMODE) {
             next_rec = next2_rec;
             next_key = next2_key;
-            if (c4 < (int)((next_rec >> 32) & 31)) nv = vals[(int64_t)(next_rec & 0xffffffffull) + c4];  // indices of the next piece
+            if (c4 < (int)((next_rec >> 32) & 31)) nv = remap(vals[(int64_t)(next_rec & 0xffffffffull) + c4]);  // indices of the next piece
             next2_rec = 0;
             next2_key = ~0ull;
-            if (gi < groups && p + 2 * stride < np) {
-                const ulonglong2 r = pieces[p + 2 * stride];
+            const int64_t p2 = piece0(it + 2) + gi;
+            if (gi < groups && p2 < np) {
+                const ulonglong2 r = pieces[p2];
                 next2_rec = r.x;
                 next2_key = r.y;
             }
-        } else if (gi < groups && p + stride < np) {  // next record in flight during this piece
-            const ulonglong2 r = pieces[p + stride];
+        } else if (gi < groups && piece0(it + 1) + gi < np) {  // next record in flight during this piece
+            const ulonglong2 r = pieces[piece0(it + 1) + gi];
             next_rec = r.x;
             next_key = r.y;
+        } else {
+            next_rec = 0;
+            next_key = ~0ull;
         }
         const int64_t s0 = (int64_t)(rec & 0xffffffffull);
         const int len = active ? (int)((rec >> 32) & 31) : 0;
@@ -871,7 +913,7 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         const uint32_t* vv = vals + s0;
         // entry i of the piece: VMODE 1 reads it from lane i of the group (every lane of a group runs the same trip count, so
         // the source lanes are active), VMODE 0 from memory
-        auto idx = [&](int i) -> uint32_t { return VMODE ? (uint32_t)__shfl((int)myv, glane0 + i) : vv[i]; };
+        auto idx = [&](int i) -> uint32_t { return VMODE ? (uint32_t)__shfl((int)myv, glane0 + i) : remap(vv[i]); };
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         int i = 0;
         for (; i + 4 <= len; i += 4) {
@@ -899,18 +941,52 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
         part_s[buf][threadIdx.x] = acc;
         if (c4 == 0 && gi < 64) part_key[buf][gi] = partial ? key : ~0ull;
         __syncthreads();
+        auto add_carry = [&](int hm, const f32x4 sum) {
+            float* cr = carry + (int64_t)hm * D + c4 * 4;
+            atomicAdd(cr + 0, sum.x);
+            atomicAdd(cr + 1, sum.y);
+            atomicAdd(cr + 2, sum.z);
+            atomicAdd(cr + 3, sum.w);
+        };
         if (partial && (gi == 0 || part_key[buf][gi - 1] != key)) {
             f32x4 sum = acc;
-            for (int g2 = gi + 1; g2 < groups && part_key[buf][g2] == key; ++g2) sum += part_s[buf][g2 * LPR + c4];
-            float* cr = carry + (int64_t)home[p] * D + c4 * 4;
+            int g2 = gi + 1;
+            for (; g2 < groups && part_key[buf][g2] == key; ++g2) sum += part_s[buf][g2 * LPR + c4];
+            if (RUNS) {
+                if (gi == 0 && pend_key[pb ^ 1] == key) sum = pend_s[pb ^ 1][c4] + sum;  // the run entered through group 0
+                if (g2 == groups) {  // ... and leaves through the last group: its sum waits for the next iteration
+                    pend_s[pb][c4] = sum;
+                    if (c4 == 0) {
+                        pend_key[pb] = key;
+                        pend_home[pb] = home[p];
+                    }
+                } else {
+                    add_carry(home[p], sum);
+                }
+            } else {
+                add_carry(home[p], sum);
+            }
+        }
+        if (RUNS) {
+            // a waiting sum whose run did not continue through group 0 is added now; no run leaves this iteration: nothing waits
+            if (gi == 0 && pend_key[pb ^ 1] != ~0ull && !(partial && pend_key[pb ^ 1] == key)) add_carry(pend_home[pb ^ 1], pend_s[pb ^ 1][c4]);
+            if (gi == groups - 1 && c4 == 0 && !partial) pend_key[pb] = ~0ull;
+            pb ^= 1;  // written after this iteration's barrier, read after the next one's, rewritten after the one after that
+        }
+        // two buffers: the next iteration writes the other one, and the one after that is separated from the reads above by
+        // the next iteration's barrier
+        if (VMODE) buf ^= 1; else __syncthreads();
+    }
+    if (RUNS) {
+        __syncthreads();
+        if (gi == 0 && pend_key[pb ^ 1] != ~0ull) {
+            float* cr = carry + (int64_t)pend_home[pb ^ 1] * D + c4 * 4;
+            const f32x4 sum = pend_s[pb ^ 1][c4];
             atomicAdd(cr + 0, sum.x);
             atomicAdd(cr + 1, sum.y);
             atomicAdd(cr + 2, sum.z);
             atomicAdd(cr + 3, sum.w);
         }
-        // two buffers: the next iteration writes the other one, and the one after that is separated from the reads above by
-        // the next iteration's barrier
-        if (VMODE) buf ^= 1; else __syncthreads();
     }
 }
 
@@ -921,7 +997,7 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
                                                          const uint32_t* __restrict__ vals, int64_t n, int D, int LPR,
                                                          const float* __restrict__ carry, int opt, const OptHyper hp,
                                                          const float* __restrict__ grad, int64_t grad_row_stride,
-                                                         int deterministic) {
+                                                         int deterministic, const GradMap gm) {
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
     const int gi = threadIdx.x / LPR;
     const int c4 = threadIdx.x - gi * LPR;
@@ -947,8 +1023,11 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
         }
         for (int64_t i = st; i < n && keys[i] == key; ++i) {
             const uint32_t v = vals[i];
-            g += *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & ((1u << 26) - 1)) * grad_row_stride +
-                                                 a.offset[v >> 26] + c4 * 4);
+            int64_t r = (int64_t)(v & ((1u << 26) - 1));
+            if (gm.map != nullptr) r = gm.map[(int64_t)(v >> 26) * gm.map_stride + r];
+            f32x4 gv = *reinterpret_cast<const f32x4*>(grad + r * grad_row_stride + a.offset[v >> 26] + c4 * 4);
+            if (gm.map != nullptr) gv = gv / gm.scale[(int64_t)(v >> 26) * gm.scale_stride + r];
+            g += gv;
         }
     }
     RowRmw rr;
@@ -1004,7 +1083,7 @@ bool deterministic_mode() { return g_deterministic != 0; }
 template <typename IdT, typename KeyT>
 int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbits, const WsLayout& L, char* ws, int64_t B, int F,
                        int D, const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp,
-                       hipStream_t s, int phases) {
+                       hipStream_t s, int phases, const GradMap gm = GradMap{nullptr, 0, nullptr, 0}) {
     void* kbuf[2] = {ws + L.off_keys_a, ws + L.off_keys_b};
     uint32_t* vbuf[2] = {reinterpret_cast<uint32_t*>(ws + L.off_vals_a), reinterpret_cast<uint32_t*>(ws + L.off_vals_b)};
     float* carry = reinterpret_cast<float*>(ws + L.off_carry);
@@ -1072,9 +1151,19 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         // the group's lanes fetch and hand out a piece's sample indices (kernel comment) where a group is an aligned 16- / 32-lane
         // part of a wavefront
         const bool vmode = (LPR == 16 || LPR == 32);  // D = 64 / 128 (GPU-tested); 64-lane groups (D = 256) keep mode 0 until a test covers them
-        auto kern = vmode ? piece_reduce_apply_kernel<1> : piece_reduce_apply_kernel<0>;
+        // multi-hot updates (a value list per sample: long runs in every small table) carry run sums across iterations
+        const int runs = (gm.map != nullptr) ? 1 : 0;
+        static int tile_log2 = -1;
+        if (tile_log2 < 0) {
+            const char* e = getenv("MERLIN_HIP_APPLY_TILE_LOG2");
+            tile_log2 = e ? atoi(e) : 3;
+            if (tile_log2 < 0 || tile_log2 > 16) tile_log2 = 3;
+        }
+        auto kern = runs ? (vmode ? piece_reduce_apply_kernel<1, 1> : piece_reduce_apply_kernel<0, 1>)
+                         : (vmode ? piece_reduce_apply_kernel<1, 0> : piece_reduce_apply_kernel<0, 0>);
         int64_t nb = mh_ceil_div(L.n, groups);  // never more groups than entries
-        static int resident[2] = {0, 0};  // workgroups per CU the kernel's register budget allows: exactly one resident wave
+        static int resident_of[4] = {0, 0, 0, 0};  // workgroups per CU the kernel's register budget allows: exactly one resident wave
+        int* resident = resident_of + 2 * runs;
         if (resident[vmode] == 0) {
             int r = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, kern, 256, 0) != hipSuccess || r < 1) r = 4;
@@ -1092,10 +1181,10 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         const int64_t cap = (int64_t)mh_num_cus() * res;
         if (nb > cap) nb = cap;
         MH_LAUNCH(kern, dim3((unsigned)nb), dim3(256), 0, s, a, vals, D, LPR, grad, grad_row_stride, carry, home,
-                           pieces, counter, optimizer, hp, det);
+                           pieces, counter, optimizer, hp, det, gm, tile_log2);
     }
     MH_LAUNCH((carry_apply_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.nchunks, groups)), dim3(256), 0, s, a, keys,
-                       vals, L.n, D, LPR, carry, optimizer, hp, grad, grad_row_stride, det);
+                       vals, L.n, D, LPR, carry, optimizer, hp, grad, grad_row_stride, det, gm);
     MH_CHECK_LAUNCH("mh_embedding_gather_bwd");
     return MH_OK;
 }
@@ -1199,6 +1288,122 @@ __global__ __launch_bounds__(256) void bag_expand_max_kernel(const float* __rest
     }
 }
 
+
+// ---- several multi-hot features in ONE sparse update (mh_embedding_bag_bwd_multi) -----------------------------------------------
+struct BagMultiArgs {
+    const void* values[MH_MAX_FEATURES];
+    const void* offsets[MH_MAX_FEATURES];  // CSR offsets [B + 1] of the feature, or nullptr: dense list of length L
+    int64_t nnz[MH_MAX_FEATURES];
+};
+
+// scale[f][bag] = the combiner's divisor of the bag (1 | kept | sqrt(kept)) for every feature in one launch.  A LANE per bag (a
+// wavefront per bag, as bag_scale_kernel does it, spends 64 lanes on ~20 ids: 0.38 ms for 26 x 65 536 bags); the lanes of a wavefront
+// walk 64 neighbouring bags side by side, bags longer than 64 ids are then counted by the whole wavefront one after the other.
+template <typename IdT>
+__global__ __launch_bounds__(256) void bag_scale_multi_kernel(const BagMultiArgs a, int64_t L, int64_t B, int combiner,
+                                                              float* __restrict__ scale) {
+    const int f = blockIdx.y;
+    const int64_t bag = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const IdT* values = static_cast<const IdT*>(a.values[f]);
+    const IdT* offsets = static_cast<const IdT*>(a.offsets[f]);
+    int64_t kept = L;  // dense list: every position counts
+    if (offsets && combiner != MH_COMBINER_SUM) {  // safe_embedding_lookup_sparse: negative ids are pruned and not counted
+        int64_t beg = 0, end = 0;
+        if (bag < B) {
+            beg = (int64_t)offsets[bag];
+            end = (int64_t)offsets[bag + 1];
+        }
+        const bool long_bag = end - beg > 64;
+        int cnt = 0;
+        if (!long_bag)
+            for (int64_t p = beg; p < end; ++p) cnt += (values[p] >= 0) ? 1 : 0;
+        unsigned long long todo = __ballot(long_bag);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t b2 = __shfl(beg, src), e2 = __shfl(end, src);
+            int c2 = 0;
+            for (int64_t p = b2 + lane; p < e2; p += 64) c2 += (values[p] >= 0) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c2 += __shfl_xor(c2, o);
+            if (lane == src) cnt = c2;
+        }
+        kept = cnt;
+    }
+    if (bag >= B) return;
+    float dv = 1.f;
+    if (combiner == MH_COMBINER_MEAN && kept > 0) dv = (float)kept;
+    if (combiner == MH_COMBINER_SQRTN && kept > 0) dv = sqrtf((float)kept);
+    scale[(int64_t)f * B + bag] = dv;
+}
+
+// map[f][j] = bag of value j, idpad[f][j] = its id for j < nnz[f]; the padding up to Bp entries carries id -1 (no row: the sort
+// sends it to the sentinel key, nothing is read for it).  A workgroup owns 256 neighbouring BAGS: their offsets go to LDS, the
+// values between the first and the last of them are walked with coalesced accesses and every value finds its bag in the LDS window
+// (8 steps).  (A workgroup per 256 VALUES needs two 17-step searches of the global offsets before it can start: 0.40 ms for 34 M
+// values, all of it latency.)  Dense lists: bag = j / L.  The workgroups past the last bag write the padding.
+template <typename IdT>
+__global__ __launch_bounds__(256) void bag_index_pad_kernel(const BagMultiArgs a, int64_t L, int64_t B, int64_t Bp,
+                                                            int32_t* __restrict__ map, IdT* __restrict__ idpad) {
+    __shared__ int64_t win[257];
+    const int f = blockIdx.y;
+    const int64_t n = a.nnz[f];
+    const IdT* offsets = static_cast<const IdT*>(a.offsets[f]);
+    const IdT* values = static_cast<const IdT*>(a.values[f]);
+    int32_t* mp = map + (int64_t)f * Bp;
+    IdT* ip = idpad + (int64_t)f * Bp;
+    const int64_t nbag_blocks = (B + 255) / 256;
+    if ((int64_t)blockIdx.x >= nbag_blocks) {  // padding: entries n .. Bp - 1, split over the remaining workgroups
+        const int64_t nb = (int64_t)gridDim.x - nbag_blocks;
+        int64_t covered = offsets ? (int64_t)offsets[B] : B * L;  // values past the last bag (a caller's nnz > offsets[B]) are padding too
+        if (covered > n) covered = n;
+        for (int64_t j = covered + ((int64_t)blockIdx.x - nbag_blocks) * 256 + threadIdx.x; j < Bp; j += nb * 256) {
+            mp[j] = 0;
+            ip[j] = (IdT)-1;
+        }
+        return;
+    }
+    const int64_t b0 = (int64_t)blockIdx.x * 256;
+    const int nb = (int)((B - b0 < 256) ? B - b0 : 256);
+    if (!offsets) {
+        for (int64_t j = b0 * L + threadIdx.x; j < (b0 + nb) * L; j += 256) {
+            mp[j] = (int32_t)(j / L);
+            ip[j] = values[j];
+        }
+        return;
+    }
+    for (int t = threadIdx.x; t <= nb; t += 256) win[t] = (int64_t)offsets[b0 + t];
+    __syncthreads();
+    const int64_t j0 = win[0], j1 = win[nb] < n ? win[nb] : n;
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+        int lo = 0, hi = nb;  // win[lo] <= j < win[hi]; empty bags share an offset with their successor: the LAST bag with offset <= j
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (win[mid] <= j) lo = mid; else hi = mid;
+        }
+        mp[j] = (int32_t)(b0 + lo);
+        ip[j] = values[j];
+    }
+}
+
+struct BagMultiWs {
+    int64_t Bp, off_scale, off_map, off_ids, off_inner, total;
+};
+
+bool bag_multi_ws(int64_t B, int64_t max_nnz, int F, int D, BagMultiWs* w) {
+    w->Bp = (max_nnz + 63) / 64 * 64;
+    const int64_t inner = mh_embedding_bwd_workspace_bytes(w->Bp, F, D);
+    if (inner < 0) return false;
+    int64_t o = 0;
+    w->off_scale = o; o = (int64_t)align_up((size_t)(o + (int64_t)F * B * 4), 256);
+    w->off_map = o;   o = (int64_t)align_up((size_t)(o + (int64_t)F * w->Bp * 4), 256);
+    w->off_ids = o;   o = (int64_t)align_up((size_t)(o + (int64_t)F * w->Bp * 8), 256);
+    w->off_inner = o; o += inner;
+    w->total = o;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1220,7 +1425,7 @@ static int32_t gather_bwd_impl(float* const* tables, float* const* state, const 
                                const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
                                int32_t optimizer, float lr, float eps, float* const* state2, float beta1, float beta2,
                                const float* lr_device, void* workspace, int64_t workspace_bytes,
-                               mh_stream_t stream, int phases) {
+                               mh_stream_t stream, int phases, const GradMap gm = GradMap{nullptr, 0, nullptr, 0}) {
     if (phases == PH_PREPARE) {  // ids only: no gradient, no optimizer state yet
         static const int64_t zero_off[MH_MAX_FEATURES] = {0};
         MH_REQUIRE(tables && table_rows && ids, "mh_embedding_gather_bwd_prepare: null argument");
@@ -1317,11 +1522,11 @@ static int32_t gather_bwd_impl(float* const* tables, float* const* state, const 
     }
     const bool wide = (uint64_t)total_rows >= 0xffffffffull;
     if (ids_dtype == MH_I32) {
-        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
-        return run_pipeline_t<int32_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
+        if (!wide) return run_pipeline_t<int32_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases, gm);
+        return run_pipeline_t<int32_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases, gm);
     }
-    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
-    return run_pipeline_t<int64_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases);
+    if (!wide) return run_pipeline_t<int64_t, uint32_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases, gm);
+    return run_pipeline_t<int64_t, uint64_t>(a, sa, npass, rbits, L, ws, B, F, D, grad, grad_row_stride, optimizer, hp, s, phases, gm);
 }
 
 int32_t mh_embedding_gather_bwd(float* const* tables, float* const* state, const int64_t* table_rows,
@@ -1452,5 +1657,73 @@ int32_t mh_embedding_bag_bwd(float* table, float* state, float* state2, int64_t 
                                    workspace_bytes - (ws - static_cast<char*>(workspace)), stream);
 }
 
+
+
+int64_t mh_embedding_bag_bwd_multi_workspace_bytes(int64_t B, int64_t max_nnz, int32_t F, int32_t D) {
+    if (B <= 0 || max_nnz <= 0 || F <= 0 || D <= 0) return 0;
+    BagMultiWs w;
+    if (!bag_multi_ws(B, max_nnz, F, D, &w)) return -1;
+    return w.total;
+}
+
+// F multi-hot features over DISTINCT tables in one fused update: the combiner divisors of all bags (one launch), bag index + padded
+// ids of all values (one launch), then ONE segmented sort / piece list / segmented reduce + optimizer over the F x max(nnz) values
+// (mh_embedding_gather_bwd's pipeline) that reads the gradient row of a value through its bag index -- no expanded [nnz, D] gradient.
+int32_t mh_embedding_bag_bwd_multi(float* const* tables, float* const* state, float* const* state2, const int64_t* table_rows,
+                                   const void* const* values, const int64_t* nnz, const void* const* offsets, int64_t L,
+                                   int32_t ids_dtype, int64_t B, int32_t F, int32_t D, int32_t combiner, const float* grad,
+                                   int64_t grad_row_stride, const int64_t* grad_offset, int32_t optimizer, float lr, float eps,
+                                   float beta1, float beta2, const float* lr_device, void* workspace, int64_t workspace_bytes,
+                                   mh_stream_t stream) {
+    MH_REQUIRE(tables && table_rows && values && nnz && grad && grad_offset, "mh_embedding_bag_bwd_multi: null argument");
+    MH_REQUIRE(F >= 1 && F < MH_MAX_FEATURES, "mh_embedding_bag_bwd_multi: F=%d outside [1,%d]", F, MH_MAX_FEATURES - 1);
+    MH_REQUIRE(ids_dtype == MH_I32 || ids_dtype == MH_I64, "mh_embedding_bag_bwd_multi: bad ids_dtype");
+    MH_REQUIRE(combiner >= MH_COMBINER_SUM && combiner <= MH_COMBINER_SQRTN, "mh_embedding_bag_bwd_multi: combiner must be sum, mean or sqrtn");
+    MH_REQUIRE(offsets || L >= 1, "mh_embedding_bag_bwd_multi: need CSR offsets or a list length L >= 1");
+    if (B <= 0) return MH_OK;
+    int64_t max_nnz = 0;
+    for (int f = 0; f < F; ++f) {
+        MH_REQUIRE(nnz[f] >= 0 && (nnz[f] == 0 || values[f]), "mh_embedding_bag_bwd_multi: null values of feature %d", f);
+        MH_REQUIRE(offsets == nullptr || offsets[f], "mh_embedding_bag_bwd_multi: null offsets of feature %d", f);
+        MH_REQUIRE(offsets != nullptr || nnz[f] == B * L, "mh_embedding_bag_bwd_multi: dense list needs nnz == B * L");
+        for (int g = 0; g < f; ++g)
+            MH_REQUIRE(tables[g] != tables[f], "mh_embedding_bag_bwd_multi: features %d and %d share a table (one call per table set)", g, f);
+        if (nnz[f] > max_nnz) max_nnz = nnz[f];
+    }
+    if (max_nnz == 0) return MH_OK;
+    BagMultiWs w;
+    MH_REQUIRE(bag_multi_ws(B, max_nnz, F, D, &w), "mh_embedding_bag_bwd_multi: sizes out of range");
+    MH_REQUIRE(workspace && workspace_bytes >= w.total, "mh_embedding_bag_bwd_multi: workspace too small (%lld < %lld)",
+               (long long)workspace_bytes, (long long)w.total);
+    MH_REQUIRE(w.Bp < (1ll << 26) && B < (1ll << 26), "mh_embedding_bag_bwd_multi: B and the longest value list must be < 2^26");
+    hipStream_t s = mh_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* scale = reinterpret_cast<float*>(ws + w.off_scale);
+    int32_t* map = reinterpret_cast<int32_t*>(ws + w.off_map);
+    void* idpad = ws + w.off_ids;
+    BagMultiArgs ba;
+    std::memset(&ba, 0, sizeof(ba));
+    for (int f = 0; f < F; ++f) {
+        ba.values[f] = values[f];
+        ba.offsets[f] = offsets ? offsets[f] : nullptr;
+        ba.nnz[f] = nnz[f];
+    }
+    const dim3 gs((unsigned)mh_ceil_div(B, 256), (unsigned)F);
+    // one workgroup per 256 bags + the workgroups that write the padding (at most Bp - min nnz entries)
+    const dim3 gi((unsigned)(mh_ceil_div(B, 256) + 64), (unsigned)F);
+    const void* idp[MH_MAX_FEATURES];
+    if (ids_dtype == MH_I32) {
+        MH_LAUNCH((bag_scale_multi_kernel<int32_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
+        MH_LAUNCH((bag_index_pad_kernel<int32_t>), gi, dim3(256), 0, s, ba, L, B, w.Bp, map, static_cast<int32_t*>(idpad));
+        for (int f = 0; f < F; ++f) idp[f] = static_cast<int32_t*>(idpad) + (int64_t)f * w.Bp;
+    } else {
+        MH_LAUNCH((bag_scale_multi_kernel<int64_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
+        MH_LAUNCH((bag_index_pad_kernel<int64_t>), gi, dim3(256), 0, s, ba, L, B, w.Bp, map, static_cast<int64_t*>(idpad));
+        for (int f = 0; f < F; ++f) idp[f] = static_cast<int64_t*>(idpad) + (int64_t)f * w.Bp;
+    }
+    const GradMap gm{map, w.Bp, scale, B};
+    return gather_bwd_impl(tables, state, table_rows, idp, ids_dtype, w.Bp, F, D, grad, grad_row_stride, grad_offset, optimizer, lr, eps,
+                           state2, beta1, beta2, lr_device, ws + w.off_inner, workspace_bytes - w.off_inner, stream, PH_ALL, gm);
+}
 
 }  // extern "C"

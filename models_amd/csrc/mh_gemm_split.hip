@@ -139,6 +139,7 @@ struct GsArgs {
     const float *bias, *x0, *xres;  // EPI 1: p = acc + bias[n]; C = x0 * p + xres (all [M, ld_e]); p_out optional
     float* p_out;
     int64_t ld_e;
+    int act;  // EPI 2: C = act(acc + bias[n])  (Dense forward)
 };
 
 __device__ __forceinline__ void g_dma16(const void* g, void* lds) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
         const bool n_ok = n < a.N;
         const int nc = n_ok ? n : a.N - 1;
         float bias = 0.f;
-        if (EPI == 1 && a.bias) bias = a.bias[nc];
+        if ((EPI == 1 || EPI == 2) && a.bias) bias = a.bias[nc];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int64_t mbase = row0 + wm * 64 + mb * 32 + 4 * h;
@@ -306,6 +307,10 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
                     v += bias;
                     if (a.p_out && n_ok && m < a.M) a.p_out[m * a.ld_e + n] = v;
                     v = fmaf(e0[i], v, e1[i]);
+                } else if (EPI == 2) {
+                    v += bias;
+                    if (a.act == MH_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (a.act == MH_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
                 } else if (a.addend) {
                     v += e0[i];
                 }
@@ -321,6 +326,14 @@ __global__ __launch_bounds__(256) void gs_reduce_slabs_kernel(const f32x4* __res
     if (i >= len4) return;
     f32x4 t = part[i];
     for (int s = 1; s < S; ++s) t += part[(int64_t)s * len4 + i];
+    out[i] = t;
+}
+
+__global__ __launch_bounds__(256) void gs_reduce_slabs_scalar_kernel(const float* __restrict__ part, int S, int64_t len, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    float t = part[i];
+    for (int s = 1; s < S; ++s) t += part[(int64_t)s * len + i];
     out[i] = t;
 }
 
@@ -533,6 +546,115 @@ int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p
         }
     }
     MH_CHECK_LAUNCH("mh_cross_layer_bwd_split");
+    return MH_OK;
+}
+
+
+// ---- Dense layer  y = act(x W + b)  (blocks/mlp.py:275-280) in the same arithmetic ---------------------------------------------
+int64_t mh_linear_split_workspace_bytes(int64_t M, int32_t K, int32_t N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    const int64_t Kp = pad_to(K, 64), Np = pad_to(N, 64), Mp = pad_to(M, 64);
+    // forward: x, W^T;  backward: dz, W (dX), x^T, dz^T, eight dW slabs, db partials (dW)
+    const int64_t fwd = pair_bytes(M, Kp) + pair_bytes(N, Kp);
+    const int64_t bwd = pair_bytes(M, Np) + pair_bytes(K, Np) + pair_bytes(K, Mp) + pair_bytes(N, Mp) + al256(8 * (int64_t)K * N * 4) +
+                        al256(64 * (int64_t)N * 4);
+    return (fwd > bwd ? fwd : bwd) + 1024;
+}
+
+int32_t mh_linear_bias_act_fwd_split(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int32_t K, int32_t N,
+                                     int32_t act, float* y, int64_t ldy, void* workspace, int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(x && W && y, "mh_linear_bias_act_fwd_split: null argument");
+    MH_REQUIRE(M >= 0 && K >= 1 && N >= 1, "mh_linear_bias_act_fwd_split: bad shape M=%lld K=%d N=%d", (long long)M, K, N);
+    MH_REQUIRE(ldx >= K && ldy >= N, "mh_linear_bias_act_fwd_split: leading dimension smaller than row");
+    MH_REQUIRE(act >= MH_ACT_NONE && act <= MH_ACT_SIGMOID, "mh_linear_bias_act_fwd_split: bad activation %d", act);
+    if (M == 0) return MH_OK;
+    MH_REQUIRE(workspace && workspace_bytes >= mh_linear_split_workspace_bytes(M, K, N), "mh_linear_bias_act_fwd_split: workspace too small");
+    hipStream_t s = mh_stream(stream);
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t Kp = pad_to(K, 64);
+    const SplitBuf sx = take_pair(p, M, Kp), sw = take_pair(p, N, Kp);
+    split_rows(x, M, K, ldx, sx, s);
+    split_transpose(W, K, N, N, sw, s);  // W [K, N] -> W^T [n][k], pad columns zero
+    GsArgs a{};
+    a.ah = sx.hi; a.al = sx.lo; a.bh = sw.hi; a.bl = sw.lo;
+    a.M = M; a.N = N; a.Kp = (int)Kp; a.lda = Kp; a.ldb = Kp;
+    a.C = y; a.ldc = ldy; a.slab = 0;
+    a.bias = b; a.act = act;
+    const int32_t st = launch_gemm<2>(a, 1, s);
+    if (st != MH_OK) return st;
+    MH_CHECK_LAUNCH("mh_linear_bias_act_fwd_split");
+    return MH_OK;
+}
+
+// same contract as mh_linear_bias_act_bwd (dy becomes dz = dy * act'(y) in place; dx masked by x_act; dW / db optional)
+int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W, const float* y, int64_t ldy, float* dy, int64_t lddy,
+                                     int64_t M, int32_t K, int32_t N, int32_t act, int32_t x_act, float* dx, int64_t lddx, float* dW,
+                                     float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream) {
+    MH_REQUIRE(x && dy, "mh_linear_bias_act_bwd_split: null argument");
+    MH_REQUIRE(!dx || W, "mh_linear_bias_act_bwd_split: W is required for dx");
+    MH_REQUIRE(M >= 1 && K >= 1 && N >= 1, "mh_linear_bias_act_bwd_split: bad shape");
+    MH_REQUIRE(dW || !db, "mh_linear_bias_act_bwd_split: db rides on the dW pass (pass dW too)");
+    MH_REQUIRE(ldx >= K && lddy >= N && (!dx || lddx >= K), "mh_linear_bias_act_bwd_split: bad leading dimension");
+    hipStream_t s = mh_stream(stream);
+    if (act != MH_ACT_NONE) {  // dz = dy * act'(y) in place: the fp32 library's element-wise pass
+        const int32_t st = mh_linear_bias_act_bwd(x, ldx, nullptr, y, ldy, dy, lddy, M, K, N, act, MH_ACT_NONE, nullptr, 0, nullptr, nullptr,
+                                                  nullptr, 0, stream);
+        if (st != MH_OK) return st;
+    }
+    if (!dx && !dW) return MH_OK;
+    MH_REQUIRE(workspace && workspace_bytes >= mh_linear_split_workspace_bytes(M, K, N), "mh_linear_bias_act_bwd_split: workspace too small");
+    char* wp = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t Np = pad_to(N, 64), Mp = pad_to(M, 64);
+    const SplitBuf sz = take_pair(wp, M, Np), sw = take_pair(wp, K, Np), sxt = take_pair(wp, K, Mp), szt = take_pair(wp, N, Mp);
+    float* slabs = reinterpret_cast<float*>(wp);
+    wp += al256(8 * (int64_t)K * N * 4);
+    float* dbp = reinterpret_cast<float*>(wp);
+    if (dx) {
+        split_rows(dy, M, N, lddy, sz, s);
+        split_rows(W, K, N, N, sw, s);  // W [K, N] row-major = B^T [n = k_in][k = n_out]
+        GsArgs a{};
+        a.ah = sz.hi; a.al = sz.lo; a.bh = sw.hi; a.bl = sw.lo;
+        a.M = M; a.N = K; a.Kp = (int)Np; a.lda = Np; a.ldb = Np;
+        a.C = dx; a.ldc = lddx;
+        const int32_t st = launch_gemm<0>(a, 1, s);
+        if (st != MH_OK) return st;
+        if (x_act != MH_ACT_NONE) {  // dx *= x_act'(x): x is the previous layer's activated output
+            const int32_t st2 = mh_linear_bias_act_bwd(x, ldx, nullptr, x, ldx, dx, lddx, M, K, K, x_act, MH_ACT_NONE, nullptr, 0, nullptr,
+                                                       nullptr, nullptr, 0, stream);
+            if (st2 != MH_OK) return st2;
+        }
+    }
+    if (dW) {
+        split_transpose(x, M, K, ldx, sxt, s);    // x^T  [K, Mp]
+        split_transpose(dy, M, N, lddy, szt, s);  // dz^T [N, Mp]
+        GsArgs a{};
+        a.ah = sxt.hi; a.al = sxt.lo; a.bh = szt.hi; a.bl = szt.lo;
+        a.M = K; a.N = N; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
+        const int64_t otiles = mh_ceil_div(K, 256) * mh_ceil_div(N, gemm_geo() == 2 ? 256 : 128);
+        int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
+        if (splits > 8) splits = 8;
+        if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);
+        if (splits < 1) splits = 1;
+        a.C = splits > 1 ? slabs : dW; a.ldc = N; a.slab = (int64_t)K * N;
+        const int32_t st = launch_gemm<0>(a, splits, s);
+        if (st != MH_OK) return st;
+        if (splits > 1) {
+            const int64_t len = (int64_t)K * N;
+            if (len % 4 == 0) {
+                MH_LAUNCH(gs_reduce_slabs_kernel, dim3((unsigned)mh_ceil_div(len / 4, 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(slabs),
+                          splits, len / 4, reinterpret_cast<f32x4*>(dW));
+            } else {
+                MH_LAUNCH(gs_reduce_slabs_scalar_kernel, dim3((unsigned)mh_ceil_div(len, 256)), dim3(256), 0, s, (const float*)slabs, splits, len, dW);
+            }
+        }
+        if (db) {
+            const int S = 64;
+            const int rps = (int)mh_ceil_div(M, S);
+            MH_LAUNCH(gs_colsum_kernel, dim3((unsigned)mh_ceil_div(N, 64), (unsigned)S), dim3(256), 0, s, (const float*)dy, M, (int)N, lddy, rps, dbp);
+            MH_LAUNCH(gs_colsum_finish_kernel, dim3((unsigned)mh_ceil_div(N, 256)), dim3(256), 0, s, (const float*)dbp, S, (int)N, db);
+        }
+    }
+    MH_CHECK_LAUNCH("mh_linear_bias_act_bwd_split");
     return MH_OK;
 }
 

@@ -369,7 +369,31 @@ class EmbeddingsBlock(ParallelBlock):
         done = {n for grp in merged for n in grp}
         lists = [n for n in lists if n not in done]
         names = [n for n in names if n not in done]
-        # ragged / dense-list features: gradient rows scale with the combiner, one fused launch chain each
+        # ragged / dense-list features over their own tables: the features of one width, combiner and id layout go through ONE
+        # sort + segmented reduce + optimizer (mh_embedding_bag_bwd_multi reads a value's gradient row through its bag index)
+        multi: Dict[tuple, list] = {}
+        for n in lists:
+            ft, x = self.feature_table[n], self._last[n]
+            ragged = isinstance(x, Ragged)
+            if ft.sequence_combiner in ("sum", "mean", "sqrtn") and g2.is_contiguous():
+                key = (ft.dim, ft.sequence_combiner, ragged, x.values.dtype if ragged else x.dtype,
+                       x.offsets.dtype if ragged else tuple(x.shape[1:]))
+                multi.setdefault(key, []).append(n)
+        for key, grp in multi.items():
+            if len(grp) < 2:
+                continue
+            for start in range(0, len(grp), 63):
+                part = grp[start:start + 63]
+                tabs = [self.feature_table[n].table for n in part]
+                sts = [_states(t) for t in tabs]
+                xs = [self._last[n] for n in part]
+                ops.embedding_bag_backward_multi(
+                    [t.data for t in tabs], None if sts[0][0] is None else [a for a, _ in sts],
+                    [x.values if key[2] else x for x in xs], [x.offsets for x in xs] if key[2] else None, g2,
+                    [offsets[n] for n in part], key[1], opt.name, opt.learning_rate, opt.epsilon,
+                    None if sts[0][1] is None else [b for _, b in sts], opt.beta_1, opt.beta_2, opt.lr_device)
+            lists = [n for n in lists if n not in grp]
+        # the rest: one fused launch chain each
         for n in lists:
             ft = self.feature_table[n]
             x = self._last[n]

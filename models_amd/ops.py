@@ -535,6 +535,12 @@ def _rowmajor_2d(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def _linear_split_ok(M: int, K: int, N: int) -> bool:
+    """The Dense layers that run in the opt-in bf16x3 arithmetic under MERLIN_HIP_GEMM_ARITH=bf16x3: wide ones (the 256 x 256 output
+    tiles of mh_gemm_split.hip need N >= 256 to be filled; the DCN-v2 deep tower's 3341 -> 512 -> 256)."""
+    return gemm_arith() == "bf16x3" and M >= 1024 and K >= 512 and N >= 256
+
+
 def linear(
     x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor] = None, activation: Optional[str] = None,
     out: Optional[torch.Tensor] = None,
@@ -558,6 +564,12 @@ def linear(
     else:
         _rowmajor_2d(out, "out")
     if M == 0:
+        return out
+    if _linear_split_ok(M, K, N):  # opt-in bf16x3 arithmetic of the wide Dense layers
+        ws = _workspace(lib.mh_linear_split_workspace_bytes(M, K, N), x.device, "linear_split")
+        with _timed(f"linear_{K}x{N}", nbytes=4 * (M * K + K * N + M * N), flops=2 * M * K * N):
+            check(lib.mh_linear_bias_act_fwd_split(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation], _ptr(out),
+                                                   out.stride(0), _ptr(ws), ws.numel(), _stream()), "mh_linear_bias_act_fwd_split")
         return out
     with _timed(f"linear_{K}x{N}", nbytes=4 * (M * K + K * N + M * N), flops=2 * M * K * N):
         check(
@@ -816,7 +828,9 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         dx = buf[:, :K]
     dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
-    nbytes = lib.mh_linear_bwd_workspace_bytes(M, K, N)
+    split = _linear_split_ok(M, K, N)  # same contract, bf16x3 GEMMs; the dX phase needs the workspace too
+    bwd = lib.mh_linear_bias_act_bwd_split if split else lib.mh_linear_bias_act_bwd
+    nbytes = lib.mh_linear_split_workspace_bytes(M, K, N) if split else lib.mh_linear_bwd_workspace_bytes(M, K, N)
     yp, ldy = (_ptr(y), y.stride(0)) if act != 0 else (None, 0)
     if SIDE.active("dw"):
         # dz first (in place), then dX on this stream while dW / db run on the "dw" side stream
@@ -828,15 +842,16 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         # backward) instead of competing with dX for the matrix pipe
         def run_dx():
             if need_dx:
-                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
-                                                 ACT[x_activation], _ptr(dx), lddx, None, None, None, 0, _stream()),
+                wsx = _workspace(nbytes, x.device, "linear_split_dx") if split else None
+                check(bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
+                          ACT[x_activation], _ptr(dx), lddx, None, None, _ptr(wsx), 0 if wsx is None else wsx.numel(), _stream()),
                       "mh_linear_bias_act_bwd")
 
         def run_dw():
             ws = _workspace(nbytes, x.device, "linear_bwd_side")
             with SIDE.on("dw", keep=(x, dy)):
-                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
-                                                 None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                check(bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
+                          None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
                       "mh_linear_bias_act_bwd")
 
         # (round 4 re-measured the alternatives on one box -- dW forked before dX, dW on its own stream, both, three streams: all
@@ -845,8 +860,8 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         if late_dw is not None:
             def run_dw_late():
                 ws = _workspace(nbytes, x.device, "linear_bwd_late")
-                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
-                                                 None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                check(bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0,
+                          None, 0, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
                       "mh_linear_bias_act_bwd")
 
             late_dw.append(run_dw_late)
@@ -857,8 +872,8 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
     ws = _workspace(nbytes, x.device, "linear_bwd")
     with _timed(f"linear_bwd_{K}x{N}", nbytes=4 * (2 * M * K + 2 * K * N + 2 * M * N), flops=(4 if need_dx else 2) * M * K * N):
         check(
-            lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), _ptr(W), yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
-                                       ACT[x_activation], _ptr(dx), lddx, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+            bwd(_ptr(x), x.stride(0), _ptr(W), yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
+                ACT[x_activation], _ptr(dx), lddx, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), _stream()),
             "mh_linear_bias_act_bwd",
         )
     return dx, dW, db
@@ -1092,6 +1107,101 @@ def embedding_bag_backward(table: torch.Tensor, state: Optional[torch.Tensor], v
                                      _lib.OPT[optimizer], lr, eps, beta1, beta2, _ptr(lr_device), _ptr(ws), ws.numel(),
                                      _stream()),
             "mh_embedding_bag_bwd",
+        )
+
+
+def embedding_bag_backward_multi(tables: Sequence[torch.Tensor], states: Optional[Sequence[Optional[torch.Tensor]]],
+                                 values: Sequence[torch.Tensor], offsets: Optional[Sequence[torch.Tensor]], grad: torch.Tensor,
+                                 grad_offset: Sequence[int], combiner: str = "mean", optimizer: str = "sgd", lr: float = 0.01,
+                                 eps: float = 1e-7, states2: Optional[Sequence[torch.Tensor]] = None, beta1: float = 0.9,
+                                 beta2: float = 0.999, lr_device: Optional[torch.Tensor] = None) -> None:
+    """``embedding_bag_backward`` of F list features over F distinct tables of one width in ONE sparse update
+    (``mh_embedding_bag_bwd_multi``): ``grad`` is a contiguous ``[B, ...]`` buffer, feature f's ``[B, D]`` block starts
+    ``grad_offset[f]`` floats into row b.  ``offsets=None``: every ``values[f]`` is a dense ``[B, L]`` list of one L.
+    The same sums as F single-feature calls (a run of equal ids may be cut into partial sums at other places: a few ulp); no
+    ``[nnz, D]`` expanded gradient is materialised."""
+    lib = _lib.load()
+    _sync_deterministic(lib)
+    F = len(tables)
+    if F == 0:
+        return
+    if F > _lib.MAX_FEATURES - 1:
+        raise ValueError(f"at most {_lib.MAX_FEATURES - 1} features per backward call")
+    if combiner not in COMBINER or combiner == "max":
+        raise ValueError(f"combiner must be sum, mean or sqrtn, got {combiner!r}")
+    if len(values) != F or len(grad_offset) != F or (offsets is not None and len(offsets) != F):
+        raise ValueError("tables, values, offsets and grad_offset must have one entry per feature")
+    _dev(grad, "grad", torch.float32)
+    if not grad.is_contiguous():
+        raise ValueError("grad must be contiguous")
+    B = grad.shape[0]
+    if B == 0:
+        return
+    D = tables[0].shape[1]
+    row_stride = grad.numel() // B
+    idt = _ids_dtype(values[0], "values[0]")
+    for f, w in enumerate(tables):
+        _dev(w, f"tables[{f}]", torch.float32)
+        if w.shape[1] != D:
+            raise ValueError("all tables of one call share the embedding width")
+        if values[f].dtype != values[0].dtype:
+            raise TypeError("all value lists share one integer dtype")
+        if int(grad_offset[f]) < 0 or int(grad_offset[f]) + D > row_stride:
+            raise ValueError(f"grad_offset[{f}] + D exceeds the gradient row")
+    if len({w.data_ptr() for w in tables}) != F:
+        raise ValueError("the features of one call use distinct tables (shared tables: embedding_bag_expand + one gather update)")
+    L = 0
+    if offsets is None:
+        vals = []
+        for v in values:
+            if v.dim() == 3 and v.shape[-1] == 1:
+                v = v.squeeze(-1)
+            if v.dim() != 2 or v.shape[0] != B:
+                raise ValueError("dense list values must be [B, L]")
+            if L and v.shape[1] != L:
+                raise ValueError("dense lists of one call share the list length")
+            L = v.shape[1]
+            vals.append(v.reshape(-1).contiguous())
+        offs = None
+    else:
+        vals = [_dev(v, "values").reshape(-1).contiguous() for v in values]
+        offs = []
+        for o in offsets:
+            _dev(o, "offsets")
+            if o.dtype != values[0].dtype:
+                raise TypeError("offsets and values must share one integer dtype")
+            o = o.reshape(-1).contiguous()
+            if o.shape[0] != B + 1:
+                raise ValueError(f"offsets must have B + 1 = {B + 1} entries")
+            offs.append(o)
+    st = st2 = None
+    if optimizer in ("adagrad", "adam", "lazy_adam"):
+        if states is None or any(s is None for s in states):
+            raise ValueError(f"{optimizer} needs a state tensor per table")
+        st = _host_ptr_array([s.data_ptr() for s in states])
+    if optimizer in ("adam", "lazy_adam"):
+        if states2 is None or any(s is None for s in states2):
+            raise ValueError("adam needs a second-moment tensor per table")
+        st2 = _host_ptr_array([s.data_ptr() for s in states2])
+    nnz = [int(v.shape[0]) for v in vals]
+    if max(nnz) == 0:
+        return
+    tab = _host_ptr_array([w.data_ptr() for w in tables])
+    vp = _host_ptr_array([v.data_ptr() if v.numel() else 0 for v in vals])
+    op = None if offs is None else _host_ptr_array([o.data_ptr() for o in offs])
+    rows = (C.c_int64 * F)(*[w.shape[0] for w in tables])
+    nz = (C.c_int64 * F)(*nnz)
+    slot = (C.c_int64 * F)(*[int(s) for s in grad_offset])
+    nbytes = lib.mh_embedding_bag_bwd_multi_workspace_bytes(B, max(nnz), F, D)
+    if nbytes < 0:
+        raise _lib.MerlinHipError("mh_embedding_bag_bwd_multi_workspace_bytes failed")
+    ws = _workspace(nbytes, grad.device, "embedding_bag_bwd_multi")
+    with _timed("embedding_bag_bwd_multi"):
+        check(
+            lib.mh_embedding_bag_bwd_multi(tab, st, st2, rows, vp, nz, op, L, idt, B, F, D, COMBINER[combiner], _ptr(grad),
+                                           row_stride, slot, _lib.OPT[optimizer], lr, eps, beta1, beta2, _ptr(lr_device),
+                                           _ptr(ws), ws.numel(), _stream()),
+            "mh_embedding_bag_bwd_multi",
         )
 
 
@@ -1332,6 +1442,7 @@ def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: 
     loss = torch.empty((B,), dtype=torch.float32, device=q.device)
     lse = torch.empty((B,), dtype=torch.float32, device=q.device)
     ws = _workspace(lib.mh_inbatch_softmax_workspace_bytes(B, Nn, E, 0), q.device, "scorer_fwd")
+    _sync_scorer_arith(lib)
     with _timed("inbatch_softmax_fwd", nbytes=4 * (2 * B + Nn) * E, flops=2 * B * Nn * E + 2 * B * E):
         check(
             lib.mh_inbatch_softmax_fwd(_ptr(q), _ptr(item), _ptr(neg_item), _ptr(pos_ids), _ptr(neg_ids), idt, B, Nn, E,
@@ -1476,7 +1587,8 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
 
 def gemm_arith() -> str:
     """MERLIN_HIP_GEMM_ARITH = f32 (default) | bf16x3: the opt-in three-term split-bf16 arithmetic of the DCN-v2 cross layer's GEMMs
-    (``mh_cross_layer_fwd_split`` / ``_bwd_split``; not bit-identical to the fp32 kernels, reported under its own dtype label)."""
+    (``mh_cross_layer_fwd_split`` / ``_bwd_split``) and of the wide Dense layers (``mh_linear_bias_act_fwd_split`` / ``_bwd_split``);
+    not bit-identical to the fp32 kernels, reported under its own dtype label."""
     import os
 
     return "bf16x3" if os.environ.get("MERLIN_HIP_GEMM_ARITH", "f32") == "bf16x3" else "f32"

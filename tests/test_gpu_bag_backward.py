@@ -266,3 +266,136 @@ def test_shared_table_onehot_and_list_take_one_optimizer_step(optimizer, idt):
     go = np.zeros_like(Wo0)
     np.add.at(go, oth, grad[:, names.index("other")])
     assert not np.allclose(emb.feature_table["other"].table.numpy(), Wo0)
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("combiner,optimizer", [("mean", "sgd"), ("sqrtn", "adagrad"), ("sum", "adam")])
+def test_bag_backward_multi_matches_single_calls(dtype, combiner, optimizer):
+    """mh_embedding_bag_bwd_multi: F ragged features (different value counts, empty bags, pruned and out-of-range ids) over F
+    tables in one update against F mh_embedding_bag_bwd calls on copies of the same tables (the same sums; a run of equal ids is
+    cut into pieces at other places when the features share one sorted array, so the association -- not the terms -- may differ:
+    a few ulp of the sum), and the dense gradient against the oracle."""
+    from models_amd import ops
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(17)
+    B, D, F = 1500, 32, 3
+    Vs = [200, 5000, 37]
+    feats = [_csr(rng, B, V, m) for V, m in zip(Vs, (12, 3, 30))]
+    wide = rng.standard_normal((B, 8 + F * D)).astype(np.float32)
+    slot = [8 + f * D for f in range(F)]
+    g = torch.from_numpy(wide).to(dev)
+    W0 = [rng.standard_normal((V, D)).astype(np.float32) for V in Vs]
+
+    def fresh():
+        W = [torch.from_numpy(w.copy()).to(dev) for w in W0]
+        S = [torch.full((V, D), 0.1, device=dev) for V in Vs] if optimizer != "sgd" else None
+        S2 = [torch.full((V, D), 0.1, device=dev) for V in Vs] if optimizer == "adam" else None  # v > 0: a well-conditioned step
+        return W, S, S2
+
+    vals = [torch.from_numpy(v).to(dtype).to(dev) for v, _ in feats]
+    offs = [torch.from_numpy(o).to(dtype).to(dev) for _, o in feats]
+    Wm, Sm, S2m = fresh()
+    ops.embedding_bag_backward_multi(Wm, Sm, vals, offs, g, slot, combiner, optimizer, 0.05, 1e-7, S2m)
+    Ws, Ss, S2s = fresh()
+    for f in range(F):
+        ops.embedding_bag_backward(Ws[f], None if Ss is None else Ss[f], vals[f], offs[f], g[:, slot[f]:slot[f] + D], combiner,
+                                   optimizer, 0.05, 1e-7, None if S2s is None else S2s[f])
+    for f in range(F):
+        # runs that cross 16-entry chunks are summed with float atomics in both paths (default mode): a few ulp of the sum, which
+        # the optimizer's g / (sqrt(acc) + eps) passes on at the same relative size
+        torch.testing.assert_close(Wm[f], Ws[f], rtol=1e-5, atol=2e-5)
+        if Sm is not None:
+            torch.testing.assert_close(Sm[f], Ss[f], rtol=1e-5, atol=2e-5)
+        if S2m is not None:
+            torch.testing.assert_close(S2m[f], S2s[f], rtol=1e-5, atol=2e-5)
+    if optimizer == "sgd":
+        for f in range(F):
+            dW = O.embedding_bag_grad(Vs[f], feats[f][0], feats[f][1], wide[:, slot[f]:slot[f] + D], combiner)
+            np.testing.assert_allclose(Wm[f].cpu().numpy(), W0[f] - 0.05 * dW, rtol=1e-5, atol=1e-6)
+
+
+def test_bag_backward_multi_dense_lists_and_argument_checks():
+    from models_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(23)
+    B, L, D, F = 777, 5, 16, 4
+    Vs = [50, 51, 52, 53]
+    ids = [torch.from_numpy(rng.integers(0, V, size=(B, L))).to(dev) for V in Vs]
+    g = torch.from_numpy(rng.standard_normal((B, F * D)).astype(np.float32)).to(dev)
+    Wm = [torch.zeros(V, D, device=dev) for V in Vs]
+    Ws = [torch.zeros(V, D, device=dev) for V in Vs]
+    ops.embedding_bag_backward_multi(Wm, None, ids, None, g, [f * D for f in range(F)], "mean", "sgd", -1.0)
+    for f in range(F):
+        ops.embedding_bag_backward(Ws[f], None, ids[f], None, g[:, f * D:(f + 1) * D], "mean", "sgd", -1.0)
+        torch.testing.assert_close(Wm[f], Ws[f], rtol=2e-6, atol=2e-6)
+    with pytest.raises(ValueError, match="distinct tables"):
+        ops.embedding_bag_backward_multi([Wm[0], Wm[0]], None, ids[:2], None, g, [0, D], "mean", "sgd", 0.1)
+    with pytest.raises(ValueError, match="sum, mean or sqrtn"):
+        ops.embedding_bag_backward_multi(Wm[:2], None, ids[:2], None, g, [0, D], "max", "sgd", 0.1)
+
+
+def test_bag_backward_multi_giant_bag_and_long_stretches_of_empty_bags():
+    """The index kernel's LDS window (the bags of 256 neighbouring values) falls back to the global search when thousands of empty
+    bags lie between two values; the divisor kernel counts a bag longer than a wavefront with all lanes."""
+    from models_amd import ops
+
+    dev = _dev()
+    rng = np.random.default_rng(31)
+    B, D, V = 9000, 16, 97
+    lens0 = np.zeros(B, dtype=np.int64)
+    lens0[[10, 3000, 3001, 8000, 8999]] = [5, 300, 40000, 7, 70]
+    lens1 = rng.integers(0, 4, size=B)
+    feats = []
+    for lens in (lens0, lens1):
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        val = rng.integers(0, V, size=int(off[-1])).astype(np.int64)
+        val[rng.random(val.shape) < 0.1] = -1
+        feats.append((torch.from_numpy(val).to(dev), torch.from_numpy(off).to(dev)))
+    g = torch.from_numpy(rng.standard_normal((B, 2 * D)).astype(np.float32)).to(dev)
+    for comb in ("mean", "sqrtn", "sum"):
+        Wm = [torch.zeros(V, D, device=dev) for _ in range(2)]
+        Ws = [torch.zeros(V, D, device=dev) for _ in range(2)]
+        ops.embedding_bag_backward_multi(Wm, None, [v for v, _ in feats], [o for _, o in feats], g, [0, D], comb, "sgd", -1.0)
+        for f in range(2):
+            ops.embedding_bag_backward(Ws[f], None, feats[f][0], feats[f][1], g[:, f * D:(f + 1) * D], comb, "sgd", -1.0)
+            torch.testing.assert_close(Wm[f], Ws[f], rtol=1e-5, atol=2e-4)  # sums of up to 40 000 terms in another order
+
+
+def test_embeddings_block_updates_several_ragged_features_in_one_launch(monkeypatch):
+    """Two ragged features over their own tables (same width and combiner) and a one-hot feature in one apply_sparse: the block
+    takes the two lists through ONE mh_embedding_bag_bwd_multi (asserted) and every table gets the oracle's Adagrad step."""
+    import models_amd as mm
+    from models_amd import ops, optim
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(19)
+    B, D = 129, 16
+    schema = mm.Schema([mm.schema.categorical("a", 50), mm.schema.categorical("l1", 40), mm.schema.categorical("l2", 700)])
+    emb = mm.Embeddings(schema, dim=D, sequence_combiner="mean", device=dev)
+    v1, o1 = _csr(rng, B, 40, 5)
+    v2, o2 = _csr(rng, B, 700, 9)
+    a = rng.integers(0, 50, size=B).astype(np.int64)
+    inputs = {"a": torch.from_numpy(a).to(dev), "l1": mm.Ragged(torch.from_numpy(v1).to(dev), torch.from_numpy(o1).to(dev)),
+              "l2": mm.Ragged(torch.from_numpy(v2).to(dev), torch.from_numpy(o2).to(dev))}
+    emb(inputs)
+    W0 = {n: emb.feature_table[n].table.numpy().copy() for n in ("a", "l1", "l2")}
+    grad = rng.standard_normal((B, 3, D)).astype(np.float32)
+    emb.set_pending_grad(torch.from_numpy(grad).to(dev), {"a": 0, "l1": D, "l2": 2 * D})
+    calls = []
+    real = ops.embedding_bag_backward_multi
+    monkeypatch.setattr(ops, "embedding_bag_backward_multi", lambda *a_, **k: (calls.append(len(a_[0])), real(*a_, **k))[1])
+    emb.apply_sparse(optim.Adagrad(learning_rate=0.5, initial_accumulator_value=0.1))
+    assert calls == [2]
+    for n, (v, o, V, col) in {"l1": (v1, o1, 40, 1), "l2": (v2, o2, 700, 2)}.items():
+        dW = O.embedding_bag_grad(V, v, o, grad[:, col], "mean")
+        touched = np.zeros(V, bool)
+        touched[np.unique(v[(v >= 0) & (v < V)])] = True
+        acc = np.full((V, D), 0.1, np.float32)
+        acc[touched] += dW[touched] ** 2
+        w = W0[n].copy()
+        w[touched] -= 0.5 * dW[touched] / (np.sqrt(acc[touched]) + 1e-7)
+        np.testing.assert_allclose(emb.feature_table[n].table.numpy(), w, rtol=2e-5, atol=2e-6)

@@ -44,3 +44,56 @@ def test_cross_layer_split_matches_fp32_and_float64(device, monkeypatch, M, d):
         # bf16x3 against float64: 1e-4 of the largest entry (dW sums M products per entry: its fp32 accumulation error alone is ~1e-5 of scale)
         torch.testing.assert_close(got, w, atol=1e-4 * scale, rtol=1e-4, msg=lambda m, n=n: f"{n} vs float64: {m}")
         torch.testing.assert_close(got, ref, atol=1e-4 * scale, rtol=1e-4, msg=lambda m, n=n: f"{n} vs fp32 kernels: {m}")
+
+
+@pytest.mark.parametrize("M,K,N,act,x_act", [(1536, 3341, 512, "relu", None), (1100, 512, 256, "relu", "relu"), (2048, 600, 300, None, None),
+                                              (1024, 1000, 256, "sigmoid", "relu")])
+def test_dense_layer_split_matches_fp32_and_float64(device, monkeypatch, M, K, N, act, x_act):
+    """Wide Dense layers under MERLIN_HIP_GEMM_ARITH=bf16x3 (mh_linear_bias_act_fwd_split / _bwd_split): y, dz, dx (with the
+    producer's activation mask), dW, db against float64 and against the exact-fp32 kernels; ragged K (3341 = the DCN-v2 tower input)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    if x_act == "relu":
+        x = x.clamp_min(0.0)  # x is the producer's activated output
+    W = torch.randn(K, N, generator=g) * (1.0 / np.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(M, N, generator=g)
+    dev = lambda t: t.to(device)
+
+    def run():
+        y = ops.linear(dev(x), dev(W), dev(b), act)
+        dyc = dev(dy).clone()
+        dx, dW, db = ops.linear_backward(dev(x), dev(W), y, dyc, act, True, True, x_act)
+        return [t.cpu().double() for t in (y, dyc, dx, dW, db)]
+
+    monkeypatch.setenv("MERLIN_HIP_GEMM_ARITH", "f32")
+    f32 = run()
+    monkeypatch.setenv("MERLIN_HIP_GEMM_ARITH", "bf16x3")
+    assert ops._linear_split_ok(M, K, N)
+    sp = run()
+    monkeypatch.setenv("MERLIN_HIP_GEMM_ARITH", "f32")
+    assert any(not torch.equal(a, b_) for a, b_ in zip(f32, sp)), "the bf16x3 switch did not change the arithmetic"
+    x64, W64, b64, d64 = (t.double() for t in (x, W, b, dy))
+    z64 = x64 @ W64 + b64
+    if act == "relu":
+        y64, dz64 = z64.clamp_min(0.0), d64 * (z64 > 0)
+    elif act == "sigmoid":
+        y64 = torch.sigmoid(z64)
+        dz64 = d64 * y64 * (1 - y64)
+    else:
+        y64, dz64 = z64, d64
+    # a pre-activation within the arithmetic's error of zero lands on either side of the relu gate, and ONE flipped gate moves a whole
+    # row of dx by dy * W[:, n]: the GEMMs of the backward are checked on the dz this run produced (its gates), dz itself where |z| is clear
+    dz_run = sp[1] if act == "relu" else dz64
+    dx64 = dz_run @ W64.T
+    if x_act == "relu":
+        dx64 = dx64 * (x64 > 0)
+    want = [y64, dz64, dx64, x64.T @ dz_run, dz_run.sum(0)]
+    for n, got, ref, w in zip(("y", "dz", "dx", "dW", "db"), sp, f32, want):
+        scale = float(w.abs().max())
+        if n == "dz" and act == "relu":
+            clear = (z64.abs() > 1e-4)
+            got, ref, w = got * clear, ref * clear, w * clear
+        torch.testing.assert_close(got, w, atol=1e-4 * scale, rtol=1e-4, msg=lambda m, n=n: f"{n} vs float64: {m}")
+        if act != "relu" or n in ("y", "dz"):
+            torch.testing.assert_close(got, ref, atol=1e-4 * scale, rtol=1e-4, msg=lambda m, n=n: f"{n} vs fp32 kernels: {m}")
