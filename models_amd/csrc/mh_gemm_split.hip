@@ -34,17 +34,23 @@ constexpr int GBK = 32;
 //             by the MFMAs of the other; the A panel is re-read twice as often from L2.
 //   BM = 256, BN = 256: 8 wavefronts of 64 x 128 (2 x 4 accumulators), 2 stages of 64 KB: half the barriers and 3 / 4 of the LDS reads per
 //             MFMA of the 256 x 128 tile; 7 % of the column tiles of d = 3344 are padding (3.3 % at BN = 128).
-template <int BM, int BN>
+//   BM = BN = 256, BK = 16, 5 stages of 32 KB (160 KB): the same tile with FOUR k-tiles in flight instead of one -- the ring of the
+//             BK = 32 form tolerates ~1.3 us of load latency (one 64 KB tile ahead of 1.3 us of MFMAs), this one ~2.5 us.
+template <int BM, int BN, int BK_ = 32, int ST_ = 0>
 struct Geo {
+    static constexpr int BK = BK_;
+    static constexpr int CPR = BK / 8;                   // 16-byte chunks per row of a k-tile
+    static constexpr int RS = BK * 2;                    // bytes per row of a k-tile in LDS
+    static constexpr int KS = BK / 16;                   // 16-wide k-steps per tile
     static constexpr int NT = BM * 2;                    // threads: 64 rows per wavefront, two column wavefronts
     static constexpr int NB = BN / 64;                   // 32-column blocks per wavefront
-    static constexpr int ST = (BM == 256 && BN == 128) ? 3 : 2;  // ring depth
-    static constexpr int A_ARR = BM * GBK * 2;
-    static constexpr int B_ARR = BN * GBK * 2;
+    static constexpr int ST = ST_ ? ST_ : ((BM == 256 && BN == 128) ? 3 : 2);  // ring depth
+    static constexpr int A_ARR = BM * BK * 2;
+    static constexpr int B_ARR = BN * BK * 2;
     static constexpr int STAGE = 2 * A_ARR + 2 * B_ARR;
     static constexpr int LDS = ST * STAGE;
-    static constexpr int DMA_A = 2 * BM * 4 / NT;        // A chunks of 16 bytes per thread and k-tile
-    static constexpr int DMA_B = 2 * BN * 4 / NT;
+    static constexpr int DMA_A = 2 * BM * CPR / NT;      // A chunks of 16 bytes per thread and k-tile
+    static constexpr int DMA_B = 2 * BN * CPR / NT;
     static constexpr int DMA = DMA_A + DMA_B;
 };
 
@@ -58,12 +64,25 @@ __device__ __forceinline__ float g_f32(uint16_t h) { return __uint_as_float((uin
 
 // x [R, C] (leading dimension ld) -> hi, lo [R, Cp] bf16, columns C .. Cp - 1 zero (Cp % 8 == 0).  One 8-column group per thread.
 __global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int Cp,
-                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int pack) {
     const int g8 = Cp / 8;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * g8) return;
-    const int64_t r = i / g8;
-    const int c0 = (int)(i - r * g8) * 8;
+    // row-major: thread i -> (row, group of 8 columns), groups fastest.  Packed (k-tile major, see GsArgs): i -> (k-tile, row, quarter
+    // of the tile's 32 columns), quarters fastest: four lanes read 128 contiguous bytes of a row and a wavefront writes 1 KB contiguous.
+    int64_t r;
+    int c0;
+    int64_t dst;
+    if (pack) {
+        const int64_t kt = i / (R * 4), rem = i - kt * (R * 4);
+        r = rem >> 2;
+        c0 = (int)kt * 32 + (int)(rem & 3) * 8;
+        dst = (kt * R + r) * 32 + (rem & 3) * 8;
+    } else {
+        r = i / g8;
+        c0 = (int)(i - r * g8) * 8;
+        dst = r * Cp + c0;
+    }
     // two 16-byte loads where the row allows them (C % 4 == 0 and 16-byte aligned rows: what the callers pass), scalars otherwise
     float v8[8];
     const bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
@@ -86,13 +105,13 @@ __global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restr
         wh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
         wl[k] = (uint32_t)g_bf16(v0 - g_f32(h0)) | ((uint32_t)g_bf16(v1 - g_f32(h1)) << 16);
     }
-    *reinterpret_cast<uint4*>(hi + r * Cp + c0) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-    *reinterpret_cast<uint4*>(lo + r * Cp + c0) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    *reinterpret_cast<uint4*>(hi + dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+    *reinterpret_cast<uint4*>(lo + dst) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
 }
 
 // x [R, C] (ld) -> hiT, loT [C, Rp] bf16 (the transpose), columns R .. Rp - 1 zero (Rp % 64 == 0).  64 x 64 tiles through LDS.
 __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int64_t Rp,
-                                                                uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT) {
+                                                                uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT, int pack) {
     __shared__ uint16_t sh[64][66], sl[64][66];
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
@@ -115,8 +134,10 @@ __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __
         wh[k] = (uint32_t)sh[r][c] | ((uint32_t)sh[r + 1][c] << 16);
         wl[k] = (uint32_t)sl[r][c] | ((uint32_t)sl[r + 1][c] << 16);
     }
-    uint16_t* ph = hiT + (int64_t)(c0 + c) * Rp + r0 + seg * 16;
-    uint16_t* pl = loT + (int64_t)(c0 + c) * Rp + r0 + seg * 16;
+    // packed: element (row c0 + c, k = r0 + seg 16 ...) of the [C, Rp] result lives at ((k / 32) C + row) 32 + k % 32
+    const int64_t off = pack ? (((r0 >> 5) + (seg >> 1)) * (int64_t)C + c0 + c) * 32 + (seg & 1) * 16 : (int64_t)(c0 + c) * Rp + r0 + seg * 16;
+    uint16_t* ph = hiT + off;
+    uint16_t* pl = loT + off;
     *reinterpret_cast<uint4*>(ph) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
     *reinterpret_cast<uint4*>(ph + 8) = make_uint4(wh[4], wh[5], wh[6], wh[7]);
     *reinterpret_cast<uint4*>(pl) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
@@ -124,8 +145,12 @@ __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __
 }
 
 struct GsArgs {
-    const uint16_t *ah, *al, *bh, *bl;  // A [M, lda], B^T [N, ldb] bf16 bit patterns, K-contiguous, zero-padded to Kp
-    int64_t M, lda, ldb;
+    const uint16_t *ah, *al, *bh, *bl;  // A [M, Kp], B^T [N, Kp] bf16 bit patterns, zero-padded to Kp.  Row-major (element (r, k) at
+                                        // r lda + k) or PACKED k-tile major (at ((k / 32) rows + r) 32 + k % 32: the 64 bytes a row
+                                        // contributes to a k-tile lie next to those of its neighbours, so a tile-load instruction of a
+                                        // wavefront fetches 1 KB contiguous = 8 whole cache lines instead of 16 half lines)
+    int64_t M, lda, ldb;                // row-major leading dimensions (unused when packed)
+    int pack;
     int N, Kp;
     float* C;
     int64_t ldc;
@@ -140,6 +165,8 @@ struct GsArgs {
     float* p_out;
     int64_t ld_e;
     int act;  // EPI 2: C = act(acc + bias[n])  (Dense forward)
+    int ablate;  // timing experiments only (MERLIN_HIP_GEMM_SPLIT_ABLATE; results are wrong): 1 = no tile loads inside the k-loop,
+                 // 2 = the loads are issued but a tile is used without waiting for it (up to two tiles in flight)
 };
 
 __device__ __forceinline__ void g_dma16(const void* g, void* lds) {
@@ -151,9 +178,10 @@ __device__ __forceinline__ void g_wait_vm_and_barrier() {
 }
 __device__ __forceinline__ f32x16 g_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-template <int EPI, int BM, int BN, bool PIPE>
+template <int EPI, int BM, int BN, bool PIPE, int BK = 32, int ST = 0>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kernel(const GsArgs a) {
-    using G = Geo<BM, BN>;
+    using G = Geo<BM, BN, BK, ST>;
+    constexpr int CPR = G::CPR, RS = G::RS, KS = G::KS;
     constexpr int GBM = BM, GBN = BN, GNT = G::NT, GST = G::ST, G_A_ARR = G::A_ARR, G_B_ARR = G::B_ARR, G_STAGE = G::STAGE, G_DMA = G::DMA;
     constexpr int NB = G::NB;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -173,7 +201,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
     }
     const int64_t row0 = rt * GBM;
     const int n0 = ct * GBN;
-    const int nkt_all = a.Kp / GBK;
+    const int nkt_all = a.Kp / BK;
     const int kt_beg = blockIdx.y * a.kt_per_split;
     const int kt_end = (kt_beg + a.kt_per_split < nkt_all) ? kt_beg + a.kt_per_split : nkt_all;
     const int T = kt_end - kt_beg;
@@ -183,27 +211,31 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
 #pragma unroll
     for (int j = 0; j < G::DMA_A; ++j) {  // A: 2 arrays x BM rows x 4 chunks
         const int L = j * GNT + threadIdx.x;
-        const int arr = L / (BM * 4), Lp = L % (BM * 4), r = Lp >> 2, p = Lp & 3, c = p ^ ((r >> 2) & 3);
+        const int arr = L / (BM * CPR), Lp = L % (BM * CPR), r = Lp / CPR, p = Lp % CPR;
+        const int c = p ^ (CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1));
         int64_t row = row0 + r;
         if (row > a.M - 1) row = a.M - 1;
-        src[j] = (arr ? a.al : a.ah) + row * a.lda + c * 8;
+        src[j] = (arr ? a.al : a.ah) + row * (a.pack ? (int64_t)32 : a.lda) + c * 8;
     }
 #pragma unroll
     for (int j = 0; j < G::DMA_B; ++j) {  // B: 2 arrays x BN rows x 4 chunks
         const int L = j * GNT + threadIdx.x;
-        const int arr = L / (BN * 4), Lp = L % (BN * 4), r = Lp >> 2, p = Lp & 3, c = p ^ ((r >> 2) & 3);
+        const int arr = L / (BN * CPR), Lp = L % (BN * CPR), r = Lp / CPR, p = Lp % CPR;
+        const int c = p ^ (CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1));
         int col = n0 + r;
         if (col > a.N - 1) col = a.N - 1;
-        src[G::DMA_A + j] = (arr ? a.bl : a.bh) + (int64_t)col * a.ldb + c * 8;
+        src[G::DMA_A + j] = (arr ? a.bl : a.bh) + (int64_t)col * (a.pack ? (int64_t)32 : a.ldb) + c * 8;
     }
-    auto issue = [&](int t) {  // k-tile kt_beg + t -> stage t % GST
-        unsigned char* st = smem + (t % GST) * G_STAGE;
-        const int64_t koff = (int64_t)(kt_beg + t) * GBK;
+    const int64_t ks_a = a.pack ? a.M * 32 : (int64_t)BK, ks_b = a.pack ? (int64_t)a.N * 32 : (int64_t)BK;  // elements per k-tile step
+    auto issue_at = [&](int tile, int stage) {  // k-tile kt_beg + tile -> LDS stage
+        unsigned char* st = smem + stage * G_STAGE;
+        const int64_t ka = (int64_t)(kt_beg + tile) * ks_a, kb = (int64_t)(kt_beg + tile) * ks_b;
 #pragma unroll
-        for (int j = 0; j < G::DMA_A; ++j) g_dma16(src[j] + koff, st + (j * GNT + wave * 64) * 16);
+        for (int j = 0; j < G::DMA_A; ++j) g_dma16(src[j] + ka, st + (j * GNT + wave * 64) * 16);
 #pragma unroll
-        for (int j = 0; j < G::DMA_B; ++j) g_dma16(src[G::DMA_A + j] + koff, st + 2 * G_A_ARR + (j * GNT + wave * 64) * 16);
+        for (int j = 0; j < G::DMA_B; ++j) g_dma16(src[G::DMA_A + j] + kb, st + 2 * G_A_ARR + (j * GNT + wave * 64) * 16);
     };
+    auto issue = [&](int t) { issue_at(t, t % GST); };
     f32x16 acc[2][NB];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -219,56 +251,89 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         const int r = wm * 64 + mb * 32 + l31;
-        a_off[mb] = r * 64;
-        a_sw[mb] = (r >> 2) & 3;
+        a_off[mb] = r * RS;
+        a_sw[mb] = CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1);
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int r = wn * (BN / 2) + nb * 32 + l31;
-        b_off[nb] = 2 * G_A_ARR + r * 64;
-        b_sw[nb] = (r >> 2) & 3;
+        b_off[nb] = 2 * G_A_ARR + r * RS;
+        b_sw[nb] = CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1);
     }
-    for (int t = 0; t < T; ++t) {
-        // tile t is complete when at most the loads of tiles t + 1 .. t + GST - 2 are outstanding
-        if (t + GST - 2 < T) g_wait_vm_and_barrier<(GST - 2) * G_DMA>();
-        else g_wait_vm_and_barrier<0>();
-        if (t + GST - 1 < T) issue(t + GST - 1);
-        const unsigned char* st = smem + (t % GST) * G_STAGE;
-        // The fragments of BOTH 16-wide k-steps of the tile are read from LDS up front (LDS returns in order: the MFMAs of step 0 wait
-        // for the first half only), so the reads of step 1 can run behind the MFMAs of step 0; PIPE adds a scheduling hint that pins
-        // "all reads, then all MFMAs".  Measured: no gain (57.4 ms for the DCN-v2 step without the hint, 59.1 with it): the k-loop is
-        // not bound by an un-overlapped LDS phase.
-        bf16x8_t ah[2][2], al[2][2], bh[2][NB], bl[2][NB];
+    auto read_frags = [&](const unsigned char* st, int ks, bf16x8_t (&fah)[2], bf16x8_t (&fal)[2], bf16x8_t (&fbh)[NB], bf16x8_t (&fbl)[NB]) {
+        const int c = 2 * ks + h;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int c = 2 * s + h;
+        for (int mb = 0; mb < 2; ++mb) {
+            const unsigned char* p = st + a_off[mb] + ((c ^ a_sw[mb]) << 4);
+            fah[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+            fal[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_A_ARR));
+        }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const unsigned char* p = st + a_off[mb] + ((c ^ a_sw[mb]) << 4);
-                ah[s][mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
-                al[s][mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_A_ARR));
-            }
+        for (int nb = 0; nb < NB; ++nb) {
+            const unsigned char* p = st + b_off[nb] + ((c ^ b_sw[nb]) << 4);
+            fbh[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+            fbl[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_B_ARR));
+        }
+    };
+    auto mfma_step = [&](const bf16x8_t (&fah)[2], const bf16x8_t (&fal)[2], const bf16x8_t (&fbh)[NB], const bf16x8_t (&fbl)[NB]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const unsigned char* p = st + b_off[nb] + ((c ^ b_sw[nb]) << 4);
-                bh[s][nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
-                bl[s][nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_B_ARR));
+                acc[mb][nb] = g_mfma(fal[mb], fbh[nb], acc[mb][nb]);  // small terms first
+                acc[mb][nb] = g_mfma(fah[mb], fbl[nb], acc[mb][nb]);
+                acc[mb][nb] = g_mfma(fah[mb], fbh[nb], acc[mb][nb]);
             }
+    };
+    if (PIPE && KS == 2 && GST == 2) {
+        // The barrier of a k-tile sits in the MIDDLE of the previous tile's MFMAs, and every batch of fragment reads is issued right
+        // behind the FIRST MFMA of the other batch: [MFMA, 12 LDS reads, 23 MFMAs] twice per tile.  The fragments of k-step 0 of tile
+        // t + 1 fly while k-step 1 of tile t runs, those of k-step 1 while k-step 0 runs; the wait the compiler puts in front of the
+        // first MFMA of a batch (lgkmcnt(0): it cannot count across the back edge) then only covers reads issued ~750 cycles
+        // earlier.  (The plain loop reads the whole tile right behind its barrier: eight wavefronts want 96 KB from LDS at once and
+        // the matrix pipe idles for the first of it -- halving the k-tile, i.e. doubling the number of such phases, cost 24 %.)
+        // No branch inside the body (the scheduler works on one block): the last iterations re-load tile t into the stage it just
+        // left and read fragments nobody uses.
+        bf16x8_t ah0[2], al0[2], bh0[NB], bl0[NB], ah1[2], al1[2], bh1[NB], bl1[NB];
+        g_wait_vm_and_barrier<0>();  // tile 0
+        if (1 < T) issue(1);
+        read_frags(smem, 0, ah0, al0, bh0, bl0);
+        for (int t = 0; t < T; ++t) {
+            const unsigned char* st = smem + (t % GST) * G_STAGE;
+            const unsigned char* sn = smem + ((t + 1) % GST) * G_STAGE;
+            read_frags(st, 1, ah1, al1, bh1, bl1);
+            mfma_step(ah0, al0, bh0, bl0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NB - 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // tile t + 1 has arrived and every wavefront has read all of tile t (its k-step-1 fragments are in registers: lgkmcnt 0)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue_at((t + 2 < T) ? t + 2 : t, t % GST);  // tile t + 2 (or, at the end, tile t again) into the stage tile t has just left
+            read_frags(sn, 0, ah0, al0, bh0, bl0);
+            mfma_step(ah1, al1, bh1, bl1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NB, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NB - 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy re-loads of the last iterations
+    } else {
+    for (int t = 0; t < T; ++t) {
+        // tile t is complete when at most the loads of tiles t + 1 .. t + GST - 2 are outstanding
+        if (a.ablate & 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");  // experiment: does not wait for the tile
+        else if (t + GST - 2 < T) g_wait_vm_and_barrier<(GST - 2) * G_DMA>();
+        else g_wait_vm_and_barrier<0>();
+        if (t + GST - 1 < T && !(a.ablate & 1)) issue(t + GST - 1);
+        const unsigned char* st = smem + (t % GST) * G_STAGE;
+        // The fragments of ALL 16-wide k-steps of the tile are read from LDS up front (LDS returns in order: the MFMAs of step 0 wait
+        // for the first half only), so the reads of step 1 can run behind the MFMAs of step 0.
+        bf16x8_t ah[KS][2], al[KS][2], bh[KS][NB], bl[KS][NB];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s) read_frags(st, s, ah[s], al[s], bh[s], bl[s]);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    acc[mb][nb] = g_mfma(al[s][mb], bh[s][nb], acc[mb][nb]);  // small terms first
-                    acc[mb][nb] = g_mfma(ah[s][mb], bl[s][nb], acc[mb][nb]);
-                    acc[mb][nb] = g_mfma(ah[s][mb], bh[s][nb], acc[mb][nb]);
-                }
-        if (PIPE) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (4 + 2 * NB), 0);  // every LDS read of the tile ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * 2 * NB * 3, 0);    // ... ahead of its MFMAs
-        }
+        for (int s = 0; s < KS; ++s) mfma_step(ah[s], al[s], bh[s], bl[s]);
+    }
     }
     // ---- epilogue: acc[mb][nb][i] = C[row0 + wm 64 + mb 32 + (i & 3) + 8 (i >> 2) + 4 h][n0 + wn 64 + nb 32 + l31] --------------------
     // The operands of an epilogue (x0 and x of the cross form, the addend of the dX form) are fetched for a whole 32 x 32 block before
@@ -285,36 +350,45 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int64_t mbase = row0 + wm * 64 + mb * 32 + 4 * h;
-            float e0[16], e1[16];
-            if (EPI == 1 || a.addend) {
+            // EB elements per batch: the cross form holds two operands per element beside the 128 accumulators -- 16 at a time spilled 61
+            // registers per lane (244 bytes of scratch in the resource report); 8 at a time fit
+            constexpr int EB = (EPI == 1) ? 8 : 16;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    int64_t m = mbase + (i & 3) + 8 * (i >> 2);
-                    if (m > a.M - 1) m = a.M - 1;
-                    if (EPI == 1) {
-                        e0[i] = a.x0[m * a.ld_e + nc];
-                        e1[i] = a.xres[m * a.ld_e + nc];
-                    } else {
-                        e0[i] = a.addend[m * a.ld_add + nc];
+            for (int i0 = 0; i0 < 16; i0 += EB) {
+                float e0[EB], e1[EB];
+                if (EPI == 1 || a.addend) {
+#pragma unroll
+                    for (int u = 0; u < EB; ++u) {
+                        const int i = i0 + u;
+                        int64_t m = mbase + (i & 3) + 8 * (i >> 2);
+                        if (m > a.M - 1) m = a.M - 1;
+                        if (EPI == 1) {
+                            e0[u] = a.x0[m * a.ld_e + nc];
+                            e1[u] = a.xres[m * a.ld_e + nc];
+                        } else {
+                            e0[u] = a.addend[m * a.ld_add + nc];
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t m = mbase + (i & 3) + 8 * (i >> 2);
-                float v = acc[mb][nb][i];
-                if (EPI == 1) {
-                    v += bias;
-                    if (a.p_out && n_ok && m < a.M) a.p_out[m * a.ld_e + n] = v;
-                    v = fmaf(e0[i], v, e1[i]);
-                } else if (EPI == 2) {
-                    v += bias;
-                    if (a.act == MH_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (a.act == MH_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-                } else if (a.addend) {
-                    v += e0[i];
+                for (int u = 0; u < EB; ++u) {
+                    const int i = i0 + u;
+                    const int64_t m = mbase + (i & 3) + 8 * (i >> 2);
+                    float v = acc[mb][nb][i];
+                    if (EPI == 1) {
+                        v += bias;
+                        if (a.p_out && n_ok && m < a.M) a.p_out[m * a.ld_e + n] = v;
+                        v = fmaf(e0[u], v, e1[u]);
+                    } else if (EPI == 2) {
+                        v += bias;
+                        if (a.act == MH_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (a.act == MH_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+                    } else if (a.addend) {
+                        v += e0[u];
+                    }
+                    if (n_ok && m < a.M) C[m * a.ldc + n] = v;
                 }
-                if (n_ok && m < a.M) C[m * a.ldc + n] = v;
+                __builtin_amdgcn_sched_barrier(0);  // the next batch's loads stay behind this batch's stores
             }
         }
     }
@@ -382,19 +456,29 @@ SplitBuf take_pair(char*& p, int64_t rows, int64_t ld) {
 }
 inline int64_t pair_bytes(int64_t rows, int64_t ld) { return 2 * al256(rows * ld * 2); }
 
+int gemm_geo();
+int gemm_pack() {  // MERLIN_HIP_GEMM_SPLIT_PACK = 1 (default) | 0: k-tile major operand images (GsArgs); the 16-wide k-tile forms are row-major
+    static int pack = -1;
+    if (pack < 0) {
+        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_PACK");
+        pack = (e ? atoi(e) : 1) && gemm_geo() < 3;
+    }
+    return pack;
+}
+
 void split_rows(const float* x, int64_t R, int C, int64_t ld, const SplitBuf& b, hipStream_t s) {
     const int64_t n = R * (b.ld / 8);
-    MH_LAUNCH(gs_split_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, s, x, R, C, ld, (int)b.ld, b.hi, b.lo);
+    MH_LAUNCH(gs_split_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, s, x, R, C, ld, (int)b.ld, b.hi, b.lo, gemm_pack());
 }
 void split_transpose(const float* x, int64_t R, int C, int64_t ld, const SplitBuf& b, hipStream_t s) {
     MH_LAUNCH(gs_split_transpose_kernel, dim3((unsigned)(b.ld / 64), (unsigned)mh_ceil_div(C, 64)), dim3(256), 0, s, x, R, C, ld, b.ld,
-              b.hi, b.lo);
+              b.hi, b.lo, gemm_pack());
 }
 
-template <int EPI, int BM, int BN, bool PIPE>
+template <int EPI, int BM, int BN, bool PIPE, int BK = 32, int ST = 0>
 int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
-    using G = Geo<BM, BN>;
-    auto kern = gemm_split_nt_kernel<EPI, BM, BN, PIPE>;
+    using G = Geo<BM, BN, BK, ST>;
+    auto kern = gemm_split_nt_kernel<EPI, BM, BN, PIPE, BK, ST>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
@@ -404,7 +488,7 @@ int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
         attr_done = true;
     }
     a.ntn = (int)mh_ceil_div(a.N, BN);
-    const int nkt = a.Kp / GBK;
+    const int nkt = a.Kp / BK;
     a.kt_per_split = (int)mh_ceil_div(nkt, splits);
     static int xmap = -1;  // MERLIN_HIP_GEMM_SPLIT_XCD = 0 | 1
     if (xmap < 0) {
@@ -412,6 +496,13 @@ int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
         xmap = e ? atoi(e) : 1;
     }
     a.xcd_map = xmap;
+    a.pack = gemm_pack();
+    static int ablate = -1;
+    if (ablate < 0) {
+        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_ABLATE");
+        ablate = e ? atoi(e) : 0;
+    }
+    a.ablate = ablate;
     int64_t nrt = mh_ceil_div(a.M, BM);
     if (xmap) nrt = mh_ceil_div(nrt, 8) * 8;  // whole groups of 8 row tiles (the surplus workgroups exit at once)
     const int64_t tiles = nrt * a.ntn;
@@ -425,7 +516,7 @@ int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 1
     if (geo < 0) {
         const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_GEO");
         // measured at 65536 x 3344 x 3344 (DCN-v2 step, same box): 256x256 56.9 ms, 256x128 59.5 ms, 128x128 79 ms
-        geo = !e ? 2 : (!strcmp(e, "128x128") ? 1 : (!strcmp(e, "256x128") ? 0 : 2));
+        geo = !e ? 2 : (!strcmp(e, "128x128") ? 1 : (!strcmp(e, "256x128") ? 0 : (!strcmp(e, "256x256k16") ? 3 : (!strcmp(e, "256x256k16s4") ? 4 : 2))));
     }
     return geo;
 }
@@ -433,12 +524,16 @@ int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 1
 template <int EPI>
 int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
     const int geo = gemm_geo();
-    static int pipe = -1;  // MERLIN_HIP_GEMM_SPLIT_PIPE = 0 | 1: the schedule hint of the k-loop (see the kernel)
+    static int pipe = -1;  // MERLIN_HIP_GEMM_SPLIT_PIPE = 1 | 0: the k-loop with the barrier in the middle of a tile's MFMAs (see the kernel)
     if (pipe < 0) {
         const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_PIPE");
-        pipe = e ? atoi(e) : 0;  // measured (DCN-v2 step, same box): 57.4 ms without the hint, 59.1 with it
+        pipe = e ? atoi(e) : 1;  // measured (DCN-v2 step, same box, row-major operands): 54.2-54.5 ms plain, 53.2-53.5 with the mid-tile barrier
     }
     if (geo == 1) return launch_gemm_geo<EPI, 128, 128, false>(a, splits, s);
+    // 16-wide k-tiles, 5 / 4 stages (three / two more tiles in flight): +24 % time, also with the mid-tile barrier -- twice the tile-load
+    // requests per byte (32-byte row pieces); kept selectable for that measurement only
+    if (geo == 3) return launch_gemm_geo<EPI, 256, 256, false, 16, 5>(a, splits, s);
+    if (geo == 4) return launch_gemm_geo<EPI, 256, 256, false, 16, 4>(a, splits, s);
     if (geo == 2) return pipe ? launch_gemm_geo<EPI, 256, 256, true>(a, splits, s) : launch_gemm_geo<EPI, 256, 256, false>(a, splits, s);
     return pipe ? launch_gemm_geo<EPI, 256, 128, true>(a, splits, s) : launch_gemm_geo<EPI, 256, 128, false>(a, splits, s);
 }
@@ -525,7 +620,7 @@ int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p
         a.M = d; a.N = d; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
         // few output tiles (378 of 256 x 128 at d = 3344, 196 of 256 x 256), a long contraction: split it so that the grid fills the 256 CUs
         // about three times over
-        const int64_t otiles = mh_ceil_div(d, 256) * mh_ceil_div(d, gemm_geo() == 2 ? 256 : 128);
+        const int64_t otiles = mh_ceil_div(d, 256) * mh_ceil_div(d, gemm_geo() >= 2 ? 256 : 128);
         int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
         if (splits > 8) splits = 8;
         if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);
@@ -630,7 +725,7 @@ int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W
         GsArgs a{};
         a.ah = sxt.hi; a.al = sxt.lo; a.bh = szt.hi; a.bl = szt.lo;
         a.M = K; a.N = N; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
-        const int64_t otiles = mh_ceil_div(K, 256) * mh_ceil_div(N, gemm_geo() == 2 ? 256 : 128);
+        const int64_t otiles = mh_ceil_div(K, 256) * mh_ceil_div(N, gemm_geo() >= 2 ? 256 : 128);
         int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
         if (splits > 8) splits = 8;
         if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);
