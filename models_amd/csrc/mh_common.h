@@ -66,6 +66,21 @@ static inline int64_t mh_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b
 int32_t mh_fill_words(void* dst, uint32_t value, int64_t words, hipStream_t s);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// hi = bf16(v), lo = bf16(v - hi) for a PAIR of values, packed (first value in the low half): the 3-term split of the opt-in
+// bf16x3 arithmetic.  gfx950 converts two floats to two round-to-nearest-even bf16 in one instruction (v_cvt_pk_bf16_f32): five
+// instructions per pair where the bit-twiddling form (add 0x7fff + lsb, shift, class test) needs ~30 -- the epilogue of the split
+// scorer was vector-ALU bound on it.  Same results for finite values.
+#if defined(__HIPCC__)
+typedef __bf16 mh_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float mh_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mh_split_pair(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+    const mh_f32x2_t v = {v0, v1};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mh_bf16x2_t));
+    const mh_f32x2_t hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, mh_bf16x2_t));
+}
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Number of workgroups that fill the chip a few times over for grid-stride kernels.

@@ -100,10 +100,7 @@ __global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restr
     uint32_t wh[4], wl[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float v0 = v8[2 * k], v1 = v8[2 * k + 1];
-        const uint16_t h0 = g_bf16(v0), h1 = g_bf16(v1);
-        wh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        wl[k] = (uint32_t)g_bf16(v0 - g_f32(h0)) | ((uint32_t)g_bf16(v1 - g_f32(h1)) << 16);
+        mh_split_pair(v8[2 * k], v8[2 * k + 1], wh[k], wl[k]);
     }
     *reinterpret_cast<uint4*>(hi + dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
     *reinterpret_cast<uint4*>(lo + dst) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
@@ -119,9 +116,10 @@ __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __
         const int r = i >> 6, c = i & 63;
         float v = 0.f;
         if (r0 + r < R && c0 + c < C) v = x[(r0 + r) * ld + c0 + c];
-        const uint16_t h = g_bf16(v);
-        sh[r][c] = h;
-        sl[r][c] = g_bf16(v - g_f32(h));
+        uint32_t wh2, wl2;
+        mh_split_pair(v, 0.f, wh2, wl2);
+        sh[r][c] = (uint16_t)wh2;
+        sl[r][c] = (uint16_t)wl2;
     }
     __syncthreads();
     // thread (c, seg): rows seg * 16 .. + 15 of column c -> 32 contiguous bytes of row c0 + c of the transposed arrays

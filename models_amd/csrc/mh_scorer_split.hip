@@ -70,9 +70,14 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
         if (row < N) v = *reinterpret_cast<const f32x4*>(x + row * PE + c4 * 4);
         uint16_t h[4], l[4];
 #pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+            uint32_t wh2, wl2;
+            mh_split_pair(v[k], v[k + 1], wh2, wl2);
+            h[k] = (uint16_t)wh2; h[k + 1] = (uint16_t)(wh2 >> 16);
+            l[k] = (uint16_t)wl2; l[k + 1] = (uint16_t)(wl2 >> 16);
+        }
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
-            h[k] = p_bf16(v[k]);
-            l[k] = p_bf16(v[k] - p_f32(h[k]));
             sh[r][c4 * 4 + k] = h[k];
             sl[r][c4 * 4 + k] = l[k];
         }
@@ -122,7 +127,11 @@ __device__ __forceinline__ void p_dma4(const void* g, void* lds) {
 __device__ __forceinline__ f32x16 p_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 // XT = 32-row blocks of X per wavefront: 2 -> 4 wavefronts per workgroup, one per SIMD with 512 registers; 1 -> 8 wavefronts, two
-// per SIMD with 256 registers each (the epilogue of one hides behind the MFMAs of the other; twice the LDS reads per MFMA)
+// per SIMD with 256 registers each (the epilogue of one hides behind the MFMAs of the other; twice the LDS reads per MFMA).
+// Measured and NOT kept: the two units of a tile as one software-pipelined block (G1(0) | G1(1) + E(0) | G2(0) + E(1) | G2(1)) in
+// the gradient mode: 5.49-5.51 ms against 5.48-5.54 for this loop -- with two wavefronts per SIMD the overlap is already there.
+// What did move the kernel: the probabilities are split into bf16 hi / lo by mh_split_pair (v_cvt_pk_bf16_f32: 5 instructions per
+// pair instead of ~30 of bit arithmetic): forward + dq 6.8 -> 5.6 ms, gradient pass 6.7 -> 5.5 ms at 65 536 x 65 536 x 128.
 template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT>
 __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitArgs a) {
     constexpr int IDW = sizeof(IdT) / 4;
@@ -298,10 +307,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                     uint32_t wh[4], wl[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float p0 = acc[tn][8 * s + 2 * k], p1 = acc[tn][8 * s + 2 * k + 1];
-                        const uint16_t h0 = p_bf16(p0), h1 = p_bf16(p1);
-                        wh[k] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                        wl[k] = (uint32_t)p_bf16(p0 - p_f32(h0)) | ((uint32_t)p_bf16(p1 - p_f32(h1)) << 16);
+                        mh_split_pair(acc[tn][8 * s + 2 * k], acc[tn][8 * s + 2 * k + 1], wh[k], wl[k]);
                     }
                     ph[tn][s] = __builtin_bit_cast(bf16x8_t, make_uint4(wh[0], wh[1], wh[2], wh[3]));
                     pl[tn][s] = __builtin_bit_cast(bf16x8_t, make_uint4(wl[0], wl[1], wl[2], wl[3]));
@@ -440,6 +446,7 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
     int tps = 1;
     const int nsplit = mh_split_plan(Nx, Ny, &tps);
     a.tiles_per_split = tps;
+
     dim3 grid((unsigned)mh_ceil_div(Nx, PXB), (unsigned)nsplit);
     // MERLIN_HIP_SCORER_XT = 1 | 2 (experiments): 32-row blocks of X per wavefront (see the kernel)
     static int xt = -1;
