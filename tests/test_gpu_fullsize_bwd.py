@@ -137,6 +137,8 @@ def test_c3_scorer_backward_full_batch(device, case):
 def test_c5_linear_backward_wide(device, K, N, act, x_act):
     """dX = dz W^T (NT) and dW = x^T dz (split-M TN), db = colsum(dz) at the DCN-v2 widths, M = 4 096."""
     M = 4096
+    if ops._linear_split_ok(M, K, N):
+        pytest.skip("pins the fp32 GEMMs bit for bit; the bf16x3 Dense layer has its own test (test_gpu_gemm_split.py)")
     g = torch.Generator().manual_seed(K + N)
     x = torch.randn(M, K, generator=g)
     if x_act == "relu":

@@ -1,0 +1,37 @@
+#!/bin/bash
+# One gpurun call that regenerates the round-5 evidence under profiles/ for the current kernels (outputs under gpurun_out/refresh5/):
+#   gpurun --timeout 2700 -- 'bash tools/refresh_profiles_r5.sh'
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+F='amdgpu.ids\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl'
+O=gpurun_out/refresh5; rm -rf $O; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+MERLIN_HIP_SCORER_ARITH=bf16x3 MERLIN_HIP_GEMM_ARITH=bf16x3 timeout 1200 python -m pytest tests -m gpu -q \
+  --deselect tests/test_gpu_bench_world2.py > $O/pytest_gpu_bf16x3.log 2>&1; tail -2 $O/pytest_gpu_bf16x3.log
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# HBM traffic of the HBM-bound launches FIRST, and into profiles/ on this box: the bench lines below then carry roofline.traffic
+# measured with exactly the kernels they time (bench.py refuses a file stamped with other kernel sources)
+timeout 600 python tools/pmc_traffic.py > $O/pmc_traffic.txt 2>&1; cp gpurun_out/pmc_traffic.json $O/ 2>/dev/null && cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json; rm -rf gpurun_out/pmc_traffic
+{
+timeout 600 python bench.py
+timeout 200 python bench.py --mode fwd --no-cpu-baseline --no-secondary --sustain 1
+timeout 200 python bench.py --ids lognormal --no-cpu-baseline --no-secondary --sustain 1
+MH_FORCE_DISTRIBUTED=1 timeout 200 python bench.py --steps 50 --warmup 8 --no-cpu-baseline --no-secondary --sustain 1
+timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 50 --warmup 8 --no-cpu-baseline --no-secondary --sustain 1
+} 2>$O/bench_err.log | grep "^{" > $O/bench_lines.jsonl; echo "bench lines: $(wc -l < $O/bench_lines.jsonl) (expect 5)"
+# the one driver command at N = 2 on the shared-GPU transport (two ranks on this one GPU): secondaries of the multi-GPU line
+MH_BENCH_SHARED_GPU=1 MASTER_ADDR=127.0.0.1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 \
+  --master-port 29544 tests/bench_world2_harness.py --gpus 2 --steps 4 --warmup 2 --batch 2048 --sustain 0 --no-cpu-baseline \
+  --shard-threshold 100000 --c4-rows 1000001 --tt-batches 2048,4096 2>$O/world2_err.log | grep "^{" > $O/bench_world2_shared_gpu.jsonl
+echo "world-2 lines: $(wc -l < $O/bench_world2_shared_gpu.jsonl) (expect 1)"
+# kernel stats of the bench step (eager launches WITH side streams: durations include overlap) and of the secondary workloads
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python bench.py --no-cpu-baseline --no-secondary --sustain 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/topk -o k -- python tools/dbg/run_secondary.py topk > /dev/null 2>&1
+MERLIN_HIP_SCORER_ARITH=bf16x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/twotower_bf16x3 -o w -- python tools/dbg/run_secondary.py twotower batch=65536 > /dev/null 2>&1
+MERLIN_HIP_GEMM_ARITH=bf16x3 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcn_bf16x3 -o d -- python tools/dbg/run_secondary.py dcn_train > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcn -o d -- python tools/dbg/run_secondary.py dcn_train > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bag -o b -- python tools/dbg/bag_bwd_probe.py 4 > /dev/null 2>&1
+for w in train topk twotower_bf16x3 dcn_bf16x3 dcn bag; do cp $(find $O/$w -name '*kernel_stats.csv' | head -1) $O/bench_${w}_kernel_stats.csv; rm -rf $O/$w; done
+# isolated, SINGLE-STREAM kernel trace of the dominant launch
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/embada -o t -- python tools/microbench.py embada > $O/embada.log 2>&1
+cp $(find $O/embada -name '*kernel_stats.csv' | head -1) $O/embada_kernel_stats.csv; rm -rf $O/embada
+ls -la $O
