@@ -13,6 +13,7 @@ from typing import List, Optional, Sequence, Union
 
 import numpy as np
 import torch
+from contextlib import nullcontext as _nullcontext
 
 from . import ops
 from .core import Block, ConcatFeatures, ParallelBlock, Parameter, SequentialBlock, TabularData
@@ -530,10 +531,16 @@ class DLRMBlock(Block):
             ld = (width + 3) // 4 * 4
             # persistent per block: the alignment column behind `width` is zeroed ONCE (no kernel writes it), not by a fill launch
             # in every step
-            buf = getattr(self, "_top_buf", None)
+            slot_name = "_top_buf"
+            if getattr(self, "pipeline_dw", None) is not None and _TAPE[0] > 0:
+                # pipelined steps: the first top layer's dW GEMM of step t reads step t's top_in while step t + 1 writes its own
+                self._top_flip = not getattr(self, "_top_flip", False)
+                slot_name = "_top_buf_b" if self._top_flip else "_top_buf"
+            buf = getattr(self, slot_name, None)
             if buf is None or buf.shape != (B, ld) or buf.device != dev:
                 ops.park_replaced(buf)  # a captured step may still address the old one
-                buf = self._top_buf = torch.zeros((B, ld), dtype=torch.float32, device=dev)
+                buf = torch.zeros((B, ld), dtype=torch.float32, device=dev)
+                setattr(self, slot_name, buf)
             ops.note_captured(buf)
             top_in = buf[:, :width]
             ops.dlrm_interaction_fused(slot_tables, slot_ids, dense, append_dense=True, out=top_in)
@@ -543,7 +550,9 @@ class DLRMBlock(Block):
                 # rather than competing with the gather for memory
                 self.embeddings.prepare_sparse(inputs, self.cat_names)
             self._top_in = top_in
+            self.finish_deferred()  # the first top layer's weights of the previous step's update (pipelined steps)
             return self._top(top_in, head)
+        self.flush_deferred()
         stacked = torch.empty((B, F, D), dtype=torch.float32, device=dev)
         tail = None
         if self.bottom_block is not None:
@@ -572,6 +581,53 @@ class DLRMBlock(Block):
         tl = _dense_layers(blk) if blk is not None else None
         return tl[-1].activation if tl else None
 
+    # ---- pipelined steps: the first top layer's dW GEMM + dense update one step later (see backward) -------------------------
+    def _can_defer(self, tl, head) -> bool:
+        opt = getattr(self, "pipeline_dw", None)
+        if opt is None or head is None or not tl or not getattr(self, "_fused", False) or self.bottom_block is None:
+            return False
+        if getattr(self, "_deferred", None) is not None:  # the previous one was never launched (no forward in between): not twice
+            return False
+        lay = tl[0]
+        if getattr(lay, "kernel_regularizer", None) is not None or getattr(lay, "bias_regularizer", None) is not None:
+            return False
+        return ops.SIDE.active("dw") and ops.SIDE.recorder is None and not ops.SIDE.crec and not torch.cuda.is_current_stream_capturing()
+
+    def launch_deferred(self) -> None:
+        """Start of a pipelined step: last step's dW / db of the first top layer and that layer's dense update, on the side stream."""
+        rec = getattr(self, "_deferred", None)
+        if rec is None or rec.get("launched"):
+            return
+        opt, lay = rec["opt"], rec["layer"]
+        side = ops.SIDE.active("dw") and ops.SIDE.recorder is None and not torch.cuda.is_current_stream_capturing()
+        ctx = ops.SIDE.on("dw", keep=rec["keep"] + (rec["dW"],) + (() if rec["db"] is None else (rec["db"],))) if side else _nullcontext()
+        with ctx:
+            for fn in rec["fns"]:
+                fn()
+            lay.kernel.grad = rec["dW"]
+            params = [lay.kernel]
+            if lay.bias is not None:
+                lay.bias.grad = rec["db"]
+                params.append(lay.bias)
+            ops.dense_optimizer_step_multi(opt, params)
+            for p_ in params:
+                p_.grad = None
+        rec["launched"], rec["side"] = True, side
+
+    def finish_deferred(self) -> None:
+        """The launch stream waits for the pipelined update (before anything reads the first top layer's weights)."""
+        rec = getattr(self, "_deferred", None)
+        if rec is None:
+            return
+        if not rec.get("launched"):
+            self.launch_deferred()
+        if rec.get("side"):
+            ops.SIDE.join_stream("dw")
+        self._deferred = None
+
+    def flush_deferred(self) -> None:
+        self.finish_deferred()
+
     def backward(self, grad, pre_masked: bool = False):
         D = self.dim
         head = getattr(self, "_head", None)
@@ -586,11 +642,28 @@ class DLRMBlock(Block):
             # apply: MFMA work beside memory work.  OPT-IN (MERLIN_HIP_DW_LATE=1): measured neutral in the eager step (0.952 vs 0.955 ms) and worse under the segmented replay (1.107 vs 0.978 ms) -- beside the persistent, HBM-saturating apply kernel the GEMM takes 250 us instead of 84 and the apply 275-300 instead of 186: the two serialise whichever way they are queued (profiles/r5_notes.md).
             import os as _os
 
+            defer = self._can_defer(tl, head)
             late = [] if (getattr(self, "_fused", False) and self.bottom_block is not None
-                          and _os.environ.get("MERLIN_HIP_DW_LATE", "0") == "1") else None
+                          and (defer or _os.environ.get("MERLIN_HIP_DW_LATE", "0") == "1")) else None
             if head is not None and tl:  # grad is the head's dz (the loss gradient w.r.t. its pre-activation)
                 grad = mlp_backward(tl + [head], grad, True, pre_masked=True, zero_pad=False, late_dw_first=late)
                 late_dw = late
+                if defer and late:
+                    # PIPELINED STEPS (Model.pipelined_updates): dW / db of the first top layer (K = P + D = 415 at C2: the one large dW
+                    # GEMM of the step, 84 us alone, 260-280 us beside the interaction backward, which it slows from 190 to 230 us and
+                    # behind which the sparse apply then queues) are computed at the START of the next step, on the side stream beside
+                    # the HBM-bound gather -> interaction kernel, followed by this layer's dense update; the launch stream waits for
+                    # both right before the layer's forward.  Same kernels, same operands, same update, one step later in wall time:
+                    # weights after a flush are bit-identical to un-pipelined steps (tests/test_gpu_models.py).  Opt-in
+                    # (MERLIN_HIP_DW_DEFER=1): the interaction backward does drop to 183 us and the apply starts the moment its input
+                    # exists, but the forward pays more than that (Model.pipelined_updates).
+                    lay = tl[0]
+                    self._deferred = {"fns": late, "layer": lay, "dW": lay.kernel.grad, "db": None if lay.bias is None else lay.bias.grad,
+                                      "keep": (lay._x, grad), "opt": self.pipeline_dw}
+                    lay.kernel.grad = None
+                    if lay.bias is not None:
+                        lay.bias.grad = None
+                    late_dw = None
             else:
                 if head is not None:
                     grad = head.backward(grad, pre_masked=True)

@@ -7,6 +7,7 @@
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, Iterable, List, Optional, Sequence, Union
 
@@ -78,6 +79,53 @@ class Model(Block):
     def train_step(self, inputs: TabularData, targets: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError
 
+    # --- pipelined steps: work of step t that nothing in step t waits for runs at the start of step t + 1 ----------------------------
+    def _pipeline_blocks(self):
+        return [b for b in optim._walk(self) if hasattr(b, "launch_deferred") and not isinstance(b, Model)]
+
+    def pipelined_updates(self):
+        """``with model.pipelined_updates():`` -- eager train steps inside run software-pipelined: the dW GEMM of the DLRM block's
+        first top-MLP layer and that layer's dense update are launched at the START of the next step, on the side stream beside the
+        HBM-bound gather -> interaction kernel, instead of beside the interaction backward (blocks.DLRMBlock.backward).  Exact: the
+        same kernels on the same operands and the same update, applied before the layer's next forward; at exit (and before
+        ``evaluate`` / ``predict`` / ``save_weights``) everything outstanding is flushed, the weights are then bit-identical to
+        un-pipelined steps.  Only with SGD / Adagrad at a constant learning rate on one rank (a schedule, Adam's step counter or a
+        dense all-reduce would have to travel with the deferred update); otherwise the context changes nothing.
+        OPT-IN (``MERLIN_HIP_DW_DEFER=1``; ``fit`` enters the context for its eager steps): measured SLOWER on MI355X -- beside
+        the deferred GEMM (84 us alone, 219 us there) the gather -> interaction kernel takes 197 us instead of 98: the two do not
+        overlap, they share the CUs (1.028 vs 0.963 ms per step, profiles/r5_step_timeline_pipelined.txt)."""
+        model = self
+
+        class _Ctx:
+            def __enter__(self_):
+                opt = model.optimizer
+                ok = (opt is not None and opt.name in ("sgd", "adagrad") and getattr(opt, "lr_device", None) is None
+                      and getattr(model, "loss_grad_divisor", 1) == 1 and os.environ.get("MERLIN_HIP_DW_DEFER", "0") == "1")
+                self_.blocks = model._pipeline_blocks() if ok else []
+                for b in self_.blocks:
+                    b.pipeline_dw = opt
+                model._pipelined = bool(self_.blocks)
+                return model
+
+            def __exit__(self_, *exc):
+                model.flush_deferred()
+                for b in self_.blocks:
+                    b.pipeline_dw = None
+                model._pipelined = False
+                return False
+
+        return _Ctx()
+
+    def launch_deferred(self) -> None:
+        if getattr(self, "_pipelined", False):
+            for b in self._pipeline_blocks():
+                b.launch_deferred()
+
+    def flush_deferred(self) -> None:
+        """Everything a pipelined step left for the next one, now (no-op otherwise)."""
+        for b in self._pipeline_blocks():
+            b.flush_deferred()
+
     @staticmethod
     def _split(batch):
         """A batch is ``inputs`` or ``(inputs, targets)`` (what ``models_amd.Loader`` yields)."""
@@ -88,6 +136,7 @@ class Model(Block):
     def predict(self, batches) -> np.ndarray:
         """Minimal ``Model.predict`` (models/base.py): forward over the batches, outputs concatenated on the host."""
         outs = []
+        self.flush_deferred()
         for batch in batches:
             x, _ = self._split(batch)
             y = self(x)
@@ -105,6 +154,7 @@ class Model(Block):
         Parameters stored elsewhere (the row shards of a distributed model, written per rank)."""
         arrays: Dict[str, np.ndarray] = {}
         names = []
+        self.flush_deferred()
         for i, p in enumerate(self.parameters()):
             names.append(p.name)
             if id(p) in skip:
@@ -124,6 +174,7 @@ class Model(Block):
         existing tensors (parameters, optimizer state, the on-device Adam step) wherever they exist, so a captured
         hipGraph keeps updating the restored buffers."""
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        self.flush_deferred()
         params = self.parameters()
         names = [str(n) for n in z["__names__"]]
         if len(names) != len(params):
@@ -255,6 +306,16 @@ class Model(Block):
             ok = all(isinstance(v, torch.Tensor) and v.is_cuda for v in x.values())
             return ok and (y is None or isinstance(y, torch.Tensor)) and self.graph_capturable
 
+        pipe = self.pipelined_updates()  # eager steps run software-pipelined (flushed before a replay and at the end)
+        pipe.__enter__()
+        try:
+            return self._fit_loop(batches, epochs, steps_per_epoch, graph, Step, history, probe, probe_tick, pack, eager, can_graph,
+                                  lambda: prefer_eager)
+        finally:
+            pipe.__exit__(None, None, None)
+
+    def _fit_loop(self, batches, epochs, steps_per_epoch, graph, Step, history, probe, probe_tick, pack, eager, can_graph, prefer_eager_fn):
+        graphed, sig = None, None
         for _ in range(epochs):
             t0, n, steps, last = None, 0, 0, None
             for step, batch in enumerate(batches):
@@ -268,11 +329,13 @@ class Model(Block):
                     if graphed is None and (graph or step >= 1):  # step 0 runs eagerly: builds lazily-shaped layers
                         # warmup=0: step 0 already ran eagerly (layers built, kernels' LDS attributes set); a warm-up
                         # replay here would TRAIN on this batch several times
+                        self.flush_deferred()
                         graphed, sig = Step(eager, d, warmup=0), this_sig
                     if graphed is not None and this_sig == sig:
-                        if prefer_eager or probe["mode"] == "eager":
+                        if prefer_eager_fn() or probe["mode"] == "eager":
                             last = eager(d)
                         else:
+                            self.flush_deferred()  # what a pipelined eager step left behind
                             last = graphed.replay(d)  # the batch's columns go into the static inputs in ONE launch
                         probe_tick(probe["mode"])
                     else:
@@ -316,6 +379,7 @@ class RankingModel(Model):
             self.compile()
         x = prepare_features(inputs)
         fused_head = bool(getattr(self.body, "accepts_head", False))
+        self.launch_deferred()  # pipelined steps: the previous step's deferred dW + update start beside this forward
         with blocks_tape():
             p = self._predict(x)
         self.optimizer.ensure_begun(p.device)

@@ -868,3 +868,63 @@ def test_dlrm_loads_reference_layout_weights(device, D):
     # and the opposite row order must NOT match (the test can tell the two layouts apart)
     top0.kernel.data.copy_(torch.from_numpy(np.concatenate([K_inter, K_bottom], axis=0)).to(device))
     assert np.abs(model(xd).cpu().numpy() - ref).max() > 1e-3
+
+
+@pytest.mark.parametrize("optimizer", ["adagrad", "sgd", "adam"])
+def test_pipelined_train_steps_equal_plain_steps_bit_for_bit(device, optimizer, monkeypatch):
+    """Model.pipelined_updates(): the first top-MLP layer's dW GEMM and dense update of step t run at the start of step t + 1
+    (blocks.DLRMBlock.backward).  Deterministic sparse update on both sides: after the flush every parameter and every optimizer
+    state tensor equals the un-pipelined run BIT FOR BIT; an evaluate in the middle sees flushed weights; with Adam (step counter)
+    the context changes nothing."""
+    monkeypatch.setenv("MERLIN_HIP_DETERMINISTIC", "1")
+    monkeypatch.setenv("MERLIN_HIP_DW_DEFER", "1")  # opt-in (measured slower on MI355X: Model.pipelined_updates)
+    # 12 + 1 stacked features of width 64: the first top layer reads 78 + 64 = 142 columns -- too wide for the fused MLP chain, so it
+    # is a layer of its own with its own dW GEMM (as the 415 -> 128 layer of configs[1] is)
+    cards = {f"C{j}": v for j, v in enumerate([5000, 7, 300, 50, 1000, 3, 64, 900, 12, 4000, 33, 256], 1)}
+    cols = [S.categorical(n, v) for n, v in cards.items()] + [S.continuous(f"I{i}") for i in range(1, 4)]
+    cols.append(S.binary_target("label"))
+    schema = mm.Schema(cols)
+
+    def build():
+        m = mm.DLRMModel(schema, embedding_dim=64, bottom_block=mm.MLPBlock([32, 64], device=device, seed=7),
+                         top_block=mm.MLPBlock([64, 16], device=device, seed=17), device=device)
+        m.output.to_call.seed = 99
+        m.compile(optimizer=optimizer, learning_rate=0.05)
+        return m
+
+    g = torch.Generator().manual_seed(21)
+    batches = []
+    for _ in range(6):
+        x, xd = _batch(schema, 256, g, device)
+        batches.append((xd, torch.randint(0, 2, (256, 1), generator=g).float().to(device)))
+    a, b = build(), build()
+    a(batches[0][0]), b(batches[0][0])
+    for pb, pa in zip(b.parameters(), a.parameters()):
+        pb.data.copy_(pa.data)
+    dlrm = [blk for blk in b._pipeline_blocks()]
+    assert len(dlrm) == 1
+    deferred_seen = 0
+    losses_a, losses_b = [], []
+    with b.pipelined_updates():
+        for i, (xd, y) in enumerate(batches):
+            losses_a.append(float(a.train_step(xd, y)))
+            losses_b.append(float(b.train_step(xd, y)))
+            deferred_seen += getattr(dlrm[0], "_deferred", None) is not None
+            if i == 2:  # a forward outside a train step flushes first
+                ea, eb = a.evaluate([(xd, y)]), b.evaluate([(xd, y)])
+                assert ea == eb
+                assert getattr(dlrm[0], "_deferred", None) is None
+    assert getattr(dlrm[0], "_deferred", None) is None and getattr(dlrm[0], "pipeline_dw", None) is None
+    assert deferred_seen == (0 if optimizer == "adam" else len(batches))
+    assert losses_a == losses_b
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa.data, pb.data), pa.name
+        for k in pa.state:
+            assert torch.equal(pa.state[k], pb.state[k]), (pa.name, k)
+    # fit() pipelines its eager steps and leaves nothing behind
+    h = b.fit(batches, epochs=1, graph=False)
+    monkeypatch.setenv("MERLIN_HIP_DW_DEFER", "0")  # the plain loop for the twin
+    a_h = a.fit(batches, epochs=1, graph=False)
+    assert h["loss"] == a_h["loss"] and getattr(dlrm[0], "_deferred", None) is None
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa.data, pb.data), pa.name
