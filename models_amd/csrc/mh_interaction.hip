@@ -946,6 +946,17 @@ static int32_t fill_fused_args(FusedArgs* a, const float* const* slot_tables, co
 // one resident set of workgroups (every wavefront walks one contiguous run of samples): CUs x what LDS and a <= 128 VGPR
 // budget allow
 static dim3 fused_grid(int64_t B, size_t lds, int max_occ = 4) {
+    // LDS is handed out in granules of 1280 bytes (160 KB / 128; measured: a request of 53 952 bytes -- 27 tables + the dense slot at
+    // D = 64 -- is resident TWICE per CU, not the three times 163 840 / 53 952 promises and the occupancy query reports; a grid sized for
+    // three then ran 1.5 rounds: the 278 us of `dlrm_fused_bwd` at F = 28 against 219 us with this rounding, profiles/r5_notes.md).
+    // MERLIN_HIP_FUSED_LDS_GRANULE overrides (1 = the old arithmetic).
+    static int lds_gran = -1;
+    if (lds_gran < 0) {
+        const char* e = getenv("MERLIN_HIP_FUSED_LDS_GRANULE");
+        lds_gran = e ? atoi(e) : 1280;
+        if (lds_gran < 1) lds_gran = 1;
+    }
+    lds = (lds + lds_gran - 1) / lds_gran * lds_gran;
     int occ = (int)((160 * 1024) / lds);
     if (occ > max_occ) occ = max_occ;
     if (occ < 1) occ = 1;
