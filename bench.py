@@ -11,7 +11,10 @@ path over one synthetic batch that is already resident in HBM; the timed loop RO
 distinct pre-generated batches (copied into the static inputs of the captured hipGraph, two device copies per
 step), so no step re-trains the ids of the previous one.
 
-Rank 0 prints ONE JSON line (contract in the task statement).  Beyond the contract keys:
+Rank 0's LAST stdout line is the contract's JSON line: <= 4 KB, strict JSON (`headline()`): contract keys + `roofline` +
+`cpu_baseline` + `twotower_b64k` (the metric names both models).  Before it come one compact `{"secondary": name, ...}` line per
+secondary configuration and `{"detail": key, ...}` lines with the long forms; the whole object is also written to
+gpurun_out/bench_full_n<N>.json.  `reassemble(stdout)` puts them back together.  The objects:
   roofline          the op that takes the most time of the step (HBM-bound embedding backward in train mode):
                     algorithmic bytes of exactly the timed launches / their hipEvent time
   roofline_gather   the multi-table gather (the kernel north_star names)
@@ -224,6 +227,139 @@ def graph_or_eager(eager, packed0, want_graph):
     if not want_graph:
         return None
     return GraphedStep(eager, packed0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# output: secondaries first (one compact line each), the full object to a file, the <= 4 KB headline LAST
+# ------------------------------------------------------------------------------------------------------------
+HEADLINE_MAX_BYTES = 4000   # round-5 review: the 21.6 KB single object was not parsed by the driver (BENCH_r05.parsed = null)
+
+
+def finite(o):
+    """strict JSON: NaN / +-inf -> null, numpy scalars -> python, 7 significant digits"""
+    if isinstance(o, dict):
+        return {str(k): finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [finite(v) for v in o]
+    if isinstance(o, (bool, type(None), str, int)):
+        return o
+    if isinstance(o, (float, np.floating)):
+        f = float(o)
+        return float(f"{f:.7g}") if math.isfinite(f) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.ndarray):
+        return finite(o.tolist())
+    return str(o)
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def headline(out):
+    """The line the driver parses: contract keys + roofline + cpu_baseline + the TwoTower-64K half of BASELINE.json's metric,
+    everything else lives on the secondary lines / in the full-object file.  Never more than HEADLINE_MAX_BYTES."""
+    pick = lambda d, keys: {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+    h = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    h["vs_baseline"] = out.get("vs_baseline")
+    h.update(pick(out, ("dtype", "data")))
+    h["data"] = _clip(h.get("data"), 140)
+    cfg = out.get("config") or {}
+    h["config"] = pick(cfg, ("workload", "global_batch", "per_gpu_batch", "mode", "optimizer", "launch", "parallelism"))
+    h["config"]["workload"] = _clip(h["config"].get("workload"), 200)
+    rl = out.get("roofline")
+    if isinstance(rl, dict):
+        r = pick(rl, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"))
+        r["kernel"] = _clip(r.get("kernel"), 120)
+        r.setdefault("traffic", None)
+        whole = rl.get("whole_update")
+        if isinstance(whole, dict):
+            r["whole_update_frac"] = whole.get("frac")
+            r["whole_update_ms"] = whole.get("avg_launch_ms")
+        r["bytes"] = "dedup-aware"
+        h["roofline"] = r
+    else:
+        h["roofline"] = None
+    cb = out.get("cpu_baseline")
+    h["cpu_baseline"] = None if not isinstance(cb, dict) else dict(pick(cb, ("value", "unit", "cores", "kind")), sample=_clip(cb.get("sample"), 160))
+    sec = out.get("secondary") or {}
+    for key, name in (("twotower_b64k", "twotower_train_b64k"), ("twotower_b32k", "twotower_train")):
+        e = sec.get(name)
+        if isinstance(e, dict) and "value" in e:
+            h[key] = dict(pick(e, ("value", "ms_per_step", "n_gpus")), dtype=e.get("dtype", "f32"), unit="samples/s")
+    if out.get("max_abs_err_vs_oracle") is not None:
+        h["max_abs_err_vs_oracle"] = out["max_abs_err_vs_oracle"]
+    if isinstance(out.get("sustained"), dict):
+        h["sustained"] = pick(out["sustained"], ("value", "ms_per_step", "seconds"))
+    ex = out.get("exchange")
+    if isinstance(ex, dict):
+        h["exchange"] = {"communicator": _clip(str(ex.get("communicator")), 120),
+                         "groups": [pick(g, ("dedup", "window_slots", "local_rows")) for g in (ex.get("groups") or [])][:4]}
+        h["exchange"].update(pick(ex, ("dense_bucket_bytes", "error")))
+    if out.get("secondary_aborted"):
+        h["secondary_aborted"] = _clip(out["secondary_aborted"], 120)
+    errs = sorted(k for k, v in sec.items() if isinstance(v, dict) and "error" in v)
+    h["secondary_lines"] = {"printed_before_this_line": len(sec), "errors": errs[:12]}
+    if out.get("full_object"):
+        h["full_object"] = out["full_object"]
+    h = finite(h)
+    for drop in ("full_object", "exchange", "sustained", "twotower_b32k", "secondary_lines"):  # never reached at today's sizes: a backstop
+        if len(json.dumps(h, allow_nan=False, separators=(",", ":"))) <= HEADLINE_MAX_BYTES:
+            break
+        h.pop(drop, None)
+    return h
+
+
+def emit(out, stream=None):
+    """Rank 0's whole output.  stdout: `{"secondary": name, ...}` lines (one per secondary configuration, compact, strict JSON),
+    `{"detail": ...}` lines of the headline's long-form objects, then the headline as the LAST line.  The full object also goes to
+    gpurun_out/bench_full_n<N>.json (best effort)."""
+    stream = stream or sys.stdout
+    dump = lambda o: json.dumps(finite(o), allow_nan=False, separators=(",", ":"))
+    out = dict(out)
+    try:
+        d = ROOT / "gpurun_out"
+        d.mkdir(exist_ok=True)
+        path = d / f"bench_full_n{out.get('n_gpus', 1)}.json"
+        path.write_text(json.dumps(finite(out), allow_nan=False, indent=1))
+        out["full_object"] = str(path.relative_to(ROOT))
+    except Exception:  # noqa: BLE001 -- a read-only tree must not cost the line
+        pass
+    for name, v in (out.get("secondary") or {}).items():
+        print(dump(dict({"secondary": name}, **(v if isinstance(v, dict) else {"value": v}))), file=stream, flush=True)
+    detail_keys = ("roofline", "roofline_gather", "roofline_fused_fwd", "roofline_fused_bwd", "mfma", "kernels_ms", "step_ms", "sharded",
+                   "parity_notes", "exchange", "negatives", "accuracy_vs_f32_kernels")
+    for k in detail_keys:
+        if out.get(k) is not None:
+            print(dump({"detail": k, k: out[k], "launch_probe": (out.get("config") or {}).get("launch_probe")} if k == "roofline"
+                       else {"detail": k, k: out[k]}), file=stream, flush=True)
+    line = json.dumps(headline(out), allow_nan=False, separators=(",", ":"))
+    assert len(line) <= HEADLINE_MAX_BYTES + 96, len(line)
+    print(line, file=stream, flush=True)
+    return line
+
+
+def reassemble(stdout_text):
+    """The inverse of `emit` for readers of a captured stdout (tests, tools/): headline keys, plus `secondary` = {name: object} from
+    the secondary lines and the long-form objects of the detail lines (which replace the headline's short forms)."""
+    objs = [json.loads(l) for l in stdout_text.splitlines() if l.startswith("{")]
+    if not objs:
+        return None
+    out = dict(objs[-1])
+    short = {k: out[k] for k in ("roofline", "exchange") if k in out}
+    sec = {}
+    for o in objs[:-1]:
+        if "secondary" in o:
+            sec[o.pop("secondary")] = o
+        elif "detail" in o:
+            k = o["detail"]
+            out[k] = o[k]
+            if k == "roofline" and o.get("launch_probe") is not None:
+                out.setdefault("config", {})["launch_probe"] = o["launch_probe"]
+    out["secondary"] = sec
+    out["headline_short_forms"] = short
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -641,7 +777,17 @@ def run_c4_one_gpu(args, device, tm: Timing, rows=100_000_000, steps=40):
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
     rl = hbm_roofline(km, "embedding_bwd", "mh_embedding_gather_bwd (27 tables incl. the 100 M-row one: three sort passes)")
     if rl:
-        out["roofline"] = {k: rl[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "avg_launch_ms")}
+        # ONE byte definition per launch, the headline's (round-5 review): gradient rows once, table + state rows read and written once
+        # per UNIQUE id of the batch.  SURVEY 8d's figure (every looked-up row billed as unique) stays beside it, labelled.
+        passes = {"sgd": 3, "adagrad": 5, "adam": 7}[args.optimizer]
+        names = [n for n in batches[0].tensors if n.startswith("C")]
+        uniq = sum(int(torch.unique(b.tensors[n]).numel()) for b in batches for n in names) / len(batches)
+        look = sum(int(batches[0].tensors[n].numel()) for n in names)
+        per_launch = look * (64 * 4 + 4) + uniq * (passes - 1) * 64 * 4
+        ach = per_launch / (rl["avg_launch_ms"] * 1e-3) / 1e9
+        out["roofline"] = {"kernel": rl["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": rl["avg_launch_ms"],
+                           "bytes": "dedup-aware", "unique_rows_per_batch": uniq, "frac_survey_8d": rl["frac"]}
     for k in ("dlrm_fused_fwd", "dlrm_fused_bwd"):
         r2 = hbm_roofline(km, k, k)
         if r2:
@@ -758,10 +904,12 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
                                                "frac": bwd_bytes_dd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                "frac_survey_8d": bwd_bytes_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     res["unique_rows"] = uniq
-    res["roofline"] = {"bound": "hbm", "achieved": res["fwd"]["mean"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": res["fwd"]["mean"]["frac"], "traffic": None,
-                       "note": "the 26 tables hold 1.6 GB: most row reads are served by L2 / Infinity Cache (algorithmic bytes count every "
-                               "looked-up row, SURVEY 8d); the cache-busting figure is `cold`"}
+    # NOT a roofline: the 26 tables hold 1.6 GB and 86 % of the lookups repeat a row, so most row reads are served by L2 / Infinity
+    # Cache and bytes / time can exceed the HBM peak (round-5 review).  The HBM figure of this kernel is `cold` below.
+    for comb in res["fwd"]:
+        res["fwd"][comb]["cache_resident"] = True
+    res["cache_resident_rate"] = {"cache_resident": True, "GBps": res["fwd"]["mean"]["GBps"], "frac_of_hbm_peak": res["fwd"]["mean"]["frac"],
+                                  "note": "algorithmic bytes count every looked-up row (SURVEY 8d); served mostly from cache"}
     # dense list twin: [B, L] ids, no offsets
     L = mean_nnz
     dl = [torch.randint(0, int(v), (B, L), dtype=torch.int32, device=device, generator=g) for v in CRITEO_CARDINALITIES]
@@ -771,8 +919,8 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
         for f in range(F):
             ops.embedding_dense_list(tabs[f], dl[f], "mean", out=out[:, f * D:(f + 1) * D])
     ms = timed(dfwd)
-    res["dense_list_fwd_mean"] = {"shape": f"{F} x [{B}, {L}]", "ms": ms, "GBps": dl_bytes / (ms * 1e-3) / 1e9,
-                                  "frac": dl_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res["dense_list_fwd_mean"] = {"shape": f"{F} x [{B}, {L}]", "ms": ms, "GBps": dl_bytes / (ms * 1e-3) / 1e9, "cache_resident": True,
+                                  "frac_of_hbm_peak": dl_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     del tabs, accs, dl, feats
     torch.cuda.empty_cache()
     # cache-busting: one 12.8 GB table
@@ -794,6 +942,8 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
     cb = int(offs[-1]) * (D * 4 + 4) + B * (D * 4 + 8)
     res["cold"] = {"shape": f"one {rows}-row x {D} table (12.8 GB), {B} bags, {int(offs[-1])} uniform ids", "ms": ms, "algorithmic_bytes": cb,
                    "GBps": cb / (ms * 1e-3) / 1e9, "frac": cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res["roofline"] = {"kernel": "bag_fwd_kernel<int32, COOP>, cold table", "bound": "hbm", "achieved": res["cold"]["GBps"], "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": res["cold"]["frac"], "traffic": None, "algorithmic_bytes_per_launch": cb, "avg_launch_ms": ms}
     del big, sets
     torch.cuda.empty_cache()
     return res
@@ -1088,7 +1238,7 @@ class Deadline:
             try:
                 out = self.line_fn()
                 out["secondary_aborted"] = f"deadline of {self.seconds:.0f} s passed inside the N > 1 secondaries: the line holds what had finished"
-                print(json.dumps(out), flush=True)
+                emit(out)
             except Exception as e:  # noqa: BLE001
                 print(f"[bench] deadline fired and the line could not be printed: {e}", file=sys.stderr, flush=True)
         os._exit(0 if self.rank == 0 else 0)
@@ -1271,7 +1421,7 @@ def main():
         if rank == 0:
             out = dict(common)
             out.update(res)
-            print(json.dumps(out), flush=True)
+            emit(out)
         if world > 1:
             import torch.distributed as dist
 

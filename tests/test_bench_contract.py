@@ -119,3 +119,71 @@ def test_deadline_prints_the_line_it_has_and_ends_the_process():
 
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert out.returncode == 0 and line["value"] == 1.0 and "deadline" in line["secondary_aborted"]
+
+
+def _fat_result():
+    """A result object of the size round 5 printed (18 secondaries, long-form rooflines) with non-finite values sprinkled in."""
+    long = "x" * 400
+    sec = {f"sec{i}": {"metric": long, "value": 1.0 + i, "ms_per_step": float("nan") if i == 3 else 2.0, "kernels_ms": {f"k{j}": j for j in range(40)}}
+           for i in range(18)}
+    sec["twotower_train_b64k"] = {"value": 3.1e6, "ms_per_step": 21.0, "steps": 8, "kernels_ms": {}}
+    sec["broken"] = {"error": "RuntimeError: boom"}
+    rl = {"kernel": long, "op": "embedding_bwd", "bound": "hbm", "achieved": 5028.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.6285, "traffic": 1.13e9,
+          "traffic_source": long, "algorithmic_bytes_per_launch": 1.04e9, "avg_launch_ms": 0.2077, "definition": long,
+          "whole_update": {"frac": 0.39, "avg_launch_ms": 0.335, "definition": long}}
+    return {"metric": "samples/sec at batch 64K (DLRM)", "value": 6.7e7, "unit": "samples/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 0.97, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": long, "global_batch": 65536, "per_gpu_batch": 65536, "mode": "train", "optimizer": "adagrad",
+                       "launch": "eager + side streams", "launch_probe": {"a": float("inf")}, "parallelism": "dp1", "input_staging": long},
+            "roofline": rl, "roofline_fused_fwd": {"frac": 0.7, "note": long}, "mfma": {"linear_415x128": {"tflops": 91.3}},
+            "kernels_ms": {f"k{j}": j * 0.1 for j in range(40)}, "parity_notes": {"pinned": long, "unpinned": long},
+            "cpu_baseline": {"value": 63245.9, "unit": "samples/s", "cores": 16, "kind": "port", "sample": long},
+            "secondary": sec, "max_abs_err_vs_oracle": 5.96e-8, "sustained": {"value": 6.8e7, "ms_per_step": 0.96, "seconds": 5.0, "steps": 5000}}
+
+
+def test_last_stdout_line_is_a_small_strict_json_headline(tmp_path, monkeypatch):
+    """Round-5 review, item 1: the driver could not parse a 21.6 KB single object.  The LAST line must be < 4 KB of strict JSON with
+    the contract keys + roofline + cpu_baseline + the TwoTower-64K half of the metric; every other line strict JSON too."""
+    import io
+    import json
+
+    b = _bench_module()
+    monkeypatch.setattr(b, "ROOT", tmp_path)
+    buf = io.StringIO()
+    b.emit(_fat_result(), buf)
+    lines = buf.getvalue().splitlines()
+    strict = lambda l: json.loads(l, parse_constant=lambda c: (_ for _ in ()).throw(AssertionError(f"non-finite {c}")))
+    objs = [strict(l) for l in lines]
+    last = lines[-1]
+    assert len(last) < 4096, len(last)
+    h = objs[-1]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in h, k
+    assert set(h["config"]) == {"workload", "global_batch", "per_gpu_batch", "mode", "optimizer", "launch", "parallelism"}
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "whole_update_frac"):
+        assert k in h["roofline"], k
+    assert h["roofline"]["frac"] == 0.6285 and h["roofline"]["whole_update_frac"] == 0.39
+    assert {"value", "unit", "cores", "kind"} <= set(h["cpu_baseline"]) and h["cpu_baseline"]["value"] == 63245.9
+    assert h["twotower_b64k"]["value"] == 3.1e6 and h["twotower_b64k"]["ms_per_step"] == 21.0
+    assert h["max_abs_err_vs_oracle"] == 5.96e-8 and h["secondary_lines"]["errors"] == ["broken"]
+    # the secondaries ride on their own lines, before the headline; the full object is on disk
+    names = [o["secondary"] for o in objs[:-1] if "secondary" in o]
+    assert len(names) == 20 and "twotower_train_b64k" in names
+    assert objs[names.index("sec3")]["ms_per_step"] is None  # NaN -> null
+    full = json.loads((tmp_path / h["full_object"]).read_text())
+    assert full["config"]["launch_probe"]["a"] is None and len(full["secondary"]) == 20
+    # and the inverse used by the tests / tools
+    r = b.reassemble(buf.getvalue())
+    assert r["secondary"]["sec5"]["value"] == 6.0 and r["roofline"]["whole_update"]["frac"] == 0.39 and r["value"] == 6.7e7
+
+
+def test_headline_survives_missing_objects():
+    import json
+
+    b = _bench_module()
+    h = b.headline({"metric": "m", "value": float("nan"), "n_gpus": 2, "roofline": None, "cpu_baseline": None,
+                    "exchange": {"communicator": "RCCL", "groups": [{"dedup": True, "window_slots": 5, "local_rows": 7, "features": ["a"] * 100}]}})
+    s = json.dumps(h, allow_nan=False)
+    assert h["value"] is None and h["roofline"] is None and h["cpu_baseline"] is None and h["exchange"]["groups"] == [{"dedup": True, "window_slots": 5, "local_rows": 7}]
+    assert len(s) < 4096

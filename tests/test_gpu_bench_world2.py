@@ -28,8 +28,19 @@ def _run(extra, timeout=600):
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_world2_harness.py"), "--gpus", "2", *extra]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
-    return json.loads(lines[0])
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    # the driver reads the LAST line: <= 4 KB of strict JSON carrying the contract keys (round-5 review, item 1)
+    last = r.stdout.rstrip().splitlines()[-1]
+    assert last == lines[-1] and len(last) < 4096, len(last)
+    head = json.loads(last, parse_constant=lambda c: pytest.fail(f"non-finite constant {c} in the headline"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in head, k
+    assert head["n_gpus"] == 2 and "communicator" in head.get("exchange", {"communicator": 1})
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench.reassemble(r.stdout)
 
 
 def test_dlrm_bench_line_at_world_2(device):
