@@ -58,22 +58,45 @@ class LogitsTemperatureScaler(Block):
 class ItemRetrievalScorer(ContrastiveOutput):
     """blocks/retrieval/base.py:130-420 (the V1 scorer) in its own argument names: in-batch (and sampler-provided) negatives,
     false negatives rescored to ``sampling_downscore_false_negatives_value``, positives in column 0 -- the computation of
-    ``ContrastiveOutput`` (one fused kernel: ``mh_inbatch_softmax_*``)."""
+    ``ContrastiveOutput`` (one fused kernel: ``mh_inbatch_softmax_*``).
+
+    The ids false negatives are recognised by are read from ``features[item_id_feature_name]`` (base.py:313-316, 379-383);
+    ``item_id_column`` (this package's keyword) overrides the name.
+
+    ``sampled_softmax_mode=True`` (base.py:274, 313-331, 400): candidates are rows of the ITEM EMBEDDING TABLE -- positives =
+    lookup(targets), sampled negatives = lookup(sampled ids) -- which the reference fetches from its ModelContext by
+    ``item_domain``.  There is no ModelContext here: hand the table over as ``item_table=`` (an ``EmbeddingTable``); the scorer is
+    then ``ContrastiveOutput(EmbeddingTable)`` under the V1 name.  Without a sampler that needs no batch embeddings (e.g.
+    ``PopularityBasedSamplerV2``) there is nothing to sample from, as in the reference."""
 
     def __init__(self, samplers: Sequence = (), sampling_downscore_false_negatives: bool = True,
                  sampling_downscore_false_negatives_value: float = MIN_FLOAT, item_id_feature_name: str = "item_id",
                  item_domain: str = "item_id", query_name: str = "query", item_name: str = "item", cache_query: bool = False,
                  sampled_softmax_mode: bool = False, store_negative_ids: bool = False, logits_temperature: float = 1.0,
-                 item_id_column: Optional[ColumnSchema] = None, post=None, name: Optional[str] = None):
-        if sampled_softmax_mode:
-            raise NotImplementedError("sampled_softmax_mode (output-layer weights as candidates): use ContrastiveOutput(EmbeddingTable)")
+                 item_id_column: Optional[ColumnSchema] = None, item_table=None, post=None, name: Optional[str] = None):
         if cache_query:
             raise NotImplementedError("cache_query (ModelContext) is outside the hot path")
-        super().__init__(item_id_column, list(samplers) if samplers else "in-batch",
-                         downscore_false_negatives=sampling_downscore_false_negatives and item_id_column is not None,
+        if sampled_softmax_mode:
+            from .inputs import EmbeddingTable
+
+            if not isinstance(item_table, EmbeddingTable):
+                raise ValueError("sampled_softmax_mode=True scores against the rows of the item embedding table (the reference reads it "
+                                 "from its ModelContext by item_domain): pass it as item_table=EmbeddingTable(...)")
+            if not samplers:
+                raise ValueError("At least one sampler is required by ItemRetrievalScorer for negative sampling")  # base.py:319-321
+            to_call = item_table
+        else:
+            if item_table is not None:
+                raise ValueError("item_table is the candidate-weight table of sampled_softmax_mode=True")
+            # V1 default: downscore by the ids under `item_id_feature_name` (round-5 advisor finding: a missing item_id_column
+            # silently switched the rescoring off)
+            to_call = item_id_column if item_id_column is not None else ColumnSchema(item_id_feature_name)
+        super().__init__(to_call, list(samplers) if samplers else "in-batch",
+                         downscore_false_negatives=sampling_downscore_false_negatives,
                          false_negative_score=sampling_downscore_false_negatives_value, logits_temperature=logits_temperature,
                          store_negative_ids=store_negative_ids, query_name=query_name, candidate_name=item_name, post=post, name=name)
         self.item_id_feature_name, self.item_domain = item_id_feature_name, item_domain
+        self.sampled_softmax_mode = bool(sampled_softmax_mode)
 
 
 class ItemRetrievalTask:

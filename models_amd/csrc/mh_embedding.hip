@@ -131,7 +131,12 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
         for (int64_t c0 = beg; c0 < end; c0 += 64) {
             const int nchunk = (int)((end - c0) < 64 ? (end - c0) : 64);
             const IdT myid = (lane < nchunk) ? values[c0 + lane] : (IdT)0;
-            for (int k0 = g; k0 < nchunk; k0 += 8 * G) {
+            // WAVE-UNIFORM trip count (kb, not g, drives the loop): the shuffle below reads ids out of lanes of OTHER groups, and a group
+            // that had left the loop would be EXEC-masked -- ds_bpermute returns 0 for a disabled source lane, i.e. table row 0 in
+            // place of the real row (chunks of 33 / 34 ids at D = 64, 33 / 49 at D = 128).  Every lane runs every trip; only the
+            // load and the accumulate are predicated.
+            for (int kb = 0; kb < nchunk; kb += 8 * G) {
+                const int k0 = kb + g;
                 f32x4 v[8];
                 int kept[8];
 #pragma unroll

@@ -1376,6 +1376,13 @@ __global__ __launch_bounds__(256) void bag_index_pad_kernel(const BagMultiArgs a
     for (int t = threadIdx.x; t <= nb; t += 256) win[t] = (int64_t)offsets[b0 + t];
     __syncthreads();
     const int64_t j0 = win[0], j1 = win[nb] < n ? win[nb] : n;
+    if (blockIdx.x == 0) {  // offsets of a sliced CSR view need not start at 0: the values in front of the first bag belong to no bag
+        const int64_t lead = j0 < n ? j0 : n;
+        for (int64_t j = threadIdx.x; j < lead; j += 256) {
+            mp[j] = 0;
+            ip[j] = (IdT)-1;
+        }
+    }
     for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
         int lo = 0, hi = nb;  // win[lo] <= j < win[hi]; empty bags share an offset with their successor: the LAST bag with offset <= j
         while (hi - lo > 1) {

@@ -198,7 +198,18 @@ class Loader:
             nbytes = sum((v[0].numel() * v[0].element_size() + 8 * len(v[1])) if isinstance(v, tuple) else v.numel() * v.element_size()
                          for v in self._pinned.values())
             self.dataset_bytes = int(nbytes)
-            if device_resident_bytes and nbytes <= device_resident_bytes:
+            # the pinned copy IS the dataset from here on: the decoded arrays are released (they doubled the host footprint)
+            self.columns = {}
+            # never more than half of what is FREE on this GPU right now (round-5 advisor finding: 48 GB assumed a 288 GB device
+            # with nothing else on it; beside large embedding tables the cache would have run the device out of memory mid-epoch)
+            budget = int(device_resident_bytes or 0)
+            if budget:
+                try:
+                    budget = min(budget, torch.cuda.mem_get_info(self.device)[0] // 2)
+                except Exception:  # noqa: BLE001 -- no usable figure: stream the chunks
+                    budget = 0
+            self.device_resident = bool(budget and nbytes <= budget)
+            if self.device_resident:
                 self._dev_cache = {}
 
     def _init_streaming(self, path, buffer_rows: int) -> None:
@@ -240,7 +251,10 @@ class Loader:
             st = list(range(0, n, C))
             r = np.random.default_rng(self.seed + ep)
             if self.shuffle and len(st) > 1:
-                st = [st[i] for i in r.permutation(len(st))]
+                # the short last chunk STAYS last: in the middle of an epoch its partial batch would run eagerly inside fit
+                # (a captured step has one static shape) and every later batch of the epoch would sit at a shifted offset
+                tail = [st.pop()] if n % C else []
+                st = [st[i] for i in r.permutation(len(st))] + tail
             return st, r
 
         starts, rng = plan(epoch)

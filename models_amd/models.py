@@ -169,36 +169,43 @@ class Model(Block):
             arrays["__adam_step__"] = opt._step_dev.detach().cpu().numpy()
         np.savez(path, **arrays)
 
-    def load_weights(self, path, skip=()) -> None:
+    def load_weights(self, path, skip=(), legacy_layout: Optional[str] = None) -> None:
         """Inverse of ``save_weights`` for an identically constructed (and built) model.  Values are copied INTO the
         existing tensors (parameters, optimizer state, the on-device Adam step) wherever they exist, so a captured
-        hipGraph keeps updating the restored buffers."""
+        hipGraph keeps updating the restored buffers.
+
+        ``legacy_layout``: only for checkpoints WITHOUT the ``__format__`` tag of a model holding a DLRMBlock.  Such files were
+        written in one of two layouts of the first top-MLP kernel -- ``"interactions_first"`` (the oldest ones: rows
+        [interactions | bottom output]; rotated here to today's order, optimizer state with them) or ``"bottom_first"`` (already the
+        reference's [bottom output | interactions]; loaded as they are) -- and the file cannot say which (round-5 advisor finding:
+        guessing corrupted the second kind).  Without the argument an untagged DLRM checkpoint is refused."""
         z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
         self.flush_deferred()
         params = self.parameters()
         names = [str(n) for n in z["__names__"]]
         if len(names) != len(params):
             raise ValueError(f"checkpoint has {len(names)} parameters, the model has {len(params)}")
-        # Layout tag (round-4 advisor finding).  Checkpoints written before the tag existed fed the DLRM top MLP
-        # [interactions | bottom output]; the reference -- and this package since -- feeds it [bottom output | interactions]
-        # (blocks.DLRMBlock).  Parameters are stored by position and shape, so such a file would load without an error with the
-        # first top-MLP kernel's rows applied to the wrong columns: its last D rows are rotated to the front here (the
-        # optimizer state of that kernel with them), with a warning.
+        if legacy_layout not in (None, "interactions_first", "bottom_first"):
+            raise ValueError(f"legacy_layout={legacy_layout!r}: expected 'interactions_first' or 'bottom_first'")
         rotate = {}
         if "__format__" not in z.files:
             from .blocks import DLRMBlock, _dense_layers
 
+            ambiguous = {}
             for blk in self.blocks_of_type(DLRMBlock):
                 tl = _dense_layers(blk.top_block) if blk.top_block is not None else None
                 if tl and blk.bottom_block is not None:
-                    rotate[id(tl[0].kernel)] = blk.dim
-            if rotate:
-                import warnings
-
-                warnings.warn("untagged checkpoint (written before the DLRM top-MLP input order changed to the reference's "
-                              "[bottom | interactions]): rotating the first top-MLP kernel's rows", stacklevel=2)
+                    ambiguous[id(tl[0].kernel)] = blk.dim
+            if ambiguous and legacy_layout is None:
+                raise ValueError("untagged checkpoint of a model with a DLRMBlock: the first top-MLP kernel is stored either as "
+                                 "[interactions | bottom] (oldest files) or as [bottom | interactions] (the reference's order) and the file "
+                                 "does not say which; pass legacy_layout='interactions_first' or 'bottom_first'")
+            if legacy_layout == "interactions_first":
+                rotate = ambiguous
         elif str(z["__format__"]) != CHECKPOINT_FORMAT:
             raise ValueError(f"checkpoint format {str(z['__format__'])!r} is not {CHECKPOINT_FORMAT!r}")
+        elif legacy_layout is not None:
+            raise ValueError("legacy_layout is for untagged checkpoints only; this one is tagged " + CHECKPOINT_FORMAT)
         fix = lambda a, D: np.concatenate([a[-D:], a[:-D]], axis=0)
         for i, p in enumerate(params):
             if id(p) in skip:

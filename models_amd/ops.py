@@ -1161,7 +1161,7 @@ def embedding_bag_backward_multi(tables: Sequence[torch.Tensor], states: Optiona
             if L and v.shape[1] != L:
                 raise ValueError("dense lists of one call share the list length")
             L = v.shape[1]
-            vals.append(v.reshape(-1).contiguous())
+            vals.append(_dev(v, "values").reshape(-1).contiguous())
         offs = None
     else:
         vals = [_dev(v, "values").reshape(-1).contiguous() for v in values]

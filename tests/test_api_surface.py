@@ -153,8 +153,8 @@ def test_save_and_load_weights_round_trip(tmp_path):
 
 def test_untagged_checkpoint_of_the_old_dlrm_layout_is_rotated_not_misapplied(tmp_path):
     """Checkpoints carry a layout tag; a file without one was written when the top MLP's input was [interactions | bottom]:
-    the first top-MLP kernel's last D rows (and its optimizer state) move to the front on load, with a warning; a file with
-    an unknown tag is refused."""
+    with legacy_layout="interactions_first" the first top-MLP kernel's last D rows (and its optimizer state) move to the front on
+    load; without the argument the untagged file is refused; a file with an unknown tag is refused."""
     import numpy as np
     import torch
     from models_amd import schema as S
@@ -185,10 +185,20 @@ def test_untagged_checkpoint_of_the_old_dlrm_layout_is_rotated_not_misapplied(tm
     for key in (f"p{pos}", f"s{pos}:accumulator"):
         old[key] = np.concatenate([z[key][D:], z[key][:D]], axis=0)
     np.savez(tmp_path / "old", **old)
-    with pytest.warns(UserWarning, match="untagged checkpoint"):
+    # the file cannot say which of the two untagged layouts it holds: refused without the caller's word (round-5 advisor finding)
+    with pytest.raises(ValueError, match="legacy_layout"):
         b.load_weights(tmp_path / "old")
+    b.load_weights(tmp_path / "old", legacy_layout="interactions_first")
     kb = b.body.top_block.layers[0].kernel
     assert torch.equal(kb.data, k.data) and torch.equal(kb.state["accumulator"], k.state["accumulator"])
+    # an untagged file written after the order changed (bottom first) loads as it is
+    c = build(9)
+    np.savez(tmp_path / "window", **{key: v for key, v in z.items() if key != "__format__"})
+    c.load_weights(tmp_path / "window", legacy_layout="bottom_first")
+    kc = c.body.top_block.layers[0].kernel
+    assert torch.equal(kc.data, k.data) and torch.equal(kc.state["accumulator"], k.state["accumulator"])
+    with pytest.raises(ValueError, match="untagged checkpoints only"):
+        c.load_weights(tmp_path / "new", legacy_layout="bottom_first")
     z["__format__"] = np.array("models_amd/99")
     np.savez(tmp_path / "future", **z)
     with pytest.raises(ValueError, match="format"):

@@ -399,3 +399,24 @@ def test_embeddings_block_updates_several_ragged_features_in_one_launch(monkeypa
         w = W0[n].copy()
         w[touched] -= 0.5 * dW[touched] / (np.sqrt(acc[touched]) + 1e-7)
         np.testing.assert_allclose(emb.feature_table[n].table.numpy(), w, rtol=2e-5, atol=2e-6)
+
+
+def test_bag_backward_multi_offsets_of_a_sliced_csr_view():
+    """offsets[0] > 0 (a CSR view cut out of a longer one, values tensor kept whole): the values in front of the first bag belong to
+    no bag -- they must not reach the sort / optimizer as uninitialised workspace (round-5 advisor finding)."""
+    from models_amd import ops
+    from oracle import oracle as O
+
+    dev = _dev()
+    rng = np.random.default_rng(31)
+    B, D, V, lead = 300, 16, 97, 7
+    vals0, offs0 = _csr(rng, B, V, 6)
+    vals = np.concatenate([rng.integers(0, V, size=lead), vals0]).astype(np.int64)
+    offs = (offs0 + lead).astype(np.int64)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    for _ in range(3):  # the workspace is reused: stale entries of an earlier call would show on a later one
+        W = torch.zeros(V, D, device=dev)
+        ops.embedding_bag_backward_multi([W], None, [torch.from_numpy(vals).to(dev)], [torch.from_numpy(offs).to(dev)],
+                                         torch.from_numpy(g).to(dev), [0], "sum", "sgd", -1.0)
+        want = O.embedding_bag_grad(V, vals0, offs0, g, "sum")
+        np.testing.assert_allclose(W.cpu().numpy(), want, rtol=1e-5, atol=1e-5)

@@ -82,3 +82,46 @@ def test_multi_optimizer_updates_each_block_with_its_own_rule(device):
     model2.train_step(x, y)
     rb = [t for t in ref.body.embeddings.feature_table.values() if t.input_dim == 5000][0]
     torch.testing.assert_close(l2[0].table.data, rb.table.data, atol=1e-6, rtol=1e-5)
+
+
+def test_v1_item_retrieval_scorer_sampled_softmax_mode(device):
+    """blocks/retrieval/base.py:274,313-331,400: sampled_softmax_mode scores the query against rows of the item embedding table
+    (positives = lookup(targets), negatives = lookup(sampled ids)).  Here the table is handed over as `item_table`; the logits equal
+    the oracle's contrastive_outputs over those rows, positives in column 0, false negatives at MIN_FLOAT."""
+    from oracle import oracle as O
+
+    torch.manual_seed(1)
+    col = S.categorical("item_id", 101, [S.Tags.ITEM, S.Tags.ITEM_ID])
+    table = mm.EmbeddingTable(16, col, device=device)
+    sampler = mm.PopularityBasedSamplerV2(max_id=100, max_num_samples=20, min_id=1, seed=5)
+    out = mm.ItemRetrievalScorer(samplers=[sampler], sampled_softmax_mode=True, item_table=table, store_negative_ids=True)
+    assert out.sampled_softmax_mode and out.has_candidate_weights
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(50, 16, generator=g).to(device)
+    tgt = torch.randint(1, 101, (50, 1), generator=g).to(device)
+    pred = out({"query": q}, features={}, targets=tgt, training=True)
+    nid = pred.negative_candidate_ids.cpu().numpy()
+    W, t = table.table.data.cpu().numpy(), tgt.reshape(-1).cpu().numpy()
+    want, _ = O.contrastive_outputs(q.cpu().numpy(), W[t], W[nid], t, nid)
+    got = pred.outputs.cpu().numpy()
+    assert got.shape == (50, 21) and np.array_equal(pred.targets.cpu().numpy()[:, 0], np.ones(50))
+    np.testing.assert_allclose(got, want, atol=1e-4)
+    assert (got[:, 1:][t[:, None] == nid[None, :]] < -1e30).all() and (t[:, None] == nid[None, :]).any()   # sampled positives are downscored
+    with pytest.raises(ValueError, match="item_table"):
+        mm.ItemRetrievalScorer(samplers=[sampler], sampled_softmax_mode=True)
+    with pytest.raises(ValueError, match="sampler"):
+        mm.ItemRetrievalScorer(sampled_softmax_mode=True, item_table=table)
+
+
+def test_v1_item_retrieval_scorer_downscores_by_the_named_feature_by_default(device):
+    """base.py:313-316, 379-383: the ids come from features[item_id_feature_name]; no item_id_column is needed for the rescoring."""
+    g = torch.Generator().manual_seed(3)
+    q, c = torch.randn(8, 4, generator=g).to(device), torch.randn(8, 4, generator=g).to(device)
+    ids = torch.tensor([5, 6, 5, 7, 8, 6, 9, 10], device=device).reshape(-1, 1)
+    out = mm.ItemRetrievalScorer(item_id_feature_name="sku")
+    assert out.downscore_false_negatives
+    pred = out({"query": q, "item": c}, features={"sku": ids}, training=True)
+    lg = pred.outputs.cpu().numpy()
+    assert lg.shape == (8, 9) and lg[0, 1 + 2] < -1e30 and lg[2, 1 + 0] < -1e30 and lg[1, 1 + 5] < -1e30 and lg[0, 1 + 1] > -1e30
+    with pytest.raises(ValueError):
+        out({"query": q, "item": c}, features={}, training=True)

@@ -75,6 +75,30 @@ def test_bag_matches_oracle(device, combiner, D, mean_len):
     assert np.all(out.cpu().numpy()[lens == 0] == 0)
 
 
+@pytest.mark.parametrize("D", [16, 32, 64, 128])
+@pytest.mark.parametrize("dense_list", [False, True])
+def test_bag_lengths_that_end_inside_a_partial_group_round(device, D, dense_list):
+    """The wave-cooperative kernel hands ids to its lane groups by shuffle: a chunk of 33 / 34 ids at D = 64 (4 groups) or 33 / 49 at
+    D = 128 (2 groups) once made a group read the id out of a lane whose group had already left the loop (reads as 0: row 0 summed in
+    place of the real row -- round-5 advisor finding).  Row 0 is poisoned here so that such a read cannot hide."""
+    rng = np.random.default_rng(41)
+    V = 2003
+    W = rng.normal(size=(V, D)).astype(np.float32)
+    W[0] = 1.0e6
+    lens = np.array([33, 34, 35, 49, 50, 63, 64, 65, 97, 98, 113, 127, 128, 129, 161, 162, 1, 2, 31, 32] * 3, dtype=np.int64)
+    for combiner in ("sum", "mean"):
+        if dense_list:
+            for L in (33, 34, 49, 97, 98):
+                ids = rng.integers(1, V, size=(37, L)).astype(np.int32)
+                out = ops.embedding_dense_list(_t(W, device), _t(ids, device), combiner)
+                np.testing.assert_allclose(out.cpu().numpy(), O.embedding_dense_list(W, ids, combiner), rtol=1e-5, atol=1e-4)
+        else:
+            offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            values = rng.integers(1, V, size=int(offsets[-1])).astype(np.int64)   # never row 0
+            out = ops.embedding_bag(_t(W, device), _t(values, device), _t(offsets, device), combiner)
+            np.testing.assert_allclose(out.cpu().numpy(), O.embedding_bag(W, values, offsets, combiner), rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("combiner", ["sum", "mean"])
 @pytest.mark.parametrize("L", [1, 5, 24])
 def test_dense_list_matches_oracle(device, combiner, L):
