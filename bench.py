@@ -1519,20 +1519,6 @@ def main():
                         step, graphed, best, launch_mode = rec_step, None, pr, "recorded launch sequence (C replay)"
                 except Exception as e:  # noqa: BLE001
                     launch_probe["recorded_error"] = f"{type(e).__name__}: {e}"
-            if not sharded and hasattr(model, "pipelined_updates") and os.environ.get("MERLIN_HIP_DW_DEFER") == "1":
-                # the eager step, software-pipelined across steps (Model.pipelined_updates: the first top-MLP layer's dW GEMM and dense
-                # update of step t run at the start of step t + 1 beside the HBM-bound gather -> interaction kernel; every timed step
-                # still does exactly one such GEMM + update -- the previous step's -- and the last one is flushed after the region).
-                # Measured LAST: the captures above must not see a pending update.
-                ctx = model.pipelined_updates()
-                ctx.__enter__()
-                try:
-                    pp = probe(eager_step)
-                finally:
-                    ctx.__exit__(None, None, None)
-                launch_probe["eager_pipelined_ms"] = pp
-                if pp < best * 0.995:
-                    step, graphed, best, launch_mode, pipelined = eager_step, None, pp, "eager + side streams, pipelined steps", True
         except Exception as e:  # noqa: BLE001 -- the replayed graph stays the timed mode
             launch_probe = {"error": f"{type(e).__name__}: {e}"}
     elif graphed and args.launch == "segmented" and args.mode == "train":

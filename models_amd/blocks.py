@@ -635,16 +635,11 @@ class DLRMBlock(Block):
         if self.top_block is not None:
             tl = _dense_layers(self.top_block)
             # zero_pad=False: the interaction backward reads the P + D gradient columns only, never the alignment column of dx
-            # The dW GEMM of the FIRST top-MLP layer (K = P + D = 415 at C2: the one large dW of the step) is not launched beside
-            # its dX: it would run beside the LDS-filling interaction backward (84 us alone, 279 us there, and the interaction
-            # backward itself 190 -> 237 us), with the sparse apply queued behind it on the side stream.  It is launched on the
-            # launch stream BEHIND the bottom-MLP backward instead, where that stream otherwise only waits for the HBM-bound sparse
-            # apply: MFMA work beside memory work.  OPT-IN (MERLIN_HIP_DW_LATE=1): measured neutral in the eager step (0.952 vs 0.955 ms) and worse under the segmented replay (1.107 vs 0.978 ms) -- beside the persistent, HBM-saturating apply kernel the GEMM takes 250 us instead of 84 and the apply 275-300 instead of 186: the two serialise whichever way they are queued (profiles/r5_notes.md).
-            import os as _os
-
+            # (Launching the first top-MLP layer's dW GEMM late -- behind the bottom-MLP backward, beside the sparse apply -- was
+            # measured neutral in the eager step and slower under the segmented replay, and is gone: profiles/r5_notes.md.  The list
+            # below only exists for the pipelined steps of Model.pipelined_updates.)
             defer = self._can_defer(tl, head)
-            late = [] if (getattr(self, "_fused", False) and self.bottom_block is not None
-                          and (defer or _os.environ.get("MERLIN_HIP_DW_LATE", "0") == "1")) else None
+            late = [] if (getattr(self, "_fused", False) and self.bottom_block is not None and defer) else None
             if head is not None and tl:  # grad is the head's dz (the loss gradient w.r.t. its pre-activation)
                 grad = mlp_backward(tl + [head], grad, True, pre_masked=True, zero_pad=False, late_dw_first=late)
                 late_dw = late
@@ -654,8 +649,8 @@ class DLRMBlock(Block):
                     # behind which the sparse apply then queues) are computed at the START of the next step, on the side stream beside
                     # the HBM-bound gather -> interaction kernel, followed by this layer's dense update; the launch stream waits for
                     # both right before the layer's forward.  Same kernels, same operands, same update, one step later in wall time:
-                    # weights after a flush are bit-identical to un-pipelined steps (tests/test_gpu_models.py).  Opt-in
-                    # (MERLIN_HIP_DW_DEFER=1): the interaction backward does drop to 183 us and the apply starts the moment its input
+                    # weights after a flush are bit-identical to un-pipelined steps (tests/test_gpu_models.py).  Opt-in (entering the
+                    # context): the interaction backward does drop to 183 us and the apply starts the moment its input
                     # exists, but the forward pays more than that (Model.pipelined_updates).
                     lay = tl[0]
                     self._deferred = {"fns": late, "layer": lay, "dW": lay.kernel.grad, "db": None if lay.bias is None else lay.bias.grad,

@@ -58,7 +58,9 @@ def _compile(src: Path, verbose: bool) -> Path:
     hdr_t = max(p.stat().st_mtime for p in _deps() if p.suffix == ".h")
     if obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_t):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", str(src), "-o", str(obj)]
+    # MH_LAB=1 (with force=True): the tuning / ablation knobs of the labs are compiled in (mh_common.h: MH_LAB_ENV); never shipped
+    lab = ["-DMH_LAB"] if os.environ.get("MH_LAB") == "1" else []
+    cmd = [_hipcc(), *FLAGS, *lab, "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -57,6 +57,15 @@ void mh_record_op(std::function<void()>&& op);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                   \
     } while (0)
 
+// Tuning / ablation knobs of the labs (tools/exp, profiles/*_notes.md) exist only in a library built with -DMH_LAB
+// (MH_LAB=1 python -c "from models_amd import build; build.build(force=True)").  The shipped library reads the switches documented in
+// README.md ("Environment switches", enforced by tests/test_abi.py) and nothing else: MH_LAB_ENV is a constant nullptr there.
+#ifdef MH_LAB
+#define MH_LAB_ENV(name) getenv(name)
+#else
+#define MH_LAB_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 static inline int64_t mh_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Fill of `words` 32-bit words as a KERNEL on the stream (mh_misc.hip).  hipMemsetAsync is not used anywhere in the library:

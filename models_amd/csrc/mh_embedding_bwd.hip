@@ -1107,7 +1107,7 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
     // XCD's dirty L2 lines -- pass 0 has just written 13.6 MB of keys) and reading them an agent-scope acquire (invalidate), and
     // those cost more than two kernel boundaries, which do the same thing once for everybody.  (Relaxed atomic loads for the
     // counts were worse still: issued one at a time, 120 dependent round trips per thread.)
-    const char* sort_env = getenv("MERLIN_HIP_SORT");  // read per launch (host-side string test): tests switch it in-process
+    const char* sort_env = MH_LAB_ENV("MERLIN_HIP_SORT");  // read per launch (host-side string test): tests switch it in-process
     const bool classic = !(sort_env && !strcmp(sort_env, "lookback"));
     const bool lookback = !classic && npass >= 2;
     int* cnt1 = reinterpret_cast<int*>(ws + L.off_cnt1);
@@ -1155,7 +1155,7 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         const int runs = (gm.map != nullptr) ? 1 : 0;
         static int tile_log2 = -1;
         if (tile_log2 < 0) {
-            const char* e = getenv("MERLIN_HIP_APPLY_TILE_LOG2");
+            const char* e = MH_LAB_ENV("MERLIN_HIP_APPLY_TILE_LOG2");
             tile_log2 = e ? atoi(e) : 3;
             if (tile_log2 < 0 || tile_log2 > 16) tile_log2 = 3;
         }
@@ -1174,7 +1174,7 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
         // needs 120 per lane, this kernel 96 x 5 of 512)
         static int cap_env = -1;
         if (cap_env < 0) {
-            const char* e = getenv("MERLIN_HIP_APPLY_RESIDENT");
+            const char* e = MH_LAB_ENV("MERLIN_HIP_APPLY_RESIDENT");
             cap_env = e ? atoi(e) : 0;
         }
         const int res = (cap_env > 0 && cap_env < resident[vmode]) ? cap_env : resident[vmode];

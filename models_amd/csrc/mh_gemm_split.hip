@@ -163,7 +163,7 @@ struct GsArgs {
     float* p_out;
     int64_t ld_e;
     int act;  // EPI 2: C = act(acc + bias[n])  (Dense forward)
-    int ablate;  // timing experiments only (MERLIN_HIP_GEMM_SPLIT_ABLATE; results are wrong): 1 = no tile loads inside the k-loop,
+    int ablate;  // -DMH_LAB builds only: timing experiments (MERLIN_HIP_GEMM_SPLIT_ABLATE; results are wrong): 1 = no tile loads inside the k-loop,
                  // 2 = the loads are issued but a tile is used without waiting for it (up to two tiles in flight)
 };
 
@@ -319,10 +319,17 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
     } else {
     for (int t = 0; t < T; ++t) {
         // tile t is complete when at most the loads of tiles t + 1 .. t + GST - 2 are outstanding
+#ifdef MH_LAB
         if (a.ablate & 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");  // experiment: does not wait for the tile
-        else if (t + GST - 2 < T) g_wait_vm_and_barrier<(GST - 2) * G_DMA>();
+        else
+#endif
+        if (t + GST - 2 < T) g_wait_vm_and_barrier<(GST - 2) * G_DMA>();
         else g_wait_vm_and_barrier<0>();
+#ifdef MH_LAB
         if (t + GST - 1 < T && !(a.ablate & 1)) issue(t + GST - 1);
+#else
+        if (t + GST - 1 < T) issue(t + GST - 1);
+#endif
         const unsigned char* st = smem + (t % GST) * G_STAGE;
         // The fragments of ALL 16-wide k-steps of the tile are read from LDS up front (LDS returns in order: the MFMAs of step 0 wait
         // for the first half only), so the reads of step 1 can run behind the MFMAs of step 0.
@@ -458,7 +465,7 @@ int gemm_geo();
 int gemm_pack() {  // MERLIN_HIP_GEMM_SPLIT_PACK = 1 (default) | 0: k-tile major operand images (GsArgs); the 16-wide k-tile forms are row-major
     static int pack = -1;
     if (pack < 0) {
-        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_PACK");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_GEMM_SPLIT_PACK");
         pack = (e ? atoi(e) : 1) && gemm_geo() < 3;
     }
     return pack;
@@ -490,14 +497,14 @@ int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
     a.kt_per_split = (int)mh_ceil_div(nkt, splits);
     static int xmap = -1;  // MERLIN_HIP_GEMM_SPLIT_XCD = 0 | 1
     if (xmap < 0) {
-        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_XCD");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_GEMM_SPLIT_XCD");
         xmap = e ? atoi(e) : 1;
     }
     a.xcd_map = xmap;
     a.pack = gemm_pack();
     static int ablate = -1;
     if (ablate < 0) {
-        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_ABLATE");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_GEMM_SPLIT_ABLATE");
         ablate = e ? atoi(e) : 0;
     }
     a.ablate = ablate;
@@ -512,7 +519,7 @@ int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
 int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 128x128
     static int geo = -1;
     if (geo < 0) {
-        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_GEO");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_GEMM_SPLIT_GEO");
         // measured at 65536 x 3344 x 3344 (DCN-v2 step, same box): 256x256 56.9 ms, 256x128 59.5 ms, 128x128 79 ms
         geo = !e ? 2 : (!strcmp(e, "128x128") ? 1 : (!strcmp(e, "256x128") ? 0 : (!strcmp(e, "256x256k16") ? 3 : (!strcmp(e, "256x256k16s4") ? 4 : 2))));
     }
@@ -524,7 +531,7 @@ int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
     const int geo = gemm_geo();
     static int pipe = -1;  // MERLIN_HIP_GEMM_SPLIT_PIPE = 1 | 0: the k-loop with the barrier in the middle of a tile's MFMAs (see the kernel)
     if (pipe < 0) {
-        const char* e = getenv("MERLIN_HIP_GEMM_SPLIT_PIPE");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_GEMM_SPLIT_PIPE");
         pipe = e ? atoi(e) : 1;  // measured (DCN-v2 step, same box, row-major operands): 54.2-54.5 ms plain, 53.2-53.5 with the mid-tile barrier
     }
     if (geo == 1) return launch_gemm_geo<EPI, 128, 128, false>(a, splits, s);

@@ -952,7 +952,7 @@ static dim3 fused_grid(int64_t B, size_t lds, int max_occ = 4) {
     // MERLIN_HIP_FUSED_LDS_GRANULE overrides (1 = the old arithmetic).
     static int lds_gran = -1;
     if (lds_gran < 0) {
-        const char* e = getenv("MERLIN_HIP_FUSED_LDS_GRANULE");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_FUSED_LDS_GRANULE");
         lds_gran = e ? atoi(e) : 1280;
         if (lds_gran < 1) lds_gran = 1;
     }

@@ -203,171 +203,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(const float* __re
     store_tile<TM, TN>(acc, Cm, ldc, row0 + wm * TM * 32, n0 + wn * TN * 32, M, Nout, lane, ep);
 }
 
-// ---- C[M, Nout] = A[M, KC] B[Nout, KC]^T with the A rows STATIONARY IN REGISTERS --------------------------------------------------
-// dX of a Dense layer with few outputs (the first top-MLP layer of the DLRM: dZ[65536, 128] W[416, 128]^T): the contraction is
-// short (KC = 128: 8 k-tiles) and the output wide, so a tiled kernel spends as long in the prologue / epilogue of its
-// (row tile, column tile) workgroups as in their k-loops -- every tiling tried lands at 60-72 TF (profiles/r3_notes.md).
-// Here a wavefront keeps its 32 rows of A for the whole kernel (KC / 2 registers per lane: lane (row l31, half h) holds
-// A[row][2 s + h], s = 0 .. KC / 2 - 1, exactly the operand order of v_mfma_f32_32x32x2_f32), and walks ALL column blocks, TWO
-// per step; the 64 rows of B of a step are shared by the 8 wavefronts of the workgroup (256 rows) through LDS, one barrier per
-// step, no other synchronisation.  What the in-kernel timelines and the issue-rate lab decided (profiles/r3_astat_timeline_v*.txt,
-// r3_mfma_f32_issue_lab.txt):
-//   * B sits in LDS k-DE-INTERLEAVED (per row: the 64 even k, then the 64 odd k), so that the float4 a lane reads holds ITS k-slot
-//     of four consecutive MFMA steps.  With B as it lies in memory a lane reads {k, k+1, k+2, k+3} and needs a select per MFMA
-//     to pick its slot; selects on freshly read LDS data in front of the MFMAs cost 41 % of the loop (90.6 vs 64.0 cycles per
-//     MFMA in the lab).  The permutation is 16-byte-internal, so the tiles go global -> registers -> ds_write_b64 (not DMA): four
-//     float4 per thread and step, loaded one step ahead.
-//   * Two column blocks per step on two accumulators (a dependent MFMA chain with anything issued in between loses the
-//     accumulator forwarding); each accumulator is still ONE k-ascending fmaf chain from zero: bit-identical to gemm_nt_kernel.
-//   * Results leave as 16-byte stores of full 128-byte lines, transposed through a per-wavefront LDS patch: from the MFMA C
-//     layout a block is 16 dword store instructions, and the vector memory pipe takes ~100 cycles per store instruction.
-//     They are issued during the next step's MFMA groups.
-template <int KC>
-__global__ __launch_bounds__(512) void gemm_nt_astat_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Bm,
-                                                          int64_t ldb, int64_t M, int Nout, float* __restrict__ Cm, int64_t ldc) {
-    static_assert(KC == 128, "the chunk arithmetic below is written for KC = 128");
-    constexpr int CH = KC / 4;          // 16-byte chunks per B row (32)
-    constexpr int TILE_FL = 64 * KC;    // two column blocks of B
-    constexpr int NL = 64 * CH / 512;   // float4 loads per thread per step (4)
-    constexpr int LDP = 36;
-    extern __shared__ __attribute__((aligned(1024))) float smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 32;
-    const int nb = (Nout + 31) / 32, ns = (nb + 1) / 2;
-
-    // ---- B: this thread's chunks of a step (row c, k = 4 q .. 4 q + 3) and where their even / odd k pairs go in the tile image
-    //      [64 rows][half][64 floats]: pair (2 q, 2 q + 1) of half h' at float 128 c + 64 h' + 4 ((q / 2) ^ (c & 15)) + 2 (q & 1)
-    //      (the chunk swizzle makes ds_read_b128 of 16 consecutive rows conflict-free)
-    int bsrc[NL], bdst[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int L = i * 512 + threadIdx.x;
-        const int c = L / CH, q = L % CH;
-        bsrc[i] = c;
-        bdst[i] = 128 * c + 4 * ((q >> 1) ^ (c & 15)) + 2 * (q & 1);
-    }
-    const float* const bcol = Bm + 4 * (threadIdx.x % CH);
-    f32x4 bq[NL];
-    auto load_b = [&](int j) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int r = j * 64 + bsrc[i];
-            if (r > Nout - 1) r = Nout - 1;  // rows at or past Nout (last step): re-read row Nout - 1, never stored
-            bq[i] = *reinterpret_cast<const f32x4*>(bcol + (int64_t)r * ldb);
-        }
-    };
-    auto write_b = [&](int j) {
-        float* st = smem + (j & 1) * TILE_FL;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            *reinterpret_cast<HIP_vector_type<float, 2>*>(st + bdst[i]) = HIP_vector_type<float, 2>(bq[i].x, bq[i].z);
-            *reinterpret_cast<HIP_vector_type<float, 2>*>(st + bdst[i] + 64) = HIP_vector_type<float, 2>(bq[i].y, bq[i].w);
-        }
-    };
-    load_b(0);
-
-    // ---- A rows -> registers: a[s] = A[row][2 s + h]; both half-wavefronts read the row's float4 chunks and keep their parity
-    float a[KC / 2];
-    {
-        int64_t r = row0 + l31;
-        if (r > M - 1) r = M - 1;
-        const f32x4* srow = reinterpret_cast<const f32x4*>(A + r * lda);
-        f32x4 v[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) v[c] = srow[c];  // one round trip for the whole row
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            a[2 * c] = h ? v[c].y : v[c].x;
-            a[2 * c + 1] = h ? v[c].w : v[c].z;
-        }
-    }
-    write_b(0);
-    if (ns > 1) load_b(1);
-
-    // ---- results -> C: block transposed through the wavefront's LDS patch ([32][36] floats) into 4 float4 per lane (lane -> row
-    //      q / 8, columns 4 (q % 8) .., q = lane + 64 i): 4 store instructions of eight full 128-byte lines each
-    float* const patch = smem + 2 * TILE_FL + wave * (32 * LDP);
-    const bool vec_c = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(Cm) & 15) == 0;  // uniform
-    auto transpose_block = [&](const f32x16& v, f32x4 (&o)[4]) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * h) * LDP + l31] = v[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = lane + 64 * i;
-            o[i] = *reinterpret_cast<const f32x4*>(patch + (q >> 3) * LDP + 4 * (q & 7));
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto store_quarter = [&](const f32x4 (&o)[4], int jb, int i) {  // rows 8 i .. 8 i + 7 of block jb
-        const int q = lane + 64 * i;
-        const int64_t row = row0 + (q >> 3);
-        const int col = jb * 32 + 4 * (q & 7);
-        if (row >= M || col >= Nout) return;
-        float* p = Cm + row * ldc + col;
-        if (vec_c && col + 3 < Nout) {
-            *reinterpret_cast<f32x4*>(p) = o[i];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (col + e < Nout) p[e] = o[i][e];
-        }
-    };
-
-    f32x4 out0[4], out1[4];
-    const int fb = l31 * 128 + h * 64 + ((l31 & 15) << 2);  // this lane's float4 u of its B row (block 0 of a step): fb ^ (u << 2)
-    for (int j = 0; j < ns; ++j) {
-        __syncthreads();  // tile j is complete in LDS; every wavefront is done with the other stage (step j - 1)
-        if (j + 1 < ns) write_b(j + 1);
-        if (j + 2 < ns) load_b(j + 2);
-        const float* st = smem + (j & 1) * TILE_FL;
-        const bool two = 2 * j + 1 < nb;  // uniform: the last step of an odd block count holds one block
-        const bool flush = j > 0;         // uniform
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-        // per group u (4 MFMA steps x 2 blocks = 8 MFMAs): first MFMA pair, then the LDS reads of group u + 1 (the compiler waits
-        // for ALL outstanding LDS reads in front of a group's first use, so they must not be in flight before that point; behind
-        // the first pair they have 6 MFMAs to land), 6 MFMAs; during the first 8 groups one store instruction of the previous
-        // step's results each.  The fences keep the scheduler from undoing the order.
-        constexpr int NG = KC / 8;  // 16
-        f32x4 b0[2], b1[2];
-        b0[0] = *reinterpret_cast<const f32x4*>(st + fb);
-        if (two) b1[0] = *reinterpret_cast<const f32x4*>(st + 32 * 128 + fb);
-#pragma unroll
-        for (int u = 0; u < NG; ++u) {
-            const f32x4 x = b0[u & 1], y = b1[u & 1];
-            acc0 = mhgemm2::mfma32(a[4 * u], x.x, acc0);
-            if (two) acc1 = mhgemm2::mfma32(a[4 * u], y.x, acc1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < NG) {
-                b0[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(st + (fb ^ ((u + 1) << 2)));
-                if (two) b1[(u + 1) & 1] = *reinterpret_cast<const f32x4*>(st + 32 * 128 + (fb ^ ((u + 1) << 2)));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc0 = mhgemm2::mfma32(a[4 * u + 1], x.y, acc0);
-            if (two) acc1 = mhgemm2::mfma32(a[4 * u + 1], y.y, acc1);
-            acc0 = mhgemm2::mfma32(a[4 * u + 2], x.z, acc0);
-            if (two) acc1 = mhgemm2::mfma32(a[4 * u + 2], y.z, acc1);
-            acc0 = mhgemm2::mfma32(a[4 * u + 3], x.w, acc0);
-            if (two) acc1 = mhgemm2::mfma32(a[4 * u + 3], y.w, acc1);
-            if (flush && u < 8) {
-                if (u < 4) store_quarter(out0, 2 * j - 2, u);
-                else store_quarter(out1, 2 * j - 1, u - 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        transpose_block(acc0, out0);
-        if (two) transpose_block(acc1, out1);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) store_quarter(out0, 2 * ns - 2, i);
-    if (2 * ns - 1 < nb) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) store_quarter(out1, 2 * ns - 1, i);
-    }
-}
+// (An A-rows-stationary form of this product for the DLRM's first top-MLP layer -- gemm_nt_astat_kernel, rounds 3-5 -- was measured
+// faster alone and slower in every multi-stream step, and is gone: profiles/r3_notes.md, r3_astat_timeline_v*.txt.)
 
 // Split-M "TN" GEMM: part[s][K, N] = x[m in slice s][K]^T dz[m in slice s][N].
 // Both operands are staged n-major ([BK contraction rows][cols]); fragments are ds_read_b32.
@@ -530,24 +367,6 @@ int32_t mh_internal_gemm_nt_ep(const float* A, int64_t lda, const float* Bm, int
             mh_set_error("gemm_nt: launch failed: %s", hipGetErrorString(e));
             return MH_ERR_LAUNCH;
         }
-        return MH_OK;
-    }
-    // short contraction, wide output, a batch that gives every CU a 256-row workgroup: A rows stationary in registers.
-    // OPT-IN (MERLIN_HIP_ASTAT=1): alone it beats the tiled kernel (79.9 vs 95 us for dZ[65536, 128] W[415, 128]^T) and a step
-    // replayed as ONE graph gains 12 us, but its 256 persistent 512-thread workgroups (211 registers, 100 KB of LDS) leave no room
-    // on a CU for the dW GEMM that the eager / segmented step runs beside dX on a side stream: those steps LOSE 30-45 us
-    // (0.967 -> 1.012 ms eager, same box, four alternating runs each; profiles/r3_notes.md).
-    static const bool astat = getenv("MERLIN_HIP_ASTAT") != nullptr;
-    if (astat && !addend && (!maskx || x_act == MH_ACT_NONE) && Kc == 128 && vec_a && vec_b && Nout >= 128 && mh_ceil_div(M, 256) * 10 >= (int64_t)mh_num_cus() * 9) {
-        auto kern = gemm_nt_astat_kernel<128>;
-        const size_t lds = (size_t)(2 * 64 * 128 + 8 * 32 * 36) * sizeof(float);  // two B stages + one transpose patch per wavefront
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        MH_LAUNCH(kern, dim3((unsigned)mh_ceil_div(M, 256)), dim3(512), lds, s, A, lda, Bm, ldb, M, Nout, Cm, ldc);
-        MH_CHECK_LAUNCH("gemm_nt(astat)");
         return MH_OK;
     }
     if (Nout > 64) {

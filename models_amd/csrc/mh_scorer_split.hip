@@ -451,7 +451,7 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
     // MERLIN_HIP_SCORER_XT = 1 | 2 (experiments): 32-row blocks of X per wavefront (see the kernel)
     static int xt = -1;
     if (xt < 0) {
-        const char* e = getenv("MERLIN_HIP_SCORER_XT");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_SCORER_XT");
         xt = (e && atoi(e) == 2) ? 2 : 1;
     }
     if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1>(a, ids_dtype, grid, s);

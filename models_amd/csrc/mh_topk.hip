@@ -876,7 +876,7 @@ SplitPlan make_split_plan(int64_t Bq, int64_t N, int k, int E) {
         // The dense bootstrap only has to hand the filter stages a first threshold: 16 k' candidates (2048 at k = 100) instead of
         // the fp32 pipeline's 128 MiB chunk -- the streaming select costs ~0.5 us per list insertion, the filter stages that take
         // over the difference run at the bf16 rate.  MERLIN_HIP_TOPK_N0 overrides (experiments).
-        const char* e = getenv("MERLIN_HIP_TOPK_N0");
+        const char* e = MH_LAB_ENV("MERLIN_HIP_TOPK_N0");
         int64_t n0 = e ? atoll(e) : 16 * (int64_t)p.kp;
         if (n0 < 16 * (int64_t)p.kp) n0 = 16 * (int64_t)p.kp;
         n0 = (n0 + 127) / 128 * 128;
@@ -1003,10 +1003,10 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
         attr_done = true;
     }
     const int nqb = (int)mh_ceil_div(Bq, SX_QB);
-    const char* senv = getenv("MERLIN_HIP_TOPK_SPLITS");
-    const char* genv = getenv("MERLIN_HIP_TOPK_GROWTH");
+    const char* senv = MH_LAB_ENV("MERLIN_HIP_TOPK_SPLITS");
+    const char* genv = MH_LAB_ENV("MERLIN_HIP_TOPK_GROWTH");
     int growth = genv ? atoi(genv) : 4;
-    const char* menv = getenv("MERLIN_HIP_TOPK_XCD_MAP");
+    const char* menv = MH_LAB_ENV("MERLIN_HIP_TOPK_XCD_MAP");
     const int xcd_map = menv ? atoi(menv) : 0;  // measured: the plain order (query block fastest) is 3 % faster than one-split-per-XCD
     if (growth < 2) growth = 2;
     int64_t beg = p.f.n0;

@@ -91,7 +91,7 @@ class Model(Block):
         ``evaluate`` / ``predict`` / ``save_weights``) everything outstanding is flushed, the weights are then bit-identical to
         un-pipelined steps.  Only with SGD / Adagrad at a constant learning rate on one rank (a schedule, Adam's step counter or a
         dense all-reduce would have to travel with the deferred update); otherwise the context changes nothing.
-        OPT-IN (``MERLIN_HIP_DW_DEFER=1``; ``fit`` enters the context for its eager steps): measured SLOWER on MI355X -- beside
+        OPT-IN by entering the context (``fit`` does not): measured SLOWER on MI355X -- beside
         the deferred GEMM (84 us alone, 219 us there) the gather -> interaction kernel takes 197 us instead of 98: the two do not
         overlap, they share the CUs (1.028 vs 0.963 ms per step, profiles/r5_step_timeline_pipelined.txt)."""
         model = self
@@ -100,7 +100,7 @@ class Model(Block):
             def __enter__(self_):
                 opt = model.optimizer
                 ok = (opt is not None and opt.name in ("sgd", "adagrad") and getattr(opt, "lr_device", None) is None
-                      and getattr(model, "loss_grad_divisor", 1) == 1 and os.environ.get("MERLIN_HIP_DW_DEFER", "0") == "1")
+                      and getattr(model, "loss_grad_divisor", 1) == 1)
                 self_.blocks = model._pipeline_blocks() if ok else []
                 for b in self_.blocks:
                     b.pipeline_dw = opt
@@ -313,13 +313,11 @@ class Model(Block):
             ok = all(isinstance(v, torch.Tensor) and v.is_cuda for v in x.values())
             return ok and (y is None or isinstance(y, torch.Tensor)) and self.graph_capturable
 
-        pipe = self.pipelined_updates()  # eager steps run software-pipelined (flushed before a replay and at the end)
-        pipe.__enter__()
         try:
             return self._fit_loop(batches, epochs, steps_per_epoch, graph, Step, history, probe, probe_tick, pack, eager, can_graph,
                                   lambda: prefer_eager)
         finally:
-            pipe.__exit__(None, None, None)
+            self.flush_deferred()  # a caller's own `with model.pipelined_updates():` around fit leaves nothing pending
 
     def _fit_loop(self, batches, epochs, steps_per_epoch, graph, Step, history, probe, probe_tick, pack, eager, can_graph, prefer_eager_fn):
         graphed, sig = None, None

@@ -228,10 +228,7 @@ class _SideStreams:
         dev = torch.cuda.current_device()
         st = self._streams.get((dev, name))
         if st is None:
-            # MERLIN_HIP_SIDE_PRIORITY=-1: a high-priority HIP stream for the side work (experiments; 0 = default priority)
-            import os as _os
-
-            st = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("MERLIN_HIP_SIDE_PRIORITY", "0")))
+            st = torch.cuda.Stream(device=dev)  # default priority (a high-priority side stream was measured: no gain, profiles/r4_ab_side_streams.txt)
             self._streams[(dev, name)] = st
         return st
 
@@ -643,11 +640,9 @@ class _TailWork:
 
         # Parking moves two small launches behind the sparse hand-off.  Measured (round 4, alternating runs on one box each): it LOSES
         # ~20 us in the eager step (0.945 -> 0.966 ms) and in the C-recorded replay (0.958 -> 0.976), and WINS ~10 us when the step is
-        # replayed as hipGraph segments (segmented 0.977 -> 0.967).  So: on while a step is stream-captured, off otherwise;
-        # MERLIN_HIP_TAIL=0 / 1 forces it.
-        env = _os.environ.get("MERLIN_HIP_TAIL")
+        # replayed as hipGraph segments (segmented 0.977 -> 0.967).  So: on while a step is stream-captured, off otherwise.
         replayed = SIDE.recorder is not None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
-        TAIL[0] = [] if (env == "1" or (env is None and replayed)) else None
+        TAIL[0] = [] if replayed else None
         return self
 
     def __exit__(self, *exc):

@@ -59,3 +59,32 @@ def test_every_exported_entry_point_is_named_in_the_integration_guide():
     syms = sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", header)))
     assert len(syms) >= 60
     assert [s for s in syms if s not in guide] == []
+
+
+def test_environment_switches_are_exactly_the_documented_ones():
+    """Round-5 review, item 7: every environment variable the shipped library (`getenv` in csrc/) or the package (`MERLIN_HIP_*` in
+    models_amd/*.py) reads is a row of README.md's switch table and vice versa; at most 20 of them; lab knobs (MH_LAB_ENV) are constant
+    nullptr without -DMH_LAB and must not appear in the table; no wrong-results ablation is reachable in the shipped build."""
+    csrc = ROOT / "models_amd" / "csrc"
+    read_by_lib, lab = set(), set()
+    for p in list(csrc.glob("*.hip")) + list(csrc.glob("*.h")):
+        text = re.sub(r"//[^\n]*", "", p.read_text())
+        read_by_lib |= set(re.findall(r'(?<![A-Z_])getenv\("([A-Z0-9_]+)"\)', text))
+        lab |= set(re.findall(r'MH_LAB_ENV\("([A-Z0-9_]+)"\)', text))
+    read_by_py = set()
+    for p in (ROOT / "models_amd").glob("*.py"):
+        read_by_py |= set(re.findall(r"MERLIN_HIP_[A-Z0-9_]+", p.read_text()))
+    readme = (ROOT / "README.md").read_text()
+    table = set()
+    for line in readme.splitlines():
+        if line.startswith("| `MERLIN_HIP_"):
+            table |= set(re.findall(r"MERLIN_HIP_[A-Z0-9_]+", line.split("|")[1]))
+    shipped = read_by_lib | read_by_py
+    assert shipped == table, (sorted(shipped - table), sorted(table - shipped))
+    assert len(shipped) <= 20, sorted(shipped)
+    assert not (lab & table) and not (lab & shipped), sorted(lab & (table | shipped))
+    assert "MERLIN_HIP_GEMM_SPLIT_ABLATE" in lab  # the wrong-results timing switch exists in lab builds only
+    common = (csrc / "mh_common.h").read_text()
+    assert "#ifdef MH_LAB" in common and "static_cast<const char*>(nullptr)" in common
+    for gone in ("MERLIN_HIP_DW_LATE", "MERLIN_HIP_DW_DEFER", "MERLIN_HIP_ASTAT", "MERLIN_HIP_SIDE_PRIORITY", "MERLIN_HIP_TAIL"):
+        assert gone not in shipped and gone not in lab, gone

@@ -71,12 +71,9 @@ def test_dot_interaction_backward(device, F, D, with_tail):
         assert torch.equal(dx2, dx)
 
 
-@pytest.mark.parametrize("sort", ["classic", "lookback"])
 @pytest.mark.parametrize("opt", ["sgd", "adagrad"])
 @pytest.mark.parametrize("idt", [torch.int32, torch.int64])
-def test_embedding_backward_dedup_and_optimizers(device, opt, idt, sort, monkeypatch):
-    # sort = lookback: the opt-in second pass without its own histogram / scan launches (MERLIN_HIP_SORT=lookback)
-    monkeypatch.setenv("MERLIN_HIP_SORT", sort)
+def test_embedding_backward_dedup_and_optimizers(device, opt, idt):
     g = torch.Generator().manual_seed(5)
     rows = [4, 1000, 37, 50000]  # tiny tables -> very long duplicate runs crossing many chunks
     B, D, S = 3001, 64, 6

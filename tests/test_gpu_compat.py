@@ -106,7 +106,8 @@ def test_v1_item_retrieval_scorer_sampled_softmax_mode(device):
     got = pred.outputs.cpu().numpy()
     assert got.shape == (50, 21) and np.array_equal(pred.targets.cpu().numpy()[:, 0], np.ones(50))
     np.testing.assert_allclose(got, want, atol=1e-4)
-    assert (got[:, 1:][t[:, None] == nid[None, :]] < -1e30).all() and (t[:, None] == nid[None, :]).any()   # sampled positives are downscored
+    hit = t[:, None] == nid[None, :]
+    assert hit.any() and np.allclose(got[:, 1:][hit], mm.outputs.MIN_FLOAT)   # sampled positives are downscored (utils/constants.py:19)
     with pytest.raises(ValueError, match="item_table"):
         mm.ItemRetrievalScorer(samplers=[sampler], sampled_softmax_mode=True)
     with pytest.raises(ValueError, match="sampler"):
@@ -122,6 +123,7 @@ def test_v1_item_retrieval_scorer_downscores_by_the_named_feature_by_default(dev
     assert out.downscore_false_negatives
     pred = out({"query": q, "item": c}, features={"sku": ids}, training=True)
     lg = pred.outputs.cpu().numpy()
-    assert lg.shape == (8, 9) and lg[0, 1 + 2] < -1e30 and lg[2, 1 + 0] < -1e30 and lg[1, 1 + 5] < -1e30 and lg[0, 1 + 1] > -1e30
+    mf = mm.outputs.MIN_FLOAT
+    assert lg.shape == (8, 9) and np.isclose(lg[0, 1 + 2], mf) and np.isclose(lg[2, 1 + 0], mf) and np.isclose(lg[1, 1 + 5], mf) and lg[0, 1 + 1] > -100
     with pytest.raises(ValueError):
         out({"query": q, "item": c}, features={}, training=True)

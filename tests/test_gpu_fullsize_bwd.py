@@ -244,45 +244,3 @@ def test_c4_table_above_4gb_gather_and_adagrad(device, idt):
         touched = torch.zeros(v, dtype=torch.bool, device=device)
         touched[ut] = True
         assert torch.equal((tabs[f] != tabs0[f]).any(dim=1) | (acc[f] != acc0[f]).any(dim=1), touched), f
-
-
-def test_c2_top_layer_dx_rows_stationary_kernel_equals_the_tiled_kernels(device, tmp_path):
-    """dX of a Dense layer with N = 128 outputs at a batch that fills the chip (the DLRM's first top-MLP layer: K = 415 inputs) can run
-    the A-rows-stationary kernel (gemm_nt_astat_kernel, opt-in: MERLIN_HIP_ASTAT=1 -- it loses beside the side-stream dW GEMM, see the
-    dispatch comment).  One k-ascending fmaf chain per output either way: bit-identical to the tiled kernels of the default path,
-    including the ragged last row block and the ragged last column block; checked against the definition on a row sample."""
-    import os
-    import subprocess
-    import sys
-    import textwrap
-
-    code = textwrap.dedent("""
-        import sys, torch
-        from models_amd import ops
-        out = []
-        for K in (415, 416, 160):
-            g = torch.Generator().manual_seed(K)
-            M, N = 65536 + 77, 128
-            ld = (K + 3) // 4 * 4
-            x = torch.randn(M, ld, generator=g).cuda()[:, :K]
-            W = (torch.randn(K, N, generator=g) * 0.1).cuda()
-            dy = torch.randn(M, N, generator=g).cuda()
-            y = ops.linear(x, W, None, "relu")
-            dx, dW, db = ops.linear_backward(x, W, y, dy.clone(), "relu")
-            idx = torch.randint(0, M, (512,), generator=g).cuda()
-            dz = (dy * (y > 0)).double()
-            torch.testing.assert_close(dx[idx].double(), dz[idx] @ W.double().t(), atol=1e-4, rtol=1e-5)
-            out.append(dx.cpu())
-        torch.save(out, sys.argv[1])
-    """)
-    res = []
-    for on in (False, True):
-        env = dict(os.environ)
-        env.pop("MERLIN_HIP_ASTAT", None)
-        if on:
-            env["MERLIN_HIP_ASTAT"] = "1"
-        f = tmp_path / f"dx_{int(on)}.pt"
-        subprocess.run([sys.executable, "-c", code, str(f)], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
-        res.append(torch.load(f))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)

@@ -877,7 +877,6 @@ def test_pipelined_train_steps_equal_plain_steps_bit_for_bit(device, optimizer, 
     state tensor equals the un-pipelined run BIT FOR BIT; an evaluate in the middle sees flushed weights; with Adam (step counter)
     the context changes nothing."""
     monkeypatch.setenv("MERLIN_HIP_DETERMINISTIC", "1")
-    monkeypatch.setenv("MERLIN_HIP_DW_DEFER", "1")  # opt-in (measured slower on MI355X: Model.pipelined_updates)
     # 12 + 1 stacked features of width 64: the first top layer reads 78 + 64 = 142 columns -- too wide for the fused MLP chain, so it
     # is a layer of its own with its own dW GEMM (as the 415 -> 128 layer of configs[1] is)
     cards = {f"C{j}": v for j, v in enumerate([5000, 7, 300, 50, 1000, 3, 64, 900, 12, 4000, 33, 256], 1)}
@@ -921,9 +920,9 @@ def test_pipelined_train_steps_equal_plain_steps_bit_for_bit(device, optimizer, 
         assert torch.equal(pa.data, pb.data), pa.name
         for k in pa.state:
             assert torch.equal(pa.state[k], pb.state[k]), (pa.name, k)
-    # fit() pipelines its eager steps and leaves nothing behind
-    h = b.fit(batches, epochs=1, graph=False)
-    monkeypatch.setenv("MERLIN_HIP_DW_DEFER", "0")  # the plain loop for the twin
+    # fit() inside a caller's context runs pipelined eager steps and leaves nothing behind
+    with b.pipelined_updates():
+        h = b.fit(batches, epochs=1, graph=False)
     a_h = a.fit(batches, epochs=1, graph=False)
     assert h["loss"] == a_h["loss"] and getattr(dlrm[0], "_deferred", None) is None
     for pa, pb in zip(a.parameters(), b.parameters()):
