@@ -30,6 +30,7 @@
 
 #include "mh_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -54,10 +55,13 @@ struct BwdArgs {
 // p of feature f reads gradient row map[f * map_stride + p] (its BAG) and divides it by scale[f * scale_stride + row] (the bag's
 // combiner divisor) -- exactly the value bag_expand_kernel would have materialised, without the nnz x D round trip through HBM.
 struct GradMap {
-    const int32_t* map;  // nullptr: identity (one-hot lookups)
+    const int32_t* map;  // handed to the SORT as its payload (SortArgs::pmap: the sorted payload of an entry is its bag); nullptr: one-hot lookups
     int64_t map_stride;
-    const float* scale;
-    int64_t scale_stride;
+    // multi != 0: the gradient handed to the pipeline is the PRE-SCALED, FEATURE-MAJOR copy gs[f][bag][D] = grad[bag][f] / divisor(f, bag)
+    // (bag_prescale_kernel: one division per gradient element, where round 5 divided per VALUE -- 20 x more divisions, ~0.5 ms of the
+    // reduce kernel's 3.4 -- and read the divisor with a scattered load per value): row stride D, a.offset[f] = f * B * D.
+    int multi;
+    int64_t bags;  // multi: rows of one feature's block of the gradient copy (the walk kernel forms bag * D in 32 bits where that fits)
 };
 
 // ---- segmented LSD radix sort ---------------------------------------------------------------------------------------
@@ -75,6 +79,12 @@ struct SortArgs {
     int npass[MAX_SEG];                // passes this segment needs (its key bits / the digit widths); later passes skip it
     int nseg;
     int64_t B;
+    // Optional PAYLOAD of the sort (multi-hot lookups): entry b of feature f carries (f << 26 | pmap[f * pmap_stride + b]) -- its BAG -- instead
+    // of (f << 26 | b).  Read coalesced, once, where pass 0 forms its pairs; the kernels behind the sort then find the gradient row of
+    // an entry in the sorted payload itself (round 5 carried the position and looked the bag up per entry in the reduce kernel: 34 M
+    // scattered 4-byte loads, one more link in its dependent chain).  The sort is stable: the order inside a run is the same either way.
+    const int32_t* pmap;
+    int64_t pmap_stride;
 };
 
 __device__ __forceinline__ int seg_of_tile(const SortArgs& a, int tile) {
@@ -152,7 +162,9 @@ struct Pass0 {
     }
     __device__ __forceinline__ uint32_t val(const SortArgs& a, int s, int it, int lane) const {
         if (one) return ((uint32_t)feat << 26) | (uint32_t)(b0 + it * 64 + lane);
-        return ((uint32_t)(a.seg_f0[s] + pos.fo) << 26) | (uint32_t)pos.b;
+        const int f = a.seg_f0[s] + (int)pos.fo;
+        if (a.pmap) return ((uint32_t)f << 26) | (uint32_t)a.pmap[(int64_t)f * a.pmap_stride + pos.b];
+        return ((uint32_t)f << 26) | (uint32_t)pos.b;
     }
     __device__ __forceinline__ void next(const SortArgs& a) {
         if (!one) pos.advance(64, a.B);
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const SortArgs a, const
         const int64_t end = beg + per < clear_vec ? beg + per : clear_vec;
         for (int64_t i = beg + threadIdx.x; i < end; i += 256) clear[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0u;
+    if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) clear_word[0] = clear_word[1] = 0u;  // piece counters (whole / partial, see piece_list_kernel)
     if (pass >= a.npass[s]) return;  // this segment is already sorted
     // input of pass p = output of pass p - 1 (see radix_scatter_kernel for the buffer parity)
     const uint32_t* keys_in = static_cast<const uint32_t*>(((a.npass[s] - pass) & 1) ? keys0 : keys1);
@@ -418,13 +430,29 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const SortArgs a, in
     const int64_t nw = n_s - e0;  // entries of this wavefront (<= 0: none)
     if (pass == 0 && p0.one) {  // wave-uniform; loads first, branch-free (see Pass0::raw)
         IdT r[RITEMS];
+        const int nwi = (int)(nw < RTILE / 4 ? nw : RTILE / 4);
 #pragma unroll
-        for (int it = 0; it < RITEMS; ++it) r[it] = p0.raw(it, lane, (int)(nw < RTILE / 4 ? nw : RTILE / 4));
+        for (int it = 0; it < RITEMS; ++it) r[it] = p0.raw(it, lane, nwi);
+        if (a.pmap) {  // kernel-uniform: the payload is the entry's bag (SortArgs::pmap), loaded like the ids -- all up front, branch-free
+            const int32_t* pm = a.pmap + (int64_t)p0.feat * a.pmap_stride + p0.b0;
+            int32_t m[RITEMS];
+#pragma unroll
+            for (int it = 0; it < RITEMS; ++it) {
+                int i = it * 64 + lane;
+                if (i > nwi - 1) i = nwi - 1;
+                m[it] = pm[i];
+            }
+#pragma unroll
+            for (int it = 0; it < RITEMS; ++it) val[it] = ((uint32_t)p0.feat << 26) | (uint32_t)m[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < RITEMS; ++it) val[it] = p0.val(a, s, it, lane);
+        }
 #pragma unroll
         for (int it = 0; it < RITEMS; ++it) {
             const bool live = it * 64 + lane < nw;
             key[it] = live ? p0.finish(a, s, r[it]) : 0u;
-            val[it] = live ? p0.val(a, s, it, lane) : 0u;
+            if (!live) val[it] = 0u;
         }
     } else if (pass > 0 && nw > 0) {  // wave-uniform
         uint2 kv[RITEMS];
@@ -648,11 +676,17 @@ __device__ __forceinline__ void finish_row(RowRmw& r, f32x4 g, int opt, const Op
 // bump per 256 entries cost 79 us for 1.7M entries); the list is ordered inside a workgroup, unordered across.
 constexpr int LIST_TILES = 8;
 
-template <typename KeyT>
+// SPLIT (the multi-hot update): the list comes in TWO regions of the same array -- pieces that are a whole run (applied to their table row
+// directly) from the front, counter[0] of them; pieces of runs that cross a chunk boundary from the BACK (logical index q at cap - 1 - q),
+// counter[1] of them -- so that each kind is walked by a kernel that holds nothing of the other's state in registers.
+template <typename KeyT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, const KeyT* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals, int64_t n,
                                                          ulonglong2* __restrict__ pieces, int* __restrict__ home,
-                                                         unsigned int* __restrict__ counter) {
+                                                         unsigned int* __restrict__ counter, int64_t cap = 0) {
+    __shared__ unsigned int wave_cnt_w[LIST_TILES][4];  // SPLIT: whole pieces of (tile, wave)
+    __shared__ unsigned int block_base_p;
+    unsigned int rank_w[LIST_TILES];
     constexpr KeyT SENT = KeyTraits<KeyT>::sentinel;
     __shared__ unsigned int wave_cnt[LIST_TILES][4];
     __shared__ int64_t wave_last_start[LIST_TILES][4];  // last run start inside (tile, wave), -1 if none
@@ -752,17 +786,27 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
     }
 #pragma unroll
     for (int t = 0; t < LIST_TILES; ++t) {
+        const bool ends = (pe[t] >= n) || (ke[t] != kk[t]);
         if (pcut[t]) {
             const int64_t i = w0 + t * 256 + threadIdx.x;
-            const bool ends = (pe[t] >= n) || (ke[t] != kk[t]);
             rec[t] = (uint64_t)i | ((uint64_t)plen[t] << 32) | ((uint64_t)(pstart[t] ? 1 : 0) << 37) |
                      ((uint64_t)(ends ? 1 : 0) << 38) | ((uint64_t)(pv[t] >> 26) << 39) | (1ull << 63);
+        }
+        if (SPLIT) {
+            const uint64_t wh = __ballot(pcut[t] && pstart[t] && ends);
+            rank_w[t] = __popcll(wh & lt_mask);
+            if (lane == 0) wave_cnt_w[t][wave] = __popcll(wh);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned int tot = 0;
+        unsigned int tot = 0, tot_w = 0;
         for (int t = 0; t < LIST_TILES; ++t) tot += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
+        if (SPLIT) {
+            for (int t = 0; t < LIST_TILES; ++t) tot_w += wave_cnt_w[t][0] + wave_cnt_w[t][1] + wave_cnt_w[t][2] + wave_cnt_w[t][3];
+            block_base = tot_w ? atomicAdd(counter, tot_w) : 0u;
+            block_base_p = (tot - tot_w) ? atomicAdd(counter + 1, tot - tot_w) : 0u;
+        } else
         block_base = tot ? atomicAdd(counter, tot) : 0u;
         int64_t run = pre_start;
         for (int t = 0; t < LIST_TILES; ++t)
@@ -772,18 +816,32 @@ __global__ __launch_bounds__(256) void piece_list_kernel(const SortArgs sa, cons
             }
     }
     __syncthreads();
-    unsigned int o = block_base;
+    unsigned int o = block_base, op = SPLIT ? block_base_p : 0u;
 #pragma unroll
     for (int t = 0; t < LIST_TILES; ++t) {
-        unsigned int before = 0;
+        unsigned int before = 0, before_w = 0;
         for (int w = 0; w < wave; ++w) before += wave_cnt[t][w];
+        if (SPLIT)
+            for (int w = 0; w < wave; ++w) before_w += wave_cnt_w[t][w];
         if (rec[t]) {
-            const unsigned int p = o + before + rank[t];
+            int64_t p = (int64_t)o + before + rank[t];
+            if (SPLIT) {
+                const bool whole = ((rec[t] >> 37) & 3) == 3;
+                // a partial piece's rank among the partial pieces = its rank among all pieces - its rank among the whole ones
+                p = whole ? (int64_t)o + before_w + rank_w[t] : cap - 1 - ((int64_t)op + (before - before_w) + (rank[t] - rank_w[t]));
+            }
             pieces[p] = make_ulonglong2(rec[t], (uint64_t)kk[t]);
             const int64_t st = (my_start[t] >= 0) ? my_start[t] : start_before[t][wave];
             home[p] = (int)(st / CHUNK);
         }
-        o += wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
+        const unsigned int all = wave_cnt[t][0] + wave_cnt[t][1] + wave_cnt[t][2] + wave_cnt[t][3];
+        if (SPLIT) {
+            const unsigned int allw = wave_cnt_w[t][0] + wave_cnt_w[t][1] + wave_cnt_w[t][2] + wave_cnt_w[t][3];
+            o += allw;
+            op += all - allw;
+        } else {
+            o += all;
+        }
     }
 }
 
@@ -843,17 +901,12 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
     constexpr uint32_t PMASK = (1u << 26) - 1;
     // multi-hot lookups: the position of an entry is replaced by its gradient row (bag) where the entry is fetched from the sorted
     // list -- one iteration ahead of its use in VMODE 1 -- so that the row loads below keep their chain length
-    auto remap = [&](uint32_t v) -> uint32_t {
-        if (!RUNS) return v;
-        return (v & ~PMASK) | (uint32_t)gm.map[(int64_t)(v >> 26) * gm.map_stride + (v & PMASK)];
-    };
+    // (multi-hot lookups: the sorted payload already IS the bag -- SortArgs::pmap)
+    auto remap = [&](uint32_t v) -> uint32_t { return v; };
     auto row = [&](uint32_t v) -> f32x4 {
         const int f = (int)(v >> 26);
-        if (RUNS) {  // bag gradients are re-read by every value of the bag: cached loads, divided by the bag's divisor
-            const f32x4 g = *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & PMASK) * grad_row_stride + feat[f].offset + c4 * 4);
-            const float dv = gm.scale[(int64_t)f * gm.scale_stride + (v & PMASK)];
-            return g / dv;
-        }
+        if (RUNS)  // bag gradients (pre-scaled, GradMap::multi) are re-read by every value of the bag: cached loads
+            return *reinterpret_cast<const f32x4*>(grad + (int64_t)(v & PMASK) * grad_row_stride + feat[f].offset + c4 * 4);
         // gradient rows are read exactly once: streaming loads (the table / state rows of hot ids stay cached)
         return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + (int64_t)(v & PMASK) * grad_row_stride +
                                                                          feat[f].offset + c4 * 4));
@@ -990,6 +1043,179 @@ __global__ __launch_bounds__(256) void piece_reduce_apply_kernel(const BwdArgs a
     }
 }
 
+// The MULTI-HOT update (GradMap::multi; D / 4 in {16, 32, 64}).  Round 5 ran piece_reduce_apply_kernel<1, 1> here: 3.45 ms for 34 M values
+// in 6.5 M pieces, 0.15 of the HBM peak for the whole update.  What the round-6 ablations showed (tools/gpu_bag_ablate.sh, profiles/r6_notes.md):
+// removing the workgroup barrier of that kernel and putting all 16 rows of a piece in flight changed nothing -- with EVERY memory access and
+// every division switched off the loop still took half its time: it was bound by the instructions issued per value (a shuffle for the payload
+// and one for the divisor, 64-bit address arithmetic, four IEEE divisions, 32 divergent branch regions per piece).  Hence:
+//   * the gradient arrives PRE-SCALED and feature-major (bag_prescale_kernel): no divisor, no division, a 32-bit row offset;
+//   * the payload IS the bag (SortArgs::pmap): no per-entry map lookup;
+//   * the trip count of the row loop is the WAVE-UNIFORM maximum of the piece lengths of the wavefront's lane groups (one scalar branch per
+//     NR rows; a group whose piece is shorter predicates its loads): every shuffle source is active, no divergent branch regions;
+//   * the list comes SPLIT (piece_list_kernel<SPLIT>) and each half has its own kernel: the whole-run pieces (the 1-2-value runs of the large
+//     tables: 4.7 of the 6.5 M pieces, each a read-modify-write of a table and a state row) need many wavefronts in flight and little else;
+//     the pieces of crossing runs (the long runs of the small tables) need 16 gradient rows in flight and the run's partial sum in registers.
+//     One kernel for both held the registers of both (166: three wavefronts per SIMD) everywhere.
+// Whole pieces are summed in sorted order, one chain, over the same quotients as before: bit-identical to the round-5 kernel in
+// deterministic mode (where crossing runs are left to carry_apply_kernel's ordered walk).
+template <int NR>
+__global__ __launch_bounds__(256, 5) void piece_whole_apply_kernel(const BwdArgs a, const uint32_t* __restrict__ vals, int D, int LPR,
+                                                               const float* __restrict__ grad, const ulonglong2* __restrict__ pieces,
+                                                               const unsigned int* __restrict__ counter, int opt, const OptHyper hp) {
+    __shared__ FeatRow feat[MH_MAX_FEATURES];
+    if (threadIdx.x < MH_MAX_FEATURES) {
+        const int f = threadIdx.x;
+        feat[f].table = a.table[f];
+        feat[f].state = a.state[f];
+        feat[f].state2 = a.state2[f];
+        feat[f].first = a.first[f];
+        feat[f].offset = a.offset[f];
+    }
+    __syncthreads();
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    const int glane0 = (int)(threadIdx.x & 63) - c4;
+    const int64_t np = (int64_t)counter[0];
+    constexpr uint32_t PMASK = (1u << 26) - 1;
+    const ulonglong2 none = make_ulonglong2(0ull, ~0ull);
+    // iteration `it` of this workgroup takes `groups` neighbouring pieces (coalesced records); grid-stride over iterations
+    auto piece_of = [&](int64_t it) -> int64_t { return (it * gridDim.x + blockIdx.x) * groups + gi; };
+    auto rec_at = [&](int64_t q) -> ulonglong2 { return q < np ? pieces[q] : none; };
+    auto vals_of = [&](const ulonglong2& r) -> uint32_t {
+        return (c4 < (int)((r.x >> 32) & 31)) ? vals[(int64_t)(r.x & 0xffffffffull) + c4] : 0u;
+    };
+    ulonglong2 r0 = rec_at(piece_of(0)), r1 = rec_at(piece_of(1)), r2 = rec_at(piece_of(2));
+    uint32_t v0 = vals_of(r0), v1 = vals_of(r1);
+    const uint32_t Du = (uint32_t)D;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t it = 0; (it * gridDim.x + blockIdx.x) * groups < np; ++it) {  // workgroup-uniform
+        const uint64_t rec = r0.x, key = r0.y;
+        const uint32_t myv = v0;
+        r0 = r1; r1 = r2; r2 = rec_at(piece_of(it + 3));
+        v0 = v1; v1 = vals_of(r1);
+        const int len = (int)((rec >> 32) & 31);
+        const int l0 = __builtin_amdgcn_readlane(len, 0), l1 = __builtin_amdgcn_readlane(len, 16), l2 = __builtin_amdgcn_readlane(len, 32),
+                  l3 = __builtin_amdgcn_readlane(len, 48);
+        const int m01 = l0 > l1 ? l0 : l1, m23 = l2 > l3 ? l2 : l3;
+        const int maxlen = m01 > m23 ? m01 : m23;  // wave-uniform (scalar)
+        if (maxlen == 0) continue;
+        const int fk = (int)((rec >> 39) & 63);
+        RowRmw rr;
+        if (len > 0) load_row(feat[fk], (int64_t)key, D, c4, opt, rr);  // independent of the gradient rows: overlaps them
+        const float* gbase = grad + feat[fk].offset + c4 * 4;
+        f32x4 acc = zero;
+        for (int i = 0; i < maxlen; i += NR) {
+            f32x4 q[NR];
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const uint32_t v = (uint32_t)__shfl((int)myv, glane0 + ((i + u) & 15));
+                q[u] = zero;
+                if (i + u < len) q[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)((v & PMASK) * Du));
+            }
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+                if (i + u < len) acc += q[u];  // sorted order, one chain; rows past the piece's end are skipped, not added (x + 0 is not x for -0)
+        }
+        if (len > 0) finish_row(rr, acc, opt, hp);
+    }
+}
+
+// the pieces of runs that cross a chunk boundary: a lane group WALKS ITS OWN contiguous stretch of T pieces (no LDS, no barrier after the feature
+// table is staged); the partial sums of a run are carried IN REGISTERS along the stretch and leave as ONE set of float atomics when the run ends,
+// another run begins, or the stretch ends (the list is ordered inside a piece_list window only: continuation is decided by the KEY); record
+// (+ home chunk) three pieces ahead, the piece's <= 16 payloads two ahead.  Logical piece q lies at pieces[cap - 1 - q] (piece_list_kernel<SPLIT>).
+template <int NR>
+__global__ __launch_bounds__(256) void piece_partial_walk_kernel(const BwdArgs a, const uint32_t* __restrict__ vals, int D, int LPR,
+                                                                const float* __restrict__ grad, float* __restrict__ carry,
+                                                                const int* __restrict__ home, const ulonglong2* __restrict__ pieces,
+                                                                const unsigned int* __restrict__ counter, int64_t cap, int T) {
+    __shared__ int64_t foff[MH_MAX_FEATURES];
+    if (threadIdx.x < MH_MAX_FEATURES) foff[threadIdx.x] = a.offset[threadIdx.x];
+    __syncthreads();
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    const int glane0 = (int)(threadIdx.x & 63) - c4;
+    const int64_t np = (int64_t)counter[1];
+    // stretches of the wavefront's groups: a group past the list's end keeps running with empty pieces (wave-uniform control flow below)
+    const int64_t p_begin = ((int64_t)blockIdx.x * groups + gi) * T;
+    const int64_t wave_begin = ((int64_t)blockIdx.x * groups + (gi - (glane0 / LPR))) * T;  // first group of this wavefront
+    if (wave_begin >= np) return;  // the whole wavefront has nothing
+    const int64_t p_end = (p_begin + T < np) ? p_begin + T : (p_begin < np ? np : p_begin);
+    constexpr uint32_t PMASK = (1u << 26) - 1;
+    auto add_carry = [&](int hm, const f32x4 sum) {
+        float* cr = carry + (int64_t)hm * D + c4 * 4;
+        atomicAdd(cr + 0, sum.x);
+        atomicAdd(cr + 1, sum.y);
+        atomicAdd(cr + 2, sum.z);
+        atomicAdd(cr + 3, sum.w);
+    };
+    const ulonglong2 none = make_ulonglong2(0ull, ~0ull);
+    auto rec_at = [&](int64_t q) -> ulonglong2 { return q < p_end ? pieces[cap - 1 - q] : none; };
+    auto home_at = [&](int64_t q) -> int { return q < p_end ? home[cap - 1 - q] : 0; };
+    auto vals_of = [&](const ulonglong2& r) -> uint32_t {
+        return (c4 < (int)((r.x >> 32) & 31)) ? vals[(int64_t)(r.x & 0xffffffffull) + c4] : 0u;
+    };
+    ulonglong2 r0 = rec_at(p_begin), r1 = rec_at(p_begin + 1), r2 = rec_at(p_begin + 2);
+    int h0 = home_at(p_begin), h1 = home_at(p_begin + 1), h2 = home_at(p_begin + 2);
+    uint32_t v0 = vals_of(r0), v1 = vals_of(r1);
+    f32x4 run_sum = {0.f, 0.f, 0.f, 0.f};
+    uint64_t run_key = ~0ull;  // ~0: no run is open
+    int run_home = 0;
+    const uint32_t Du = (uint32_t)D;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < T; ++j) {  // wave-uniform trip count; a group past its stretch sees records of length 0
+        const int64_t p = p_begin + j;
+        const uint64_t rec = r0.x, key = r0.y;
+        const int hm = h0;
+        const uint32_t myv = v0;
+        r0 = r1; r1 = r2; r2 = rec_at(p + 3);
+        h0 = h1; h1 = h2; h2 = home_at(p + 3);
+        v0 = v1; v1 = vals_of(r1);
+        const int len = (int)((rec >> 32) & 31);
+        const int l0 = __builtin_amdgcn_readlane(len, 0), l1 = __builtin_amdgcn_readlane(len, 16), l2 = __builtin_amdgcn_readlane(len, 32),
+                  l3 = __builtin_amdgcn_readlane(len, 48);
+        const int m01 = l0 > l1 ? l0 : l1, m23 = l2 > l3 ? l2 : l3;
+        const int maxlen = m01 > m23 ? m01 : m23;
+        if (maxlen == 0) break;  // a real piece has a length: every group of the wavefront is past the end of its stretch
+        const bool ends = (rec >> 38) & 1;
+        const int fk = (int)((rec >> 39) & 63);
+        const float* gbase = grad + foff[fk] + c4 * 4;  // every entry of a piece belongs to the piece's feature
+        f32x4 acc = zero;
+        for (int i = 0; i < maxlen; i += NR) {  // scalar loop: all lanes of the wavefront take every trip, so every shuffle source is active
+            f32x4 q[NR];
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const uint32_t v = (uint32_t)__shfl((int)myv, glane0 + ((i + u) & 15));
+                q[u] = zero;
+                if (i + u < len) q[u] = *reinterpret_cast<const f32x4*>(gbase + (size_t)((v & PMASK) * Du));
+            }
+#pragma unroll
+            for (int u = 0; u < NR; ++u)
+                if (i + u < len) acc += q[u];
+        }
+        if (len > 0) {
+            if (run_key != ~0ull && run_key != key) {  // the open run continues somewhere else in the list (or has ended there)
+                add_carry(run_home, run_sum);
+                run_key = ~0ull;
+            }
+            if (run_key == ~0ull) {
+                run_sum = acc;
+                run_key = key;
+                run_home = hm;
+            } else {
+                run_sum += acc;
+            }
+            if (ends) {
+                add_carry(run_home, run_sum);
+                run_key = ~0ull;
+            }
+        }
+    }
+    if (run_key != ~0ull) add_carry(run_home, run_sum);
+}
+
 // Chunk c is home to a carried sum iff its last run starts inside it and continues into chunk c + 1.
 // deterministic != 0: nothing was carried; the group walks the whole crossing run in sorted (sample) order.
 template <typename KeyT>
@@ -1023,10 +1249,9 @@ __global__ __launch_bounds__(256) void carry_apply_kernel(const BwdArgs a, const
         }
         for (int64_t i = st; i < n && keys[i] == key; ++i) {
             const uint32_t v = vals[i];
-            int64_t r = (int64_t)(v & ((1u << 26) - 1));
-            if (gm.map != nullptr) r = gm.map[(int64_t)(v >> 26) * gm.map_stride + r];
+            const int64_t r = (int64_t)(v & ((1u << 26) - 1));  // multi-hot: the bag (SortArgs::pmap)
             f32x4 gv = *reinterpret_cast<const f32x4*>(grad + r * grad_row_stride + a.offset[v >> 26] + c4 * 4);
-            if (gm.map != nullptr) gv = gv / gm.scale[(int64_t)(v >> 26) * gm.scale_stride + r];
+
             g += gv;
         }
     }
@@ -1044,7 +1269,16 @@ struct WsLayout {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // digit width of the sort for n entries: 11 bits, narrower for very long inputs (bounds the counter array)
-int radix_bits_for(int64_t n) { return n > (1ll << 24) ? 8 : RBITS_MAX; }
+// (measured, round 6, the 34 M values of the multi-hot bench: two 11-bit passes over the 20-bit keys take 1.0 ms -- scatter 276 + scan 140 + histogram
+// 87 us each -- against 0.69 ms for three 8-bit passes: 2048 bins per 4096-entry tile scatter two entries per bin)
+int radix_bits_for(int64_t n) {
+    static int lim = -1;
+    if (lim < 0) {
+        const char* e = MH_LAB_ENV("MERLIN_HIP_SORT_WIDE_LOG2");
+        lim = e ? atoi(e) : 24;
+    }
+    return n > (1ll << lim) ? 8 : RBITS_MAX;
+}
 
 // Sized for 64-bit final keys (the 32-bit variant uses the front of the same buffers).
 bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
@@ -1057,7 +1291,7 @@ bool ws_layout(int64_t B, int F, int D, WsLayout* L) {
     L->off_vals_a = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_vals_b = o; o = align_up(o + (size_t)L->n * 4, 256);
     L->off_carry = o; o = align_up(o + (size_t)L->nchunks * D * 4, 256);
-    L->off_counter = o; o = align_up(o + 4, 256);  // right behind the carry rows: ONE fill kernel clears both
+    L->off_counter = o; o = align_up(o + 8, 256);  // right behind the carry rows: ONE fill kernel clears both (two counters: whole / partial pieces)
     L->off_pieces = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 16, 256);  // <= one cut per run + per chunk
     L->off_home = o; o = align_up(o + ((size_t)L->n + (size_t)L->nchunks) * 4, 256);
     L->off_cnt = o; o = align_up(o + (size_t)L->max_tiles * ((size_t)1 << RBITS_MAX) * 4, 256);
@@ -1083,7 +1317,7 @@ bool deterministic_mode() { return g_deterministic != 0; }
 template <typename IdT, typename KeyT>
 int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbits, const WsLayout& L, char* ws, int64_t B, int F,
                        int D, const float* grad, int64_t grad_row_stride, int optimizer, const OptHyper& hp,
-                       hipStream_t s, int phases, const GradMap gm = GradMap{nullptr, 0, nullptr, 0}) {
+                       hipStream_t s, int phases, const GradMap gm = GradMap{nullptr, 0, 0, 0}) {
     void* kbuf[2] = {ws + L.off_keys_a, ws + L.off_keys_b};
     uint32_t* vbuf[2] = {reinterpret_cast<uint32_t*>(ws + L.off_vals_a), reinterpret_cast<uint32_t*>(ws + L.off_vals_b)};
     float* carry = reinterpret_cast<float*>(ws + L.off_carry);
@@ -1134,25 +1368,57 @@ int32_t run_pipeline_t(const BwdArgs& a, const SortArgs& sa, int npass, int rbit
 
     // ---- 2. piece list, 3. segmented reduce + fused optimizer, 4. carried runs -------------------------------------------
     if ((phases & PH_PREPARE) && !lean) {  // a kernel, not a memset node (see mh_fill_words)
-        const int32_t st = det ? mh_fill_words(counter, 0u, 1, s)
-                               : mh_fill_words(carry, 0u, (int64_t)(L.off_counter + 4 - L.off_carry) / 4, s);
+        const int32_t st = det ? mh_fill_words(counter, 0u, 2, s)
+                               : mh_fill_words(carry, 0u, (int64_t)(L.off_counter + 8 - L.off_carry) / 4, s);
         if (st != MH_OK) return st;
     }
     const int LPR = D / 4;
     const int groups = (256 / LPR) < 64 ? (256 / LPR) : 64;
-    if (phases & PH_PREPARE)
-        MH_LAUNCH((piece_list_kernel<KeyT>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
-                           keys, vals, L.n, pieces, home, counter);
+    // multi-hot update with a wave-friendly row width: the list is split into whole-run pieces and pieces of crossing runs
+    const bool split_list = gm.multi && (LPR == 16 || LPR == 32 || LPR == 64) && gm.bags * D < (1ll << 32);
+    const int64_t pieces_cap = L.n + L.nchunks;  // a cut per run start + per chunk boundary at most (the list's allocation)
+    if (phases & PH_PREPARE) {
+        if (split_list)
+            MH_LAUNCH((piece_list_kernel<KeyT, true>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
+                               keys, vals, L.n, pieces, home, counter, pieces_cap);
+        else
+            MH_LAUNCH((piece_list_kernel<KeyT, false>), dim3((unsigned)mh_ceil_div(L.n, 256 * LIST_TILES)), dim3(256), 0, s, sa,
+                               keys, vals, L.n, pieces, home, counter, (int64_t)0);
+    }
     if (!(phases & PH_APPLY)) {
         MH_CHECK_LAUNCH("mh_embedding_gather_bwd_prepare");
         return MH_OK;
     }
-    {
+    if (split_list) {
+        // multi-hot update: the two halves of the split list, each with its own kernel (kernel comments)
+        static int walk_t = -1;
+        if (walk_t < 0) {
+            const char* e = MH_LAB_ENV("MERLIN_HIP_APPLY_WALK_T");
+            walk_t = e ? atoi(e) : 64;
+            if (walk_t < 1 || walk_t > 65536) walk_t = 64;
+        }
+        static int res_whole = 0;
+        if (res_whole == 0) {
+            int r = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&r, piece_whole_apply_kernel<4>, 256, 0) != hipSuccess || r < 1) r = 4;
+            res_whole = r;
+        }
+        int64_t nbw = mh_ceil_div(pieces_cap, (int64_t)(256 / LPR));
+        const int64_t capw = (int64_t)mh_num_cus() * res_whole;  // persistent: exactly one resident wave of workgroups
+        if (nbw > capw) nbw = capw;
+        MH_LAUNCH(piece_whole_apply_kernel<4>, dim3((unsigned)nbw), dim3(256), 0, s, a, vals, D, LPR, grad, pieces, counter, optimizer, hp);
+        if (!det) {  // deterministic mode: crossing runs are walked in sorted order by carry_apply_kernel
+            const int64_t nbp = mh_ceil_div(pieces_cap, (int64_t)(256 / LPR) * walk_t);
+            MH_REQUIRE(nbp < (1ll << 31), "mh_embedding_bag_bwd_multi: grid too large");
+            MH_LAUNCH(piece_partial_walk_kernel<16>, dim3((unsigned)nbp), dim3(256), 0, s, a, vals, D, LPR, grad, carry, home, pieces, counter,
+                      pieces_cap, walk_t);
+        }
+    } else {
         // the group's lanes fetch and hand out a piece's sample indices (kernel comment) where a group is an aligned 16- / 32-lane
         // part of a wavefront
         const bool vmode = (LPR == 16 || LPR == 32);  // D = 64 / 128 (GPU-tested); 64-lane groups (D = 256) keep mode 0 until a test covers them
         // multi-hot updates (a value list per sample: long runs in every small table) carry run sums across iterations
-        const int runs = (gm.map != nullptr) ? 1 : 0;
+        const int runs = gm.multi ? 1 : 0;
         static int tile_log2 = -1;
         if (tile_log2 < 0) {
             const char* e = MH_LAB_ENV("MERLIN_HIP_APPLY_TILE_LOG2");
@@ -1290,6 +1556,10 @@ __global__ __launch_bounds__(256) void bag_expand_max_kernel(const float* __rest
 
 
 // ---- several multi-hot features in ONE sparse update (mh_embedding_bag_bwd_multi) -----------------------------------------------
+struct BwdArgsOffsets {
+    int64_t v[MH_MAX_FEATURES];
+    int sidx[MH_MAX_FEATURES];  // row of `scale` (original feature index) of the f-th feature of the launch
+};
 struct BagMultiArgs {
     const void* values[MH_MAX_FEATURES];
     const void* offsets[MH_MAX_FEATURES];  // CSR offsets [B + 1] of the feature, or nullptr: dense list of length L
@@ -1394,8 +1664,28 @@ __global__ __launch_bounds__(256) void bag_index_pad_kernel(const BagMultiArgs a
     }
 }
 
+// (Round 6 also built a bag-major path for tables of a few rows -- a table of 4 .. 96 rows under 1.3 M values is one run of tens of thousands of
+// values per row, 31 % of the values of the multi-hot bench -- in four forms: workgroup-shared LDS accumulators with ds_add_f32 (3.4 ms for the
+// eight small tables, in up to 16 bank-skewed replicas just the same: the LDS float atomic itself is the bound), wavefront-private LDS
+// accumulators with plain read / add / write and register forwarding (1.2 ms), register accumulators fed by ballot counts (0.72 ms).  The sort
+// pipeline spends ~0.4 ms on those values -- their pieces of 16 are the cheap ones of the walk kernel -- so none of them paid and the path is
+// gone; the form that would pay is the count-matrix GEMM (acc[rows, D] += C^T[rows, 64 bags] G[64 bags, D] on the fp32 MFMA): profiles/r6_notes.md.)
+// gs[f][bag][:] = grad[bag][offset f ..] / scale[f][bag]: the gradient row every value of the bag adds to its table row, formed ONCE per bag
+// (the reduce kernel of round 5 divided once per value).  Streaming: 16 bytes per thread in, 16 out.
+__global__ __launch_bounds__(256) void bag_prescale_kernel(const float* __restrict__ grad, int64_t grad_row_stride, const BwdArgsOffsets off,
+                                                          const float* __restrict__ scale, int64_t B, int LPR, float* __restrict__ gs) {
+    const int f = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t bag = t / LPR;
+    const int c4 = (int)(t - bag * LPR);
+    if (bag >= B) return;
+    const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grad + bag * grad_row_stride + off.v[f] + c4 * 4));
+    const float dv = scale[(int64_t)off.sidx[f] * B + bag];
+    *reinterpret_cast<f32x4*>(gs + ((int64_t)f * B + bag) * (LPR * 4) + c4 * 4) = g / dv;
+}
+
 struct BagMultiWs {
-    int64_t Bp, off_scale, off_map, off_ids, off_inner, total;
+    int64_t Bp, off_scale, off_map, off_ids, off_gs, off_inner, total;
 };
 
 bool bag_multi_ws(int64_t B, int64_t max_nnz, int F, int D, BagMultiWs* w) {
@@ -1406,6 +1696,7 @@ bool bag_multi_ws(int64_t B, int64_t max_nnz, int F, int D, BagMultiWs* w) {
     w->off_scale = o; o = (int64_t)align_up((size_t)(o + (int64_t)F * B * 4), 256);
     w->off_map = o;   o = (int64_t)align_up((size_t)(o + (int64_t)F * w->Bp * 4), 256);
     w->off_ids = o;   o = (int64_t)align_up((size_t)(o + (int64_t)F * w->Bp * 8), 256);
+    w->off_gs = o;    o = (int64_t)align_up((size_t)(o + (int64_t)F * B * D * 4), 256);  // pre-scaled feature-major gradient
     w->off_inner = o; o += inner;
     w->total = o;
     return true;
@@ -1432,7 +1723,7 @@ static int32_t gather_bwd_impl(float* const* tables, float* const* state, const 
                                const float* grad, int64_t grad_row_stride, const int64_t* grad_offset,
                                int32_t optimizer, float lr, float eps, float* const* state2, float beta1, float beta2,
                                const float* lr_device, void* workspace, int64_t workspace_bytes,
-                               mh_stream_t stream, int phases, const GradMap gm = GradMap{nullptr, 0, nullptr, 0}) {
+                               mh_stream_t stream, int phases, const GradMap gm = GradMap{nullptr, 0, 0, 0}) {
     if (phases == PH_PREPARE) {  // ids only: no gradient, no optimizer state yet
         static const int64_t zero_off[MH_MAX_FEATURES] = {0};
         MH_REQUIRE(tables && table_rows && ids, "mh_embedding_gather_bwd_prepare: null argument");
@@ -1476,7 +1767,7 @@ static int32_t gather_bwd_impl(float* const* tables, float* const* state, const 
         MH_REQUIRE(tables[f] && ids[f], "mh_embedding_gather_bwd: null table/ids for feature %d", f);
         MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_gather_bwd: null optimizer state for feature %d", f);
         MH_REQUIRE(optimizer != MH_OPT_ADAM || state2[f], "mh_embedding_gather_bwd: null second moment for feature %d", f);
-        MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && grad_offset[f] + D <= grad_row_stride,
+        MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && (gm.multi || grad_offset[f] + D <= grad_row_stride),
                    "mh_embedding_gather_bwd: grad offset of feature %d misaligned or out of row", f);
         if (placed[f]) continue;
         sa.seg_f0[nseg] = pos;
@@ -1497,6 +1788,8 @@ static int32_t gather_bwd_impl(float* const* tables, float* const* state, const 
     sa.seg_f0[nseg] = F;
     sa.nseg = nseg;
     sa.B = B;
+    sa.pmap = gm.map;  // multi-hot: the sort's payload is the entry's bag (features of such a call use distinct tables: order[] is the identity)
+    sa.pmap_stride = gm.map_stride;
     int tiles = 0;
     for (int sg = 0; sg < nseg; ++sg) {
         sa.tile0[sg] = tiles;
@@ -1708,29 +2001,74 @@ int32_t mh_embedding_bag_bwd_multi(float* const* tables, float* const* state, fl
     float* scale = reinterpret_cast<float*>(ws + w.off_scale);
     int32_t* map = reinterpret_cast<int32_t*>(ws + w.off_map);
     void* idpad = ws + w.off_ids;
+    MH_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024 && grad_row_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0,
+               "mh_embedding_bag_bwd_multi: grad must be 16-byte aligned with D and grad_row_stride multiples of 4");
+    MH_REQUIRE(optimizer >= MH_OPT_SGD && optimizer <= MH_OPT_ADAM, "mh_embedding_bag_bwd_multi: bad optimizer %d", optimizer);
+    MH_REQUIRE(optimizer == MH_OPT_SGD || state, "mh_embedding_bag_bwd_multi: Adagrad / Adam need state tables");
+    MH_REQUIRE(optimizer != MH_OPT_ADAM || state2, "mh_embedding_bag_bwd_multi: Adam needs the second-moment tables");
+    // combiner divisors of every bag of every feature
     BagMultiArgs ba;
     std::memset(&ba, 0, sizeof(ba));
     for (int f = 0; f < F; ++f) {
+        MH_REQUIRE(table_rows[f] >= 1 && tables[f], "mh_embedding_bag_bwd_multi: table %d is null or has no rows", f);
+        MH_REQUIRE(optimizer == MH_OPT_SGD || state[f], "mh_embedding_bag_bwd_multi: null optimizer state for feature %d", f);
+        MH_REQUIRE(optimizer != MH_OPT_ADAM || state2[f], "mh_embedding_bag_bwd_multi: null second moment for feature %d", f);
+        MH_REQUIRE(grad_offset[f] >= 0 && grad_offset[f] % 4 == 0 && grad_offset[f] + D <= grad_row_stride,
+                   "mh_embedding_bag_bwd_multi: grad offset of feature %d misaligned or out of row", f);
         ba.values[f] = values[f];
         ba.offsets[f] = offsets ? offsets[f] : nullptr;
         ba.nnz[f] = nnz[f];
     }
     const dim3 gs((unsigned)mh_ceil_div(B, 256), (unsigned)F);
+    if (ids_dtype == MH_I32) MH_LAUNCH((bag_scale_multi_kernel<int32_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
+    else MH_LAUNCH((bag_scale_multi_kernel<int64_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
+
+    int nbig = 0, big[MH_MAX_FEATURES];
+    for (int f = 0; f < F; ++f) big[nbig++] = f;
+    const int LPR = D / 4;
+
+    // ---- the other features: bag of every value + padded ids, pre-scaled feature-major gradient, ONE sort / piece list / walk ---------
+    int64_t big_nnz = 0;
+    BagMultiArgs bb;
+    std::memset(&bb, 0, sizeof(bb));
+    BwdArgsOffsets go;
+    std::memset(&go, 0, sizeof(go));
+    float* btab[MH_MAX_FEATURES];
+    float* bst[MH_MAX_FEATURES];
+    float* bst2[MH_MAX_FEATURES];
+    int64_t brows[MH_MAX_FEATURES], fm_off[MH_MAX_FEATURES];
+    for (int g = 0; g < nbig; ++g) {
+        const int f = big[g];
+        bb.values[g] = values[f];
+        bb.offsets[g] = offsets ? offsets[f] : nullptr;
+        bb.nnz[g] = nnz[f];
+        if (nnz[f] > big_nnz) big_nnz = nnz[f];
+        go.v[g] = grad_offset[f];
+        go.sidx[g] = f;
+        btab[g] = tables[f];
+        bst[g] = state ? state[f] : nullptr;
+        bst2[g] = state2 ? state2[f] : nullptr;
+        brows[g] = table_rows[f];
+        fm_off[g] = (int64_t)g * B * D;
+    }
+    if (big_nnz == 0) return MH_OK;
+    const int64_t Bp = (big_nnz + 63) / 64 * 64;  // <= w.Bp: the buffers were sized for the longest list of ALL features
     // one workgroup per 256 bags + the workgroups that write the padding (at most Bp - min nnz entries)
-    const dim3 gi((unsigned)(mh_ceil_div(B, 256) + 64), (unsigned)F);
+    const dim3 gi((unsigned)(mh_ceil_div(B, 256) + 64), (unsigned)nbig);
     const void* idp[MH_MAX_FEATURES];
     if (ids_dtype == MH_I32) {
-        MH_LAUNCH((bag_scale_multi_kernel<int32_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
-        MH_LAUNCH((bag_index_pad_kernel<int32_t>), gi, dim3(256), 0, s, ba, L, B, w.Bp, map, static_cast<int32_t*>(idpad));
-        for (int f = 0; f < F; ++f) idp[f] = static_cast<int32_t*>(idpad) + (int64_t)f * w.Bp;
+        MH_LAUNCH((bag_index_pad_kernel<int32_t>), gi, dim3(256), 0, s, bb, L, B, Bp, map, static_cast<int32_t*>(idpad));
+        for (int g = 0; g < nbig; ++g) idp[g] = static_cast<int32_t*>(idpad) + (int64_t)g * Bp;
     } else {
-        MH_LAUNCH((bag_scale_multi_kernel<int64_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
-        MH_LAUNCH((bag_index_pad_kernel<int64_t>), gi, dim3(256), 0, s, ba, L, B, w.Bp, map, static_cast<int64_t*>(idpad));
-        for (int f = 0; f < F; ++f) idp[f] = static_cast<int64_t*>(idpad) + (int64_t)f * w.Bp;
+        MH_LAUNCH((bag_index_pad_kernel<int64_t>), gi, dim3(256), 0, s, bb, L, B, Bp, map, static_cast<int64_t*>(idpad));
+        for (int g = 0; g < nbig; ++g) idp[g] = static_cast<int64_t*>(idpad) + (int64_t)g * Bp;
     }
-    const GradMap gm{map, w.Bp, scale, B};
-    return gather_bwd_impl(tables, state, table_rows, idp, ids_dtype, w.Bp, F, D, grad, grad_row_stride, grad_offset, optimizer, lr, eps,
-                           state2, beta1, beta2, lr_device, ws + w.off_inner, workspace_bytes - w.off_inner, stream, PH_ALL, gm);
+    float* gsc = reinterpret_cast<float*>(ws + w.off_gs);
+    MH_LAUNCH(bag_prescale_kernel, dim3((unsigned)mh_ceil_div(B * LPR, 256), (unsigned)nbig), dim3(256), 0, s, grad, grad_row_stride, go, scale, B,
+              LPR, gsc);
+    const GradMap gm{map, Bp, 1, B};
+    return gather_bwd_impl(btab, state ? bst : nullptr, brows, idp, ids_dtype, Bp, nbig, D, gsc, D, fm_off, optimizer, lr, eps,
+                           state2 ? bst2 : nullptr, beta1, beta2, lr_device, ws + w.off_inner, workspace_bytes - w.off_inner, stream, PH_ALL, gm);
 }
 
 }  // extern "C"

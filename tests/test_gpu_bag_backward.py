@@ -268,9 +268,10 @@ def test_shared_table_onehot_and_list_take_one_optimizer_step(optimizer, idt):
     assert not np.allclose(emb.feature_table["other"].table.numpy(), Wo0)
 
 
+@pytest.mark.parametrize("D", [32, 64, 128, 256])  # 64 / 128 / 256: the split list + the whole / partial walk kernels; 32: the tiled reduce kernel
 @pytest.mark.parametrize("dtype", [torch.int32, torch.int64])
 @pytest.mark.parametrize("combiner,optimizer", [("mean", "sgd"), ("sqrtn", "adagrad"), ("sum", "adam")])
-def test_bag_backward_multi_matches_single_calls(dtype, combiner, optimizer):
+def test_bag_backward_multi_matches_single_calls(dtype, combiner, optimizer, D):
     """mh_embedding_bag_bwd_multi: F ragged features (different value counts, empty bags, pruned and out-of-range ids) over F
     tables in one update against F mh_embedding_bag_bwd calls on copies of the same tables (the same sums; a run of equal ids is
     cut into pieces at other places when the features share one sorted array, so the association -- not the terms -- may differ:
@@ -280,7 +281,7 @@ def test_bag_backward_multi_matches_single_calls(dtype, combiner, optimizer):
 
     dev = _dev()
     rng = np.random.default_rng(17)
-    B, D, F = 1500, 32, 3
+    B, F = 1500, 3
     Vs = [200, 5000, 37]
     feats = [_csr(rng, B, V, m) for V, m in zip(Vs, (12, 3, 30))]
     wide = rng.standard_normal((B, 8 + F * D)).astype(np.float32)

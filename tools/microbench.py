@@ -158,3 +158,24 @@ if "cross" in which:
         W = torch.randn(d, d, device=dev) * 0.02
         bb = torch.zeros(d, device=dev)
         timeit(f"cross layer 64K x {d} x {d}", lambda: ops.cross_layer(x0, x0, W, bb), flops=2 * B * d * d, iters=3)
+if "bagbwd" in which:  # the multi-hot update of bench.py's `embedding_bag` secondary (26 ragged features, nnz ~ Poisson(20)), one call
+    import numpy as np
+    from models_amd.synthetic import CRITEO_CARDINALITIES
+
+    rng = np.random.default_rng(99)
+    tabs = [torch.rand(int(v), D, device=dev) - 0.5 for v in CRITEO_CARDINALITIES]
+    accs = [torch.full_like(t, 0.1) for t in tabs]
+    vs, os_ = [], []
+    for v in CRITEO_CARDINALITIES:
+        lens = np.maximum(rng.poisson(20, size=B), 1)
+        offs = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(lens, out=offs[1:])
+        vs.append(torch.from_numpy(rng.integers(0, int(v), size=int(offs[-1])).astype(np.int32)).to(dev))
+        os_.append(torch.from_numpy(offs).to(dev))
+    nF = len(tabs)
+    grad = torch.rand(B, nF * D, device=dev) - 0.5
+    nnz = sum(int(v.numel()) for v in vs)
+    uniq = sum(int(torch.unique(v).numel()) for v in vs)
+    by = nF * B * (D * 4 + 8) + nnz * 4 + uniq * 4 * D * 4
+    timeit(f"bag_bwd_multi adagrad ({nnz} values, {uniq} unique)", lambda: ops.embedding_bag_backward_multi(
+        tabs, accs, vs, os_, grad, [f * D for f in range(nF)], "mean", optimizer="adagrad", lr=0.0), nbytes=by, iters=6)
