@@ -712,10 +712,11 @@ template <int R>
 __global__ __launch_bounds__(256) void topk_merge_segments_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
                                                                  const int* __restrict__ cnt, int segcap, int nsplit, int64_t Bq, int k,
                                                                  float* __restrict__ best_s, int32_t* __restrict__ best_i,
-                                                                 float* __restrict__ tau) {
+                                                                 float* __restrict__ tau, const int* __restrict__ only = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= Bq) return;
+    if (only && !only[row]) return;  // the rows topk_sort_merge_kernel left over (more entries than its LDS holds)
     RegList<R> L;
     L.load(best_s + row * k, best_i + row * k, k, lane);
     float tl;
@@ -746,6 +747,176 @@ __global__ __launch_bounds__(256) void topk_merge_segments_kernel(const float* _
     }
     L.store(best_s + row * k, best_i + row * k, k, lane);
     if (lane == 0) tau[row] = tl;
+}
+
+// The merge of a stage (and the bootstrap's selection) as a SORT: a workgroup per row gathers the row's running list and its survivor segments
+// (or a dense block of scores) into LDS as 64-bit keys -- (score descending, index ascending) as ONE ascending integer order: the float's bits
+// mapped monotonically and complemented in the high word, the candidate index in the low word --, sorts them with a bitonic network and
+// keeps the first k'.  The insertion list of topk_merge_segments_kernel / topk_select_kernel costs ~0.5 us per insertion and a stage inserts
+// ~k' ln(growth) entries per row (115 us per stage at k' = 128, 276 us for the bootstrap over 2048 candidates); the network is 45-66 steps of
+// <= 4 compare-exchanges per thread whatever the data.  Same total order, so the same list: the result of a call stays bit-identical.
+// Rows with more entries than SORT_MAX are left to the insertion kernel (`big[row]` = 1).
+constexpr int SORT_MAX = 1024;  // entries a wavefront sorts in its 8 KB of LDS
+
+__device__ __forceinline__ uint64_t topk_key(float s, int32_t idx) {
+    uint32_t u = __float_as_uint(s + 0.f);  // -0 -> +0: the float comparisons of the insertion list hold them equal
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending unsigned order = ascending float order (-inf lowest; no NaNs reach here)
+    return ((uint64_t)(~u) << 32) | (uint32_t)idx;
+}
+__device__ __forceinline__ float topk_key_score(uint64_t key) {
+    uint32_t u = ~(uint32_t)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+// Bitonic network over EPL x 64 keys held in the registers of one wavefront (element e = r * 64 + lane: register r, lane `lane`), ascending.
+// Strides below 64 exchange between lanes (two 32-bit shuffles per key), strides from 64 up between registers of the same lane (static
+// indices: the loops are fully unrolled).  No LDS, no barrier: ~8 instructions per key and step.
+template <int EPL>
+__device__ __forceinline__ void topk_bitonic_regs(uint64_t (&x)[EPL], int lane) {
+    constexpr int P = EPL * 64;
+#pragma unroll
+    for (int size = 2; size <= P; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride < 64) {
+#pragma unroll
+                for (int r = 0; r < EPL; ++r) {
+                    const uint32_t plo = (uint32_t)__shfl_xor((int)(uint32_t)x[r], stride);
+                    const uint32_t phi = (uint32_t)__shfl_xor((int)(uint32_t)(x[r] >> 32), stride);
+                    const uint64_t other = ((uint64_t)phi << 32) | plo;
+                    const bool is_lo = (lane & stride) == 0;
+                    const bool up = (((r * 64 + lane) & size) == 0) || size == P;  // size == P: the last merge is ascending everywhere
+                    const bool keep_min = is_lo == up;
+                    const uint64_t mn = x[r] < other ? x[r] : other, mx = x[r] < other ? other : x[r];
+                    x[r] = keep_min ? mn : mx;
+                }
+            } else {
+                constexpr int dummy = 0;
+                (void)dummy;
+#pragma unroll
+                for (int r = 0; r < EPL; ++r) {
+                    const int rs = stride >> 6;
+                    if ((r & rs) == 0) {
+                        const int q = r | rs;
+                        const bool up = (((r * 64) & size) == 0) || size == P;
+                        const uint64_t a = x[r], b = x[q];
+                        const uint64_t mn = a < b ? a : b, mx = a < b ? b : a;
+                        x[r] = up ? mn : mx;
+                        x[q] = up ? mx : mn;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One WAVEFRONT per row (four rows per workgroup), everything wave-synchronous -- no workgroup barrier: LDS operations of a wavefront complete
+// in order.  (First version: a workgroup per row with a barrier per network step -- 90 us per launch, all of it the latency of ~5 dependent
+// global round trips per workgroup with eight workgroups on a CU.)  Lane s holds the count of segment s (+ 64, ...) and fetches entry r of
+// its segments for all r at once: nmax rounds of independent, coalesced loads.
+// dense == nullptr: entries = the row's list (k) + its survivor segments (cnt / cs / ci as topk_filter_bf16x3_kernel leaves them);
+// dense != nullptr: entries = (seen > 0 ? the row's list : nothing) + the ncur scores dense[row * ld + j] of candidates c0 + j
+__global__ __launch_bounds__(256) void topk_sort_merge_kernel(const float* __restrict__ cs, const int32_t* __restrict__ ci,
+                                                             const int* __restrict__ cnt, int segcap, int nsplit, int64_t Bq, int k,
+                                                             float* __restrict__ best_s, int32_t* __restrict__ best_i,
+                                                             float* __restrict__ tau, int* __restrict__ big, const float* __restrict__ dense,
+                                                             int64_t ld, int ncur, int64_t c0, int seen) {
+    __shared__ uint64_t keys_all[4][SORT_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= Bq) return;
+    uint64_t* keys = keys_all[wave];
+    int M;
+    int n_s[4] = {0, 0, 0, 0}, off_s[4] = {0, 0, 0, 0};  // nsplit <= 256: lane s owns segments s, s + 64, s + 128, s + 192
+    if (dense) {
+        M = seen + ncur;
+    } else {
+        int run = k;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 64 < nsplit) {  // wave-uniform
+                const int sg = g * 64 + lane;
+                n_s[g] = sg < nsplit ? cnt[row * nsplit + sg] : 0;
+                int incl = n_s[g];  // inclusive scan over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                off_s[g] = run + incl - n_s[g];
+                run += __shfl(incl, 63);
+            }
+        }
+        M = run;
+    }
+    if (M > SORT_MAX) {  // wave-uniform
+        if (lane == 0) big[row] = 1;
+        return;
+    }
+    if (lane == 0) big[row] = 0;
+    int P = 64;
+    while (P < M) P <<= 1;
+    const int nlist = dense ? seen : k;
+    for (int i = lane; i < nlist; i += 64) keys[i] = topk_key(best_s[row * k + i], best_i[row * k + i]);
+    if (dense) {
+        for (int j = lane; j < ncur; j += 64) keys[nlist + j] = topk_key(dense[row * ld + j], (int32_t)(c0 + j));
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g * 64 < nsplit) {
+                int nmax = n_s[g];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+                const int64_t seg = row * (int64_t)segcap * nsplit + g * 64 + lane;
+                for (int r0 = 0; r0 < nmax; r0 += 8) {  // eight rounds of loads in flight
+                    float v[8];
+                    int32_t vi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = (r0 + u < n_s[g]) ? r0 + u : 0;  // clamped: branch-free loads (entry 0 exists wherever the result is used)
+                        const bool ok = n_s[g] > 0 && g * 64 + lane < nsplit;
+                        v[u] = ok ? cs[seg + (int64_t)r * nsplit] : 0.f;
+                        vi[u] = ok ? ci[seg + (int64_t)r * nsplit] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (r0 + u < n_s[g]) keys[off_s[g] + r0 + u] = topk_key(v[u], vi[u]);
+                }
+            }
+        }
+    }
+    for (int i = M + lane; i < P; i += 64) keys[i] = ~0ull;  // worst key: behind every entry
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the network in registers (LDS only served the gather): P / 64 keys per lane
+    auto finish = [&](auto epl_tag) {
+        constexpr int EPL = decltype(epl_tag)::value;
+        uint64_t x[EPL];
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) x[r] = keys[r * 64 + lane];
+        topk_bitonic_regs<EPL>(x, lane);
+        const int nout = M < k ? M : k;
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const int i = r * 64 + lane;
+            if (i < k) {
+                // fewer entries than the list holds: the sentinel of the insertion list (topk_select_kernel)
+                best_s[row * k + i] = i < nout ? topk_key_score(x[r]) : -INFINITY;
+                best_i[row * k + i] = i < nout ? (int32_t)(uint32_t)x[r] : 0x7fffffff;
+            }
+            if (r == ((k - 1) >> 6)) {  // wave-uniform
+                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(x[r] >> 32), (k - 1) & 63);
+                if (lane == 0) tau[row] = M >= k ? topk_key_score((uint64_t)hi << 32) : -INFINITY;
+            }
+        }
+    };
+    if (P <= 64) finish(std::integral_constant<int, 1>{});
+    else if (P <= 128) finish(std::integral_constant<int, 2>{});
+    else if (P <= 256) finish(std::integral_constant<int, 4>{});
+    else if (P <= 512) finish(std::integral_constant<int, 8>{});
+    else finish(std::integral_constant<int, 16>{});
 }
 
 // The last stage of the split pipeline: decide per row whether the k' kept candidates provably contain the exact top-k (see the
@@ -988,6 +1159,18 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
         const int32_t st = mh_internal_gemm_nt(q, E, cand + c0 * E, E, Bq, (int)ncur, E, sc, nc, s);
         if (st != MH_OK) return st;
         const int seen = (int)(c0 < kp ? c0 : kp);
+        if (kp <= SORT_MAX / 4 && ncur <= 8 * SORT_MAX) {
+            // the bootstrap's selection as sorts (kernel comment): blocks of SORT_MAX - (entries kept so far) dense scores at a time
+            for (int64_t j0 = 0; j0 < ncur;) {
+                const int have = (int)(c0 + j0 < kp ? c0 + j0 : kp);
+                const int take = (int)((ncur - j0 < SORT_MAX - have) ? ncur - j0 : SORT_MAX - have);
+                MH_LAUNCH(topk_sort_merge_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, (const float*)nullptr,
+                          (const int32_t*)nullptr, (const int*)nullptr, 0, 0, Bq, kp, ls, li, tau, cnt, (const float*)(sc + j0), nc, take, c0 + j0,
+                          have);
+                j0 += take;
+            }
+            continue;
+        }
 #define MH_SEL(R_)                                                                                                          \
     MH_LAUNCH(topk_select_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, sc, nc, Bq, (int)ncur, c0, kp, seen, \
               ls, li, (const int32_t*)nullptr, 0, (int32_t*)nullptr)
@@ -1025,9 +1208,12 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
         MH_LAUNCH(topk_filter_bf16x3_kernel, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
                   (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, segcnt, cs, ci, segcap, dirty, nqb,
                   nsplit, tps, xcd_map);
+        // the stage's merge as a sort (a workgroup per row); rows holding more than SORT_MAX entries go through the insertion list
+        MH_LAUNCH(topk_sort_merge_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, (const float*)cs, (const int32_t*)ci, (const int*)segcnt, segcap,
+                  nsplit, Bq, kp, ls, li, tau, cnt, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, 0);
 #define MH_MRG(R_)                                                                                                             \
     MH_LAUNCH(topk_merge_segments_kernel<R_>, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, (const float*)cs,              \
-              (const int32_t*)ci, (const int*)segcnt, segcap, nsplit, Bq, kp, ls, li, tau)
+              (const int32_t*)ci, (const int*)segcnt, segcap, nsplit, Bq, kp, ls, li, tau, (const int*)cnt)
         MH_TOPK_BY_R(MH_MRG);
 #undef MH_MRG
         beg = end;
