@@ -1059,6 +1059,69 @@ def run_fit_from_parquet(args, device, rows=4_194_304, min_seconds=2.5):
         torch.cuda.empty_cache()
 
 
+def run_fit_streaming(args, device, rows=16_777_216, min_seconds=2.0):
+    """The loader when the dataset does NOT stay on the device (round-5 review: real Criteo does not fit the cache): a Criteo-shaped
+    Parquet file of `rows` rows (2.7 GB of columns at 16 M) -> mm.Loader(device_resident_bytes=0) -> model.fit: every epoch crosses
+    the host link again, in two persistent device buffer sets filled by 4 MB copies spread over the previous chunk's batches
+    (models_amd/loader.py).  Wall clock of one fit() call against the same model's step on resident batches."""
+    import shutil
+    import tempfile
+
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    import models_amd as mm
+    from models_amd.graph import PackedBatch, SegmentedStep
+    from models_amd.synthetic import CRITEO_CONT_NAMES
+
+    B = args.batch
+    rng = np.random.default_rng(987)
+    tmp = tempfile.mkdtemp(prefix="mh_fit16_")
+    try:
+        cols = {n: rng.integers(0, v, size=rows, dtype=np.int32) for n, v in _cat_columns()}
+        for n in CRITEO_CONT_NAMES:
+            cols[n] = rng.random(rows, dtype=np.float32)
+        cols["label"] = rng.integers(0, 2, size=rows).astype(np.float32)
+        path = os.path.join(tmp, "part0.parquet")
+        pq.write_table(pa.table(cols), path, row_group_size=1 << 20, compression="none", use_dictionary=False)
+        size = os.path.getsize(path)
+        del cols
+        model, schema = build_model(device)
+        model.compile(optimizer=args.optimizer, learning_rate=0.01)
+        loader = mm.Loader(path, schema, batch_size=B, shuffle=True, seed=1, device=device, drop_last=True, device_resident_bytes=0)
+        model.fit(loader, epochs=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.fit(loader, epochs=1)
+        torch.cuda.synchronize()
+        per_epoch = max(time.perf_counter() - t0, 1e-3)
+        epochs = int(min(max(3, math.ceil(min_seconds / per_epoch)), 200))
+        t0 = time.perf_counter()
+        model.fit(loader, epochs=epochs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rate = epochs * len(loader) * B / dt
+        batches = [PackedBatch(make_batch(device, B, 700 + i)) for i in range(4)]
+        split = lambda t: ({k: v for k, v in t.items() if k != "__label__"}, t["__label__"])
+        seg = SegmentedStep(lambda t: model.train_step(*split(t)), batches[0])
+        for i in range(10):
+            seg.replay(batches[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(100):
+            seg.replay(batches[i % 4])
+        torch.cuda.synchronize()
+        step_rate = 100 * B / (time.perf_counter() - t0)
+        return {"workload": f"synthetic Criteo-shaped Parquet ({rows} rows, {size / 1e9:.2f} GB, 40 columns) -> mm.Loader(device_resident_bytes=0: every "
+                            f"epoch over the host link, {getattr(loader, 'device_chunk_rows', None)}-row chunks, shuffle) -> DLRMModel.fit, B={B}",
+                "value": rate, "unit": "samples/s", "fit_epochs": epochs, "fit_seconds": dt, "batches_per_epoch": len(loader),
+                "resident_step_samples_per_s": step_rate, "fit_over_resident_step": rate / step_rate,
+                "device_resident_dataset": bool(getattr(loader, "device_resident", False))}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        torch.cuda.empty_cache()
+
+
 def run_dcn(args, device, tm: Timing):
     """BASELINE configs[4]: DCN-v2 depth 3 (d = 3341), emb_dim=128, deep [512, 256], B = 64 K per GPU, data-parallel."""
     from models_amd.graph import PackedBatch
@@ -1832,6 +1895,7 @@ def main():
             secondary("c4_one_gpu", lambda: run_c4_one_gpu(args, device, tm))
             secondary("negatives", lambda: run_negatives(args, device, tm, ["queue", "popularity"], steps=10))
             secondary("fit_from_parquet", lambda: run_fit_from_parquet(args, device))
+            secondary("fit_streaming_16m", lambda: run_fit_streaming(args, device))
         res["secondary"] = sec
     # CPU baseline on rank 0 at N = 1 only: at N > 1 the tables are sharded and a forward is a collective
     if not args.no_cpu_baseline and world == 1 and not args.extra_table_rows and not force:

@@ -265,6 +265,17 @@ class Loader:
         lists = [k for k, v in self._pinned.items() if isinstance(v, tuple)]
 
         cache = self._dev_cache
+        # STREAMING (the dataset does not stay on the device): the chunks land in two PERSISTENT buffer sets (raw columns + shuffled columns,
+        # allocated once for the largest chunk) that alternate -- no allocation, no allocator bookkeeping across streams, nothing for the
+        # caching allocator to give back and fetch again while an epoch runs.  Set j is refilled on the copy stream once the compute stream
+        # has passed the event recorded behind the last batch that was cut from it.
+        persistent = cache is None and not lists
+        if persistent and getattr(self, "_sets", None) is None:
+            rows = min(C, n)
+            self._sets = [{"raw": {k: torch.empty((rows,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in self._pinned.items()},
+                           "out": {k: torch.empty((rows,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in self._pinned.items()}
+                           if self.shuffle else None, "free": None} for _ in range(2)]
+            self._set_next = 0
 
         def upload(key, host_slice):
             """The chunk's part of one column on the device: copied from pinned memory, or -- device-resident mode -- the copy
@@ -276,7 +287,69 @@ class Loader:
                 cache[key] = t
             return t
 
+        PIECE = 1 << 20  # rows per host-to-device copy: ~4 MB, ~70 us on the link
+
+        class _Staging:
+            """A chunk on its way into buffer set `st`, as a sequence of SMALL steps the consumer loop advances a few at a time between
+            batches.  Measured (round 6, rocprofv3 kernel + copy trace of a streaming fit): while one of the 32 MB column copies of the
+            earlier all-at-once staging was in flight the train step took 1.8 ms instead of 0.99 -- kernels of the step queue behind the
+            0.6 ms copy that happens to share their hardware queue (stream priorities and GPU_MAX_HW_QUEUES changed nothing); a
+            chunk's 23 ms of copies cost 12 ms of step time: 0.79-0.87 of the resident rate.  In pieces of 4 MB a kernel waits 70 us
+            at most, and spread over the batches of the previous chunk the host never spends more than a few calls at once."""
+
+            def __init__(self_, a, rng):
+                self_.b = min(a + C, n)
+                self_.a, self_.m = a, min(a + C, n) - a
+                self_.st = self._sets[self._set_next]
+                self._set_next ^= 1
+                self_.rng, self_.cols, self_.done, self_.ev = rng, {}, False, None
+                self_.steps = self_._run()
+                self_.n_steps = len(self._pinned) * (-(-self_.m // PIECE) + 1) + 1
+
+            def _run(self_):
+                st, a, m = self_.st, self_.a, self_.m
+                with torch.cuda.stream(copy_stream):
+                    if st["free"] is not None:
+                        copy_stream.wait_event(st["free"])  # the batches cut from this set have all been consumed
+                    perm = None
+                    if self.shuffle:
+                        g = torch.Generator(device=dev).manual_seed(int(self_.rng.integers(0, 2 ** 62)))
+                        perm = torch.randperm(m, device=dev, generator=g)
+                yield
+                for k, v in self._pinned.items():
+                    raw = st["raw"][k][:m]
+                    for p0 in range(0, m, PIECE):
+                        p1 = min(p0 + PIECE, m)
+                        with torch.cuda.stream(copy_stream):
+                            raw[p0:p1].copy_(v[a + p0:a + p1], non_blocking=True)
+                        yield
+                    with torch.cuda.stream(copy_stream):
+                        if perm is not None:
+                            out = st["out"][k][:m]
+                            torch.index_select(raw, 0, perm, out=out)
+                            self_.cols[k] = out
+                        else:
+                            self_.cols[k] = raw
+                    yield
+                with torch.cuda.stream(copy_stream):
+                    self_.ev = torch.cuda.Event()
+                    self_.ev.record(copy_stream)
+                self_.done = True
+
+            def advance(self_, k):
+                for _ in range(k):
+                    if self_.done or next(self_.steps, StopIteration) is StopIteration:
+                        return
+
+            def result(self_):
+                while not self_.done:
+                    if next(self_.steps, StopIteration) is StopIteration:
+                        break
+                return self_.cols, {}, self_.ev, self_.m, self_.st
+
         def stage(a: int, rng=rng):
+            if persistent:
+                return _Staging(a, rng)
             b = min(a + C, n)
             m = b - a
             host_offs = {}
@@ -315,7 +388,7 @@ class Loader:
                         cols[k] = t.index_select(0, perm) if perm is not None else t
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
-            return cols, host_offs, ev, m
+            return cols, host_offs, ev, m, None
 
         # the first chunk of THIS epoch may have been staged while the previous epoch's last chunk was being consumed
         pre = getattr(self, "_prestaged", None)
@@ -325,7 +398,8 @@ class Loader:
         else:
             nxt = stage(starts[0])
         for ci in range(len(starts)):
-            cols, host_offs, ev, m = nxt
+            cols, host_offs, ev, m, bufset = nxt.result() if hasattr(nxt, "result") else nxt  # (a staging of the previous epoch is an instance of ITS local class)
+            pending = None  # the staging that advances while this chunk's batches are handed out
             if ci + 1 < len(starts):
                 nxt = stage(starts[ci + 1], rng)  # the next chunk's copies overlap this chunk's steps
             else:
@@ -334,10 +408,14 @@ class Loader:
                 nxt = None
                 st2, r2 = plan(epoch + 1)
                 self._prestaged = (epoch + 1, stage(st2[0], r2), st2, r2)
+            pending = nxt if nxt is not None else self._prestaged[1]
+            nbatch = max(-(-m // B), 1)
+            per_batch = -(-pending.n_steps // nbatch) if hasattr(pending, "n_steps") else 0
             cur_stream.wait_event(ev)
-            for v in cols.values():
-                for t in (v if isinstance(v, tuple) else (v,)):
-                    t.record_stream(cur_stream)  # allocated on the copy stream, consumed on the compute stream
+            if bufset is None:
+                for v in cols.values():
+                    for t in (v if isinstance(v, tuple) else (v,)):
+                        t.record_stream(cur_stream)  # allocated on the copy stream, consumed on the compute stream
             for a in range(0, m, B):
                 b = min(a + B, m)
                 if b - a < B and self.drop_last:
@@ -352,11 +430,18 @@ class Loader:
                         dev_b[k] = v[a:b].reshape(-1, 1)
                     else:
                         dev_b[k] = v[a:b]
+                if per_batch:
+                    pending.advance(per_batch)  # a few small copies of the NEXT chunk behind every batch of this one
                 if not self.label_names:
                     yield dev_b, None
                 else:
                     labels = {nm: dev_b.pop(nm) for nm in self.label_names}
                     yield dev_b, (labels[self.label_names[0]] if len(labels) == 1 else labels)
+            if hasattr(pending, "result"):
+                pending.result()  # whatever is left of the next chunk's staging is enqueued before this chunk is given up
+            if bufset is not None:  # everything the consumer enqueued for this chunk's batches lies before this point of its stream
+                bufset["free"] = torch.cuda.Event()
+                bufset["free"].record(cur_stream)
 
     def _typed(self, cols: Columns) -> Columns:
         """ids -> int32 / int64 (values and offsets of a list share the dtype), continuous / targets -> float32."""
