@@ -212,9 +212,22 @@ def dense_optimizer_step_multi(opt, params):
             p.data -= opt.learning_rate * g / (p.state["accumulator"].sqrt() + opt.epsilon)
         elif opt.name == "sgd":
             p.data -= opt.learning_rate * g
+        elif opt.name == "adam":  # keras Adam on a dense gradient (mh_dense_optimizer_step with the bias-corrected lr of adam_tick)
+            if "m" not in p.state:
+                p.state["m"], p.state["v"] = torch.zeros_like(p.data), torch.zeros_like(p.data)
+            p.state["m"].mul_(opt.beta_1).add_(g, alpha=1 - opt.beta_1)
+            p.state["v"].mul_(opt.beta_2).addcmul_(g, g, value=1 - opt.beta_2)
+            p.data -= float(opt.lr_device) * p.state["m"] / (p.state["v"].sqrt() + opt.epsilon)
         else:
-            raise NotImplementedError("shim: sgd / adagrad only")
+            raise NotImplementedError("shim: sgd / adagrad / adam")
         p.grad = None
+
+
+def adam_tick(opt):
+    """mh_adam_tick: step += 1, lr_device = lr sqrt(1 - b2^t) / (1 - b1^t)"""
+    opt._step_dev += 1.0
+    t = float(opt._step_dev)
+    opt.lr_device.fill_(opt.learning_rate * (1 - opt.beta_2 ** t) ** 0.5 / (1 - opt.beta_1 ** t))
 
 
 def route_build(ids, world_size, slots=None, n_slots=None, capacity=0, overflow=None, dedup=False):
@@ -311,7 +324,7 @@ def install():
     from models_amd import ops
 
     for name in ("embedding_gather", "linear", "dot_interaction", "dot_interaction_backward", "linear_backward",
-                 "embedding_gather_backward", "bce", "dense_optimizer_step_multi", "route_build", "eltwise", "rowwise_dot",
+                 "embedding_gather_backward", "bce", "dense_optimizer_step_multi", "adam_tick", "route_build", "eltwise", "rowwise_dot",
                  "cross_layer", "cross_layer_backward", "cross_lowrank_dx", "inbatch_softmax", "inbatch_softmax_train", "inbatch_softmax_backward", "l2norm", "embedding_bag",
                  "embedding_dense_list", "embedding_bag_expand", "embedding_bag_backward", "zero_pad_columns"):
         setattr(ops, name, globals()[name])

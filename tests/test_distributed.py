@@ -738,3 +738,83 @@ def test_dedup_route_statement_properties_random():
                 if int(ids[f][b]) < 0:
                     assert int(pos[f, b]) == -1
         assert int(over) == int(dropped)
+
+
+def _adam_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import ops_shim
+
+        ops_shim.install()
+        import models_amd as mm
+        from models_amd import schema as S
+        from models_amd.inputs import EmbeddingsBlock
+
+        dev = torch.device("cpu")
+        cols = [S.categorical("C1", 900), S.continuous("I1"), S.binary_target("label")]  # 900 rows < shard_threshold: REPLICATED
+        m = mm.DCNModel(mm.Schema(cols), depth=1, deep_block=mm.MLPBlock([8], device=dev, seed=5), embedding_dim=8, device=dev)
+        m.compile(optimizer="adam", learning_rate=0.01)
+        B = 32
+        g = torch.Generator().manual_seed(3)
+        # step 1 looks up rows 0 .. 99 only, steps 2 and 3 rows 500 .. 899 only
+        ids = [torch.randint(0, 100, (world, B, 1), generator=g)] + [torch.randint(500, 900, (world, B, 1), generator=g) for _ in range(2)]
+        xs = [torch.rand(world, B, 1, generator=g) for _ in range(3)]
+        ys = [torch.randint(0, 2, (world, B, 1), generator=g).float() for _ in range(3)]
+        m({"C1": ids[0][rank], "I1": xs[0][rank]})
+        _reseed(m)
+        dm = D.DistributedModel(m, shard_threshold=1000)
+        tab = next(iter(m.blocks_of_type(EmbeddingsBlock))).feature_table["C1"].table
+        snaps = [tab.data.numpy().copy()]
+        for t in range(3):
+            dm.train_step({"C1": ids[t][rank], "I1": xs[t][rank]}, ys[t][rank])
+            snaps.append(tab.data.numpy().copy())
+        q.put((rank, "ok", {"snaps": snaps, "touched1": np.unique(ids[0].numpy())}))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "FAIL: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_model_adam_on_replicated_tables_is_the_dense_keras_form():
+    """DistributedModel steps a REPLICATED table with the dense optimizer on its summed gradient (distributed.py, class docstring): with
+    Adam that is Keras's Adam on the densified gradient (what hvd.DistributedOptimizer(sparse_as_dense=True) hands it,
+    tf/models/base.py:476-508) -- the moments of EVERY row decay every step -- and not the LazyAdam of the single-GPU sparse path.
+    Pinned here (round-5 review, item 9) on rows that are looked up in step 1 only: under dense Adam they keep moving in steps 2 and 3
+    by lr_t b1^(t-1) (1 - b1) g / (sqrt(b2^(t-1) (1 - b2)) |g| + eps) with lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), i.e. a known multiple
+    of their first step (lr sign(g)); under LazyAdam they would stand still."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_adam_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+    assert all(m == "ok" for _, m, _ in res), [m for _, m, _ in res]
+    b1, b2, lr = 0.9, 0.999, 0.01
+    for _, _, st in res:
+        s0, s1, s2, s3 = st["snaps"]
+        rows = st["touched1"]
+        d1 = (s1[rows] - s0[rows]).astype(np.float64)
+        # first step: d1 = -lr g / (|g| + e), e = eps / sqrt(1 - b2): the gradient of every element follows from its own first step
+        e = 1e-7 / np.sqrt(1 - b2)
+        ok = (np.abs(d1) > 0.5 * lr) & (np.abs(d1) < 0.995 * lr)
+        assert ok.mean() > 0.3
+        g = -np.sign(d1) * e * np.abs(d1) / (lr - np.abs(d1))
+        for t, (a, b) in ((2, (s1, s2)), (3, (s2, s3))):
+            lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            want = -lr_t * (b1 ** (t - 1) * (1 - b1)) * g / (np.sqrt(b2 ** (t - 1) * (1 - b2)) * np.abs(g) + 1e-7)
+            dt = (b[rows] - a[rows]).astype(np.float64)
+            assert np.abs(dt[ok]).min() > 0, "rows untouched in this step stood still: that would be LazyAdam"
+            np.testing.assert_allclose(dt[ok], want[ok], rtol=2e-2)
+        # rows never looked up have zero moments: they do not move under either form
+        never = np.setdiff1d(np.arange(100, 500), rows)
+        assert np.array_equal(s3[never], s0[never])
+    np.testing.assert_array_equal(res[0][2]["snaps"][3], res[1][2]["snaps"][3])  # the replicas stay identical
