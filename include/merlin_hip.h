@@ -197,6 +197,18 @@ int32_t mh_linear_bias_act_fwd_split(const float* x, int64_t ldx, const float* W
 int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W, const float* y, int64_t ldy, float* dy, int64_t lddy,
                                      int64_t M, int32_t K, int32_t N, int32_t act, int32_t x_act, float* dx, int64_t lddx, float* dW,
                                      float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+/* Tower layers -- Dense layers with N = 128 outputs, 32 <= K <= 1024, at batch >= 4096 (tf/blocks/mlp.py:275-280: the DLRM's 415 -> 128, the
+ * two-tower's 256 -> 128) -- on the bf16 matrix pipe in the SIX-term split "bf16x6" (mh_tower_split.hip): x = h + m + l (three bf16 pieces of
+ * the 24-bit significand), products h h + h m + m h + h l + l h + m m with fp32 accumulators; dropped terms <= 2^-25 |x y|, i.e. below the
+ * rounding of an fp32 product: fp32-grade accuracy (NOT the fmaf chain's bits), 16 / 6 of the fp32 MFMA rate.  Same arguments as
+ * mh_linear_bias_act_fwd / _bwd plus a workspace (mh_tower_workspace_bytes: the operand images of W).  mh_tower_supported: 1 when the shape
+ * is covered.  Replaces the same Keras Dense call sites as mh_linear_bias_act_fwd / _bwd (tf/blocks/mlp.py:270-330). */
+int32_t mh_tower_supported(int64_t M, int32_t K, int32_t N);
+int64_t mh_tower_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int32_t mh_tower_linear_fwd(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int32_t K, int32_t N, int32_t act,
+                            float* y, int64_t ldy, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
+int32_t mh_tower_linear_dx(const float* dz, int64_t lddz, const float* W, int64_t M, int32_t K, int32_t N, float* dx, int64_t lddx,
+                           void* workspace, int64_t workspace_bytes, mh_stream_t stream);
 int64_t mh_embedding_bwd_workspace_bytes(int64_t B, int32_t F, int32_t D);
 int32_t mh_embedding_gather_bwd(float* const* tables /*HOST [F]*/, float* const* state /*HOST [F]*/,
                                 const int64_t* table_rows /*HOST [F]*/,

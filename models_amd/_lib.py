@@ -50,6 +50,10 @@ SIGNATURES = {
     "mh_linear_bias_act_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "mh_linear_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_linear_bias_act_bwd": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),
+    "mh_tower_supported": (_i32, [_i64, _i32, _i32]),
+    "mh_tower_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "mh_tower_linear_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p]),
+    "mh_tower_linear_dx": (_i32, [_p, _i64, _p, _i64, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "mh_linear_split_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "mh_linear_bias_act_fwd_split": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p]),
     "mh_linear_bias_act_bwd_split": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i64, _p]),

@@ -532,6 +532,19 @@ def _rowmajor_2d(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def tower_arith() -> bool:
+    """The tower layers (N = 128, K <= 1024, batch >= 4096) run in the fp32-grade six-term split "bf16x6" (mh_tower_split.hip) unless
+    MERLIN_HIP_GEMM_ARITH=f32 asks for the exact fmaf-chain kernels everywhere."""
+    import os
+
+    return os.environ.get("MERLIN_HIP_GEMM_ARITH", "") != "f32"
+
+
+def _tower_ok(M: int, K: int, N: int, x: torch.Tensor) -> bool:
+    return (tower_arith() and N == 128 and bool(_lib.load().mh_tower_supported(M, K, N)) and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0)
+
+
 def _linear_split_ok(M: int, K: int, N: int) -> bool:
     """The Dense layers that run in the opt-in bf16x3 arithmetic under MERLIN_HIP_GEMM_ARITH=bf16x3: wide ones (the 256 x 256 output
     tiles of mh_gemm_split.hip need N >= 256 to be filled; the DCN-v2 deep tower's 3341 -> 512 -> 256)."""
@@ -561,6 +574,12 @@ def linear(
     else:
         _rowmajor_2d(out, "out")
     if M == 0:
+        return out
+    if _tower_ok(M, K, N, x):  # the tower layers in the fp32-grade six-term split (default; MERLIN_HIP_GEMM_ARITH=f32: the exact chain)
+        ws = _workspace(lib.mh_tower_workspace_bytes(M, K, N), x.device, f"tower_{K}x{N}")
+        with _timed(f"linear_{K}x{N}", nbytes=4 * (M * K + K * N + M * N), flops=2 * M * K * N):
+            check(lib.mh_tower_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation], _ptr(out), out.stride(0),
+                                          _ptr(ws), ws.numel(), _stream()), "mh_tower_linear_fwd")
         return out
     if _linear_split_ok(M, K, N):  # opt-in bf16x3 arithmetic of the wide Dense layers
         ws = _workspace(lib.mh_linear_split_workspace_bytes(M, K, N), x.device, "linear_split")
@@ -823,6 +842,14 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         dx = buf[:, :K]
     dW = torch.empty((K, N), dtype=torch.float32, device=x.device)
     db = torch.empty((N,), dtype=torch.float32, device=x.device) if need_db else None
+    # dX of a tower layer (N = 128, K <= 1024, large batch) in the fp32-grade six-term split (mh_tower_split.hip), like its forward
+    tower_dx = need_dx and ACT[x_activation] == 0 and _tower_ok(M, K, N, dy)
+
+    def run_tower_dx():
+        ws = _workspace(lib.mh_tower_workspace_bytes(M, K, N), x.device, f"tower_{K}x{N}")
+        check(lib.mh_tower_linear_dx(_ptr(dy), dy.stride(0), _ptr(W), M, K, N, _ptr(dx), lddx, _ptr(ws), ws.numel(), _stream()),
+              "mh_tower_linear_dx")
+
     split = _linear_split_ok(M, K, N)  # same contract, bf16x3 GEMMs; the dX phase needs the workspace too
     bwd = lib.mh_linear_bias_act_bwd_split if split else lib.mh_linear_bias_act_bwd
     nbytes = lib.mh_linear_split_workspace_bytes(M, K, N) if split else lib.mh_linear_bwd_workspace_bytes(M, K, N)
@@ -836,6 +863,8 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         # runs beside whatever FOLLOWS dX on the launch stream (for the top-MLP layer of a DLRM: the HBM-bound interaction
         # backward) instead of competing with dX for the matrix pipe
         def run_dx():
+            if tower_dx:
+                return run_tower_dx()
             if need_dx:
                 wsx = _workspace(nbytes, x.device, "linear_split_dx") if split else None
                 check(bwd(_ptr(x), x.stride(0), _ptr(W), None, 0, _ptr(dy), dy.stride(0), M, K, N, 0,
@@ -865,6 +894,15 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         SIDE.maybe_join()
         return dx, dW, db
     ws = _workspace(nbytes, x.device, "linear_bwd")
+    if tower_dx:  # dz in place, dX by the tower kernel, dW / db by the exact-chain kernels
+        with _timed(f"linear_bwd_{K}x{N}", nbytes=4 * (2 * M * K + 2 * K * N + 2 * M * N), flops=4 * M * K * N):
+            if act != 0:
+                check(lib.mh_linear_bias_act_bwd(_ptr(x), x.stride(0), None, yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,
+                                                 0, None, 0, None, None, None, 0, _stream()), "mh_linear_bias_act_bwd")
+            run_tower_dx()
+            check(bwd(_ptr(x), x.stride(0), None, None, 0, _ptr(dy), dy.stride(0), M, K, N, 0, 0, None, 0, _ptr(dW), _ptr(db),
+                      _ptr(ws), ws.numel(), _stream()), "mh_linear_bias_act_bwd")
+        return dx, dW, db
     with _timed(f"linear_bwd_{K}x{N}", nbytes=4 * (2 * M * K + 2 * K * N + 2 * M * N), flops=(4 if need_dx else 2) * M * K * N):
         check(
             bwd(_ptr(x), x.stride(0), _ptr(W), yp, ldy, _ptr(dy), dy.stride(0), M, K, N, act,

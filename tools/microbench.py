@@ -179,3 +179,19 @@ if "bagbwd" in which:  # the multi-hot update of bench.py's `embedding_bag` seco
     by = nF * B * (D * 4 + 8) + nnz * 4 + uniq * 4 * D * 4
     timeit(f"bag_bwd_multi adagrad ({nnz} values, {uniq} unique)", lambda: ops.embedding_bag_backward_multi(
         tabs, accs, vs, os_, grad, [f * D for f in range(nF)], "mean", optimizer="adagrad", lr=0.0), nbytes=by, iters=6)
+if "tower" in which:  # the N = 128 tower layers: six-term split (default) against the exact fp32 chain
+    import os
+    for (K, N) in [(415, 128), (256, 128)]:
+        xx = torch.randn(B, (K + 3) // 4 * 4, device=dev)[:, :K]
+        W = torch.randn(K, N, device=dev) * 0.1
+        bb = torch.randn(N, device=dev)
+        for mode in ("", "f32"):
+            if mode:
+                os.environ["MERLIN_HIP_GEMM_ARITH"] = mode
+            else:
+                os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
+            timeit(f"linear fwd {K}x{N} [{mode or 'bf16x6'}]", lambda: ops.linear(xx, W, bb, "relu"), flops=2 * B * K * N, nbytes=4 * B * (K + N))
+            yy = ops.linear(xx, W, bb, "relu")
+            dyy = torch.randn(B, N, device=dev)
+            timeit(f"linear bwd {K}x{N} [{mode or 'bf16x6 dX'}]", lambda: ops.linear_backward(xx, W, yy, dyy, "relu"), flops=4 * B * K * N, nbytes=4 * B * (2 * K + 2 * N))
+        os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
