@@ -340,6 +340,10 @@ __global__ __launch_bounds__(TW_WV * 64, 2) void tower_dx_kernel(const TwDxArgs 
     }
 }
 
+// (dW = x^T dz of these layers was built in the same arithmetic too -- both operands transposed through LDS as bf16 images [3][column][32 batch
+// rows], a workgroup per batch slab accumulating its whole [Kin, 128] partial in registers, partials summed by a second kernel -- and measured
+// 72 + 16 us at 65 536 x 415 against 83 us for the exact-chain split-M kernel alone, and a SLOWER train step (0.99 against 0.95 ms: 104 KB of
+// LDS per workgroup beside the interaction backward).  Not kept: dW / db of a tower layer stay on the exact-chain kernels; profiles/r6_notes.md.)
 inline int64_t tw_al256(int64_t v) { return (v + 255) / 256 * 256; }
 inline int tw_kp(int K) { return (K + TW_BK - 1) / TW_BK * TW_BK; }
 

@@ -8,6 +8,7 @@ test infrastructure only).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional, Sequence, Tuple
 
 import torch
