@@ -1477,6 +1477,12 @@ def main():
     tm = Timing(world, device)
     common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "cpu_baseline": None}
+    from models_amd import ops as _ops_arith
+
+    if _ops_arith.tower_arith():
+        # the arithmetic the path computes in: fp32 everywhere; the tower GEMMs (N = 128, K <= 1024: forward and dX) form every fp32 product
+        # from six bf16 MFMA terms with fp32 accumulators -- fp32-grade (dropped terms <= 2^-25 |x y|), not the fmaf chain's bits
+        common["dtype"] = "f32 (tower GEMMs fwd / dX: bf16x6 six-term split, fp32-grade; MERLIN_HIP_GEMM_ARITH=f32: exact fmaf chain)"
     if shared_gpu:
         common["data"] = "synthetic; TEST TRANSPORT: all ranks share GPU 0 over gloo (MH_BENCH_SHARED_GPU=1) -- not a measurement"
 
