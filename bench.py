@@ -876,7 +876,7 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
     bwd_bytes_8d = nnz * (5 * D * 4 + 4) + F * B * 8
     bwd_bytes_dd = F * B * (D * 4 + 8) + nnz * 4 + uniq * 4 * D * 4  # bag gradients once, table + state rows r / w once per unique id
     res = {"shape": f"{F} ragged features x {B} bags, nnz ~ Poisson({mean_nnz}) ({nnz} ids), D={D}, Criteo-cardinality tables, int32 ids",
-           "algorithmic_bytes_fwd": fwd_bytes, "kernel": "bag_fwd_kernel<int32, COOP> (mh_embedding.hip): wavefront-shuffle segmented reduce",
+           "algorithmic_bytes_fwd": fwd_bytes, "kernel": "bag_fwd_coop_kernel<int32> (mh_embedding.hip): persistent, wavefront-shuffle segmented reduce",
            "fwd": {}, "bwd_adagrad": {}, "bwd_adagrad_one_update": {},
            "bwd_note": "bwd_adagrad: one mh_embedding_bag_bwd per feature (expanded [nnz, D] gradient + its own sort and update); "
                        "bwd_adagrad_one_update: mh_embedding_bag_bwd_multi, all 26 features in one sort / segmented reduce / Adagrad "
@@ -942,7 +942,7 @@ def run_embedding_bag(device, B=65536, D=64, mean_nnz=20, iters=6):
     cb = int(offs[-1]) * (D * 4 + 4) + B * (D * 4 + 8)
     res["cold"] = {"shape": f"one {rows}-row x {D} table (12.8 GB), {B} bags, {int(offs[-1])} uniform ids", "ms": ms, "algorithmic_bytes": cb,
                    "GBps": cb / (ms * 1e-3) / 1e9, "frac": cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    res["roofline"] = {"kernel": "bag_fwd_kernel<int32, COOP>, cold table", "bound": "hbm", "achieved": res["cold"]["GBps"], "peak": HBM_PEAK_GBS,
+    res["roofline"] = {"kernel": "bag_fwd_coop_kernel<int32>, cold table", "bound": "hbm", "achieved": res["cold"]["GBps"], "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": res["cold"]["frac"], "traffic": None, "algorithmic_bytes_per_launch": cb, "avg_launch_ms": ms}
     del big, sets
     torch.cuda.empty_cache()

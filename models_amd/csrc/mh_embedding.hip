@@ -68,14 +68,11 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const GatherArgs args, 
     }
 }
 
-// Bag (multi-hot) lookup.  COOP=false: one LPR-lane group per bag, sequential accumulate
-// (4 independent row loads in flight).  COOP=true (LPR power of two <= 32): the 64/LPR groups
-// of a wavefront split one bag round-robin and combine with wavefront shuffles -- the
-// segmented reduce of the north star; no LDS round trip is needed because a row never spans
-// more than one wavefront.
+// Bag (multi-hot) lookup, short bags: one LPR-lane group per bag, sequential accumulate (4 independent row loads in flight).  Long bags
+// (>= 8 ids on average) take bag_fwd_coop_kernel below.
 //   offsets == nullptr  -> dense list of fixed length L (bag b = [b*L, (b+1)*L)), negatives
 //                          are not pruned (tf.gather semantics, zero row, still counted).
-template <typename IdT, bool COOP>
+template <typename IdT>
 __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ table, int64_t rows,
                                                      const IdT* __restrict__ values,
                                                      const IdT* __restrict__ offsets, int64_t L,
@@ -84,27 +81,11 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
                                                      int64_t out_row_stride) {
     const int t = threadIdx.x;
     const bool prune_neg = (offsets != nullptr);
-    int64_t bag;
-    int c, g, G;
-    if (COOP) {
-        const int wave = t >> 6, lane = t & 63;
-        G = 64 / LPR;
-        g = lane / LPR;
-        c = lane - g * LPR;
-        bag = (int64_t)blockIdx.x * 4 + wave;
-    } else {
-        const int groups = 256 / LPR;
-        const int r_in = t / LPR;
-        c = t - r_in * LPR;
-        g = 0;
-        G = 1;
-        bag = (r_in < groups) ? (int64_t)blockIdx.x * groups + r_in : B;
-    }
-    if (bag >= B) {
-        if (!COOP) return;
-        // COOP: whole wave shares the bag, so the whole wave exits together.
-        return;
-    }
+    const int groups = 256 / LPR;
+    const int r_in = t / LPR;
+    const int c = t - r_in * LPR;
+    const int64_t bag = (r_in < groups) ? (int64_t)blockIdx.x * groups + r_in : B;
+    if (bag >= B) return;
     const int64_t beg = offsets ? (int64_t)offsets[bag] : bag * L;
     const int64_t end = offsets ? (int64_t)offsets[bag + 1] : beg + L;
     // MAX (dense lists only, process_str_sequence_combiner "max", inputs/embedding.py:1579-1580): elementwise maximum
@@ -121,46 +102,10 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
     };
     int cnt = 0;
     const int64_t stride = (int64_t)LPR * 4;
-    if (COOP) {
-        // The ids of the bag are fetched by the LANES, 64 at a time in one coalesced load, and handed to the groups with
-        // shuffles; a group then has up to 8 row loads in flight.  (First version: every group read its own ids, 4 per trip, and
-        // the tail one at a time -- a bag of 20 ids cost offsets -> ids -> rows -> ids -> rows: five dependent round trips; one
-        // 12.8 GB table, 65 536 bags of ~20: 0.50 of the HBM peak.)  The order of the additions inside a group is unchanged:
-        // entry g, g + G, g + 2 G, ... -- results are bit-identical.
-        const int lane = t & 63;
-        for (int64_t c0 = beg; c0 < end; c0 += 64) {
-            const int nchunk = (int)((end - c0) < 64 ? (end - c0) : 64);
-            const IdT myid = (lane < nchunk) ? values[c0 + lane] : (IdT)0;
-            // WAVE-UNIFORM trip count (kb, not g, drives the loop): the shuffle below reads ids out of lanes of OTHER groups, and a group
-            // that had left the loop would be EXEC-masked -- ds_bpermute returns 0 for a disabled source lane, i.e. table row 0 in
-            // place of the real row (chunks of 33 / 34 ids at D = 64, 33 / 49 at D = 128).  Every lane runs every trip; only the
-            // load and the accumulate are predicated.
-            for (int kb = 0; kb < nchunk; kb += 8 * G) {
-                const int k0 = kb + g;
-                f32x4 v[8];
-                int kept[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + u * G;
-                    const bool live = k < nchunk;  // group-uniform
-                    const int64_t id = (int64_t)__shfl(myid, live ? k : 0);
-                    const bool ok = live && id >= 0 && id < rows;
-                    kept[u] = (live && !(prune_neg && id < 0)) ? 1 : 0;
-                    v[u] = ok ? *reinterpret_cast<const f32x4*>(table + id * stride + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (is_max && !live) v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (k0 + u * G < nchunk) comb(acc, v[u]);
-                    cnt += kept[u];
-                }
-            }
-        }
-    }
-    int64_t p = COOP ? end : beg + g;
+    int64_t p = beg;
     // 4 independent loads per trip
-    for (; p + 3 * G < end; p += 4 * G) {
-        int64_t i0 = values[p], i1 = values[p + G], i2 = values[p + 2 * G], i3 = values[p + 3 * G];
+    for (; p + 3 < end; p += 4) {
+        int64_t i0 = values[p], i1 = values[p + 1], i2 = values[p + 2], i3 = values[p + 3];
         const bool k0 = !(prune_neg && i0 < 0), k1 = !(prune_neg && i1 < 0),
                    k2 = !(prune_neg && i2 < 0), k3 = !(prune_neg && i3 < 0);
         const bool o0 = i0 >= 0 && i0 < rows, o1 = i1 >= 0 && i1 < rows, o2 = i2 >= 0 && i2 < rows,
@@ -176,21 +121,13 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
         comb(acc, v3);
         cnt += (int)k0 + (int)k1 + (int)k2 + (int)k3;
     }
-    for (; p < end; p += G) {
+    for (; p < end; ++p) {
         int64_t i0 = values[p];
         const bool k0 = !(prune_neg && i0 < 0);
         const bool o0 = i0 >= 0 && i0 < rows;
         const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
         comb(acc, o0 ? *reinterpret_cast<const f32x4*>(table + i0 * stride + c * 4) : zz);
         cnt += (int)k0;
-    }
-    if (COOP) {
-        for (int off = LPR; off < 64; off <<= 1) {
-            const f32x4 o = {__shfl_xor(acc.x, off), __shfl_xor(acc.y, off), __shfl_xor(acc.z, off), __shfl_xor(acc.w, off)};
-            comb(acc, o);
-            cnt += __shfl_xor(cnt, off);
-        }
-        if (g != 0) return;
     }
     if (is_max && acc.x == -INFINITY) acc = f32x4{0.f, 0.f, 0.f, 0.f};  // a group that saw no position (cannot happen for L >= 1)
     if (cnt > 0) {
@@ -208,7 +145,8 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(const float* __restrict__ 
 // The wave-cooperative lookup as a PERSISTENT kernel (round 6): a wavefront walks bags w, w + W, w + 2 W, ... and keeps three loads of three
 // different bags in flight -- the offsets of bag i + 2, the ids of bag i + 1 (its range arrived an iteration ago) and the rows of bag i -- so a
 // bag costs ONE memory round trip instead of the three dependent ones (offsets -> ids -> rows) of a wavefront that handles a single bag
-// (bag_fwd_kernel<., true>: 0.57 of the HBM peak on a 12.8 GB table).  Same additions in the same order: group g takes entries g, g + G, ...
+// (the round-5 form: 0.52-0.57 of the HBM peak on a 12.8 GB table; this one measures the same 0.57 -- the random 256-byte row reads
+// themselves, 4.3 TB/s of them, are what a cold table allows; tools/gpu_bagfwd.py).  Same additions in the same order: group g takes entries g, g + G, ...
 // of every 64-id chunk, the groups combine by wavefront shuffles -- bit-identical results.
 template <typename IdT>
 __global__ __launch_bounds__(256) void bag_fwd_coop_kernel(const float* __restrict__ table, int64_t rows, const IdT* __restrict__ values,
@@ -312,7 +250,7 @@ int launch_bag(const float* table, int64_t rows, const void* values, const void*
     } else {
         const int groups = 256 / LPR;
         dim3 grid((unsigned)mh_ceil_div(B, groups));
-        MH_LAUNCH((bag_fwd_kernel<IdT, false>), grid, dim3(256), 0, s, table, rows,
+        MH_LAUNCH((bag_fwd_kernel<IdT>), grid, dim3(256), 0, s, table, rows,
                            (const IdT*)values, (const IdT*)offsets, L, B, LPR, combiner, out,
                            out_row_stride);
     }
