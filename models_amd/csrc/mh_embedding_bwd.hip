@@ -1664,12 +1664,192 @@ __global__ __launch_bounds__(256) void bag_index_pad_kernel(const BagMultiArgs a
     }
 }
 
-// (Round 6 also built a bag-major path for tables of a few rows -- a table of 4 .. 96 rows under 1.3 M values is one run of tens of thousands of
-// values per row, 31 % of the values of the multi-hot bench -- in four forms: workgroup-shared LDS accumulators with ds_add_f32 (3.4 ms for the
-// eight small tables, in up to 16 bank-skewed replicas just the same: the LDS float atomic itself is the bound), wavefront-private LDS
-// accumulators with plain read / add / write and register forwarding (1.2 ms), register accumulators fed by ballot counts (0.72 ms).  The sort
-// pipeline spends ~0.4 ms on those values -- their pieces of 16 are the cheap ones of the walk kernel -- so none of them paid and the path is
-// gone; the form that would pay is the count-matrix GEMM (acc[rows, D] += C^T[rows, 64 bags] G[64 bags, D] on the fp32 MFMA): profiles/r6_notes.md.)
+// ---- multi-hot update of SMALL tables (D = 64, rows <= 128) as a count-matrix GEMM on the fp32 matrix pipe ------------------------------
+// A table of a few rows under 1.3 M values (Criteo: eight tables of 4 .. 96 rows) is one run of tens of thousands of values per row.  Through
+// the sort pipeline every one of those values is sorted, listed, and re-reads its bag's 256-byte gradient row from the caches: 31 % of the
+// values of the multi-hot bench, none of which needs a sort to find its duplicates.  Bag-major instead:
+//     acc[rows, D] += C^T[rows, 64 bags] . G'[64 bags, D],   C[b][r] = how often id r occurs in bag b,   G'[b] = grad[b] / divisor(b)
+// per block of 64 neighbouring bags -- a GEMM whose contraction runs over the BAGS.  A wavefront builds C for its block in LDS (lane = bag:
+// a lane walks ITS bag's ids and bumps its own column of 16-bit counts: plain read-modify-write, nobody else touches the column; row stride
+// rows + 2 shorts = an odd number of words, so the lanes' writes of one id fall into 64 different banks), streams the block's gradient rows
+// ONCE straight from global memory as the B operand of v_mfma_f32_32x32x2f32 (lane (n, k): one float of bag k -- 128 contiguous bytes per
+// bag), reads the counts back as the A operand, and keeps acc (<= 4 x 2 tiles of 32 x 32: 128 registers) for all its blocks.  Counts are
+// small integers: count x g is one exact-to-rounding fp32 product, the same sum in another association as adding g count times.
+// What was tried before (all measured on the eight small tables, 10.9 M values; profiles/r6_notes.md): LDS accumulators with ds_add_f32,
+// shared or in 16 bank-skewed replicas 3.4 ms (the LDS float atomic itself); wavefront-private LDS accumulators, plain read / add / write with
+// register forwarding 1.2 ms; register accumulators fed by ballot counts 0.72 ms.  Not used in deterministic mode (the partial blocks of the
+// wavefronts are added in a fixed order, but the sort pipeline's ordered walk is the reproducible statement of this update).
+constexpr int SMALL_TABLE_BYTES = 32 * 1024;  // rows * D * 4
+constexpr int SMALL_BLOCKS = 256;             // wavefronts (= partial blocks) per small feature
+constexpr int SMALL_MAX_ROWS = 128;
+constexpr int SMALL_CSTRIDE = SMALL_MAX_ROWS + 2;  // shorts per bag column of the count matrix (odd number of 32-bit words)
+
+struct BagSmallArgs {
+    const void* values[MH_MAX_FEATURES];
+    const void* offsets[MH_MAX_FEATURES];
+    float* table[MH_MAX_FEATURES];
+    float* state[MH_MAX_FEATURES];
+    float* state2[MH_MAX_FEATURES];
+    int64_t goff[MH_MAX_FEATURES];   // float offset of the feature inside a gradient row
+    int64_t soff[MH_MAX_FEATURES];   // float offset of the feature's partial blocks in gsum: [nblk][rows * D sums | rows flags]
+    int rows[MH_MAX_FEATURES];
+    int feat[MH_MAX_FEATURES];       // original feature index (row of `scale`)
+};
+
+template <typename IdT>
+__global__ __launch_bounds__(256, 2) void bag_small_gemm_kernel(const BagSmallArgs a, int64_t L, int64_t B, const float* __restrict__ grad,
+                                                               int64_t grad_row_stride, const float* __restrict__ scale,
+                                                               float* __restrict__ gsum) {
+    constexpr int D = 64;
+    __shared__ uint16_t cnt_all[4][64 * SMALL_CSTRIDE];  // per wavefront: [bag][row] counts
+    const int fs = blockIdx.y;
+    const int rows = a.rows[fs];
+    const int RT = (rows + 31) / 32;  // row tiles (wave-uniform)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nwaves = (int)gridDim.x * 4, wid = (int)blockIdx.x * 4 + wave;
+    uint16_t* cnt = cnt_all[wave];
+    const IdT* values = static_cast<const IdT*>(a.values[fs]);
+    const IdT* offsets = static_cast<const IdT*>(a.offsets[fs]);
+    const float* sc = scale + (int64_t)a.feat[fs] * B;
+    const float* gcol = grad + a.goff[fs] + l31;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][ct][i] = 0.f;
+    float seen[4] = {0.f, 0.f, 0.f, 0.f};  // sum of the counts this lane fed for row rt * 32 + l31: > 0 <=> the row was looked up
+    const int64_t nblocks = (B + 63) / 64;
+    for (int64_t blk = wid; blk < nblocks; blk += nwaves) {
+        const int64_t bb = blk * 64;
+        const int nbag = (int)((B - bb < 64) ? B - bb : 64);
+        const int64_t bl = bb + (lane < nbag ? lane : nbag - 1);
+        const int64_t beg = offsets ? (int64_t)offsets[bl] : bl * L;
+        const int64_t end = offsets ? (int64_t)offsets[bl + 1] : beg + L;
+        const int len = lane < nbag ? (int)(end - beg) : 0;
+        const float dvl = sc[bl];
+        // zero this wavefront's count matrix (64 x SMALL_CSTRIDE shorts = 4160 words)
+        for (int i = lane; i < 64 * SMALL_CSTRIDE / 2; i += 64) reinterpret_cast<uint32_t*>(cnt)[i] = 0u;
+        int maxlen = len;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // C: lane = bag walks its own ids, four loads in flight (branch-free: a position past the bag re-reads its first id, masked)
+        uint16_t* mine = cnt + lane * SMALL_CSTRIDE;
+        for (int t0 = 0; t0 < maxlen; t0 += 4) {
+            int64_t idv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = t0 + u < len;
+                const int64_t v = (int64_t)values[live ? beg + t0 + u : (len > 0 ? beg : 0)];
+                idv[u] = (live && v >= 0 && v < rows) ? v : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (idv[u] >= 0) mine[idv[u]] = (uint16_t)(mine[idv[u]] + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // acc += C^T G': 32 k-steps of two bags; B operand: lane (n = l31, k = h) = G'[bag 2 s + h][ct * 32 + n]
+#pragma unroll 1
+        for (int s0 = 0; s0 < 32; s0 += 8) {
+            float bv[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kb = 2 * (s0 + u) + h;
+                const int kc = kb < nbag ? kb : nbag - 1;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bv[u][ct] = gcol[(bb + kc) * grad_row_stride + ct * 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kb = 2 * (s0 + u) + h;
+                // (the builtin is an INTEGER lane read: a float handed to it is converted, i.e. truncated -- sqrt(30) became 5)
+                const float d0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dvl), 2 * (s0 + u)));
+                const float d1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dvl), 2 * (s0 + u) + 1));
+                const float dv = h ? d1 : d0;
+                const bool live = kb < nbag;
+                const float b0 = live ? bv[u][0] / dv : 0.f, b1 = live ? bv[u][1] / dv : 0.f;
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    if (rt < RT) {  // wave-uniform
+                        const float av = live ? (float)cnt[kb * SMALL_CSTRIDE + rt * 32 + l31] : 0.f;
+                        seen[rt] += av;
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[rt][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the counts are read: the next block may zero them
+    }
+    // partial block of this wavefront: [rows][D] sums + [rows] flags; C layout: entry i of lane (l31, h) = row (i >> 2) * 8 + h * 4 + (i & 3), column l31
+    float* out = gsum + a.soff[fs] + (int64_t)wid * ((int64_t)rows * D + ((rows + 3) & ~3));
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        if (rt < RT) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r = rt * 32 + (i >> 2) * 8 + h * 4 + (i & 3);
+                    if (r < rows) out[(int64_t)r * D + ct * 32 + l31] = acc[rt][ct][i];
+                }
+            const float tot = seen[rt] + __shfl_xor(seen[rt], 32);
+            const int r = rt * 32 + l31;
+            if (h == 0 && r < rows) reinterpret_cast<uint32_t*>(out + (int64_t)rows * D)[r] = tot > 0.f ? 1u : 0u;
+        }
+    }
+}
+
+// optimizer step of the touched rows of the small tables (lazy: an untouched row keeps weights AND state): the row's gradient is the sum of
+// the workgroups' partial blocks in index order
+__global__ __launch_bounds__(256) void bag_small_apply_kernel(const BagSmallArgs a, int nblk, int D, int LPR, const float* __restrict__ gsum,
+                                                             int opt, const OptHyper hp) {
+    const int fs = blockIdx.y;
+    const int groups = 256 / LPR;
+    const int gi = threadIdx.x / LPR;
+    const int c4 = threadIdx.x - gi * LPR;
+    if (gi >= groups) return;
+    const int r = blockIdx.x * groups + gi;
+    const int rows = a.rows[fs];
+    if (r >= rows) return;
+    const float* part = gsum + a.soff[fs];
+    const int64_t blk = (int64_t)rows * D + ((rows + 3) & ~3);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    uint32_t any = 0;
+    for (int q = 0; q < nblk; q += 4) {  // four blocks in flight
+        f32x4 v[4];
+        uint32_t t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int qq = (q + u < nblk) ? q + u : nblk - 1;
+            v[u] = *reinterpret_cast<const f32x4*>(part + qq * blk + (int64_t)r * D + c4 * 4);
+            t[u] = reinterpret_cast<const uint32_t*>(part + qq * blk + (int64_t)rows * D)[r];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (q + u < nblk) {
+                g += v[u];
+                any |= t[u];
+            }
+    }
+    if (!any) return;
+    FeatRow ft;
+    ft.table = a.table[fs];
+    ft.state = a.state[fs];
+    ft.state2 = a.state2[fs];
+    ft.first = 0;
+    ft.offset = 0;
+    RowRmw rr;
+    load_row(ft, (int64_t)r, D, c4, opt, rr);
+    finish_row(rr, g, opt, hp);
+}
+
 // gs[f][bag][:] = grad[bag][offset f ..] / scale[f][bag]: the gradient row every value of the bag adds to its table row, formed ONCE per bag
 // (the reduce kernel of round 5 divided once per value).  Streaming: 16 bytes per thread in, 16 out.
 __global__ __launch_bounds__(256) void bag_prescale_kernel(const float* __restrict__ grad, int64_t grad_row_stride, const BwdArgsOffsets off,
@@ -1685,7 +1865,7 @@ __global__ __launch_bounds__(256) void bag_prescale_kernel(const float* __restri
 }
 
 struct BagMultiWs {
-    int64_t Bp, off_scale, off_map, off_ids, off_gs, off_inner, total;
+    int64_t Bp, off_scale, off_map, off_ids, off_gs, off_small, small_words, off_inner, total;
 };
 
 bool bag_multi_ws(int64_t B, int64_t max_nnz, int F, int D, BagMultiWs* w) {
@@ -1697,6 +1877,9 @@ bool bag_multi_ws(int64_t B, int64_t max_nnz, int F, int D, BagMultiWs* w) {
     w->off_map = o;   o = (int64_t)align_up((size_t)(o + (int64_t)F * w->Bp * 4), 256);
     w->off_ids = o;   o = (int64_t)align_up((size_t)(o + (int64_t)F * w->Bp * 8), 256);
     w->off_gs = o;    o = (int64_t)align_up((size_t)(o + (int64_t)F * B * D * 4), 256);  // pre-scaled feature-major gradient
+    // small tables: per feature SMALL_BLOCKS partial blocks of [rows, D] sums + [rows] flags, rows * D * 4 <= SMALL_TABLE_BYTES
+    w->small_words = (int64_t)F * SMALL_BLOCKS * (SMALL_TABLE_BYTES / 4 + SMALL_TABLE_BYTES / 16 + 4);
+    w->off_small = o; o = (int64_t)align_up((size_t)(o + w->small_words * 4), 256);
     w->off_inner = o; o += inner;
     w->total = o;
     return true;
@@ -2023,9 +2206,51 @@ int32_t mh_embedding_bag_bwd_multi(float* const* tables, float* const* state, fl
     if (ids_dtype == MH_I32) MH_LAUNCH((bag_scale_multi_kernel<int32_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
     else MH_LAUNCH((bag_scale_multi_kernel<int64_t>), gs, dim3(256), 0, s, ba, L, B, combiner, scale);
 
-    int nbig = 0, big[MH_MAX_FEATURES];
-    for (int f = 0; f < F; ++f) big[nbig++] = f;
+    // ---- small tables (D = 64, <= 128 rows): the count-matrix GEMM (kernel comment); everything else: the sort pipeline ------------------
     const int LPR = D / 4;
+    bool small_ok = !deterministic_mode() && D == 64;
+    if (const char* e = MH_LAB_ENV("MERLIN_HIP_BAG_SMALL")) small_ok = small_ok && atoi(e) != 0;
+    BagSmallArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    int nsmall = 0, nbig = 0, big[MH_MAX_FEATURES];
+    int64_t sw = 0;  // words used of the small-table buffers
+    int max_small_rows = 0;
+    // one partial block per wavefront: SMALL_BLOCKS wavefronts per feature at most (64 bags per block of work)
+    int64_t nwg = SMALL_BLOCKS / 4;
+    const int64_t max_wg = mh_ceil_div(mh_ceil_div(B, 64), 4);
+    if (nwg > max_wg) nwg = max_wg;
+    const int64_t nblk = nwg * 4;
+    for (int f = 0; f < F; ++f) {
+        const bool is_small = small_ok && nnz[f] > 0 && table_rows[f] <= SMALL_MAX_ROWS && table_rows[f] * D * 4 <= SMALL_TABLE_BYTES;
+        if (!is_small) {
+            big[nbig++] = f;
+            continue;
+        }
+        const int k = nsmall++;
+        sa.values[k] = values[f];
+        sa.offsets[k] = offsets ? offsets[f] : nullptr;
+        sa.table[k] = tables[f];
+        sa.state[k] = state ? state[f] : nullptr;
+        sa.state2[k] = state2 ? state2[f] : nullptr;
+        sa.goff[k] = grad_offset[f];
+        sa.rows[k] = (int)table_rows[f];
+        sa.feat[k] = f;
+        sa.soff[k] = sw;
+        sw += nblk * (table_rows[f] * D + ((table_rows[f] + 3) & ~3ll));  // nblk partial blocks of [rows, D] sums + [rows] flags
+        if ((int)table_rows[f] > max_small_rows) max_small_rows = (int)table_rows[f];
+    }
+    if (nsmall > 0) {
+        float* gsum = reinterpret_cast<float*>(ws + w.off_small);
+        MH_REQUIRE(sw <= w.small_words, "mh_embedding_bag_bwd_multi: small-table buffers out of range");
+        const OptHyper hp = {lr, eps, beta1, beta2, lr_device};
+        const dim3 ga((unsigned)nwg, (unsigned)nsmall);
+        if (ids_dtype == MH_I32) MH_LAUNCH((bag_small_gemm_kernel<int32_t>), ga, dim3(256), 0, s, sa, L, B, grad, grad_row_stride, scale, gsum);
+        else MH_LAUNCH((bag_small_gemm_kernel<int64_t>), ga, dim3(256), 0, s, sa, L, B, grad, grad_row_stride, scale, gsum);
+        MH_LAUNCH(bag_small_apply_kernel, dim3((unsigned)mh_ceil_div(max_small_rows, 256 / LPR), (unsigned)nsmall), dim3(256), 0, s, sa, (int)nblk, D, LPR,
+                  gsum, optimizer, hp);
+        MH_CHECK_LAUNCH("mh_embedding_bag_bwd_multi (small tables)");
+    }
+    if (nbig == 0) return MH_OK;
 
     // ---- the other features: bag of every value + padded ids, pre-scaled feature-major gradient, ONE sort / piece list / walk ---------
     int64_t big_nnz = 0;
