@@ -725,8 +725,14 @@ def run_cross_gemm(device, M=65536, d=3344, iters=4):
     torch.cuda.synchronize()
     ms = a.elapsed_time(e) / iters
     tf = 2.0 * M * d * d / (ms * 1e-3) / 1e12
-    return {"shape": f"{M} x {d} x {d}, cross epilogue fused", "kernel": "gemm2_kernel<256,128,4,2,NN,3> (mh_gemm2.h)", "ms": ms,
-            "tflops": tf, "frac_of_peak": tf / MFMA_F32_PEAK_TF}
+    arith = ops.gemm_arith()
+    if arith == "f32":
+        return {"shape": f"{M} x {d} x {d}, cross epilogue fused", "kernel": "gemm2_kernel<256,128,4,2,NN,3> (mh_gemm2.h)", "dtype": "f32 (exact fmaf chain)",
+                "ms": ms, "tflops": tf, "frac_of_peak": tf / MFMA_F32_PEAK_TF}
+    terms = 3 if arith == "bf16x3" else 6
+    return {"shape": f"{M} x {d} x {d}, cross epilogue fused (incl. the operand splits)", "kernel": "gemm_split_nt_kernel<1> (mh_gemm_split.hip)",
+            "dtype": f"{arith} ({terms} bf16 MFMA terms per fp32 product)", "ms": ms, "fp32_equivalent_tflops": tf,
+            "frac_of_bf16_peak": terms * tf / MFMA_BF16_PEAK_TF}
 
 
 def warm_until_flat(step, tm: Timing, group=10, tol=0.03, max_groups=30):
@@ -1159,19 +1165,26 @@ def run_dcn(args, device, tm: Timing):
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
     from models_amd import ops as _ops
 
-    if _ops.gemm_arith() == "bf16x3":
-        res["dtype"] = ("bf16x3 (fp32-equivalent split: the three GEMMs of every cross layer = hi hi + hi lo + lo hi on the bf16 MFMA, fp32 "
-                        "accumulators); embeddings, deep MLP and optimizer f32")
+    arith = _ops.gemm_arith()
+    if arith == "bf16x3":
+        res["dtype"] = ("bf16x3 (opt-in three-term split: the three GEMMs of every cross layer and the wide Dense layers = hi hi + hi lo + lo hi on the bf16 "
+                        "MFMA, fp32 accumulators; 2^-17 per operand); embeddings, small layers and optimizer f32")
+    elif arith == "bf16x6":
+        res["dtype"] = ("f32 (cross / wide Dense GEMMs: bf16x6 six-term split on the bf16 MFMA, fp32 accumulators, fp32-grade; "
+                        "MERLIN_HIP_GEMM_ARITH=f32: exact fmaf chains)")
+    if arith != "f32":
         res["mfma"] = {}  # the f32-peak fractions do not apply to these launches
     if tm.world > 1:
         res["exchange"] = exchange_summary(runner)
         res["exchange"]["dense_bucket_bytes"] = int(runner._bucket.numel() * 4) if getattr(runner, "_bucket", None) is not None else None
-    if cross and _ops.gemm_arith() == "bf16x3":
+    if cross and arith != "f32":
+        terms = 3 if arith == "bf16x3" else 6
         tf = km[cross]["flops"] / (km[cross]["total_ms"] * 1e-3) / 1e12
-        res["roofline"] = {"kernel": "gemm_split_nt_kernel<1> (mh_gemm_split.hip: 256 x 256 tiles, hi / lo k-tiles of k-tile major operand images through a 2-deep LDS DMA ring) + "
-                                     "the split of x and the transposed split of W", "op": cross, "bound": "mfma", "achieved": 3 * tf,
-                           "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3 * tf / MFMA_BF16_PEAK_TF, "traffic": None,
-                           "fp32_equivalent_tflops": tf, "avg_launch_ms": km[cross]["avg_ms"]}
+        geo = "256 x 256 tiles, hi / lo" if terms == 3 else "256 x 128 tiles, h / m / l"
+        res["roofline"] = {"kernel": f"gemm_split_nt_kernel<1> (mh_gemm_split.hip: {geo} k-tiles of k-tile major operand images through a 2-deep LDS DMA ring) + "
+                                     "the split of x and the transposed split of W", "op": cross, "bound": "mfma", "achieved": terms * tf,
+                           "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": terms * tf / MFMA_BF16_PEAK_TF, "traffic": None,
+                           "bf16_terms_per_fp32_product": terms, "fp32_equivalent_tflops": tf, "avg_launch_ms": km[cross]["avg_ms"]}
     elif cross:
         tf = km[cross]["flops"] / (km[cross]["total_ms"] * 1e-3) / 1e12
         res["roofline"] = {"kernel": "gemm2_kernel<256,128,4,2,NN,3> (mh_gemm2.h: DMA tiles, 3-deep ring; cross epilogue, p = xW + b stored for the backward in train mode)", "op": cross, "bound": "mfma", "achieved": tf,
@@ -1483,6 +1496,8 @@ def main():
         # the arithmetic the path computes in: fp32 everywhere; the tower GEMMs (N = 128, K <= 1024: forward and dX) form every fp32 product
         # from six bf16 MFMA terms with fp32 accumulators -- fp32-grade (dropped terms <= 2^-25 |x y|), not the fmaf chain's bits
         common["dtype"] = "f32 (tower GEMMs fwd / dX: bf16x6 six-term split, fp32-grade; MERLIN_HIP_GEMM_ARITH=f32: exact fmaf chain)"
+    if _ops_arith.gemm_arith() == "bf16x3":
+        common["dtype"] = "f32 + bf16x3 (opt-in three-term split of the cross / wide Dense GEMMs) + bf16x6 tower GEMMs"
     if shared_gpu:
         common["data"] = "synthetic; TEST TRANSPORT: all ranks share GPU 0 over gloo (MH_BENCH_SHARED_GPU=1) -- not a measurement"
 
@@ -1846,7 +1861,19 @@ def main():
             return r
 
         secondary("scorer_fwd_bf16x3", scorer_fwd_split)
+        def with_gemm_arith(mode, fn):
+            prev = os.environ.get("MERLIN_HIP_GEMM_ARITH")
+            os.environ["MERLIN_HIP_GEMM_ARITH"] = mode
+            try:
+                return fn()
+            finally:
+                if prev is None:
+                    os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
+                else:
+                    os.environ["MERLIN_HIP_GEMM_ARITH"] = prev
+
         secondary("dcn_cross_gemm", lambda: run_cross_gemm(device))
+        secondary("dcn_cross_gemm_f32_chain", lambda: with_gemm_arith("f32", lambda: run_cross_gemm(device)))
         secondary("twotower_train", lambda: pick(run_twotower(args, device, tm, steps=20, warmup=3, sustain=0.0),
                                                  ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline")))
         secondary("twotower_train_b64k", lambda: pick(run_twotower(args, device, tm, steps=8, warmup=2, sustain=0.0, batch=65536),
@@ -1877,25 +1904,18 @@ def main():
             sub.steps, sub.warmup, sub.sustain, sub.batches, sub.mode = 6, 2, 0.0, 2, "train"
             r = run_dcn(sub, device, tm)
             torch.cuda.empty_cache()
-            return pick(r, ("metric", "value", "unit", "ms_per_step", "config", "mfma", "kernels_ms", "roofline"))
+            return pick(r, ("metric", "value", "unit", "ms_per_step", "config", "dtype", "mfma", "kernels_ms", "roofline"))
 
         def dcn_train_split():
-            prev = os.environ.get("MERLIN_HIP_GEMM_ARITH")
-            os.environ["MERLIN_HIP_GEMM_ARITH"] = "bf16x3"
-            try:
-                sub = argparse.Namespace(**vars(args))
-                sub.steps, sub.warmup, sub.sustain, sub.batches, sub.mode = 6, 2, 0.0, 2, "train"
-                r = run_dcn(sub, device, tm)
-            finally:
-                if prev is None:
-                    os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
-                else:
-                    os.environ["MERLIN_HIP_GEMM_ARITH"] = prev
-            torch.cuda.empty_cache()
-            return pick(r, ("metric", "value", "unit", "ms_per_step", "config", "dtype", "kernels_ms", "roofline"))
+            r = with_gemm_arith("bf16x3", dcn_train)
+            return r
+
+        def dcn_train_f32_chain():
+            return with_gemm_arith("f32", dcn_train)
 
         if args.mode == "train":
             secondary("dcn_train", dcn_train)
+            secondary("dcn_train_f32_chain", dcn_train_f32_chain)
             secondary("dcn_train_bf16x3", dcn_train_split)
             secondary("embedding_bwd_nodup", lambda: run_embedding_bwd_nodup(device))
             secondary("c4_one_gpu", lambda: run_c4_one_gpu(args, device, tm))

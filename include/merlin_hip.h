@@ -175,12 +175,14 @@ int32_t mh_set_deterministic(int32_t on);
  *     MFMA rate).  Not bit-identical to mode 0: opt-in (initial value MERLIN_HIP_SCORER_ARITH=bf16x3 through the Python layer). */
 int32_t mh_set_scorer_arith(int32_t mode);
 
-/* ---- a9 in the same opt-in arithmetic: the three GEMMs of a full-rank DCN-v2 cross layer (Cross.call, blocks/cross.py:188-202) ----
+/* ---- a9 on the split-bf16 GEMM: the three GEMMs of a full-rank DCN-v2 cross layer (Cross.call, blocks/cross.py:188-202) ----
  * mh_cross_layer_fwd_split = mh_cross_layer_fwd / _fwd_save (p_out may be NULL), mh_cross_layer_bwd_split = mh_cross_layer_bwd
- * (same phases, selected by the non-NULL outputs) with every product formed as hi hi + hi lo + lo hi on the bf16 MFMA (fp32
- * accumulators; operands split -- and, for dW, transposed -- once per call into the workspace).  d % 4 == 0 (zero-padded layer).
- * mh_set_gemm_arith(1) only records the caller's choice for hosts that dispatch on it (initial value MERLIN_HIP_GEMM_ARITH=bf16x3
- * through the Python layer): the two entry points below ALWAYS compute in the split arithmetic. */
+ * (same phases, selected by the non-NULL outputs) with every fp32 product formed from bf16 pieces on the bf16 MFMA (fp32 accumulators;
+ * operands split -- and, for dW, transposed -- once per call into the workspace).  d % 4 == 0 (zero-padded layer).
+ * mh_set_gemm_arith(mode) selects WHICH split the *_split entry points compute in: 2 = six terms "bf16x6" (x = h + m + l, products
+ * h h + h m + m h + h l + l h + m m; dropped terms <= 2^-25 of a product: fp32-grade -- what the Python layer sets by default);
+ * 1 (and the initial 0) = three terms "bf16x3" (x = hi + lo, hi hi + hi lo + lo hi; 2^-17 per operand: MERLIN_HIP_GEMM_ARITH=bf16x3).
+ * The exact fp32 kernels are the entry points WITHOUT the _split suffix (MERLIN_HIP_GEMM_ARITH=f32 through the Python layer). */
 int32_t mh_set_gemm_arith(int32_t mode);
 int64_t mh_cross_layer_split_workspace_bytes(int64_t M, int32_t d);
 int32_t mh_cross_layer_fwd_split(const float* x0, const float* x, const float* W, const float* b, int64_t M, int32_t d,
@@ -188,8 +190,8 @@ int32_t mh_cross_layer_fwd_split(const float* x0, const float* x, const float* W
 int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p, const float* dout, const float* W,
                                  int64_t M, int32_t d, float* g, float* dx0_acc, int32_t accumulate_dx0, float* dx,
                                  float* dW, float* db, void* workspace, int64_t workspace_bytes, mh_stream_t stream);
-/* Dense layer (blocks/mlp.py:275-280) in the same opt-in arithmetic: the contracts of mh_linear_bias_act_fwd / _bwd (same argument
- * meaning, dy overwritten with dz, dx masked by x_act, dW / db optional) with the three GEMMs on the bf16x3 kernel; the workspace
+/* Dense layer (blocks/mlp.py:275-280) on the same split-bf16 GEMM: the contracts of mh_linear_bias_act_fwd / _bwd (same argument
+ * meaning, dy overwritten with dz, dx masked by x_act, dW / db optional) with the three GEMMs in the arithmetic mh_set_gemm_arith selected; the workspace
  * (mh_linear_split_workspace_bytes) is needed by every phase.  Meant for wide layers (N >= 256: whole 256 x 256 output tiles). */
 int64_t mh_linear_split_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int32_t mh_linear_bias_act_fwd_split(const float* x, int64_t ldx, const float* W, const float* b, int64_t M, int32_t K, int32_t N,

@@ -89,6 +89,18 @@ __device__ __forceinline__ void mh_split_pair(float v0, float v1, uint32_t& hi, 
     const mh_f32x2_t hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v - hf, mh_bf16x2_t));
 }
+// h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) for a PAIR of values: the three bf16 pieces of the six-term "bf16x6" arithmetic -- together they
+// hold the 24-bit significand (|v - h - m - l| <= 2^-27 |v|); both subtractions are exact in fp32
+__device__ __forceinline__ void mh_split3_pair(float v0, float v1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const mh_f32x2_t v = {v0, v1};
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mh_bf16x2_t));
+    const mh_f32x2_t hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    const mh_f32x2_t r1 = v - hf;
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, mh_bf16x2_t));
+    const mh_f32x2_t mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    const mh_f32x2_t r2 = r1 - mf;
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, mh_bf16x2_t));
+}
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -36,21 +36,22 @@ constexpr int GBK = 32;
 //             MFMA of the 256 x 128 tile; 7 % of the column tiles of d = 3344 are padding (3.3 % at BN = 128).
 //   BM = BN = 256, BK = 16, 5 stages of 32 KB (160 KB): the same tile with FOUR k-tiles in flight instead of one -- the ring of the
 //             BK = 32 form tolerates ~1.3 us of load latency (one 64 KB tile ahead of 1.3 us of MFMAs), this one ~2.5 us.
-template <int BM, int BN, int BK_ = 32, int ST_ = 0>
+template <int BM, int BN, int BK_ = 32, int ST_ = 0, int NIMG_ = 2>
 struct Geo {
+    static constexpr int NIMG = NIMG_;                   // bf16 images per operand: 2 (hi, lo: bf16x3) or 3 (h, m, l: bf16x6)
     static constexpr int BK = BK_;
     static constexpr int CPR = BK / 8;                   // 16-byte chunks per row of a k-tile
     static constexpr int RS = BK * 2;                    // bytes per row of a k-tile in LDS
     static constexpr int KS = BK / 16;                   // 16-wide k-steps per tile
     static constexpr int NT = BM * 2;                    // threads: 64 rows per wavefront, two column wavefronts
     static constexpr int NB = BN / 64;                   // 32-column blocks per wavefront
-    static constexpr int ST = ST_ ? ST_ : ((BM == 256 && BN == 128) ? 3 : 2);  // ring depth
+    static constexpr int ST = ST_ ? ST_ : ((BM == 256 && BN == 128 && NIMG_ == 2) ? 3 : 2);  // ring depth
     static constexpr int A_ARR = BM * BK * 2;
     static constexpr int B_ARR = BN * BK * 2;
-    static constexpr int STAGE = 2 * A_ARR + 2 * B_ARR;
+    static constexpr int STAGE = NIMG * (A_ARR + B_ARR);
     static constexpr int LDS = ST * STAGE;
-    static constexpr int DMA_A = 2 * BM * CPR / NT;      // A chunks of 16 bytes per thread and k-tile
-    static constexpr int DMA_B = 2 * BN * CPR / NT;
+    static constexpr int DMA_A = NIMG * BM * CPR / NT;   // A chunks of 16 bytes per thread and k-tile
+    static constexpr int DMA_B = NIMG * BN * CPR / NT;
     static constexpr int DMA = DMA_A + DMA_B;
 };
 
@@ -63,8 +64,10 @@ __device__ __forceinline__ uint16_t g_bf16(float x) {
 __device__ __forceinline__ float g_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 // x [R, C] (leading dimension ld) -> hi, lo [R, Cp] bf16, columns C .. Cp - 1 zero (Cp % 8 == 0).  One 8-column group per thread.
+// mid == nullptr: two images (hi, lo) = the three-term arithmetic; mid != nullptr: three images (h, m, l in hi, mid, lo) = the six-term one
 __global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int Cp,
-                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int pack) {
+                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int pack,
+                                                           uint16_t* __restrict__ mid = nullptr) {
     const int g8 = Cp / 8;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * g8) return;
@@ -97,40 +100,46 @@ __global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restr
             for (int j = 0; j < 4; ++j) v8[4 * q + j] = (c + j < C) ? x[r * ld + c + j] : 0.f;
         }
     }
-    uint32_t wh[4], wl[4];
+    uint32_t wh[4], wl[4], wm[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        mh_split_pair(v8[2 * k], v8[2 * k + 1], wh[k], wl[k]);
+        if (mid) mh_split3_pair(v8[2 * k], v8[2 * k + 1], wh[k], wm[k], wl[k]);
+        else mh_split_pair(v8[2 * k], v8[2 * k + 1], wh[k], wl[k]);
     }
     *reinterpret_cast<uint4*>(hi + dst) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
     *reinterpret_cast<uint4*>(lo + dst) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    if (mid) *reinterpret_cast<uint4*>(mid + dst) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
 }
 
 // x [R, C] (ld) -> hiT, loT [C, Rp] bf16 (the transpose), columns R .. Rp - 1 zero (Rp % 64 == 0).  64 x 64 tiles through LDS.
 __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int64_t Rp,
-                                                                uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT, int pack) {
-    __shared__ uint16_t sh[64][66], sl[64][66];
+                                                                uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT, int pack,
+                                                                uint16_t* __restrict__ midT = nullptr) {
+    __shared__ uint16_t sh[64][66], sl[64][66], sm[64][66];
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         float v = 0.f;
         if (r0 + r < R && c0 + c < C) v = x[(r0 + r) * ld + c0 + c];
-        uint32_t wh2, wl2;
-        mh_split_pair(v, 0.f, wh2, wl2);
+        uint32_t wh2, wl2, wm2 = 0;
+        if (midT) mh_split3_pair(v, 0.f, wh2, wm2, wl2);
+        else mh_split_pair(v, 0.f, wh2, wl2);
         sh[r][c] = (uint16_t)wh2;
         sl[r][c] = (uint16_t)wl2;
+        sm[r][c] = (uint16_t)wm2;
     }
     __syncthreads();
     // thread (c, seg): rows seg * 16 .. + 15 of column c -> 32 contiguous bytes of row c0 + c of the transposed arrays
     const int c = threadIdx.x & 63, seg = threadIdx.x >> 6;
     if (c0 + c >= C) return;
-    uint32_t wh[8], wl[8];
+    uint32_t wh[8], wl[8], wm[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int r = seg * 16 + 2 * k;
         wh[k] = (uint32_t)sh[r][c] | ((uint32_t)sh[r + 1][c] << 16);
         wl[k] = (uint32_t)sl[r][c] | ((uint32_t)sl[r + 1][c] << 16);
+        wm[k] = (uint32_t)sm[r][c] | ((uint32_t)sm[r + 1][c] << 16);
     }
     // packed: element (row c0 + c, k = r0 + seg 16 ...) of the [C, Rp] result lives at ((k / 32) C + row) 32 + k % 32
     const int64_t off = pack ? (((r0 >> 5) + (seg >> 1)) * (int64_t)C + c0 + c) * 32 + (seg & 1) * 16 : (int64_t)(c0 + c) * Rp + r0 + seg * 16;
@@ -140,10 +149,16 @@ __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __
     *reinterpret_cast<uint4*>(ph + 8) = make_uint4(wh[4], wh[5], wh[6], wh[7]);
     *reinterpret_cast<uint4*>(pl) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
     *reinterpret_cast<uint4*>(pl + 8) = make_uint4(wl[4], wl[5], wl[6], wl[7]);
+    if (midT) {
+        uint16_t* pm = midT + off;
+        *reinterpret_cast<uint4*>(pm) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
+        *reinterpret_cast<uint4*>(pm + 8) = make_uint4(wm[4], wm[5], wm[6], wm[7]);
+    }
 }
 
 struct GsArgs {
-    const uint16_t *ah, *al, *bh, *bl;  // A [M, Kp], B^T [N, Kp] bf16 bit patterns, zero-padded to Kp.  Row-major (element (r, k) at
+    const uint16_t *ai[3], *bi[3];      // images of A [M, Kp] and B^T [N, Kp] (bf16 bit patterns, zero-padded to Kp): [0] = hi, [1] = lo
+                                        // (two images, bf16x3) or [0] = h, [1] = m, [2] = l (three, bf16x6).  Row-major (element (r, k) at
                                         // r lda + k) or PACKED k-tile major (at ((k / 32) rows + r) 32 + k % 32: the 64 bytes a row
                                         // contributes to a k-tile lie next to those of its neighbours, so a tile-load instruction of a
                                         // wavefront fetches 1 KB contiguous = 8 whole cache lines instead of 16 half lines)
@@ -176,9 +191,10 @@ __device__ __forceinline__ void g_wait_vm_and_barrier() {
 }
 __device__ __forceinline__ f32x16 g_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-template <int EPI, int BM, int BN, bool PIPE, int BK = 32, int ST = 0>
+template <int EPI, int BM, int BN, bool PIPE, int BK = 32, int ST = 0, int NIMG = 2>
 __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kernel(const GsArgs a) {
-    using G = Geo<BM, BN, BK, ST>;
+    using G = Geo<BM, BN, BK, ST, NIMG>;
+    constexpr int TERMS = NIMG == 3 ? 6 : 3;  // bf16 MFMAs per fp32-equivalent one
     constexpr int CPR = G::CPR, RS = G::RS, KS = G::KS;
     constexpr int GBM = BM, GBN = BN, GNT = G::NT, GST = G::ST, G_A_ARR = G::A_ARR, G_B_ARR = G::B_ARR, G_STAGE = G::STAGE, G_DMA = G::DMA;
     constexpr int NB = G::NB;
@@ -207,22 +223,22 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
     // DMA sources of this thread inside a k-tile (rows clamped to the last valid row: their products are never stored)
     const uint16_t* src[G_DMA];
 #pragma unroll
-    for (int j = 0; j < G::DMA_A; ++j) {  // A: 2 arrays x BM rows x 4 chunks
+    for (int j = 0; j < G::DMA_A; ++j) {  // A: NIMG arrays x BM rows x 4 chunks
         const int L = j * GNT + threadIdx.x;
         const int arr = L / (BM * CPR), Lp = L % (BM * CPR), r = Lp / CPR, p = Lp % CPR;
         const int c = p ^ (CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1));
         int64_t row = row0 + r;
         if (row > a.M - 1) row = a.M - 1;
-        src[j] = (arr ? a.al : a.ah) + row * (a.pack ? (int64_t)32 : a.lda) + c * 8;
+        src[j] = a.ai[arr] + row * (a.pack ? (int64_t)32 : a.lda) + c * 8;
     }
 #pragma unroll
-    for (int j = 0; j < G::DMA_B; ++j) {  // B: 2 arrays x BN rows x 4 chunks
+    for (int j = 0; j < G::DMA_B; ++j) {  // B: NIMG arrays x BN rows x 4 chunks
         const int L = j * GNT + threadIdx.x;
         const int arr = L / (BN * CPR), Lp = L % (BN * CPR), r = Lp / CPR, p = Lp % CPR;
         const int c = p ^ (CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1));
         int col = n0 + r;
         if (col > a.N - 1) col = a.N - 1;
-        src[G::DMA_A + j] = (arr ? a.bl : a.bh) + (int64_t)col * (a.pack ? (int64_t)32 : a.ldb) + c * 8;
+        src[G::DMA_A + j] = a.bi[arr] + (int64_t)col * (a.pack ? (int64_t)32 : a.ldb) + c * 8;
     }
     const int64_t ks_a = a.pack ? a.M * 32 : (int64_t)BK, ks_b = a.pack ? (int64_t)a.N * 32 : (int64_t)BK;  // elements per k-tile step
     auto issue_at = [&](int tile, int stage) {  // k-tile kt_beg + tile -> LDS stage
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
 #pragma unroll
         for (int j = 0; j < G::DMA_A; ++j) g_dma16(src[j] + ka, st + (j * GNT + wave * 64) * 16);
 #pragma unroll
-        for (int j = 0; j < G::DMA_B; ++j) g_dma16(src[G::DMA_A + j] + kb, st + 2 * G_A_ARR + (j * GNT + wave * 64) * 16);
+        for (int j = 0; j < G::DMA_B; ++j) g_dma16(src[G::DMA_A + j] + kb, st + NIMG * G_A_ARR + (j * GNT + wave * 64) * 16);
     };
     auto issue = [&](int t) { issue_at(t, t % GST); };
     f32x16 acc[2][NB];
@@ -255,33 +271,37 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int r = wn * (BN / 2) + nb * 32 + l31;
-        b_off[nb] = 2 * G_A_ARR + r * RS;
+        b_off[nb] = NIMG * G_A_ARR + r * RS;
         b_sw[nb] = CPR == 4 ? ((r >> 2) & 3) : ((r >> 3) & 1);
     }
-    auto read_frags = [&](const unsigned char* st, int ks, bf16x8_t (&fah)[2], bf16x8_t (&fal)[2], bf16x8_t (&fbh)[NB], bf16x8_t (&fbl)[NB]) {
+    // fragments of one 16-wide k-step: fa[image][row block], fb[image][column block]; image 0 = hi / h, 1 = lo / m, 2 = l
+    auto read_frags = [&](const unsigned char* st, int ks, bf16x8_t (&fa)[NIMG][2], bf16x8_t (&fb)[NIMG][NB]) {
         const int c = 2 * ks + h;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const unsigned char* p = st + a_off[mb] + ((c ^ a_sw[mb]) << 4);
-            fah[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
-            fal[mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_A_ARR));
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) fa[im][mb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + im * G_A_ARR));
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const unsigned char* p = st + b_off[nb] + ((c ^ b_sw[nb]) << 4);
-            fbh[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
-            fbl[nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + G_B_ARR));
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) fb[im][nb] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p + im * G_B_ARR));
         }
     };
-    auto mfma_step = [&](const bf16x8_t (&fah)[2], const bf16x8_t (&fal)[2], const bf16x8_t (&fbh)[NB], const bf16x8_t (&fbl)[NB]) {
+    // terms in the OUTER loop: consecutive MFMAs go to different accumulators (2 x NB independent chains); every accumulator still takes its
+    // terms small first: lo hi, hi lo, hi hi (bf16x3) / l h, h l, m m, m h, h m, h h (bf16x6)
+    auto mfma_step = [&](const bf16x8_t (&fa)[NIMG][2], const bf16x8_t (&fb)[NIMG][NB]) {
+        constexpr int TA[2][6] = {{1, 0, 0, 0, 0, 0}, {2, 0, 1, 1, 0, 0}};  // image of A per term
+        constexpr int TB[2][6] = {{0, 1, 0, 0, 0, 0}, {0, 2, 1, 0, 1, 0}};  // image of B per term
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int tm = 0; tm < TERMS; ++tm)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                acc[mb][nb] = g_mfma(fal[mb], fbh[nb], acc[mb][nb]);  // small terms first
-                acc[mb][nb] = g_mfma(fah[mb], fbl[nb], acc[mb][nb]);
-                acc[mb][nb] = g_mfma(fah[mb], fbh[nb], acc[mb][nb]);
-            }
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[mb][nb] = g_mfma(fa[TA[NIMG - 2][tm]][mb], fb[TB[NIMG - 2][tm]][nb], acc[mb][nb]);
     };
     if (PIPE && KS == 2 && GST == 2) {
         // The barrier of a k-tile sits in the MIDDLE of the previous tile's MFMAs, and every batch of fragment reads is issued right
@@ -292,27 +312,27 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
         // the matrix pipe idles for the first of it -- halving the k-tile, i.e. doubling the number of such phases, cost 24 %.)
         // No branch inside the body (the scheduler works on one block): the last iterations re-load tile t into the stage it just
         // left and read fragments nobody uses.
-        bf16x8_t ah0[2], al0[2], bh0[NB], bl0[NB], ah1[2], al1[2], bh1[NB], bl1[NB];
+        bf16x8_t fa0[NIMG][2], fb0[NIMG][NB], fa1[NIMG][2], fb1[NIMG][NB];
         g_wait_vm_and_barrier<0>();  // tile 0
         if (1 < T) issue(1);
-        read_frags(smem, 0, ah0, al0, bh0, bl0);
+        read_frags(smem, 0, fa0, fb0);
         for (int t = 0; t < T; ++t) {
             const unsigned char* st = smem + (t % GST) * G_STAGE;
             const unsigned char* sn = smem + ((t + 1) % GST) * G_STAGE;
-            read_frags(st, 1, ah1, al1, bh1, bl1);
-            mfma_step(ah0, al0, bh0, bl0);
+            read_frags(st, 1, fa1, fb1);
+            mfma_step(fa0, fb0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NB - 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NIMG * (2 + NB), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS * NB - 1, 0);
             __builtin_amdgcn_sched_barrier(0);
             // tile t + 1 has arrived and every wavefront has read all of tile t (its k-step-1 fragments are in registers: lgkmcnt 0)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             issue_at((t + 2 < T) ? t + 2 : t, t % GST);  // tile t + 2 (or, at the end, tile t again) into the stage tile t has just left
-            read_frags(sn, 0, ah0, al0, bh0, bl0);
-            mfma_step(ah1, al1, bh1, bl1);
+            read_frags(sn, 0, fa0, fb0);
+            mfma_step(fa1, fb1);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NB, 1);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NB - 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NIMG * (2 + NB), 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS * NB - 1, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy re-loads of the last iterations
@@ -333,11 +353,11 @@ __global__ __launch_bounds__(BM * 2, BM == 256 ? 1 : 2) void gemm_split_nt_kerne
         const unsigned char* st = smem + (t % GST) * G_STAGE;
         // The fragments of ALL 16-wide k-steps of the tile are read from LDS up front (LDS returns in order: the MFMAs of step 0 wait
         // for the first half only), so the reads of step 1 can run behind the MFMAs of step 0.
-        bf16x8_t ah[KS][2], al[KS][2], bh[KS][NB], bl[KS][NB];
+        bf16x8_t fa[KS][NIMG][2], fb[KS][NIMG][NB];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) read_frags(st, s, ah[s], al[s], bh[s], bl[s]);
+        for (int s = 0; s < KS; ++s) read_frags(st, s, fa[s], fb[s]);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) mfma_step(ah[s], al[s], bh[s], bl[s]);
+        for (int s = 0; s < KS; ++s) mfma_step(fa[s], fb[s]);
     }
     }
     // ---- epilogue: acc[mb][nb][i] = C[row0 + wm 64 + mb 32 + (i & 3) + 8 (i >> 2) + 4 h][n0 + wn 64 + nb 32 + l31] --------------------
@@ -439,27 +459,38 @@ __global__ __launch_bounds__(256) void gs_colsum_finish_kernel(const float* __re
     out[c] = s;
 }
 
-int g_gemm_arith = 0;  // 0 = f32 (default), 1 = bf16x3 (mh_set_gemm_arith)
+int g_gemm_arith = 0;  // what the *_split entry points compute in: 1 = bf16x3 (three terms), 2 = bf16x6 (six terms, fp32-grade); 0 behaves as 1 (mh_set_gemm_arith)
 
 inline int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
 inline int64_t pad_to(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// number of bf16 images per operand the entry points of this file use: 2 = the three-term bf16x3 (mh_set_gemm_arith(1)), 3 = the six-term,
+// fp32-grade bf16x6 (mh_set_gemm_arith(2)); workspaces are sized for three
+int split_images() { return g_gemm_arith == 2 ? 3 : 2; }
+
 struct SplitBuf {
-    uint16_t *hi, *lo;
+    uint16_t* img[3];  // [0] = hi / h, [1] = lo / m, [2] = l (null with two images)
     int64_t ld;
 };
 
-// carve a [rows, ld] hi / lo pair out of the workspace cursor
+// carve the images of a [rows, ld] operand out of the workspace cursor
 SplitBuf take_pair(char*& p, int64_t rows, int64_t ld) {
     SplitBuf b;
     b.ld = ld;
-    b.hi = reinterpret_cast<uint16_t*>(p);
-    p += al256(rows * ld * 2);
-    b.lo = reinterpret_cast<uint16_t*>(p);
-    p += al256(rows * ld * 2);
+    b.img[2] = nullptr;
+    for (int i = 0; i < split_images(); ++i) {
+        b.img[i] = reinterpret_cast<uint16_t*>(p);
+        p += al256(rows * ld * 2);
+    }
     return b;
 }
-inline int64_t pair_bytes(int64_t rows, int64_t ld) { return 2 * al256(rows * ld * 2); }
+inline int64_t pair_bytes(int64_t rows, int64_t ld) { return 3 * al256(rows * ld * 2); }
+inline void set_operands(GsArgs& a, const SplitBuf& A, const SplitBuf& B) {
+    for (int i = 0; i < 3; ++i) {
+        a.ai[i] = A.img[i];
+        a.bi[i] = B.img[i];
+    }
+}
 
 int gemm_geo();
 int gemm_pack() {  // MERLIN_HIP_GEMM_SPLIT_PACK = 1 (default) | 0: k-tile major operand images (GsArgs); the 16-wide k-tile forms are row-major
@@ -473,17 +504,20 @@ int gemm_pack() {  // MERLIN_HIP_GEMM_SPLIT_PACK = 1 (default) | 0: k-tile major
 
 void split_rows(const float* x, int64_t R, int C, int64_t ld, const SplitBuf& b, hipStream_t s) {
     const int64_t n = R * (b.ld / 8);
-    MH_LAUNCH(gs_split_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, s, x, R, C, ld, (int)b.ld, b.hi, b.lo, gemm_pack());
+    const bool three = split_images() == 3;
+    MH_LAUNCH(gs_split_rows_kernel, dim3((unsigned)mh_ceil_div(n, 256)), dim3(256), 0, s, x, R, C, ld, (int)b.ld, b.img[0], three ? b.img[2] : b.img[1],
+              gemm_pack(), three ? b.img[1] : (uint16_t*)nullptr);
 }
 void split_transpose(const float* x, int64_t R, int C, int64_t ld, const SplitBuf& b, hipStream_t s) {
+    const bool three = split_images() == 3;
     MH_LAUNCH(gs_split_transpose_kernel, dim3((unsigned)(b.ld / 64), (unsigned)mh_ceil_div(C, 64)), dim3(256), 0, s, x, R, C, ld, b.ld,
-              b.hi, b.lo, gemm_pack());
+              b.img[0], three ? b.img[2] : b.img[1], gemm_pack(), three ? b.img[1] : (uint16_t*)nullptr);
 }
 
-template <int EPI, int BM, int BN, bool PIPE, int BK = 32, int ST = 0>
+template <int EPI, int BM, int BN, bool PIPE, int BK = 32, int ST = 0, int NIMG = 2>
 int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
-    using G = Geo<BM, BN, BK, ST>;
-    auto kern = gemm_split_nt_kernel<EPI, BM, BN, PIPE, BK, ST>;
+    using G = Geo<BM, BN, BK, ST, NIMG>;
+    auto kern = gemm_split_nt_kernel<EPI, BM, BN, PIPE, BK, ST, NIMG>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
@@ -528,6 +562,8 @@ int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 1
 
 template <int EPI>
 int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
+    // six-term arithmetic (three images per operand): 256 x 128 tiles, two 72 KB stages, the k-loop with the mid-tile barrier
+    if (split_images() == 3) return launch_gemm_geo<EPI, 256, 128, true, 32, 2, 3>(a, splits, s);
     const int geo = gemm_geo();
     static int pipe = -1;  // MERLIN_HIP_GEMM_SPLIT_PIPE = 1 | 0: the k-loop with the barrier in the middle of a tile's MFMAs (see the kernel)
     if (pipe < 0) {
@@ -548,7 +584,7 @@ int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
 extern "C" {
 
 int32_t mh_set_gemm_arith(int32_t mode) {
-    MH_REQUIRE(mode == 0 || mode == 1, "mh_set_gemm_arith: mode must be 0 (f32) or 1 (bf16x3)");
+    MH_REQUIRE(mode >= 0 && mode <= 2, "mh_set_gemm_arith: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16x6)");
     g_gemm_arith = mode;
     return MH_OK;
 }
@@ -575,7 +611,7 @@ int32_t mh_cross_layer_fwd_split(const float* x0, const float* x, const float* W
     split_rows(x, M, d, d, sx, s);
     split_transpose(W, d, d, d, sw, s);  // W^T [n = d_out][k = d_in], pad columns zero (Kp is a multiple of 64: whole tiles)
     GsArgs a{};
-    a.ah = sx.hi; a.al = sx.lo; a.bh = sw.hi; a.bl = sw.lo;
+    set_operands(a, sx, sw);
     a.M = M; a.N = d; a.Kp = (int)Kp; a.lda = Kp; a.ldb = Kp;
     a.C = out; a.ldc = d; a.slab = 0;
     a.bias = b; a.x0 = x0; a.xres = x; a.p_out = p_out; a.ld_e = d;
@@ -610,7 +646,7 @@ int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p
         split_rows(g, M, d, d, sg, s);
         split_rows(W, d, d, d, sw, s);  // W [d_in, d_out] row-major = B^T [n = d_in][k = d_out]
         GsArgs a{};
-        a.ah = sg.hi; a.al = sg.lo; a.bh = sw.hi; a.bl = sw.lo;
+        set_operands(a, sg, sw);
         a.M = M; a.N = d; a.Kp = (int)Kp; a.lda = Kp; a.ldb = Kp;
         a.C = dx; a.ldc = d; a.addend = dout; a.ld_add = d;
         const int32_t st = launch_gemm<0>(a, 1, s);
@@ -621,11 +657,11 @@ int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p
         split_transpose(x, M, d, d, sxt, s);  // x^T [d_in, Mp]
         split_transpose(g, M, d, d, sgt, s);  // g^T [d_out, Mp]
         GsArgs a{};
-        a.ah = sxt.hi; a.al = sxt.lo; a.bh = sgt.hi; a.bl = sgt.lo;
+        set_operands(a, sxt, sgt);
         a.M = d; a.N = d; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
         // few output tiles (378 of 256 x 128 at d = 3344, 196 of 256 x 256), a long contraction: split it so that the grid fills the 256 CUs
         // about three times over
-        const int64_t otiles = mh_ceil_div(d, 256) * mh_ceil_div(d, gemm_geo() >= 2 ? 256 : 128);
+        const int64_t otiles = mh_ceil_div(d, 256) * mh_ceil_div(d, (gemm_geo() >= 2 && split_images() == 2) ? 256 : 128);
         int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
         if (splits > 8) splits = 8;
         if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);
@@ -676,7 +712,7 @@ int32_t mh_linear_bias_act_fwd_split(const float* x, int64_t ldx, const float* W
     split_rows(x, M, K, ldx, sx, s);
     split_transpose(W, K, N, N, sw, s);  // W [K, N] -> W^T [n][k], pad columns zero
     GsArgs a{};
-    a.ah = sx.hi; a.al = sx.lo; a.bh = sw.hi; a.bl = sw.lo;
+    set_operands(a, sx, sw);
     a.M = M; a.N = N; a.Kp = (int)Kp; a.lda = Kp; a.ldb = Kp;
     a.C = y; a.ldc = ldy; a.slab = 0;
     a.bias = b; a.act = act;
@@ -713,7 +749,7 @@ int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W
         split_rows(dy, M, N, lddy, sz, s);
         split_rows(W, K, N, N, sw, s);  // W [K, N] row-major = B^T [n = k_in][k = n_out]
         GsArgs a{};
-        a.ah = sz.hi; a.al = sz.lo; a.bh = sw.hi; a.bl = sw.lo;
+        set_operands(a, sz, sw);
         a.M = M; a.N = K; a.Kp = (int)Np; a.lda = Np; a.ldb = Np;
         a.C = dx; a.ldc = lddx;
         const int32_t st = launch_gemm<0>(a, 1, s);
@@ -728,9 +764,9 @@ int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W
         split_transpose(x, M, K, ldx, sxt, s);    // x^T  [K, Mp]
         split_transpose(dy, M, N, lddy, szt, s);  // dz^T [N, Mp]
         GsArgs a{};
-        a.ah = sxt.hi; a.al = sxt.lo; a.bh = szt.hi; a.bl = szt.lo;
+        set_operands(a, sxt, szt);
         a.M = K; a.N = N; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
-        const int64_t otiles = mh_ceil_div(K, 256) * mh_ceil_div(N, gemm_geo() >= 2 ? 256 : 128);
+        const int64_t otiles = mh_ceil_div(K, 256) * mh_ceil_div(N, (gemm_geo() >= 2 && split_images() == 2) ? 256 : 128);
         int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
         if (splits > 8) splits = 8;
         if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);

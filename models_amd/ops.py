@@ -536,8 +536,6 @@ def _rowmajor_2d(t: torch.Tensor, name: str) -> torch.Tensor:
 def tower_arith() -> bool:
     """The tower layers (N = 128, K <= 1024, batch >= 4096) run in the fp32-grade six-term split "bf16x6" (mh_tower_split.hip) unless
     MERLIN_HIP_GEMM_ARITH=f32 asks for the exact fmaf-chain kernels everywhere."""
-    import os
-
     return os.environ.get("MERLIN_HIP_GEMM_ARITH", "") != "f32"
 
 
@@ -547,9 +545,10 @@ def _tower_ok(M: int, K: int, N: int, x: torch.Tensor) -> bool:
 
 
 def _linear_split_ok(M: int, K: int, N: int) -> bool:
-    """The Dense layers that run in the opt-in bf16x3 arithmetic under MERLIN_HIP_GEMM_ARITH=bf16x3: wide ones (the 256 x 256 output
-    tiles of mh_gemm_split.hip need N >= 256 to be filled; the DCN-v2 deep tower's 3341 -> 512 -> 256)."""
-    return gemm_arith() == "bf16x3" and M >= 1024 and K >= 512 and N >= 256
+    """The wide Dense layers that run on the split-bf16 GEMM of mh_gemm_split.hip (six terms by default, three under
+    MERLIN_HIP_GEMM_ARITH=bf16x3, never under =f32): the output tiles of that kernel need N >= 256 to be filled (the DCN-v2 deep tower's
+    3341 -> 512 -> 256, the two-tower's 512 -> 256)."""
+    return gemm_arith() != "f32" and M >= 1024 and K >= 512 and N >= 256
 
 
 def linear(
@@ -582,7 +581,8 @@ def linear(
             check(lib.mh_tower_linear_fwd(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation], _ptr(out), out.stride(0),
                                           _ptr(ws), ws.numel(), _stream()), "mh_tower_linear_fwd")
         return out
-    if _linear_split_ok(M, K, N):  # opt-in bf16x3 arithmetic of the wide Dense layers
+    if _linear_split_ok(M, K, N):  # wide Dense layers on the split-bf16 GEMM (six terms by default)
+        _sync_gemm_arith(lib)
         ws = _workspace(lib.mh_linear_split_workspace_bytes(M, K, N), x.device, "linear_split")
         with _timed(f"linear_{K}x{N}", nbytes=4 * (M * K + K * N + M * N), flops=2 * M * K * N):
             check(lib.mh_linear_bias_act_fwd_split(_ptr(x), x.stride(0), _ptr(W), _ptr(b), M, K, N, ACT[activation], _ptr(out),
@@ -851,7 +851,9 @@ def linear_backward(x, W, y, dy, activation=None, need_dx: bool = True, need_db:
         check(lib.mh_tower_linear_dx(_ptr(dy), dy.stride(0), _ptr(W), M, K, N, _ptr(dx), lddx, _ptr(ws), ws.numel(), _stream()),
               "mh_tower_linear_dx")
 
-    split = _linear_split_ok(M, K, N)  # same contract, bf16x3 GEMMs; the dX phase needs the workspace too
+    split = _linear_split_ok(M, K, N)  # same contract, split-bf16 GEMMs; the dX phase needs the workspace too
+    if split:
+        _sync_gemm_arith(lib)
     bwd = lib.mh_linear_bias_act_bwd_split if split else lib.mh_linear_bias_act_bwd
     nbytes = lib.mh_linear_split_workspace_bytes(M, K, N) if split else lib.mh_linear_bwd_workspace_bytes(M, K, N)
     yp, ldy = (_ptr(y), y.stride(0)) if act != 0 else (None, 0)
@@ -1620,16 +1622,28 @@ def topk_dot(q: torch.Tensor, candidates: torch.Tensor, cand_ids: Optional[torch
 
 
 def gemm_arith() -> str:
-    """MERLIN_HIP_GEMM_ARITH = f32 (default) | bf16x3: the opt-in three-term split-bf16 arithmetic of the DCN-v2 cross layer's GEMMs
-    (``mh_cross_layer_fwd_split`` / ``_bwd_split``) and of the wide Dense layers (``mh_linear_bias_act_fwd_split`` / ``_bwd_split``);
-    not bit-identical to the fp32 kernels, reported under its own dtype label."""
-    import os
+    """The arithmetic of the GEMM-heavy layers that have a split-bf16 form -- the DCN-v2 cross layer's three GEMMs (``mh_cross_layer_fwd_split`` /
+    ``_bwd_split``), wide Dense layers (``mh_linear_bias_act_fwd_split`` / ``_bwd_split``) and the tower layers (``mh_tower_split.hip``):
+      unset / ``bf16x6``  the six-term split (x = h + m + l; dropped terms <= 2^-25 of a product): fp32-grade, the DEFAULT;
+      ``f32``             the exact k-ascending fmaf-chain kernels everywhere (bit-reproducible against oracle/oracle_c.c);
+      ``bf16x3``          the opt-in three-term split (2^-17 per operand; own dtype label) for the cross / wide layers, bf16x6 for the towers."""
+    v = os.environ.get("MERLIN_HIP_GEMM_ARITH", "bf16x6")
+    return v if v in ("f32", "bf16x3") else "bf16x6"
 
-    return "bf16x3" if os.environ.get("MERLIN_HIP_GEMM_ARITH", "f32") == "bf16x3" else "f32"
+
+_GARITH = [None]
+
+
+def _sync_gemm_arith(lib) -> None:
+    """the *_split entry points compute in what ``mh_set_gemm_arith`` last recorded (1 = three terms, 2 = six): handed over when it changes"""
+    want = 1 if gemm_arith() == "bf16x3" else 2
+    if _GARITH[0] != want:
+        check(lib.mh_set_gemm_arith(want), "mh_set_gemm_arith")
+        _GARITH[0] = want
 
 
 def _cross_split_ok(M: int, d: int, W: torch.Tensor) -> bool:
-    return gemm_arith() == "bf16x3" and d % 4 == 0 and d >= 64 and M >= 256 and tuple(W.shape) == (d, d)
+    return gemm_arith() != "f32" and d % 4 == 0 and d >= 64 and M >= 256 and tuple(W.shape) == (d, d)
 
 
 def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], save_p: bool = False):
@@ -1643,6 +1657,7 @@ def cross_layer(x0: torch.Tensor, x: torch.Tensor, W: torch.Tensor, b: Optional[
     M, d = x.shape
     out = torch.empty_like(x)
     if _cross_split_ok(M, d, W):
+        _sync_gemm_arith(lib)
         p = torch.empty_like(x) if save_p else None
         ws = _workspace(lib.mh_cross_layer_split_workspace_bytes(M, d), x.device, "cross_split")
         with _timed(f"cross_{d}", nbytes=4 * ((5 if save_p else 4) * M * d + d * d), flops=2 * M * d * d):
@@ -1701,7 +1716,8 @@ def cross_layer_backward(x0: torch.Tensor, x: torch.Tensor, p: torch.Tensor, dou
     dx = torch.empty_like(x)
     dW = torch.empty((d, d), dtype=torch.float32, device=x.device)
     db = torch.empty((d,), dtype=torch.float32, device=x.device)
-    if _cross_split_ok(M, d, W):  # opt-in bf16x3 arithmetic: the same three phases through mh_cross_layer_bwd_split
+    if _cross_split_ok(M, d, W):  # split-bf16 GEMMs (six terms by default): the same three phases through mh_cross_layer_bwd_split
+        _sync_gemm_arith(lib)
         nb = lib.mh_cross_layer_split_workspace_bytes(M, d)
         if SIDE.active("dw"):
             ws = _workspace(nb, x.device, "cross_split")
