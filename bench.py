@@ -457,23 +457,47 @@ def run_twotower(args, device, tm: Timing, steps, warmup, sustain, batch=None):
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in km.items()}}
     from models_amd import ops as _ops
 
-    if _ops.scorer_arith() == "bf16x3":
-        res["dtype"] = "bf16x3 (fp32-equivalent split: every product of the scorer's gradient passes = hi hi + hi lo + lo hi on the bf16 MFMA, fp32 accumulators); towers and embeddings f32"
-        res["accuracy_vs_f32_kernels"] = scorer_arith_error(device)
+    arith = _ops.scorer_arith()
+    terms = SCORER_TERMS[arith]
+    res["dtype"] = SCORER_DTYPE[arith]
+    if terms:  # split-bf16 scorer: the rates of its ops against the bf16 pipe (terms bf16 MFMAs per fp32-equivalent product)
+        for v in res["mfma"].values():
+            v["fp32_equivalent_tflops"] = v.pop("tflops")
+            v["frac_of_bf16_peak"] = round(terms * v["fp32_equivalent_tflops"] / MFMA_BF16_PEAK_TF, 3)
+            v.pop("frac_of_peak", None)
+        res["accuracy_vs_f32_kernels"] = scorer_arith_error(device, arith)
     if tm.world > 1:
         res["exchange"] = exchange_summary(runner)
         res["config"]["parallelism"] = f"dp{tm.world} + row-sharded user_id / item_id tables (all-to-all), in-batch negatives rank-local"
     k = "inbatch_softmax_fwd_dq" if train else "inbatch_softmax_fwd"
     if k in km and km[k]["flops"]:
         tf = km[k]["flops"] / (km[k]["total_ms"] * 1e-3) / 1e12
-        res["roofline"] = {"kernel": "stream_kernel (mh_scorer_stream.hip): q stationary, items streamed; scores + mask + online LSE"
-                                     + (" + dq" if train else ""), "op": k, "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": km[k]["avg_ms"]}
+        if terms:
+            res["roofline"] = {"kernel": f"stream_split_kernel<NIMG = {3 if terms == 6 else 2}> (mh_scorer_split.hip): q stationary as bf16 pieces, "
+                                         "items streamed through LDS; scores + mask + online LSE" + (" + dq" if train else ""),
+                               "op": k, "bound": "mfma", "achieved": terms * tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": terms * tf / MFMA_BF16_PEAK_TF, "traffic": None, "avg_launch_ms": km[k]["avg_ms"],
+                               "bf16_terms_per_fp32_product": terms, "fp32_equivalent_tflops": tf,
+                               "note": "the op's launch includes the split of both matrices (split_prepare_kernel) and the combine kernel"}
+        else:
+            res["roofline"] = {"kernel": "stream_kernel (mh_scorer_stream.hip): q stationary, items streamed; scores + mask + online LSE"
+                                         + (" + dq" if train else ""), "op": k, "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+                               "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None, "avg_launch_ms": km[k]["avg_ms"]}
     return res
 
 
-def scorer_arith_error(device, B=16384, E=128, T=0.05):
-    """The opt-in bf16x3 scorer against the exact-fp32 kernels on the same inputs (L2-normalised rows, the temperature of the
+SCORER_TERMS = {"f32": 0, "bf16x6": 6, "bf16x3": 3}
+SCORER_DTYPE = {
+    "f32": "f32",
+    "bf16x6": "f32 (scorer GEMMs: bf16x6 six-term split on the bf16 MFMA, fp32 accumulators, fp32-grade; MERLIN_HIP_SCORER_ARITH=f32: exact "
+              "fp32 MFMA chains)",
+    "bf16x3": "bf16x3 (fp32-equivalent split: every product of the scorer's gradient passes = hi hi + hi lo + lo hi on the bf16 MFMA, fp32 "
+              "accumulators); towers and embeddings f32",
+}
+
+
+def scorer_arith_error(device, arith="bf16x3", B=16384, E=128, T=0.05):
+    """A split-bf16 scorer (``arith``) against the exact-fp32 kernels on the same inputs (L2-normalised rows, the temperature of the
     retrieval configs, duplicate ids so that false negatives are rescored): max |difference| of the per-row lse (a logit-scale
     quantity: north_star's tolerance is 1e-4) and of the gradients of the MEAN loss scaled back by B."""
     from models_amd import ops
@@ -485,7 +509,7 @@ def scorer_arith_error(device, B=16384, E=128, T=0.05):
     prev = os.environ.get("MERLIN_HIP_SCORER_ARITH")
     out = {}
     try:
-        for mode in ("f32", "bf16x3"):
+        for mode in ("f32", arith):
             os.environ["MERLIN_HIP_SCORER_ARITH"] = mode
             res, dq, ditem = ops.inbatch_softmax_train(q, it, it, ids, ids, T)
             _, _, dneg = ops.inbatch_softmax_backward(q, it, it, res.lse, ids, ids, T, need_dq=False)
@@ -495,7 +519,7 @@ def scorer_arith_error(device, B=16384, E=128, T=0.05):
             os.environ.pop("MERLIN_HIP_SCORER_ARITH", None)
         else:
             os.environ["MERLIN_HIP_SCORER_ARITH"] = prev
-    a, b = out["f32"], out["bf16x3"]
+    a, b = out["f32"], out[arith]
     d = lambda i: float((a[i] - b[i]).abs().max())
     return {"shape": f"{B} x {B} x {E}, L2-normalised rows, 1/T = {1 / T:.0f}, ids with duplicates", "max_abs_lse_err": d(0), "max_abs_loss_err": d(1),
             "max_abs_dq_err_times_B": d(2) * B, "max_abs_dneg_err_times_B": d(3) * B, "max_abs_dq_times_B": float(a[2].abs().max()) * B,
@@ -1278,7 +1302,7 @@ def run_multi_gpu_secondaries(args, device, tm: Timing, rank, sec):
 
     def tt(B, steps):
         r = run_twotower(args, device, tm, steps=steps, warmup=3, sustain=0.0, batch=B)
-        return pick(r, ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline", "exchange"))
+        return pick(r, ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "mfma", "kernels_ms", "roofline", "exchange"))
 
     def dcn():
         sub = argparse.Namespace(**vars(args))
@@ -1842,25 +1866,32 @@ def main():
         secondary("hbm_copy_peak", lambda: run_hbm_copy_peak(device))
         secondary("gather_cold", lambda: run_gather_cold(device))
         secondary("embedding_bag", lambda: run_embedding_bag(device))
-        secondary("scorer_fwd", lambda: run_scorer_fwd(device))
-
-        def scorer_fwd_split():
+        def with_scorer_arith(mode, fn):
             prev = os.environ.get("MERLIN_HIP_SCORER_ARITH")
-            os.environ["MERLIN_HIP_SCORER_ARITH"] = "bf16x3"
+            os.environ["MERLIN_HIP_SCORER_ARITH"] = mode
             try:
-                r = run_scorer_fwd(device)
+                return fn()
             finally:
                 if prev is None:
                     os.environ.pop("MERLIN_HIP_SCORER_ARITH", None)
                 else:
                     os.environ["MERLIN_HIP_SCORER_ARITH"] = prev
-            r["dtype"] = "bf16x3 (fp32-equivalent split on the bf16 MFMA)"
-            r["frac_of_bf16_peak"] = 3 * r["tflops"] / MFMA_BF16_PEAK_TF
-            r["fp32_equivalent_tflops"] = r.pop("tflops")
-            r.pop("frac_of_peak", None)
+
+        def scorer_fwd():
+            from models_amd import ops as _ops
+
+            arith = _ops.scorer_arith()
+            r = run_scorer_fwd(device)
+            r["dtype"] = SCORER_DTYPE[arith].split(";")[0]
+            if SCORER_TERMS[arith]:
+                r["frac_of_bf16_peak"] = SCORER_TERMS[arith] * r["tflops"] / MFMA_BF16_PEAK_TF
+                r["fp32_equivalent_tflops"] = r.pop("tflops")
+                r.pop("frac_of_peak", None)
             return r
 
-        secondary("scorer_fwd_bf16x3", scorer_fwd_split)
+        secondary("scorer_fwd", scorer_fwd)  # the default arithmetic (bf16x6 unless MERLIN_HIP_SCORER_ARITH says otherwise)
+        secondary("scorer_fwd_f32_chain", lambda: with_scorer_arith("f32", scorer_fwd))
+        secondary("scorer_fwd_bf16x3", lambda: with_scorer_arith("bf16x3", scorer_fwd))
         def with_gemm_arith(mode, fn):
             prev = os.environ.get("MERLIN_HIP_GEMM_ARITH")
             os.environ["MERLIN_HIP_GEMM_ARITH"] = mode
@@ -1874,26 +1905,20 @@ def main():
 
         secondary("dcn_cross_gemm", lambda: run_cross_gemm(device))
         secondary("dcn_cross_gemm_f32_chain", lambda: with_gemm_arith("f32", lambda: run_cross_gemm(device)))
-        secondary("twotower_train", lambda: pick(run_twotower(args, device, tm, steps=20, warmup=3, sustain=0.0),
-                                                 ("metric", "value", "unit", "ms_per_step", "steps", "config", "mfma", "kernels_ms", "roofline")))
-        secondary("twotower_train_b64k", lambda: pick(run_twotower(args, device, tm, steps=8, warmup=2, sustain=0.0, batch=65536),
-                                                      ("metric", "value", "unit", "ms_per_step", "steps", "mfma", "kernels_ms")))
+        tt_keys = ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "mfma", "kernels_ms", "roofline", "accuracy_vs_f32_kernels")
+        # default arithmetic of the scorer: the fp32-grade six-term split (MERLIN_HIP_SCORER_ARITH unset)
+        secondary("twotower_train", lambda: pick(run_twotower(args, device, tm, steps=20, warmup=3, sustain=0.0), tt_keys))
+        secondary("twotower_train_b64k", lambda: pick(run_twotower(args, device, tm, steps=8, warmup=2, sustain=0.0, batch=65536), tt_keys))
 
-        def tt_split(batch, steps):
-            # the SAME train step with the scorer's gradient passes in the opt-in bf16x3 arithmetic (every other line stays f32)
-            prev = os.environ.get("MERLIN_HIP_SCORER_ARITH")
-            os.environ["MERLIN_HIP_SCORER_ARITH"] = "bf16x3"
-            try:
-                r = run_twotower(args, device, tm, steps=steps, warmup=3, sustain=0.0, batch=batch)
-            finally:
-                if prev is None:
-                    os.environ.pop("MERLIN_HIP_SCORER_ARITH", None)
-                else:
-                    os.environ["MERLIN_HIP_SCORER_ARITH"] = prev
-            return pick(r, ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "accuracy_vs_f32_kernels", "kernels_ms"))
+        def tt_arith(mode, batch, steps):
+            # the SAME train step with the scorer in another arithmetic: "f32" = the exact fp32 MFMA chains, "bf16x3" = the opt-in 3-term split
+            r = with_scorer_arith(mode, lambda: run_twotower(args, device, tm, steps=steps, warmup=3, sustain=0.0, batch=batch))
+            return pick(r, ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "accuracy_vs_f32_kernels", "mfma", "kernels_ms"))
 
-        secondary("twotower_train_bf16x3", lambda: tt_split(None, 20))
-        secondary("twotower_train_b64k_bf16x3", lambda: tt_split(65536, 8))
+        secondary("twotower_train_f32_chain", lambda: tt_arith("f32", None, 20))
+        secondary("twotower_train_b64k_f32_chain", lambda: tt_arith("f32", 65536, 8))
+        secondary("twotower_train_bf16x3", lambda: tt_arith("bf16x3", None, 20))
+        secondary("twotower_train_b64k_bf16x3", lambda: tt_arith("bf16x3", 65536, 8))
         tk = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "roofline", "dtype", "bit_identical_to_f32_pipeline",
               "index_split_ms", "fp32_equivalent_tflops", "kernels_ms")
         secondary("topk", lambda: pick(run_topk(args, device, steps=6, warmup=4), tk))

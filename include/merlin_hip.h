@@ -168,11 +168,14 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
 /* Deterministic mode of the fused sparse update (process-wide; initial value from MERLIN_HIP_DETERMINISTIC=1 at load time):
  * crossing runs are walked in sample order instead of summed with float atomics -- bit-reproducible, slower on very hot rows. */
 int32_t mh_set_deterministic(int32_t on);
-/* Arithmetic of the gradient passes of the in-batch scorer (mh_inbatch_softmax_fwd_dq / _bwd) at E = 128:
- *   0 (default) exact fp32 MFMA, every score one k-ascending fmaf chain;
+/* Arithmetic of the in-batch scorer (mh_inbatch_softmax_fwd without logits, _fwd_dq, _bwd) at E = 128 (mh_scorer_split.hip):
+ *   0 (the library's initial value) exact fp32 MFMA, every score one k-ascending fmaf chain;
  *   1 "bf16x3": every fp32 operand split into two bf16 values, every product of both GEMMs of a pass formed as hi hi + hi lo + lo hi
  *     on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (error of a dot product <= ~2.3e-6 |q| |item| measured; 16 / 3 of the fp32
- *     MFMA rate).  Not bit-identical to mode 0: opt-in (initial value MERLIN_HIP_SCORER_ARITH=bf16x3 through the Python layer). */
+ *     MFMA rate).  NOT fp32-grade: opt-in (MERLIN_HIP_SCORER_ARITH=bf16x3 through the Python layer);
+ *   2 "bf16x6": three bf16 pieces per operand (they hold the 24-bit significand exactly), six terms h h + h m + m h + h l + l h + m m
+ *     per product, dropped terms <= 2^-25 of it: as close to the real dot product as the fp32 chain (16 / 6 of the fp32 MFMA rate).
+ *     The host side (models_amd/ops.py) selects this mode unless MERLIN_HIP_SCORER_ARITH says f32 or bf16x3. */
 int32_t mh_set_scorer_arith(int32_t mode);
 
 /* ---- a9 on the split-bf16 GEMM: the three GEMMs of a full-rank DCN-v2 cross layer (Cross.call, blocks/cross.py:188-202) ----

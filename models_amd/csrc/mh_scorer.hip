@@ -336,21 +336,30 @@ int32_t mh_scorer_tiled_fwd(const float* q, const float* neg, const void* pos_id
                             int64_t Nn, int E, float invT, float fns, const float* neg_corr, int corr_after_mask, float* part_m,
                             float* part_s, hipStream_t s);
 void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst, hipStream_t s);
-// opt-in bf16x3 arithmetic of the gradient passes (mh_scorer_split.hip): hi / lo bf16 split of both matrices, 3-term products
+// split-bf16 arithmetics of the gradient passes (mh_scorer_split.hip): two (bf16x3, three-term products) or three (bf16x6, six-term,
+// fp32-grade) bf16 images of both matrices
 struct MhSplitMatrix {
-    uint16_t *hi, *lo, *hiT, *loT;
+    uint16_t *img[3], *imgT[3];
     int64_t ldT;
+    int nimg;
 };
 int64_t mh_split_matrix_bytes(int64_t N);
-MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, hipStream_t s);
-int mh_split_plan(int64_t Nx, int64_t Ny, int* tiles_per_split);
+MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, int nimg, hipStream_t s);
+int mh_split_plan(int64_t Nx, int64_t Ny, int nimg, int* tiles_per_split);
 int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X, int64_t Nx, const MhSplitMatrix& Y, int64_t Ny,
                                const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
                                float fns, float gscale, float* part_m, float* part_s, float* opart, hipStream_t s);
 
 namespace {
 
-int g_scorer_arith = 0;  // 0 = f32 (default), 1 = bf16x3 (mh_set_scorer_arith)
+int g_scorer_arith = 0;  // 0 = f32, 1 = bf16x3 (opt-in), 2 = bf16x6 (fp32-grade; what the host side selects by default): mh_set_scorer_arith
+inline int split_images() { return g_scorer_arith == 2 ? 3 : 2; }
+// the largest split count of the two split-bf16 plans (the partial buffers do not depend on the arithmetic selected later)
+inline int split_plan_max(int64_t Nx, int64_t Ny) {
+    int tps = 0;
+    const int a = mh_split_plan(Nx, Ny, 2, &tps), b = mh_split_plan(Nx, Ny, 3, &tps);
+    return a > b ? a : b;
+}
 
 inline int padded_E(int E) { return E <= 32 ? 32 : (E <= 64 ? 64 : 128); }
 inline int64_t align64(int64_t n) { return (n + 63) / 64 * 64; }  // floats: keeps every sub-buffer 256-byte aligned
@@ -386,16 +395,15 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         // pass 0 may run the tiled forward, which writes one partial per 256-candidate tile
         int64_t ns = w.row.nsplit;
         if (pass == 0 && mh_scorer_tiled_nsplit(Nn) > ns) ns = mh_scorer_tiled_nsplit(Nn);
-        int tps2 = 0;
-        if (E == 128 && mh_split_plan(B, Nn, &tps2) > ns) ns = mh_split_plan(B, Nn, &tps2);
+        if (E == 128 && split_plan_max(B, Nn) > ns) ns = split_plan_max(B, Nn);
         w.part_m = take(ns * B);
         w.part_s = take(ns * B);
     }
-    // partials: the larger of the fp32 plan's and the bf16x3 plan's split count (64-row tiles: up to twice as many splits)
-    int ns_row = w.row.nsplit, ns_col = w.col.nsplit, tps_ = 0;
+    // partials: the largest of the fp32 plan's and the split-bf16 plans' split counts (64- / 32-row tiles: more splits on small shapes)
+    int ns_row = w.row.nsplit, ns_col = w.col.nsplit;
     if (E == 128 && pass != 0) {
-        if (mh_split_plan(B, Nn, &tps_) > ns_row) ns_row = mh_split_plan(B, Nn, &tps_);
-        if (mh_split_plan(Nn, B, &tps_) > ns_col) ns_col = mh_split_plan(Nn, B, &tps_);
+        if (split_plan_max(B, Nn) > ns_row) ns_row = split_plan_max(B, Nn);
+        if (split_plan_max(Nn, B) > ns_col) ns_col = split_plan_max(Nn, B);
     }
     if (pass == 1 || pass == 2) w.opart_row = take((int64_t)ns_row * B * w.Ep);
     if (pass == 1) w.opart_col = take((int64_t)ns_col * Nn * w.Ep);
@@ -405,7 +413,7 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         if (pass == 1) w.outp_col = take(Nn * w.Ep);
     }
     w.split_q = w.split_n = 0;
-    if (E == 128) {  // the bf16 (hi, lo) splits of q and of the negatives, both orientations (bf16x3 arithmetic)
+    if (E == 128) {  // the bf16 images of q and of the negatives, both orientations (sized for three images: bf16x6)
         w.split_q = take(mh_split_matrix_bytes(B) / 4);
         w.split_n = take(mh_split_matrix_bytes(Nn) / 4);
     }
@@ -413,10 +421,10 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
     return w;
 }
 
-// the bf16x3 kernels cover the plain in-batch case: E = 128, no logQ correction inside the kernel, 16-byte aligned rows (the partial
+// the split-bf16 kernels cover the plain in-batch case: E = 128, no logQ correction inside the kernel, 16-byte aligned rows (the partial
 // buffers are sized for the larger of the two plans' split counts: stream_ws)
 bool split_ok(int64_t Nx, int64_t Ny, int E, const float* x_corr, const float* y_corr, const float* a, const float* b, int fp32_nsplit) {
-    if (g_scorer_arith != 1 || E != 128 || x_corr || y_corr || Ny < 64) return false;
+    if (g_scorer_arith == 0 || E != 128 || x_corr || y_corr || Ny < 64) return false;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return false;
     (void)Nx;
     (void)fp32_nsplit;
@@ -428,7 +436,7 @@ bool split_ok(int64_t Nx, int64_t Ny, int E, const float* x_corr, const float* y
 extern "C" {
 
 int32_t mh_set_scorer_arith(int32_t mode) {
-    MH_REQUIRE(mode == 0 || mode == 1, "mh_set_scorer_arith: mode must be 0 (f32) or 1 (bf16x3)");
+    MH_REQUIRE(mode >= 0 && mode <= 2, "mh_set_scorer_arith: mode must be 0 (f32), 1 (bf16x3) or 2 (bf16x6)");
     g_scorer_arith = mode;
     return MH_OK;
 }
@@ -501,11 +509,11 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
             return MH_OK;
         }
     }
-    if (!logits && split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {  // opt-in bf16x3 arithmetic, loss / lse only
-        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, s);
-        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, s);
+    if (!logits && split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {  // split-bf16 arithmetic, loss / lse only
+        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, split_images(), s);
+        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, split_images(), s);
         int tps = 0;
-        const int ns = mh_split_plan(B, Nn, &tps);
+        const int ns = mh_split_plan(B, Nn, split_images(), &tps);
         const int32_t st = mh_stream_split_launch(SM_FWD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
                                                   1.f, ws + w.part_m, ws + w.part_s, nullptr, s);
         if (st != MH_OK) return st;
@@ -570,10 +578,10 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
     int32_t st;
     int nsplit = plan.nsplit;
     if (split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {
-        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, s);
-        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, s);
+        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, split_images(), s);
+        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, split_images(), s);
         int tps = 0;
-        nsplit = mh_split_plan(B, Nn, &tps);
+        nsplit = mh_split_plan(B, Nn, split_images(), &tps);
         st = mh_stream_split_launch(SM_FWD_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
                                     1.f, ws + w.part_m, ws + w.part_s, ws + w.opart_row, s);
     } else {
@@ -651,15 +659,15 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
                            split_ok(Nn, B, E, neg_logq, nullptr, q, neg_item, w.col.nsplit) && B >= 64;
     MhSplitMatrix sq{}, sn{};
     if (use_split) {
-        sq = mh_split_prepare(q, B, ws + w.split_q, s);
-        sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, s);
+        sq = mh_split_prepare(q, B, ws + w.split_q, split_images(), s);
+        sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, split_images(), s);
     }
     if (dq) {
         const MhStreamPlan& pr = w.row;
         int ns = pr.nsplit;
         if (use_split) {
             int tps = 0;
-            ns = mh_split_plan(B, Nn, &tps);
+            ns = mh_split_plan(B, Nn, split_images(), &tps);
             st = mh_stream_split_launch(SM_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT, false_neg_score,
                                         gscale, nullptr, nullptr, ws + w.opart_row, s);
         } else {
@@ -681,7 +689,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
     int nsc = pc.nsplit;
     if (use_split) {
         int tps = 0;
-        nsc = mh_split_plan(Nn, B, &tps);
+        nsc = mh_split_plan(Nn, B, split_images(), &tps);
         st = mh_stream_split_launch(SM_GRAD, 1, sn, Nn, sq, B, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT, false_neg_score, gscale,
                                     nullptr, nullptr, ws + w.opart_col, s);
     } else {

@@ -1,4 +1,5 @@
-// In-batch sampled-softmax scorer on the bf16 matrix pipe: the OPT-IN "bf16x3" arithmetic of mh_inbatch_softmax_fwd_dq / _bwd.
+// In-batch sampled-softmax scorer on the bf16 matrix pipe: the six-term "bf16x6" (fp32-grade, the host side's default) and the OPT-IN
+// three-term "bf16x3" arithmetic of mh_inbatch_softmax_fwd_dq / _bwd.
 // Reference: the same functions as mh_scorer_stream.hip -- ContrastiveOutput.outputs (tf/outputs/contrastive.py:276-344),
 // ItemRetrievalScorer.call_outputs (tf/blocks/retrieval/base.py:283-429), rescore_false_negatives (tf/utils/tf_utils.py:126-154),
 // CategoricalCrossEntropy(from_logits=True) (tf/losses/listwise.py:38-52) and their gradients (tf/models/base.py:1121-1174).
@@ -25,6 +26,14 @@
 //     A operand is read from the transposed image in that order (two 8-byte LDS reads per fragment): no shuffle, no transpose.
 //   * partial results per candidate split in the layout of the fp32 kernels (part_m / part_s / opart): the combine kernels of
 //     mh_scorer_stream.hip finish the pass unchanged.
+//
+// bf16x6 (NIMG = 3).  x = h + m + l, three bf16 pieces that hold the 24-bit significand exactly, and every product of BOTH GEMMs as
+// h h + h m + m h + h l + l h + m m: the dropped terms are <= 2^-25 of the product -- half an fp32 rounding, so the result is as close to
+// the real dot product as the fp32 fmaf chain is (the argument and the float64 test are mh_tower_split.hip's).  Six MFMAs per
+// fp32-equivalent one = 16 / 6 of the fp32 MFMA rate.  Differences from the three-term kernel: three images of every matrix (and of
+// the probabilities, split in registers by mh_split3_pair); 32-row tiles of the streamed matrix so that two stages of 2 x 3 images fit
+// the LDS (96 KB); the six terms of GEMM 1 go to TWO accumulators alternately (one dependent MFMA chain per wavefront was what held
+// the three-term kernel at 0.47 of the pipe) and GEMM 2 walks two 32-column blocks of O^T at a time for the same reason.
 #include "mh_common.h"
 
 #include <math.h>
@@ -37,11 +46,16 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int PE = 128;            // embedding width (the whole K of GEMM 1)
 constexpr int PKS = PE / 16;       // k-steps of GEMM 1
 constexpr int PXB = 256;           // stationary rows per workgroup
-constexpr int PBN = 64;            // streamed rows per tile (two 32-row units)
-constexpr int P_ARR = PBN * PE * 2;                // one of {hi, lo} of either image: 16 KB
-constexpr int P_STAGE = 4 * P_ARR;                 // Y hi, Y lo, Y^T hi, Y^T lo: 64 KB
-constexpr int P_AUX = 2 * P_STAGE;                 // ids (2 x 512 B), lse (2 x 256 B) behind the two stages
-constexpr int P_LDS = P_AUX + 2 * 512 + 2 * 256;
+// Geometry by the number of bf16 images per matrix: 2 (bf16x3) -> 64 streamed rows per tile, 3 (bf16x6) -> 32
+template <int NIMG>
+struct PG {
+    static constexpr int BN = (NIMG == 3) ? 32 : 64;  // streamed rows per tile (units of 32 rows)
+    static constexpr int ARR = BN * PE * 2;            // one image of either orientation: 16 KB / 8 KB
+    static constexpr int STAGE = 2 * NIMG * ARR;       // row-major images, then the transposed ones: 64 KB / 48 KB
+    static constexpr int NST = (NIMG == 3) ? 3 : 2;    // stages of the ring (three: the late wavefronts work one tile behind, see the kernel)
+    static constexpr int AUX = NST * STAGE;            // ids (NST x 512 B), lse (NST x 256 B) behind the stages
+    static constexpr int LDS = AUX + NST * 512 + NST * 256;
+};
 constexpr float P_LOG2E = 1.4426950408889634f;
 constexpr float P_NEG_BIG = -1.0e30f;
 constexpr float P_LAZY = 16.f;
@@ -57,33 +71,37 @@ __device__ __forceinline__ uint16_t p_bf16(float x) {  // round to nearest even 
 __device__ __forceinline__ float p_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 // x[N, 128] fp32 -> hi, lo [N, 128] (bf16 bit patterns) and hiT, loT [128, ldT] (ldT = N rounded up to 64; the columns past N
-// are written as zeros).  One workgroup per 64 rows; the transpose goes through LDS.
+// are written as zeros).  One workgroup per 64 rows; the transpose goes through LDS.  THREE: also the middle piece (mid, midT) and
+// lo = the third piece of mh_split3_pair (bf16x6).
+template <bool THREE>
 __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restrict__ x, int64_t N, uint16_t* __restrict__ hi,
-                                                           uint16_t* __restrict__ lo, uint16_t* __restrict__ hiT,
+                                                           uint16_t* __restrict__ mid, uint16_t* __restrict__ lo,
+                                                           uint16_t* __restrict__ hiT, uint16_t* __restrict__ midT,
                                                            uint16_t* __restrict__ loT, int64_t ldT) {
-    __shared__ uint16_t sh[64][PE + 2], sl[64][PE + 2];
+    constexpr int NI = THREE ? 3 : 2;
+    __shared__ uint16_t sp[NI][64][PE + 2];
+    uint16_t* const img[3] = {hi, THREE ? mid : lo, lo};
+    uint16_t* const imgT[3] = {hiT, THREE ? midT : loT, loT};
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     for (int i = threadIdx.x; i < 64 * (PE / 4); i += 256) {
         const int r = i / (PE / 4), c4 = i % (PE / 4);
         const int64_t row = r0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < N) v = *reinterpret_cast<const f32x4*>(x + row * PE + c4 * 4);
-        uint16_t h[4], l[4];
+        uint32_t w[NI][2];
 #pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-            uint32_t wh2, wl2;
-            mh_split_pair(v[k], v[k + 1], wh2, wl2);
-            h[k] = (uint16_t)wh2; h[k + 1] = (uint16_t)(wh2 >> 16);
-            l[k] = (uint16_t)wl2; l[k + 1] = (uint16_t)(wl2 >> 16);
+        for (int k = 0; k < 2; ++k) {
+            if (THREE) mh_split3_pair(v[2 * k], v[2 * k + 1], w[0][k], w[1][k], w[NI - 1][k]);
+            else mh_split_pair(v[2 * k], v[2 * k + 1], w[0][k], w[1][k]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sh[r][c4 * 4 + k] = h[k];
-            sl[r][c4 * 4 + k] = l[k];
-        }
-        if (row < N) {
-            *reinterpret_cast<uint2*>(hi + row * PE + c4 * 4) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            *reinterpret_cast<uint2*>(lo + row * PE + c4 * 4) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+        for (int a = 0; a < NI; ++a) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                sp[a][r][c4 * 4 + 2 * k] = (uint16_t)w[a][k];
+                sp[a][r][c4 * 4 + 2 * k + 1] = (uint16_t)(w[a][k] >> 16);
+            }
+            if (row < N) *reinterpret_cast<uint2*>(img[a] + row * PE + c4 * 4) = make_uint2(w[a][0], w[a][1]);
         }
     }
     __syncthreads();
@@ -91,24 +109,24 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     // thread (e, half): 32 consecutive rows of column e -> 64 contiguous bytes of the transposed arrays
     const int e = threadIdx.x & (PE - 1), half = threadIdx.x >> 7;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        uint32_t wh[4], wl[4];
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = half * 32 + g * 8 + 2 * k;
-            wh[k] = (uint32_t)sh[r][e] | ((uint32_t)sh[r + 1][e] << 16);
-            wl[k] = (uint32_t)sl[r][e] | ((uint32_t)sl[r + 1][e] << 16);
+        for (int g = 0; g < 4; ++g) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = half * 32 + g * 8 + 2 * k;
+                wv[k] = (uint32_t)sp[a][r][e] | ((uint32_t)sp[a][r + 1][e] << 16);
+            }
+            const int64_t col = r0 + half * 32 + g * 8;
+            *reinterpret_cast<uint4*>(imgT[a] + (int64_t)e * ldT + col) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
         }
-        const int64_t col = r0 + half * 32 + g * 8;
-        *reinterpret_cast<uint4*>(hiT + (int64_t)e * ldT + col) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-        *reinterpret_cast<uint4*>(loT + (int64_t)e * ldT + col) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
-    }
 }
 
 struct SplitArgs {
-    const uint16_t *xhi, *xlo;               // stationary [Nx, 128]
-    const uint16_t *yhi, *ylo;               // streamed   [Ny, 128]
-    const uint16_t *ythi, *ytlo;             // streamed, transposed [128, ldT]
+    const uint16_t* x[3];                    // stationary [Nx, 128]: hi, (mid,) lo
+    const uint16_t* y[3];                    // streamed   [Ny, 128]
+    const uint16_t* yt[3];                   // streamed, transposed [128, ldT]
     int64_t Nx, Ny, ldT;
     const void *x_ids, *y_ids;
     const float* lse;   // GRAD: natural-log lse of the softmax rows (stationary side, or streamed side if LSE_STREAM)
@@ -116,6 +134,7 @@ struct SplitArgs {
     float invT, fns, gscale;
     float *part_m, *part_s, *opart;
     int tiles_per_split;
+    int lab;  // ablation bits of lab builds (MH_LAB); 0 in the shipped library
 };
 
 __device__ __forceinline__ void p_dma16(const void* g, void* lds) {
@@ -132,10 +151,15 @@ __device__ __forceinline__ f32x16 p_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { ret
 // the gradient mode: 5.49-5.51 ms against 5.48-5.54 for this loop -- with two wavefronts per SIMD the overlap is already there.
 // What did move the kernel: the probabilities are split into bf16 hi / lo by mh_split_pair (v_cvt_pk_bf16_f32: 5 instructions per
 // pair instead of ~30 of bit arithmetic): forward + dq 6.8 -> 5.6 ms, gradient pass 6.7 -> 5.5 ms at 65 536 x 65 536 x 128.
-template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT>
+template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT, int NIMG>
 __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitArgs a) {
+    using G = PG<NIMG>;
+    constexpr int PBN = G::BN, P_ARR = G::ARR, P_STAGE = G::STAGE, P_AUX = G::AUX, NST = G::NST;
+    constexpr bool ROT = (NIMG == 3);  // rotated schedule of the second wavefront of every SIMD (below)
+    static_assert(!ROT || PBN == 32, "the rotated schedule is written for one 32-row unit per tile");
     constexpr int IDW = sizeof(IdT) / 4;
     constexpr int NW = 8 / XT;  // wavefronts per workgroup
+    constexpr int ID_WI = (PBN * IDW + 63) / 64;  // wave instructions of 64 words that bring a tile's ids
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
@@ -145,26 +169,29 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     const int t_beg = split * a.tiles_per_split;
     const int t_end = (t_beg + a.tiles_per_split < nt_all) ? t_beg + a.tiles_per_split : nt_all;
 
-    // one tile: 4 arrays x 1024 chunks of 16 bytes; chunk position L of an array <- a swizzled source chunk
+    // one tile: NIMG arrays x PBN * 16 chunks of 16 bytes per orientation; chunk position L of an array <- a swizzled source chunk
+    constexpr int CPA = PBN * 16;            // chunks per array (both orientations)
+    constexpr int WI = NIMG * CPA / 64;      // wave instructions per orientation
     auto issue = [&](int t, int stage) {
         unsigned char* st = smem + stage * P_STAGE;
         const int64_t row0 = (int64_t)t * PBN;
 #pragma unroll
-        for (int j = 0; j < 32 / NW; ++j) {  // row-major image: position (r, p) holds chunk p ^ (r & 15) of row r (rows clamped)
-            const int L = (j * NW + wave) * 64 + lane;
-            const int arr = L >> 10, Lp = L & 1023, r = Lp >> 4, p = Lp & 15, c = p ^ (r & 15);
+        for (int j = 0; j < WI / NW; ++j) {  // row-major image: position (r, p) holds chunk p ^ (r & 15) of row r (rows clamped)
+            const int wi = j * NW + wave;
+            const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, r = Lp >> 4, p = Lp & 15, c = p ^ (r & 15);
             int64_t row = row0 + r;
             if (row > a.Ny - 1) row = a.Ny - 1;
-            p_dma16((arr ? a.ylo : a.yhi) + row * PE + c * 8, st + (j * NW + wave) * 1024);
+            p_dma16(a.y[arr] + row * PE + c * 8, st + wi * 1024);
         }
         if (MODE != PM_FWD)
 #pragma unroll
-        for (int j = 0; j < 32 / NW; ++j) {  // transposed image: position (e, p) holds chunk p ^ ((e >> 1) & 7) of row e (8 rows of Y each)
-            const int L = (j * NW + wave) * 64 + lane;
-            const int arr = L >> 10, Lp = L & 1023, e = Lp >> 3, p = Lp & 7, c = p ^ ((e >> 1) & 7);
-            p_dma16((arr ? a.ytlo : a.ythi) + (int64_t)e * a.ldT + row0 + c * 8, st + 2 * P_ARR + (j * NW + wave) * 1024);
+        for (int j = 0; j < WI / NW; ++j) {  // transposed image: position (e, p) holds chunk p ^ swz(e) of row e (8 rows of Y each)
+            constexpr int CPE = PBN / 8;  // chunks per row e
+            const int wi = j * NW + wave;
+            const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, e = Lp / CPE, p = Lp % CPE, c = p ^ ((e >> 1) & (CPE - 1));
+            p_dma16(a.yt[arr] + (int64_t)e * a.ldT + row0 + c * 8, st + NIMG * P_ARR + wi * 1024);
         }
-        if (HAS_IDS && wave < IDW) {  // 64 ids = IDW wave-instructions of 64 words
+        if (HAS_IDS && wave < ID_WI) {  // PBN ids = PBN * IDW words (a whole wave instruction is loaded; the words past the tile are ignored)
             int64_t w = row0 * IDW + wave * 64 + lane;
             const int64_t last = a.Ny * IDW - 1;
             if (w > last) w = last;
@@ -173,13 +200,13 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         if (MODE == PM_GRAD && LSE_STREAM && wave == NW - 1) {
             int64_t w = row0 + lane;
             if (w > a.Ny - 1) w = a.Ny - 1;
-            p_dma4(a.lse + w, smem + P_AUX + 1024 + stage * 256);
+            p_dma4(a.lse + w, smem + P_AUX + NST * 512 + stage * 256);
         }
     };
     if (t_beg < t_end) issue(t_beg, 0);
 
-    // stationary fragments (B operand of GEMM 1: lane = column l31 of its 32-row block, k = 16 ks + 8 h .. + 7)
-    bf16x8_t xh[XT][PKS], xl[XT][PKS];
+    // stationary fragments (B operand of GEMM 1: lane = column l31 of its 32-row block, k = 16 ks + 8 h .. + 7), image by image
+    bf16x8_t xs[NIMG][XT][PKS];
     bool xvalid[XT];
     IdT x_id[XT];
     float lse2_x[XT], m_run[XT], s_run[XT];
@@ -189,10 +216,10 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         xvalid[tn] = xrow < a.Nx;
         if (!xvalid[tn]) xrow = a.Nx - 1;
 #pragma unroll
-        for (int ks = 0; ks < PKS; ++ks) {
-            xh[tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a.xhi + xrow * PE + ks * 16 + h * 8));
-            xl[tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a.xlo + xrow * PE + ks * 16 + h * 8));
-        }
+        for (int g = 0; g < NIMG; ++g)
+#pragma unroll
+            for (int ks = 0; ks < PKS; ++ks)
+                xs[g][tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a.x[g] + xrow * PE + ks * 16 + h * 8));
         x_id[tn] = 0;
         if (HAS_IDS) x_id[tn] = static_cast<const IdT*>(a.x_ids)[xrow];
         lse2_x[tn] = 0.f;
@@ -210,135 +237,221 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[eb][tn][i] = 0.f;
 
-    __syncthreads();  // vmcnt(0) + barrier: tile t_beg has landed for every wavefront
-
-    for (int t = t_beg; t < t_end; ++t) {
-        const int odd = (t - t_beg) & 1;
-        if (t + 1 < t_end) issue(t + 1, odd ^ 1);
-        const unsigned char* st = smem + odd * P_STAGE;
-        const int64_t j_tile = (int64_t)t * PBN;
-        const int nvalid = (j_tile + PBN <= a.Ny) ? PBN : (int)(a.Ny - j_tile);
-        const IdT* ids = reinterpret_cast<const IdT*>(smem + P_AUX + odd * 512);
-        const float* lsej = reinterpret_cast<const float*>(smem + P_AUX + 1024 + odd * 256);
-#pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
-            if (u * 32 >= nvalid) break;
-            // ---- GEMM 1 on the unit's 32 streamed rows, software-pipelined over the 8 k-steps ---------------------------------
-            f32x16 acc[XT];
+    // The unit of work: 32 streamed rows against the wavefront's 32 * XT stationary rows, in three phases -- GEMM 1 (matrix pipe),
+    // epilogue (vector ALU), GEMM 2 (matrix pipe + the split of the probabilities).  `acc` carries the scores, then the probabilities.
+    f32x16 acc[XT];
+    auto gemm1 = [&](const unsigned char* st, int u) {
+        // ---- GEMM 1 on the unit's 32 streamed rows, software-pipelined over the 8 k-steps ---------------------------------
+        f32x16 acc2[XT];  // the second chain of the six-term form (unused otherwise)
+#pragma unroll
+        for (int tn = 0; tn < XT; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tn][i] = acc2[tn][i] = 0.f;
+        const int rd = (u * 32 + l31) * 256;
+        auto frag = [&](int ks, int arr) {
+            const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
+            return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + arr * P_ARR + rd + pos));
+        };
+        bf16x8_t af[NIMG];
+#pragma unroll
+        for (int g = 0; g < NIMG; ++g) af[g] = frag(0, g);
+#pragma unroll
+        for (int ks = 0; ks < PKS; ++ks) {
+            bf16x8_t nf[NIMG];
+#pragma unroll
+            for (int g = 0; g < NIMG; ++g) nf[g] = (ks + 1 < PKS) ? frag(ks + 1, g) : af[g];
+            if (NIMG == 2) {
+#pragma unroll
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(af[1], xs[0][tn][ks], acc[tn]);  // small terms first
+#pragma unroll
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(af[0], xs[1][tn][ks], acc[tn]);
+#pragma unroll
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(af[0], xs[0][tn][ks], acc[tn]);
+            } else {  // six terms, two chains: (l h, h l, m m) into acc2 and (m h, h m, h h) into acc, alternately
+                constexpr int TA[6] = {2, 1, 0, 0, 1, 0}, TB[6] = {0, 0, 2, 1, 1, 0};  // image of the streamed / of the stationary operand
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) {
+                        if (tm & 1) acc[tn] = p_mfma(af[TA[tm] % NIMG], xs[TB[tm] % NIMG][tn][ks], acc[tn]);
+                        else acc2[tn] = p_mfma(af[TA[tm] % NIMG], xs[TB[tm] % NIMG][tn][ks], acc2[tn]);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < NIMG; ++g) af[g] = nf[g];
+        }
+        if (NIMG == 3)
 #pragma unroll
             for (int tn = 0; tn < XT; ++tn)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[tn][i] = 0.f;
-            const int rd = (u * 32 + l31) * 256;
-            auto frag = [&](int ks, int arr) {
-                const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
-                return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + arr * P_ARR + rd + pos));
-            };
-            bf16x8_t ah = frag(0, 0), al = frag(0, 1);
+                for (int i = 0; i < 16; ++i) acc[tn][i] += acc2[tn][i];
+    };
+    auto epilogue = [&](int u, int nvalid, const IdT* ids, const float* lsej) {
+        // ---- epilogue: lane = stationary row tn * 32 + l31, streamed rows jl(i) = u * 32 + (i >> 2) * 8 + 4 h + (i & 3) ----------
+        const int jl0 = u * 32 + 4 * h;
 #pragma unroll
-            for (int ks = 0; ks < PKS; ++ks) {
-                bf16x8_t nh = ah, nl = al;
-                if (ks + 1 < PKS) {
-                    nh = frag(ks + 1, 0);
-                    nl = frag(ks + 1, 1);
-                }
+        for (int tn = 0; tn < XT; ++tn) {
+            // the 16 scores of this lane are turned into base-2 logits and then into probabilities IN PLACE (acc[tn]); the mask
+            // of rescored false negatives is one bit per score
+            unsigned mbits = 0;
 #pragma unroll
-                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(al, xh[tn][ks], acc[tn]);  // small terms first
-#pragma unroll
-                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(ah, xl[tn][ks], acc[tn]);
-#pragma unroll
-                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(ah, xh[tn][ks], acc[tn]);
-                ah = nh;
-                al = nl;
+            for (int i = 0; i < 16; ++i) {
+                const int jl = jl0 + (i >> 2) * 8 + (i & 3);
+                bool masked = false;
+                if (HAS_IDS) masked = (ids[jl] == x_id[tn]);
+                mbits |= (masked ? 1u : 0u) << i;
+                float v2 = (masked ? a.fns : acc[tn][i]) * scale2;
+                if (nvalid < PBN && jl >= nvalid) v2 = -INFINITY;  // only the last tile of Y can be partial
+                acc[tn][i] = v2;
             }
-            // ---- epilogue: lane = stationary row tn * 32 + l31, streamed rows jl(i) = u * 32 + (i >> 2) * 8 + 4 h + (i & 3) ----------
-            bf16x8_t ph[XT][2], pl[XT][2];  // [tn][k-step]: the probabilities as the B operand of GEMM 2, hi and lo
-            const int jl0 = u * 32 + 4 * h;
-#pragma unroll
-            for (int tn = 0; tn < XT; ++tn) {
-                // the 16 scores of this lane are turned into base-2 logits and then into probabilities IN PLACE (acc[tn]); the mask
-                // of rescored false negatives is one bit per score
-                unsigned mbits = 0;
+            if (MODE == PM_GRAD) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int jl = jl0 + (i >> 2) * 8 + (i & 3);
-                    bool masked = false;
-                    if (HAS_IDS) masked = (ids[jl] == x_id[tn]);
-                    mbits |= (masked ? 1u : 0u) << i;
-                    float v2 = (masked ? a.fns : acc[tn][i]) * scale2;
-                    if (nvalid < PBN && jl >= nvalid) v2 = -INFINITY;  // only the last tile of Y can be partial
-                    acc[tn][i] = v2;
+                    const float l2 = LSE_STREAM ? lsej[jl0 + (i >> 2) * 8 + (i & 3)] * P_LOG2E : lse2_x[tn];
+                    const float e = __builtin_amdgcn_exp2f(acc[tn][i] - l2) * a.gscale;  // -inf on invalid rows -> 0
+                    acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
                 }
-                if (MODE == PM_GRAD) {
+            } else {  // FWD / FWD_GRAD: lazy reference max shared by the two lanes of a row
+                float tmax = acc[tn][0];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float l2 = LSE_STREAM ? lsej[jl0 + (i >> 2) * 8 + (i & 3)] * P_LOG2E : lse2_x[tn];
-                        const float e = __builtin_amdgcn_exp2f(acc[tn][i] - l2) * a.gscale;  // -inf on invalid rows -> 0
-                        acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
-                    }
-                } else {  // FWD / FWD_GRAD: lazy reference max shared by the two lanes of a row
-                    float tmax = acc[tn][0];
+                for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[tn][i]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                if (__any(tmax > m_run[tn] + P_LAZY)) {
+                    const float m_new = (tmax > m_run[tn] + P_LAZY) ? tmax : m_run[tn];
+                    const float f = __builtin_amdgcn_exp2f(m_run[tn] - m_new);
+                    s_run[tn] *= f;
+                    m_run[tn] = m_new;
+                    if (MODE != PM_FWD)
 #pragma unroll
-                    for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[tn][i]);
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                    if (__any(tmax > m_run[tn] + P_LAZY)) {
-                        const float m_new = (tmax > m_run[tn] + P_LAZY) ? tmax : m_run[tn];
-                        const float f = __builtin_amdgcn_exp2f(m_run[tn] - m_new);
-                        s_run[tn] *= f;
-                        m_run[tn] = m_new;
-                        if (MODE != PM_FWD)
+                    for (int eb = 0; eb < OB; ++eb)
 #pragma unroll
-                        for (int eb = 0; eb < OB; ++eb)
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) o[eb][tn][i] *= f;  // every accumulator element of this lane belongs to its row
-                    }
-                    float s_add = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float e = __builtin_amdgcn_exp2f(acc[tn][i] - m_run[tn]);
-                        s_add += e;  // rescored false negatives stay in the denominator
-                        acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
-                    }
-                    s_run[tn] += s_add;
+                        for (int i = 0; i < 16; ++i) o[eb][tn][i] *= f;  // every accumulator element of this lane belongs to its row
                 }
-                if (MODE != PM_FWD)
+                float s_add = 0.f;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    uint32_t wh[4], wl[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        mh_split_pair(acc[tn][8 * s + 2 * k], acc[tn][8 * s + 2 * k + 1], wh[k], wl[k]);
-                    }
-                    ph[tn][s] = __builtin_bit_cast(bf16x8_t, make_uint4(wh[0], wh[1], wh[2], wh[3]));
-                    pl[tn][s] = __builtin_bit_cast(bf16x8_t, make_uint4(wl[0], wl[1], wl[2], wl[3]));
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(acc[tn][i] - m_run[tn]);
+                    s_add += e;  // rescored false negatives stay in the denominator
+                    acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
                 }
+                s_run[tn] += s_add;
             }
-            // ---- GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x]; A = two 8-byte pieces of row e of the transposed image ----------
-            const unsigned char* yt = st + 2 * P_ARR;
-            if (MODE != PM_FWD)
+        }
+    };
+    auto gemm2 = [&](const unsigned char* st, int u) {
+        // ---- GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x]; A = two 8-byte pieces of row e of the transposed image; the 16
+        // probabilities of a lane, split into bf16 pieces, are the B operand of its two k-steps --------------------------------
+        const unsigned char* yt = st + NIMG * P_ARR;
+        if (MODE != PM_FWD)
 #pragma unroll
-            for (int eb = 0; eb < OB; ++eb) {
-                const int e = eb * 32 + l31, sw = (e >> 1) & 7;
-                const unsigned char* row_h = yt + e * 128 + 8 * h;
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t pp[NIMG][XT];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int c0 = 4 * u + 2 * s;
-                    const uint2 h0 = *reinterpret_cast<const uint2*>(row_h + ((c0 ^ sw) << 4));
-                    const uint2 h1 = *reinterpret_cast<const uint2*>(row_h + (((c0 + 1) ^ sw) << 4));
-                    const uint2 l0 = *reinterpret_cast<const uint2*>(row_h + P_ARR + ((c0 ^ sw) << 4));
-                    const uint2 l1 = *reinterpret_cast<const uint2*>(row_h + P_ARR + (((c0 + 1) ^ sw) << 4));
-                    const bf16x8_t ath = __builtin_bit_cast(bf16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
-                    const bf16x8_t atl = __builtin_bit_cast(bf16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            for (int tn = 0; tn < XT; ++tn) {
+                uint32_t w[NIMG][4];
 #pragma unroll
-                    for (int tn = 0; tn < XT; ++tn) o[eb][tn] = p_mfma(atl, ph[tn][s], o[eb][tn]);
+                for (int k = 0; k < 4; ++k) {
+                    if (NIMG == 3) mh_split3_pair(acc[tn][8 * s + 2 * k], acc[tn][8 * s + 2 * k + 1], w[0][k], w[1][k], w[NIMG - 1][k]);
+                    else mh_split_pair(acc[tn][8 * s + 2 * k], acc[tn][8 * s + 2 * k + 1], w[0][k], w[1][k]);
+                }
 #pragma unroll
-                    for (int tn = 0; tn < XT; ++tn) o[eb][tn] = p_mfma(ath, pl[tn][s], o[eb][tn]);
+                for (int g = 0; g < NIMG; ++g) pp[g][tn] = __builtin_bit_cast(bf16x8_t, make_uint4(w[g][0], w[g][1], w[g][2], w[g][3]));
+            }
+            constexpr int EBG = (NIMG == 3 && OB > 1) ? 2 : 1;  // column blocks of O^T walked together (independent MFMA chains)
+            const int c0 = 4 * u + 2 * s;
 #pragma unroll
-                    for (int tn = 0; tn < XT; ++tn) o[eb][tn] = p_mfma(ath, ph[tn][s], o[eb][tn]);
+            for (int eb0 = 0; eb0 < OB; eb0 += EBG) {
+                bf16x8_t at[NIMG][EBG];
+#pragma unroll
+                for (int q = 0; q < EBG; ++q) {
+                    const int e = (eb0 + q) * 32 + l31, sw = (e >> 1) & (PBN / 8 - 1);
+                    const unsigned char* row_h = yt + e * (PBN * 2) + 8 * h;
+#pragma unroll
+                    for (int g = 0; g < NIMG; ++g) {
+                        const uint2 v0 = *reinterpret_cast<const uint2*>(row_h + g * P_ARR + ((c0 ^ sw) << 4));
+                        const uint2 v1 = *reinterpret_cast<const uint2*>(row_h + g * P_ARR + (((c0 + 1) ^ sw) << 4));
+                        at[g][q] = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+                    }
+                }
+                if (NIMG == 2) {
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) o[eb0][tn] = p_mfma(at[1][0], pp[0][tn], o[eb0][tn]);
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) o[eb0][tn] = p_mfma(at[0][0], pp[1][tn], o[eb0][tn]);
+#pragma unroll
+                    for (int tn = 0; tn < XT; ++tn) o[eb0][tn] = p_mfma(at[0][0], pp[0][tn], o[eb0][tn]);
+                } else {
+                    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};  // l h, h l, m m, m h, h m, h h
+#pragma unroll
+                    for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < XT; ++tn)
+#pragma unroll
+                            for (int q = 0; q < EBG; ++q)
+                                o[eb0 + q][tn] = p_mfma(at[TA[tm] % NIMG][q], pp[TB[tm] % NIMG][tn], o[eb0 + q][tn]);
                 }
             }
         }
-        __syncthreads();  // every wavefront is done with this tile; the next one (vmcnt(0)) has landed
+    };
+    auto tile_rows = [&](int t) {
+        const int64_t j_tile = (int64_t)t * PBN;
+        return (j_tile + PBN <= a.Ny) ? PBN : (int)(a.Ny - j_tile);
+    };
+    auto tile_ids = [&](int stage) { return reinterpret_cast<const IdT*>(smem + P_AUX + stage * 512); };
+    auto tile_lse = [&](int stage) { return reinterpret_cast<const float*>(smem + P_AUX + NST * 512 + stage * 256); };
+
+    __syncthreads();  // vmcnt(0) + barrier: tile t_beg has landed for every wavefront
+
+    if constexpr (!ROT) {
+        for (int t = t_beg; t < t_end; ++t) {
+            const int odd = (t - t_beg) & 1;
+            if (t + 1 < t_end) issue(t + 1, odd ^ 1);
+            const unsigned char* st = smem + odd * P_STAGE;
+            const int nvalid = tile_rows(t);
+#pragma unroll 1
+            for (int u = 0; u < PBN / 32; ++u) {
+                if (u * 32 >= nvalid) break;
+                gemm1(st, u);
+                epilogue(u, nvalid, tile_ids(odd), tile_lse(odd));
+                gemm2(st, u);
+            }
+            __syncthreads();  // every wavefront is done with this tile; the next one (vmcnt(0)) has landed
+        }
+    } else {
+        // Rotated schedule.  The workgroup barrier of every tile puts the two wavefronts of a SIMD in LOCKSTEP: both in GEMM 1 (the
+        // matrix pipe shared, the vector ALU idle), then both in the epilogue (the matrix pipe idle) -- the phases ADD (measured: the
+        // three-term kernel's 3674 cycles per unit = 1536 of MFMA + ~1900 of vector work).  Here the second wavefront of a SIMD
+        // (waves NW/2 ...) executes its barrier of tile t BETWEEN its GEMM 1 and its epilogue, the first one at the end of the tile
+        // (s_barrier counts wavefronts, not code addresses): between two barriers the early wavefront runs G1(t) E(t) G2(t) and the
+        // late one E(t-1) G2(t-1) G1(t), so that each epilogue runs beside the other wavefront's MFMAs.  Tile t + 2 is requested by
+        // a wavefront when it has passed barrier t (nobody reads tile t - 1 any more: three stages) and has landed before it arrives
+        // at barrier t + 1.
+#ifdef MH_LAB  // lab builds: 1 = odd wavefronts late, 2 = nobody late, 4 / 8 / 16 / 32 / 64 = skip GEMM 1 / epilogue / GEMM 2 / the tile requests / the barrier (timing only)
+        const bool late = (a.lab & 2) ? false : ((a.lab & 1) ? ((wave & 1) != 0) : (wave >= NW / 2));
+#define MH_SKIP(bit) (a.lab & (bit))
+#else
+        const bool late = wave >= NW / 2;
+#define MH_SKIP(bit) false
+#endif
+        if (t_beg + 1 < t_end) issue(t_beg + 1, 1);
+        int s_cur = 0;  // stage of tile t
+        for (int t = t_beg; t < t_end; ++t) {
+            const int s_prev = (s_cur == 0) ? NST - 1 : s_cur - 1;  // = the stage of tile t + 2
+            const unsigned char* st = smem + s_cur * P_STAGE;
+            if (!MH_SKIP(4)) gemm1(st, 0);
+            if (late) {
+                if (!MH_SKIP(64)) __syncthreads();
+                if (t + 2 < t_end && !MH_SKIP(32)) issue(t + 2, s_prev);
+            }
+            if (!MH_SKIP(8)) epilogue(0, tile_rows(t), tile_ids(s_cur), tile_lse(s_cur));
+            if (!MH_SKIP(16)) gemm2(st, 0);
+            if (!late) {
+                if (!MH_SKIP(64)) __syncthreads();
+                if (t + 2 < t_end && !MH_SKIP(32)) issue(t + 2, s_prev);
+            }
+            s_cur = (s_cur == NST - 1) ? 0 : s_cur + 1;
+        }
+#undef MH_SKIP
     }
 
     // ---- results: the partial layouts of mh_scorer_stream.hip ---------------------------------------------------------------------
@@ -368,21 +481,21 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     }
 }
 
-template <int MODE, bool LSE_STREAM, int XT>
+template <int MODE, bool LSE_STREAM, int XT, int NIMG>
 int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStream_t s) {
 #define MH_LAUNCH_SPLIT(IdT, HAS)                                                                                          \
     do {                                                                                                                   \
-        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT>;                                                   \
+        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT, NIMG>;                                             \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                    P_LDS) != hipSuccess) {                                                                \
-                mh_set_error("scorer (bf16x3): cannot raise the dynamic LDS limit");                                       \
+                                    PG<NIMG>::LDS) != hipSuccess) {                                                        \
+                mh_set_error("scorer (split bf16): cannot raise the dynamic LDS limit");                                   \
                 return MH_ERR_LAUNCH;                                                                                      \
             }                                                                                                              \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
-        MH_LAUNCH(kern, grid, dim3(512 / XT), (size_t)P_LDS, s, a);                                                        \
+        MH_LAUNCH(kern, grid, dim3(512 / XT), (size_t)PG<NIMG>::LDS, s, a);                                                \
     } while (0)
     if (!a.x_ids) MH_LAUNCH_SPLIT(int32_t, false);
     else if (ids_dtype == MH_I32) MH_LAUNCH_SPLIT(int32_t, true);
@@ -394,38 +507,47 @@ int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStrea
 }  // namespace
 
 // ---- internal interface used by mh_scorer.hip ------------------------------------------------------------------------------------
-// Bytes of the split of ONE [N, 128] matrix: hi, lo [N, 128] and hiT, loT [128, ldT] (all bf16), 256-byte aligned parts.
+// Bytes of the split of ONE [N, 128] matrix: three images [N, 128] and three transposed ones [128, ldT] (all bf16; the three-term
+// arithmetic uses two of each), 256-byte aligned parts.
 int64_t mh_split_matrix_bytes(int64_t N) {
     const int64_t ldT = (N + 63) / 64 * 64;
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-    return 2 * al(N * PE * 2) + 2 * al(PE * ldT * 2);
+    return 3 * al(N * PE * 2) + 3 * al(PE * ldT * 2);
 }
 
 struct MhSplitMatrix {
-    uint16_t *hi, *lo, *hiT, *loT;
+    uint16_t *img[3], *imgT[3];  // hi, (mid,) lo -- img[nimg - 1] is the last piece
     int64_t ldT;
+    int nimg;
 };
 
-MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, hipStream_t s) {
+MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, int nimg, hipStream_t s) {
     MhSplitMatrix m;
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
     char* p = static_cast<char*>(buf);
     m.ldT = (N + 63) / 64 * 64;
-    m.hi = reinterpret_cast<uint16_t*>(p);
-    p += al(N * PE * 2);
-    m.lo = reinterpret_cast<uint16_t*>(p);
-    p += al(N * PE * 2);
-    m.hiT = reinterpret_cast<uint16_t*>(p);
-    p += al(PE * m.ldT * 2);
-    m.loT = reinterpret_cast<uint16_t*>(p);
-    MH_LAUNCH(split_prepare_kernel, dim3((unsigned)mh_ceil_div(N, 64)), dim3(256), 0, s, x, N, m.hi, m.lo, m.hiT, m.loT, m.ldT);
+    m.nimg = nimg;
+    for (int g = 0; g < 3; ++g) {
+        m.img[g] = reinterpret_cast<uint16_t*>(p);
+        p += al(N * PE * 2);
+    }
+    for (int g = 0; g < 3; ++g) {
+        m.imgT[g] = reinterpret_cast<uint16_t*>(p);
+        p += al(PE * m.ldT * 2);
+    }
+    const dim3 grid((unsigned)mh_ceil_div(N, 64));
+    if (nimg == 3)
+        MH_LAUNCH(split_prepare_kernel<true>, grid, dim3(256), 0, s, x, N, m.img[0], m.img[1], m.img[2], m.imgT[0], m.imgT[1], m.imgT[2], m.ldT);
+    else
+        MH_LAUNCH(split_prepare_kernel<false>, grid, dim3(256), 0, s, x, N, m.img[0], (uint16_t*)nullptr, m.img[1], m.imgT[0],
+                  (uint16_t*)nullptr, m.imgT[1], m.ldT);
     return m;
 }
 
-// number of candidate splits (<= the fp32 plan's for the same shapes: the partial buffers are sized by that one)
-int mh_split_plan(int64_t Nx, int64_t Ny, int* tiles_per_split) {
+// number of candidate splits (<= the fp32 plan's for the same shapes: the partial buffers are sized by the largest of the plans)
+int mh_split_plan(int64_t Nx, int64_t Ny, int nimg, int* tiles_per_split) {
     const int row_tiles = (int)mh_ceil_div(Nx, PXB);
-    const int nt = (int)mh_ceil_div(Ny, PBN);
+    const int nt = (int)mh_ceil_div(Ny, nimg == 3 ? PG<3>::BN : PG<2>::BN);
     int want = mh_num_cus() / row_tiles;
     if (want < 1) want = 1;
     if (want > nt) want = nt;
@@ -440,27 +562,49 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
                                const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
                                float fns, float gscale, float* part_m, float* part_s, float* opart, hipStream_t s) {
     SplitArgs a;
-    a.xhi = X.hi; a.xlo = X.lo; a.yhi = Y.hi; a.ylo = Y.lo; a.ythi = Y.hiT; a.ytlo = Y.loT;
+    const int nimg = X.nimg;
+    for (int g = 0; g < 3; ++g) {
+        a.x[g] = X.img[g < nimg ? g : nimg - 1];
+        a.y[g] = Y.img[g < nimg ? g : nimg - 1];
+        a.yt[g] = Y.imgT[g < nimg ? g : nimg - 1];
+    }
     a.Nx = Nx; a.Ny = Ny; a.ldT = Y.ldT; a.x_ids = x_ids; a.y_ids = y_ids; a.lse = lse; a.pos = pos;
     a.invT = invT; a.fns = fns; a.gscale = gscale; a.part_m = part_m; a.part_s = part_s; a.opart = opart;
     int tps = 1;
-    const int nsplit = mh_split_plan(Nx, Ny, &tps);
+    const int nsplit = mh_split_plan(Nx, Ny, nimg, &tps);
     a.tiles_per_split = tps;
+    static int lab = -1;
+    if (lab < 0) {
+        const char* e = MH_LAB_ENV("MERLIN_HIP_SCORER_LAB");
+        lab = e ? atoi(e) : 0;
+    }
+    a.lab = lab;
 
     dim3 grid((unsigned)mh_ceil_div(Nx, PXB), (unsigned)nsplit);
-    // MERLIN_HIP_SCORER_XT = 1 | 2 (experiments): 32-row blocks of X per wavefront (see the kernel)
-    static int xt = -1;
+    static int xt = -1;  // MERLIN_HIP_SCORER_XT = 1 | 2 (lab builds): 32-row blocks of X per wavefront (see the kernel)
     if (xt < 0) {
         const char* e = MH_LAB_ENV("MERLIN_HIP_SCORER_XT");
         xt = (e && atoi(e) == 2) ? 2 : 1;
     }
-    if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1>(a, ids_dtype, grid, s);
-    if (xt == 2) {
-        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2>(a, ids_dtype, grid, s);
-        if (lse_stream) return launch_split_mode<PM_GRAD, true, 2>(a, ids_dtype, grid, s);
-        return launch_split_mode<PM_GRAD, false, 2>(a, ids_dtype, grid, s);
+    if (nimg == 3 && xt == 2) {
+        if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 2, 3>(a, ids_dtype, grid, s);
+        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2, 3>(a, ids_dtype, grid, s);
+        if (lse_stream) return launch_split_mode<PM_GRAD, true, 2, 3>(a, ids_dtype, grid, s);
+        return launch_split_mode<PM_GRAD, false, 2, 3>(a, ids_dtype, grid, s);
     }
-    if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1>(a, ids_dtype, grid, s);
-    if (lse_stream) return launch_split_mode<PM_GRAD, true, 1>(a, ids_dtype, grid, s);
-    return launch_split_mode<PM_GRAD, false, 1>(a, ids_dtype, grid, s);
+    if (nimg == 3) {
+        if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3>(a, ids_dtype, grid, s);
+        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 3>(a, ids_dtype, grid, s);
+        if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 3>(a, ids_dtype, grid, s);
+        return launch_split_mode<PM_GRAD, false, 1, 3>(a, ids_dtype, grid, s);
+    }
+    if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 2>(a, ids_dtype, grid, s);
+    if (xt == 2) {
+        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2, 2>(a, ids_dtype, grid, s);
+        if (lse_stream) return launch_split_mode<PM_GRAD, true, 2, 2>(a, ids_dtype, grid, s);
+        return launch_split_mode<PM_GRAD, false, 2, 2>(a, ids_dtype, grid, s);
+    }
+    if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 2>(a, ids_dtype, grid, s);
+    if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 2>(a, ids_dtype, grid, s);
+    return launch_split_mode<PM_GRAD, false, 1, 2>(a, ids_dtype, grid, s);
 }

@@ -1442,22 +1442,23 @@ def _logq_pair(pos_logq, neg_logq, B, Nn):
 _ARITH = [None]
 
 
-def _sync_scorer_arith(lib) -> None:
-    """MERLIN_HIP_SCORER_ARITH = f32 (default) | bf16x3 is read HERE (a dict lookup per call) and handed to the library when it
-    changes (``mh_set_scorer_arith``): the opt-in split-bf16 arithmetic of the scorer's gradient passes at E = 128 -- dot products
-    within ~2.3e-6 |q| |item| of the exact ones at 16 / 3 of the fp32 MFMA rate; never the default, reported under its own dtype."""
-    import os
-
-    want = 1 if os.environ.get("MERLIN_HIP_SCORER_ARITH", "f32") == "bf16x3" else 0
-    if _ARITH[0] != want:
-        check(lib.mh_set_scorer_arith(want), "mh_set_scorer_arith")
-        _ARITH[0] = want
+_SCORER_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
 def scorer_arith() -> str:
-    import os
+    """Arithmetic of the in-batch scorer's products at E = 128 (``MERLIN_HIP_SCORER_ARITH``): "bf16x6" (default) -- the fp32-grade
+    six-term split on the bf16 MFMA (every product from h h + h m + m h + h l + l h + m m, dropped terms <= 2^-25 of it); "f32" -- the
+    exact fp32 MFMA chains; "bf16x3" -- the opt-in three-term split (2^-17 per operand, NOT fp32-grade, own dtype label)."""
+    v = os.environ.get("MERLIN_HIP_SCORER_ARITH", "bf16x6")
+    return v if v in _SCORER_MODES else "bf16x6"
 
-    return "bf16x3" if os.environ.get("MERLIN_HIP_SCORER_ARITH", "f32") == "bf16x3" else "f32"
+
+def _sync_scorer_arith(lib) -> None:
+    """The switch is read HERE (a dict lookup per call) and handed to the library when it changes (``mh_set_scorer_arith``)."""
+    want = _SCORER_MODES[scorer_arith()]
+    if _ARITH[0] != want:
+        check(lib.mh_set_scorer_arith(want), "mh_set_scorer_arith")
+        _ARITH[0] = want
 
 
 def inbatch_softmax(q, item, neg_item, pos_ids=None, neg_ids=None, temperature: float = 1.0,

@@ -14,10 +14,11 @@ ATOL = 1e-4  # north-star fp32 logits tolerance
 
 
 def _pins_f32_arithmetic():
-    """Tests that pin the f32 scorer to the oracle at ATOL: under the opt-in MERLIN_HIP_SCORER_ARITH=bf16x3 the logits-free E=128
-    forward runs the 3-term bf16 split, whose own tolerance is tested in test_gpu_scorer_split.py."""
-    if ops.scorer_arith() != "f32":
-        pytest.skip("pins the f32 scorer; the bf16x3 mode has its own tests (test_gpu_scorer_split.py)")
+    """Tests that pin the scorer to the oracle at ATOL in an fp32-grade arithmetic (the exact chains, or the default six-term bf16x6):
+    under the opt-in MERLIN_HIP_SCORER_ARITH=bf16x3 the logits-free E=128 forward runs the 3-term bf16 split, whose own tolerance is
+    tested in test_gpu_scorer_split.py."""
+    if ops.scorer_arith() == "bf16x3":
+        pytest.skip("pins the fp32-grade scorer; the bf16x3 mode has its own tests (test_gpu_scorer_split.py)")
 
 
 def _t(a, device):
@@ -63,9 +64,14 @@ def test_inbatch_scorer_matches_oracle(device, B, E, temperature, idt):
     r2 = ops.inbatch_softmax(_t(q, device), _t(it, device), _t(it, device), _t(ids, device), _t(ids, device), temperature,
                              materialize=False)
     assert r2.logits is None
-    # one kernel family behind both modes: bit for bit -- unless the opt-in tiled forward kernel (another summation order) is on
+    # one kernel family behind both modes: bit for bit -- unless the opt-in tiled forward kernel (another summation order) is on, or the
+    # logits-free E = 128 forward runs the (fp32-grade) six-term split while the materialised logits come from the exact chains: a few
+    # ulps of the lse's scale then
     tiled = os.environ.get("MERLIN_HIP_SCORER_FWD") == "tiled"
-    torch.testing.assert_close(r2.loss, r.loss, atol=2e-6 if tiled else 0, rtol=1e-6 if tiled else 0)
+    if E == 128 and ops.scorer_arith() != "f32":
+        torch.testing.assert_close(r2.loss, r.loss, atol=2e-5, rtol=4e-6)
+    else:
+        torch.testing.assert_close(r2.loss, r.loss, atol=2e-6 if tiled else 0, rtol=1e-6 if tiled else 0)
 
 
 def test_scorer_scores_are_fmaf_chains(device):

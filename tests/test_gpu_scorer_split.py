@@ -1,7 +1,8 @@
-"""The opt-in bf16x3 arithmetic of the in-batch scorer's gradient passes (mh_set_scorer_arith(1), mh_scorer_split.hip): loss, lse,
-dq, ditem, dneg against the exact-fp32 kernels on the same inputs and against a float64 statement of
-ContrastiveOutput.outputs + CategoricalCrossEntropy (tf/outputs/contrastive.py:276-344, tf/losses/listwise.py:38-52), at
-north_star's tolerance: logits / lse within 1e-4."""
+"""The split-bf16 arithmetics of the in-batch scorer (mh_scorer_split.hip): the fp32-grade six-term "bf16x6" (mh_set_scorer_arith(2), the
+default) and the opt-in three-term "bf16x3" (mh_set_scorer_arith(1)): loss, lse, dq, ditem, dneg against the exact-fp32 kernels on the
+same inputs and against a float64 statement of ContrastiveOutput.outputs + CategoricalCrossEntropy (tf/outputs/contrastive.py:276-344,
+tf/losses/listwise.py:38-52).  bf16x3: north_star's tolerance (logits / lse within 1e-4).  bf16x6: no further from float64 than a small
+multiple of the exact fp32 kernels' own distance."""
 import numpy as np
 import pytest
 import torch
@@ -26,8 +27,10 @@ def _ref64(q, it, neg, pid, nid, T, fns):
     return loss.detach().numpy(), lse.detach().numpy(), q64.grad.numpy(), i64.grad.numpy(), n64.grad.numpy()
 
 
-@pytest.mark.parametrize("B,Nn,ids,idt", [(512, 512, True, np.int32), (300, 300, True, np.int64), (256, 1000, False, None), (4096, 4096, True, np.int32)])
-def test_bf16x3_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, Nn, ids, idt):
+@pytest.mark.parametrize("arith", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("B,Nn,ids,idt", [(512, 512, True, np.int32), (300, 300, True, np.int64), (256, 1000, False, None),
+                                          (700, 97, True, np.int64), (333, 65, True, np.int32), (4096, 4096, True, np.int32)])
+def test_split_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, Nn, ids, idt, arith):
     rng = np.random.default_rng(B + Nn)
     E, T, fns = 128, 0.05, -655.04
     unit = lambda a: (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
@@ -49,16 +52,23 @@ def test_bf16x3_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, 
 
     monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
     f32 = run()
-    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "bf16x3")
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", arith)
     sp = run()
     monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
     names = ("loss", "lse", "dq", "ditem", "dneg", "dq(bwd)", "ditem(bwd)", "dneg(bwd)", "loss(fwd)", "lse(fwd)")
-    assert any(not np.array_equal(a, b) for a, b in zip(f32, sp)), "the bf16x3 switch did not change the arithmetic"
+    assert any(not np.array_equal(a, b) for a, b in zip(f32, sp)), "the switch did not change the arithmetic"
+    x6 = arith == "bf16x6"
     for n, a, b in zip(names, f32, sp):
-        tol = 1e-4 if n.startswith(("loss", "lse")) else 2e-6  # gradients of the MEAN loss carry 1 / B
-        np.testing.assert_allclose(b, a, atol=tol, rtol=2e-4, err_msg=n)
-    if B <= 512:
+        # gradients of the MEAN loss carry 1 / B; bf16x6 against the fp32 kernels: a few ulps of the lse (~ 10: ulp 1e-6)
+        tol = (1e-5 if x6 else 1e-4) if n.startswith(("loss", "lse")) else (2e-7 if x6 else 2e-6)
+        np.testing.assert_allclose(b, a, atol=tol, rtol=2e-5 if x6 else 2e-4, err_msg=n)
+    if B <= 1024:
         loss, lse, dq, ditem, dneg = _ref64(q, it, neg, pid, nid, T, fns)
+        if x6:  # fp32-grade: never further from float64 than 4 x the exact fp32 kernels (+ an ulp of the quantity's scale)
+            for k, want in ((0, loss), (1, lse), (2, dq), (3, ditem), (4, dneg), (8, loss), (9, lse)):
+                e_sp, e_f32 = np.abs(sp[k] - want).max(), np.abs(f32[k] - want).max()
+                floor = 2.0 ** -23 * max(np.abs(want).max(), 1e-30)
+                assert e_sp <= 4 * e_f32 + floor, (names[k], e_sp, e_f32)
         np.testing.assert_allclose(sp[0], loss, atol=1e-4, rtol=1e-5)
         np.testing.assert_allclose(sp[1], lse, atol=1e-4, rtol=1e-5)
         np.testing.assert_allclose(sp[2], dq, atol=2e-6, rtol=2e-4)
