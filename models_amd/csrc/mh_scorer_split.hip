@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     }
     __syncthreads();
     if (!hiT) return;
-    // thread (e, half): 32 consecutive rows of column e -> 64 contiguous bytes of the transposed arrays
+    // thread (e, half): 32 consecutive rows of column e -> 64 contiguous bytes of the transposed arrays.  Inside every group of 16
+    // rows the order is 0-3, 8-11, 4-7, 12-15 (bits 2 and 3 of the row swapped): the 8 rows a lane of GEMM 2 needs for one k-step --
+    // streamed rows 8 (i >> 2) + 4 h + (i & 3) of the group, the order in which it holds its probabilities -- are then 16
+    // CONTIGUOUS bytes (one ds_read_b128 = the MFMA operand, no register moves)
     const int e = threadIdx.x & (PE - 1), half = threadIdx.x >> 7;
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
             uint32_t wv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int r = half * 32 + g * 8 + 2 * k;
+                const int j = 2 * k;  // stored position g * 8 + j of the half <- row (g >> 1) * 16 + 8 (j >> 2) + 4 (g & 1) + (j & 3)
+                const int r = half * 32 + (g >> 1) * 16 + 8 * (j >> 2) + 4 * (g & 1) + (j & 3);
                 wv[k] = (uint32_t)sp[a][r][e] | ((uint32_t)sp[a][r + 1][e] << 16);
             }
             const int64_t col = r0 + half * 32 + g * 8;
@@ -186,9 +190,10 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         if (MODE != PM_FWD)
 #pragma unroll
         for (int j = 0; j < WI / NW; ++j) {  // transposed image: position (e, p) holds chunk p ^ swz(e) of row e (8 rows of Y each)
-            constexpr int CPE = PBN / 8;  // chunks per row e
+            constexpr int CPE = PBN / 8;  // chunks per row e; swz(e) = (e / (16 / CPE)) mod CPE: the b128 reads of GEMM 2 are conflict-free
             const int wi = j * NW + wave;
-            const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, e = Lp / CPE, p = Lp % CPE, c = p ^ ((e >> 1) & (CPE - 1));
+            const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, e = Lp / CPE, p = Lp % CPE,
+                      c = p ^ ((e / (16 / CPE)) & (CPE - 1));
             p_dma16(a.yt[arr] + (int64_t)e * a.ldT + row0 + c * 8, st + NIMG * P_ARR + wi * 1024);
         }
         if (HAS_IDS && wave < ID_WI) {  // PBN ids = PBN * IDW words (a whole wave instruction is loaded; the words past the tile are ignored)
@@ -243,10 +248,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     auto gemm1 = [&](const unsigned char* st, int u) {
         // ---- GEMM 1 on the unit's 32 streamed rows, software-pipelined over the 8 k-steps ---------------------------------
         f32x16 acc2[XT];  // the second chain of the six-term form (unused otherwise)
-#pragma unroll
-        for (int tn = 0; tn < XT; ++tn)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[tn][i] = acc2[tn][i] = 0.f;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // C of a chain's first MFMA
         const int rd = (u * 32 + l31) * 256;
         auto frag = [&](int ks, int arr) {
             const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
             for (int g = 0; g < NIMG; ++g) nf[g] = (ks + 1 < PKS) ? frag(ks + 1, g) : af[g];
             if (NIMG == 2) {
 #pragma unroll
-                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(af[1], xs[0][tn][ks], acc[tn]);  // small terms first
+                for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(af[1], xs[0][tn][ks], ks == 0 ? zero : acc[tn]);  // small terms first
 #pragma unroll
                 for (int tn = 0; tn < XT; ++tn) acc[tn] = p_mfma(af[0], xs[1][tn][ks], acc[tn]);
 #pragma unroll
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                 for (int tm = 0; tm < 6; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < XT; ++tn) {
-                        if (tm & 1) acc[tn] = p_mfma(af[TA[tm] % NIMG], xs[TB[tm] % NIMG][tn][ks], acc[tn]);
-                        else acc2[tn] = p_mfma(af[TA[tm] % NIMG], xs[TB[tm] % NIMG][tn][ks], acc2[tn]);
+                        if (tm & 1) acc[tn] = p_mfma(af[TA[tm] % NIMG], xs[TB[tm] % NIMG][tn][ks], (ks == 0 && tm == 1) ? zero : acc[tn]);
+                        else acc2[tn] = p_mfma(af[TA[tm] % NIMG], xs[TB[tm] % NIMG][tn][ks], (ks == 0 && tm == 0) ? zero : acc2[tn]);
                     }
             }
 #pragma unroll
@@ -291,31 +293,36 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         const int jl0 = u * 32 + 4 * h;
 #pragma unroll
         for (int tn = 0; tn < XT; ++tn) {
-            // the 16 scores of this lane are turned into base-2 logits and then into probabilities IN PLACE (acc[tn]); the mask
-            // of rescored false negatives is one bit per score
-            unsigned mbits = 0;
+            // the 16 scores of this lane are turned into probabilities IN PLACE (acc[tn]).  Rescored false negatives (one bit per
+            // score) and the rows past the end of Y are rare: both are handled under wave-uniform branches, the common tile pays
+            // 16 compares for them
+            bool hit = false;
+            if (HAS_IDS)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int jl = jl0 + (i >> 2) * 8 + (i & 3);
-                bool masked = false;
-                if (HAS_IDS) masked = (ids[jl] == x_id[tn]);
-                mbits |= (masked ? 1u : 0u) << i;
-                float v2 = (masked ? a.fns : acc[tn][i]) * scale2;
-                if (nvalid < PBN && jl >= nvalid) v2 = -INFINITY;  // only the last tile of Y can be partial
-                acc[tn][i] = v2;
-            }
+                for (int i = 0; i < 16; ++i) hit |= (ids[jl0 + (i >> 2) * 8 + (i & 3)] == x_id[tn]);
+            const bool any_masked = HAS_IDS && __any(hit);
+            unsigned mbits = 0;
+            if (any_masked)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool masked = ids[jl0 + (i >> 2) * 8 + (i & 3)] == x_id[tn];
+                    mbits |= (masked ? 1u : 0u) << i;
+                    acc[tn][i] = masked ? a.fns : acc[tn][i];
+                }
+            if (nvalid < PBN)  // only the last tile of Y can be partial
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tn][i] = (jl0 + (i >> 2) * 8 + (i & 3) >= nvalid) ? -INFINITY : acc[tn][i];
             if (MODE == PM_GRAD) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float l2 = LSE_STREAM ? lsej[jl0 + (i >> 2) * 8 + (i & 3)] * P_LOG2E : lse2_x[tn];
-                    const float e = __builtin_amdgcn_exp2f(acc[tn][i] - l2) * a.gscale;  // -inf on invalid rows -> 0
-                    acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
+                    acc[tn][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tn][i], scale2, -l2)) * a.gscale;  // -inf on invalid rows -> 0
                 }
-            } else {  // FWD / FWD_GRAD: lazy reference max shared by the two lanes of a row
+            } else {  // FWD / FWD_GRAD: lazy reference max shared by the two lanes of a row (scale2 > 0: the max commutes with it)
                 float tmax = acc[tn][0];
 #pragma unroll
                 for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, acc[tn][i]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale2;
                 if (__any(tmax > m_run[tn] + P_LAZY)) {
                     const float m_new = (tmax > m_run[tn] + P_LAZY) ? tmax : m_run[tn];
                     const float f = __builtin_amdgcn_exp2f(m_run[tn] - m_new);
@@ -330,12 +337,14 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                 float s_add = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float e = __builtin_amdgcn_exp2f(acc[tn][i] - m_run[tn]);
-                    s_add += e;  // rescored false negatives stay in the denominator
-                    acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : e;
+                    acc[tn][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tn][i], scale2, -m_run[tn]));
+                    s_add += acc[tn][i];  // rescored false negatives stay in the denominator
                 }
                 s_run[tn] += s_add;
             }
+            if (any_masked && MODE != PM_FWD)  // ... and out of the gradient
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tn][i] = ((mbits >> i) & 1u) ? 0.f : acc[tn][i];
         }
     };
     auto gemm2 = [&](const unsigned char* st, int u) {
@@ -364,14 +373,13 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                 bf16x8_t at[NIMG][EBG];
 #pragma unroll
                 for (int q = 0; q < EBG; ++q) {
-                    const int e = (eb0 + q) * 32 + l31, sw = (e >> 1) & (PBN / 8 - 1);
-                    const unsigned char* row_h = yt + e * (PBN * 2) + 8 * h;
+                    // row e of the transposed image, chunk 2 (2 u + s) + h: the lane's 8 rows of this k-step (see split_prepare_kernel)
+                    constexpr int CPE = PBN / 8;
+                    const int e = (eb0 + q) * 32 + l31, sw = (e / (16 / CPE)) & (CPE - 1);
+                    const unsigned char* frag_at = yt + e * (PBN * 2) + (((c0 + h) ^ sw) << 4);
 #pragma unroll
-                    for (int g = 0; g < NIMG; ++g) {
-                        const uint2 v0 = *reinterpret_cast<const uint2*>(row_h + g * P_ARR + ((c0 ^ sw) << 4));
-                        const uint2 v1 = *reinterpret_cast<const uint2*>(row_h + g * P_ARR + (((c0 + 1) ^ sw) << 4));
-                        at[g][q] = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                    }
+                    for (int g = 0; g < NIMG; ++g)
+                        at[g][q] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(frag_at + g * P_ARR));
                 }
                 if (NIMG == 2) {
 #pragma unroll

@@ -18,7 +18,9 @@ def one(src):
     deps = [src] + sorted(B.CSRC.glob("*.h"))
     if obj.exists() and obj.stat().st_mtime > max(p.stat().st_mtime for p in deps):
         return obj
-    r = subprocess.run([B._hipcc(), *B.FLAGS, "-DMH_LAB", "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+    import os
+    extra = os.environ.get("MH_LAB_FLAGS", "").split()  # e.g. MH_LAB_FLAGS=-fno-slp-vectorize (delete csrc/lab/*.o first)
+    r = subprocess.run([B._hipcc(), *B.FLAGS, *extra, "-DMH_LAB", "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
     if r.returncode:
         raise SystemExit(f"{src.name}:\n{r.stderr}")
     return obj
