@@ -563,6 +563,11 @@ int gemm_geo() {  // MERLIN_HIP_GEMM_SPLIT_GEO = 256x256 (default) | 256x128 | 1
 template <int EPI>
 int32_t launch_gemm(GsArgs a, int splits, hipStream_t s) {
     // six-term arithmetic (three images per operand): 256 x 128 tiles, two 72 KB stages, the k-loop with the mid-tile barrier
+#ifdef MH_LAB  // lab: 256 x 256 tiles with 16-wide k-tiles in a three-stage ring (3 x 48 KB) for the six-term arithmetic
+    if (split_images() == 3 && gemm_geo() == 3) return launch_gemm_geo<EPI, 256, 256, false, 16, 3, 3>(a, splits, s);
+    if (split_images() == 3 && gemm_geo() == 4) return launch_gemm_geo<EPI, 256, 256, true, 16, 3, 3>(a, splits, s);
+    if (split_images() == 3 && gemm_geo() == 0) return launch_gemm_geo<EPI, 256, 128, false, 32, 2, 3>(a, splits, s);
+#endif
     if (split_images() == 3) return launch_gemm_geo<EPI, 256, 128, true, 32, 2, 3>(a, splits, s);
     const int geo = gemm_geo();
     static int pipe = -1;  // MERLIN_HIP_GEMM_SPLIT_PIPE = 1 | 0: the k-loop with the barrier in the middle of a tile's MFMAs (see the kernel)

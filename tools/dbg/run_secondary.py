@@ -25,5 +25,6 @@ fns = {"embedding_bag": lambda: bench.run_embedding_bag(device, **kw),
        "topk_f32": lambda: bench.run_topk(args, device, steps=6, warmup=4, mode="f32"),
        "c4_one_gpu": lambda: bench.run_c4_one_gpu(args, device, tm, **kw),
        "dcn_train": lambda: bench.run_dcn(argparse.Namespace(**dict(vars(args), steps=6, warmup=2, batches=2)), device, tm),
+       "cross_gemm": lambda: bench.run_cross_gemm(device, **kw),
        "twotower": lambda: bench.run_twotower(args, device, tm, steps=20, warmup=3, sustain=0.0, **kw)}
 print(json.dumps(fns[name](), indent=None))

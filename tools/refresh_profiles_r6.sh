@@ -6,7 +6,7 @@ O=gpurun_out/refresh6; rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 MERLIN_HIP_SCORER_ARITH=bf16x3 MERLIN_HIP_GEMM_ARITH=bf16x3 timeout 1200 python -m pytest tests -m gpu -q \
   --deselect tests/test_gpu_bench_world2.py > $O/pytest_gpu_bf16x3.log 2>&1; tail -2 $O/pytest_gpu_bf16x3.log
-MERLIN_HIP_GEMM_ARITH=f32 timeout 600 python -m pytest tests/test_gpu_dense.py tests/test_gpu_backward.py tests/test_gpu_models.py tests/test_gpu_fullsize.py tests/test_gpu_fullsize_bwd.py -m gpu -q > $O/pytest_gpu_f32_chain.log 2>&1; tail -1 $O/pytest_gpu_f32_chain.log
+MERLIN_HIP_SCORER_ARITH=f32 MERLIN_HIP_GEMM_ARITH=f32 timeout 1200 python -m pytest tests -m gpu -q --deselect tests/test_gpu_bench_world2.py > $O/pytest_gpu_f32_chain.log 2>&1; tail -1 $O/pytest_gpu_f32_chain.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # HBM traffic of the HBM-bound launches FIRST, and into profiles/ on this box: the bench line below then carries roofline.traffic
 # measured with exactly the kernels it times (bench.py refuses a file stamped with other kernel sources)
@@ -30,7 +30,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o 
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/topk -o k -- python bench.py --workload topk --no-cpu-baseline --steps 3 --warmup 2 --sustain 0 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bag -o b -- python tools/microbench.py bagbwd > $O/bag_microbench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tower -o w -- python tools/microbench.py tower > $O/tower_microbench.log 2>&1
-for w in train topk bag tower; do cp $(find $O/$w -name '*kernel_stats.csv' | head -1) $O/bench_${w}_kernel_stats.csv; rm -rf $O/$w; done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/twotower -o w -- python bench.py --workload twotower --tt-batch 65536 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --sustain 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dcn -o w -- python bench.py --workload dcn --steps 4 --warmup 2 --batches 2 --no-cpu-baseline --no-secondary --sustain 0 > /dev/null 2>&1
+timeout 200 python tools/gpu_scorer_arith.py > $O/scorer_arith.log 2>&1; cat $O/scorer_arith.log
+for w in train topk bag tower twotower dcn; do cp $(find $O/$w -name '*kernel_stats.csv' | head -1) $O/bench_${w}_kernel_stats.csv; rm -rf $O/$w; done
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/embada -o t -- python tools/microbench.py embada > $O/embada.log 2>&1
 cp $(find $O/embada -name '*kernel_stats.csv' | head -1) $O/embada_kernel_stats.csv; rm -rf $O/embada
 ls $O
