@@ -236,10 +236,12 @@ class MultiOptimizer(optim.Optimizer):
                     grad, offsets = blk._pending
                     blk._pending, blk._pending_event = None, None
                     ops.SIDE.join()  # the gradient's producer: the per-optimizer launches below run on the launch stream
+                    first = True  # the block's batch-regularisation loss is the sum over its optimizer groups
                     for o in used.values():
                         mine = {n: off for n, off in offsets.items() if tabs[id(blk.feature_table[n].table)] is o}
                         if mine:
-                            blk._apply_sparse_now(o, grad, mine)
+                            blk._apply_sparse_now(o, grad, mine, reset_reg=first)
+                            first = False
                 elif hasattr(blk, "apply_sparse") and not isinstance(blk, EmbeddingsBlock):
                     blk.apply_sparse(self.default_optimizer)
             ops.run_tail()
@@ -342,8 +344,17 @@ class TopKMetricsAggregator:
         return cls(*ms)
 
     def update_state(self, y_true, y_pred, sample_weight=None, label_relevant_counts=None) -> None:
+        if sample_weight is not None:
+            raise NotImplementedError("sample_weight is outside the hot path")
+        groups: Dict[tuple, List[TopkMetric]] = {}
         for m in self.topk_metrics:
-            m.update_state(y_true, y_pred, sample_weight, label_relevant_counts)
+            groups.setdefault((m.k, m.pre_sorted), []).append(m)
+        for ms in groups.values():  # one extraction, one mh_topk_metrics launch and one host read per k
+            rows = ms[0]._rows(y_true, y_pred, label_relevant_counts)
+            sums = rows.sum(dim=0, dtype=torch.float64).tolist()
+            for m in ms:
+                m._sum += sums[m._column]
+                m._n += int(rows.shape[0])
 
     def result(self) -> Dict[str, float]:
         return {m.name: m.result() for m in self.topk_metrics}

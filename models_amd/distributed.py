@@ -1262,12 +1262,12 @@ class _ShardedEmbeddings:
         emb._last = {n: inputs[n] for n in names}
         emb._record_fwd_out(names, lambda n: buf[:, offsets[n]:offsets[n] + emb.feature_table[n].dim])
 
-    def apply_sparse_now(self, opt, grad, offsets) -> None:
+    def apply_sparse_now(self, opt, grad, offsets, reset_reg: bool = True) -> None:
         from . import ops
 
         emb = self.emb
         g2 = grad.reshape(grad.shape[0], -1)
-        emb._apply_batch_regularization(g2, offsets)
+        emb._apply_batch_regularization(g2, offsets, reset=reset_reg)
         B, stride = g2.shape
         present = [n for n in offsets if n in emb._last and emb.feature_table[n].table.trainable]
         for d, (grp, gnames) in self.groups.items():

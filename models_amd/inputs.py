@@ -308,20 +308,23 @@ class EmbeddingsBlock(ParallelBlock):
             return
         self._apply_sparse_now(opt, grad, offsets)
 
-    def _apply_batch_regularization(self, g2: torch.Tensor, offsets) -> None:
-        """d (factor * sum out^2) / d out = 2 factor out, added to the incoming gradient (embedding.py:463-464)."""
+    def _apply_batch_regularization(self, g2: torch.Tensor, offsets, reset: bool = True) -> None:
+        """d (factor * sum out^2) / d out = 2 factor out, added to the incoming gradient (embedding.py:463-464).  ``reset=False``: the
+        step's regularisation loss keeps accumulating (MultiOptimizer: one call per optimizer group over disjoint features)."""
         if not self.has_batch_regularization:
             return
         if getattr(self, "_reg_loss", None) is None:
             self._reg_loss = torch.zeros(1, dtype=torch.float32, device=g2.device)
-        self._reg_loss.zero_()
+            reset = False
+        if reset:
+            self._reg_loss.zero_()
         for n in offsets:
             ft = self.feature_table[n]
             if n in self._last and ft.l2_batch_regularization_factor > 0:
                 ops.l2_batch_reg(self._fwd_out[n], g2[:, offsets[n]:offsets[n] + ft.dim],
                                  ft.l2_batch_regularization_factor, self._reg_loss)
 
-    def _apply_sparse_now(self, opt, grad, offsets) -> None:
+    def _apply_sparse_now(self, opt, grad, offsets, reset_reg: bool = True) -> None:
         names = [n for n in offsets if n in self._last and self.feature_table[n].table.trainable]
         lists = [n for n in names if not self._is_onehot(self._last[n])]
         names = [n for n in names if n not in lists]
@@ -338,7 +341,7 @@ class EmbeddingsBlock(ParallelBlock):
             return None, None
 
         g2 = grad.reshape(grad.shape[0], -1)
-        self._apply_batch_regularization(g2, offsets)
+        self._apply_batch_regularization(g2, offsets, reset=reset_reg)
         # A table looked up through a list feature AND any other feature (item_id + item_id_history is the common case):
         # Keras sums the IndexedSlices of all lookups of a variable before ONE optimizer apply, so Adagrad / Adam must see
         # the summed row gradient once -- two fused launches would step the shared rows twice.  Those tables go through
