@@ -692,13 +692,17 @@ int32_t mh_cross_layer_bwd_split(const float* x0, const float* x, const float* p
 
 
 // ---- Dense layer  y = act(x W + b)  (blocks/mlp.py:275-280) in the same arithmetic ---------------------------------------------
+// dW slabs of the split-M form: at most 8 when the output has >= 32 tiles of 256 x 128 (the DCN-v2 3341 -> 512 layer: 56 tiles x 8
+// splits), up to 64 for small outputs over a long batch (512 x 256 at M = 65 536: 4 tiles -- 8 splits were 32 workgroups on 256 CUs)
+static int dw_split_cap(int K, int N) { return mh_ceil_div(K, 256) * mh_ceil_div(N, 128) >= 32 ? 8 : 64; }
+
 int64_t mh_linear_split_workspace_bytes(int64_t M, int32_t K, int32_t N) {
     if (M <= 0 || K <= 0 || N <= 0) return 0;
     const int64_t Kp = pad_to(K, 64), Np = pad_to(N, 64), Mp = pad_to(M, 64);
     // forward: x, W^T;  backward: dz, W (dX), x^T, dz^T, eight dW slabs, db partials (dW)
     const int64_t fwd = pair_bytes(M, Kp) + pair_bytes(N, Kp);
-    const int64_t bwd = pair_bytes(M, Np) + pair_bytes(K, Np) + pair_bytes(K, Mp) + pair_bytes(N, Mp) + al256(8 * (int64_t)K * N * 4) +
-                        al256(64 * (int64_t)N * 4);
+    const int64_t bwd = pair_bytes(M, Np) + pair_bytes(K, Np) + pair_bytes(K, Mp) + pair_bytes(N, Mp) +
+                        al256(dw_split_cap(K, N) * (int64_t)K * N * 4) + al256(64 * (int64_t)N * 4);
     return (fwd > bwd ? fwd : bwd) + 1024;
 }
 
@@ -748,7 +752,7 @@ int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W
     const int64_t Np = pad_to(N, 64), Mp = pad_to(M, 64);
     const SplitBuf sz = take_pair(wp, M, Np), sw = take_pair(wp, K, Np), sxt = take_pair(wp, K, Mp), szt = take_pair(wp, N, Mp);
     float* slabs = reinterpret_cast<float*>(wp);
-    wp += al256(8 * (int64_t)K * N * 4);
+    wp += al256(dw_split_cap(K, N) * (int64_t)K * N * 4);
     float* dbp = reinterpret_cast<float*>(wp);
     if (dx) {
         split_rows(dy, M, N, lddy, sz, s);
@@ -773,7 +777,7 @@ int32_t mh_linear_bias_act_bwd_split(const float* x, int64_t ldx, const float* W
         a.M = K; a.N = N; a.Kp = (int)Mp; a.lda = Mp; a.ldb = Mp;
         const int64_t otiles = mh_ceil_div(K, 256) * mh_ceil_div(N, (gemm_geo() >= 2 && split_images() == 2) ? 256 : 128);
         int splits = (int)mh_ceil_div(3 * (int64_t)mh_num_cus(), otiles);
-        if (splits > 8) splits = 8;
+        if (splits > dw_split_cap(K, N)) splits = dw_split_cap(K, N);
         if (splits > Mp / GBK / 32) splits = (int)(Mp / GBK / 32);
         if (splits < 1) splits = 1;
         a.C = splits > 1 ? slabs : dW; a.ldc = N; a.slab = (int64_t)K * N;

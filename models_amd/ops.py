@@ -546,9 +546,11 @@ def _tower_ok(M: int, K: int, N: int, x: torch.Tensor) -> bool:
 
 def _linear_split_ok(M: int, K: int, N: int) -> bool:
     """The wide Dense layers that run on the split-bf16 GEMM of mh_gemm_split.hip (six terms by default, three under
-    MERLIN_HIP_GEMM_ARITH=bf16x3, never under =f32): the output tiles of that kernel need N >= 256 to be filled (the DCN-v2 deep tower's
-    3341 -> 512 -> 256, the two-tower's 512 -> 256)."""
-    return gemm_arith() != "f32" and M >= 1024 and K >= 512 and N >= 256
+    MERLIN_HIP_GEMM_ARITH=bf16x3, never under =f32).  The operands are split (and, for dW, transposed) per call: M (K + N) elements of
+    preparation against M K N of saved MFMA time, so the layer has to be wide in BOTH directions -- K N / (K + N) >= 384 keeps the
+    DCN-v2 deep tower's 3341 -> 512 (forward 1.98 -> 1.81 ms, backward 4.34 -> 3.99 at batch 64 K) and sends 512 -> 256 (two-tower and
+    DCN-v2; backward 0.41 ms exact chain against 0.89 split, forward equal) to the exact-chain kernels."""
+    return gemm_arith() != "f32" and M >= 1024 and K >= 512 and N >= 256 and K * N >= 384 * (K + N)
 
 
 def linear(

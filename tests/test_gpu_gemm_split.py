@@ -60,8 +60,8 @@ def test_cross_layer_split_matches_fp32_and_float64(device, monkeypatch, M, d, a
 
 
 @pytest.mark.parametrize("arith", ["bf16x6", "bf16x3"])
-@pytest.mark.parametrize("M,K,N,act,x_act", [(1536, 3341, 512, "relu", None), (1100, 512, 256, "relu", "relu"), (2048, 600, 300, None, None),
-                                              (1024, 1000, 256, "sigmoid", "relu")])
+@pytest.mark.parametrize("M,K,N,act,x_act", [(1536, 3341, 512, "relu", None), (1100, 1024, 768, "relu", "relu"), (2048, 1200, 600, None, None),
+                                              (1024, 1000, 640, "sigmoid", "relu")])
 def test_dense_layer_split_matches_fp32_and_float64(device, monkeypatch, M, K, N, act, x_act, arith):
     """Wide Dense layers on the split-bf16 GEMM (mh_linear_bias_act_fwd_split / _bwd_split): y, dz, dx (with the
     producer's activation mask), dW, db against float64 and against the exact-fp32 kernels; ragged K (3341 = the DCN-v2 tower input)."""

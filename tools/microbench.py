@@ -195,3 +195,18 @@ if "tower" in which:  # the N = 128 tower layers: six-term split (default) again
             dyy = torch.randn(B, N, device=dev)
             timeit(f"linear bwd {K}x{N} [{mode or 'bf16x6 dX'}]", lambda: ops.linear_backward(xx, W, yy, dyy, "relu"), flops=4 * B * K * N, nbytes=4 * B * (2 * K + 2 * N))
         os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
+if "ttlin" in which:  # the TwoTower tower layers (512 -> 256 -> 128, 256 -> 256) at batch 64 K / 32 K under each GEMM arithmetic
+    import os
+
+    for M in (65536, 32768):
+        for (K, N) in [(512, 256), (256, 256), (256, 128)]:
+            xx = torch.randn(M, K, device=dev)
+            W = torch.randn(K, N, device=dev) * 0.1
+            bb = torch.zeros(N, device=dev)
+            dy = torch.randn(M, N, device=dev)
+            for mode in ("f32", "bf16x6", "bf16x3"):
+                os.environ["MERLIN_HIP_GEMM_ARITH"] = mode
+                y = ops.linear(xx, W, bb, "relu")
+                timeit(f"M={M} linear fwd {K}x{N} [{mode}]", lambda: ops.linear(xx, W, bb, "relu"), flops=2 * M * K * N)
+                timeit(f"M={M} linear bwd {K}x{N} [{mode}]", lambda: ops.linear_backward(xx, W, y, dy, "relu"), flops=4 * M * K * N)
+            os.environ.pop("MERLIN_HIP_GEMM_ARITH", None)
