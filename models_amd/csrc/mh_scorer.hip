@@ -348,7 +348,8 @@ MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, int nimg, h
 int mh_split_plan(int64_t Nx, int64_t Ny, int nimg, int* tiles_per_split);
 int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X, int64_t Nx, const MhSplitMatrix& Y, int64_t Ny,
                                const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
-                               float fns, float gscale, float* part_m, float* part_s, float* opart, hipStream_t s);
+                               float fns, float gscale, float* part_m, float* part_s, float* opart, const float* x_corr,
+                               const float* y_corr, int corr_after_mask, hipStream_t s);
 
 namespace {
 
@@ -421,10 +422,11 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
     return w;
 }
 
-// the split-bf16 kernels cover the plain in-batch case: E = 128, no logQ correction inside the kernel, 16-byte aligned rows (the partial
+// the split-bf16 kernels cover the in-batch case at E = 128 with 16-byte aligned rows (logQ corrections: six-term kernel only; the partial
 // buffers are sized for the larger of the two plans' split counts: stream_ws)
 bool split_ok(int64_t Nx, int64_t Ny, int E, const float* x_corr, const float* y_corr, const float* a, const float* b, int fp32_nsplit) {
-    if (g_scorer_arith == 0 || E != 128 || x_corr || y_corr || Ny < 64) return false;
+    if (g_scorer_arith == 0 || E != 128 || Ny < 64) return false;
+    if ((x_corr || y_corr) && g_scorer_arith != 2) return false;  // the logQ correction lives in the six-term kernel only
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return false;
     (void)Nx;
     (void)fp32_nsplit;
@@ -515,7 +517,7 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
         int tps = 0;
         const int ns = mh_split_plan(B, Nn, split_images(), &tps);
         const int32_t st = mh_stream_split_launch(SM_FWD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
-                                                  1.f, ws + w.part_m, ws + w.part_s, nullptr, s);
+                                                  1.f, ws + w.part_m, ws + w.part_s, nullptr, nullptr, neg_logq, logq_after_mask, s);
         if (st != MH_OK) return st;
         mh_stream_fwd_finalize(pos, B, ns, ws + w.part_m, ws + w.part_s, invT, nullptr, 0, loss, lse, s);
         MH_CHECK_LAUNCH("mh_inbatch_softmax_fwd");
@@ -583,7 +585,7 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
         int tps = 0;
         nsplit = mh_split_plan(B, Nn, split_images(), &tps);
         st = mh_stream_split_launch(SM_FWD_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
-                                    1.f, ws + w.part_m, ws + w.part_s, ws + w.opart_row, s);
+                                    1.f, ws + w.part_m, ws + w.part_s, ws + w.opart_row, nullptr, neg_logq, logq_after_mask, s);
     } else {
         st = mh_stream_launch(SM_FWD_GRAD, 0, plan, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT,
                               false_neg_score, 1.f, nullptr, 0, ws + w.part_m, ws + w.part_s, ws + w.opart_row, nullptr, neg_logq,
@@ -669,7 +671,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
             int tps = 0;
             ns = mh_split_plan(B, Nn, split_images(), &tps);
             st = mh_stream_split_launch(SM_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT, false_neg_score,
-                                        gscale, nullptr, nullptr, ws + w.opart_row, s);
+                                        gscale, nullptr, nullptr, ws + w.opart_row, nullptr, neg_logq, logq_after_mask, s);
         } else {
             st = mh_stream_launch(SM_GRAD, 0, pr, qx, B, nx, Nn, w.Ep, pos_ids, neg_ids, ids_dtype, lse, nullptr, invT,
                                   false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_row, nullptr, neg_logq, logq_after_mask, s);
@@ -691,7 +693,7 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
         int tps = 0;
         nsc = mh_split_plan(Nn, B, split_images(), &tps);
         st = mh_stream_split_launch(SM_GRAD, 1, sn, Nn, sq, B, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT, false_neg_score, gscale,
-                                    nullptr, nullptr, ws + w.opart_col, s);
+                                    nullptr, nullptr, ws + w.opart_col, neg_logq, nullptr, logq_after_mask, s);
     } else {
         st = mh_stream_launch(SM_GRAD, 1, pc, nx, Nn, qx, B, w.Ep, neg_ids, pos_ids, ids_dtype, lse, nullptr, invT,
                               false_neg_score, gscale, nullptr, 0, nullptr, nullptr, ws + w.opart_col, neg_logq, nullptr, logq_after_mask, s);

@@ -53,8 +53,8 @@ struct PG {
     static constexpr int ARR = BN * PE * 2;            // one image of either orientation: 16 KB / 8 KB
     static constexpr int STAGE = 2 * NIMG * ARR;       // row-major images, then the transposed ones: 64 KB / 48 KB
     static constexpr int NST = (NIMG == 3) ? 3 : 2;    // stages of the ring (three: the late wavefronts work one tile behind, see the kernel)
-    static constexpr int AUX = NST * STAGE;            // ids (NST x 512 B), lse (NST x 256 B) behind the stages
-    static constexpr int LDS = AUX + NST * 512 + NST * 256;
+    static constexpr int AUX = NST * STAGE;            // ids (NST x 512 B), lse (NST x 256 B), logQ corrections (NST x 256 B) behind the stages
+    static constexpr int LDS = AUX + NST * 512 + NST * 256 + NST * 256;
 };
 constexpr float P_LOG2E = 1.4426950408889634f;
 constexpr float P_NEG_BIG = -1.0e30f;
@@ -135,6 +135,10 @@ struct SplitArgs {
     const void *x_ids, *y_ids;
     const float* lse;   // GRAD: natural-log lse of the softmax rows (stationary side, or streamed side if LSE_STREAM)
     const float* pos;   // FWD_GRAD: positive scores [Nx]
+    // logQ sampling correction (outputs/contrastive.py:309-319, transforms/bias.py:238-254): score -= x_corr[x] + y_corr[j] (either may be
+    // NULL); corr_after_mask = 1 applies it AFTER the false-negative rescoring.  Six-term kernel only (HAS_CORR instantiations)
+    const float *x_corr, *y_corr;
+    int corr_after_mask;
     float invT, fns, gscale;
     float *part_m, *part_s, *opart;
     int tiles_per_split;
@@ -155,7 +159,7 @@ __device__ __forceinline__ f32x16 p_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { ret
 // the gradient mode: 5.49-5.51 ms against 5.48-5.54 for this loop -- with two wavefronts per SIMD the overlap is already there.
 // What did move the kernel: the probabilities are split into bf16 hi / lo by mh_split_pair (v_cvt_pk_bf16_f32: 5 instructions per
 // pair instead of ~30 of bit arithmetic): forward + dq 6.8 -> 5.6 ms, gradient pass 6.7 -> 5.5 ms at 65 536 x 65 536 x 128.
-template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT, int NIMG>
+template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT, int NIMG, bool HAS_CORR>
 __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitArgs a) {
     using G = PG<NIMG>;
     constexpr int PBN = G::BN, P_ARR = G::ARR, P_STAGE = G::STAGE, P_AUX = G::AUX, NST = G::NST;
@@ -207,6 +211,11 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
             if (w > a.Ny - 1) w = a.Ny - 1;
             p_dma4(a.lse + w, smem + P_AUX + NST * 512 + stage * 256);
         }
+        if (HAS_CORR && a.y_corr && wave == NW - 2) {
+            int64_t w = row0 + lane;
+            if (w > a.Ny - 1) w = a.Ny - 1;
+            p_dma4(a.y_corr + w, smem + P_AUX + NST * 768 + stage * 256);
+        }
     };
     if (t_beg < t_end) issue(t_beg, 0);
 
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     bf16x8_t xs[NIMG][XT][PKS];
     bool xvalid[XT];
     IdT x_id[XT];
-    float lse2_x[XT], m_run[XT], s_run[XT];
+    float lse2_x[XT], m_run[XT], s_run[XT], xc[XT];
 #pragma unroll
     for (int tn = 0; tn < XT; ++tn) {
         int64_t xrow = x0 + tn * 32 + l31;
@@ -227,6 +236,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                 xs[g][tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a.x[g] + xrow * PE + ks * 16 + h * 8));
         x_id[tn] = 0;
         if (HAS_IDS) x_id[tn] = static_cast<const IdT*>(a.x_ids)[xrow];
+        xc[tn] = (HAS_CORR && a.x_corr) ? a.x_corr[xrow] : 0.f;
         lse2_x[tn] = 0.f;
         if (MODE == PM_GRAD && !LSE_STREAM) lse2_x[tn] = a.lse[xrow] * P_LOG2E;
         m_run[tn] = (MODE != PM_GRAD) ? a.pos[xrow] * a.invT * P_LOG2E : P_NEG_BIG;  // the reference max starts at the positive logit
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[tn][i] += acc2[tn][i];
     };
-    auto epilogue = [&](int u, int nvalid, const IdT* ids, const float* lsej) {
+    auto epilogue = [&](int u, int nvalid, const IdT* ids, const float* lsej, const float* ycorr) {
         // ---- epilogue: lane = stationary row tn * 32 + l31, streamed rows jl(i) = u * 32 + (i >> 2) * 8 + 4 h + (i & 3) ----------
         const int jl0 = u * 32 + 4 * h;
 #pragma unroll
@@ -301,6 +311,9 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hit |= (ids[jl0 + (i >> 2) * 8 + (i & 3)] == x_id[tn]);
             const bool any_masked = HAS_IDS && __any(hit);
+            if (HAS_CORR && !a.corr_after_mask)  // logQ correction of the scores that are NOT rescored
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tn][i] -= xc[tn] + (a.y_corr ? ycorr[jl0 + (i >> 2) * 8 + (i & 3)] : 0.f);
             unsigned mbits = 0;
             if (any_masked)
 #pragma unroll
@@ -309,6 +322,9 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                     mbits |= (masked ? 1u : 0u) << i;
                     acc[tn][i] = masked ? a.fns : acc[tn][i];
                 }
+            if (HAS_CORR && a.corr_after_mask)  // the `post` form: the rescored entries are corrected too
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[tn][i] -= xc[tn] + (a.y_corr ? ycorr[jl0 + (i >> 2) * 8 + (i & 3)] : 0.f);
             if (nvalid < PBN)  // only the last tile of Y can be partial
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[tn][i] = (jl0 + (i >> 2) * 8 + (i & 3) >= nvalid) ? -INFINITY : acc[tn][i];
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     };
     auto tile_ids = [&](int stage) { return reinterpret_cast<const IdT*>(smem + P_AUX + stage * 512); };
     auto tile_lse = [&](int stage) { return reinterpret_cast<const float*>(smem + P_AUX + NST * 512 + stage * 256); };
+    auto tile_corr = [&](int stage) { return reinterpret_cast<const float*>(smem + P_AUX + NST * 768 + stage * 256); };
 
     __syncthreads();  // vmcnt(0) + barrier: tile t_beg has landed for every wavefront
 
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
             for (int u = 0; u < PBN / 32; ++u) {
                 if (u * 32 >= nvalid) break;
                 gemm1(st, u);
-                epilogue(u, nvalid, tile_ids(odd), tile_lse(odd));
+                epilogue(u, nvalid, tile_ids(odd), tile_lse(odd), tile_corr(odd));
                 gemm2(st, u);
             }
             __syncthreads();  // every wavefront is done with this tile; the next one (vmcnt(0)) has landed
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
                 if (!MH_SKIP(64)) __syncthreads();
                 if (t + 2 < t_end && !MH_SKIP(32)) issue(t + 2, s_prev);
             }
-            if (!MH_SKIP(8)) epilogue(0, tile_rows(t), tile_ids(s_cur), tile_lse(s_cur));
+            if (!MH_SKIP(8)) epilogue(0, tile_rows(t), tile_ids(s_cur), tile_lse(s_cur), tile_corr(s_cur));
             if (!MH_SKIP(16)) gemm2(st, 0);
             if (!late) {
                 if (!MH_SKIP(64)) __syncthreads();
@@ -489,11 +506,11 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     }
 }
 
-template <int MODE, bool LSE_STREAM, int XT, int NIMG>
+template <int MODE, bool LSE_STREAM, int XT, int NIMG, bool HAS_CORR = false>
 int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStream_t s) {
 #define MH_LAUNCH_SPLIT(IdT, HAS)                                                                                          \
     do {                                                                                                                   \
-        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT, NIMG>;                                             \
+        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT, NIMG, HAS_CORR>;                                             \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
@@ -568,8 +585,10 @@ int mh_split_plan(int64_t Nx, int64_t Ny, int nimg, int* tiles_per_split) {
 // as mh_stream_launch
 int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X, int64_t Nx, const MhSplitMatrix& Y, int64_t Ny,
                                const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
-                               float fns, float gscale, float* part_m, float* part_s, float* opart, hipStream_t s) {
+                               float fns, float gscale, float* part_m, float* part_s, float* opart, const float* x_corr,
+                               const float* y_corr, int corr_after_mask, hipStream_t s) {
     SplitArgs a;
+    a.x_corr = x_corr; a.y_corr = y_corr; a.corr_after_mask = corr_after_mask;
     const int nimg = X.nimg;
     for (int g = 0; g < 3; ++g) {
         a.x[g] = X.img[g < nimg ? g : nimg - 1];
@@ -594,11 +613,23 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
         const char* e = MH_LAB_ENV("MERLIN_HIP_SCORER_XT");
         xt = (e && atoi(e) == 2) ? 2 : 1;
     }
-    if (nimg == 3 && xt == 2) {
+#ifdef MH_LAB  // measured: 20.5 ms per pass against 9.7 (560-720 bytes of scratch)
+    if (nimg == 3 && xt == 2 && !x_corr && !y_corr) {
         if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 2, 3>(a, ids_dtype, grid, s);
         if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2, 3>(a, ids_dtype, grid, s);
         if (lse_stream) return launch_split_mode<PM_GRAD, true, 2, 3>(a, ids_dtype, grid, s);
         return launch_split_mode<PM_GRAD, false, 2, 3>(a, ids_dtype, grid, s);
+    }
+#endif
+    if (nimg == 3 && (x_corr || y_corr)) {  // logQ-corrected scores: the six-term kernel only
+        if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3, true>(a, ids_dtype, grid, s);
+        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 3, true>(a, ids_dtype, grid, s);
+        if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 3, true>(a, ids_dtype, grid, s);
+        return launch_split_mode<PM_GRAD, false, 1, 3, true>(a, ids_dtype, grid, s);
+    }
+    if (x_corr || y_corr) {
+        mh_set_error("scorer (bf16x3): the logQ correction is not implemented in the three-term kernel");
+        return MH_ERR_UNSUPPORTED;
     }
     if (nimg == 3) {
         if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3>(a, ids_dtype, grid, s);

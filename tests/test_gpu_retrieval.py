@@ -189,10 +189,11 @@ def test_scorer_logq_golden_vectors(device):
 
 
 @pytest.mark.parametrize("after_mask", [False, True])
-@pytest.mark.parametrize("B,Nn,E", [(300, 450, 64), (129, 129, 128), (70, 33, 24), (64, 200, 160)])
+@pytest.mark.parametrize("B,Nn,E", [(300, 450, 64), (129, 129, 128), (70, 33, 24), (64, 200, 160), (600, 1000, 128), (700, 97, 128)])
 def test_scorer_logq_forward_backward(device, B, Nn, E, after_mask):
     """Forward (materialised and fused), the fused forward+dq pass and both backward passes with the logQ terms,
-    against the oracle and fp64 autograd of the corrected logits (E = 160 takes the tiled E > 128 kernels)."""
+    against the oracle and fp64 autograd of the corrected logits (E = 160 takes the tiled E > 128 kernels; at E = 128 the passes
+    without logits run the six-term split kernel by default, whose epilogue applies the corrections in either order)."""
     rng = np.random.default_rng(B + Nn + E)
     T = 0.7
     q, it, ng = (rng.normal(size=s).astype(np.float32) * 0.4 for s in ((B, E), (B, E), (Nn, E)))
@@ -228,6 +229,9 @@ def test_scorer_logq_forward_backward(device, B, Nn, E, after_mask):
     np.testing.assert_allclose(dq.cpu().numpy(), qt.grad.numpy(), **tol)
     np.testing.assert_allclose(ditem.cpu().numpy(), itt.grad.numpy(), **tol)
     np.testing.assert_allclose(dneg.cpu().numpy(), ngt.grad.numpy(), **tol)
+    rf = ops.inbatch_softmax(*args, materialize=False, **lkw)  # loss / lse without logits
+    np.testing.assert_allclose(rf.loss.cpu().numpy(), loss, atol=ATOL, rtol=1e-4)
+    np.testing.assert_allclose(rf.lse.cpu().numpy(), lse, atol=ATOL, rtol=1e-5)
     fused = ops.inbatch_softmax_train(*args, **lkw)
     if E <= 128:
         r2, dq2, ditem2 = fused

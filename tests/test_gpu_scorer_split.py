@@ -76,3 +76,49 @@ def test_split_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, N
         np.testing.assert_allclose(sp[4], dneg, atol=2e-6, rtol=2e-4)
         np.testing.assert_allclose(sp[8], loss, atol=1e-4, rtol=1e-5)
         np.testing.assert_allclose(sp[9], lse, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("after_mask", [False, True])
+def test_six_term_scorer_applies_the_logq_corrections(device, monkeypatch, after_mask):
+    """logQ sampling correction (outputs/contrastive.py:309-319) inside the six-term kernel, before or after the false-negative
+    rescoring: against float64 never further than 4 x the exact-fp32 kernels (the corrected logits reach +-150: an ulp of a logit is
+    1.5e-5 there, for either kernel) -- and not the same bits as those kernels (the split kernel really ran)."""
+    rng = np.random.default_rng(7)
+    B, Nn, E, T, fns = 640, 1000, 128, 0.05, -655.04
+    unit = lambda a: (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    q, it, neg = unit(rng.normal(size=(B, E))), unit(rng.normal(size=(B, E))), unit(rng.normal(size=(Nn, E)))
+    pid, nid = rng.integers(0, 300, size=B).astype(np.int32), rng.integers(0, 300, size=Nn).astype(np.int32)
+    plq = np.log(rng.random(B) * 0.3 + 1e-3).astype(np.float32)
+    nlq = np.log(rng.random(Nn) * 0.3 + 1e-3).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    args = (t(q), t(it), t(neg), t(pid), t(nid), T, fns)
+    kw = dict(pos_logq=t(plq), neg_logq=t(nlq), logq_after_mask=after_mask)
+
+    # float64 statement of the corrected logits and the gradients of the mean loss
+    q64, i64, n64 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (q, it, neg))
+    lp, ln = torch.tensor(plq, dtype=torch.float64), torch.tensor(nlq, dtype=torch.float64)
+    sc = q64 @ n64.T
+    mask = torch.tensor(pid.reshape(-1, 1) == nid.reshape(1, -1))
+    sc = (torch.where(mask, torch.full_like(sc, fns), sc) - ln[None, :]) if after_mask else torch.where(mask, torch.full_like(sc, fns), sc - ln[None, :])
+    z = torch.cat([(q64 * i64).sum(1, keepdim=True) - lp[:, None], sc], 1) / T
+    lse64 = torch.logsumexp(z, 1)
+    (lse64 - z[:, 0]).mean().backward()
+    want = [(lse64 - z[:, 0]).detach().numpy(), lse64.detach().numpy(), q64.grad.numpy(), i64.grad.numpy(), n64.grad.numpy(), lse64.detach().numpy()]
+
+    def run():
+        res, dq, ditem = ops.inbatch_softmax_train(*args, **kw)
+        _, _, dneg = ops.inbatch_softmax_backward(args[0], args[1], args[2], res.lse, args[3], args[4], T, fns, need_dq=False, **kw)
+        fw = ops.inbatch_softmax(*args, materialize=False, **kw)
+        return [x.cpu().numpy() for x in (res.loss, res.lse, dq, ditem, dneg, fw.lse)]
+
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
+    f32 = run()
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "bf16x6")
+    sp = run()
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
+    assert any(not np.array_equal(a, b) for a, b in zip(f32, sp)), "the six-term kernel did not take the logQ-corrected passes"
+    for n, a, b, w in zip(("loss", "lse", "dq", "ditem", "dneg", "lse(fwd)"), f32, sp, want):
+        e_sp, e_f32 = np.abs(b - w).max(), np.abs(a - w).max()
+        floor = 2.0 ** -23 * max(np.abs(w).max(), 1e-30)
+        assert e_sp <= 4 * e_f32 + floor, (n, e_sp, e_f32)
+        np.testing.assert_allclose(b, w, atol=1e-4 if n.startswith(("loss", "lse")) else 1e-6, rtol=1e-3, err_msg=n)
