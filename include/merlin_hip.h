@@ -168,7 +168,8 @@ int32_t mh_embedding_dense_list_fwd(const float* table, int64_t rows, const void
 /* Deterministic mode of the fused sparse update (process-wide; initial value from MERLIN_HIP_DETERMINISTIC=1 at load time):
  * crossing runs are walked in sample order instead of summed with float atomics -- bit-reproducible, slower on very hot rows. */
 int32_t mh_set_deterministic(int32_t on);
-/* Arithmetic of the in-batch scorer (mh_inbatch_softmax_fwd without logits, _fwd_dq, _bwd) at E = 128 (mh_scorer_split.hip):
+/* Arithmetic of the in-batch scorer (mh_inbatch_softmax_fwd without logits, _fwd_dq, _bwd) at E = 128, mode 2 also at E = 64 and with the
+ * logQ corrections (mh_scorer_split.hip):
  *   0 (the library's initial value) exact fp32 MFMA, every score one k-ascending fmaf chain;
  *   1 "bf16x3": every fp32 operand split into two bf16 values, every product of both GEMMs of a pass formed as hi hi + hi lo + lo hi
  *     on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (error of a dot product <= ~2.3e-6 |q| |item| measured; 16 / 3 of the fp32

@@ -341,10 +341,10 @@ void mh_stream_unpad_rows(const float* src, int64_t N, int E, int Ep, float* dst
 struct MhSplitMatrix {
     uint16_t *img[3], *imgT[3];
     int64_t ldT;
-    int nimg;
+    int nimg, E;
 };
-int64_t mh_split_matrix_bytes(int64_t N);
-MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, int nimg, hipStream_t s);
+int64_t mh_split_matrix_bytes(int64_t N, int E);
+MhSplitMatrix mh_split_prepare(const float* x, int64_t N, int E, void* buf, int nimg, hipStream_t s);
 int mh_split_plan(int64_t Nx, int64_t Ny, int nimg, int* tiles_per_split);
 int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X, int64_t Nx, const MhSplitMatrix& Y, int64_t Ny,
                                const void* x_ids, const void* y_ids, int ids_dtype, const float* lse, const float* pos, float invT,
@@ -396,13 +396,13 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         // pass 0 may run the tiled forward, which writes one partial per 256-candidate tile
         int64_t ns = w.row.nsplit;
         if (pass == 0 && mh_scorer_tiled_nsplit(Nn) > ns) ns = mh_scorer_tiled_nsplit(Nn);
-        if (E == 128 && split_plan_max(B, Nn) > ns) ns = split_plan_max(B, Nn);
+        if ((E == 128 || E == 64) && split_plan_max(B, Nn) > ns) ns = split_plan_max(B, Nn);
         w.part_m = take(ns * B);
         w.part_s = take(ns * B);
     }
     // partials: the largest of the fp32 plan's and the split-bf16 plans' split counts (64- / 32-row tiles: more splits on small shapes)
     int ns_row = w.row.nsplit, ns_col = w.col.nsplit;
-    if (E == 128 && pass != 0) {
+    if ((E == 128 || E == 64) && pass != 0) {
         if (split_plan_max(B, Nn) > ns_row) ns_row = split_plan_max(B, Nn);
         if (split_plan_max(Nn, B) > ns_col) ns_col = split_plan_max(Nn, B);
     }
@@ -414,19 +414,19 @@ StreamWs stream_ws(int pass, int64_t B, int64_t Nn, int E, int ids_bytes) {
         if (pass == 1) w.outp_col = take(Nn * w.Ep);
     }
     w.split_q = w.split_n = 0;
-    if (E == 128) {  // the bf16 images of q and of the negatives, both orientations (sized for three images: bf16x6)
-        w.split_q = take(mh_split_matrix_bytes(B) / 4);
-        w.split_n = take(mh_split_matrix_bytes(Nn) / 4);
+    if (E == 128 || E == 64) {  // the bf16 images of q and of the negatives, both orientations (sized for three images: bf16x6)
+        w.split_q = take(mh_split_matrix_bytes(B, E) / 4);
+        w.split_n = take(mh_split_matrix_bytes(Nn, E) / 4);
     }
     w.total = o;
     return w;
 }
 
-// the split-bf16 kernels cover the in-batch case at E = 128 with 16-byte aligned rows (logQ corrections: six-term kernel only; the partial
+// the split-bf16 kernels cover the in-batch case at E = 128 (six-term: also E = 64) with 16-byte aligned rows (logQ: six-term only; the partial
 // buffers are sized for the larger of the two plans' split counts: stream_ws)
 bool split_ok(int64_t Nx, int64_t Ny, int E, const float* x_corr, const float* y_corr, const float* a, const float* b, int fp32_nsplit) {
-    if (g_scorer_arith == 0 || E != 128 || Ny < 64) return false;
-    if ((x_corr || y_corr) && g_scorer_arith != 2) return false;  // the logQ correction lives in the six-term kernel only
+    if (g_scorer_arith == 0 || (E != 128 && E != 64) || Ny < 64) return false;
+    if ((x_corr || y_corr || E == 64) && g_scorer_arith != 2) return false;  // the logQ correction and E = 64: six-term kernel only
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return false;
     (void)Nx;
     (void)fp32_nsplit;
@@ -512,8 +512,8 @@ int32_t mh_inbatch_softmax_fwd(const float* q, const float* item, const float* n
         }
     }
     if (!logits && split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {  // split-bf16 arithmetic, loss / lse only
-        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, split_images(), s);
-        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, split_images(), s);
+        const MhSplitMatrix sq = mh_split_prepare(q, B, E, ws + w.split_q, split_images(), s);
+        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, E, ws + w.split_n, split_images(), s);
         int tps = 0;
         const int ns = mh_split_plan(B, Nn, split_images(), &tps);
         const int32_t st = mh_stream_split_launch(SM_FWD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
@@ -580,8 +580,8 @@ int32_t mh_inbatch_softmax_fwd_dq(const float* q, const float* item, const float
     int32_t st;
     int nsplit = plan.nsplit;
     if (split_ok(B, Nn, E, nullptr, neg_logq, q, neg_item, plan.nsplit)) {
-        const MhSplitMatrix sq = mh_split_prepare(q, B, ws + w.split_q, split_images(), s);
-        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, split_images(), s);
+        const MhSplitMatrix sq = mh_split_prepare(q, B, E, ws + w.split_q, split_images(), s);
+        const MhSplitMatrix sn = mh_split_prepare(neg_item, Nn, E, ws + w.split_n, split_images(), s);
         int tps = 0;
         nsplit = mh_split_plan(B, Nn, split_images(), &tps);
         st = mh_stream_split_launch(SM_FWD_GRAD, 0, sq, B, sn, Nn, pos_ids, neg_ids, ids_dtype, nullptr, pos, invT, false_neg_score,
@@ -661,8 +661,8 @@ int32_t mh_inbatch_softmax_bwd(const float* q, const float* item, const float* n
                            split_ok(Nn, B, E, neg_logq, nullptr, q, neg_item, w.col.nsplit) && B >= 64;
     MhSplitMatrix sq{}, sn{};
     if (use_split) {
-        sq = mh_split_prepare(q, B, ws + w.split_q, split_images(), s);
-        sn = mh_split_prepare(neg_item, Nn, ws + w.split_n, split_images(), s);
+        sq = mh_split_prepare(q, B, E, ws + w.split_q, split_images(), s);
+        sn = mh_split_prepare(neg_item, Nn, E, ws + w.split_n, split_images(), s);
     }
     if (dq) {
         const MhStreamPlan& pr = w.row;

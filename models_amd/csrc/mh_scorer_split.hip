@@ -43,14 +43,13 @@ namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int PE = 128;            // embedding width (the whole K of GEMM 1)
-constexpr int PKS = PE / 16;       // k-steps of GEMM 1
+// The embedding width EW (the whole K of GEMM 1) is a template parameter: 128 (both arithmetics) or 64 (six-term kernel only)
 constexpr int PXB = 256;           // stationary rows per workgroup
 // Geometry by the number of bf16 images per matrix: 2 (bf16x3) -> 64 streamed rows per tile, 3 (bf16x6) -> 32
-template <int NIMG>
+template <int NIMG, int EW = 128>
 struct PG {
     static constexpr int BN = (NIMG == 3) ? 32 : 64;  // streamed rows per tile (units of 32 rows)
-    static constexpr int ARR = BN * PE * 2;            // one image of either orientation: 16 KB / 8 KB
+    static constexpr int ARR = BN * EW * 2;            // one image of either orientation: 16 KB / 8 KB (EW = 128)
     static constexpr int STAGE = 2 * NIMG * ARR;       // row-major images, then the transposed ones: 64 KB / 48 KB
     static constexpr int NST = (NIMG == 3) ? 3 : 2;    // stages of the ring (three: the late wavefronts work one tile behind, see the kernel)
     static constexpr int AUX = NST * STAGE;            // ids (NST x 512 B), lse (NST x 256 B), logQ corrections (NST x 256 B) behind the stages
@@ -73,21 +72,21 @@ __device__ __forceinline__ float p_f32(uint16_t h) { return __uint_as_float((uin
 // x[N, 128] fp32 -> hi, lo [N, 128] (bf16 bit patterns) and hiT, loT [128, ldT] (ldT = N rounded up to 64; the columns past N
 // are written as zeros).  One workgroup per 64 rows; the transpose goes through LDS.  THREE: also the middle piece (mid, midT) and
 // lo = the third piece of mh_split3_pair (bf16x6).
-template <bool THREE>
+template <bool THREE, int EW>
 __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restrict__ x, int64_t N, uint16_t* __restrict__ hi,
                                                            uint16_t* __restrict__ mid, uint16_t* __restrict__ lo,
                                                            uint16_t* __restrict__ hiT, uint16_t* __restrict__ midT,
                                                            uint16_t* __restrict__ loT, int64_t ldT) {
     constexpr int NI = THREE ? 3 : 2;
-    __shared__ uint16_t sp[NI][64][PE + 2];
+    __shared__ uint16_t sp[NI][64][EW + 2];
     uint16_t* const img[3] = {hi, THREE ? mid : lo, lo};
     uint16_t* const imgT[3] = {hiT, THREE ? midT : loT, loT};
     const int64_t r0 = (int64_t)blockIdx.x * 64;
-    for (int i = threadIdx.x; i < 64 * (PE / 4); i += 256) {
-        const int r = i / (PE / 4), c4 = i % (PE / 4);
+    for (int i = threadIdx.x; i < 64 * (EW / 4); i += 256) {
+        const int r = i / (EW / 4), c4 = i % (EW / 4);
         const int64_t row = r0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < N) v = *reinterpret_cast<const f32x4*>(x + row * PE + c4 * 4);
+        if (row < N) v = *reinterpret_cast<const f32x4*>(x + row * EW + c4 * 4);
         uint32_t w[NI][2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -101,28 +100,29 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
                 sp[a][r][c4 * 4 + 2 * k] = (uint16_t)w[a][k];
                 sp[a][r][c4 * 4 + 2 * k + 1] = (uint16_t)(w[a][k] >> 16);
             }
-            if (row < N) *reinterpret_cast<uint2*>(img[a] + row * PE + c4 * 4) = make_uint2(w[a][0], w[a][1]);
+            if (row < N) *reinterpret_cast<uint2*>(img[a] + row * EW + c4 * 4) = make_uint2(w[a][0], w[a][1]);
         }
     }
     __syncthreads();
     if (!hiT) return;
-    // thread (e, half): 32 consecutive rows of column e -> 64 contiguous bytes of the transposed arrays.  Inside every group of 16
+    // thread (e, part): RP consecutive rows of column e -> 2 RP contiguous bytes of the transposed arrays.  Inside every group of 16
     // rows the order is 0-3, 8-11, 4-7, 12-15 (bits 2 and 3 of the row swapped): the 8 rows a lane of GEMM 2 needs for one k-step --
     // streamed rows 8 (i >> 2) + 4 h + (i & 3) of the group, the order in which it holds its probabilities -- are then 16
     // CONTIGUOUS bytes (one ds_read_b128 = the MFMA operand, no register moves)
-    const int e = threadIdx.x & (PE - 1), half = threadIdx.x >> 7;
+    constexpr int NPART = 256 / EW, RP = 64 / NPART;  // EW = 128: two parts of 32 rows; 64: four parts of 16
+    const int e = threadIdx.x & (EW - 1), part = threadIdx.x / EW;
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < RP / 8; ++g) {
             uint32_t wv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int j = 2 * k;  // stored position g * 8 + j of the half <- row (g >> 1) * 16 + 8 (j >> 2) + 4 (g & 1) + (j & 3)
-                const int r = half * 32 + (g >> 1) * 16 + 8 * (j >> 2) + 4 * (g & 1) + (j & 3);
+                const int j = 2 * k;  // stored position g * 8 + j of the part <- row (g >> 1) * 16 + 8 (j >> 2) + 4 (g & 1) + (j & 3)
+                const int r = part * RP + (g >> 1) * 16 + 8 * (j >> 2) + 4 * (g & 1) + (j & 3);
                 wv[k] = (uint32_t)sp[a][r][e] | ((uint32_t)sp[a][r + 1][e] << 16);
             }
-            const int64_t col = r0 + half * 32 + g * 8;
+            const int64_t col = r0 + part * RP + g * 8;
             *reinterpret_cast<uint4*>(imgT[a] + (int64_t)e * ldT + col) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
         }
 }
@@ -159,9 +159,14 @@ __device__ __forceinline__ f32x16 p_mfma(bf16x8_t a, bf16x8_t b, f32x16 c) { ret
 // the gradient mode: 5.49-5.51 ms against 5.48-5.54 for this loop -- with two wavefronts per SIMD the overlap is already there.
 // What did move the kernel: the probabilities are split into bf16 hi / lo by mh_split_pair (v_cvt_pk_bf16_f32: 5 instructions per
 // pair instead of ~30 of bit arithmetic): forward + dq 6.8 -> 5.6 ms, gradient pass 6.7 -> 5.5 ms at 65 536 x 65 536 x 128.
-template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT, int NIMG, bool HAS_CORR>
+template <int MODE, typename IdT, bool HAS_IDS, bool LSE_STREAM, int XT, int NIMG, bool HAS_CORR, int EW>
 __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitArgs a) {
-    using G = PG<NIMG>;
+    using G = PG<NIMG, EW>;
+    constexpr int PKS = EW / 16;   // k-steps of GEMM 1
+    constexpr int CR = EW / 8;     // 16-byte chunks per row of the row-major images
+    // chunk swizzle of row r of the row-major images (the b128 fragment reads of GEMM 1 are conflict-free): 256-byte rows r mod 16,
+    // 128-byte rows (r / 2) mod 8
+    auto swzr = [](int r) { return EW == 128 ? (r & 15) : ((r >> 1) & 7); };
     constexpr int PBN = G::BN, P_ARR = G::ARR, P_STAGE = G::STAGE, P_AUX = G::AUX, NST = G::NST;
     constexpr bool ROT = (NIMG == 3);  // rotated schedule of the second wavefront of every SIMD (below)
     static_assert(!ROT || PBN == 32, "the rotated schedule is written for one 32-row unit per tile");
@@ -177,25 +182,28 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     const int t_beg = split * a.tiles_per_split;
     const int t_end = (t_beg + a.tiles_per_split < nt_all) ? t_beg + a.tiles_per_split : nt_all;
 
-    // one tile: NIMG arrays x PBN * 16 chunks of 16 bytes per orientation; chunk position L of an array <- a swizzled source chunk
-    constexpr int CPA = PBN * 16;            // chunks per array (both orientations)
+    // one tile: NIMG arrays x PBN * CR chunks of 16 bytes per orientation; chunk position L of an array <- a swizzled source chunk
+    constexpr int CPA = PBN * CR;            // chunks per array (both orientations)
     constexpr int WI = NIMG * CPA / 64;      // wave instructions per orientation
+    constexpr int WJ = (WI + NW - 1) / NW;   // ... per wavefront (the last round may be partial: wave-uniform guard)
     auto issue = [&](int t, int stage) {
         unsigned char* st = smem + stage * P_STAGE;
         const int64_t row0 = (int64_t)t * PBN;
 #pragma unroll
-        for (int j = 0; j < WI / NW; ++j) {  // row-major image: position (r, p) holds chunk p ^ (r & 15) of row r (rows clamped)
+        for (int j = 0; j < WJ; ++j) {  // row-major image: position (r, p) holds chunk p ^ swzr(r) of row r (rows clamped)
             const int wi = j * NW + wave;
-            const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, r = Lp >> 4, p = Lp & 15, c = p ^ (r & 15);
+            if (WI % NW != 0 && wi >= WI) break;
+            const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, r = Lp / CR, p = Lp % CR, c = p ^ swzr(r);
             int64_t row = row0 + r;
             if (row > a.Ny - 1) row = a.Ny - 1;
-            p_dma16(a.y[arr] + row * PE + c * 8, st + wi * 1024);
+            p_dma16(a.y[arr] + row * EW + c * 8, st + wi * 1024);
         }
         if (MODE != PM_FWD)
 #pragma unroll
-        for (int j = 0; j < WI / NW; ++j) {  // transposed image: position (e, p) holds chunk p ^ swz(e) of row e (8 rows of Y each)
+        for (int j = 0; j < WJ; ++j) {  // transposed image: position (e, p) holds chunk p ^ swz(e) of row e (8 rows of Y each)
             constexpr int CPE = PBN / 8;  // chunks per row e; swz(e) = (e / (16 / CPE)) mod CPE: the b128 reads of GEMM 2 are conflict-free
             const int wi = j * NW + wave;
+            if (WI % NW != 0 && wi >= WI) break;
             const int arr = wi / (CPA / 64), Lp = (wi % (CPA / 64)) * 64 + lane, e = Lp / CPE, p = Lp % CPE,
                       c = p ^ ((e / (16 / CPE)) & (CPE - 1));
             p_dma16(a.yt[arr] + (int64_t)e * a.ldT + row0 + c * 8, st + NIMG * P_ARR + wi * 1024);
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         for (int g = 0; g < NIMG; ++g)
 #pragma unroll
             for (int ks = 0; ks < PKS; ++ks)
-                xs[g][tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a.x[g] + xrow * PE + ks * 16 + h * 8));
+                xs[g][tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a.x[g] + xrow * EW + ks * 16 + h * 8));
         x_id[tn] = 0;
         if (HAS_IDS) x_id[tn] = static_cast<const IdT*>(a.x_ids)[xrow];
         xc[tn] = (HAS_CORR && a.x_corr) ? a.x_corr[xrow] : 0.f;
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         s_run[tn] = 0.f;
     }
     const float scale2 = a.invT * P_LOG2E;
-    constexpr int OB = (MODE == PM_FWD) ? 1 : 4;  // forward-only: no output accumulators (one dummy block keeps the code uniform)
+    constexpr int OB = (MODE == PM_FWD) ? 1 : EW / 32;  // forward-only: no output accumulators (one dummy block keeps the code uniform)
     f32x16 o[OB][XT];  // O^T: block eb of 32 columns e x block tn of 32 stationary rows; lane: row x = l31, e = (i & 3) + 8 (i >> 2) + 4 h
 #pragma unroll
     for (int eb = 0; eb < OB; ++eb)
@@ -259,9 +267,9 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         // ---- GEMM 1 on the unit's 32 streamed rows, software-pipelined over the 8 k-steps ---------------------------------
         f32x16 acc2[XT];  // the second chain of the six-term form (unused otherwise)
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // C of a chain's first MFMA
-        const int rd = (u * 32 + l31) * 256;
+        const int rd = (u * 32 + l31) * (EW * 2);
         auto frag = [&](int ks, int arr) {
-            const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
+            const int pos = ((2 * ks + h) ^ swzr(l31)) * 16;
             return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + arr * P_ARR + rd + pos));
         };
         bf16x8_t af[NIMG];
@@ -491,11 +499,11 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         }
     }
     if (MODE == PM_FWD) return;
-    float* op = a.opart + (int64_t)split * a.Nx * PE;
+    float* op = a.opart + (int64_t)split * a.Nx * EW;
 #pragma unroll
     for (int tn = 0; tn < XT; ++tn) {
         if (!xvalid[tn]) continue;
-        float* orow = op + (x0 + tn * 32 + l31) * PE;
+        float* orow = op + (x0 + tn * 32 + l31) * EW;
 #pragma unroll
         for (int eb = 0; eb < OB; ++eb)
 #pragma unroll
@@ -506,21 +514,22 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
     }
 }
 
-template <int MODE, bool LSE_STREAM, int XT, int NIMG, bool HAS_CORR = false>
+template <int MODE, bool LSE_STREAM, int XT, int NIMG, bool HAS_CORR = false, int EW = 128>
 int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStream_t s) {
+    constexpr int LDS_BYTES = PG<NIMG, EW>::LDS;
 #define MH_LAUNCH_SPLIT(IdT, HAS)                                                                                          \
     do {                                                                                                                   \
-        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT, NIMG, HAS_CORR>;                                             \
+        auto kern = stream_split_kernel<MODE, IdT, HAS, LSE_STREAM, XT, NIMG, HAS_CORR, EW>;                               \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                                    PG<NIMG>::LDS) != hipSuccess) {                                                        \
+                                    LDS_BYTES) != hipSuccess) {                                                            \
                 mh_set_error("scorer (split bf16): cannot raise the dynamic LDS limit");                                   \
                 return MH_ERR_LAUNCH;                                                                                      \
             }                                                                                                              \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
-        MH_LAUNCH(kern, grid, dim3(512 / XT), (size_t)PG<NIMG>::LDS, s, a);                                                \
+        MH_LAUNCH(kern, grid, dim3(512 / XT), (size_t)LDS_BYTES, s, a);                                                    \
     } while (0)
     if (!a.x_ids) MH_LAUNCH_SPLIT(int32_t, false);
     else if (ids_dtype == MH_I32) MH_LAUNCH_SPLIT(int32_t, true);
@@ -529,42 +538,60 @@ int32_t launch_split_mode(const SplitArgs& a, int ids_dtype, dim3 grid, hipStrea
     return MH_OK;
 }
 
+// the six-term kernel by mode, with or without the logQ corrections, at embedding width EW
+template <int EW>
+int32_t launch_six_term(int mode, int lse_stream, bool corr, const SplitArgs& a, int ids_dtype, dim3 grid, hipStream_t s) {
+    if (corr) {
+        if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3, true, EW>(a, ids_dtype, grid, s);
+        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 3, true, EW>(a, ids_dtype, grid, s);
+        if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 3, true, EW>(a, ids_dtype, grid, s);
+        return launch_split_mode<PM_GRAD, false, 1, 3, true, EW>(a, ids_dtype, grid, s);
+    }
+    if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3, false, EW>(a, ids_dtype, grid, s);
+    if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 3, false, EW>(a, ids_dtype, grid, s);
+    if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 3, false, EW>(a, ids_dtype, grid, s);
+    return launch_split_mode<PM_GRAD, false, 1, 3, false, EW>(a, ids_dtype, grid, s);
+}
+
 }  // namespace
 
 // ---- internal interface used by mh_scorer.hip ------------------------------------------------------------------------------------
-// Bytes of the split of ONE [N, 128] matrix: three images [N, 128] and three transposed ones [128, ldT] (all bf16; the three-term
-// arithmetic uses two of each), 256-byte aligned parts.
-int64_t mh_split_matrix_bytes(int64_t N) {
+// Bytes of the split of ONE [N, E] matrix (E = 64 or 128): three images [N, E] and three transposed ones [E, ldT] (all bf16; the
+// three-term arithmetic uses two of each), 256-byte aligned parts.
+int64_t mh_split_matrix_bytes(int64_t N, int E) {
     const int64_t ldT = (N + 63) / 64 * 64;
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-    return 3 * al(N * PE * 2) + 3 * al(PE * ldT * 2);
+    return 3 * al(N * E * 2) + 3 * al(E * ldT * 2);
 }
 
 struct MhSplitMatrix {
     uint16_t *img[3], *imgT[3];  // hi, (mid,) lo -- img[nimg - 1] is the last piece
     int64_t ldT;
-    int nimg;
+    int nimg, E;
 };
 
-MhSplitMatrix mh_split_prepare(const float* x, int64_t N, void* buf, int nimg, hipStream_t s) {
+MhSplitMatrix mh_split_prepare(const float* x, int64_t N, int E, void* buf, int nimg, hipStream_t s) {
     MhSplitMatrix m;
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
     char* p = static_cast<char*>(buf);
     m.ldT = (N + 63) / 64 * 64;
     m.nimg = nimg;
+    m.E = E;
     for (int g = 0; g < 3; ++g) {
         m.img[g] = reinterpret_cast<uint16_t*>(p);
-        p += al(N * PE * 2);
+        p += al(N * E * 2);
     }
     for (int g = 0; g < 3; ++g) {
         m.imgT[g] = reinterpret_cast<uint16_t*>(p);
-        p += al(PE * m.ldT * 2);
+        p += al(E * m.ldT * 2);
     }
     const dim3 grid((unsigned)mh_ceil_div(N, 64));
-    if (nimg == 3)
-        MH_LAUNCH(split_prepare_kernel<true>, grid, dim3(256), 0, s, x, N, m.img[0], m.img[1], m.img[2], m.imgT[0], m.imgT[1], m.imgT[2], m.ldT);
+    if (nimg == 3 && E == 64)
+        MH_LAUNCH((split_prepare_kernel<true, 64>), grid, dim3(256), 0, s, x, N, m.img[0], m.img[1], m.img[2], m.imgT[0], m.imgT[1], m.imgT[2], m.ldT);
+    else if (nimg == 3)
+        MH_LAUNCH((split_prepare_kernel<true, 128>), grid, dim3(256), 0, s, x, N, m.img[0], m.img[1], m.img[2], m.imgT[0], m.imgT[1], m.imgT[2], m.ldT);
     else
-        MH_LAUNCH(split_prepare_kernel<false>, grid, dim3(256), 0, s, x, N, m.img[0], (uint16_t*)nullptr, m.img[1], m.imgT[0],
+        MH_LAUNCH((split_prepare_kernel<false, 128>), grid, dim3(256), 0, s, x, N, m.img[0], (uint16_t*)nullptr, m.img[1], m.imgT[0],
                   (uint16_t*)nullptr, m.imgT[1], m.ldT);
     return m;
 }
@@ -608,34 +635,27 @@ int32_t mh_stream_split_launch(int mode, int lse_stream, const MhSplitMatrix& X,
     a.lab = lab;
 
     dim3 grid((unsigned)mh_ceil_div(Nx, PXB), (unsigned)nsplit);
+    const bool corr = x_corr || y_corr;
+    if ((corr || X.E != 128) && nimg != 3) {
+        mh_set_error("scorer (bf16x3): the logQ correction and E = 64 exist in the six-term kernel only");
+        return MH_ERR_UNSUPPORTED;
+    }
     static int xt = -1;  // MERLIN_HIP_SCORER_XT = 1 | 2 (lab builds): 32-row blocks of X per wavefront (see the kernel)
     if (xt < 0) {
         const char* e = MH_LAB_ENV("MERLIN_HIP_SCORER_XT");
         xt = (e && atoi(e) == 2) ? 2 : 1;
     }
 #ifdef MH_LAB  // measured: 20.5 ms per pass against 9.7 (560-720 bytes of scratch)
-    if (nimg == 3 && xt == 2 && !x_corr && !y_corr) {
+    if (nimg == 3 && xt == 2 && !corr && X.E == 128) {
         if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 2, 3>(a, ids_dtype, grid, s);
         if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 2, 3>(a, ids_dtype, grid, s);
         if (lse_stream) return launch_split_mode<PM_GRAD, true, 2, 3>(a, ids_dtype, grid, s);
         return launch_split_mode<PM_GRAD, false, 2, 3>(a, ids_dtype, grid, s);
     }
 #endif
-    if (nimg == 3 && (x_corr || y_corr)) {  // logQ-corrected scores: the six-term kernel only
-        if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3, true>(a, ids_dtype, grid, s);
-        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 3, true>(a, ids_dtype, grid, s);
-        if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 3, true>(a, ids_dtype, grid, s);
-        return launch_split_mode<PM_GRAD, false, 1, 3, true>(a, ids_dtype, grid, s);
-    }
-    if (x_corr || y_corr) {
-        mh_set_error("scorer (bf16x3): the logQ correction is not implemented in the three-term kernel");
-        return MH_ERR_UNSUPPORTED;
-    }
     if (nimg == 3) {
-        if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 3>(a, ids_dtype, grid, s);
-        if (mode == PM_FWD_GRAD) return launch_split_mode<PM_FWD_GRAD, false, 1, 3>(a, ids_dtype, grid, s);
-        if (lse_stream) return launch_split_mode<PM_GRAD, true, 1, 3>(a, ids_dtype, grid, s);
-        return launch_split_mode<PM_GRAD, false, 1, 3>(a, ids_dtype, grid, s);
+        if (X.E == 64) return launch_six_term<64>(mode, lse_stream, corr, a, ids_dtype, grid, s);
+        return launch_six_term<128>(mode, lse_stream, corr, a, ids_dtype, grid, s);
     }
     if (mode == PM_FWD) return launch_split_mode<PM_FWD, false, 1, 2>(a, ids_dtype, grid, s);
     if (xt == 2) {

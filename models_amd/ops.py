@@ -1448,7 +1448,7 @@ _SCORER_MODES = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
 def scorer_arith() -> str:
-    """Arithmetic of the in-batch scorer's products at E = 128 (``MERLIN_HIP_SCORER_ARITH``): "bf16x6" (default) -- the fp32-grade
+    """Arithmetic of the in-batch scorer's products at E = 128 and E = 64 (``MERLIN_HIP_SCORER_ARITH``; bf16x3: 128 only): "bf16x6" (default) -- the fp32-grade
     six-term split on the bf16 MFMA (every product from h h + h m + m h + h l + l h + m m, dropped terms <= 2^-25 of it); "f32" -- the
     exact fp32 MFMA chains; "bf16x3" -- the opt-in three-term split (2^-17 per operand, NOT fp32-grade, own dtype label)."""
     v = os.environ.get("MERLIN_HIP_SCORER_ARITH", "bf16x6")

@@ -65,10 +65,10 @@ def test_inbatch_scorer_matches_oracle(device, B, E, temperature, idt):
                              materialize=False)
     assert r2.logits is None
     # one kernel family behind both modes: bit for bit -- unless the opt-in tiled forward kernel (another summation order) is on, or the
-    # logits-free E = 128 forward runs the (fp32-grade) six-term split while the materialised logits come from the exact chains: a few
+    # logits-free E = 128 / 64 forward runs the (fp32-grade) six-term split while the materialised logits come from the exact chains: a few
     # ulps of the lse's scale then
     tiled = os.environ.get("MERLIN_HIP_SCORER_FWD") == "tiled"
-    if E == 128 and ops.scorer_arith() != "f32":
+    if (E == 128 and ops.scorer_arith() != "f32") or (E == 64 and ops.scorer_arith() == "bf16x6"):
         torch.testing.assert_close(r2.loss, r.loss, atol=2e-5, rtol=4e-6)
     else:
         torch.testing.assert_close(r2.loss, r.loss, atol=2e-6 if tiled else 0, rtol=1e-6 if tiled else 0)

@@ -28,11 +28,15 @@ def _ref64(q, it, neg, pid, nid, T, fns):
 
 
 @pytest.mark.parametrize("arith", ["bf16x6", "bf16x3"])
-@pytest.mark.parametrize("B,Nn,ids,idt", [(512, 512, True, np.int32), (300, 300, True, np.int64), (256, 1000, False, None),
-                                          (700, 97, True, np.int64), (333, 65, True, np.int32), (4096, 4096, True, np.int32)])
-def test_split_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, Nn, ids, idt, arith):
-    rng = np.random.default_rng(B + Nn)
-    E, T, fns = 128, 0.05, -655.04
+@pytest.mark.parametrize("B,Nn,ids,idt,E", [(512, 512, True, np.int32, 128), (300, 300, True, np.int64, 128), (256, 1000, False, None, 128),
+                                            (700, 97, True, np.int64, 128), (333, 65, True, np.int32, 128), (4096, 4096, True, np.int32, 128),
+                                            (512, 512, True, np.int32, 64), (300, 1000, True, np.int64, 64), (700, 97, False, None, 64),
+                                            (4096, 4096, True, np.int32, 64)])
+def test_split_scorer_matches_fp32_kernels_and_float64(device, monkeypatch, B, Nn, ids, idt, E, arith):
+    if E == 64 and arith == "bf16x3":
+        pytest.skip("E = 64 exists in the six-term kernel only (bf16x3 calls run the exact chains there)")
+    rng = np.random.default_rng(B + Nn + E)
+    T, fns = 0.05, -655.04
     unit = lambda a: (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
     q, it = unit(rng.normal(size=(B, E))), unit(rng.normal(size=(B, E)))
     neg = it if Nn == B else unit(rng.normal(size=(Nn, E)))

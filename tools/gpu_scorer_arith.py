@@ -1,5 +1,5 @@
 """Scorer passes at B x B x 128 under the three arithmetics (f32 chains, bf16x6, bf16x3): time per pass and distance to float64.
-Usage (GPU box): python tools/gpu_scorer_arith.py [B=65536]"""
+Usage (GPU box): python tools/gpu_scorer_arith.py [B=65536] [E=128|64] [modes=f32,bf16x6,bf16x3]"""
 import os
 import sys
 import time
@@ -10,12 +10,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from models_amd import ops  # noqa: E402
 
-B = 65536
+B, E_ARG = 65536, 128
 for a in sys.argv[1:]:
     if a.startswith("B="):
         B = int(a[2:])
+    if a.startswith("E="):
+        E_ARG = int(a[2:])
 dev = torch.device("cuda:0")
-E, T = 128, 0.05
+E, T = E_ARG, 0.05
 g = torch.Generator().manual_seed(5)
 unit = lambda x: x / x.norm(dim=1, keepdim=True)
 q, it = unit(torch.randn(B, E, generator=g)).to(dev), unit(torch.randn(B, E, generator=g)).to(dev)
@@ -67,5 +69,5 @@ for mode in (MODES[0] if MODES else ("f32", "bf16x6", "bf16x3")):
     e_dq = float((dq.double().cpu() - dq64).abs().max() * n)
     e_di = float(((ditem + dneg).double().cpu() - di64).abs().max() * n)
     fl = 2.0 * B * B * E
-    print(f"{mode:7s} B={B}: fwd+dq {t1:7.3f} ms ({2 * fl / t1 / 1e9:7.1f} TF fp32-eq)  column pass {t2:7.3f} ms  fwd only {t3:7.3f} ms   "
+    print(f"{mode:7s} B={B} E={E}: fwd+dq {t1:7.3f} ms ({2 * fl / t1 / 1e9:7.1f} TF fp32-eq)  column pass {t2:7.3f} ms  fwd only {t3:7.3f} ms   "
           f"n={n}: |lse-f64| {e_lse:.2e}  |dq-f64|*n {e_dq:.2e}  |ditem-f64|*n {e_di:.2e}", flush=True)
