@@ -1892,6 +1892,18 @@ def main():
         secondary("scorer_fwd", scorer_fwd)  # the default arithmetic (bf16x6 unless MERLIN_HIP_SCORER_ARITH says otherwise)
         secondary("scorer_fwd_f32_chain", lambda: with_scorer_arith("f32", scorer_fwd))
         secondary("scorer_fwd_bf16x3", lambda: with_scorer_arith("bf16x3", scorer_fwd))
+
+        def scorer_e64():
+            # the tower width of the reference's retrieval examples (MLPBlock([128, 64])): the six-term kernel at E = 64 against the exact chains
+            r = run_scorer_fwd(device, E=64)
+            f = with_scorer_arith("f32", lambda: run_scorer_fwd(device, E=64))
+            return {"shape": r["shape"], "ms": r["ms"], "ms_f32_chain": f["ms"], "fp32_equivalent_tflops": r["tflops"],
+                    "frac_of_bf16_peak": 6 * r["tflops"] / MFMA_BF16_PEAK_TF, "dtype": SCORER_DTYPE["bf16x6"].split(";")[0]}
+
+        from models_amd import ops as _ops_e64
+
+        if _ops_e64.scorer_arith() == "bf16x6":
+            secondary("scorer_fwd_e64", scorer_e64)
         def with_gemm_arith(mode, fn):
             prev = os.environ.get("MERLIN_HIP_GEMM_ARITH")
             os.environ["MERLIN_HIP_GEMM_ARITH"] = mode
