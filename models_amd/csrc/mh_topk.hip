@@ -542,7 +542,7 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
     const uint16_t* __restrict__ chi, const uint16_t* __restrict__ clo, const uint16_t* __restrict__ qhi,
     const uint16_t* __restrict__ qlo, int64_t c_beg, int64_t c_end, int Bq, const float* __restrict__ tau, int* __restrict__ cnt,
     float* __restrict__ cs, int32_t* __restrict__ ci, int segcap, int* __restrict__ dirty, int nqb, int nsplit,
-    int tiles_per_split, int xcd_map) {
+    int tiles_per_split, int xcd_map, const float* __restrict__ qn2, const unsigned* __restrict__ cmax2_bits) {
     // Survivors go to a segment PRIVATE to this workgroup: list[(row nsplit + split) segcap ..], its fill count kept in LDS (one
     // counter per query of the workgroup) and written out once at the end.  No global atomic: the first version reserved slots with
     // atomicAdd on a per-row counter -- a returning device-scope atomic is ~2 us of latency in the middle of the MFMA loop, and the
@@ -574,14 +574,20 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
 
     // query fragments (B operand: lane = column l31, k = 16 ks + 8 h .. + 7); rows past Bq repeat the last query (masked below)
     bf16x8_t qh[2][SX_KS], ql[2][SX_KS];
-    float thr[2];
+    float thr[2], thr_hi[2];
     int qrow[2];
+    const float cmax2 = __uint_as_float(*cmax2_bits);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         const int qi = qb * SX_QB + wave * SX_QW + tn * 32 + l31;
         const int qc = qi < Bq ? qi : Bq - 1;
         qrow[tn] = qi < Bq ? qi : -1;
         thr[tn] = qi < Bq ? tau[qi] : INFINITY;
+        // Coarse test on the hi hi term alone: the two small terms of a score are bounded by
+        //   sum_e |cl_e qh_e| + |ch_e ql_e| <= 2 * 2^-9 (1 + 2^-8)^2 sum_e |c_e q_e| <= 2^-8 (1 + 2^-6) |c| |q|
+        // (|x - bf16(x)| <= 2^-9 |x|, Cauchy-Schwarz), so a candidate whose hi hi product is below thr - 1.05 * 2^-8 |q| max|c|
+        // cannot reach thr with them (1.05 also covers the fp32 additions of the 16 small MFMAs).
+        thr_hi[tn] = thr[tn] - 1.05f * (1.0f / 256.0f) * sqrtf(qn2[qc] * cmax2);
 #pragma unroll
         for (int ks = 0; ks < SX_KS; ++ks) {
             qh[tn][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qhi + (int64_t)qc * SX_E + ks * 16 + h * 8));
@@ -620,47 +626,52 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
         else sx_wait_vm_and_barrier<0>();
         if (t + SX_STAGES - 1 < T) issue(t + SX_STAGES - 1);
         const unsigned char* st = sx_smem + (t % SX_STAGES) * SX_TILE;
-        f32x16 acc[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
-        // Software-pipelined over the 8 k-steps: the A fragments (hi, lo) of step ks + 1 are read from LDS BEFORE the six MFMAs of
-        // step ks are issued (192 cycles of matrix work cover the ~128-cycle LDS round trip).  Left to itself the compiler used one
-        // register quad for every fragment -- ds_read, s_waitcnt lgkmcnt(0), 2-4 MFMAs, 16 times per tile: every LDS round trip
-        // exposed, hidden only by the second wavefront of the SIMD (rocprof: 0.43 of the bf16 peak).
+        // Two levels.  (1) The hi hi term of all 32 x 64 scores of the wavefront's tile: 16 MFMAs, a third of the three-term product.
+        // (2) Only for a 32-query block in which SOME lane holds a score that the two small terms could still lift to its threshold
+        // (thr_hi above; wave-uniform test) the remaining 16 MFMAs of that block run on top of the same accumulators -- the scores of a
+        // skipped block are all below their thresholds whatever the small terms are, so it has no survivors either way, and a block that
+        // is not skipped gets exactly the three-term scores: the survivor lists, the proof and the result are those of the full product.
+        // Survivors are ~k' / n_seen of the scores: in the late stages (most of the catalogue) most blocks are skipped.
         auto lds_frag = [&](int ks, int arr) {
             const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
             return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + arr * SX_ARR + rd + pos));
         };
-        bf16x8_t ah = lds_frag(0, 0), al = lds_frag(0, 1);
+        bf16x8_t ah[SX_KS];
+#pragma unroll
+        for (int ks = 0; ks < SX_KS; ++ks) ah[ks] = lds_frag(ks, 0);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc[2];
 #pragma unroll
         for (int ks = 0; ks < SX_KS; ++ks) {
-            bf16x8_t nh = ah, nl = al;
-            if (ks + 1 < SX_KS) {
-                nh = lds_frag(ks + 1, 0);
-                nl = lds_frag(ks + 1, 1);
-            }
-            // small terms first
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[0][ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[1][ks], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[0][ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[1][ks], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[0][ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[1][ks], acc[1], 0, 0, 0);
-            ah = nh;
-            al = nl;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], qh[0][ks], ks ? acc[0] : zero, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], qh[1][ks], ks ? acc[1] : zero, 0, 0, 0);
         }
-        // the schedule of the unrolled tile, in order: fragments of step 0; then for every step the two LDS reads of the NEXT step
-        // ahead of the six MFMAs of this one
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        bool live[2];
 #pragma unroll
-        for (int ks = 0; ks + 1 < SX_KS; ++ks) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        for (int tn = 0; tn < 2; ++tn) {
+            float mx = __builtin_fmaxf(acc[tn][0], acc[tn][1]);
+#pragma unroll
+            for (int i = 2; i < 16; ++i) mx = __builtin_fmaxf(mx, acc[tn][i]);
+            live[tn] = __any(mx >= thr_hi[tn]);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        if (live[0] || live[1]) {
+#pragma unroll
+            for (int ks = 0; ks < SX_KS; ++ks) {
+                const bf16x8_t al = lds_frag(ks, 1);
+                if (live[0]) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[0][ks], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], ql[0][ks], acc[0], 0, 0, 0);
+                }
+                if (live[1]) {
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[1][ks], acc[1], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], ql[1][ks], acc[1], 0, 0, 0);
+                }
+            }
+        }
         const int cb = t * SX_CT + h * 4;  // candidate of accumulator entry i, relative to c0: cb + (i >> 2) * 8 + (i & 3)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
+            if (!live[tn]) continue;  // (wave-uniform) the block was rejected by its hi hi products
             // common case first: the largest of the 16 scores against the threshold (v_max3: 8 instructions), the mask only behind it
             float mx = __builtin_fmaxf(acc[tn][0], acc[tn][1]);
 #pragma unroll
@@ -1207,7 +1218,7 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
         const int segcap = p.f.cap / nsplit;  // the row's survivor capacity divided among the splits' private segments
         MH_LAUNCH(topk_filter_bf16x3_kernel, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
                   (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, segcnt, cs, ci, segcap, dirty, nqb,
-                  nsplit, tps, xcd_map);
+                  nsplit, tps, xcd_map, (const float*)qn, reinterpret_cast<const unsigned*>(cand_norm2_max));
         // the stage's merge as a sort (a workgroup per row); rows holding more than SORT_MAX entries go through the insertion list
         MH_LAUNCH(topk_sort_merge_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, (const float*)cs, (const int32_t*)ci, (const int*)segcnt, segcap,
                   nsplit, Bq, kp, ls, li, tau, cnt, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, 0);
