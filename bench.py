@@ -669,7 +669,7 @@ def run_topk(args, device, steps, warmup, mode="split"):
         res["fp32_equivalent_tflops"] = eq_tf
         res["roofline"] = {"kernel": "topk_filter_bf16x3_kernel (mh_topk.hip) + select / merge / exact finalize", "bound": "mfma",
                            "achieved": 3 * eq_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3 * eq_tf / MFMA_BF16_PEAK_TF,
-                           "traffic": None, "note": "3 bf16 MFMAs per fp32-equivalent product; whole call (bootstrap, merges, finalize included)"}
+                           "traffic": None, "note": "nominal work of the three-term product (3 bf16 MFMAs per fp32-equivalent one) over the whole call (bootstrap, merges, finalize included); the two-level filter issues the two small terms only for blocks with a score near its threshold, so the MFMAs really issued are fewer"}
     else:
         res["dtype"] = "f32"
         res["roofline"] = {"kernel": "top-k score GEMM + selection (mh_topk.hip)", "bound": "mfma", "achieved": eq_tf,
