@@ -112,22 +112,48 @@ __global__ __launch_bounds__(256) void gs_split_rows_kernel(const float* __restr
 }
 
 // x [R, C] (ld) -> hiT, loT [C, Rp] bf16 (the transpose), columns R .. Rp - 1 zero (Rp % 64 == 0).  64 x 64 tiles through LDS.
+// The output packs two consecutive ROWS of x into one 32-bit word, so a thread loads the same four columns of rows 2 rp and 2 rp + 1
+// (two float4), splits the four (row, row + 1) pairs -- one mh_split*_pair each, the packed word of every image falls out -- and stores
+// them as one ds_write_b128 per image; the transposing side reads eight words per image.  (First version: one element per thread and
+// pass, 16-bit LDS cells: 48 ds_write_b16 + 48 ds_read_u16 per thread, half of every pair split wasted: 2.8 TB/s.)
 __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __restrict__ x, int64_t R, int C, int64_t ld, int64_t Rp,
                                                                 uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT, int pack,
                                                                 uint16_t* __restrict__ midT = nullptr) {
-    __shared__ uint16_t sh[64][66], sl[64][66], sm[64][66];
+    __shared__ __attribute__((aligned(16))) uint32_t sw[3][32][68];  // [image][row pair][column]; 272-byte rows keep the b128 stores aligned
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        float v = 0.f;
-        if (r0 + r < R && c0 + c < C) v = x[(r0 + r) * ld + c0 + c];
-        uint32_t wh2, wl2, wm2 = 0;
-        if (midT) mh_split3_pair(v, 0.f, wh2, wm2, wl2);
-        else mh_split_pair(v, 0.f, wh2, wl2);
-        sh[r][c] = (uint16_t)wh2;
-        sl[r][c] = (uint16_t)wl2;
-        sm[r][c] = (uint16_t)wm2;
+    const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const int c4 = threadIdx.x & 15, cc = c0 + 4 * c4;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int rp = (threadIdx.x >> 4) + 16 * it;
+        const int64_t ra = r0 + 2 * rp, rb = ra + 1;
+        float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec_ok && cc + 3 < C) {
+            if (ra < R) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(x + ra * ld + cc);
+                va[0] = t[0]; va[1] = t[1]; va[2] = t[2]; va[3] = t[3];
+            }
+            if (rb < R) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(x + rb * ld + cc);
+                vb[0] = t[0]; vb[1] = t[1]; vb[2] = t[2]; vb[3] = t[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ra < R && cc + j < C) va[j] = x[ra * ld + cc + j];
+                if (rb < R && cc + j < C) vb[j] = x[rb * ld + cc + j];
+            }
+        }
+        uint32_t wh[4], wm[4] = {0u, 0u, 0u, 0u}, wl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (midT) mh_split3_pair(va[j], vb[j], wh[j], wm[j], wl[j]);
+            else mh_split_pair(va[j], vb[j], wh[j], wl[j]);
+        }
+        *reinterpret_cast<uint4*>(&sw[0][rp][4 * c4]) = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+        *reinterpret_cast<uint4*>(&sw[1][rp][4 * c4]) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+        if (midT) *reinterpret_cast<uint4*>(&sw[2][rp][4 * c4]) = make_uint4(wm[0], wm[1], wm[2], wm[3]);
     }
     __syncthreads();
     // thread (c, seg): rows seg * 16 .. + 15 of column c -> 32 contiguous bytes of row c0 + c of the transposed arrays
@@ -136,10 +162,9 @@ __global__ __launch_bounds__(256) void gs_split_transpose_kernel(const float* __
     uint32_t wh[8], wl[8], wm[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int r = seg * 16 + 2 * k;
-        wh[k] = (uint32_t)sh[r][c] | ((uint32_t)sh[r + 1][c] << 16);
-        wl[k] = (uint32_t)sl[r][c] | ((uint32_t)sl[r + 1][c] << 16);
-        wm[k] = (uint32_t)sm[r][c] | ((uint32_t)sm[r + 1][c] << 16);
+        wh[k] = sw[0][seg * 8 + k][c];
+        wl[k] = sw[1][seg * 8 + k][c];
+        wm[k] = midT ? sw[2][seg * 8 + k][c] : 0u;
     }
     // packed: element (row c0 + c, k = r0 + seg 16 ...) of the [C, Rp] result lives at ((k / 32) C + row) 32 + k % 32
     const int64_t off = pack ? (((r0 >> 5) + (seg >> 1)) * (int64_t)C + c0 + c) * 32 + (seg & 1) * 16 : (int64_t)(c0 + c) * Rp + r0 + seg * 16;
