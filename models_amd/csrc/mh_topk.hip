@@ -489,8 +489,15 @@ __global__ __launch_bounds__(256) void topk_redo_rows_kernel(const float* __rest
 // 16 query blocks of one split run on ONE XCD at the same time, so a candidate tile enters that XCD's L2 once and is read 16 times.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int SX_E = 128, SX_KS = SX_E / 16, SX_NWV = 4, SX_QW = 64, SX_QB = SX_QW * SX_NWV, SX_CT = 32, SX_STAGES = 4;
-constexpr int SX_ARR = SX_CT * SX_E * 2, SX_TILE = 2 * SX_ARR, SX_DMA = SX_TILE / (SX_NWV * 64 * 16);
+constexpr int SX_NWV = 4, SX_QW = 64, SX_QB = SX_QW * SX_NWV, SX_CT = 32, SX_STAGES = 4;
+// geometry of the filter kernel by the embedding width EW (128 or 64): k-steps, bytes of one image of a tile, of a tile (hi + lo), 16-byte
+// DMA chunks per thread and tile
+template <int EW>
+struct SXG {
+    static constexpr int KS = EW / 16, CR = EW / 8, ARR = SX_CT * EW * 2, TILE = 2 * ARR, DMA = TILE / (SX_NWV * 64 * 16);
+    // chunk swizzle of row r of a tile image (conflict-free b128 fragment reads): 256-byte rows r mod 16, 128-byte rows (r / 2) mod 8
+    static __device__ __forceinline__ int swz(int r) { return EW == 128 ? (r & 15) : ((r >> 1) & 7); }
+};
 constexpr int SX_MAX_SPLITS = 256;
 constexpr float SX_MREL = 1.0f / 8192.0f;  // 2^-13: margin = SX_MREL |q| max|c|
 
@@ -538,6 +545,7 @@ __device__ __forceinline__ void sx_wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+template <int EW>
 __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
     const uint16_t* __restrict__ chi, const uint16_t* __restrict__ clo, const uint16_t* __restrict__ qhi,
     const uint16_t* __restrict__ qlo, int64_t c_beg, int64_t c_end, int Bq, const float* __restrict__ tau, int* __restrict__ cnt,
@@ -548,6 +556,7 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
     // atomicAdd on a per-row counter -- a returning device-scope atomic is ~2 us of latency in the middle of the MFMA loop, and the
     // s_waitcnt it forces also drains the candidate DMA ring (first stage: ~16 survivors per wavefront and tile, 645 us for 6 % of
     // the catalogue).  A lane reserves the slots of ALL its survivors of a tile with ONE ds_add_rtn.
+    constexpr int SX_E = EW, SX_KS = SXG<EW>::KS, SX_ARR = SXG<EW>::ARR, SX_TILE = SXG<EW>::TILE, SX_DMA = SXG<EW>::DMA;
     extern __shared__ __attribute__((aligned(1024))) unsigned char sx_smem[];
     __shared__ int sx_cnt[SX_QB];
     sx_cnt[threadIdx.x] = 0;
@@ -600,10 +609,11 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
 #pragma unroll
     for (int jj = 0; jj < SX_DMA; ++jj) {
         const int L = (jj * SX_NWV + wave) * 64 + lane;
-        const int Lp = L & 511, r = Lp >> 4, p = Lp & 15;
-        asrc[jj] = L >> 9;
+        constexpr int CPA = SX_CT * SXG<EW>::CR;  // chunks per image of a tile
+        const int Lp = L % CPA, r = Lp / SXG<EW>::CR, p = Lp % SXG<EW>::CR;
+        asrc[jj] = L / CPA;
         rsrc[jj] = r;
-        csrc[jj] = (p ^ (r & 15)) * 8;
+        csrc[jj] = (p ^ SXG<EW>::swz(r)) * 8;
     }
     const int64_t last_row = c_end - 1;
     auto issue = [&](int t) {
@@ -619,7 +629,7 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
 #pragma unroll
     for (int t = 0; t < SX_STAGES - 1; ++t)
         if (t < T) issue(t);
-    const int rd = l31 * 256;  // byte offset of this lane's candidate row inside a tile array
+    const int rd = l31 * (EW * 2);  // byte offset of this lane's candidate row inside a tile array
     for (int t = 0; t < T; ++t) {
         // tile t is complete when at most the loads of tiles t+1 .. t+STAGES-2 are outstanding
         if (t + SX_STAGES - 2 < T) sx_wait_vm_and_barrier<(SX_STAGES - 2) * SX_DMA>();
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
         // is not skipped gets exactly the three-term scores: the survivor lists, the proof and the result are those of the full product.
         // Survivors are ~k' / n_seen of the scores: in the late stages (most of the catalogue) most blocks are skipped.
         auto lds_frag = [&](int ks, int arr) {
-            const int pos = ((2 * ks + h) ^ (l31 & 15)) * 16;
+            const int pos = ((2 * ks + h) ^ SXG<EW>::swz(l31)) * 16;
             return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(st + arr * SX_ARR + rd + pos));
         };
         bf16x8_t ah[SX_KS];
@@ -1132,7 +1142,7 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
     }
     const bool aligned = ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cand) | reinterpret_cast<uintptr_t>(cand_hi) |
                            reinterpret_cast<uintptr_t>(cand_lo)) & 15) == 0;
-    if (!(p.f.fused && E == SX_E && aligned && Bq < (1 << 30))) {
+    if (!(p.f.fused && (E == 128 || E == 64) && aligned && Bq < (1 << 30))) {
         // small catalogues (the dense path scores everything exactly anyway), other widths: the fp32 pipeline
         return mh_topk_dot(q, cand, cand_ids, Bq, N, E, k, out_scores, out_ids, out_idx, workspace, workspace_bytes, stream);
     }
@@ -1191,9 +1201,12 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
     MH_LAUNCH(topk_stage_init_kernel, dim3((unsigned)mh_ceil_div(Bq, 256)), dim3(256), 0, s, ls, kp, Bq, tau, cnt);
     // ---- filter stages on the bf16 pipe (3-term split product), survivors merged by their approximate scores ----
     static bool attr_done = false;
-    const size_t lds = (size_t)SX_STAGES * SX_TILE;
+    const size_t lds = (size_t)SX_STAGES * (E == 64 ? SXG<64>::TILE : SXG<128>::TILE);
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_filter_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_filter_bf16x3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SX_STAGES * SXG<128>::TILE);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_filter_bf16x3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SX_STAGES * SXG<64>::TILE);
         attr_done = true;
     }
     const int nqb = (int)mh_ceil_div(Bq, SX_QB);
@@ -1216,9 +1229,14 @@ int32_t mh_topk_dot_split(const float* q, const float* cand, const uint16_t* can
         while (nsplit > 8 && tiles_all / nsplit < 8) nsplit -= 8;
         const int tps = (int)mh_ceil_div(tiles_all, nsplit);
         const int segcap = p.f.cap / nsplit;  // the row's survivor capacity divided among the splits' private segments
-        MH_LAUNCH(topk_filter_bf16x3_kernel, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
-                  (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, segcnt, cs, ci, segcap, dirty, nqb,
-                  nsplit, tps, xcd_map, (const float*)qn, reinterpret_cast<const unsigned*>(cand_norm2_max));
+        if (E == 64)
+            MH_LAUNCH(topk_filter_bf16x3_kernel<64>, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
+                      (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, segcnt, cs, ci, segcap, dirty, nqb,
+                      nsplit, tps, xcd_map, (const float*)qn, reinterpret_cast<const unsigned*>(cand_norm2_max));
+        else
+            MH_LAUNCH(topk_filter_bf16x3_kernel<128>, dim3((unsigned)(nsplit * nqb)), dim3(SX_NWV * 64), lds, s, cand_hi, cand_lo,
+                      (const uint16_t*)qhi, (const uint16_t*)qlo, beg, end, (int)Bq, (const float*)tau, segcnt, cs, ci, segcap, dirty, nqb,
+                      nsplit, tps, xcd_map, (const float*)qn, reinterpret_cast<const unsigned*>(cand_norm2_max));
         // the stage's merge as a sort (a workgroup per row); rows holding more than SORT_MAX entries go through the insertion list
         MH_LAUNCH(topk_sort_merge_kernel, dim3((unsigned)mh_ceil_div(Bq, 4)), dim3(256), 0, s, (const float*)cs, (const int32_t*)ci, (const int*)segcnt, segcap,
                   nsplit, Bq, kp, ls, li, tau, cnt, (const float*)nullptr, (int64_t)0, 0, (int64_t)0, 0);

@@ -1576,7 +1576,7 @@ class TopKSplit:
 
     @staticmethod
     def supported(E: int) -> bool:
-        return int(E) == 128  # the width the filter kernel is written for; others run the fp32 pipeline
+        return int(E) in (64, 128)  # the widths the filter kernel is instantiated for; others run the fp32 pipeline
 
 
 def topk_mode() -> str:
