@@ -497,7 +497,9 @@ int32_t mh_topk_dot(const float* q, const float* cand, const int32_t* cand_ids, 
  * (hi hi + hi lo + lo hi) on v_mfma_f32_32x32x16_bf16, keeps the best k' = k + slack approximate scores per row, proves from the
  * error bound 2^-13 |q| max|c| that they contain the exact top-k, re-scores those k' in exact fp32 and orders them; rows for
  * which the proof fails (more than `slack` candidates within the error band of the k-th score) are recomputed exactly on the
- * device.  Catalogues too small for the filter path and E != 128 run mh_topk_dot itself.  No host synchronisation: capturable.
+ * device.  The filter forms hi hi for every 32 x 32 block and the two small terms only where a score can still reach its threshold
+ * (bound 1.05 * 2^-8 |q| max|c|): same survivors.  Catalogues too small for the filter path and widths other than 128 / 64 run
+ * mh_topk_dot itself.  No host synchronisation: capturable.
  * workspace: mh_topk_split_workspace_bytes(Bq, N, k, E) (>= mh_topk_workspace_bytes). */
 int32_t mh_topk_split(const float* x, int64_t n, int32_t E, uint16_t* hi, uint16_t* lo, float* norm2,
                       float* norm2_max, mh_stream_t stream);
