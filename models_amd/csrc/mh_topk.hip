@@ -489,7 +489,13 @@ __global__ __launch_bounds__(256) void topk_redo_rows_kernel(const float* __rest
 // 16 query blocks of one split run on ONE XCD at the same time, so a candidate tile enters that XCD's L2 once and is read 16 times.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int SX_NWV = 4, SX_QW = 64, SX_QB = SX_QW * SX_NWV, SX_CT = 32, SX_STAGES = 4;
+#ifndef MH_SX_NWV
+#define MH_SX_NWV 4
+#endif
+#ifndef MH_SX_STAGES
+#define MH_SX_STAGES 4
+#endif
+constexpr int SX_NWV = MH_SX_NWV, SX_QW = 64, SX_QB = SX_QW * SX_NWV, SX_CT = 32, SX_STAGES = MH_SX_STAGES;
 // geometry of the filter kernel by the embedding width EW (128 or 64): k-steps, bytes of one image of a tile, of a tile (hi + lo), 16-byte
 // DMA chunks per thread and tile
 template <int EW>
@@ -546,7 +552,7 @@ __device__ __forceinline__ void sx_wait_vm_and_barrier() {
 }
 
 template <int EW>
-__global__ __launch_bounds__(SX_NWV * 64, 2) void topk_filter_bf16x3_kernel(
+__global__ __launch_bounds__(SX_NWV * 64, SX_NWV == 4 ? 2 : 1) void topk_filter_bf16x3_kernel(
     const uint16_t* __restrict__ chi, const uint16_t* __restrict__ clo, const uint16_t* __restrict__ qhi,
     const uint16_t* __restrict__ qlo, int64_t c_beg, int64_t c_end, int Bq, const float* __restrict__ tau, int* __restrict__ cnt,
     float* __restrict__ cs, int32_t* __restrict__ ci, int segcap, int* __restrict__ dirty, int nqb, int nsplit,
