@@ -88,3 +88,20 @@ compare("opt-in bf16x3 scorer", ref, run(build, batches, steps, {"MERLIN_HIP_SCO
 compare("exact chains, second run", ref, run(build, batches, steps, {"MERLIN_HIP_SCORER_ARITH": "f32", "MERLIN_HIP_GEMM_ARITH": "f32"}))
 compare("exact chains, float atomics", ref, run(build, batches, steps, {"MERLIN_HIP_SCORER_ARITH": "f32", "MERLIN_HIP_GEMM_ARITH": "f32",
                                                                        "MERLIN_HIP_DETERMINISTIC": "0"}))
+
+# ---- DCN-v2 configs[4], B = 16 384, 20 steps ----------------------------------------------------------------------------------------------
+LR[0] = 0.05
+B, steps = 16384, 20
+batches = [bench.make_batch(dev, B, s) for s in range(4)]
+for b in batches:
+    b["__label__"] = (b[CRITEO_CONT_NAMES[0]] + b[CRITEO_CONT_NAMES[1]] > 1.0).float()
+build = lambda: bench.build_model(dev, dcn=True)[0]
+mm.set_seed(11)
+pinit = [p.data.double().cpu() for p in (lambda m: (m(dict((k, v) for k, v in batches[0].items() if k != "__label__")), m)[1])(build()).parameters()]
+print(f"\nDCN-v2 configs[4] (3 full-rank cross layers at d = 3341, deep tower [512, 256]), B = {B}, Adagrad lr 0.05, {steps} train steps:")
+ref = run(build, batches, steps, {"MERLIN_HIP_GEMM_ARITH": "f32"})
+print(f"  {'exact fp32 chains (reference run)':34s} loss first / last {ref[0][0]:.6f} / {ref[0][-1]:.6f}")
+compare("default (cross / 3341->512 bf16x6)", ref, run(build, batches, steps, {}))
+compare("opt-in bf16x3", ref, run(build, batches, steps, {"MERLIN_HIP_GEMM_ARITH": "bf16x3"}))
+compare("exact chains, second run", ref, run(build, batches, steps, {"MERLIN_HIP_GEMM_ARITH": "f32"}))
+compare("exact chains, float atomics", ref, run(build, batches, steps, {"MERLIN_HIP_GEMM_ARITH": "f32", "MERLIN_HIP_DETERMINISTIC": "0"}))
