@@ -1,11 +1,16 @@
-// The three GEMMs of a full-rank DCN-v2 cross layer in the OPT-IN "bf16x3" arithmetic (mh_set_gemm_arith(1)):
+// The three GEMMs of a full-rank DCN-v2 cross layer, and wide Dense layers, on the bf16 matrix pipe through a split of every fp32 operand
+// into bf16 pieces (mh_set_gemm_arith): mode 2 "bf16x6" -- six terms, fp32-grade, what the host side selects by default -- or mode 1
+// "bf16x3" -- three terms, opt-in:
 //   forward   out = x0 * (x W + b) + x            (Cross.call, tf/blocks/cross.py:188-202; W [d, d], d = 3341 padded to 3344 at C5)
 //   backward  dx = g W^T + dout,  dW = x^T g,  db = column sums of g     (g = dout * x0; mh_cross_layer_bwd's phases)
 // The exact-fp32 kernels (mh_gemm2.h) run these at 0.76-0.82 of the 157 TF fp32 MFMA peak: the DCN step is the sum of its GEMMs
-// (115 ms, 84 ms at 100 % of that peak).  Here every fp32 operand is split once into two bf16 values, x = hi + lo + r with
-// |r| <= 2^-18 |x|, and every product is hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulators: three bf16
-// MFMAs per fp32-equivalent one, 16 / 3 of the fp32 rate.  NOT bit-identical to the fp32 path (dropped terms <= 3 * 2^-18 |a b|
-// per element): never the default, reported under its own dtype label.
+// (115 ms, 84 ms at 100 % of that peak).
+//   bf16x3: x = hi + lo + r with |r| <= 2^-18 |x|, every product hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 with fp32
+//           accumulators: three bf16 MFMAs per fp32-equivalent one, 16 / 3 of the fp32 rate.  Dropped terms <= 3 * 2^-18 |a b| per
+//           element: NOT fp32-grade, never the default, reported under its own dtype label.
+//   bf16x6: x = h + m + l (three bf16 pieces hold the 24-bit significand exactly), every product h h + h m + m h + h l + l h + m m:
+//           dropped terms <= 2^-25 |a b| -- as close to the real product as the fp32 chain (argument and float64 test:
+//           mh_tower_split.hip, tests/test_gpu_gemm_split.py).  Three images per operand (Geo<.., NIMG = 3>), 16 / 6 of the fp32 rate.
 //
 // ONE kernel form: C[M, N] = A[M, K] B^T with BOTH operands K-contiguous ("NT").  The prepare kernels make that true for the three
 // products -- forward: A = x, B^T = W^T; dX: A = g, B^T = W (row-major [d_in, d_out] IS [n][k] for it); dW: A = x^T, B^T = g^T
@@ -574,7 +579,7 @@ int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
-            mh_set_error("gemm (bf16x3): cannot raise the dynamic LDS limit");
+            mh_set_error("gemm (split bf16): cannot raise the dynamic LDS limit");
             return MH_ERR_LAUNCH;
         }
         attr_done = true;
@@ -598,7 +603,7 @@ int32_t launch_gemm_geo(GsArgs a, int splits, hipStream_t s) {
     int64_t nrt = mh_ceil_div(a.M, BM);
     if (xmap) nrt = mh_ceil_div(nrt, 8) * 8;  // whole groups of 8 row tiles (the surplus workgroups exit at once)
     const int64_t tiles = nrt * a.ntn;
-    MH_REQUIRE(tiles < (1ll << 31), "gemm (bf16x3): grid too large");
+    MH_REQUIRE(tiles < (1ll << 31), "gemm (split bf16): grid too large");
     MH_LAUNCH(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(G::NT), (size_t)G::LDS, s, a);
     return MH_OK;
 }

@@ -8,32 +8,38 @@
 // Every fp32 operand is split once, x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|, and every product
 // of the two GEMMs of a pass is formed as  hi hi + hi lo + lo hi  in fp32 accumulators: three bf16 MFMAs per fp32-equivalent one.
 // Dropped terms are <= 3 * 2^-18 |a b| per element; measured on L2-normalised rows: max |dot - dot64| = 2.3e-6 (the plain fp32
-// fmaf chain: 2.5e-7), i.e. 4.6e-5 on a logit at 1/T = 20 -- inside north_star's 1e-4.  This is NOT bit-identical to the fp32
-// path and therefore never the default: `mh_set_scorer_arith(1)` / MERLIN_HIP_SCORER_ARITH=bf16x3 turns it on, bench.py reports
-// it under its own dtype label, and the parity suite runs under both settings.
+// fmaf chain: 2.5e-7), i.e. 4.6e-5 on a logit at 1/T = 20 -- inside north_star's 1e-4.  This three-term form is NOT fp32-grade
+// and therefore never the default: `mh_set_scorer_arith(1)` / MERLIN_HIP_SCORER_ARITH=bf16x3 turns it on, bench.py reports
+// it under its own dtype label, and the parity suite runs under every setting.
 //
 // Structure (the row-stationary streaming core of mh_scorer_stream.hip, re-tiled for the 32x32x16 bf16 MFMA):
-//   * a workgroup (4 wavefronts, ONE per SIMD: 512 registers each) owns 256 rows of the stationary matrix X; a wavefront keeps
-//     its 64 rows (two 32-row blocks) as B-operand fragments, hi and lo, in 128 registers for the whole kernel;
-//   * the streamed matrix Y arrives in 64-row tiles by direct-to-LDS DMA, double-buffered, one barrier per tile, in TWO images:
-//     row-major [row][e] (hi, lo) for GEMM 1 and TRANSPOSED [e][row] (hi, lo) for GEMM 2 -- the transposed copy of the whole
-//     matrix is made once per call by split_prepare_kernel (a bf16 MFMA operand is 8 consecutive k per lane: GEMM 2 contracts
-//     over the streamed rows, so its A operand wants 8 rows of ONE column);
-//   * GEMM 1 per 32-row unit: S^T[j, x] = sum_e Y[j, e] X[x, e], 24 MFMAs per x-block.  In the C layout a lane holds ONE
-//     stationary row and 16 streamed rows: masks, temperature, the (lazy) online max and exp2 are per-lane loops;
-//   * GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x].  The 16 probabilities a lane holds ARE its B operand (split into hi / lo in
+//   * a workgroup owns 256 rows of the stationary matrix X: 8 wavefronts (two per SIMD, 256 registers each) with one 32-row block
+//     each (XT = 1, the shipped form; XT = 2 -- 4 wavefronts with two blocks each -- is a lab build's experiment); a wavefront keeps its
+//     rows as B-operand fragments, all images, in registers for the whole kernel;
+//   * the streamed matrix Y arrives in tiles by direct-to-LDS DMA through a ring, one barrier per tile, in TWO orientations:
+//     row-major [row][e] for GEMM 1 and TRANSPOSED [e][row] for GEMM 2 -- the transposed copy of the whole matrix is made once per
+//     call by split_prepare_kernel (a bf16 MFMA operand is 8 consecutive k per lane: GEMM 2 contracts over the streamed rows, so its
+//     A operand wants 8 rows of ONE column);
+//   * GEMM 1 per 32-row unit: S^T[j, x] = sum_e Y[j, e] X[x, e].  In the C layout a lane holds ONE stationary row and 16 streamed
+//     rows: masks, logQ corrections, temperature, the (lazy) online max and exp2 are per-lane loops; rescored false negatives and the
+//     rows past the end of Y are handled under wave-uniform branches (rare);
+//   * GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x].  The 16 probabilities a lane holds ARE its B operand (split into bf16 pieces in
 //     registers): MFMA k-slot (step s, half h, slot i) is defined to mean streamed row 16 s + 8 (i >> 2) + 4 h + (i & 3), and the
-//     A operand is read from the transposed image in that order (two 8-byte LDS reads per fragment): no shuffle, no transpose.
+//     transposed images store every 16-row group in that order (split_prepare_kernel), so the A operand of a k-step is ONE 16-byte
+//     LDS read: no shuffle, no transpose, no register moves;
 //   * partial results per candidate split in the layout of the fp32 kernels (part_m / part_s / opart): the combine kernels of
 //     mh_scorer_stream.hip finish the pass unchanged.
+//
+// bf16x3 (NIMG = 2): 64-row tiles (two units), two stages of 64 KB, E = 128 without logQ corrections.
 //
 // bf16x6 (NIMG = 3).  x = h + m + l, three bf16 pieces that hold the 24-bit significand exactly, and every product of BOTH GEMMs as
 // h h + h m + m h + h l + l h + m m: the dropped terms are <= 2^-25 of the product -- half an fp32 rounding, so the result is as close to
 // the real dot product as the fp32 fmaf chain is (the argument and the float64 test are mh_tower_split.hip's).  Six MFMAs per
 // fp32-equivalent one = 16 / 6 of the fp32 MFMA rate.  Differences from the three-term kernel: three images of every matrix (and of
-// the probabilities, split in registers by mh_split3_pair); 32-row tiles of the streamed matrix so that two stages of 2 x 3 images fit
-// the LDS (96 KB); the six terms of GEMM 1 go to TWO accumulators alternately (one dependent MFMA chain per wavefront was what held
-// the three-term kernel at 0.47 of the pipe) and GEMM 2 walks two 32-column blocks of O^T at a time for the same reason.
+// the probabilities, split in registers by mh_split3_pair); 32-row tiles of the streamed matrix in a THREE-stage ring (3 x 48 KB at
+// E = 128) with the second wavefront of every SIMD one phase behind (rotated barrier, see the kernel); the six terms of GEMM 1 go to
+// TWO accumulators alternately and GEMM 2 walks two 32-column blocks of O^T at a time (independent MFMA chains); the embedding width
+// is a template parameter (128 or 64); the logQ sampling corrections are applied in the epilogue (HAS_CORR instantiations).
 #include "mh_common.h"
 
 #include <math.h>
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(512 / XT, 1) void stream_split_kernel(const SplitAr
         }
     };
     auto gemm2 = [&](const unsigned char* st, int u) {
-        // ---- GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x]; A = two 8-byte pieces of row e of the transposed image; the 16
+        // ---- GEMM 2: O^T[e, x] += sum_j Y^T[e, j] P^T[j, x]; A = one 16-byte piece of row e of the transposed image; the 16
         // probabilities of a lane, split into bf16 pieces, are the B operand of its two k-steps --------------------------------
         const unsigned char* yt = st + NIMG * P_ARR;
         if (MODE != PM_FWD)
