@@ -126,3 +126,37 @@ def test_six_term_scorer_applies_the_logq_corrections(device, monkeypatch, after
         floor = 2.0 ** -23 * max(np.abs(w).max(), 1e-30)
         assert e_sp <= 4 * e_f32 + floor, (n, e_sp, e_f32)
         np.testing.assert_allclose(b, w, atol=1e-4 if n.startswith(("loss", "lse")) else 1e-6, rtol=1e-3, err_msg=n)
+
+
+@pytest.mark.parametrize("E", [128, 64])
+@pytest.mark.parametrize("B,Nn,ids,logq", [(10, 1000, True, False), (65, 64, True, True), (1, 64, False, False), (31, 97, True, True),
+                                           (257, 2049, True, False), (1000, 65, True, True), (33, 4097, False, True)])
+def test_six_term_scorer_odd_shapes(device, monkeypatch, E, B, Nn, ids, logq):
+    """Fewer stationary rows than a wavefront block, one streamed tile, ragged everything, int64 ids, corrections in either order: every
+    output of the six-term kernel within 2e-4 of its scale of the exact-chain kernels' (and finite)."""
+    rng = np.random.default_rng(B * 7 + Nn + E)
+    unit = lambda a: (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    q, it, neg = unit(rng.normal(size=(B, E))), unit(rng.normal(size=(B, E))), unit(rng.normal(size=(Nn, E)))
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    pid = rng.integers(0, 50, size=B).astype(np.int64) if ids else None
+    nid = rng.integers(0, 50, size=Nn).astype(np.int64) if ids else None
+    kw = {}
+    if logq:
+        kw = dict(pos_logq=t(np.log(rng.random(B) * 0.3 + 1e-3).astype(np.float32)),
+                  neg_logq=t(np.log(rng.random(Nn) * 0.3 + 1e-3).astype(np.float32)), logq_after_mask=bool(B % 2))
+    args = (t(q), t(it), t(neg), t(pid), t(nid), 0.05, -655.04)
+
+    def run():
+        res, dq, ditem = ops.inbatch_softmax_train(*args, **kw)
+        _, _, dneg = ops.inbatch_softmax_backward(args[0], args[1], args[2], res.lse, args[3], args[4], 0.05, -655.04, need_dq=False, **kw)
+        fw = ops.inbatch_softmax(*args, materialize=False, **kw)
+        return [x.double().cpu() for x in (res.loss, res.lse, dq, ditem, dneg, fw.lse)]
+
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
+    f32 = run()
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "bf16x6")
+    sp = run()
+    monkeypatch.setenv("MERLIN_HIP_SCORER_ARITH", "f32")
+    for n, a, b in zip(("loss", "lse", "dq", "ditem", "dneg", "lse(fwd)"), f32, sp):
+        assert torch.isfinite(b).all(), n
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(a.abs().max()), 1e-30), n
